@@ -1,0 +1,65 @@
+"""ctypes loader of the gfx950 C-ABI library (include/avt.h).
+
+There is no CPU fallback: if libavt_hip.so is missing or a call fails, the
+product path raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C audio-video-textures_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavt_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avt.h")
+
+_i32p, _i64p, _f32p, _vp = (C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_void_p)
+
+# name -> argtypes; mirrors include/avt.h one to one (tests/test_abi.py checks the header against it)
+SIGNATURES = {
+    "avt_abi_version": [],
+    "avt_device_check": [C.c_char_p, C.c_size_t],
+    "avt_clip_sample_table": [C.c_int, _vp, _vp],
+    "avt_clip_pack_plan": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
+    "avt_clip_pack_u8": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
+                         C.c_int, _vp, _vp, C.c_int, _vp],
+    "avt_l2norm_rows": [_vp, C.c_int, _vp, C.c_int, C.c_int64, C.c_float, _vp, _vp, _vp, _vp],
+    "avt_sim_gemm_nt": [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, _vp, C.c_int64, _vp],
+    "avt_row_transition": [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_float,
+                           C.c_float, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "avt_row_topk": [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int, _vp, _vp, _vp],
+    "avt_softmax_ce_fwd": [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],
+    "avt_softmax_ce_bwd": [_vp, _vp, C.c_int64, C.c_int64, C.c_float, _vp, _vp],
+}
+
+
+class AvtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AvtError(
+                "HIP extension not built: %s is missing. Run `make -C %s` (needs hipcc); "
+                "there is no CPU fallback for the hot path." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        handle.avt_last_error.argtypes = []
+        handle.avt_last_error.restype = C.c_char_p
+        if handle.avt_abi_version() != 1:
+            raise AvtError("libavt_hip.so ABI version %d, expected 1" % handle.avt_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().avt_last_error()
+        raise AvtError("%s failed (%d): %s" % (what, status, msg.decode() if msg else "?"))

@@ -1,0 +1,56 @@
+// Shared helpers of the gfx950 kernels behind include/avt.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/avt.h"
+
+namespace avt {
+
+void set_error(const char* fmt, ...);
+
+#define AVT_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      avt::set_error(__VA_ARGS__);        \
+      return AVT_ERR_ARG;                 \
+    }                                     \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  return AVT_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// fp32 -> bf16 bits, round-to-nearest-even, NaN kept a NaN
+// (same arithmetic as oracle/avt_oracle.c f32_to_bf16_rne).
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
+  return __uint_as_float((uint32_t)h << 16);
+}
+
+// 64-lane wave reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace avt

@@ -1,0 +1,271 @@
+// sim_gemm_nt — out[i,j] = <q_i, t_j> / temp on the gfx950 matrix cores.
+// Replaces torch.bmm(q, t) + `output /= temp` of the reference operator
+// (contrastive_video_textures/models/models.py:416-417; audio :439, :455-457),
+// for every query row at once instead of one GEMV per query per chunk.
+//
+// Both operands are row-major with K contiguous ("NT"), which is exactly the
+// MFMA A/B fragment order: lane l of a wave holds 16 contiguous bytes of row
+// (l & 31) at k-offset 16*(l >> 5) bytes, for A and B alike.
+//
+//   AVT_SIM_F32    v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 fmaf chain.
+//                  A lane loads 4 consecutive k (one ds_read_b128); MFMA step s
+//                  uses element s of both halves, so inside a group of 8 the
+//                  chain visits k = 0,4,1,5,2,6,3,7.  That order IS the
+//                  canonical definition (oracle/avt_oracle.c) and makes the
+//                  whole matrix bit-identical to the CPU oracle.
+//   AVT_SIM_BF16   v_mfma_f32_32x32x16_bf16 on the bf16(hi) tables.
+//   AVT_SIM_BF16X3 three MFMAs per k-step: hi*hi + hi*lo + lo*hi (~2^-16 rel).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each
+// 64x64 = 2x2 MFMA tiles, 64 accumulator VGPRs).  Per K-step every operand
+// plane is a [128 rows][128 data bytes] slab staged global -> registers -> LDS
+// (the next slab's loads are issued before the MFMAs of the current one), LDS
+// rows padded to 144 B so each 16-lane ds_read_b128 group (16 distinct rows at
+// one k-offset) touches all 64 banks once.  Roofline: MFMA (2*nq*nt*d flop).
+#include "avt_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 128;        // data bytes per row per K-step
+constexpr int LSTR = 144;        // LDS row stride in bytes (ROWB + 16 pad)
+constexpr int PLANE = 128 * LSTR;  // bytes of one operand plane in LDS
+
+template <int MODE>
+struct Cfg {
+  static constexpr int ELEM = (MODE == AVT_SIM_F32) ? 4 : 2;
+  static constexpr int BK = ROWB / ELEM;                       // elements per K-step
+  static constexpr int NPL = (MODE == AVT_SIM_BF16X3) ? 2 : 1;  // planes per operand
+};
+
+struct Args {
+  const char* q[2];  // plane 0 (f32 / bf16 hi), plane 1 (bf16 lo)
+  const char* t[2];
+  int64_t nq, nt;
+  int d;
+  float temp;
+  float* out;
+  int64_t ldo;
+  int tiles_n;
+  int nblk;
+};
+
+// one 16-byte chunk of a slab: rows beyond `nrows` and k beyond d read as zero
+template <int ELEM, bool ALIGNED>
+__device__ __forceinline__ uint4 load_chunk(const char* base, int64_t row, int64_t nrows, int d, int k0, int col16) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (row >= nrows) return v;
+  constexpr int EPC = 16 / ELEM;  // elements per chunk
+  const int k = k0 + col16 * EPC;
+  const char* p = base + ((int64_t)row * d + k) * ELEM;
+  if (ALIGNED) {
+    if (k < d) v = *reinterpret_cast<const uint4*>(p);  // d % EPC == 0: chunk is all in or all out
+  } else {
+    if (ELEM == 4) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < d) w[e] = reinterpret_cast<const uint32_t*>(p)[e];
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      uint16_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (k + e < d) h[e] = reinterpret_cast<const uint16_t*>(p)[e];
+      v = make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16), h[4] | ((uint32_t)h[5] << 16),
+                     h[6] | ((uint32_t)h[7] << 16));
+    }
+  }
+  return v;
+}
+
+template <int MODE, bool ALIGNED>
+__global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
+  using C = Cfg<MODE>;
+  constexpr int NPL = C::NPL;
+  // LDS (dynamic, 2*NPL planes): [A planes][B planes], each 128 rows x 144 B
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so
+  // give each XCD a contiguous run of tiles (they share the same Q panel and
+  // walk neighbouring T panels -> L2 hits).  Bijective for any nblk.
+  const int bid = blockIdx.x;
+  const int qd = a.nblk / 8, rm = a.nblk % 8, x = bid % 8;
+  const int swz = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + bid / 8;
+  const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
+  const int64_t row0 = (int64_t)tm * BM, col0 = (int64_t)tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  // staging registers: per plane 4 chunks per thread (1024 chunks / 256 threads)
+  uint4 ra[NPL][4], rb[NPL][4];
+  const int nk = (a.d + C::BK - 1) / C::BK;
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * C::BK;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + u * 256, r = c >> 3, c16 = c & 7;
+        ra[p][u] = load_chunk<C::ELEM, ALIGNED>(a.q[p], row0 + r, a.nq, a.d, k0, c16);
+        rb[p][u] = load_chunk<C::ELEM, ALIGNED>(a.t[p], col0 + r, a.nt, a.d, k0, c16);
+      }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + u * 256, r = c >> 3, c16 = c & 7;
+        *reinterpret_cast<uint4*>(lds + p * PLANE + r * LSTR + c16 * 16) = ra[p][u];
+        *reinterpret_cast<uint4*>(lds + (NPL + p) * PLANE + r * LSTR + c16 * 16) = rb[p][u];
+      }
+  };
+
+  // this lane's fragment row addresses (bytes) inside a plane
+  const int arow = (wr * 64 + lr) * LSTR + lh * 16;
+  const int brow = (wc * 64 + lr) * LSTR + lh * 16;
+
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // 4 sub-steps of 32 bytes of K per row
+      if (MODE == AVT_SIM_F32) {
+        float4 fa[2], fb[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          fa[m] = *reinterpret_cast<const float4*>(lds + arow + m * 32 * LSTR + ks * 32);
+          fb[m] = *reinterpret_cast<const float4*>(lds + PLANE + brow + m * 32 * LSTR + ks * 32);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              const float av = s == 0 ? fa[m].x : s == 1 ? fa[m].y : s == 2 ? fa[m].z : fa[m].w;
+              const float bv = s == 0 ? fb[n].x : s == 1 ? fb[n].y : s == 2 ? fb[n].z : fb[n].w;
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
+            }
+      } else {
+        bf16x8 ah[2], bh[2], al[2], bl[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          ah[m] = *reinterpret_cast<const bf16x8*>(lds + arow + m * 32 * LSTR + ks * 32);
+          bh[m] = *reinterpret_cast<const bf16x8*>(lds + NPL * PLANE + brow + m * 32 * LSTR + ks * 32);
+          if (MODE == AVT_SIM_BF16X3) {
+            al[m] = *reinterpret_cast<const bf16x8*>(lds + PLANE + arow + m * 32 * LSTR + ks * 32);
+            bl[m] = *reinterpret_cast<const bf16x8*>(lds + (NPL + 1) * PLANE + brow + m * 32 * LSTR + ks * 32);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            if (MODE == AVT_SIM_BF16X3) {
+              // small cross terms first, then the dominant hi*hi
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            }
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+          }
+      }
+    }
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);  // next slab's HBM/L2 latency hides under the MFMAs
+    compute();
+    __syncthreads();
+    if (kt + 1 < nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int64_t col = col0 + wc * 64 + n * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < a.nq && col < a.nt) a.out[row * a.ldo + col] = __fdiv_rn(acc[m][n][r], a.temp);
+      }
+    }
+}
+
+template <int MODE>
+int launch(const Args& a, bool aligned, hipStream_t st) {
+  const dim3 grid((unsigned)a.nblk), block(256);
+  constexpr int lds_bytes = 2 * Cfg<MODE>::NPL * PLANE;
+  auto kern = aligned ? sim_gemm_kernel<MODE, true> : sim_gemm_kernel<MODE, false>;
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       lds_bytes);
+    if (e != hipSuccess) {
+      avt::set_error("avt_sim_gemm_nt: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+      return AVT_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, a);
+  return avt::check_launch("avt_sim_gemm_nt");
+}
+
+}  // namespace
+
+extern "C" int avt_sim_gemm_nt(const void* q, const void* q_lo, const void* t, const void* t_lo, int64_t nq,
+                               int64_t nt, int d, float temp, int precision, float* out, int64_t ldo, void* stream) {
+  AVT_REQUIRE(q && t && out, "avt_sim_gemm_nt: NULL q/t/out");
+  AVT_REQUIRE(nq >= 0 && nt >= 0 && d > 0, "avt_sim_gemm_nt: bad sizes nq=%lld nt=%lld d=%d", (long long)nq,
+              (long long)nt, d);
+  AVT_REQUIRE(ldo >= nt, "avt_sim_gemm_nt: ldo < nt");
+  AVT_REQUIRE(temp != 0.0f, "avt_sim_gemm_nt: temp == 0");
+  AVT_REQUIRE(precision == AVT_SIM_BF16 || precision == AVT_SIM_BF16X3 || precision == AVT_SIM_F32,
+              "avt_sim_gemm_nt: unknown precision %d", precision);
+  AVT_REQUIRE(precision != AVT_SIM_BF16X3 || (q_lo && t_lo), "avt_sim_gemm_nt: bf16x3 needs q_lo and t_lo");
+  if (nq == 0 || nt == 0) return AVT_OK;
+  Args a;
+  a.q[0] = static_cast<const char*>(q);
+  a.q[1] = static_cast<const char*>(q_lo);
+  a.t[0] = static_cast<const char*>(t);
+  a.t[1] = static_cast<const char*>(t_lo);
+  a.nq = nq;
+  a.nt = nt;
+  a.d = d;
+  a.temp = temp;
+  a.out = out;
+  a.ldo = ldo;
+  const int64_t tiles_m = (nq + BM - 1) / BM, tiles_n = (nt + BN - 1) / BN;
+  AVT_REQUIRE(tiles_m * tiles_n < (1ll << 31), "avt_sim_gemm_nt: grid too large");
+  a.tiles_n = (int)tiles_n;
+  a.nblk = (int)(tiles_m * tiles_n);
+  const int epc = precision == AVT_SIM_F32 ? 4 : 8;
+  bool aligned = (d % epc == 0) && avt::aligned16(q) && avt::aligned16(t);
+  if (precision == AVT_SIM_BF16X3) aligned = aligned && avt::aligned16(q_lo) && avt::aligned16(t_lo);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (precision) {
+    case AVT_SIM_F32: return launch<AVT_SIM_F32>(a, aligned, st);
+    case AVT_SIM_BF16: return launch<AVT_SIM_BF16>(a, aligned, st);
+    default: return launch<AVT_SIM_BF16X3>(a, aligned, st);
+  }
+}

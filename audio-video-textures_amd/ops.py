@@ -1,0 +1,183 @@
+"""Torch-tensor wrappers over the C ABI (include/avt.h).
+
+Plumbing only: tensors supply device memory and the current HIP stream; every
+operator below is one call into libavt_hip.so.  CPU tensors are rejected —
+there is no fallback path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SIM_BF16, SIM_BF16X3, SIM_F32 = 0, 1, 2
+_PREC = {"bf16": SIM_BF16, "bf16x3": SIM_BF16X3, "f32": SIM_F32}
+FAST_T, SLOW_T, SLOTS = 32, 8, 40
+
+
+def _dev(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.AvtError("%s must be a device (HIP) tensor; the hot path has no CPU fallback" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.AvtError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.AvtError("%s must be contiguous" % name)
+    return t
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_check():
+    buf = C.create_string_buffer(64)
+    _lib.check(_lib.lib().avt_device_check(buf, 64), "avt_device_check")
+    return buf.value.decode()
+
+
+# ---- clip_pack ---------------------------------------------------------------
+def clip_sample_table(win_len):
+    """(fast_idx[32], slow_idx[8]) — torch.linspace(0, W-1, 32).long() and its 8-subsample."""
+    fast = np.empty(FAST_T, np.int32)
+    slow = np.empty(SLOW_T, np.int32)
+    _lib.check(_lib.lib().avt_clip_sample_table(int(win_len), fast.ctypes.data, slow.ctypes.data),
+               "avt_clip_sample_table")
+    return fast, slow
+
+
+def clip_pack_plan(win_start, win_len, n_frames):
+    """Host CSR plan frame -> (window, slot) destinations."""
+    win_start = np.ascontiguousarray(win_start, np.int32)
+    n_win = win_start.shape[0]
+    off = np.empty(n_frames + 1, np.int32)
+    slot = np.empty(max(n_win * SLOTS, 1), np.int32)
+    _lib.check(_lib.lib().avt_clip_pack_plan(win_start.ctypes.data, n_win, int(win_len), int(n_frames),
+                                             off.ctypes.data, slot.ctypes.data), "avt_clip_pack_plan")
+    return off, slot[: n_win * SLOTS]
+
+
+def clip_pack(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0.225, bgr=True,
+              dtype=torch.bfloat16, plan=None):
+    """frames_u8 [F,H,W,3] uint8 RGB (device) -> slow [n,3,8,hw,hw], fast [n,3,32,hw,hw]."""
+    _dev(frames_u8, "frames_u8", torch.uint8)
+    assert frames_u8.dim() == 4 and frames_u8.shape[3] == 3
+    n_frames, h, w, _ = frames_u8.shape
+    win_start = np.ascontiguousarray(win_start, np.int32)
+    n_win = win_start.shape[0]
+    if plan is None:
+        off, slot = clip_pack_plan(win_start, win_len, n_frames)
+        plan = (torch.from_numpy(off).to(frames_u8.device), torch.from_numpy(slot).to(frames_u8.device))
+    d_off, d_slot = plan
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise _lib.AvtError("clip_pack: dtype must be bfloat16 or float32")
+    slow = torch.empty((n_win, 3, SLOW_T, out_hw, out_hw), dtype=dtype, device=frames_u8.device)
+    fast = torch.empty((n_win, 3, FAST_T, out_hw, out_hw), dtype=dtype, device=frames_u8.device)
+    _lib.check(_lib.lib().avt_clip_pack_u8(_p(frames_u8), n_frames, h, w, _p(d_off), _p(d_slot), n_win, int(out_hw),
+                                           float(mean), float(std), 1 if bgr else 0, _p(slow), _p(fast),
+                                           1 if dtype == torch.bfloat16 else 0, _stream()), "avt_clip_pack_u8")
+    return slow, fast
+
+
+# ---- l2norm --------------------------------------------------------------------
+def l2norm_rows(x0, x1=None, eps=1e-12, want_f32=True, want_split=False):
+    """y = [x0|x1] / max(||.||, eps) row-wise -> (y_f32 | None, y_hi | None, y_lo | None)."""
+    _dev(x0, "x0", torch.float32)
+    n, d0 = x0.shape
+    d1 = 0
+    if x1 is not None:
+        _dev(x1, "x1", torch.float32)
+        assert x1.shape[0] == n
+        d1 = x1.shape[1]
+    d = d0 + d1
+    y = torch.empty((n, d), dtype=torch.float32, device=x0.device) if want_f32 else None
+    hi = torch.empty((n, d), dtype=torch.bfloat16, device=x0.device) if want_split else None
+    lo = torch.empty((n, d), dtype=torch.bfloat16, device=x0.device) if want_split else None
+    _lib.check(_lib.lib().avt_l2norm_rows(_p(x0), d0, _p(x1), d1, n, float(eps), _p(y), _p(hi), _p(lo), _stream()),
+               "avt_l2norm_rows")
+    return y, hi, lo
+
+
+# ---- similarity -----------------------------------------------------------------
+def sim_gemm_nt(q, t, temp, precision="f32", q_lo=None, t_lo=None, out=None):
+    """out[i,j] = <q_i, t_j> / temp.  precision: "f32" (exact, canonical) | "bf16" | "bf16x3"."""
+    prec = _PREC[precision]
+    want = torch.float32 if prec == SIM_F32 else torch.bfloat16
+    _dev(q, "q", want)
+    _dev(t, "t", want)
+    nq, d = q.shape
+    nt = t.shape[0]
+    assert t.shape[1] == d
+    if prec == SIM_BF16X3:
+        _dev(q_lo, "q_lo", torch.bfloat16)
+        _dev(t_lo, "t_lo", torch.bfloat16)
+    if out is None:
+        out = torch.empty((nq, nt), dtype=torch.float32, device=q.device)
+    else:
+        _dev(out, "out", torch.float32)
+    _lib.check(_lib.lib().avt_sim_gemm_nt(_p(q), _p(q_lo), _p(t), _p(t_lo), nq, nt, d, float(temp), prec, _p(out),
+                                          out.stride(0), _stream()), "avt_sim_gemm_nt")
+    return out
+
+
+# ---- transition select ------------------------------------------------------------
+def row_transition(sim, q_ids=None, sim_a=None, alpha=0.5, threshold=0.0, cap=64):
+    """validate.py:524-572 for every row -> dict(idx, seg, p, cnt, stats) (device tensors)."""
+    _dev(sim, "sim", torch.float32)
+    nq, nt = sim.shape
+    n_seg = 0
+    if q_ids is not None:
+        _dev(q_ids, "q_ids", torch.int64)
+        n_seg = nt
+    if sim_a is not None:
+        _dev(sim_a, "sim_a", torch.float32)
+        assert sim_a.shape == sim.shape
+    dev = sim.device
+    idx = torch.full((nq, cap), -1, dtype=torch.int32, device=dev)
+    seg = torch.full((nq, cap), -1, dtype=torch.int32, device=dev)
+    p = torch.zeros((nq, cap), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    stats = torch.zeros((nq, 4), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().avt_row_transition(_p(sim), nq, nt, sim.stride(0), _p(q_ids), n_seg, _p(sim_a),
+                                             sim_a.stride(0) if sim_a is not None else 0, float(alpha),
+                                             float(threshold), int(cap), _p(idx), _p(seg), _p(p), _p(cnt), _p(stats),
+                                             _stream()), "avt_row_transition")
+    return dict(idx=idx, seg=seg, p=p, cnt=cnt, stats=stats)
+
+
+def row_topk(sim, k, self_col=None):
+    _dev(sim, "sim", torch.float32)
+    nq, nt = sim.shape
+    if self_col is not None:
+        _dev(self_col, "self_col", torch.int64)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=sim.device)
+    val = torch.empty((nq, k), dtype=torch.float32, device=sim.device)
+    _lib.check(_lib.lib().avt_row_topk(_p(sim), nq, nt, sim.stride(0), _p(self_col), int(k), _p(idx), _p(val),
+                                       _stream()), "avt_row_topk")
+    return idx, val
+
+
+# ---- InfoNCE cross-entropy ------------------------------------------------------------
+def softmax_ce_fwd(logits, label=None):
+    _dev(logits, "logits", torch.float32)
+    b, c = logits.shape
+    if label is not None:
+        _dev(label, "label", torch.int64)
+    loss = torch.empty((b,), dtype=torch.float32, device=logits.device)
+    prob = torch.empty((b, c), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.lib().avt_softmax_ce_fwd(_p(logits), b, c, _p(label), _p(loss), _p(prob), _stream()),
+               "avt_softmax_ce_fwd")
+    return loss, prob
+
+
+def softmax_ce_bwd(prob, label=None, scale=1.0):
+    _dev(prob, "prob", torch.float32)
+    b, c = prob.shape
+    d = torch.empty_like(prob)
+    _lib.check(_lib.lib().avt_softmax_ce_bwd(_p(prob), _p(label), b, c, float(scale), _p(d), _stream()),
+               "avt_softmax_ce_bwd")
+    return d

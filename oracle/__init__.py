@@ -1,0 +1,6 @@
+"""CPU oracle of the hot path — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package, and only as the checker / the timed CPU baseline.  The product
+package (audio-video-textures_amd/) never does.
+"""

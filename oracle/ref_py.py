@@ -1,0 +1,203 @@
+"""Python half of the CPU oracle: restatement of the reference's host-side logic
+and of the torch ops the hot path calls, in plain numpy / CPU torch.
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by the product package.
+
+All citations are relative to /root/reference/contrastive_video_textures/.
+Pinned by tests/test_oracle_golden.py against tests/golden/*.npz (vectors made
+by tools/gen_golden.py from the reference's own code run in the build container).
+
+PARITY UNPINNED: `process_cv2_inputs` / SlowFast live in the third-party
+`slowfast` package that the reference neither vendors nor version-pins
+(models/models.py:18-20, 365-367); `pack_clip` below follows upstream PySlowFast
+(slowfast/visualization/utils.py process_cv2_inputs + pack_pathway_output:
+NUM_FRAMES 32, ALPHA 4, mean 0.45, std 0.225) with the /255 already applied by
+the caller as validate.py:121 does.  No reference test pins it.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+FAST_T, SLOW_T, ALPHA = 32, 8, 4
+
+
+# ---- clip preprocessing (models.py:364-383, validate.py:120-125, 333-344) -------
+def sample_indices(win_len):
+    fast = torch.linspace(0, win_len - 1, FAST_T).long()
+    pick = torch.linspace(0, FAST_T - 1, FAST_T // ALPHA).long()
+    return fast.numpy(), fast[pick].numpy()
+
+
+def pack_clip(frames_u8, start, win_len, out_hw=224, mean=0.45, std=0.225, bgr=True):
+    """frames_u8: uint8 [F,H,W,3] RGB (numpy or CPU tensor) -> (slow [3,8,hw,hw], fast [3,32,hw,hw]) fp32."""
+    fr = torch.as_tensor(frames_u8)[start : start + win_len]
+    x = fr.float() / 255  # validate.py:121
+    if bgr:
+        x = x[:, :, :, [2, 1, 0]]  # validate.py:124-125
+    x = (x - mean) / std  # tensor_normalize
+    x = x.permute(3, 0, 1, 2)  # T H W C -> C T H W
+    fast_idx = torch.linspace(0, x.shape[1] - 1, FAST_T).long()
+    fast = torch.index_select(x, 1, fast_idx)
+    slow = torch.index_select(fast, 1, torch.linspace(0, fast.shape[1] - 1, fast.shape[1] // ALPHA).long())
+    # models.py:369-376: F.interpolate(item.squeeze(0), size=(S,S), mode="bilinear") on [C,T,H,W]
+    slow = F.interpolate(slow, size=(out_hw, out_hw), mode="bilinear")
+    fast = F.interpolate(fast, size=(out_hw, out_hw), mode="bilinear")
+    return slow, fast
+
+
+# ---- chunking helpers (utils/utils.py:208-260) -----------------------------------
+def split_into_batches(x, max_segments):
+    """x [1,N,...] -> ([ceil(N/m), m, ...] zero padded, N)   (utils.py:208-230)"""
+    x = np.asarray(x)
+    assert x.shape[0] == 1
+    n = x.shape[1]
+    nb = math.ceil(n / max_segments)
+    out = np.zeros((nb, max_segments) + x.shape[2:], x.dtype)
+    for b in range(nb):
+        lo = b * max_segments
+        hi = min(lo + max_segments, n)
+        out[b, : hi - lo] = x[0, lo:hi]
+    return out, n
+
+
+def split_into_overlapping_segments(x, max_segments, W, S):
+    """x [N,...] -> ([batch, m*S+W, ...] zero padded, N)   (utils.py:233-260; chunk start uses m-1 [quirk Q4])"""
+    x = np.asarray(x)
+    n = x.shape[0]
+    total = math.ceil((n - W) / S)
+    chunk = max_segments * S + W
+    nb = math.ceil(total / max_segments)
+    out = np.zeros((nb, chunk) + x.shape[1:], x.dtype)
+    for b in range(nb):
+        lo = b * S * (max_segments - 1)
+        hi = min(lo + chunk, n)
+        if hi > lo:
+            out[b, : hi - lo] = x[lo:hi]
+    return out, n
+
+
+# ---- stitch-loop index logic (validate.py:188-195, 369-391, 442-493) -------------
+def num_segments(n_frames, W, S):
+    return math.floor((n_frames - W) / S)  # validate.py:189
+
+
+def target_segment_ids(q_id, L):
+    """validate.py:369-378: [pos] + every segment except q and pos, ascending."""
+    pos = min(q_id + 1, L - 1)
+    mask = np.ones(L, bool)
+    mask[[q_id, pos]] = False
+    return np.concatenate((np.array([pos]), np.arange(L)[mask]))
+
+
+def target_frame_ids(seg_ids, W, S):
+    """validate.py:380-388: concatenated frame ranges, order-preserving unique."""
+    ids = np.concatenate([np.arange(i * S, i * S + W) for i in seg_ids])
+    _, first = np.unique(ids, return_index=True)
+    return ids[np.sort(first)]
+
+
+def compat_window_frames(q_id, n_frames, W, S, mbs, n_gpus=1):
+    """Frame ids each OUTPUT slot of the reference's validate() row actually scores [quirks Q3/Q4].
+
+    Returns (frames [len(target_segment_ids), W] int64 with -1 = zero padding,
+             seg_ids = os_ids_t the labels the reference attaches to those slots).
+    Follows validate.py:369-395 (t_video, chunking), models.py:358-367 (re-windowing of a
+    chunk at stride S) and validate.py:442-493/522 (grouping by n_gpus, num_valid slice).
+    """
+    L = num_segments(n_frames, W, S)
+    seg_ids = target_segment_ids(q_id, L)
+    fids = target_frame_ids(seg_ids, W, S)
+    chunks, _ = split_into_overlapping_segments(fids + 1, mbs, W, S)  # +1 so that padding (0) -> -1
+    chunks = chunks.astype(np.int64) - 1
+    n_out = len(seg_ids)
+    out = np.full((n_out, W), -1, np.int64)
+    num_valid = n_out
+    n_calls = math.ceil(len(chunks) / n_gpus)
+    for itr in range(n_calls):
+        group = chunks[itr * n_gpus : itr * n_gpus + n_gpus]
+        # each replica re-windows row 0 of its chunk: windows i*S : i*S+W, i < mbs (models.py:358-367)
+        wins = np.stack([np.stack([c[i * S : i * S + W] for i in range(mbs)]) for c in group])
+        flat = wins.reshape(-1, W)
+        take = min(num_valid, n_gpus * mbs)
+        take = min(take, flat.shape[0])
+        lo = itr * n_gpus * mbs
+        if take > 0:
+            out[lo : lo + take] = flat[:take]
+        num_valid -= mbs * n_gpus
+    return out, seg_ids
+
+
+def frame_bookkeeping(q_id, p_q_id, W, S):
+    """validate.py:580-615: frame ids appended for the chosen segment, and whether it was a jump."""
+    if p_q_id == -1:
+        return np.arange(q_id * S, q_id * S + W), False
+    ids = np.arange(q_id * S + (W - S), q_id * S + W)
+    return ids, q_id != p_q_id + 1
+
+
+def row_postprocess(output, threshold, output_a=None, alpha=0.5):
+    """validate.py:524-572 on one row with torch CPU ops, exactly as written there.
+
+    Returns dict(p_pre (after /sum and blend), ce, p_post, choices, entropy)."""
+    out = torch.as_tensor(np.array(output, np.float32)).clone()
+    out /= out.sum()
+    if output_a is not None:
+        oa = torch.as_tensor(np.array(output_a, np.float32)).clone()
+        oa /= oa.sum()
+        out = alpha * out + (1 - alpha) * oa
+    pre = out.clone()
+    ce = torch.nn.CrossEntropyLoss()(out.unsqueeze(0), torch.zeros(1, dtype=torch.long))
+    out[out < (out.max() - threshold * out.max())] = 0.0
+    out[torch.nonzero(out).view(-1)] /= out.sum()
+    nz = out.nonzero().view(-1)
+    ent = abs(out[nz].log().mean(-1))
+    return dict(p_pre=pre.numpy(), ce=float(ce), p_post=out.numpy(), choices=nz.numpy(), entropy=float(ent))
+
+
+def stitch_walk(row_fn, n_frames, W, S, max_length, q_id=10, seed=None, rng=None):
+    """The serial remainder of validate(): validate.py:324, 570-572, 580-615, 685.
+
+    row_fn(q_id) -> (choices (positions, ascending), os_ids_t).  Consumes exactly one
+    np.random.choice per step from the LEGACY global-style RandomState."""
+    rng = rng or np.random.RandomState(seed)
+    new_ids, p_q, jumps, steps = [], -1, 0, []
+    while len(new_ids) < max_length:
+        choices, os_ids = row_fn(q_id)
+        rdm = rng.choice(np.asarray(choices))
+        q_id = int(os_ids[rdm])
+        ids, jump = frame_bookkeeping(q_id, p_q, W, S)
+        jumps += int(jump)
+        new_ids.extend(int(i) for i in ids)
+        steps.append(q_id)
+        p_q = q_id
+    return new_ids, steps, jumps
+
+
+# ---- classic video textures, config 1 (baselines/classic_video_textures) -------------
+def classic_d1_p1(frames, sigma_factor):
+    """computeD1.py:47-96 (RGB path) + :240-247: D1[i,j]=||f_i-f_j||_2, P1 shifted/normalised."""
+    f = torch.as_tensor(np.asarray(frames)).float().reshape(len(frames), -1)
+    d1 = torch.cdist(f.double(), f.double()).float()
+    nz = torch.nonzero(d1).size(0)
+    sigma = sigma_factor * (d1.sum() / nz)
+    p1 = torch.exp(-d1 / sigma)
+    p1 = torch.cat((p1[1:, :], p1[-1, :].unsqueeze(0)), dim=0)
+    p1 = p1 / p1.sum(1, keepdim=True)
+    return d1.numpy(), p1.numpy(), float(sigma)
+
+
+def classic_d2(d1, sigma_factor, filter_size=16):
+    """computeD2.py:21-52: diagonal binomial filter, valid conv, P2."""
+    d1 = torch.as_tensor(d1)
+    w = torch.tensor(np.diag((np.poly1d([0.5, 0.5]) ** (filter_size - 1)).coeffs), dtype=torch.float32)
+    d2 = F.conv2d(d1.view(1, 1, *d1.shape), w.view(1, 1, filter_size, filter_size))
+    d2 = d2.view(d2.shape[2], d2.shape[3])
+    nz = torch.nonzero(d2).size(0)
+    sigma = sigma_factor * (d2.sum() / nz)
+    p2 = torch.exp(-d2 / sigma)
+    p2 = torch.cat((p2[1:, :], p2[-1, :].unsqueeze(0)), dim=0)
+    p2 = p2 / p2.sum(1, keepdim=True)
+    return d2.numpy(), p2.numpy(), float(sigma)

@@ -1,0 +1,191 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle.
+
+Bar: bit-exact for indices, counts and for the canonical fp32 paths (l2norm,
+AVT_SIM_F32, survivor probabilities); stated tolerances for the bf16 MFMA modes
+and for transcendental reporting values (ce, entropy)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref, ref_py
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).numpy().astype(np.float32)
+
+
+# ---------------------------------------------------------------- l2norm
+@pytest.mark.parametrize("n,d0,d1", [(64, 2304, 0), (33, 2304, 12288), (7, 64, 0), (5, 37, 11), (3, 4100, 0), (1, 1, 0)])
+def test_l2norm_bit_exact(avt, dev, n, d0, d1):
+    x0 = _rand((n, d0), 1)
+    x1 = _rand((n, d1), 2, 3.0) if d1 else None
+    y, hi, lo = cref.l2norm_rows(x0, x1)
+    gy, ghi, glo = avt.ops.l2norm_rows(torch.from_numpy(x0).to(dev), torch.from_numpy(x1).to(dev) if d1 else None,
+                                       want_split=True)
+    assert np.array_equal(gy.cpu().numpy().view(np.uint32), y.view(np.uint32))
+    assert np.array_equal(_bits(ghi), hi)
+    assert np.array_equal(_bits(glo), lo)
+
+
+def test_l2norm_zero_row_uses_eps(avt, dev):
+    x = np.zeros((2, 64), np.float32)
+    x[1, 3] = 2.0
+    gy, _, _ = avt.ops.l2norm_rows(torch.from_numpy(x).to(dev))
+    y, _, _ = cref.l2norm_rows(x, want_split=False)
+    assert np.array_equal(gy.cpu().numpy(), y)
+    assert not np.isnan(y).any()
+
+
+# ---------------------------------------------------------------- similarity
+@pytest.mark.parametrize("nq,nt,d", [(128, 128, 64), (200, 333, 2304), (1, 517, 2304), (64, 64, 14592), (37, 53, 100),
+                                     (5, 9, 7)])
+def test_sim_f32_bit_exact(avt, dev, nq, nt, d):
+    q, _, _ = cref.l2norm_rows(_rand((nq, d), 3), want_split=False)
+    t, _, _ = cref.l2norm_rows(_rand((nt, d), 4), want_split=False)
+    ref = cref.sim_f32(q, t, 0.1)
+    out = avt.ops.sim_gemm_nt(torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev), 0.1, "f32").cpu().numpy()
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_sim_f32_identity_asymmetric(avt, dev):
+    """A = I against an asymmetric B catches a transposed C write (guide §3)."""
+    n = 128
+    q = np.eye(n, dtype=np.float32)
+    t = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 97) / 7.0
+    out = avt.ops.sim_gemm_nt(torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev), 1.0, "f32").cpu().numpy()
+    assert np.array_equal(out, t.T)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-5), ("bf16", 4e-3)])
+@pytest.mark.parametrize("nq,nt,d", [(256, 384, 2304), (70, 45, 200), (9, 5, 13)])
+def test_sim_bf16_modes(avt, dev, mode, tol, nq, nt, d):
+    """bf16 MFMA modes: vs their own fp64 emulation (tight) and vs the canonical fp32 scores.
+    Score tolerance (cos/0.1): bf16x3 2e-5 << the 1e-3 contract; plain bf16 4e-3 (not used for index decisions)."""
+    q, qh, ql = cref.l2norm_rows(_rand((nq, d), 5))
+    t, th, tl = cref.l2norm_rows(_rand((nt, d), 6))
+    tq = lambda a: torch.from_numpy(a.view(np.int16)).view(torch.bfloat16).to(dev)
+    out = avt.ops.sim_gemm_nt(tq(qh), tq(th), 0.1, mode, q_lo=tq(ql), t_lo=tq(tl)).cpu().numpy()
+    emu = cref.sim_bf16(qh, ql, th, tl, 0.1, mode == "bf16x3")
+    err_emu = np.abs(out - emu).max()
+    err_can = np.abs(out - cref.sim_f32(q, t, 0.1)).max()
+    print("mode", mode, "shape", (nq, nt, d), "vs emulation", err_emu, "vs canonical", err_can)
+    assert err_emu < 5e-6 * 10 + 1e-6  # fp32-accumulate noise only
+    if d >= 2304:  # the contract is stated at the embedding widths of the path (D=2304 / 14592)
+        assert err_can < tol
+
+
+# ---------------------------------------------------------------- transition select
+def _check_transition(g, o, cap):
+    cnt = o["cnt"]
+    assert np.array_equal(g["cnt"].cpu().numpy(), cnt)
+    gi, gs, gp = g["idx"].cpu().numpy(), g["seg"].cpu().numpy(), g["p"].cpu().numpy()
+    for r in range(len(cnt)):
+        k = min(cnt[r], cap)
+        assert np.array_equal(gi[r, :k], o["idx"][r, :k])
+        assert np.array_equal(gs[r, :k], o["seg"][r, :k])
+        assert np.array_equal(gp[r, :k].view(np.uint32), o["p"][r, :k].view(np.uint32))
+    gst, ost = g["stats"].cpu().numpy(), o["stats"]
+    assert np.array_equal(gst[:, :2].view(np.uint32), ost[:, :2].view(np.uint32))  # row_sum, row_max exact
+    np.testing.assert_allclose(gst[:, 2:], ost[:, 2:], rtol=2e-6, atol=1e-6)  # ce, entropy (exp/log)
+
+
+@pytest.mark.parametrize("th", [0.0, 0.3, 0.9])
+@pytest.mark.parametrize("n", [45, 300, 1000])
+def test_transition_target_order(avt, dev, th, n):
+    rng = np.random.default_rng(n)
+    sim = (rng.random((n, n), dtype=np.float32) * 8 + 1).astype(np.float32)
+    q_ids = np.arange(n, dtype=np.int64)
+    o = cref.row_transition(sim, q_ids=q_ids, threshold=th, cap=n)
+    g = avt.ops.row_transition(torch.from_numpy(sim).to(dev), q_ids=torch.from_numpy(q_ids).to(dev), threshold=th,
+                               cap=n)
+    _check_transition(g, o, n)
+
+
+def test_transition_audio_blend_and_negative_scores(avt, dev):
+    n = 257
+    sim = _rand((n, n), 11) * 3  # mixed signs: the row sum may be negative (validate.py:524 divides anyway)
+    sim_a = np.abs(_rand((n, n), 12)) + 0.1
+    q_ids = np.arange(n, dtype=np.int64)
+    for th in (0.0, 0.3):
+        o = cref.row_transition(sim, q_ids=q_ids, sim_a=sim_a, alpha=0.5, threshold=th, cap=n)
+        g = avt.ops.row_transition(torch.from_numpy(sim).to(dev), q_ids=torch.from_numpy(q_ids).to(dev),
+                                   sim_a=torch.from_numpy(sim_a).to(dev), alpha=0.5, threshold=th, cap=n)
+        _check_transition(g, o, n)
+
+
+def test_transition_identity_rows_ties_and_cap(avt, dev):
+    sim = np.ones((6, 40), np.float32)
+    sim[1, 5] = sim[1, 17] = 3.0  # exact tie for the max -> two survivors at th=0
+    sim[2, :] = np.arange(40)
+    o = cref.row_transition(sim, threshold=0.0, cap=4)
+    g = avt.ops.row_transition(torch.from_numpy(sim).to(dev), threshold=0.0, cap=4)
+    _check_transition(g, o, 4)
+    assert o["cnt"][0] == 40 and o["cnt"][1] == 2  # cnt is the true count even past cap
+
+
+def test_transition_long_row_uncached(avt, dev):
+    rng = np.random.default_rng(5)
+    sim = (rng.random((3, 20000), dtype=np.float32) + 0.5).astype(np.float32)
+    o = cref.row_transition(sim, threshold=0.05, cap=256)
+    g = avt.ops.row_transition(torch.from_numpy(sim).to(dev), threshold=0.05, cap=256)
+    _check_transition(g, o, 256)
+
+
+def test_topk(avt, dev):
+    sim = _rand((50, 3000), 21)
+    sim[3, 10] = sim[3, 2000] = 99.0  # tie -> lower column first
+    self_col = np.arange(50, dtype=np.int64)
+    oi, ov = cref.row_topk(sim, 8, self_col)
+    gi, gv = avt.ops.row_topk(torch.from_numpy(sim).to(dev), 8, torch.from_numpy(self_col).to(dev))
+    assert np.array_equal(gi.cpu().numpy(), oi)
+    assert np.array_equal(gv.cpu().numpy(), ov)
+
+
+# ---------------------------------------------------------------- InfoNCE CE
+def test_softmax_ce(avt, dev):
+    logits = _rand((8, 15), 31) * 10  # train.py: B=8, 1+negs=15, temp 0.1
+    loss, prob = cref.softmax_ce_fwd(logits)
+    gl, gp = avt.ops.softmax_ce_fwd(torch.from_numpy(logits).to(dev))
+    np.testing.assert_allclose(gl.cpu().numpy(), loss, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(gp.cpu().numpy(), prob, rtol=1e-6, atol=1e-7)
+    ref = torch.nn.functional.cross_entropy(torch.from_numpy(logits), torch.zeros(8, dtype=torch.long),
+                                            reduction="none")
+    np.testing.assert_allclose(gl.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    d = cref.softmax_ce_bwd(gp.cpu().numpy(), scale=1.0 / 8)
+    gd = avt.ops.softmax_ce_bwd(gp, scale=1.0 / 8)
+    assert np.array_equal(gd.cpu().numpy(), d)
+
+
+# ---------------------------------------------------------------- clip_pack
+@pytest.mark.parametrize("W,S,H,Wd,hw", [(20, 4, 128, 128, 224), (15, 6, 90, 120, 224), (20, 4, 64, 48, 100)])
+def test_clip_pack(avt, dev, W, S, H, Wd, hw):
+    g = torch.Generator().manual_seed(123)
+    n_win = 6
+    F_ = (n_win - 1) * S + W + 3
+    frames = torch.randint(0, 256, (F_, H, Wd, 3), generator=g, dtype=torch.uint8)
+    starts = np.arange(n_win) * S
+    slow, fast = avt.ops.clip_pack(frames.to(dev), starts, W, out_hw=hw, dtype=torch.float32)
+    sb, fb = avt.ops.clip_pack(frames.to(dev), starts, W, out_hw=hw, dtype=torch.bfloat16)
+    for i, st in enumerate(starts):
+        rs, rf = ref_py.pack_clip(frames, int(st), W, out_hw=hw)
+        # fp32: same op order as torch up to FMA contraction -> 1e-5 abs on values in [-2.1, 2.5]
+        assert (slow[i].cpu() - rs).abs().max() < 1e-5
+        assert (fast[i].cpu() - rf).abs().max() < 1e-5
+        # bf16 output: one bf16 ulp (2^-7 relative) where the fp32 value sits on a rounding boundary
+        assert (sb[i].float().cpu() - rs).abs().max() < 2.5 * 2 ** -7
+        assert (fb[i].float().cpu() - rf.bfloat16().float()).abs().max() < 2.5 * 2 ** -6
+        assert ((fb[i].float().cpu() - rf.bfloat16().float()).abs() > 0).float().mean() < 1e-3
+
+
+def test_errors_are_loud(avt, dev):
+    with pytest.raises(avt._lib.AvtError):
+        avt.ops.l2norm_rows(torch.zeros(4, 8))  # CPU tensor: no fallback
+    with pytest.raises(avt._lib.AvtError):
+        avt.ops.sim_gemm_nt(torch.zeros(4, 8, device=dev), torch.zeros(4, 8, device=dev), 0.0, "f32")  # temp == 0
