@@ -1,0 +1,128 @@
+"""`AudioVideoSegments` — the training / validation dataset plugin, drop-in for
+contrastive_video_textures/dataset/dataset.py:24-253 (same constructor, __len__, item tuples, and the
+same NumPy RNG consumption in the negative sampling, :183-190).
+
+Host side by design: it only picks indices and slices the video held in RAM.  `segment_plan(idx)` exposes
+the window starts of an item so a trainer can pack them on the MI355X with ops.clip_pack instead of the
+per-item CPU preprocessing of dataset.py:145-209.
+"""
+import copy
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.utils.data import Dataset
+
+from .audio_frontend import waveform_to_examples
+from .models import process_cv2_inputs
+from .validate import read_audio, read_video
+
+
+class AudioVideoSegments(Dataset):
+    def __init__(self, args, video_name, split="train", video=None, audio=None):
+        self.vdata, self.adata = args.vdata, args.adata
+        self.video_name, self.split = video_name, split
+        self.n_negs = args.n_negs
+        self.crop_size = self.img_size = args.img_size
+        self.enc_arch = args.enc_arch
+        if video is None:
+            self.video_filename = os.path.join(self.vdata, "{}.mp4".format(video_name))
+            self.video_u8, fps = read_video(self.video_filename)
+        else:
+            self.video_u8, fps = torch.as_tensor(video[0]), video[1]
+        self.fps = fps
+        if self.enc_arch != "slowfast":
+            # dataset.py:44-58 (ToPILImage/Resize/ToTensor/Normalize); resize by antialiased bilinear
+            mean = torch.tensor([0.4345, 0.4051, 0.3775]).view(1, 3, 1, 1)
+            std = torch.tensor([0.2768, 0.2713, 0.2737]).view(1, 3, 1, 1)
+            v = self.video_u8.permute(0, 3, 1, 2).float() / 255
+            if v.shape[-1] != args.img_size or v.shape[-2] != args.img_size:
+                v = F.interpolate(v, size=(args.img_size, args.img_size), mode="bilinear", antialias=True)
+            self.video = (v - mean) / std
+        else:
+            self.video = (self.video_u8.float() / 255)[:, :, :, [2, 1, 0]]  # dataset.py:68-73: 0-1, BGR
+        print("Frame shape: ", self.video[0].shape)
+        # Window of 0.5 seconds, stride of 0.2 seconds — overrides -w/-stride [quirk Q10] (dataset.py:78-80)
+        args.window = math.ceil(self.fps / 2)
+        args.stride = math.ceil(self.fps / 5)
+        print("Stride {} Window {}".format(args.stride, args.window))
+        self.stride, self.window = args.stride, args.window
+        if self.adata is None and audio is None:
+            # dummy audio (dataset.py:87-93); consumes the torch RNG in this order
+            self.audio_w = torch.rand(len(self.video) * 10)
+            self.apf = 10
+            self.audio_eg = torch.rand((math.floor((len(self.video) - self.window) / self.stride)), 10)
+        else:
+            if audio is None:
+                path = os.path.join(self.adata, "{}.wav".format(video_name))
+                assert os.path.exists(path) or os.path.exists(os.path.splitext(path)[0] + ".npz"), \
+                    "No audio found at {}".format(path)
+                audio = read_audio(path)
+            self.audio_w, self.sr = audio
+            self.apf = math.floor(self.sr / self.fps)
+            self.audio_w = np.asarray(self.audio_w)[: len(self.video) * self.apf]
+            self.audio_eg = torch.from_numpy(waveform_to_examples(self.audio_w, self.sr)).unsqueeze(dim=1).float()
+            self.audio_w = torch.tensor(self.audio_w)
+
+    def __len__(self):
+        n = math.floor((len(self.video) - self.window) / self.stride)
+        return n - 1 if self.split == "train" else n
+
+    def sample_ids(self, idx):
+        """Segment ids of an item: (positive id, negative ids) with dataset.py:128-139, 181-190 semantics:
+        n_negs drawn without replacement, then the first len(hard) overwritten by the 8 temporal neighbours
+        (idx-4..idx-1, idx+2..idx+5) that fall in [0, len] — duplicates possible [quirk]."""
+        n = self.__len__()
+        if self.split == "train":
+            pos = idx + 1
+            neg_ids = np.arange(n + 1)
+            mask = np.ones(n + 1, dtype=bool)
+            mask[[idx, idx + 1]] = False
+        else:
+            pos = (idx + 1) % n
+            neg_ids = np.arange(n)
+            mask = np.ones(n, dtype=bool)
+            mask[[idx, pos]] = False
+        neg = neg_ids[mask, ...]
+        if self.split == "train":
+            neg = np.random.choice(neg, self.n_negs, replace=False)
+            hard = np.array([idx - 4, idx - 3, idx - 2, idx - 1, idx + 2, idx + 3, idx + 4, idx + 5])
+            hard = hard[hard >= 0]
+            hard = hard[hard <= n]
+            neg[: len(hard)] = hard
+        return pos, neg
+
+    def segment_plan(self, idx):
+        """Window start frames (query, [positive] + negatives) for device-side packing."""
+        pos, neg = self.sample_ids(idx)
+        return idx * self.stride, np.concatenate(([pos], neg)) * self.stride
+
+    def _clip(self, start):
+        S, W = self.stride, self.window
+        if self.enc_arch != "slowfast":
+            return self.video[start : start + W]
+        return [F.interpolate(item.squeeze(0), size=(self.img_size, self.img_size), mode="bilinear")
+                for item in process_cv2_inputs(self.video[start : start + W])]
+
+    def __getitem__(self, idx):
+        S, W = self.stride, self.window
+        pos, neg = self.sample_ids(idx)
+        q_v = self._clip(idx * S)
+        q_aw = self.audio_w[idx * S * self.apf : (idx * S + W) * self.apf]
+        q_ae = self.audio_eg[idx]
+        t_v = [self._clip(pos * S)] + [self._clip(int(i) * S) for i in neg]
+        t_aw = [self.audio_w[pos * S * self.apf : (pos * S + W) * self.apf]]
+        t_aw += [self.audio_w[int(i) * S * self.apf : (int(i) * S + W) * self.apf] for i in neg]
+        pos_ae = idx + 1 if self.split == "train" else pos  # dataset.py:179 uses idx+1
+        t_ae = [self.audio_eg[pos_ae]] + list(self.audio_eg[neg])
+        if self.enc_arch == "slowfast":
+            t_v = copy.deepcopy([torch.stack([x[k] for x in t_v]) for k in range(2)])
+        else:
+            t_v = torch.stack(t_v)
+        t_aw, t_ae = torch.stack(t_aw), torch.stack(t_ae)
+        if self.split == "train":
+            return (q_v, q_aw, q_ae, t_v, t_aw, t_ae)
+        ordering = torch.cat((torch.tensor([pos]), torch.tensor(neg)))
+        return (q_v, q_aw, q_ae, t_v, t_aw, t_ae, idx, ordering)

@@ -1,0 +1,209 @@
+"""CLI / per-video driver, drop-in for contrastive_video_textures/main.py:41-548: every flag of the
+reference parser with the same names, defaults and types; `main(args, video_name, itr=0)`; the per-video
+loop with the fps -> window/stride override (main.py:511-516) and default checkpoint name (:520-534).
+
+Additions (all optional): --stitch_mode {compat,aligned}, --ref_num_gpus, --enc_dtype {fp32,bf16},
+--enc_batch, --vcam (the flag validate.py:299 reads but the reference never defines [quirk Q2]).
+Multi-GPU: one process per GPU under torch.distributed.run instead of torch.nn.DataParallel (main.py:420).
+"""
+import argparse
+import math
+import os
+import shutil
+
+import torch
+
+from . import dist as avt_dist
+from .dataset import AudioVideoSegments
+from .logger import Logger
+from .models import ContrastivePredictionTemporal, ModelBuilder3D
+from .train import train
+from .validate import read_video, validate
+from .vggish import VGGish
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="PyTorch Video Textures (MI355X-native hot path)")
+    a = parser.add_argument
+    a("--enc_arch", "-ea", metavar="ARCH", default="resnet18", help="model architecture")
+    a("--model_type", "-m", default=1, type=int, help="(1) Video Textures (2) Audio Video Textures")
+    a("--vdata", "-vdata", default=None, type=str, help="Path to video dataset")
+    a("--adata", "-adata", default=None, type=str, help="Path to audio")
+    a("--pdata", "-pdata", default=None, type=str, help="Path to poses")
+    a("--fdata", "-fdata", default=None, type=str, help="Path to flow")
+    a("--dadata", "-dadata", default="audio/target", type=str, help="Path to driving audio dataset")
+    a("--video_list", "-vl", default=None, type=str, nargs="+", help="list of input videos")
+    a("--fps", "-fps", default=30, type=int, help="frame rate of input video")
+    a("--subsample_rate", "-subsample", default=1, type=int, help="rate for subsampling the video")
+    a("--temp", "-temp", default=0.1, type=float, help="Temperature value")
+    a("--threshold", "-th", default=0.0, type=float, help="Threshold value")
+    a("--l2", "-l2", default=True, action="store_false", help="To use l2 norm or not")
+    a("--interpolation", "-nintp", default=True, action="store_false", help="Interpolate frames at eval")
+    a("--img_size", "-size", default=224, type=int, help="resize image to this size")
+    a("--n_negs", "-negs", default=20, type=int, help="Number negative frames to use when training")
+    a("--window", "-w", default=20, type=int, help="Size of temporal window")
+    a("--train_stride", "-train_stride", default=4, type=int, help="Stride length")
+    a("--stride", "-stride", default=4, type=int, help="Stride length")
+    a("--new_video_length", "-nvl", default=30, type=int, help="Length of new video")
+    a("--alpha", "-alpha", default=0.5, type=float, help="alpha for validation to control driving audio")
+    a("--SF", "-SF", default=5, type=int, help="slomo factor N")
+    a("-long", "--long", dest="long", default=False, action="store_true", help="unused in the reference")
+    a("-fb", "--frames_bar", dest="frames_bar", default=False, action="store_true", help="Visualize transitions.")
+    a("--epochs", default=60, type=int, metavar="N", help="number of total epochs to run")
+    a("--size", default=224, type=int, metavar="N", help="primary image input size")
+    a("--start_epoch", default=None, type=int, metavar="N", help="manual epoch number (useful on restarts)")
+    a("--batch_size", "-bs", default=32, type=int, metavar="N", help="mini-batch size (default: 32)")
+    a("--mini_batchsize", "-mbs", default=150, type=int, help="mini-batch size for target frames")
+    a("--lr", "-lr", default=10e-3, type=float, metavar="LR", help="initial learning rate")
+    a("--lr_steps", default=30, type=int, metavar="LRSteps", help="epochs to decay learning rate by 10")
+    a("--momentum", default=0.9, type=float, metavar="M", help="momentum")
+    a("--weight_decay", "--wd", default=0.0001, type=float, metavar="W", help="weight decay (default: 1e-4)")
+    a("--workers", "-j", default=4, type=int, metavar="N", help="number of data loading workers")
+    a("--print_freq", "-p", default=5, type=int, metavar="N", help="print frequency")
+    a("--log_freq", "-lf", default=10, type=int, metavar="N", help="frequency to write in tensorboard")
+    a("--resume", default="", type=str, metavar="PATH", help="path to latest checkpoint (default: none)")
+    a("-e", "--evaluate", dest="evaluate", action="store_true", help="evaluate model on validation set")
+    a("-da", "--driving_audio", default=None, type=str, nargs="+", help="list of target audios")
+    a("-daf", "--da_feats", default="VGG", type=str, help="type of feats for audio conditioning")
+    a("-daf_resume", "--daf_resume", default="", type=str, nargs="+", help="List of paths to best VideoForAudio ckpt")
+    a("-ve", "--visualize_evaluate", dest="visualize_evaluate", action="store_true",
+      help="evaluate model on validation set and visualize logits")
+    a("-vf", "--val_freq", default=5, type=int, metavar="VF", help="frequency to call validate during train)")
+    a("--logdir", default="./logs", help="folder to output tensorboard logs")
+    a("--logname", default="exp", help="name of the experiment for checkpoints and logs")
+    a("-rf", "--results_folder", default="results", type=str, help="folder for result videos")
+    a("--ckpt", default="./ckpt", help="folder to output checkpoints")
+    # --- additions of the MI355X build ---
+    a("--stitch_mode", default="compat", choices=["compat", "aligned"],
+      help="compat: the shipped reference's window/label map; aligned: the N x N matrix the labels claim")
+    a("--ref_num_gpus", default=None, type=int, help="reference GPU count to emulate in compat mode")
+    a("--enc_dtype", default="fp32", choices=["fp32", "bf16"], help="encoder compute dtype")
+    a("--enc_batch", default=32, type=int, help="windows per encoder batch")
+    a("--vcam", default=False, action="store_true", help="defined for validate.py:299; CAM dumps are out of scope")
+    return parser
+
+
+parser = build_parser()
+
+
+def main(args, video_name, itr=0):
+    best_loss = 1000000
+    rank, world, local = avt_dist.init_from_env()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if not args.evaluate and not args.visualize_evaluate:
+        dataset_train = AudioVideoSegments(args, video_name, split="train")
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset_train) if world > 1 else None
+        train_loader = torch.utils.data.DataLoader(dataset_train, batch_size=max(args.batch_size // world, 1),
+                                                   shuffle=sampler is None, sampler=sampler,
+                                                   num_workers=args.workers, drop_last=True)
+    print("=> creating model '{}'".format(args.model_type))
+    builder = ModelBuilder3D()
+    q_image_enc_model, fc_dim = builder.build_network(arch=args.enc_arch, img_size=args.size, window=args.window)
+    t_image_enc_model, fc_dim = builder.build_network(arch=args.enc_arch, img_size=args.size, window=args.window)
+    audio_enc_model = VGGish()
+    if os.path.isfile("pytorch_vggish.pth"):  # main.py:338 loads it unconditionally
+        audio_enc_model.load_state_dict(torch.load("pytorch_vggish.pth", map_location="cpu"))
+    else:
+        print("pytorch_vggish.pth not found in cwd: VGGish keeps its random init")
+    model = ContrastivePredictionTemporal(q_image_enc_model, t_image_enc_model, audio_enc_model, args.model_type,
+                                          fc_dim, args.temp, args.window, args.stride, args.threshold,
+                                          mini_batchsize=args.mini_batchsize, enc_arch=args.enc_arch,
+                                          img_size=args.img_size)
+    if args.resume:
+        assert os.path.isfile(args.resume), "No checkpoint found at '{}'".format(args.resume)
+        print("=> loading checkpoint '{}'".format(args.resume))
+        checkpoint = torch.load(args.resume, map_location="cpu")
+        if args.start_epoch is None:
+            args.start_epoch = checkpoint["epoch"]
+        best_loss = checkpoint["best_loss"]
+        model.load_state_dict(checkpoint["state_dict"])
+        print("=> loaded checkpoint '{}' (epoch {})".format(args.resume, checkpoint["epoch"]))
+    os.makedirs("./ckpt", exist_ok=True)
+    tag = "{}_model_{}_vd_{}_vn_{}_bs_{}_".format(args.logname, args.model_type, os.path.split(args.vdata)[-1],
+                                                  video_name, args.batch_size)
+    if not args.evaluate:
+        tag += "negs_{}_".format(args.n_negs)
+    logname = tag + "w_{}_stride_{}_temp_{}_th_{}_enca_{}_subr_{}_eval_{}".format(
+        args.window, args.stride, args.temp, args.threshold, args.enc_arch, args.subsample_rate,
+        args.evaluate or args.visualize_evaluate)
+    if args.evaluate and args.driving_audio is not None:
+        logname += "alpha_{}_daf_{}".format(args.alpha, args.da_feats)
+    if args.start_epoch is None:
+        args.start_epoch = 0
+
+    model = model.to(device)
+    if args.evaluate and args.enc_dtype == "bf16":
+        for enc in (model.q_encoder, model.t_encoder):
+            enc.to(torch.bfloat16).to(memory_format=torch.channels_last_3d)
+    if world > 1 and not args.evaluate:  # weights resident per rank, gradients all-reduced over RCCL
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+    torch.backends.cudnn.benchmark = True
+    tb_logdir = os.path.join(args.logdir, logname)
+    os.makedirs(tb_logdir, exist_ok=True)
+    tb_logger = Logger(tb_logdir) if rank == 0 else None
+
+    if args.evaluate:
+        if rank == 0:
+            validate(model, args, video_name=video_name, tb_logger=tb_logger, model_type=args.model_type, itr=itr)
+        return
+    optimizer = torch.optim.SGD(params=model.parameters(), lr=args.lr, momentum=args.momentum,
+                                weight_decay=args.weight_decay)
+    scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=args.lr_steps)
+    print("Training for {} epochs.".format(args.epochs - args.start_epoch))
+    for epoch in range(args.start_epoch, args.epochs):
+        if world > 1:
+            train_loader.sampler.set_epoch(epoch)
+        loss = train(train_loader, model, optimizer, args, epoch, tb_logger)
+        is_best = loss < best_loss
+        best_loss = min(loss, best_loss)
+        if rank == 0:
+            net = model.module if hasattr(model, "module") else model
+            save_checkpoint({"epoch": epoch + 1, "arch": args.enc_arch, "state_dict": net.state_dict(),
+                             "best_loss": best_loss}, is_best, os.path.join(args.ckpt, logname))
+        scheduler.step()
+        if loss < 0.07:
+            print("Loss {}. Stopping at epoch {}.".format(loss, epoch))
+            break
+
+
+def save_checkpoint(state, is_best, filename):
+    torch.save(state, filename + "_latest.pth.tar")
+    if is_best:
+        shutil.copyfile(filename + "_latest.pth.tar", filename + "_best.pth.tar")
+
+
+def cli(argv=None):
+    args = parser.parse_args(argv)
+    print(args)
+    assert os.path.exists(args.vdata), "No videos found at {}".format(args.vdata)
+    if args.adata is not None and os.path.exists(args.adata):
+        print("Audio found at {}".format(args.adata))
+    if args.video_list is None:
+        args.video_list = sorted([f.split(".")[0] for f in sorted(os.listdir(args.vdata)) if not f.startswith(".")])
+    for itr, video_name in enumerate(args.video_list):
+        args.results_folder = "results_{}".format(video_name)
+        if args.evaluate or args.visualize_evaluate:
+            _, fps = read_video(os.path.join(args.vdata, "{}.mp4".format(video_name)))
+            if fps:
+                args.fps = fps
+            print("Frame rate: ", args.fps)
+            args.window = math.ceil(args.fps / 2)  # [quirk Q10] overrides -w / -stride (main.py:515-516)
+            args.stride = math.ceil(args.fps / 5)
+            print("Stride {} Window {}".format(args.stride, args.window))
+            if args.resume == "":
+                args.resume = ("ckpt/exp_model_{}_vd_{}_vn_{}_bs_{}_negs_{}_w_{}_"
+                               "stride_{}_temp_0.1_th_0.0_enca_{}_subr_{}_eval_False_best.pth.tar".format(
+                                   args.model_type, os.path.split(args.vdata)[-1], video_name, args.batch_size,
+                                   args.n_negs, args.window, args.stride, args.enc_arch, args.subsample_rate))
+            assert os.path.isfile(args.resume), "No checkpoint found at '{}'".format(args.resume)
+            print("=> loading checkpoint '{}'".format(args.resume))
+            if args.driving_audio is not None:
+                args.results_folder += "_target_{}_{}".format(
+                    video_name, os.path.split(args.driving_audio[itr])[-1].split(".")[0])
+        print("Starting video {}".format(video_name))
+        main(args, video_name, itr)
+
+
+if __name__ == "__main__":
+    cli()

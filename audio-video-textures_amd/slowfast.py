@@ -1,0 +1,171 @@
+"""SlowFast-8x8-R50 video encoder plugin: forward([slow [B,3,8,H,W], fast [B,3,32,H,W]]) -> [B,2304].
+
+The reference builds this model through the third-party `slowfast` package, which it neither vendors
+nor pins (contrastive_video_textures/models/models.py:565-580), then replaces the head's dropout /
+projection / act by Identity so the head returns the pooled, concatenated (slow 2048 | fast 256)
+features.  This file restates the architecture from the SlowFast paper / model-zoo config
+SLOWFAST_8x8_R50 with PySlowFast's module names, so a converted reference
+checkpoint (`q_encoder.s1.pathway0_stem.conv.weight`, ...) loads by key.  PARITY UNPINNED: no
+reference test or weight file pins its arithmetic.
+
+MI355X notes: convolutions go to MIOpen; run it in bf16 with channels_last_3d (`prepare_encoder`).
+"""
+import torch
+import torch.nn as nn
+
+ALPHA, BETA_INV, FUSION_RATIO, FUSION_KERNEL = 4, 8, 2, 7
+WIDTH = 64
+DEPTHS = (3, 4, 6, 3)
+# temporal kernel of conv `a` per stage, (slow, fast): SLOWFAST_8x8: slow 1,1,3,3 / fast 3,3,3,3
+TKERNEL = ((1, 3), (1, 3), (3, 3), (3, 3))
+STEM_TK = (1, 5)
+
+
+class Stem(nn.Module):
+    def __init__(self, cout, tk):
+        super().__init__()
+        self.conv = nn.Conv3d(3, cout, (tk, 7, 7), stride=(1, 2, 2), padding=(tk // 2, 3, 3), bias=False)
+        self.bn = nn.BatchNorm3d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.pool_layer = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+
+    def forward(self, x):
+        return self.pool_layer(self.relu(self.bn(self.conv(x))))
+
+
+class VideoModelStem(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.pathway0_stem = Stem(WIDTH, STEM_TK[0])
+        self.pathway1_stem = Stem(WIDTH // BETA_INV, STEM_TK[1])
+
+    def forward(self, x):
+        return [self.pathway0_stem(x[0]), self.pathway1_stem(x[1])]
+
+
+class FuseFastToSlow(nn.Module):
+    def __init__(self, c_fast):
+        super().__init__()
+        self.conv_f2s = nn.Conv3d(c_fast, c_fast * FUSION_RATIO, (FUSION_KERNEL, 1, 1), stride=(ALPHA, 1, 1),
+                                  padding=(FUSION_KERNEL // 2, 0, 0), bias=False)
+        self.bn = nn.BatchNorm3d(c_fast * FUSION_RATIO)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return [torch.cat([x[0], self.relu(self.bn(self.conv_f2s(x[1])))], 1), x[1]]
+
+
+class BottleneckTransform(nn.Module):
+    def __init__(self, cin, cout, cinner, tk, stride):
+        super().__init__()
+        self.a = nn.Conv3d(cin, cinner, (tk, 1, 1), padding=(tk // 2, 0, 0), bias=False)
+        self.a_bn = nn.BatchNorm3d(cinner)
+        self.a_relu = nn.ReLU(inplace=True)
+        self.b = nn.Conv3d(cinner, cinner, (1, 3, 3), stride=(1, stride, stride), padding=(0, 1, 1), bias=False)
+        self.b_bn = nn.BatchNorm3d(cinner)
+        self.b_relu = nn.ReLU(inplace=True)
+        self.c = nn.Conv3d(cinner, cout, 1, bias=False)
+        self.c_bn = nn.BatchNorm3d(cout)
+
+    def forward(self, x):
+        x = self.a_relu(self.a_bn(self.a(x)))
+        x = self.b_relu(self.b_bn(self.b(x)))
+        return self.c_bn(self.c(x))
+
+
+class ResBlock(nn.Module):
+    def __init__(self, cin, cout, cinner, tk, stride):
+        super().__init__()
+        if cin != cout or stride != 1:
+            self.branch1 = nn.Conv3d(cin, cout, 1, stride=(1, stride, stride), bias=False)
+            self.branch1_bn = nn.BatchNorm3d(cout)
+        self.branch2 = BottleneckTransform(cin, cout, cinner, tk, stride)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        sc = self.branch1_bn(self.branch1(x)) if hasattr(self, "branch1") else x
+        return self.relu(sc + self.branch2(x))
+
+
+class ResStage(nn.Module):
+    def __init__(self, cin, cout, cinner, tks, stride, depth):
+        super().__init__()
+        self.depth = depth
+        for p in range(2):
+            for i in range(depth):
+                self.add_module("pathway%d_res%d" % (p, i),
+                                ResBlock(cin[p] if i == 0 else cout[p], cout[p], cinner[p], tks[p],
+                                         stride if i == 0 else 1))
+
+    def forward(self, x):
+        out = []
+        for p in range(2):
+            y = x[p]
+            for i in range(self.depth):
+                y = getattr(self, "pathway%d_res%d" % (p, i))(y)
+            out.append(y)
+        return out
+
+
+class Head(nn.Module):
+    """ResNetBasicHead after the reference's surgery (models.py:578-580): per-pathway global average
+    pool, concat slow|fast, Identity dropout/projection/act -> [B, 2304]."""
+
+    def __init__(self):
+        super().__init__()
+        self.pathway0_avgpool = nn.AdaptiveAvgPool3d(1)
+        self.pathway1_avgpool = nn.AdaptiveAvgPool3d(1)
+        self.dropout = nn.Identity()
+        self.projection = nn.Identity()
+        self.act = nn.Identity()
+
+    def forward(self, x):
+        z = torch.cat([self.pathway0_avgpool(x[0]), self.pathway1_avgpool(x[1])], 1)
+        z = self.act(self.projection(self.dropout(z.permute(0, 2, 3, 4, 1))))
+        return z.reshape(z.shape[0], -1)
+
+
+class SlowFast(nn.Module):
+    out_dim = WIDTH * 32 + WIDTH * 32 // BETA_INV  # 2048 + 256
+
+    def __init__(self):
+        super().__init__()
+        w, wf = WIDTH, WIDTH // BETA_INV
+        self.s1 = VideoModelStem()
+        self.s1_fuse = FuseFastToSlow(wf)
+        dims = []
+        cin = [w + wf * FUSION_RATIO, wf]
+        for k in range(4):
+            cout = [w * 4 * 2 ** k, wf * 4 * 2 ** k]
+            cinner = [w * 2 ** k, wf * 2 ** k]
+            dims.append((cin, cout, cinner))
+            cin = [cout[0] + cout[1] * FUSION_RATIO, cout[1]]
+        self.s2 = ResStage(*dims[0], TKERNEL[0], 1, DEPTHS[0])
+        self.s2_fuse = FuseFastToSlow(dims[0][1][1])
+        self.s3 = ResStage(*dims[1], TKERNEL[1], 2, DEPTHS[1])
+        self.s3_fuse = FuseFastToSlow(dims[1][1][1])
+        self.s4 = ResStage(*dims[2], TKERNEL[2], 2, DEPTHS[2])
+        self.s4_fuse = FuseFastToSlow(dims[2][1][1])
+        self.s5 = ResStage(*dims[3], TKERNEL[3], 2, DEPTHS[3])
+        self.head = Head()
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        for m in self.modules():  # PySlowFast zero-initialises the last BN of every residual branch
+            if isinstance(m, BottleneckTransform):
+                nn.init.zeros_(m.c_bn.weight)
+
+    def forward(self, x):
+        x = self.s1_fuse(self.s1(x))
+        x = self.s2_fuse(self.s2(x))
+        x = self.s3_fuse(self.s3(x))
+        x = self.s4_fuse(self.s4(x))
+        return self.head(self.s5(x))
+
+
+def prepare_encoder(module, device, dtype=torch.bfloat16, channels_last=True):
+    """Inference placement on MI355X: weights resident on the GPU in `dtype`, channels-last-3d."""
+    module = module.to(device=device, dtype=dtype).eval()
+    if channels_last:
+        module = module.to(memory_format=torch.channels_last_3d)
+    return module

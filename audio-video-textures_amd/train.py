@@ -1,0 +1,60 @@
+"""`train()` — one epoch of InfoNCE SGD, drop-in for contrastive_video_textures/train.py:39-210
+(same signature, same meters and prints; tensorboard images are skipped when no logger is given).
+The loss runs on the HIP softmax-CE kernels (models.InfoNCECriterion) when the logits are on the GPU."""
+import time
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .models import InfoNCECriterion
+from .utils import AverageMeter
+
+
+def to_cuda(item):
+    if isinstance(item[0], list):
+        return [[x.cuda() for x in y] for y in item]
+    elif isinstance(item, list):
+        return [x.cuda() for x in item]
+    return item.cuda()
+
+
+def train(train_loader, model, optimizer, args, epoch, tb_logger=None):
+    batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
+    model.train()
+    on_gpu = next(model.parameters()).is_cuda
+    criterion = InfoNCECriterion() if on_gpu else nn.CrossEntropyLoss()
+    end = time.time()
+    for i, batch_data in enumerate(train_loader):
+        q_frames, q_audio_wav, q_audio_eg, t_frames, t_audio_wav, t_audio_eg = batch_data
+        if on_gpu:
+            q_frames, t_frames = to_cuda(q_frames), to_cuda(t_frames)
+            q_audio_eg, t_audio_eg = q_audio_eg.cuda(), t_audio_eg.cuda()
+        data_time.update(time.time() - end)
+
+        output = model(q_frames, t_frames, q_audio_eg=q_audio_eg, t_audio_eg=t_audio_eg)  # train.py:114-116
+        batch_size = (q_frames[0] if isinstance(q_frames, list) else q_frames).shape[0]
+        labels = torch.zeros(batch_size, dtype=torch.long, device=output.device)  # positives at column 0
+        loss = criterion(output, labels).mean()
+        losses.update(loss.item(), batch_size)
+
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if i % args.print_freq == 0:
+            print("Epoch: [{0}][{1}/{2}]\t"
+                  "Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t"
+                  "Data {data_time.val:.3f} ({data_time.avg:.3f})\t"
+                  "Loss {loss.val:.4f} ({loss.avg:.4f})".format(epoch, i, len(train_loader), batch_time=batch_time,
+                                                                data_time=data_time, loss=losses))
+        if tb_logger is not None and i % args.log_freq == 0:
+            logs = OrderedDict()
+            logs["Train_IterLoss"] = losses.val
+            iter_count = epoch * len(train_loader) + i
+            for key, value in logs.items():
+                tb_logger.log_scalar(value, key, iter_count)
+            tb_logger.flush()
+    return losses.avg

@@ -201,3 +201,78 @@ def classic_d2(d1, sigma_factor, filter_size=16):
     p2 = torch.cat((p2[1:, :], p2[-1, :].unsqueeze(0)), dim=0)
     p2 = p2 / p2.sum(1, keepdim=True)
     return d2.numpy(), p2.numpy(), float(sigma)
+
+
+# ---- reference-compat stitch rows at oracle level (CPU torch encoders + C oracle) ------
+def pack_clip_ids(frames01_bgr, ids, out_hw, mean=0.45, std=0.225):
+    """Window given by explicit frame ids (-1 = the zero frame split_into_overlapping_segments pads with).
+    frames01_bgr: float [F,H,W,3] already /255 and BGR (validate.py:120-125)."""
+    ids = np.asarray(ids)
+    fr = torch.zeros((len(ids),) + tuple(frames01_bgr.shape[1:]), dtype=torch.float32)
+    ok = ids >= 0
+    fr[torch.from_numpy(ok)] = frames01_bgr[torch.from_numpy(ids[ok])]
+    x = ((fr - mean) / std).permute(3, 0, 1, 2)
+    fast = torch.index_select(x, 1, torch.linspace(0, x.shape[1] - 1, FAST_T).long())
+    slow = torch.index_select(fast, 1, torch.linspace(0, fast.shape[1] - 1, fast.shape[1] // ALPHA).long())
+    slow = F.interpolate(slow, size=(out_hw, out_hw), mode="bilinear")
+    fast = F.interpolate(fast, size=(out_hw, out_hw), mode="bilinear")
+    return slow, fast
+
+
+class CompatOracle:
+    """What the reference's validate() computes per step, with every distinct window encoded once.
+
+    q_enc / t_enc: SlowFast-contract modules ([slow, fast] -> [B,D]); vgg: audio module or None.
+    Embeddings are cached by window frame-id tuple; rows are produced by the C oracle
+    (l2norm -> canonical fp32 sim -> /temp)."""
+
+    def __init__(self, video_u8, W, S, mbs, n_gpus, img_size, q_enc, t_enc, temp, audio_eg=None, vgg=None,
+                 driving_eg=None):
+        from . import cref
+
+        self.cref = cref
+        v = torch.as_tensor(video_u8).float() / 255
+        self.frames = v[:, :, :, [2, 1, 0]]
+        self.F = len(v)
+        self.W, self.S, self.mbs, self.G, self.hw, self.temp = W, S, mbs, n_gpus, img_size, temp
+        self.q_enc, self.t_enc, self.vgg = q_enc, t_enc, vgg
+        self.L = num_segments(self.F, W, S)
+        self.audio_eg = audio_eg
+        self.driving_eg = driving_eg
+        self.cache_t, self.cache_q = {}, {}
+        self.a_feat = None
+        if vgg is not None and audio_eg is not None:
+            with torch.no_grad():
+                self.a_feat = vgg(torch.as_tensor(audio_eg[: self.L]).float()).numpy()
+                self.d_feat = vgg(torch.as_tensor(driving_eg).float()).numpy() if driving_eg is not None else None
+
+    def _embed(self, enc, cache, keys):
+        miss = [k for k in dict.fromkeys(keys) if k not in cache]
+        for i in range(0, len(miss), 64):
+            part = miss[i : i + 64]
+            packs = [pack_clip_ids(self.frames, np.array(k), self.hw) for k in part]
+            with torch.no_grad():
+                e = enc([torch.stack([p[0] for p in packs]), torch.stack([p[1] for p in packs])]).numpy()
+            for k, row in zip(part, e):
+                cache[k] = row
+        return np.stack([cache[k] for k in keys])
+
+    def row(self, q_id, step):
+        """-> (raw logits [n_out], raw audio logits or None, os_ids_t)"""
+        wins, seg_ids = compat_window_frames(q_id, self.F, self.W, self.S, self.mbs, self.G)
+        tv = self._embed(self.t_enc, self.cache_t, [tuple(w) for w in wins])
+        qv = self._embed(self.q_enc, self.cache_q, [tuple(range(q_id * self.S, q_id * self.S + self.W))])
+        ta = qa = None
+        if self.a_feat is not None:
+            mx = self.a_feat.shape[0] - 1
+            ta = self.a_feat[np.minimum(seg_ids, mx)]  # validate.py:398-401
+            qa = self.a_feat[min(q_id, mx)][None]  # validate.py:346
+        qn, _, _ = self.cref.l2norm_rows(qv, qa, want_split=False)
+        tn, _, _ = self.cref.l2norm_rows(tv, ta, want_split=False)
+        out = self.cref.sim_f32(qn, tn, self.temp)[0]
+        out_a = None
+        if self.driving_eg is not None:  # models.py:424-439 (VGG branch), driving example `step` (validate.py:417)
+            dn, _, _ = self.cref.l2norm_rows(self.d_feat[step][None], want_split=False)
+            sn, _, _ = self.cref.l2norm_rows(ta, want_split=False)
+            out_a = self.cref.sim_f32(dn, sn, self.temp)[0]
+        return out, out_a, seg_ids
