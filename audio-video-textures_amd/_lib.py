@@ -28,6 +28,8 @@ SIGNATURES = {
     "avt_row_topk": [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int, _vp, _vp, _vp],
     "avt_softmax_ce_fwd": [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],
     "avt_softmax_ce_bwd": [_vp, _vp, C.c_int64, C.c_int64, C.c_float, _vp, _vp],
+    "avt_conv3d_ktab": [C.c_int] * 7 + [_vp, C.c_int],
+    "avt_conv3d_igemm_bf16": [_vp] * 6 + [C.c_int] * 19 + [_vp],
 }
 
 

@@ -1,0 +1,315 @@
+// conv3d_igemm — implicit-GEMM 3D convolution on the gfx950 matrix cores, for the SlowFast encoder.
+// Replaces the cuDNN/MIOpen conv3d + BatchNorm + ReLU (+ residual add) sequence the reference runs through
+// the third-party SlowFast model for EVERY clip window (contrastive_video_textures/models/models.py:335, 399)
+// — ~all the FLOPs of the hot path (100 GFLOP per clip per encoder).
+//
+//   out[m, n] = act( sum_k A[m, k] * Wt[n, k] + bias[n] (+ res[m, n]) )
+//     m = (b, to, ho, wo) output position, n = output channel,
+//     k = ((dt*KH + dh)*KW + dw)*Cin + c   — Cin innermost, i.e. activations are NDHWC (channels-last-3d) bf16
+//     Wt = BN-folded weights packed [Cout, K] bf16 (K contiguous), bias = folded BN shift, fp32.
+//
+// Both operands have K contiguous per row, so a 16-byte chunk of A is 8 consecutive input channels of ONE tap:
+// the "im2col" is only an address computation (per-row base offset + per-K-chunk tap offset from a small table,
+// validity from a per-row bitmask of in-bounds taps) — nothing is materialised.  The MFMA is issued with the
+// weights as the first operand (D = Wt * A^T), so each lane ends up holding 4 CONSECUTIVE CHANNELS of one output
+// position: the epilogue packs them to bf16 (8 B), stages the tile through LDS, and writes / reads (residual)
+// global memory in 16-byte row-contiguous chunks.  BN, ReLU, residual add and the channel-slice write of the
+// lateral-fusion concat are all fused here, so every activation tensor crosses HBM once per consumer.
+//
+// Tiles (256 threads = 4 waves, v_mfma_f32_32x32x16_bf16, fp32 accumulate):
+//   <128,128>: 2x2 waves, wave tile 64(m) x 64(n)      — wide layers
+//   <256, 64>: 4x1 waves, wave tile 64(m) x 64(n)      — Cout = 64
+//   <256, 32>: 4x1 waves, wave tile 64(m) x 32(n)      — fast-pathway layers with few channels
+// LDS rows are padded to 144 B (conflict-free ds_read_b128, see sim_gemm.hip).  Roofline: MFMA for the wide
+// 3x3 layers, HBM for the 1x1x1 / few-channel layers (bytes = activations in + out (+ residual)).
+#include "avt_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int LSTR = 144;  // LDS row stride (128 data bytes = 64 bf16 of K, + 16 pad)
+constexpr int BK = 64;
+
+struct ConvArgs {
+  const uint16_t* in;
+  const uint16_t* wt;
+  const float* bias;
+  const uint16_t* res;
+  uint16_t* out;
+  const int2* ktab;  // [nk*8] {element offset of the chunk's tap+channel relative to the row base, tap id or -1}
+  int T, H, W;       // input extent
+  int To, Ho, Wo;
+  int Cout, K;
+  int KT, KH, KW, st, sh, sw, pt, ph, pw;
+  int ldi, ldo, ldr;
+  int relu;
+  int M;  // output positions (B*To*Ho*Wo)
+  int nk;
+  int tiles_n, nblk;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int WAVES_M = BM / 64;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WN = BN / WAVES_N;  // wave tile width in n
+  constexpr int NT = WN / 32, MT = 2;
+  constexpr int AU = BM / 32, BU = BN / 32;  // 16-byte chunks per thread per K-step
+  constexpr int A_BYTES = BM * LSTR;
+  constexpr int ESTR = BN * 2 + 16;  // epilogue staging row stride (bytes)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int bid = blockIdx.x;
+  const int qd = a.nblk / 8, rm = a.nblk % 8, xc = bid % 8;
+  const int swz = (xc < rm ? xc * (qd + 1) : rm * (qd + 1) + (xc - rm) * qd) + bid / 8;
+  const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int c16 = tid & 7, r0 = tid >> 3;
+
+  // ---- per-row state of the A gather: base element offset and the bitmask of in-bounds taps
+  int rowoff[AU];
+  unsigned rowmask[AU];
+#pragma unroll
+  for (int u = 0; u < AU; ++u) {
+    const int m = m0 + r0 + 32 * u;
+    rowoff[u] = 0;
+    rowmask[u] = 0u;
+    if (m < a.M) {
+      int wo = m % a.Wo;
+      int t1 = m / a.Wo;
+      int ho = t1 % a.Ho;
+      int t2 = t1 / a.Ho;
+      int to = t2 % a.To;
+      int b = t2 / a.To;
+      const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+      rowoff[u] = (((b * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.ldi;
+      unsigned mask = 0u;
+      int tap = 0;
+      for (int dt = 0; dt < a.KT; ++dt)
+        for (int dh = 0; dh < a.KH; ++dh)
+          for (int dw = 0; dw < a.KW; ++dw, ++tap) {
+            const bool ok = (unsigned)(ti0 + dt) < (unsigned)a.T && (unsigned)(hi0 + dh) < (unsigned)a.H &&
+                            (unsigned)(wi0 + dw) < (unsigned)a.W;
+            mask |= (ok ? 1u : 0u) << tap;
+          }
+      rowmask[u] = mask;
+    }
+  }
+  // rows of the weight tile this thread stages
+  int wrow[BU];
+#pragma unroll
+  for (int u = 0; u < BU; ++u) {
+    const int n = n0 + r0 + 32 * u;
+    wrow[u] = n < a.Cout ? n * a.K : -1;
+  }
+
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  uint4 ra[AU], rb[BU];
+  auto gload = [&](int kt) {
+    const int2 e = a.ktab[kt * 8 + c16];  // {offset, tap}
+    const bool kin = e.y >= 0;
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const bool ok = kin && ((rowmask[u] >> (e.y & 31)) & 1u);
+      ra[u] = ok ? *reinterpret_cast<const uint4*>(a.in + (rowoff[u] + e.x)) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int kc = (kt * 8 + c16) * 8;
+#pragma unroll
+    for (int u = 0; u < BU; ++u)
+      rb[u] = (kin && wrow[u] >= 0) ? *reinterpret_cast<const uint4*>(a.wt + (wrow[u] + kc)) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < AU; ++u) *reinterpret_cast<uint4*>(lds + (r0 + 32 * u) * LSTR + c16 * 16) = ra[u];
+#pragma unroll
+    for (int u = 0; u < BU; ++u) *reinterpret_cast<uint4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
+  };
+  const int arow = (wm * 64 + lr) * LSTR + lh * 16;
+  const int brow = A_BYTES + (wn * WN + lr) * LSTR + lh * 16;
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[MT], wf[NT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) af[j] = *reinterpret_cast<const bf16x8*>(lds + arow + j * 32 * LSTR + ks * 32);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lds + brow + i * 32 * LSTR + ks * 32);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);  // D[n][m]
+    }
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < a.nk; ++kt) {
+    if (kt + 1 < a.nk) gload(kt + 1);
+    compute();
+    __syncthreads();
+    if (kt + 1 < a.nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue phase 1: (+bias [, relu]) -> bf16 -> LDS staging tile [m][n]
+  // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n  -> regs 4g..4g+3 are 4 consecutive n
+  const bool has_res = a.res != nullptr;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = wn * WN + i * 32 + 8 * g + 4 * lh;  // tile-local first channel of this group
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias && n0 + nl < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+        float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+        if (a.relu && !has_res) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+          v2 = fmaxf(v2, 0.f);
+          v3 = fmaxf(v3, 0.f);
+        }
+        uint2 pk;
+        pk.x = avt::f32_to_bf16_rne(v0) | ((uint32_t)avt::f32_to_bf16_rne(v1) << 16);
+        pk.y = avt::f32_to_bf16_rne(v2) | ((uint32_t)avt::f32_to_bf16_rne(v3) << 16);
+        const int ml = wm * 64 + j * 32 + lr;
+        *reinterpret_cast<uint2*>(lds + ml * ESTR + nl * 2) = pk;
+      }
+    }
+  __syncthreads();
+  // ---- epilogue phase 2: 16-byte row-contiguous chunks: (+residual, relu) -> global
+  constexpr int CPR = BN / 8;  // chunks per row
+#pragma unroll
+  for (int u = 0; u < (BM * CPR) / 256; ++u) {
+    const int c = tid + 256 * u;
+    const int row = c / CPR, cc = c % CPR;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m < a.M && n < a.Cout) {
+      uint4 v = *reinterpret_cast<const uint4*>(lds + row * ESTR + cc * 16);
+      if (has_res) {
+        const uint4 rv = *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n);
+        uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
+        const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x0 = avt::bf16_bits_to_f32((uint16_t)(pv[e] & 0xffffu)) + avt::bf16_bits_to_f32((uint16_t)(pr[e] & 0xffffu));
+          float x1 = avt::bf16_bits_to_f32((uint16_t)(pv[e] >> 16)) + avt::bf16_bits_to_f32((uint16_t)(pr[e] >> 16));
+          if (a.relu) {
+            x0 = fmaxf(x0, 0.f);
+            x1 = fmaxf(x1, 0.f);
+          }
+          pv[e] = avt::f32_to_bf16_rne(x0) | ((uint32_t)avt::f32_to_bf16_rne(x1) << 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(a.out + (int64_t)m * a.ldo + n) = v;
+    }
+  }
+}
+
+template <int BM, int BN>
+int launch(ConvArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.Cout + BN - 1) / BN;
+  a.nblk = tiles_m * a.tiles_n;
+  constexpr int lds_main = (BM + BN) * LSTR;
+  constexpr int lds_epi = BM * (BN * 2 + 16);
+  constexpr int lds_bytes = lds_main > lds_epi ? lds_main : lds_epi;
+  static_assert(lds_bytes <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
+  return avt::check_launch("avt_conv3d_igemm_bf16");
+}
+
+}  // namespace
+
+extern "C" int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, int ldi, int32_t* ktab, int n_entries) {
+  AVT_REQUIRE(ktab && cin > 0 && cin % 8 == 0, "avt_conv3d_ktab: Cin must be a positive multiple of 8");
+  AVT_REQUIRE(kt * kh * kw <= 32 && kt > 0 && kh > 0 && kw > 0, "avt_conv3d_ktab: at most 32 taps");
+  const int K = kt * kh * kw * cin;
+  const int nk = (K + BK - 1) / BK;
+  AVT_REQUIRE(n_entries == nk * 8, "avt_conv3d_ktab: n_entries must be %d", nk * 8);
+  const int cpt = cin / 8;
+  for (int kc = 0; kc < nk * 8; ++kc) {
+    if (kc * 8 < K) {
+      const int tap = kc / cpt, c8 = kc % cpt;
+      const int dt = tap / (kh * kw), dh = (tap / kw) % kh, dw = tap % kw;
+      ktab[2 * kc] = ((dt * h + dh) * w + dw) * ldi + c8 * 8;
+      ktab[2 * kc + 1] = tap;
+    } else {
+      ktab[2 * kc] = 0;
+      ktab[2 * kc + 1] = -1;
+    }
+  }
+  return AVT_OK;
+}
+
+extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float* bias, const void* res, void* out,
+                                     const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
+                                     int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo,
+                                     int ldr, int relu, void* stream) {
+  AVT_REQUIRE(in && wt && out && ktab, "avt_conv3d_igemm_bf16: NULL pointer");
+  AVT_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 8 == 0, "avt_conv3d_igemm_bf16: Cin/Cout must be multiples of 8");
+  AVT_REQUIRE(kt * kh * kw <= 32, "avt_conv3d_igemm_bf16: at most 32 taps");
+  AVT_REQUIRE(ldi % 8 == 0 && ldo % 8 == 0 && (!res || ldr % 8 == 0) && ldi >= cin && ldo >= cout,
+              "avt_conv3d_igemm_bf16: leading dimensions must be multiples of 8 and cover the channels");
+  AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(wt) && avt::aligned16(out) && (!res || avt::aligned16(res)) &&
+                  (!bias || avt::aligned16(bias)),
+              "avt_conv3d_igemm_bf16: pointers must be 16-byte aligned");
+  ConvArgs a;
+  a.in = static_cast<const uint16_t*>(in);
+  a.wt = static_cast<const uint16_t*>(wt);
+  a.bias = bias;
+  a.res = static_cast<const uint16_t*>(res);
+  a.out = static_cast<uint16_t*>(out);
+  a.ktab = reinterpret_cast<const int2*>(ktab);
+  a.T = t;
+  a.H = h;
+  a.W = w;
+  a.To = (t + 2 * pt - kt) / st + 1;
+  a.Ho = (h + 2 * ph - kh) / sh + 1;
+  a.Wo = (w + 2 * pw - kw) / sw + 1;
+  AVT_REQUIRE(a.To > 0 && a.Ho > 0 && a.Wo > 0 && batch > 0, "avt_conv3d_igemm_bf16: empty output");
+  a.Cout = cout;
+  a.K = kt * kh * kw * cin;
+  a.KT = kt;
+  a.KH = kh;
+  a.KW = kw;
+  a.st = st;
+  a.sh = sh;
+  a.sw = sw;
+  a.pt = pt;
+  a.ph = ph;
+  a.pw = pw;
+  a.ldi = ldi;
+  a.ldo = ldo;
+  a.ldr = ldr;
+  a.relu = relu;
+  const int64_t M = (int64_t)batch * a.To * a.Ho * a.Wo;
+  AVT_REQUIRE(M < (1ll << 31) && (int64_t)batch * t * h * w * ldi < (1ll << 31) && M * (int64_t)ldo < (1ll << 62),
+              "avt_conv3d_igemm_bf16: tensor too large for 32-bit element offsets");
+  a.M = (int)M;
+  a.nk = (a.K + BK - 1) / BK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (cout <= 32) return launch<256, 32>(a, s);
+  if (cout <= 64) return launch<256, 64>(a, s);
+  return launch<128, 128>(a, s);
+}

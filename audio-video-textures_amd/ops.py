@@ -181,3 +181,24 @@ def softmax_ce_bwd(prob, label=None, scale=1.0):
     _lib.check(_lib.lib().avt_softmax_ce_bwd(_p(prob), _p(label), b, c, float(scale), _p(d), _stream()),
                "avt_softmax_ce_bwd")
     return d
+
+
+# ---- encoder convolutions (implicit GEMM on MFMA) ----------------------------------------
+def conv3d_ktab(cin, kernel, h, w, ldi):
+    """Host table of per-K-chunk tap offsets for avt_conv3d_igemm_bf16 (int32 [n_entries, 2])."""
+    kt, kh, kw = kernel
+    n_entries = 8 * ((kt * kh * kw * cin + 63) // 64)
+    tab = np.empty((n_entries, 2), np.int32)
+    _lib.check(_lib.lib().avt_conv3d_ktab(int(cin), kt, kh, kw, int(h), int(w), int(ldi), tab.ctypes.data, n_entries),
+               "avt_conv3d_ktab")
+    return tab
+
+
+def conv3d_igemm(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu):
+    """Raw launch: x_ptr/res_ptr/out_ptr are device addresses (int) of bf16 NDHWC rows; dims = (B,T,H,W)."""
+    b, t, h, w = dims
+    _lib.check(_lib.lib().avt_conv3d_igemm_bf16(C.c_void_p(x_ptr), _p(wt), _p(bias),
+                                                C.c_void_p(res_ptr) if res_ptr else None, C.c_void_p(out_ptr), _p(ktab),
+                                                b, t, h, w, int(cin), int(cout), *kernel, *stride, *pad, int(ldi),
+                                                int(ldo), int(ldr), 1 if relu else 0, _stream()),
+               "avt_conv3d_igemm_bf16")

@@ -75,6 +75,7 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode, as the reference sets it (main.py:421): 1.9x on SlowFast
     ops.device_check()
     W, S, N, D, temp = 20, 4, args.windows, 2304, 0.1
     n_total = N * world

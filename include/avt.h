@@ -167,6 +167,27 @@ int avt_softmax_ce_fwd(const float* logits, int64_t b, int64_t c,
 int avt_softmax_ce_bwd(const float* prob, const int64_t* label, int64_t b,
                        int64_t c, float scale, float* dlogits, void* stream);
 
+/* ------------------------------------------------------------------------
+ * conv3d_igemm_bf16 — the encoder's convolutions on the matrix cores.  Replaces the
+ *   Conv3d + BatchNorm3d + ReLU (+ residual add, + lateral-fusion concat) sequence the
+ *   reference executes through the third-party SlowFast model for every clip window
+ *   (models.py:335, :399; architecture: SURVEY.md Appendix A).
+ *   Activations are NDHWC (channels-last-3d) bf16 rows of `ld*` elements; weights are
+ *   BN-folded, packed [cout, kt*kh*kw*cin] bf16 with cin innermost; bias fp32 [cout] or NULL.
+ *   out[m, 0:cout] = act(conv(in)[m] + bias (+ res[m, 0:cout])), act = ReLU when relu != 0.
+ *   `out`/`res` may point INTO a wider row (channel slice of a concat buffer) via ldo/ldr.
+ *   cin, cout, ld* multiples of 8; at most 32 taps.  ktab comes from avt_conv3d_ktab
+ *   (HOST; 2*n_entries int32, n_entries = 8*ceil(kt*kh*kw*cin/64)), copied to the device.
+ * ---------------------------------------------------------------------- */
+int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, int ldi,
+                    int32_t* ktab, int n_entries);
+int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float* bias,
+                          const void* res, void* out, const int32_t* ktab,
+                          int batch, int t, int h, int w, int cin, int cout,
+                          int kt, int kh, int kw, int st, int sh, int sw,
+                          int pt, int ph, int pw, int ldi, int ldo, int ldr,
+                          int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

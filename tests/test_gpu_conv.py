@@ -1,0 +1,104 @@
+"""MFMA implicit-GEMM convolution (csrc/conv_igemm.hip) and the fused SlowFast runner vs plain PyTorch fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(avt, dev, cin, cout, k, s, p, dims, relu, with_res, ld_extra=0):
+    from avtex.fused_slowfast import Act, FusedConv
+
+    torch.manual_seed(cin * 131 + cout)
+    conv = nn.Conv3d(cin, cout, k, stride=s, padding=p, bias=False)
+    bn = nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    b, t, h, w = dims
+    x = torch.randn(b, cin, t, h, w)
+    xb = x.to(torch.bfloat16)
+    fc = FusedConv(conv, bn, relu, dev)
+    m_in = b * t * h * w
+    buf = torch.zeros((m_in, cin + ld_extra), dtype=torch.bfloat16, device=dev)
+    buf[:, :cin] = xb.permute(0, 2, 3, 4, 1).reshape(m_in, cin).to(dev)
+    od = fc.out_dims(dims)
+    m_out = od[0] * od[1] * od[2] * od[3]
+    res = None
+    ref = bn(conv(xb.float()))
+    if with_res:
+        r = torch.randn(m_out, cout).to(torch.bfloat16)
+        res = Act(r.to(dev), od)
+        ref = ref + r.float().view(od[0], od[1], od[2], od[3], cout).permute(0, 4, 1, 2, 3)
+    if relu:
+        ref = F.relu(ref)
+    out = fc(Act(buf, dims, 0, cin), res=res)
+    torch.cuda.synchronize()
+    got = out.buf.float().cpu().view(od[0], od[1], od[2], od[3], cout).permute(0, 4, 1, 2, 3)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    return err, scale
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,dims", [
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 14, 14)),      # bottleneck b
+    (128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 3, 14, 14)),    # strided b
+    (80, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 7, 9)),        # a, Cin = 80 (after fusion), ragged M
+    (256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 4, 8, 8)),      # strided shortcut
+    (320, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 8, 5, 5)),      # temporal a
+    (8, 16, (7, 1, 1), (4, 1, 1), (3, 0, 0), (2, 32, 6, 6)),        # lateral fusion conv, Cout = 16
+    (8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 8, 12, 12)),        # fast pathway, 8 channels
+    (32, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 16, 6, 6)),
+    (512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 7, 7)),
+])
+@pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
+def test_conv_igemm_matches_torch(avt, dev, cin, cout, k, s, p, dims, relu, with_res):
+    err, scale = _run(avt, dev, cin, cout, k, s, p, dims, relu, with_res)
+    # bf16 inputs/weights/outputs, fp32 accumulate: error budget = bf16 rounding of weights (2^-9 rel per term,
+    # random signs) + output rounding (2^-9 of the value)
+    assert err < 0.02 * max(scale, 1.0), (err, scale)
+
+
+def test_conv_writes_channel_slice(avt, dev):
+    from avtex.fused_slowfast import Act, FusedConv
+
+    torch.manual_seed(0)
+    conv = nn.Conv3d(16, 32, (1, 1, 1), bias=False)
+    fc = FusedConv(conv, None, False, dev)
+    x = torch.randn(50, 16).to(torch.bfloat16).to(dev)
+    wide = torch.full((50, 96), 7.0, dtype=torch.bfloat16, device=dev)
+    fc(Act(x, (1, 2, 5, 5)), out=Act(wide, (1, 2, 5, 5), 40, 32))
+    torch.cuda.synchronize()
+    ref = x.float().cpu() @ conv.weight.detach().view(32, 16).to(torch.bfloat16).float().t()
+    assert (wide[:, 40:72].float().cpu() - ref).abs().max() < 0.05
+    assert (wide[:, :40] == 7).all() and (wide[:, 72:] == 7).all()  # neighbours untouched
+
+
+def test_fused_slowfast_matches_module(avt, dev):
+    """Whole encoder: MFMA runner vs the PyTorch module in fp32 on the same (randomised) weights."""
+    from avtex.fused_slowfast import SlowFastMFMA
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(3)
+    m = SlowFast().eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm3d):
+                mod.weight.uniform_(0.6, 1.2); mod.bias.uniform_(-0.1, 0.1)
+                mod.running_mean.uniform_(-0.1, 0.1); mod.running_var.uniform_(0.8, 1.2)
+    slow, fast = torch.randn(2, 3, 8, 224, 224), torch.randn(2, 3, 32, 224, 224)
+    fused = SlowFastMFMA(m, dev)
+    y = fused([slow.to(dev), fast.to(dev)]).cpu()
+    with torch.no_grad():
+        ref = m.to(dev).float()([slow.to(dev), fast.to(dev)]).cpu()
+        ref16 = m.to(torch.bfloat16)([slow.to(dev, torch.bfloat16), fast.to(dev, torch.bfloat16)]).float().cpu()
+    cos = F.cosine_similarity(y, ref, dim=1)
+    cos16 = F.cosine_similarity(ref16, ref, dim=1)
+    rel = ((y - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
+    rel16 = ((ref16 - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
+    print("fused vs fp32: cos", cos.tolist(), "rel", rel, "| torch bf16 vs fp32: cos", cos16.tolist(), "rel", rel16)
+    assert y.shape == (2, 2304) and torch.isfinite(y).all()
+    assert cos.min() > 0.999 and rel < max(2.5 * rel16, 0.02)

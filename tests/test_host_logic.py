@@ -1,0 +1,114 @@
+"""Host-side logic of the product package against the oracle restatement and the reference-made fixtures."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_py
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_compat_window_map_equals_oracle_and_reference(avt):
+    from avtex.texture import compat_window_frames
+
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        W, S, mbs, G = int(rng.integers(4, 24)), int(rng.integers(1, 8)), int(rng.integers(2, 40)), int(rng.integers(1, 4))
+        F_ = int(rng.integers(W + 3 * S + 2, 260))
+        L = ref_py.num_segments(F_, W, S)
+        if L < 3:
+            continue
+        q = int(rng.integers(0, L))
+        a, sa = ref_py.compat_window_frames(q, F_, W, S, mbs, G)
+        b, sb = compat_window_frames(q, F_, W, S, mbs, G)
+        assert np.array_equal(a, b) and np.array_equal(sa, sb)
+    for case in ("sf_th03", "sf_g2"):  # and against the windows the reference's encoder really received
+        g = np.load(os.path.join(GOLD, "g5_validate_%s.npz" % case), allow_pickle=True)
+        n_frames, W, S, mbs, G = [int(x) for x in g["cfg"][:5]]
+        for step, q in enumerate(g["queries"]):
+            wins, _ = compat_window_frames(int(q), n_frames, W, S, mbs, G)
+            assert np.array_equal(g["window_frames"][step][1 : 1 + len(wins)], wins)
+
+
+def test_split_helpers_match_reference_vectors(avt):
+    g = np.load(os.path.join(GOLD, "g1_split.npz"))
+    for i in range(5):
+        n, mbs, W, S = [int(x) for x in g["ov%d_args" % i]]
+        out, nv = avt.utils.split_into_overlapping_segments(torch.arange(1, n + 1).float().view(n, 1), mbs, W, S)
+        assert np.array_equal(out.numpy()[..., 0], g["ov%d_out" % i]) and nv == g["ov%d_nvalid" % i]
+    for i in range(4):
+        n, mbs = [int(x) for x in g["sb%d_args" % i]]
+        out, nv = avt.utils.split_into_batches(torch.arange(1, n + 1).float().view(1, n, 1), mbs)
+        assert np.array_equal(out.numpy()[..., 0], g["sb%d_out" % i]) and nv == g["sb%d_nvalid" % i]
+        assert avt.utils.combine_batches(out, nv).shape == (1, n, 1)
+
+
+def test_dataset_negative_sampling_matches_reference(avt):
+    """[A14] dataset.py:183-190 incl. its duplicate-prone hard negatives, under the same NumPy seeds."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.gen_golden import make_video
+
+    g = np.load(os.path.join(GOLD, "g9_dataset.npz"))
+    args = SimpleNamespace(vdata="/tmp", adata=None, n_negs=10, img_size=16, enc_arch="slowfast", window=0, stride=0)
+    torch.manual_seed(5)
+    ds = avt.AudioVideoSegments(args, "g9", split="train", video=(make_video(3, 150, 16, 16), 20.0))
+    assert len(ds) == int(g["len"]) and [args.window, args.stride] == list(g["window_stride"])
+    for key in g.files:
+        if not key.startswith("idx"):
+            continue
+        idx = int(key[3:])
+        np.random.seed(100 + idx)
+        pos, neg = ds.sample_ids(idx)
+        assert [pos] + [int(x) for x in neg] == [int(x) for x in g[key]]
+    np.random.seed(101)
+    item = ds[1]
+    assert len(item) == 6 and item[0][0].shape == (3, 8, 16, 16) and item[3][1].shape == (11, 3, 32, 16, 16)
+
+
+def test_classic_baseline_matches_reference(avt):
+    """Config 1 (CPU plumbing): D1/P1/D2 of baselines/classic_video_textures vs G8."""
+    g = np.load(os.path.join(GOLD, "g8_classic.npz"))
+    d1, p1, s1 = avt.classic.compute_D1(g["frames"], 0.1, batch_size=7)
+    np.testing.assert_allclose(d1.numpy(), g["d1"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(p1.numpy(), g["p1"], rtol=1e-4, atol=1e-7)
+    d2, p2, s2, _ = avt.classic.compute_D2(torch.from_numpy(g["d1"]), 0.1, filter_size=4)
+    np.testing.assert_allclose(d2.numpy(), g["d2"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(p2.numpy(), g["p2"], rtol=1e-4, atol=1e-7)
+    d3, p3, p3n, _ = avt.classic.q_learning(d2, 0.1)
+    assert torch.isfinite(p3).all() and (p3n.sum(1) > 0).all()
+    seq = avt.classic.random_walk(p3n.numpy(), 30, rng=np.random.RandomState(0))
+    assert len(seq) == 30 and max(seq) < p3n.shape[0]
+
+
+def test_classic_config1_full_size_runs_on_cpu(avt):
+    """BASELINE config 1: 200-frame 128x128 clip, raw-pixel L2 transition matrix, CPU only."""
+    g = torch.Generator().manual_seed(7)
+    frames = torch.randint(0, 256, (200, 128, 128, 3), generator=g, dtype=torch.uint8)
+    d1, p1, sigma = avt.classic.compute_D1(frames, 0.1, batch_size=48)
+    assert d1.shape == (200, 200) and torch.allclose(p1.sum(1), torch.ones(200), atol=1e-5)
+    assert torch.allclose(d1, d1.t(), atol=1e-2) and (torch.diag(d1) == 0).all()
+
+
+def test_cli_flags_match_reference(avt):
+    p = avt.main.build_parser() if hasattr(avt, "main") else __import__("avtex.main", fromlist=["x"]).build_parser()
+    a = p.parse_args(["-vdata", "v", "-ea", "slowfast", "-w", "20", "-stride", "4", "-temp", "0.1", "-th", "0.3", "-bs",
+                      "24", "-e", "-mbs", "100", "-m", "2", "-alpha", "0.5", "-negs", "20", "-nintp"])
+    assert (a.enc_arch, a.window, a.stride, a.threshold, a.mini_batchsize, a.evaluate) == ("slowfast", 20, 4, 0.3, 100, True)
+    assert a.interpolation is False and a.model_type == 2 and a.stitch_mode == "compat" and a.vcam is False
+
+
+def test_checkpoint_keys_are_the_reference_prefixes(avt):
+    from avtex.slowfast import SlowFast
+
+    m = avt.ContrastivePredictionTemporal(SlowFast(), SlowFast(), avt.VGGish(), 2, 128, enc_arch="slowfast")
+    keys = list(m.state_dict().keys())
+    for pre in ("q_encoder.", "t_encoder.", "q_a_encoder.", "t_a_encoder.", "q_a_mlp.", "t_a_mlp."):
+        assert any(k.startswith(pre) for k in keys), pre
+    assert "q_encoder.s1.pathway0_stem.conv.weight" in keys and "t_encoder.s5.pathway1_res2.branch2.c_bn.weight" in keys
+    assert "q_encoder.s1_fuse.conv_f2s.weight" in keys
+    net, fc_dim = avt.ModelBuilder3D.build_network("resnet18", img_size=32, window=16, pretrained=False)
+    assert fc_dim == 128 and net.eval()(torch.zeros(1, 3, 16, 32, 32)).shape[:2] == (1, 512)
