@@ -130,6 +130,66 @@ __global__ __launch_bounds__(256) void clip_pack_kernel(PArgs a) {
   }
 }
 
+// Channels-last variant for the MFMA stem: slow [n,8,hw,hw,4], fast [n,32,hw,hw,4] bf16 (NDHWC, C padded
+// 3 -> 4 with a zero).  A workgroup resizes a strip of one source frame for all three channels; each lane owns
+// 4 consecutive output pixels = 32 contiguous bytes per destination.
+__global__ __launch_bounds__(256) void clip_pack_nhwc4_kernel(PArgs a) {
+  __shared__ float lut[256];
+  lut[threadIdx.x] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)threadIdx.x, 255.0f), a.mean), a.std);
+  __syncthreads();
+  const int tile = blockIdx.x % a.tiles;
+  const int f = blockIdx.x / a.tiles;
+  const int e0 = a.dst_off[f], e1 = a.dst_off[f + 1];
+  if (e0 == e1) return;
+  const int tid = threadIdx.x;
+  const int ry = tid / a.cpr, cx = tid - ry * a.cpr;
+  const int y = tile * a.rpb + ry;
+  if (ry >= a.rpb || y >= a.hw) return;
+  const int x0 = cx * 4;
+  int y0, y1;
+  float ly;
+  src_index(a.scale_h, y, a.H, y0, y1, ly);
+  const float hy = 1.0f - ly;
+  const uint8_t* r0 = a.frames + ((int64_t)f * a.H + y0) * a.W * 3;
+  const uint8_t* r1 = a.frames + ((int64_t)f * a.H + y1) * a.W * 3;
+  uint16_t v[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int x = x0 + j;
+    int xa = 0, xb = 0;
+    float lx = 0.0f;
+    if (x < a.hw) src_index(a.scale_w, x, a.W, xa, xb, lx);
+    const float hx = 1.0f - lx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int sc = a.bgr ? 2 - c : c;
+      const float p00 = lut[r0[xa * 3 + sc]], p01 = lut[r0[xb * 3 + sc]];
+      const float p10 = lut[r1[xa * 3 + sc]], p11 = lut[r1[xb * 3 + sc]];
+      const float o = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
+      v[j * 4 + c] = (x < a.hw) ? avt::f32_to_bf16_rne(o) : (uint16_t)0;
+    }
+    v[j * 4 + 3] = 0;
+  }
+  const int64_t plane = (int64_t)a.hw * a.hw * 4;
+  const int64_t inplane = ((int64_t)y * a.hw + x0) * 4;
+  const bool full = x0 + 4 <= a.hw;
+  for (int e = e0; e < e1; ++e) {
+    const int ds = a.dst_slot[e];
+    const int n = ds / AVT_SLOTS, slot = ds - n * AVT_SLOTS;
+    uint16_t* dst = slot < AVT_SLOW_T
+                        ? static_cast<uint16_t*>(a.slow) + ((int64_t)n * AVT_SLOW_T + slot) * plane
+                        : static_cast<uint16_t*>(a.fast) + ((int64_t)n * AVT_FAST_T + (slot - AVT_SLOW_T)) * plane;
+    dst += inplane;
+    if (full) {
+      reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(v)[0];
+      reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(v)[1];
+    } else {
+      for (int j = 0; j < 16; ++j)
+        if (x0 + j / 4 < a.hw) dst[j] = v[j];
+    }
+  }
+}
+
 // torch.linspace(start=0, end, steps) in fp32 (ATen RangeFactories: symmetric halves), then .long()
 void linspace_long(float end, int steps, int32_t* out) {
   if (steps == 1) {
@@ -226,4 +286,37 @@ extern "C" int avt_clip_pack_u8(const uint8_t* frames, int n_frames, int height,
       hipLaunchKernelGGL((clip_pack_kernel<float, false>), grid, block, 0, st, a);
   }
   return avt::check_launch("avt_clip_pack_u8");
+}
+
+extern "C" int avt_clip_pack_u8_ndhwc4(const uint8_t* frames, int n_frames, int height, int width,
+                                       const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw, float mean,
+                                       float std, int bgr, void* slow, void* fast, void* stream) {
+  AVT_REQUIRE(frames && dst_off && dst_slot && slow && fast, "avt_clip_pack_u8_ndhwc4: NULL pointer");
+  AVT_REQUIRE(n_frames > 0 && height > 0 && width > 0 && out_hw > 0 && n_win >= 0, "avt_clip_pack_u8_ndhwc4: bad sizes");
+  AVT_REQUIRE(out_hw <= 1020 && out_hw % 2 == 0, "avt_clip_pack_u8_ndhwc4: out_hw must be even and <= 1020");
+  AVT_REQUIRE(std != 0.0f, "avt_clip_pack_u8_ndhwc4: std == 0");
+  AVT_REQUIRE(avt::aligned16(slow) && avt::aligned16(fast), "avt_clip_pack_u8_ndhwc4: outputs must be 16-byte aligned");
+  if (n_win == 0) return AVT_OK;
+  PArgs a;
+  a.frames = frames;
+  a.n_frames = n_frames;
+  a.H = height;
+  a.W = width;
+  a.dst_off = dst_off;
+  a.dst_slot = dst_slot;
+  a.hw = out_hw;
+  a.mean = mean;
+  a.std = std;
+  a.bgr = bgr;
+  a.slow = slow;
+  a.fast = fast;
+  a.cpr = (out_hw + 3) / 4;
+  a.rpb = 256 / a.cpr;
+  a.tiles = (out_hw + a.rpb - 1) / a.rpb;
+  a.scale_h = (float)height / (float)out_hw;
+  a.scale_w = (float)width / (float)out_hw;
+  const int64_t nblk = (int64_t)a.tiles * n_frames;
+  AVT_REQUIRE(nblk < (1ll << 31), "avt_clip_pack_u8_ndhwc4: grid too large");
+  hipLaunchKernelGGL(clip_pack_nhwc4_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return avt::check_launch("avt_clip_pack_u8_ndhwc4");
 }

@@ -38,7 +38,7 @@ struct ConvArgs {
   const float* bias;
   const uint16_t* res;
   uint16_t* out;
-  const int2* ktab;  // [nk*8] {element offset of the chunk's tap+channel relative to the row base, tap id or -1}
+  const int2* ktab;  // [nk*8] {element offset of the chunk's tap+channel relative to the row base, tap bits or -1}
   int T, H, W;       // input extent
   int To, Ho, Wo;
   int Cout, K;
@@ -90,15 +90,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       int b = t2 / a.To;
       const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
       rowoff[u] = (((b * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.ldi;
+      // in-bounds taps are separable: bits 0-7 = dt, 8-15 = dh, 16-23 = dw
       unsigned mask = 0u;
-      int tap = 0;
-      for (int dt = 0; dt < a.KT; ++dt)
-        for (int dh = 0; dh < a.KH; ++dh)
-          for (int dw = 0; dw < a.KW; ++dw, ++tap) {
-            const bool ok = (unsigned)(ti0 + dt) < (unsigned)a.T && (unsigned)(hi0 + dh) < (unsigned)a.H &&
-                            (unsigned)(wi0 + dw) < (unsigned)a.W;
-            mask |= (ok ? 1u : 0u) << tap;
-          }
+      for (int dt = 0; dt < a.KT; ++dt) mask |= ((unsigned)(ti0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
+      for (int dh = 0; dh < a.KH; ++dh) mask |= ((unsigned)(hi0 + dh) < (unsigned)a.H ? 1u : 0u) << (8 + dh);
+      for (int dw = 0; dw < a.KW; ++dw) mask |= ((unsigned)(wi0 + dw) < (unsigned)a.W ? 1u : 0u) << (16 + dw);
       rowmask[u] = mask;
     }
   }
@@ -120,11 +116,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   uint4 ra[AU], rb[BU];
   auto gload = [&](int kt) {
-    const int2 e = a.ktab[kt * 8 + c16];  // {offset, tap}
+    const int2 e = a.ktab[kt * 8 + c16];  // {offset, tap bits: 1<<dt | 1<<(8+dh) | 1<<(16+dw)} or {0, -1}
     const bool kin = e.y >= 0;
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
-      const bool ok = kin && ((rowmask[u] >> (e.y & 31)) & 1u);
+      const bool ok = kin && ((rowmask[u] & (unsigned)e.y) == (unsigned)e.y);
       ra[u] = ok ? *reinterpret_cast<const uint4*>(a.in + (rowoff[u] + e.x)) : make_uint4(0u, 0u, 0u, 0u);
     }
     const int kc = (kt * 8 + c16) * 8;
@@ -243,7 +239,7 @@ int launch(ConvArgs& a, hipStream_t st) {
 
 extern "C" int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, int ldi, int32_t* ktab, int n_entries) {
   AVT_REQUIRE(ktab && cin > 0 && cin % 8 == 0, "avt_conv3d_ktab: Cin must be a positive multiple of 8");
-  AVT_REQUIRE(kt * kh * kw <= 32 && kt > 0 && kh > 0 && kw > 0, "avt_conv3d_ktab: at most 32 taps");
+  AVT_REQUIRE(kt > 0 && kh > 0 && kw > 0 && kt <= 8 && kh <= 8 && kw <= 8, "avt_conv3d_ktab: kernel extents must be 1..8");
   const int K = kt * kh * kw * cin;
   const int nk = (K + BK - 1) / BK;
   AVT_REQUIRE(n_entries == nk * 8, "avt_conv3d_ktab: n_entries must be %d", nk * 8);
@@ -253,7 +249,7 @@ extern "C" int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, in
       const int tap = kc / cpt, c8 = kc % cpt;
       const int dt = tap / (kh * kw), dh = (tap / kw) % kh, dw = tap % kw;
       ktab[2 * kc] = ((dt * h + dh) * w + dw) * ldi + c8 * 8;
-      ktab[2 * kc + 1] = tap;
+      ktab[2 * kc + 1] = (1 << dt) | (1 << (8 + dh)) | (1 << (16 + dw));
     } else {
       ktab[2 * kc] = 0;
       ktab[2 * kc + 1] = -1;
@@ -264,11 +260,11 @@ extern "C" int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, in
 
 extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float* bias, const void* res, void* out,
                                      const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
-                                     int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo,
-                                     int ldr, int relu, void* stream) {
+                                     int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho,
+                                     int wo, int ldi, int ldo, int ldr, int relu, void* stream) {
   AVT_REQUIRE(in && wt && out && ktab, "avt_conv3d_igemm_bf16: NULL pointer");
   AVT_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 8 == 0, "avt_conv3d_igemm_bf16: Cin/Cout must be multiples of 8");
-  AVT_REQUIRE(kt * kh * kw <= 32, "avt_conv3d_igemm_bf16: at most 32 taps");
+  AVT_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && kt <= 8 && kh <= 8 && kw <= 8, "avt_conv3d_igemm_bf16: kernel extents must be 1..8");
   AVT_REQUIRE(ldi % 8 == 0 && ldo % 8 == 0 && (!res || ldr % 8 == 0) && ldi >= cin && ldo >= cout,
               "avt_conv3d_igemm_bf16: leading dimensions must be multiples of 8 and cover the channels");
   AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(wt) && avt::aligned16(out) && (!res || avt::aligned16(res)) &&
@@ -284,10 +280,14 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   a.T = t;
   a.H = h;
   a.W = w;
-  a.To = (t + 2 * pt - kt) / st + 1;
-  a.Ho = (h + 2 * ph - kh) / sh + 1;
-  a.Wo = (w + 2 * pw - kw) / sw + 1;
-  AVT_REQUIRE(a.To > 0 && a.Ho > 0 && a.Wo > 0 && batch > 0, "avt_conv3d_igemm_bf16: empty output");
+  // output extent: 0 = the symmetric-padding formula; a smaller explicit extent crops the far edge
+  // (used by the stem, whose pixel-pair form needs padding 2 on the left and 1 on the right)
+  const int fto = (t + 2 * pt - kt) / st + 1, fho = (h + 2 * ph - kh) / sh + 1, fwo = (w + 2 * pw - kw) / sw + 1;
+  a.To = to > 0 ? to : fto;
+  a.Ho = ho > 0 ? ho : fho;
+  a.Wo = wo > 0 ? wo : fwo;
+  AVT_REQUIRE(a.To > 0 && a.Ho > 0 && a.Wo > 0 && batch > 0 && a.To <= fto && a.Ho <= fho && a.Wo <= fwo,
+              "avt_conv3d_igemm_bf16: bad output extent %dx%dx%d (max %dx%dx%d)", a.To, a.Ho, a.Wo, fto, fho, fwo);
   a.Cout = cout;
   a.K = kt * kh * kw * cin;
   a.KT = kt;

@@ -1,0 +1,70 @@
+// maxpool_hw3s2 — MaxPool3d((1,3,3), stride (1,2,2), padding (0,1,1)) on NDHWC bf16 rows, for the SlowFast
+// stems (the reference reaches it through the third-party SlowFast model,
+// contrastive_video_textures/models/models.py:335, 399).  HBM-bound: each thread owns 8 channels (16 bytes) of
+// one output position, reads its <= 9 taps with 16-byte loads and writes one 16-byte chunk — optionally into a
+// channel slice of a wider row buffer (ldo), which is how the slow stem lands in the lateral-fusion concat.
+#include "avt_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) {
+  const float a0 = avt::bf16_bits_to_f32((uint16_t)(a & 0xffffu)), a1 = avt::bf16_bits_to_f32((uint16_t)(a >> 16));
+  const float b0 = avt::bf16_bits_to_f32((uint16_t)(b & 0xffffu)), b1 = avt::bf16_bits_to_f32((uint16_t)(b >> 16));
+  const uint32_t lo = (b0 > a0) ? (b & 0xffffu) : (a & 0xffffu);
+  const uint32_t hi = (b1 > a1) ? (b >> 16) : (a >> 16);
+  return lo | (hi << 16);
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                       int bt, int H, int W, int C, int ldi, int ldo, int Ho, int Wo) {
+  const int cpr = C >> 3;
+  const int64_t total = (int64_t)bt * Ho * Wo * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    int64_t p = i / cpr;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    uint4 m;
+    bool first = true;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hi = 2 * ho - 1 + dh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wi = 2 * wo - 1 + dw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(in + (((int64_t)b * H + hi) * W + wi) * ldi + cc * 8);
+        if (first) {
+          m = v;
+          first = false;
+        } else {
+          m.x = max2(m.x, v.x);
+          m.y = max2(m.y, v.y);
+          m.z = max2(m.z, v.z);
+          m.w = max2(m.w, v.w);
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(out + (((int64_t)b * Ho + ho) * Wo + wo) * ldo + cc * 8) = m;
+  }
+}
+
+}  // namespace
+
+extern "C" int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w, int c, int ldi, int ldo,
+                                            void* stream) {
+  AVT_REQUIRE(in && out, "avt_maxpool_hw3s2_ndhwc_bf16: NULL pointer");
+  AVT_REQUIRE(bt > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldi >= c && ldo >= c,
+              "avt_maxpool_hw3s2_ndhwc_bf16: channels / leading dimensions must be multiples of 8");
+  AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(out), "avt_maxpool_hw3s2_ndhwc_bf16: pointers must be 16-byte aligned");
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)bt * ho * wo * (c / 8);
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), bt, h, w, c, ldi, ldo, ho, wo);
+  return avt::check_launch("avt_maxpool_hw3s2_ndhwc_bf16");
+}

@@ -4,9 +4,15 @@ Takes a `slowfast.SlowFast` module (the plugin the reference would get from Mode
 folds every BatchNorm into its convolution, repacks the weights [Cout, taps*Cin] in bf16, and runs the residual
 stages and lateral fusions as implicit-GEMM launches on NDHWC (channels-last-3d) bf16 activations:
 conv + BN + ReLU (+ residual add) is ONE kernel, and the fusion concat is a channel-slice write, so each
-activation tensor crosses HBM once per consumer.  The two stem convolutions (Cin = 3, 49 / 245 taps) and their
-max-pools still go through MIOpen (6.6 % of the FLOPs).  Same contract as the module it wraps:
-    forward([slow [B,3,8,H,W], fast [B,3,32,H,W]]) -> [B, 2304] (fp32).
+activation tensor crosses HBM once per consumer.
+
+The stems (Cin = 3, kernel [kt,7,7], stride [1,2,2]) run on the same kernel through a PIXEL-PAIR view: the
+channels-last clip [T,H,W,4] (3 channels + a zero, as ops.clip_pack(layout="ndhwc4") writes it) is read as
+[T,H,W/2,8] — two pixels x four channels = one 16-byte chunk — which turns the stride-2, 7-wide kernel into a
+stride-1, 4-pair-wide one (columns 2wo-4 .. 2wo+3, the first with zero weight).  The stem max-pool is a small
+HBM-bound kernel writing straight into the first fusion's concat buffer.  Same contract as the module it wraps:
+    forward([slow [B,3,8,H,W], fast [B,3,32,H,W]]) -> [B, 2304] (fp32);
+`forward_ndhwc4` takes the channels-last clips directly (no layout copy).
 """
 import torch
 import torch.nn as nn
@@ -33,28 +39,43 @@ class Act:
         return self.buf.shape[1]
 
 
+def fold_bn(conv, bn):
+    """-> (weight [Cout,Cin,kt,kh,kw] fp32 with the BN scale folded in, bias [Cout] fp32)."""
+    w = conv.weight.detach().float()
+    if bn is not None:
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        bias = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+        w = w * scale.view(-1, 1, 1, 1, 1)
+    else:
+        bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0])
+    return w, bias
+
+
 class FusedConv:
-    def __init__(self, conv, bn, relu, device):
-        w = conv.weight.detach().float()
-        cout = w.shape[0]
-        if bn is not None:
-            scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
-            bias = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
-            w = w * scale.view(-1, 1, 1, 1, 1)
+    def __init__(self, conv, bn, relu, device, packed=None):
+        """packed = (wt [Cout, taps*Cin] fp32, bias, cin, kernel, stride, pad, crop) overrides the module."""
+        self.crop = (0, 0, 0)
+        if packed is None:
+            w, bias = fold_bn(conv, bn)
+            self.kernel, self.stride, self.pad = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
+            self.cin, cout = w.shape[1], w.shape[0]
+            wt = w.permute(0, 2, 3, 4, 1).reshape(cout, -1)
         else:
-            bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(cout)
-        self.kernel, self.stride, self.pad = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
-        self.cin, self.cout, self.relu = w.shape[1], cout, relu
-        if self.cin % 8 or cout % 8:
-            raise AvtError("FusedConv: channels must be multiples of 8 (got %d -> %d)" % (self.cin, cout))
-        self.wt = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).to(torch.bfloat16).contiguous().to(device)
-        self.bias = bias.contiguous().to(device)
+            wt, bias, self.cin, self.kernel, self.stride, self.pad, self.crop = packed
+            cout = wt.shape[0]
+        self.cout, self.relu = cout, relu
+        if self.cin % 8:
+            raise AvtError("FusedConv: input channels must be a multiple of 8 (got %d)" % self.cin)
+        if cout % 8:  # pad the output channels with zero filters (the caller's buffer must be that wide)
+            raise AvtError("FusedConv: output channels must be a multiple of 8 (got %d)" % cout)
+        self.wt = wt.to(torch.bfloat16).contiguous().to(device)
+        self.bias = bias.float().contiguous().to(device)
         self.dev = device
         self._tabs = {}
 
     def out_dims(self, dims):
         b, t, h, w = dims
-        o = [(n + 2 * p - k) // s + 1 for n, p, k, s in zip((t, h, w), self.pad, self.kernel, self.stride)]
+        o = [(n + 2 * p - k) // s + 1 - c for n, p, k, s, c in zip((t, h, w), self.pad, self.kernel, self.stride, self.crop)]
         return (b, o[0], o[1], o[2])
 
     def __call__(self, x, out=None, res=None, relu=None):
@@ -71,8 +92,24 @@ class FusedConv:
             out = Act(torch.empty((m, self.cout), dtype=torch.bfloat16, device=self.dev), od)
         ops.conv3d_igemm(x.ptr, self.wt, self.bias, res.ptr if res is not None else 0, out.ptr, tab, x.dims, self.cin,
                          self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld, res.ld if res is not None else 0,
-                         self.relu if relu is None else relu)
+                         self.relu if relu is None else relu, out_dims=od[1:] if any(self.crop) else (0, 0, 0))
         return out
+
+
+def stem_conv(stem, device):
+    """Stem Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU in pixel-pair form (see module doc)."""
+    w, bias = fold_bn(stem.conv, stem.bn)  # [C, 3, kt, 7, 7]
+    c, _, kt, kh, kw = w.shape
+    if (kh, kw) != (7, 7) or tuple(stem.conv.stride) != (1, 2, 2) or tuple(stem.conv.padding) != (kt // 2, 3, 3):
+        raise AvtError("stem_conv: expected a [kt,7,7] stride-[1,2,2] stem")
+    wp = torch.zeros((c, kt, kh, 4, 2, 4))  # [n, dt, dh, pair, pixel-in-pair, channel(4)]
+    for dwp in range(4):
+        for p in range(2):
+            k = 2 * dwp + p - 1  # original column tap: column = 2wo - 4 + 2*dwp + p = 2wo - 3 + k
+            if 0 <= k < kw:
+                wp[:, :, :, dwp, p, :3] = w[:, :, :, :, k].permute(0, 2, 3, 1)
+    return FusedConv(None, None, True, device,
+                     packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)))
 
 
 class _Block:
@@ -93,12 +130,15 @@ class SlowFastMFMA(nn.Module):
 
     out_dim = 2304
 
-    def __init__(self, model, device, stem_dtype=torch.bfloat16):
+    input_layout = "ndhwc4"  # what ops.clip_pack should emit for forward_ndhwc4
+
+    def __init__(self, model, device):
         super().__init__()
         self.dev = torch.device(device)
         model = model.eval()
-        self.stem = model.s1.to(self.dev, stem_dtype)  # MIOpen (Cin = 3)
-        self.stem_dtype = stem_dtype
+        self.stem_s = stem_conv(model.s1.pathway0_stem, self.dev)
+        self.stem_f = stem_conv(model.s1.pathway1_stem, self.dev)
+        self._anchor = nn.Parameter(torch.zeros(1, dtype=torch.bfloat16, device=self.dev), requires_grad=False)
         self.fuse = [FusedConv(f.conv_f2s, f.bn, True, self.dev) for f in (model.s1_fuse, model.s2_fuse, model.s3_fuse,
                                                                             model.s4_fuse)]
         self.stages = []
@@ -106,22 +146,39 @@ class SlowFastMFMA(nn.Module):
             self.stages.append([[_Block(getattr(s, "pathway%d_res%d" % (p, i)), self.dev) for i in range(s.depth)]
                                 for p in range(2)])
 
-    def parameters(self, recurse=True):  # so callers can read device / dtype like from any nn.Module
-        return self.stem.parameters(recurse)
-
     @torch.no_grad()
     def forward(self, x):
-        slow, fast = x
+        """[slow [B,3,8,H,W], fast [B,3,32,H,W]] (the plugin contract): one layout copy, then forward_ndhwc4."""
+        def cl4(v):
+            b, c, t, h, w = v.shape
+            o = torch.zeros((b, t, h, w, 4), dtype=torch.bfloat16, device=self.dev)
+            o[..., :3] = v.to(self.dev, torch.bfloat16).permute(0, 2, 3, 4, 1)
+            return o
+
+        return self.forward_ndhwc4(cl4(x[0]), cl4(x[1]))
+
+    def _stem(self, conv, clip, out=None):
+        """clip [B,T,H,W,4] bf16 -> conv+BN+ReLU at (H/2, W/2) -> max-pool -> Act at (H/4, W/4)."""
+        b, t, h, w, _ = clip.shape
+        y = conv(Act(clip.view(b * t * h * (w // 2), 8), (b, t, h, w // 2)))
+        _, _, h2, w2 = y.dims
+        pd = (b, t, (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1)
+        if out is None:
+            out = Act(torch.empty((pd[0] * pd[1] * pd[2] * pd[3], conv.cout), dtype=torch.bfloat16, device=self.dev), pd)
+        ops.maxpool_hw3s2(y.ptr, out.ptr, b * t, h2, w2, conv.cout, y.ld, out.ld)
+        return out, pd
+
+    @torch.no_grad()
+    def forward_ndhwc4(self, slow, fast):
+        """slow [B,8,H,W,4], fast [B,32,H,W,4] bf16 channels-last clips (ops.clip_pack layout "ndhwc4")."""
         b = slow.shape[0]
-        ys, yf = self.stem([slow.to(self.dev, self.stem_dtype), fast.to(self.dev, self.stem_dtype)])
-        cf = yf.shape[1]
-        ds, df = (b,) + tuple(ys.shape[2:]), (b,) + tuple(yf.shape[2:])
-        ms, mf = ds[0] * ds[1] * ds[2] * ds[3], df[0] * df[1] * df[2] * df[3]
-        # NCDHW stem outputs -> NDHWC rows; the slow rows live in the concat buffer of the first lateral fusion
-        f_act = Act(yf.permute(0, 2, 3, 4, 1).contiguous().view(mf, cf), df)
-        cs = ys.shape[1]
-        sbuf = torch.empty((ms, cs + 2 * cf), dtype=torch.bfloat16, device=self.dev)
-        sbuf.view(*ds, cs + 2 * cf)[..., :cs].copy_(ys.permute(0, 2, 3, 4, 1))
+        f_act, df = self._stem(self.stem_f, fast)
+        cs, cf = self.stem_s.cout, self.stem_f.cout
+        hs, ws = (slow.shape[2] // 2 - 1) // 2 + 1, (slow.shape[3] // 2 - 1) // 2 + 1
+        ds = (b, slow.shape[1], hs, ws)
+        # the slow stem is pooled straight into the concat buffer of the first lateral fusion
+        sbuf = torch.empty((ds[0] * ds[1] * ds[2] * ds[3], cs + 2 * cf), dtype=torch.bfloat16, device=self.dev)
+        self._stem(self.stem_s, slow, out=Act(sbuf, ds, 0, cs))
         self.fuse[0](f_act, out=Act(sbuf, ds, cs, 2 * cf))
         s_act = Act(sbuf, ds)
         for k, (slow_blocks, fast_blocks) in enumerate(self.stages):

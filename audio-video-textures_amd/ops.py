@@ -62,8 +62,9 @@ def clip_pack_plan(win_start, win_len, n_frames):
 
 
 def clip_pack(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0.225, bgr=True,
-              dtype=torch.bfloat16, plan=None):
-    """frames_u8 [F,H,W,3] uint8 RGB (device) -> slow [n,3,8,hw,hw], fast [n,3,32,hw,hw]."""
+              dtype=torch.bfloat16, plan=None, layout="ncthw"):
+    """frames_u8 [F,H,W,3] uint8 RGB (device) -> slow [n,3,8,hw,hw], fast [n,3,32,hw,hw] (layout "ncthw"),
+    or slow [n,8,hw,hw,4], fast [n,32,hw,hw,4] bf16 with a zero 4th channel (layout "ndhwc4", MFMA stem)."""
     _dev(frames_u8, "frames_u8", torch.uint8)
     assert frames_u8.dim() == 4 and frames_u8.shape[3] == 3
     n_frames, h, w, _ = frames_u8.shape
@@ -73,6 +74,15 @@ def clip_pack(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0.225, b
         off, slot = clip_pack_plan(win_start, win_len, n_frames)
         plan = (torch.from_numpy(off).to(frames_u8.device), torch.from_numpy(slot).to(frames_u8.device))
     d_off, d_slot = plan
+    if layout == "ndhwc4":
+        if dtype != torch.bfloat16:
+            raise _lib.AvtError("clip_pack: layout ndhwc4 is bf16 only")
+        slow = torch.empty((n_win, SLOW_T, out_hw, out_hw, 4), dtype=dtype, device=frames_u8.device)
+        fast = torch.empty((n_win, FAST_T, out_hw, out_hw, 4), dtype=dtype, device=frames_u8.device)
+        _lib.check(_lib.lib().avt_clip_pack_u8_ndhwc4(_p(frames_u8), n_frames, h, w, _p(d_off), _p(d_slot), n_win,
+                                                      int(out_hw), float(mean), float(std), 1 if bgr else 0, _p(slow),
+                                                      _p(fast), _stream()), "avt_clip_pack_u8_ndhwc4")
+        return slow, fast
     if dtype not in (torch.bfloat16, torch.float32):
         raise _lib.AvtError("clip_pack: dtype must be bfloat16 or float32")
     slow = torch.empty((n_win, 3, SLOW_T, out_hw, out_hw), dtype=dtype, device=frames_u8.device)
@@ -194,11 +204,19 @@ def conv3d_ktab(cin, kernel, h, w, ldi):
     return tab
 
 
-def conv3d_igemm(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu):
+def conv3d_igemm(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu,
+                 out_dims=(0, 0, 0)):
     """Raw launch: x_ptr/res_ptr/out_ptr are device addresses (int) of bf16 NDHWC rows; dims = (B,T,H,W)."""
     b, t, h, w = dims
     _lib.check(_lib.lib().avt_conv3d_igemm_bf16(C.c_void_p(x_ptr), _p(wt), _p(bias),
                                                 C.c_void_p(res_ptr) if res_ptr else None, C.c_void_p(out_ptr), _p(ktab),
-                                                b, t, h, w, int(cin), int(cout), *kernel, *stride, *pad, int(ldi),
-                                                int(ldo), int(ldr), 1 if relu else 0, _stream()),
+                                                b, t, h, w, int(cin), int(cout), *kernel, *stride, *pad, *out_dims,
+                                                int(ldi), int(ldo), int(ldr), 1 if relu else 0, _stream()),
                "avt_conv3d_igemm_bf16")
+
+
+def maxpool_hw3s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
+    """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on NDHWC bf16 rows (raw device addresses)."""
+    _lib.check(_lib.lib().avt_maxpool_hw3s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),
+                                                       int(c), int(ldi), int(ldo), _stream()),
+               "avt_maxpool_hw3s2_ndhwc_bf16")

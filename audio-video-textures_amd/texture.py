@@ -79,6 +79,9 @@ class TextureEngine:
         self.mean, self.std = mean, std
         p = next(q_encoder.parameters(), None)
         self.pack_dtype = p.dtype if p is not None and p.dtype in (torch.bfloat16, torch.float32) else torch.float32
+        # encoders built on the MFMA conv kernel take channels-last clips directly (fused_slowfast.SlowFastMFMA)
+        self.layout = "ndhwc4" if all(getattr(e, "input_layout", None) == "ndhwc4" for e in (q_encoder, t_encoder)) \
+            else "ncthw"
         self.frames = None
         self.A = self.A_da = self.Ad = None
         self._cache = {"q": {}, "t": {}}
@@ -126,7 +129,12 @@ class TextureEngine:
     def _pack(self, frames, starts):
         lo, hi = int(starts.min()), int(starts.max()) + self.W
         return ops.clip_pack(frames[lo:hi], starts - lo, self.W, out_hw=self.hw, mean=self.mean, std=self.std,
-                             bgr=True, dtype=self.pack_dtype)
+                             bgr=True, dtype=self.pack_dtype, layout=self.layout)
+
+    def _run(self, enc, slow, fast):
+        if self.layout == "ndhwc4":
+            return enc.forward_ndhwc4(slow, fast).float()
+        return enc([slow, fast]).float()
 
     def embed_windows(self, encoders, starts=None, ids=None):
         """Packs each window ONCE and runs every encoder in `encoders` on it -> list of fp32 [n,D]."""
@@ -142,7 +150,7 @@ class TextureEngine:
                     scratch = self._frames_pad.index_select(0, flat)
                     slow, fast = self._pack(scratch, np.arange(len(part), dtype=np.int64) * self.W)
                 for k, enc in enumerate(encoders):
-                    outs[k].append(enc([slow, fast]).float())
+                    outs[k].append(self._run(enc, slow, fast))
                 self.encoded += slow.shape[0] * len(encoders)
         return [torch.cat(o, 0).contiguous() for o in outs]
 

@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=4096, help="clip windows per GPU (N)")
     ap.add_argument("--enc-dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--encoder", default="mfma", choices=["mfma", "miopen"],
+                    help="mfma: hand-written implicit-GEMM convolutions (fused_slowfast); miopen: stock nn.Module")
     ap.add_argument("--enc-batch", type=int, default=32)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"], help="similarity MFMA mode")
     ap.add_argument("--threshold", type=float, default=0.3)
@@ -86,9 +88,16 @@ def main():
     F_ = N * S + W
     video = torch.randint(0, 256, (F_, args.frame_hw, args.frame_hw, 3), generator=g, dtype=torch.uint8)
     torch.manual_seed(0)
-    q_enc = prepare_encoder(SlowFast(), dev, dt)
+    q_mod = SlowFast()
     torch.manual_seed(1)
-    t_enc = prepare_encoder(SlowFast(), dev, dt)
+    t_mod = SlowFast()
+    if args.encoder == "mfma":
+        assert dt == torch.bfloat16, "the MFMA encoder computes in bf16"
+        from avtex.fused_slowfast import SlowFastMFMA
+
+        q_enc, t_enc = SlowFastMFMA(q_mod, dev), SlowFastMFMA(t_mod, dev)
+    else:
+        q_enc, t_enc = prepare_encoder(q_mod, dev, dt), prepare_encoder(t_mod, dev, dt)
     eng = TextureEngine(q_enc, t_enc, None, window=W, stride=S, temp=temp, img_size=224, model_type=1, device=dev,
                         enc_batch=args.enc_batch)
     assert eng.set_video(video) == N
@@ -107,12 +116,13 @@ def main():
                 off, slot = ops.clip_pack_plan(st - lo, W, hi - lo)
                 plan = (torch.from_numpy(off).to(dev, non_blocking=True), torch.from_numpy(slot).to(dev, non_blocking=True))
                 slow, fast = timer.run("clip_pack", lambda: ops.clip_pack(eng.frames[lo:hi], st - lo, W, out_hw=224,
-                                                                           dtype=eng.pack_dtype, plan=plan))
+                                                                           dtype=eng.pack_dtype, plan=plan,
+                                                                           layout=eng.layout))
                 if timer.on and len(pack_bytes) < 4096:
                     pack_bytes.append((hi - lo) * args.frame_hw * args.frame_hw * 3 +
                                       (slow.numel() + fast.numel()) * slow.element_size())
-                outs[0].append(q_enc([slow, fast]).float())
-                outs[1].append(t_enc([slow, fast]).float())
+                outs[0].append(eng._run(q_enc, slow, fast))
+                outs[1].append(eng._run(t_enc, slow, fast))
         qv, tv = torch.cat(outs[0], 0), torch.cat(outs[1], 0)
         qn, qh, ql = timer.run("l2norm_rows", lambda: ops.l2norm_rows(qv, want_split=split))
         tn, th, tl = timer.run("l2norm_rows", lambda: ops.l2norm_rows(tv, want_split=split))
@@ -178,7 +188,9 @@ def main():
                                "windows per GPU (W=20,S=4, 128x128 uint8 frames -> 224^2), l2norm, N x N_total "
                                "similarity D=2304 (%s MFMA), row transition select th=%.1f" % (N, args.precision, args.threshold),
                    "windows_per_gpu": N, "windows_total": n_total, "embedding_dim": D, "encoder_dtype": args.enc_dtype,
-                   "encoder": "SlowFast-8x8-R50 x2 (random init, MIOpen)", "sim_precision": args.precision,
+                   "encoder": "SlowFast-8x8-R50 x2 (random init), %s" % (
+                       "hand-written MFMA implicit-GEMM convolutions" if args.encoder == "mfma" else "MIOpen"),
+                   "sim_precision": args.precision,
                    "parallelism": "windows sharded x%d, all-gather(T_hat)" % world if world > 1 else "single GPU"},
         "roofline": roof,
         "roofline_all": kern,

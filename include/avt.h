@@ -95,6 +95,14 @@ int avt_clip_pack_u8(const uint8_t* frames, int n_frames, int height, int width,
                      int out_hw, float mean, float std, int bgr,
                      void* slow, void* fast, int out_dtype, void* stream);
 
+/* DEVICE. Channels-last variant feeding the MFMA stem: slow [n_win,8,hw,hw,4],
+ * fast [n_win,32,hw,hw,4] bf16 (NDHWC with C padded 3 -> 4 by a zero channel). */
+int avt_clip_pack_u8_ndhwc4(const uint8_t* frames, int n_frames, int height,
+                            int width, const int32_t* dst_off,
+                            const int32_t* dst_slot, int n_win, int out_hw,
+                            float mean, float std, int bgr, void* slow,
+                            void* fast, void* stream);
+
 /* ------------------------------------------------------------------------
  * l2norm_rows — replaces torch.cat + F.normalize (models.py:347-351, 408-412,
  *   433-436): y = [x0|x1] / max(||[x0|x1]||_2, eps), row-wise.
@@ -176,8 +184,9 @@ int avt_softmax_ce_bwd(const float* prob, const int64_t* label, int64_t b,
  *   BN-folded, packed [cout, kt*kh*kw*cin] bf16 with cin innermost; bias fp32 [cout] or NULL.
  *   out[m, 0:cout] = act(conv(in)[m] + bias (+ res[m, 0:cout])), act = ReLU when relu != 0.
  *   `out`/`res` may point INTO a wider row (channel slice of a concat buffer) via ldo/ldr.
- *   cin, cout, ld* multiples of 8; at most 32 taps.  ktab comes from avt_conv3d_ktab
+ *   cin, cout, ld* multiples of 8; kernel extents 1..8.  ktab comes from avt_conv3d_ktab
  *   (HOST; 2*n_entries int32, n_entries = 8*ceil(kt*kh*kw*cin/64)), copied to the device.
+ *   to/ho/wo: output extent; 0 = (x + 2p - k)/s + 1, a smaller value crops the far edge.
  * ---------------------------------------------------------------------- */
 int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, int ldi,
                     int32_t* ktab, int n_entries);
@@ -185,8 +194,13 @@ int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float* bias,
                           const void* res, void* out, const int32_t* ktab,
                           int batch, int t, int h, int w, int cin, int cout,
                           int kt, int kh, int kw, int st, int sh, int sw,
-                          int pt, int ph, int pw, int ldi, int ldo, int ldr,
-                          int relu, void* stream);
+                          int pt, int ph, int pw, int to, int ho, int wo,
+                          int ldi, int ldo, int ldr, int relu, void* stream);
+
+/* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) of the SlowFast stems on NDHWC bf16 rows
+ * (bt = batch*frames); out may be a channel slice of a wider row buffer (ldo). */
+int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w,
+                                 int c, int ldi, int ldo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,5 +81,5 @@ def test_conv_ktab(avt):
     tab = avt.ops.conv3d_ktab(16, (1, 3, 3), 10, 12, 16)
     assert tab.shape == (8 * 3, 2)  # K = 144 -> 3 K-steps of 64
     kc = 5  # chunk 5: tap 2 (dh=0, dw=2), channels 8..15
-    assert tab[kc, 1] == 2 and tab[kc, 0] == 2 * 16 + 8
+    assert tab[kc, 1] == (1 | 1 << 8 | 1 << 18) and tab[kc, 0] == 2 * 16 + 8
     assert (tab[18:, 1] == -1).all()

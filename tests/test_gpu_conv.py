@@ -102,3 +102,55 @@ def test_fused_slowfast_matches_module(avt, dev):
     print("fused vs fp32: cos", cos.tolist(), "rel", rel, "| torch bf16 vs fp32: cos", cos16.tolist(), "rel", rel16)
     assert y.shape == (2, 2304) and torch.isfinite(y).all()
     assert cos.min() > 0.999 and rel < max(2.5 * rel16, 0.02)
+
+
+def test_clip_pack_ndhwc4_equals_ncthw(avt, dev):
+    """The channels-last clip the MFMA stem reads holds exactly the values of the NCTHW clip (+ a zero channel)."""
+    g = torch.Generator().manual_seed(9)
+    W, S, n = 20, 4, 5
+    frames = torch.randint(0, 256, ((n - 1) * S + W + 1, 96, 128, 3), generator=g, dtype=torch.uint8).to(dev)
+    starts = np.arange(n) * S
+    s0, f0 = avt.ops.clip_pack(frames, starts, W, out_hw=224, dtype=torch.bfloat16)
+    s1, f1 = avt.ops.clip_pack(frames, starts, W, out_hw=224, dtype=torch.bfloat16, layout="ndhwc4")
+    assert s1.shape == (n, 8, 224, 224, 4) and f1.shape == (n, 32, 224, 224, 4)
+    assert torch.equal(s1[..., :3].permute(0, 4, 1, 2, 3), s0) and torch.equal(f1[..., :3].permute(0, 4, 1, 2, 3), f0)
+    assert (s1[..., 3] == 0).all() and (f1[..., 3] == 0).all()
+
+
+def test_maxpool_matches_torch(avt, dev):
+    torch.manual_seed(2)
+    x = torch.randn(3, 16, 4, 30, 22).to(torch.bfloat16)  # [B,C,T,H,W]
+    ref = F.max_pool3d(x.float(), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, 16).contiguous().to(dev)
+    ho, wo = ref.shape[3], ref.shape[4]
+    out = torch.full((3 * 4 * ho * wo, 24), 5.0, dtype=torch.bfloat16, device=dev)
+    avt.ops.maxpool_hw3s2(rows.data_ptr(), out.data_ptr() + 2 * 8, 3 * 4, 30, 22, 16, 16, 24)
+    torch.cuda.synchronize()
+    got = out[:, 8:24].float().cpu().view(3, 4, ho, wo, 16).permute(0, 4, 1, 2, 3)
+    assert torch.equal(got, ref) and (out[:, :8] == 5).all()
+
+
+def test_stem_on_mfma_matches_torch(avt, dev):
+    """Pixel-pair stem (conv [kt,7,7] s2 + BN + ReLU) + max-pool vs the PyTorch stem module, both pathways."""
+    from avtex.fused_slowfast import SlowFastMFMA
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(4)
+    m = SlowFast().eval()
+    with torch.no_grad():
+        for mod in m.s1.modules():
+            if isinstance(mod, nn.BatchNorm3d):
+                mod.weight.uniform_(0.6, 1.2); mod.bias.uniform_(-0.2, 0.2)
+                mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.8, 1.2)
+    fused = SlowFastMFMA(m, dev)
+    for conv, stem, t in ((fused.stem_s, m.s1.pathway0_stem, 3), (fused.stem_f, m.s1.pathway1_stem, 7)):
+        x = torch.randn(2, 3, t, 64, 48).to(torch.bfloat16)
+        with torch.no_grad():
+            ref = stem(x.float())
+        clip = torch.zeros((2, t, 64, 48, 4), dtype=torch.bfloat16)
+        clip[..., :3] = x.permute(0, 2, 3, 4, 1)
+        act, pd = fused._stem(conv, clip.to(dev))
+        torch.cuda.synchronize()
+        got = act.buf.float().cpu().view(*pd, conv.cout).permute(0, 4, 1, 2, 3)
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max() < 0.03 * max(ref.abs().max().item(), 1.0)

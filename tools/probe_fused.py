@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""GPU probe: fused MFMA SlowFast throughput and per-layer time (HIP events around every conv launch)."""
+import sys, time, collections
+import torch
+sys.path.insert(0, ".")
+import avtex
+from avtex import ops
+from avtex.slowfast import SlowFast
+from avtex.fused_slowfast import SlowFastMFMA, FusedConv
+dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = True
+torch.manual_seed(0)
+m = SlowFastMFMA(SlowFast(), dev)
+import os
+NDHWC = True
+for b in [int(x) for x in (sys.argv[1:] or ["16", "32"])]:
+    slow = torch.randn(b, 8, 224, 224, 4, device=dev, dtype=torch.bfloat16); fast = torch.randn(b, 32, 224, 224, 4, device=dev, dtype=torch.bfloat16)
+    for _ in range(2): y = m.forward_ndhwc4(slow, fast)
+    torch.cuda.synchronize(); t0 = time.time()
+    n = 5
+    for _ in range(n): y = m.forward_ndhwc4(slow, fast)
+    torch.cuda.synchronize(); per = (time.time() - t0) / n
+    print("fused batch=%d: %.4fs/batch -> %.1f clips/s, %.1f TFLOP/s" % (b, per, b / per, b * 100.6e9 / per / 1e12), flush=True)
+# per-layer timing at batch 16
+b = 16
+slow = torch.randn(b, 8, 224, 224, 4, device=dev, dtype=torch.bfloat16); fast = torch.randn(b, 32, 224, 224, 4, device=dev, dtype=torch.bfloat16)
+recs = []
+orig = FusedConv.__call__
+def timed(self, x, out=None, res=None, relu=None):
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); o = orig(self, x, out=out, res=res, relu=relu); e.record()
+    od = self.out_dims(x.dims); M = od[0] * od[1] * od[2] * od[3]
+    K = self.kernel[0] * self.kernel[1] * self.kernel[2] * self.cin
+    byt = (x.dims[0] * x.dims[1] * x.dims[2] * x.dims[3] * self.cin + M * self.cout * (2 if res is not None else 1)) * 2
+    recs.append((a, e, "cin%d cout%d k%s s%s M%d" % (self.cin, self.cout, self.kernel, self.stride, M), 2.0 * M * K * self.cout, byt))
+    return o
+FusedConv.__call__ = timed
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); y = m.forward_ndhwc4(slow, fast); e1.record(); torch.cuda.synchronize()
+tot = e0.elapsed_time(e1)
+agg = collections.OrderedDict()
+for a, e, name, fl, byt in recs:
+    t = a.elapsed_time(e)
+    d = agg.setdefault(name, [0, 0.0, 0.0, 0.0]); d[0] += 1; d[1] += t; d[2] += fl; d[3] += byt
+conv_ms = sum(v[1] for v in agg.values())
+print("batch 16 forward %.2f ms; conv launches %.2f ms (%d launches); stem+glue %.2f ms" % (tot, conv_ms, len(recs), tot - conv_ms))
+for name, (n, t, fl, byt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%6.3f ms x%d  %-48s %7.1f TF/s %7.0f GB/s" % (t, n, name, fl / t / 1e9, byt / t / 1e6))
