@@ -32,6 +32,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LSTR = 144;  // LDS row stride (128 data bytes = 64 bf16 of K, + 16 pad)
 constexpr int BK = 64;
 
+// unsigned division by a launch-time constant without the ~40-instruction runtime divide: the row decode of a
+// short-K layer (1x1x1, few channels) would otherwise cost more than its whole K loop.
+struct FastDiv {
+  uint32_t d, magic, shift;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{d, 0u, 0u};
+  if (d > 1) {
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.magic = (uint32_t)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+    f.shift = s - 1;
+  }
+  return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  const uint32_t t = __umulhi(n, f.magic);
+  return (t + ((n - t) >> 1)) >> f.shift;
+}
+
 struct ConvArgs {
   const uint16_t* in;
   const uint16_t* wt;
@@ -48,10 +69,14 @@ struct ConvArgs {
   int M;  // output positions (B*To*Ho*Wo)
   int nk;
   int tiles_n, nblk;
+  FastDiv dWo, dHo, dTo;
 };
 
+// waves per SIMD to keep: the register budget the allocator may use follows from it (guide §6 G1)
+#define AVT_CONV_MIN_WAVES(BM, BN) ((BM) == 128 ? 3 : ((BN) == 64 ? 2 : 4))
+
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int WAVES_M = BM / 64;
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WN = BN / WAVES_N;  // wave tile width in n
@@ -82,12 +107,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     rowoff[u] = 0;
     rowmask[u] = 0u;
     if (m < a.M) {
-      int wo = m % a.Wo;
-      int t1 = m / a.Wo;
-      int ho = t1 % a.Ho;
-      int t2 = t1 / a.Ho;
-      int to = t2 % a.To;
-      int b = t2 / a.To;
+      const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
+      const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
+      const int b = (int)fastdiv((uint32_t)t2, a.dTo), to = t2 - b * a.To;
       const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
       rowoff[u] = (((b * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.ldi;
       // in-bounds taps are separable: bits 0-7 = dt, 8-15 = dh, 16-23 = dw
@@ -165,9 +187,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
   }
 
-  // ---- epilogue phase 1: (+bias [, relu]) -> bf16 -> LDS staging tile [m][n]
-  // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n  -> regs 4g..4g+3 are 4 consecutive n
+  // ---- epilogue.  The residual chunks this thread will need are requested FIRST, so their HBM latency
+  // overlaps the staging of the accumulators through LDS instead of serialising 8 round trips per thread.
+  constexpr int CPR = BN / 8;  // 16-byte chunks per output row
+  constexpr int EU = (BM * CPR) / 256;
   const bool has_res = a.res != nullptr;
+  uint4 rres[EU];
+  if (has_res) {
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int c = tid + 256 * u;
+      const int m = m0 + c / CPR, n = n0 + (c % CPR) * 8;
+      rres[u] = (m < a.M && n < a.Cout) ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n)
+                                        : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  // phase 1: (+bias [, relu]) -> bf16 -> LDS staging tile [m][n]
+  // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n  -> regs 4g..4g+3 are 4 consecutive n
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -193,19 +229,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   __syncthreads();
-  // ---- epilogue phase 2: 16-byte row-contiguous chunks: (+residual, relu) -> global
-  constexpr int CPR = BN / 8;  // chunks per row
+  // phase 2: 16-byte row-contiguous chunks: (+residual, relu) -> global
 #pragma unroll
-  for (int u = 0; u < (BM * CPR) / 256; ++u) {
+  for (int u = 0; u < EU; ++u) {
     const int c = tid + 256 * u;
     const int row = c / CPR, cc = c % CPR;
     const int m = m0 + row, n = n0 + cc * 8;
     if (m < a.M && n < a.Cout) {
       uint4 v = *reinterpret_cast<const uint4*>(lds + row * ESTR + cc * 16);
       if (has_res) {
-        const uint4 rv = *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n);
         uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
-        const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rv);
+        const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rres[u]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x0 = avt::bf16_bits_to_f32((uint16_t)(pv[e] & 0xffffu)) + avt::bf16_bits_to_f32((uint16_t)(pr[e] & 0xffffu));
@@ -308,6 +342,9 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
               "avt_conv3d_igemm_bf16: tensor too large for 32-bit element offsets");
   a.M = (int)M;
   a.nk = (a.K + BK - 1) / BK;
+  a.dWo = make_fastdiv((uint32_t)a.Wo);
+  a.dHo = make_fastdiv((uint32_t)a.Ho);
+  a.dTo = make_fastdiv((uint32_t)a.To);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (cout <= 32) return launch<256, 32>(a, s);
   if (cout <= 64) return launch<256, 64>(a, s);

@@ -16,7 +16,7 @@ __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) {
 }
 
 __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                       int bt, int H, int W, int C, int ldi, int ldo, int Ho, int Wo) {
+                                                       int bt, int H, int W, int C, int ldi, int ldo, int Ho, int Wo, int tgroup) {
   const int cpr = C >> 3;
   const int64_t total = (int64_t)bt * Ho * Wo * cpr;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -48,23 +48,29 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict
         }
       }
     }
-    *reinterpret_cast<uint4*>(out + (((int64_t)b * Ho + ho) * Wo + wo) * ldo + cc * 8) = m;
+    // tgroup > 1: the C channels are `tgroup` consecutive frames of C/tgroup channels each (the time-grouped stem):
+    // un-group while writing, so the result is plain NDHWC with bt*tgroup frames
+    const int cg = C / tgroup;
+    const int j = (cc * 8) / cg, c0 = (cc * 8) - j * cg;
+    *reinterpret_cast<uint4*>(out + ((((int64_t)b * tgroup + j) * Ho + ho) * Wo + wo) * ldo + c0) = m;
   }
 }
 
 }  // namespace
 
 extern "C" int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w, int c, int ldi, int ldo,
-                                            void* stream) {
+                                            int tgroup, void* stream) {
   AVT_REQUIRE(in && out, "avt_maxpool_hw3s2_ndhwc_bf16: NULL pointer");
-  AVT_REQUIRE(bt > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldi >= c && ldo >= c,
+  AVT_REQUIRE(bt > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldi >= c,
               "avt_maxpool_hw3s2_ndhwc_bf16: channels / leading dimensions must be multiples of 8");
   AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(out), "avt_maxpool_hw3s2_ndhwc_bf16: pointers must be 16-byte aligned");
+  AVT_REQUIRE(tgroup >= 1 && c % tgroup == 0 && (c / tgroup) % 8 == 0 && ldo >= c / tgroup,
+              "avt_maxpool_hw3s2_ndhwc_bf16: tgroup must split the channels into multiples of 8");
   const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
   const int64_t total = (int64_t)bt * ho * wo * (c / 8);
   const int64_t blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
   hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), bt, h, w, c, ldi, ldo, ho, wo);
+                     static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), bt, h, w, c, ldi, ldo, ho, wo, tgroup);
   return avt::check_launch("avt_maxpool_hw3s2_ndhwc_bf16");
 }

@@ -21,6 +21,10 @@ from . import ops
 from ._lib import AvtError
 
 
+# Optional launch observer for bench.py: PROFILER(name, launch_fn, flops, bytes) must call launch_fn().
+PROFILER = None
+
+
 class Act:
     """A [M, C] channel slice of a row-major bf16 buffer [M, ld] holding NDHWC activations of extent dims."""
 
@@ -90,14 +94,28 @@ class FusedConv:
         if out is None:
             m = od[0] * od[1] * od[2] * od[3]
             out = Act(torch.empty((m, self.cout), dtype=torch.bfloat16, device=self.dev), od)
-        ops.conv3d_igemm(x.ptr, self.wt, self.bias, res.ptr if res is not None else 0, out.ptr, tab, x.dims, self.cin,
-                         self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld, res.ld if res is not None else 0,
-                         self.relu if relu is None else relu, out_dims=od[1:] if any(self.crop) else (0, 0, 0))
+        def launch():
+            ops.conv3d_igemm(x.ptr, self.wt, self.bias, res.ptr if res is not None else 0, out.ptr, tab, x.dims,
+                             self.cin, self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld,
+                             res.ld if res is not None else 0, self.relu if relu is None else relu,
+                             out_dims=od[1:] if any(self.crop) else (0, 0, 0))
+
+        if PROFILER is None:
+            launch()
+        else:
+            m_out = od[0] * od[1] * od[2] * od[3]
+            m_in = x.dims[0] * x.dims[1] * x.dims[2] * x.dims[3]
+            PROFILER("conv3d_igemm_bf16", launch, 2.0 * m_out * self.wt.shape[1] * self.cout,
+                     2.0 * (m_in * self.cin + m_out * self.cout * (2 if res is not None else 1)) + self.wt.numel() * 2)
         return out
 
 
-def stem_conv(stem, device):
-    """Stem Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU in pixel-pair form (see module doc)."""
+def stem_conv(stem, device, tgroup=1):
+    """Stem Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU in pixel-pair form (see module doc).
+
+    tgroup = g > 1 (fast stem, C = 8): g consecutive output frames are computed as g*C channels of ONE output row
+    (block-Toeplitz weights over kt+g-1 input frames, temporal stride g), so the 32-wide MFMA tile is full instead
+    of 3/4 zero padding: (kt+g-1)/(g*kt) of the MFMA work of the plain form (8/20 for kt=5, g=4)."""
     w, bias = fold_bn(stem.conv, stem.bn)  # [C, 3, kt, 7, 7]
     c, _, kt, kh, kw = w.shape
     if (kh, kw) != (7, 7) or tuple(stem.conv.stride) != (1, 2, 2) or tuple(stem.conv.padding) != (kt // 2, 3, 3):
@@ -108,8 +126,20 @@ def stem_conv(stem, device):
             k = 2 * dwp + p - 1  # original column tap: column = 2wo - 4 + 2*dwp + p = 2wo - 3 + k
             if 0 <= k < kw:
                 wp[:, :, :, dwp, p, :3] = w[:, :, :, :, k].permute(0, 2, 3, 1)
-    return FusedConv(None, None, True, device,
+    if tgroup > 1:
+        g = tgroup
+        wg = torch.zeros((g, c, kt + g - 1) + tuple(wp.shape[2:]))
+        for j in range(g):
+            wg[j, :, j : j + kt] = wp
+        conv = FusedConv(None, None, True, device,
+                         packed=(wg.reshape(g * c, -1), bias.repeat(g), 8, (kt + g - 1, kh, 4), (g, 2, 1),
+                                 (kt // 2, 3, 2), (0, 0, 1)))
+        conv.tgroup, conv.frame_channels = g, c
+        return conv
+    conv = FusedConv(None, None, True, device,
                      packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)))
+    conv.tgroup, conv.frame_channels = 1, c
+    return conv
 
 
 class _Block:
@@ -137,7 +167,7 @@ class SlowFastMFMA(nn.Module):
         self.dev = torch.device(device)
         model = model.eval()
         self.stem_s = stem_conv(model.s1.pathway0_stem, self.dev)
-        self.stem_f = stem_conv(model.s1.pathway1_stem, self.dev)
+        self.stem_f = stem_conv(model.s1.pathway1_stem, self.dev, tgroup=4)
         self._anchor = nn.Parameter(torch.zeros(1, dtype=torch.bfloat16, device=self.dev), requires_grad=False)
         self.fuse = [FusedConv(f.conv_f2s, f.bn, True, self.dev) for f in (model.s1_fuse, model.s2_fuse, model.s3_fuse,
                                                                             model.s4_fuse)]
@@ -160,12 +190,15 @@ class SlowFastMFMA(nn.Module):
     def _stem(self, conv, clip, out=None):
         """clip [B,T,H,W,4] bf16 -> conv+BN+ReLU at (H/2, W/2) -> max-pool -> Act at (H/4, W/4)."""
         b, t, h, w, _ = clip.shape
+        if t % conv.tgroup:
+            raise AvtError("stem: %d frames do not split into groups of %d" % (t, conv.tgroup))
         y = conv(Act(clip.view(b * t * h * (w // 2), 8), (b, t, h, w // 2)))
-        _, _, h2, w2 = y.dims
+        _, tg, h2, w2 = y.dims
         pd = (b, t, (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1)
+        cf = conv.frame_channels
         if out is None:
-            out = Act(torch.empty((pd[0] * pd[1] * pd[2] * pd[3], conv.cout), dtype=torch.bfloat16, device=self.dev), pd)
-        ops.maxpool_hw3s2(y.ptr, out.ptr, b * t, h2, w2, conv.cout, y.ld, out.ld)
+            out = Act(torch.empty((pd[0] * pd[1] * pd[2] * pd[3], cf), dtype=torch.bfloat16, device=self.dev), pd)
+        ops.maxpool_hw3s2(y.ptr, out.ptr, b * tg, h2, w2, conv.cout, y.ld, out.ld, tgroup=conv.tgroup)
         return out, pd
 
     @torch.no_grad()
@@ -173,7 +206,7 @@ class SlowFastMFMA(nn.Module):
         """slow [B,8,H,W,4], fast [B,32,H,W,4] bf16 channels-last clips (ops.clip_pack layout "ndhwc4")."""
         b = slow.shape[0]
         f_act, df = self._stem(self.stem_f, fast)
-        cs, cf = self.stem_s.cout, self.stem_f.cout
+        cs, cf = self.stem_s.frame_channels, self.stem_f.frame_channels
         hs, ws = (slow.shape[2] // 2 - 1) // 2 + 1, (slow.shape[3] // 2 - 1) // 2 + 1
         ds = (b, slow.shape[1], hs, ws)
         # the slow stem is pooled straight into the concat buffer of the first lateral fusion

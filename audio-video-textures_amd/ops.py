@@ -215,8 +215,8 @@ def conv3d_igemm(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kerne
                "avt_conv3d_igemm_bf16")
 
 
-def maxpool_hw3s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
+def maxpool_hw3s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo, tgroup=1):
     """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on NDHWC bf16 rows (raw device addresses)."""
     _lib.check(_lib.lib().avt_maxpool_hw3s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),
-                                                       int(c), int(ldi), int(ldo), _stream()),
+                                                       int(c), int(ldi), int(ldo), int(tgroup), _stream()),
                "avt_maxpool_hw3s2_ndhwc_bf16")

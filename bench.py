@@ -34,9 +34,11 @@ class KernelTimer:
 
     def __init__(self):
         self.ev = {}
+        self.work = {}
         self.on = False
+        self.sample_conv = False  # conv launches are sampled (every 8th encoder batch) to keep the overhead < 1 %
 
-    def run(self, name, fn):
+    def run(self, name, fn, flops=0.0, nbytes=0.0):
         if not self.on:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,7 +46,16 @@ class KernelTimer:
         out = fn()
         b.record()
         self.ev.setdefault(name, []).append((a, b))
+        w = self.work.setdefault(name, [0.0, 0.0])
+        w[0] += flops
+        w[1] += nbytes
         return out
+
+    def conv_hook(self, name, launch, flops, nbytes):
+        if self.on and self.sample_conv:
+            self.run(name, launch, flops, nbytes)
+        else:
+            launch()
 
     def summary(self):
         torch.cuda.synchronize()
@@ -96,6 +107,7 @@ def main():
         from avtex.fused_slowfast import SlowFastMFMA
 
         q_enc, t_enc = SlowFastMFMA(q_mod, dev), SlowFastMFMA(t_mod, dev)
+        import avtex.fused_slowfast as fsf
     else:
         q_enc, t_enc = prepare_encoder(q_mod, dev, dt), prepare_encoder(t_mod, dev, dt)
     eng = TextureEngine(q_enc, t_enc, None, window=W, stride=S, temp=temp, img_size=224, model_type=1, device=dev,
@@ -103,6 +115,8 @@ def main():
     assert eng.set_video(video) == N
     starts = np.arange(N, dtype=np.int64) * S
     timer = KernelTimer()
+    if args.encoder == "mfma":
+        fsf.PROFILER = timer.conv_hook
     q_ids = torch.arange(rank * N, rank * N + N, device=dev, dtype=torch.int64)
     split = args.precision != "f32"
     pack_bytes = []
@@ -121,8 +135,10 @@ def main():
                 if timer.on and len(pack_bytes) < 4096:
                     pack_bytes.append((hi - lo) * args.frame_hw * args.frame_hw * 3 +
                                       (slow.numel() + fast.numel()) * slow.element_size())
+                timer.sample_conv = (i // args.enc_batch) % 8 == 0
                 outs[0].append(eng._run(q_enc, slow, fast))
                 outs[1].append(eng._run(t_enc, slow, fast))
+                timer.sample_conv = False
         qv, tv = torch.cat(outs[0], 0), torch.cat(outs[1], 0)
         qn, qh, ql = timer.run("l2norm_rows", lambda: ops.l2norm_rows(qv, want_split=split))
         tn, th, tl = timer.run("l2norm_rows", lambda: ops.l2norm_rows(tv, want_split=split))
@@ -169,11 +185,28 @@ def main():
                      "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
                      "algorithmic_per_launch": work_per_launch})
 
+    conv_step_ms = 0.0
+    if "conv3d_igemm_bf16" in ks:
+        # the encoder's convolutions: many shapes, so "per launch" = sampled totals / sampled launches.
+        # algorithmic flops = 2*M*K*Cout of each launch as issued (K includes the stem's zero taps: +1.5 % overall)
+        n, avg_ms = ks["conv3d_igemm_bf16"]
+        fl, by = timer.work["conv3d_igemm_bf16"]
+        sampled_ms = n * avg_ms
+        batches = -(-N // args.enc_batch)
+        sampled_batches = len(range(0, batches, 8)) * args.steps
+        conv_step_ms = sampled_ms / sampled_batches * batches  # both encoders
+        kern.append({"kernel": "conv3d_igemm_bf16", "bound": "mfma", "launches_per_step": n // sampled_batches * batches,
+                     "avg_ms": avg_ms, "achieved": fl / (sampled_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS["bf16"],
+                     "unit": "TFLOP/s", "frac": fl / (sampled_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16"], "traffic": None,
+                     "algorithmic_per_launch": fl / n, "algorithmic_GBps": by / (sampled_ms * 1e-3) / 1e9,
+                     "note": "sampled every 8th encoder batch; bytes = activations in+out(+residual)+weights"})
     add("clip_pack", "hbm", float(np.mean(pack_bytes)) if pack_bytes else 0.0, "GB/s", HBM_PEAK_GBS)
     add("l2norm_rows", "hbm", N * D * 4 + N * D * (4 + (4 if split else 0)), "GB/s", HBM_PEAK_GBS)
     add("sim_gemm_nt", "mfma", 2.0 * N * n_total * D, "TFLOP/s", MFMA_PEAK_TFLOPS[args.precision])
     add("row_transition", "hbm", N * n_total * 4.0, "GB/s", HBM_PEAK_GBS)
     per_step_ms = {k["kernel"]: k["avg_ms"] * k["launches_per_step"] for k in kern}
+    if conv_step_ms:
+        per_step_ms["conv3d_igemm_bf16"] = conv_step_ms
     dominant = max(kern, key=lambda k: per_step_ms[k["kernel"]])
     roof = {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     roof["kernel"] = dominant["kernel"]

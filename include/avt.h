@@ -198,9 +198,11 @@ int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float* bias,
                           int ldi, int ldo, int ldr, int relu, void* stream);
 
 /* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) of the SlowFast stems on NDHWC bf16 rows
- * (bt = batch*frames); out may be a channel slice of a wider row buffer (ldo). */
+ * (bt = batch*frames); out may be a channel slice of a wider row buffer (ldo).
+ * tgroup > 1: each input row holds `tgroup` consecutive frames of c/tgroup channels (the
+ * time-grouped fast stem); the output is un-grouped to bt*tgroup frames of c/tgroup channels. */
 int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w,
-                                 int c, int ldi, int ldo, void* stream);
+                                 int c, int ldi, int ldo, int tgroup, void* stream);
 
 #ifdef __cplusplus
 }

@@ -124,7 +124,7 @@ def test_maxpool_matches_torch(avt, dev):
     rows = x.permute(0, 2, 3, 4, 1).reshape(-1, 16).contiguous().to(dev)
     ho, wo = ref.shape[3], ref.shape[4]
     out = torch.full((3 * 4 * ho * wo, 24), 5.0, dtype=torch.bfloat16, device=dev)
-    avt.ops.maxpool_hw3s2(rows.data_ptr(), out.data_ptr() + 2 * 8, 3 * 4, 30, 22, 16, 16, 24)
+    avt.ops.maxpool_hw3s2(rows.data_ptr(), out.data_ptr() + 2 * 8, 3 * 4, 30, 22, 16, 16, 24, tgroup=1)
     torch.cuda.synchronize()
     got = out[:, 8:24].float().cpu().view(3, 4, ho, wo, 16).permute(0, 4, 1, 2, 3)
     assert torch.equal(got, ref) and (out[:, :8] == 5).all()
@@ -143,7 +143,7 @@ def test_stem_on_mfma_matches_torch(avt, dev):
                 mod.weight.uniform_(0.6, 1.2); mod.bias.uniform_(-0.2, 0.2)
                 mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.8, 1.2)
     fused = SlowFastMFMA(m, dev)
-    for conv, stem, t in ((fused.stem_s, m.s1.pathway0_stem, 3), (fused.stem_f, m.s1.pathway1_stem, 7)):
+    for conv, stem, t in ((fused.stem_s, m.s1.pathway0_stem, 3), (fused.stem_f, m.s1.pathway1_stem, 8)):
         x = torch.randn(2, 3, t, 64, 48).to(torch.bfloat16)
         with torch.no_grad():
             ref = stem(x.float())
@@ -151,6 +151,6 @@ def test_stem_on_mfma_matches_torch(avt, dev):
         clip[..., :3] = x.permute(0, 2, 3, 4, 1)
         act, pd = fused._stem(conv, clip.to(dev))
         torch.cuda.synchronize()
-        got = act.buf.float().cpu().view(*pd, conv.cout).permute(0, 4, 1, 2, 3)
+        got = act.buf.float().cpu().view(*pd, conv.frame_channels).permute(0, 4, 1, 2, 3)
         assert got.shape == ref.shape
         assert (got - ref).abs().max() < 0.03 * max(ref.abs().max().item(), 1.0)

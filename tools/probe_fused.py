@@ -21,8 +21,8 @@ for b in [int(x) for x in (sys.argv[1:] or ["16", "32"])]:
     for _ in range(n): y = m.forward_ndhwc4(slow, fast)
     torch.cuda.synchronize(); per = (time.time() - t0) / n
     print("fused batch=%d: %.4fs/batch -> %.1f clips/s, %.1f TFLOP/s" % (b, per, b / per, b * 100.6e9 / per / 1e12), flush=True)
-# per-layer timing at batch 16
-b = 16
+# per-layer timing
+b = int(os.environ.get('PROBE_B', '16'))
 slow = torch.randn(b, 8, 224, 224, 4, device=dev, dtype=torch.bfloat16); fast = torch.randn(b, 32, 224, 224, 4, device=dev, dtype=torch.bfloat16)
 recs = []
 orig = FusedConv.__call__
@@ -43,6 +43,6 @@ for a, e, name, fl, byt in recs:
     t = a.elapsed_time(e)
     d = agg.setdefault(name, [0, 0.0, 0.0, 0.0]); d[0] += 1; d[1] += t; d[2] += fl; d[3] += byt
 conv_ms = sum(v[1] for v in agg.values())
-print("batch 16 forward %.2f ms; conv launches %.2f ms (%d launches); stem+glue %.2f ms" % (tot, conv_ms, len(recs), tot - conv_ms))
+print("batch %d" % b + " forward %.2f ms; conv launches %.2f ms (%d launches); stem+glue %.2f ms" % (tot, conv_ms, len(recs), tot - conv_ms))
 for name, (n, t, fl, byt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%6.3f ms x%d  %-48s %7.1f TF/s %7.0f GB/s" % (t, n, name, fl / t / 1e9, byt / t / 1e6))
