@@ -79,6 +79,8 @@ def build_parser():
     a("--ref_num_gpus", default=None, type=int, help="reference GPU count to emulate in compat mode")
     a("--enc_dtype", default="fp32", choices=["fp32", "bf16"], help="encoder compute dtype")
     a("--enc_batch", default=32, type=int, help="windows per encoder batch")
+    a("--enc_impl", default="auto", choices=["auto", "mfma", "module"],
+      help="SlowFast at -e: hand-written MFMA convolutions (auto/mfma) or the nn.Module on MIOpen (module)")
     a("--vcam", default=False, action="store_true", help="defined for validate.py:299; CAM dumps are out of scope")
     return parser
 

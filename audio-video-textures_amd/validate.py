@@ -176,7 +176,18 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
             if da_model is None:
                 raise AvtError("driving audio needs pytorch_vggish.pth (validate.py:266) or a model with an audio encoder")
             print("pytorch_vggish.pth not found: driving-audio branch uses the model's own audio encoder")
-    eng = texture.TextureEngine(net.q_encoder, net.t_encoder, getattr(net, "t_a_encoder", None),
+    q_enc, t_enc = net.q_encoder, net.t_encoder
+    if getattr(args, "enc_impl", "auto") in ("auto", "mfma"):
+        # real SlowFast encoders run on the hand-written MFMA convolutions (bf16, BN folded); plugin encoders of
+        # any other class run as given
+        from .fused_slowfast import SlowFastMFMA
+        from .slowfast import SlowFast
+
+        if isinstance(q_enc, SlowFast) and isinstance(t_enc, SlowFast):
+            q_enc, t_enc = SlowFastMFMA(q_enc, dev), SlowFastMFMA(t_enc, dev)
+        elif getattr(args, "enc_impl", "auto") == "mfma":
+            raise AvtError("enc_impl=mfma needs SlowFast encoders (got {})".format(type(q_enc).__name__))
+    eng = texture.TextureEngine(q_enc, t_enc, getattr(net, "t_a_encoder", None),
                                 window=W, stride=S, temp=net.temp, img_size=args.img_size,
                                 model_type=net.model_type, device=dev,
                                 enc_batch=getattr(args, "enc_batch", 32))

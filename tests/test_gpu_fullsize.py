@@ -1,0 +1,100 @@
+"""BASELINE.json sizes on the MI355X: N=4096 (config 2) bit-exact against the oracle end to end, N=16384
+(config 4) through the row-sharded build, and size-independent properties of clip_pack."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+
+def _emb(n, d, seed):
+    return torch.randn((n, d), generator=torch.Generator().manual_seed(seed)).numpy()
+
+
+def test_n4096_build_is_bit_exact(avt, dev):
+    """Q,T = randn(4096, 2304) seeds 0/1: normalise -> sim -> select, every bit against the oracle;
+    also the clustered variant (T[j] = Q[j-1] + 0.1 noise: segment q+1 is the planted successor of q)."""
+    n, d = 4096, 2304
+    q, t = _emb(n, d, 0), _emb(n, d, 1)
+    for variant in ("random", "clustered"):
+        if variant == "clustered":
+            t = np.roll(q, 1, axis=0) + 0.1 * _emb(n, d, 2)
+        qn, qh, ql = avt.ops.l2norm_rows(torch.from_numpy(q).to(dev), want_split=True)
+        tn, th, tl = avt.ops.l2norm_rows(torch.from_numpy(t).to(dev), want_split=True)
+        sim = avt.ops.sim_gemm_nt(qn, tn, 0.1, "f32")
+        oq, _, _ = cref.l2norm_rows(q, want_split=False)
+        ot, _, _ = cref.l2norm_rows(t, want_split=False)
+        assert np.array_equal(qn.cpu().numpy(), oq) and np.array_equal(tn.cpu().numpy(), ot)
+        ref = cref.sim_f32(oq, ot, 0.1)
+        assert np.array_equal(sim.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        q_ids = np.arange(n)
+        for th_ in (0.0, 0.3):
+            sel = avt.ops.row_transition(sim, q_ids=torch.from_numpy(q_ids).to(dev), threshold=th_, cap=64)
+            o = cref.row_transition(ref, q_ids=q_ids, threshold=th_, cap=64)
+            assert np.array_equal(sel["cnt"].cpu().numpy(), o["cnt"])
+            assert np.array_equal(sel["seg"].cpu().numpy(), o["seg"])
+            assert np.array_equal(sel["p"].cpu().numpy().view(np.uint32), o["p"].view(np.uint32))
+        if variant == "clustered":  # th=0 keeps exactly the planted successor (position 0 = segment q+1)
+            assert (sel["cnt"].cpu().numpy()[:-1] >= 1).all()
+            o0 = cref.row_transition(ref, q_ids=q_ids, threshold=0.0, cap=4)
+            assert (o0["seg"][:-1, 0] == q_ids[:-1] + 1).all() and (o0["cnt"][:-1] == 1).all()
+        # bf16 MFMA modes stay within their stated error at full size
+        s3 = avt.ops.sim_gemm_nt(qh, th, 0.1, "bf16x3", q_lo=ql, t_lo=tl)
+        assert (s3 - sim).abs().max().item() < 1e-4  # << the 1e-3 contract
+        s1 = avt.ops.sim_gemm_nt(qh, th, 0.1, "bf16")
+        assert (s1 - sim).abs().max().item() < 2e-2
+
+
+def test_n16384_sharded_rows_and_topk(avt, dev):
+    """Config 4: N=16384, D=2304; rank r of 8 owns rows [2048r, 2048(r+1)).  A rank's row block equals the same rows
+    of a differently partitioned build (no dependence on the shard shape) and its top-k equals the oracle's."""
+    n, d, k = 16384, 2304, 8
+    q, t = _emb(n, d, 10), _emb(n, d, 11)
+    tn, th, _ = avt.ops.l2norm_rows(torch.from_numpy(t).to(dev), want_split=True)
+    lo, hi = 3 * 2048, 4 * 2048  # rank 3 of 8
+    qn, qh, _ = avt.ops.l2norm_rows(torch.from_numpy(q[lo:hi]).to(dev), want_split=True)
+    blk = avt.ops.sim_gemm_nt(qn, tn, 0.1, "f32")
+    qn2, _, _ = avt.ops.l2norm_rows(torch.from_numpy(q[lo - 100 : hi + 28]).to(dev))
+    blk2 = avt.ops.sim_gemm_nt(qn2, tn, 0.1, "f32")
+    assert torch.equal(blk, blk2[100 : 100 + 2048])  # tiling-independent bits
+    rows = np.arange(lo, lo + 64)
+    oq, _, _ = cref.l2norm_rows(q[rows], want_split=False)
+    ot, _, _ = cref.l2norm_rows(t, want_split=False)
+    ref = cref.sim_f32(oq, ot, 0.1)
+    assert np.array_equal(blk[:64].cpu().numpy(), ref)
+    self_col = torch.arange(lo, hi, device=dev, dtype=torch.int64)
+    idx, val = avt.ops.row_topk(blk, k, self_col)
+    oi, ov = cref.row_topk(ref, k, rows.astype(np.int64))
+    assert np.array_equal(idx[:64].cpu().numpy(), oi) and np.array_equal(val[:64].cpu().numpy(), ov)
+    # bf16 shortlist contains the exact top-1 (what a bf16-first pipeline would rely on)
+    b16 = avt.ops.sim_gemm_nt(qh, th, 0.1, "bf16")
+    i16, _ = avt.ops.row_topk(b16, 32, self_col)
+    assert (i16 == idx[:, :1]).any(dim=1).all()
+    sel = avt.ops.row_transition(blk, q_ids=self_col, threshold=0.3, cap=64)
+    o = cref.row_transition(ref, q_ids=rows, n_seg=n, threshold=0.3, cap=64)
+    assert np.array_equal(sel["cnt"][:64].cpu().numpy(), o["cnt"]) and np.array_equal(sel["seg"][:64].cpu().numpy(), o["seg"])
+
+
+def test_clip_pack_frame_sharing_and_checksum(avt, dev):
+    """At the bench shape (W=20, S=4, 128^2 -> 224^2): a source frame sampled by several windows lands as identical
+    planes everywhere (the kernel stores one computed strip to all destinations), slow frames are fast frames,
+    and both layouts carry the same values."""
+    W, S, n = 20, 4, 48
+    g = torch.Generator().manual_seed(123)
+    frames = torch.randint(0, 256, (n * S + W, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
+    starts = np.arange(n) * S
+    slow, fast = avt.ops.clip_pack(frames, starts, W, dtype=torch.bfloat16)
+    fi, si = avt.ops.clip_sample_table(W)
+    pick = torch.linspace(0, 31, 8).long()
+    assert torch.equal(slow, fast[:, :, pick])  # slow = every alpha-th fast frame
+    for a, b in ((0, 1), (5, 9), (20, 24)):  # windows a < b overlap when (b - a) * S < W
+        for sa in range(32):
+            f_abs = starts[a] + fi[sa]
+            hit = [sb for sb in range(32) if starts[b] + fi[sb] == f_abs]
+            for sb in hit[:1]:
+                assert torch.equal(fast[a, :, sa], fast[b, :, sb])
+    s4, f4 = avt.ops.clip_pack(frames, starts, W, dtype=torch.bfloat16, layout="ndhwc4")
+    assert torch.equal(f4[..., :3].permute(0, 4, 1, 2, 3), fast)
+    assert abs(float(fast.float().sum()) - float(f4.float().sum())) < 1e-3 * fast.numel()

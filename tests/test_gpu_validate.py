@@ -171,3 +171,46 @@ def test_training_step_matches_reference(avt, dev):
     assert abs(float(loss) - float(g["tr_loss"])) < 1e-5
     np.testing.assert_allclose(cpt.q_encoder.fc.weight.grad.cpu().numpy(), g["tr_grad_fc_q"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(cpt.t_encoder.fc.weight.grad.cpu().numpy(), g["tr_grad_fc_t"], rtol=1e-3, atol=1e-6)
+
+
+def test_validate_with_real_slowfast_on_mfma_encoder(avt, dev, capsys):
+    """validate() end to end with the real SlowFast-8x8-R50 (random init) on the MFMA convolution path, aligned
+    mode, against the oracle run on the SAME embedding tables: identical frames list."""
+    from avtex.slowfast import SlowFast
+    from avtex.texture import TextureEngine
+    from avtex.fused_slowfast import SlowFastMFMA
+
+    torch.manual_seed(0)
+    W, S, L = 20, 4, 14
+    g = torch.Generator().manual_seed(3)
+    video = torch.randint(0, 256, (L * S + W + 1, 64, 64, 3), generator=g, dtype=torch.uint8)
+    q_mod, t_mod = SlowFast().eval(), SlowFast().eval()
+    with torch.no_grad():  # non-degenerate residual branches (c_bn is zero-initialised)
+        for m in list(q_mod.modules()) + list(t_mod.modules()):
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.uniform_(0.5, 1.0)
+    model = avt.ContrastivePredictionTemporal(q_mod, t_mod, None, 1, 128, 0.1, W, S, 0.3, mini_batchsize=8,
+                                              enc_arch="slowfast", img_size=224).to(dev).eval()
+    args = SimpleNamespace(vdata=None, adata=None, dadata=None, subsample_rate=1, fps=4, stride=S, window=W,
+                           enc_arch="slowfast", img_size=224, model_type=1, mini_batchsize=8, threshold=0.3, alpha=0.5,
+                           temp=0.1, driving_audio=None, da_feats="VGG", interpolation=False, new_video_length=12,
+                           results_folder=None, logname="exp", batch_size=24, stitch_mode="aligned", enc_batch=8,
+                           enc_impl="mfma")
+    np.random.seed(7)
+    frames = avt.validate(model, args, video_name="x", model_type=1, video=(video, 4.0))
+    assert "Frames list: " in capsys.readouterr().out and len(frames) >= 48
+    # oracle walk on the same tables
+    eng = TextureEngine(SlowFastMFMA(q_mod, dev), SlowFastMFMA(t_mod, dev), None, window=W, stride=S, temp=0.1,
+                        img_size=224, model_type=1, device=dev, enc_batch=8)
+    assert eng.set_video(video) == L
+    qv, tv = eng.build_tables()
+    qn, _, _ = cref.l2norm_rows(qv.cpu().numpy(), want_split=False)
+    tn, _, _ = cref.l2norm_rows(tv.cpu().numpy(), want_split=False)
+    sim = cref.sim_f32(qn, tn, 0.1)
+
+    def row_fn(q):
+        o = cref.row_transition(sim[q : q + 1], q_ids=np.array([q]), n_seg=L, threshold=0.3, cap=L)
+        return o["idx"][0, : o["cnt"][0]], ref_py.target_segment_ids(q, L)
+
+    ref_frames, _, _ = ref_py.stitch_walk(row_fn, len(video), W, S, 48, q_id=10, rng=np.random.RandomState(7))
+    assert frames == ref_frames
