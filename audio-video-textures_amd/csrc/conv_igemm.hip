@@ -22,6 +22,8 @@
 //   <256, 32>: 4x1 waves, wave tile 64(m) x 32(n)      — fast-pathway layers with few channels
 // LDS rows are padded to 144 B (conflict-free ds_read_b128, see sim_gemm.hip).  Roofline: MFMA for the wide
 // 3x3 layers, HBM for the 1x1x1 / few-channel layers (bytes = activations in + out (+ residual)).
+#include <stdlib.h>
+
 #include "avt_common.h"
 
 namespace {
@@ -75,15 +77,22 @@ struct ConvArgs {
 // waves per SIMD to keep: the register budget the allocator may use follows from it (guide §6 G1)
 #define AVT_CONV_MIN_WAVES(BM, BN) ((BM) == 128 ? 3 : ((BN) == 64 ? 2 : 4))
 
-template <int BM, int BN>
+// GLDS = true: operand slabs go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write),
+// two LDS stages, ONE barrier per K-step.  The LDS image must then be lane-linear (1 KiB per wave-instruction =
+// 8 rows x 128 B, unpadded), so the bank-conflict fix is an XOR swizzle applied on the SOURCE side: the lane that
+// fills slot p of row r fetches K-chunk p ^ (r & 7), and fragment reads use the same XOR (guide rule 21).
+// Out-of-bounds / K-tail chunks are fetched from 16 zero bytes kept behind the tap table.
+template <int BM, int BN, bool GLDS>
 __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int RSTR = GLDS ? 128 : LSTR;  // LDS row stride of an operand slab
   constexpr int WAVES_M = BM / 64;
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WN = BN / WAVES_N;  // wave tile width in n
   constexpr int NT = WN / 32, MT = 2;
   constexpr int AU = BM / 32, BU = BN / 32;  // 16-byte chunks per thread per K-step
-  constexpr int A_BYTES = BM * LSTR;
-  constexpr int ESTR = BN * 2 + 16;  // epilogue staging row stride (bytes)
+  constexpr int A_BYTES = BM * RSTR;
+  constexpr int STAGE = (BM + BN) * RSTR;  // one K-step of both operands
+  constexpr int ESTR = BN * 2 + 16;        // epilogue staging row stride (bytes)
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   const int bid = blockIdx.x;
@@ -96,7 +105,10 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int lr = lane & 31, lh = lane >> 5;
-  const int c16 = tid & 7, r0 = tid >> 3;
+  const int r0 = tid >> 3;
+  // K-chunk this thread stages: GLDS fills LDS slot (tid & 7) of its rows with chunk slot ^ (row & 7); every row a
+  // thread touches has the same (row & 7) = (tid >> 3) & 7, so the chunk index is a per-thread constant either way
+  const int c16 = GLDS ? ((tid & 7) ^ ((tid >> 3) & 7)) : (tid & 7);
 
   // ---- per-row state of the A gather: base element offset and the bitmask of in-bounds taps
   int rowoff[AU];
@@ -136,36 +148,18 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  uint4 ra[AU], rb[BU];
-  auto gload = [&](int kt) {
-    const int2 e = a.ktab[kt * 8 + c16];  // {offset, tap bits: 1<<dt | 1<<(8+dh) | 1<<(16+dw)} or {0, -1}
-    const bool kin = e.y >= 0;
-#pragma unroll
-    for (int u = 0; u < AU; ++u) {
-      const bool ok = kin && ((rowmask[u] & (unsigned)e.y) == (unsigned)e.y);
-      ra[u] = ok ? *reinterpret_cast<const uint4*>(a.in + (rowoff[u] + e.x)) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    const int kc = (kt * 8 + c16) * 8;
-#pragma unroll
-    for (int u = 0; u < BU; ++u)
-      rb[u] = (kin && wrow[u] >= 0) ? *reinterpret_cast<const uint4*>(a.wt + (wrow[u] + kc)) : make_uint4(0u, 0u, 0u, 0u);
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int u = 0; u < AU; ++u) *reinterpret_cast<uint4*>(lds + (r0 + 32 * u) * LSTR + c16 * 16) = ra[u];
-#pragma unroll
-    for (int u = 0; u < BU; ++u) *reinterpret_cast<uint4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
-  };
-  const int arow = (wm * 64 + lr) * LSTR + lh * 16;
-  const int brow = A_BYTES + (wn * WN + lr) * LSTR + lh * 16;
-  auto compute = [&]() {
+  auto compute = [&](const char* st) {
+    const int xa = GLDS ? (lr & 7) : 0;  // swizzle key of this lane's fragment rows ((row & 7) = lr & 7)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 af[MT], wf[NT];
+      const int koff = GLDS ? (((ks * 2 + lh) ^ xa) * 16) : (ks * 32 + lh * 16);
 #pragma unroll
-      for (int j = 0; j < MT; ++j) af[j] = *reinterpret_cast<const bf16x8*>(lds + arow + j * 32 * LSTR + ks * 32);
+      for (int j = 0; j < MT; ++j)
+        af[j] = *reinterpret_cast<const bf16x8*>(st + (wm * 64 + j * 32 + lr) * RSTR + koff);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lds + brow + i * 32 * LSTR + ks * 32);
+      for (int i = 0; i < NT; ++i)
+        wf[i] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + (wn * WN + i * 32 + lr) * RSTR + koff);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -174,16 +168,67 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
     }
   };
 
-  gload(0);
-  lstore();
-  __syncthreads();
-  for (int kt = 0; kt < a.nk; ++kt) {
-    if (kt + 1 < a.nk) gload(kt + 1);
-    compute();
-    __syncthreads();
-    if (kt + 1 < a.nk) {
-      lstore();
+  if constexpr (GLDS) {
+    const uint16_t* zeros = reinterpret_cast<const uint16_t*>(a.ktab + a.nk * 8);  // 16 zero bytes (avt_conv3d_ktab)
+    auto stage = [&](int kt, char* st) {
+      const int2 e = a.ktab[kt * 8 + c16];
+      const bool kin = e.y >= 0;
+      const int kc = (kt * 8 + c16) * 8;
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const bool ok = kin && ((rowmask[u] & (unsigned)e.y) == (unsigned)e.y);
+        const uint16_t* src = ok ? a.in + (rowoff[u] + e.x) : zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(st + (32 * u + 8 * wid) * 128), 16, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < BU; ++u) {
+        const uint16_t* src = (kin && wrow[u] >= 0) ? a.wt + (wrow[u] + kc) : zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(st + A_BYTES + (32 * u + 8 * wid) * 128),
+                                         16, 0, 0);
+      }
+    };
+    stage(0, lds);
+    __syncthreads();  // (emits vmcnt(0) while LDS-DMA is in flight)
+    for (int kt = 0; kt < a.nk; ++kt) {
+      char* cur = lds + (kt & 1) * STAGE;
+      if (kt + 1 < a.nk) stage(kt + 1, lds + ((kt + 1) & 1) * STAGE);  // lands while this slab is multiplied
+      compute(cur);
       __syncthreads();
+    }
+  } else {
+    uint4 ra[AU], rb[BU];
+    auto gload = [&](int kt) {
+      const int2 e = a.ktab[kt * 8 + c16];  // {offset, tap bits: 1<<dt | 1<<(8+dh) | 1<<(16+dw)} or {0, -1}
+      const bool kin = e.y >= 0;
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const bool ok = kin && ((rowmask[u] & (unsigned)e.y) == (unsigned)e.y);
+        ra[u] = ok ? *reinterpret_cast<const uint4*>(a.in + (rowoff[u] + e.x)) : make_uint4(0u, 0u, 0u, 0u);
+      }
+      const int kc = (kt * 8 + c16) * 8;
+#pragma unroll
+      for (int u = 0; u < BU; ++u)
+        rb[u] = (kin && wrow[u] >= 0) ? *reinterpret_cast<const uint4*>(a.wt + (wrow[u] + kc)) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+      for (int u = 0; u < AU; ++u) *reinterpret_cast<uint4*>(lds + (r0 + 32 * u) * LSTR + c16 * 16) = ra[u];
+#pragma unroll
+      for (int u = 0; u < BU; ++u) *reinterpret_cast<uint4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
+    };
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < a.nk; ++kt) {
+      if (kt + 1 < a.nk) gload(kt + 1);
+      compute(lds);
+      __syncthreads();
+      if (kt + 1 < a.nk) {
+        lstore();
+        __syncthreads();
+      }
     }
   }
 
@@ -256,16 +301,23 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool GLDS>
 int launch(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
   a.nblk = tiles_m * a.tiles_n;
-  constexpr int lds_main = (BM + BN) * LSTR;
+  constexpr int lds_main = GLDS ? 2 * (BM + BN) * 128 : (BM + BN) * LSTR;
   constexpr int lds_epi = BM * (BN * 2 + 16);
   constexpr int lds_bytes = lds_main > lds_epi ? lds_main : lds_epi;
-  static_assert(lds_bytes <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
+  if (lds_bytes > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per kernel
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, GLDS>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+      avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+      return AVT_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, GLDS>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_bf16");
 }
 
@@ -276,7 +328,8 @@ extern "C" int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, in
   AVT_REQUIRE(kt > 0 && kh > 0 && kw > 0 && kt <= 8 && kh <= 8 && kw <= 8, "avt_conv3d_ktab: kernel extents must be 1..8");
   const int K = kt * kh * kw * cin;
   const int nk = (K + BK - 1) / BK;
-  AVT_REQUIRE(n_entries == nk * 8, "avt_conv3d_ktab: n_entries must be %d", nk * 8);
+  AVT_REQUIRE(n_entries == nk * 8 + 2, "avt_conv3d_ktab: n_entries must be %d", nk * 8 + 2);
+  ktab[2 * (nk * 8)] = ktab[2 * (nk * 8) + 1] = ktab[2 * (nk * 8) + 2] = ktab[2 * (nk * 8) + 3] = 0;  // the zero chunk
   const int cpt = cin / 8;
   for (int kc = 0; kc < nk * 8; ++kc) {
     if (kc * 8 < K) {
@@ -346,7 +399,15 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   a.dHo = make_fastdiv((uint32_t)a.Ho);
   a.dTo = make_fastdiv((uint32_t)a.To);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (cout <= 32) return launch<256, 32>(a, s);
-  if (cout <= 64) return launch<256, 64>(a, s);
-  return launch<128, 128>(a, s);
+  // LDS-DMA staging per tile shape: bit 0 = <128,128>, bit 1 = <256,64>, bit 2 = <256,32> (AVT_CONV_GLDS).
+  // Measured on MI355X, fused SlowFast, 64 clips (profiles/r01/probe_glds_ab.log): off 3009 clips/s, bit0 2767,
+  // bits0-1 2703, all 2532 -> OFF by default.  This single-stage-ahead form halves the resident workgroups
+  // (2 x 32 KB stages) and its unpadded image reads 2-way conflicted; register staging at 3 waves/SIMD wins.
+  static const int glds = []() {
+    const char* e = getenv("AVT_CONV_GLDS");
+    return e ? atoi(e) : 0;
+  }();
+  if (cout <= 32) return (glds & 4) ? launch<256, 32, true>(a, s) : launch<256, 32, false>(a, s);
+  if (cout <= 64) return (glds & 2) ? launch<256, 64, true>(a, s) : launch<256, 64, false>(a, s);
+  return (glds & 1) ? launch<128, 128, true>(a, s) : launch<128, 128, false>(a, s);
 }

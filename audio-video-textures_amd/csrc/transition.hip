@@ -177,6 +177,150 @@ __global__ __launch_bounds__(kThreads) void row_transition_kernel(TArgs a) {
   }
 }
 
+// ---- fast path: rows of up to 256*ITEMS entries live in registers ---------------------------------------------
+// Same arithmetic, same order of survivors; the row is read from HBM exactly once (coalesced: thread t owns
+// positions t, t+256, ...), every reduction is one shuffle tree + one LDS hop, and the ordered compaction needs a
+// single table of ITEMS x 4 ballot counts instead of one barrier round per 256 positions.
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
+  __shared__ BlockRed red;
+  __shared__ double red2[kThreads / 64];
+  __shared__ int cnt_tab[ITEMS * 4 + 1];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* x = a.sim + (int64_t)r * a.ld;
+  const float* xa = a.sim_a ? a.sim_a + (int64_t)r * a.ld_a : nullptr;
+  const bool perm = a.q_ids != nullptr;
+  const int n_seg = (int)a.n_seg;
+  const int q = perm ? (int)a.q_ids[r] : -1;
+  const int pos = q + 1 < n_seg - 1 ? q + 1 : n_seg - 1;
+  const int lo = q < pos ? q : pos, hi = q < pos ? pos : q;
+  const int L = perm ? (pos == q ? n_seg : n_seg - 1) : (int)a.nt;
+  auto col = [&](int i) {
+    if (!perm) return i;
+    if (i == 0) return pos;
+    int id = i - 1;
+    if (id >= lo) ++id;
+    if (hi != lo && id >= hi) ++id;
+    return id;
+  };
+  float v[ITEMS], va[ITEMS];
+  double s = 0.0, sa = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = tid + k * kThreads;
+    v[k] = 0.0f;
+    va[k] = 0.0f;
+    if (i < L) {
+      const int c = col(i);
+      v[k] = x[c];
+      s += (double)v[k];
+      if (xa) {
+        va[k] = xa[c];
+        sa += (double)va[k];
+      }
+    }
+  }
+  s = block_sum(s, red);
+  if (xa) sa = block_sum(sa, red);
+  const float sf = (float)s, saf = (float)sa;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = tid + k * kThreads;
+    float p = __fdiv_rn(v[k], sf);
+    if (xa) p = __fadd_rn(__fmul_rn(a.af, p), __fmul_rn(a.bf, __fdiv_rn(va[k], saf)));
+    v[k] = p;
+    if (i < L) mx = fmaxf(mx, p);
+  }
+  mx = block_max(mx, red);
+  const float cut = __fsub_rn(mx, __fmul_rn(a.threshold, mx));
+  double se = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = tid + k * kThreads;
+    if (i < L) {
+      se += (double)expf(v[k] - mx);
+      if (!(v[k] < cut)) s2 += (double)v[k];
+    }
+  }
+  // two sums in one LDS hop
+  se = avt::wave_sum(se);
+  s2 = avt::wave_sum(s2);
+  __syncthreads();
+  if (lane == 0) {
+    red.d[wid] = se;
+    red2[wid] = s2;
+  }
+  __syncthreads();
+  se = (red.d[0] + red.d[1]) + (red.d[2] + red.d[3]);
+  s2 = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+  const float s2f = (float)s2;
+  const float p0 = __shfl(v[0], 0, 64);  // position 0 lives in thread 0 (wave 0); broadcast below through LDS
+  // survivors: ballot per (round k, wave) -> exclusive offsets from one table
+  unsigned long long bal[ITEMS];
+  float pn[ITEMS];
+  double el = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = tid + k * kThreads;
+    pn[k] = 0.0f;
+    bool keep = false;
+    if (i < L && !(v[k] < cut) && v[k] != 0.0f) {
+      pn[k] = __fdiv_rn(v[k], s2f);
+      keep = pn[k] != 0.0f;
+    }
+    bal[k] = __ballot(keep);
+    if (keep) el += log((double)pn[k]);
+    if (lane == 0) cnt_tab[k * 4 + wid] = __popcll(bal[k]);
+  }
+  if (tid == 0) red.f[0] = p0;
+  __syncthreads();  // counts (and p0) are in LDS
+  {                 // exclusive scan of the ITEMS*4 counts (<= 64 entries) by wave 0; barriers stay uniform
+    constexpr int n = ITEMS * 4;
+    int c = 0, incl = 0;
+    if (wid == 0) {
+      c = lane < n ? cnt_tab[lane] : 0;
+      incl = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+    }
+    __syncthreads();
+    if (wid == 0) {
+      if (lane < n) cnt_tab[lane] = incl - c;
+      if (lane == n - 1) cnt_tab[n] = incl;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    if ((bal[k] >> lane) & 1ull) {
+      const int slot = cnt_tab[k * 4 + wid] + __popcll(bal[k] & ((1ull << lane) - 1ull));
+      if (slot < a.cap) {
+        const int i = tid + k * kThreads;
+        const int64_t o = (int64_t)r * a.cap + slot;
+        if (a.surv_idx) a.surv_idx[o] = i;
+        if (a.surv_seg) a.surv_seg[o] = col(i);
+        if (a.surv_p) a.surv_p[o] = pn[k];
+      }
+    }
+  }
+  const int cnt = cnt_tab[ITEMS * 4];
+  const float p_first = red.f[0];
+  el = block_sum(el, red);
+  if (tid == 0) {
+    if (a.surv_cnt) a.surv_cnt[r] = cnt;
+    if (a.stats) {
+      a.stats[r * 4 + 0] = sf;
+      a.stats[r * 4 + 1] = mx;
+      a.stats[r * 4 + 2] = (float)((double)mx + log(se) - (double)p_first);
+      a.stats[r * 4 + 3] = cnt ? (float)fabs(el / cnt) : 0.0f;
+    }
+  }
+}
+
 // ---- top-k ------------------------------------------------------------------
 struct KArgs {
   const float* sim;
@@ -272,7 +416,11 @@ extern "C" int avt_row_transition(const float* sim, int64_t nq, int64_t nt, int6
   a.stats = stats;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)nq), block(kThreads);
-  if (nt <= kMaxLds)
+  if (nt <= 8 * kThreads)
+    hipLaunchKernelGGL(row_transition_reg_kernel<8>, grid, block, 0, st, a);
+  else if (nt <= 16 * kThreads)
+    hipLaunchKernelGGL(row_transition_reg_kernel<16>, grid, block, 0, st, a);
+  else if (nt <= kMaxLds)
     hipLaunchKernelGGL(row_transition_kernel<true>, grid, block, (size_t)nt * sizeof(float), st, a);
   else
     hipLaunchKernelGGL(row_transition_kernel<false>, grid, block, 0, st, a);

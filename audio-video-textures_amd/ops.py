@@ -197,7 +197,7 @@ def softmax_ce_bwd(prob, label=None, scale=1.0):
 def conv3d_ktab(cin, kernel, h, w, ldi):
     """Host table of per-K-chunk tap offsets for avt_conv3d_igemm_bf16 (int32 [n_entries, 2])."""
     kt, kh, kw = kernel
-    n_entries = 8 * ((kt * kh * kw * cin + 63) // 64)
+    n_entries = 8 * ((kt * kh * kw * cin + 63) // 64) + 2  # + the 16 zero bytes the kernel reads for OOB chunks
     tab = np.empty((n_entries, 2), np.int32)
     _lib.check(_lib.lib().avt_conv3d_ktab(int(cin), kt, kh, kw, int(h), int(w), int(ldi), tab.ctypes.data, n_entries),
                "avt_conv3d_ktab")

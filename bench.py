@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--enc-dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--encoder", default="mfma", choices=["mfma", "miopen"],
                     help="mfma: hand-written implicit-GEMM convolutions (fused_slowfast); miopen: stock nn.Module")
-    ap.add_argument("--enc-batch", type=int, default=32)
+    ap.add_argument("--enc-batch", type=int, default=64)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"], help="similarity MFMA mode")
     ap.add_argument("--threshold", type=float, default=0.3)
     ap.add_argument("--frame-hw", type=int, default=128)
@@ -204,6 +204,7 @@ def main():
     add("l2norm_rows", "hbm", N * D * 4 + N * D * (4 + (4 if split else 0)), "GB/s", HBM_PEAK_GBS)
     add("sim_gemm_nt", "mfma", 2.0 * N * n_total * D, "TFLOP/s", MFMA_PEAK_TFLOPS[args.precision])
     add("row_transition", "hbm", N * n_total * 4.0, "GB/s", HBM_PEAK_GBS)
+    attach_pmc_traffic(kern, args)
     per_step_ms = {k["kernel"]: k["avg_ms"] * k["launches_per_step"] for k in kern}
     if conv_step_ms:
         per_step_ms["conv3d_igemm_bf16"] = conv_step_ms
@@ -235,6 +236,39 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(video, W, S, N, D, temp, args)
     print(json.dumps(out))
+
+
+def attach_pmc_traffic(kern, args):
+    """`traffic` = HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
+    runs of tools/pmc_kernels.py at these shapes, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes);
+    the committed summary is read here because counters cannot be collected inside a timed run."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_fetch_write_summary.json")
+    if not os.path.exists(path) or args.windows != 4096 or args.enc_batch != 64:
+        return
+    pmc = json.load(open(path))
+
+    def kb(prefix, key="mean"):
+        f = w = n = 0.0
+        for name, v in pmc.items():
+            if name.startswith("_") or prefix not in name:
+                continue
+            f += v.get("FETCH_SIZE", {}).get(key, 0.0)
+            w += v.get("WRITE_SIZE", {}).get(key, 0.0)
+            n += v.get("WRITE_SIZE", {}).get("launches", 0)
+        return (2.0 * f + w) * 1024.0, n
+
+    table = {"clip_pack": "clip_pack_nhwc4_kernel" if args.encoder == "mfma" else "clip_pack_kernel",
+             "l2norm_rows": "l2norm_vec4", "row_transition": "row_transition_kernel",
+             "sim_gemm_nt": {"f32": "sim_gemm_kernel<2", "bf16x3": "sim_gemm_kernel<1", "bf16": "sim_gemm_kernel<0"}[args.precision]}
+    for k in kern:
+        if k["kernel"] in table:
+            b, _ = kb(table[k["kernel"]])
+            k["traffic"] = b or None
+        elif k["kernel"] == "conv3d_igemm_bf16":
+            b, n = kb("conv_igemm_kernel", "total")
+            k["traffic"] = b / n if n else None  # average over the launches of a forward
+        if k["traffic"]:
+            k["traffic_source"] = "profiles/r01/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE)"
 
 
 def cpu_baseline(video, W, S, N, D, temp, args):

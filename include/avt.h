@@ -185,7 +185,8 @@ int avt_softmax_ce_bwd(const float* prob, const int64_t* label, int64_t b,
  *   out[m, 0:cout] = act(conv(in)[m] + bias (+ res[m, 0:cout])), act = ReLU when relu != 0.
  *   `out`/`res` may point INTO a wider row (channel slice of a concat buffer) via ldo/ldr.
  *   cin, cout, ld* multiples of 8; kernel extents 1..8.  ktab comes from avt_conv3d_ktab
- *   (HOST; 2*n_entries int32, n_entries = 8*ceil(kt*kh*kw*cin/64)), copied to the device.
+ *   (HOST; 2*n_entries int32, n_entries = 8*ceil(kt*kh*kw*cin/64) + 2: the table plus 16 zero
+ *   bytes the kernel fetches for out-of-bounds chunks), copied to the device.
  *   to/ho/wo: output extent; 0 = (x + 2p - k)/s + 1, a smaller value crops the far edge.
  * ---------------------------------------------------------------------- */
 int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, int ldi,

@@ -79,7 +79,7 @@ def test_clip_pack_plan_is_the_inverse_of_the_sample_table(avt):
 
 def test_conv_ktab(avt):
     tab = avt.ops.conv3d_ktab(16, (1, 3, 3), 10, 12, 16)
-    assert tab.shape == (8 * 3, 2)  # K = 144 -> 3 K-steps of 64
+    assert tab.shape == (8 * 3 + 2, 2)  # K = 144 -> 3 K-steps of 64, + 16 zero bytes
     kc = 5  # chunk 5: tap 2 (dh=0, dw=2), channels 8..15
     assert tab[kc, 1] == (1 | 1 << 8 | 1 << 18) and tab[kc, 0] == 2 * 16 + 8
-    assert (tab[18:, 1] == -1).all()
+    assert (tab[18:24, 1] == -1).all() and (tab[24:] == 0).all()

@@ -53,6 +53,8 @@ def _run(avt, dev, cin, cout, k, s, p, dims, relu, with_res, ld_extra=0):
     (8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 8, 12, 12)),        # fast pathway, 8 channels
     (32, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 16, 6, 6)),
     (512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 7, 7)),
+    (72, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 3, 9, 11)),      # wide tile (LDS-DMA path) with a K tail, ragged M
+    (24, 136, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 5, 6, 7)),       # 27 taps, Cout not a tile multiple
 ])
 @pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
 def test_conv_igemm_matches_torch(avt, dev, cin, cout, k, s, p, dims, relu, with_res):

@@ -36,10 +36,14 @@ def test_n4096_build_is_bit_exact(avt, dev):
             assert np.array_equal(sel["cnt"].cpu().numpy(), o["cnt"])
             assert np.array_equal(sel["seg"].cpu().numpy(), o["seg"])
             assert np.array_equal(sel["p"].cpu().numpy().view(np.uint32), o["p"].view(np.uint32))
-        if variant == "clustered":  # th=0 keeps exactly the planted successor (position 0 = segment q+1)
-            assert (sel["cnt"].cpu().numpy()[:-1] >= 1).all()
+        if variant == "clustered":
+            # th=0 keeps exactly the planted successor (position 0 = segment q+1) — on rows whose logit SUM is
+            # positive: the reference divides by the row sum whatever its sign (validate.py:524), and a negative
+            # sum flips the order, which oracle and kernel reproduce identically (checked bit for bit above)
             o0 = cref.row_transition(ref, q_ids=q_ids, threshold=0.0, cap=4)
-            assert (o0["seg"][:-1, 0] == q_ids[:-1] + 1).all() and (o0["cnt"][:-1] == 1).all()
+            pos_sum = o0["stats"][:-1, 0] > 0
+            assert pos_sum.mean() > 0.5
+            assert (o0["seg"][:-1, 0][pos_sum] == (q_ids[:-1] + 1)[pos_sum]).all() and (o0["cnt"][:-1][pos_sum] == 1).all()
         # bf16 MFMA modes stay within their stated error at full size
         s3 = avt.ops.sim_gemm_nt(qh, th, 0.1, "bf16x3", q_lo=ql, t_lo=tl)
         assert (s3 - sim).abs().max().item() < 1e-4  # << the 1e-3 contract

@@ -17,7 +17,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if row.get("Counter_Name") == c:
                 agg[row["Kernel_Name"][:90]].append(float(row["Counter_Value"]))
     for k, v in agg.items():
-        out.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v)}
+        out.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "total": sum(v)}
 json.dump(out, open("gpurun_out/pmc_summary.json", "w"), indent=1)
 for k, v in out.items():
     print(k, {c: round(x["mean"], 1) for c, x in v.items()})

@@ -26,5 +26,13 @@ for _ in range(3):
     ops.sim_gemm_nt(qh, th, 0.1, "bf16x3", q_lo=ql, t_lo=tl)
     ops.sim_gemm_nt(qh, th, 0.1, "bf16")
     ops.row_transition(sim, q_ids=q_ids, threshold=0.3, cap=64)
+# one fused-encoder forward at the bench batch (64 clips): the conv3d_igemm / maxpool launches of a forward
+from avtex.slowfast import SlowFast
+from avtex.fused_slowfast import SlowFastMFMA
+torch.manual_seed(0)
+enc = SlowFastMFMA(SlowFast(), dev)
+slow, fast = ops.clip_pack(video, starts, W, out_hw=224, dtype=torch.bfloat16, layout="ndhwc4")
+for _ in range(2):
+    enc.forward_ndhwc4(slow, fast)
 torch.cuda.synchronize()
 print("done")
