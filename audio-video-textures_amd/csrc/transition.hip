@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void row_transition_kernel(TArgs a) {
   double se = 0.0, s2 = 0.0;
   for (int64_t i = tid; i < L; i += kThreads) {
     const float v = getp(i);
-    se += (double)expf(v - mx);  // CE is a reporting value (validate.py:531): fp32 exp, fp64 sum
+    se += (double)__expf(v - mx);  // CE is a reporting value (validate.py:531): fast fp32 exp, fp64 sum
     if (!(v < cut)) s2 += (double)v;
   }
   se = block_sum(se, red);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
   for (int k = 0; k < ITEMS; ++k) {
     const int i = tid + k * kThreads;
     if (i < L) {
-      se += (double)expf(v[k] - mx);
+      se += (double)__expf(v[k] - mx);  // CE is a reporting value: fast exp, fp64 sum
       if (!(v[k] < cut)) s2 += (double)v[k];
     }
   }

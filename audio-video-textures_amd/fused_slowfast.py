@@ -55,15 +55,42 @@ def fold_bn(conv, bn):
     return w, bias
 
 
+def group_weights_w(w, g):
+    """Few-channel layers: treat g adjacent pixels along W as g*C channels (same bytes in NDHWC), so a 16-byte chunk
+    and an MFMA tile are full instead of mostly padding, and the GEMM has g times fewer rows to decode and gather.
+    w [Cout, Cin, kt, kh, kw] (stride_w 1, pad_w kw//2) -> block-Toeplitz [g*Cout, g*Cin, kt, kh, kw'] over pixel
+    GROUPS, kw' = 1 + 2*ceil((kw//2)/g); the MFMA work per pixel does not grow (structured zeros replace padding)."""
+    cout, cin, kt, kh, kw = w.shape
+    r = kw // 2
+    rg = -(-r // g)  # groups of halo on each side
+    kwg = 1 + 2 * rg
+    wg = torch.zeros((g, cout, g, cin, kt, kh, kwg))  # [po, n, pi, c, dt, dh, dg]
+    for po in range(g):
+        for dg in range(kwg):
+            for pi in range(g):
+                dw = g * (dg - rg) + pi - po + r
+                if 0 <= dw < kw:
+                    wg[po, :, pi, :, :, :, dg] = w[:, :, :, :, dw]
+    return wg.reshape(g * cout, g * cin, kt, kh, kwg), rg
+
+
 class FusedConv:
-    def __init__(self, conv, bn, relu, device, packed=None):
-        """packed = (wt [Cout, taps*Cin] fp32, bias, cin, kernel, stride, pad, crop) overrides the module."""
+    def __init__(self, conv, bn, relu, device, packed=None, folded=None):
+        """packed = (wt [Cout, taps*Cin] fp32, bias, cin, kernel, stride, pad, crop) overrides the module;
+        folded = (w [Cout,Cin,kt,kh,kw] fp32, bias, stride, pad) is a BN-folded weight in conv layout."""
         self.crop = (0, 0, 0)
+        self._folded = None
+        self._grouped = {}
         if packed is None:
-            w, bias = fold_bn(conv, bn)
-            self.kernel, self.stride, self.pad = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
+            if folded is None:
+                w, bias = fold_bn(conv, bn)
+                self.stride, self.pad = tuple(conv.stride), tuple(conv.padding)
+            else:
+                w, bias, self.stride, self.pad = folded
+            self.kernel = tuple(w.shape[2:])
             self.cin, cout = w.shape[1], w.shape[0]
             wt = w.permute(0, 2, 3, 4, 1).reshape(cout, -1)
+            self._folded = (w, bias)
         else:
             wt, bias, self.cin, self.kernel, self.stride, self.pad, self.crop = packed
             cout = wt.shape[0]
@@ -82,9 +109,41 @@ class FusedConv:
         o = [(n + 2 * p - k) // s + 1 - c for n, p, k, s, c in zip((t, h, w), self.pad, self.kernel, self.stride, self.crop)]
         return (b, o[0], o[1], o[2])
 
+    def group_factor(self, x, out, res):
+        """Pixel-group factor along W for few-channel layers (see group_weights_w); 1 = plain."""
+        if self._folded is None or self.stride[2] != 1 or self.pad[2] != self.kernel[2] // 2:
+            return 1
+        if x.ld != x.C or x.c0 or (out is not None and (out.ld != out.C or out.c0)) or \
+                (res is not None and (res.ld != res.C or res.c0)):
+            return 1  # channel slices of wider rows cannot be re-viewed
+        small = min(self.cin, self.cout)
+        g = 4 if small <= 16 else (2 if small <= 32 else 1)
+        while g > 1 and x.dims[3] % g:
+            g //= 2
+        return g
+
     def __call__(self, x, out=None, res=None, relu=None):
         if x.C != self.cin:
             raise AvtError("FusedConv: input has %d channels, conv expects %d" % (x.C, self.cin))
+        g = self.group_factor(x, out, res)
+        if g > 1:
+            sub = self._grouped.get(g)
+            if sub is None:
+                w, bias = self._folded
+                wg, rg = group_weights_w(w, g)
+                sub = FusedConv(None, None, self.relu, self.dev,
+                                folded=(wg, bias.repeat(g), self.stride, (self.pad[0], self.pad[1], rg)))
+                sub._folded = None  # never re-group
+                self._grouped[g] = sub
+            b, t, h, w_ = x.dims
+            od = self.out_dims(x.dims)
+            m_out = od[0] * od[1] * od[2] * od[3]
+            if out is None:
+                out = Act(torch.empty((m_out, self.cout), dtype=torch.bfloat16, device=self.dev), od)
+            view = lambda a, d, c: Act(a.buf.view(-1, g * c), (d[0], d[1], d[2], d[3] // g))
+            sub(view(x, x.dims, self.cin), out=view(out, od, self.cout),
+                res=view(res, od, self.cout) if res is not None else None, relu=relu)
+            return out
         key = (x.dims[2], x.dims[3], x.ld)
         tab = self._tabs.get(key)
         if tab is None:

@@ -67,14 +67,19 @@ def compat_window_frames(q_id, n_frames, W, S, mbs, n_gpus):
 
 
 class TextureEngine:
+    # per-channel statistics of the reference's non-SlowFast transform (validate.py:90-92, dataset.py:50-52)
+    GENERIC_MEAN = (0.4345, 0.4051, 0.3775)
+    GENERIC_STD = (0.2768, 0.2713, 0.2737)
+
     def __init__(self, q_encoder, t_encoder, audio_encoder=None, *, window, stride, temp=0.1, img_size=224,
-                 model_type=1, device=None, enc_batch=32, mean=0.45, std=0.225):
+                 model_type=1, device=None, enc_batch=32, mean=0.45, std=0.225, enc_arch="slowfast"):
         self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.dev.type != "cuda":
             raise AvtError("TextureEngine needs an MI355X device; the hot path has no CPU fallback")
         self.q_enc, self.t_enc, self.a_enc = q_encoder, t_encoder, audio_encoder
         self.W, self.S, self.temp, self.hw = int(window), int(stride), float(temp), int(img_size)
         self.model_type = model_type
+        self.slowfast = enc_arch == "slowfast"  # else: plugin encoders taking [B,C,T,H,W] (models.py:253-260)
         self.enc_batch = int(enc_batch)
         self.mean, self.std = mean, std
         p = next(q_encoder.parameters(), None)
@@ -100,6 +105,16 @@ class TextureEngine:
         self.N = num_segments(self.F, self.W, self.S)
         # one all-zero frame appended for the zero padding of the compat path (utils.py:252)
         self._frames_pad = torch.cat([self.frames, torch.zeros_like(self.frames[:1])], 0)
+        if not self.slowfast:
+            # validate.py:85-93, 116-118: ToPILImage/Resize/ToTensor/Normalize per frame, RGB.  Device torch ops; the
+            # resize (only when the frame is not img_size already) is antialiased bilinear like PIL's — unpinned.
+            x = self.frames.permute(0, 3, 1, 2).float() / 255
+            if x.shape[-2:] != (self.hw, self.hw):
+                x = torch.nn.functional.interpolate(x, size=(self.hw, self.hw), mode="bilinear", antialias=True)
+            m = torch.tensor(self.GENERIC_MEAN, device=self.dev).view(1, 3, 1, 1)
+            sd = torch.tensor(self.GENERIC_STD, device=self.dev).view(1, 3, 1, 1)
+            x = ((x - m) / sd).to(self.pack_dtype)
+            self._norm_pad = torch.cat([x, torch.zeros_like(x[:1])], 0)  # padding is zero AFTER the transform
         return self.N
 
     def set_audio(self, audio_eg, driving_eg=None, da_encoder=None):
@@ -140,6 +155,19 @@ class TextureEngine:
         """Packs each window ONCE and runs every encoder in `encoders` on it -> list of fp32 [n,D]."""
         n = len(starts) if starts is not None else len(ids)
         outs = [[] for _ in encoders]
+        if not self.slowfast:
+            if ids is None:
+                ids = np.asarray(starts, np.int64)[:, None] + np.arange(self.W)[None, :]
+            with torch.no_grad():
+                for i in range(0, n, self.enc_batch):
+                    part = np.asarray(ids[i : i + self.enc_batch], np.int64)
+                    flat = torch.from_numpy(np.where(part < 0, self.F, part).reshape(-1)).to(self.dev)
+                    x = self._norm_pad.index_select(0, flat).view(len(part), self.W, 3, self.hw, self.hw)
+                    x = x.permute(0, 2, 1, 3, 4).contiguous()  # (B,window,C,H,W) -> (B,C,window,H,W), models.py:332
+                    for k, enc in enumerate(encoders):
+                        outs[k].append(enc(x).float().view(len(part), -1))
+                    self.encoded += len(part) * len(encoders)
+            return [torch.cat(o, 0).contiguous() for o in outs]
         with torch.no_grad():
             for i in range(0, n, self.enc_batch):
                 if starts is not None:

@@ -99,9 +99,6 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
     batch_time, losses, accs = AverageMeter(), AverageMeter(), AverageMeter()
     model.eval()
     net = _unwrap(model)
-    if getattr(args, "enc_arch", "slowfast") != "slowfast":
-        raise AvtError("validate(): the encode-once stitch path is built for the SlowFast plugin contract "
-                       "([slow, fast] -> [B,D]); register other encoders under that contract (ModelBuilder3D.register)")
     S, W = args.stride, args.window
     dev = next(net.parameters()).device
     if dev.type != "cuda":
@@ -190,7 +187,8 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
     eng = texture.TextureEngine(q_enc, t_enc, getattr(net, "t_a_encoder", None),
                                 window=W, stride=S, temp=net.temp, img_size=args.img_size,
                                 model_type=net.model_type, device=dev,
-                                enc_batch=getattr(args, "enc_batch", 32))
+                                enc_batch=getattr(args, "enc_batch", 32),
+                                enc_arch=getattr(args, "enc_arch", "slowfast"))
     assert eng.set_video(input_video) == L
     if net.model_type == 2 or driving_audio_name is not None:
         if audio_eg.dim() != 4:

@@ -13,7 +13,7 @@ import torch
 from oracle import cref, ref_py
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from tiny_encoders import TinySlowFast, checksum, seeded  # noqa: E402
+from tiny_encoders import TinyR3D, TinySlowFast, checksum, seeded  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -29,8 +29,10 @@ def _model(avt, g, dev):
     th, alpha, temp = [float(x) for x in g["th_alpha_temp"]]
     vgg = seeded(avt.VGGish, s[2])
     assert abs(checksum(vgg) - g["enc_ck"][2]) < 1e-6
-    m = avt.ContrastivePredictionTemporal(seeded(TinySlowFast, s[0]), seeded(TinySlowFast, s[1]), vgg, 2, 128, temp, W,
-                                          S, th, mini_batchsize=mbs, enc_arch="slowfast", img_size=hw)
+    arch = str(g["arch"])
+    cls = TinySlowFast if arch == "slowfast" else TinyR3D
+    m = avt.ContrastivePredictionTemporal(seeded(cls, s[0]), seeded(cls, s[1]), vgg, 2, 128, temp, W,
+                                          S, th, mini_batchsize=mbs, enc_arch=arch, img_size=hw)
     return m.to(dev).eval()
 
 
@@ -38,13 +40,13 @@ def _args(g):
     n_frames, W, S, mbs, G, hw, L, nvl, fps, with_da = [int(x) for x in g["cfg"]]
     th, alpha, temp = [float(x) for x in g["th_alpha_temp"]]
     return SimpleNamespace(vdata=None, adata=None, dadata=None, subsample_rate=1, fps=fps, stride=S, window=W,
-                           enc_arch="slowfast", img_size=hw, model_type=2, mini_batchsize=mbs, threshold=th,
+                           enc_arch=str(g["arch"]), img_size=hw, model_type=2, mini_batchsize=mbs, threshold=th,
                            alpha=alpha, temp=temp, driving_audio=None, da_feats="VGG", interpolation=False,
                            new_video_length=nvl, results_folder=None, logname="exp", batch_size=24,
                            stitch_mode="compat", ref_num_gpus=G, enc_batch=16)
 
 
-@pytest.mark.parametrize("case", ["sf_th03", "sf_th00", "sf_g2", "sf_da"])
+@pytest.mark.parametrize("case", ["sf_th03", "sf_th00", "sf_g2", "sf_da", "r3d_th03"])
 def test_validate_reproduces_reference_frames_list(avt, dev, case, capsys):
     g = _gold(case)
     model, args = _model(avt, g, dev), _args(g)

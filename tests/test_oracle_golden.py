@@ -96,6 +96,7 @@ def test_g4_infonce_loss_and_gradient():
 
 # ------------------------------------------------------------------ G5 validate() end to end
 CASES = ["sf_th03", "sf_th00", "sf_g2", "sf_da"]
+ALL_CASES = CASES + ["r3d_th03"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -112,7 +113,7 @@ def test_g5_window_map_q3_q4(case):
         assert len(seg) == len(g["rows_pre"][step])
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", ALL_CASES)
 def test_g5_row_postprocess_and_walk(case):
     """validate.py:524-572 + :580-615 from the reference's raw logits: same rows, survivors, RNG draws, frames."""
     g = gold("g5_validate_%s.npz" % case)

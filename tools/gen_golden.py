@@ -301,7 +301,7 @@ def run_validate(validate_mod, name, args, n_frames, seed_video, seeds_enc, n_gp
     fr = fr[:, :, :, [2, 1, 0]]
     STATE.frame_lut = {f.numpy().tobytes(): i for i, f in enumerate(fr)}
     STATE.frame_lut[torch.zeros_like(fr[0]).numpy().tobytes()] = -1
-    STATE.win_log = []
+    STATE.win_log = [] if args.enc_arch == "slowfast" else None
     vgg_seed = seeds_enc[2]
     vgg = seeded(VGGish, vgg_seed)
     model = CPT(seeded(arch_cls, seeds_enc[0]), seeded(arch_cls, seeds_enc[1]), vgg, 2, 128, args.temp, args.window,
@@ -355,8 +355,11 @@ def run_validate(validate_mod, name, args, n_frames, seed_video, seeds_enc, n_gp
     # raw logits per step, assembled exactly as validate.py:481-493 does (we re-read them from the plotted row instead)
     pre = fake_plt.rows[0::2][:n_steps]
     post = fake_plt.rows[1::2][:n_steps]
-    per_step = len(STATE.win_log) // n_steps
-    wins = np.array(STATE.win_log, np.int64).reshape(n_steps, per_step, args.window)
+    if STATE.win_log is not None:
+        per_step = len(STATE.win_log) // n_steps
+        wins = np.array(STATE.win_log, np.int64).reshape(n_steps, per_step, args.window)
+    else:
+        wins = np.zeros(0, np.int64)
     calls_per_step = len(dp.calls) // n_steps
     raw = []
     for s in range(n_steps):
@@ -386,6 +389,9 @@ def gen_g5():
     run_validate(validate_mod, "sf_th00", base_args(threshold=0.0), 120, 5, (31, 32, 33), 1)
     run_validate(validate_mod, "sf_g2", base_args(threshold=0.3, mini_batchsize=6), 131, 6, (34, 35, 36), 2)
     run_validate(validate_mod, "sf_da", base_args(threshold=0.0), 120, 7, (37, 38, 39), 1, with_da=True)
+    # the non-SlowFast plugin path (enc_arch != "slowfast": transforms + [B,C,T,H,W] encoders + AdaptiveAvgPool3d)
+    run_validate(validate_mod, "r3d_th03", base_args(threshold=0.3, enc_arch="resnet18"), 120, 8, (41, 42, 43), 1,
+                 arch_cls=TinyR3D)
 
 
 # --------------------------------------------------------------------------- G6
