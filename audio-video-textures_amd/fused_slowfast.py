@@ -103,6 +103,9 @@ class FusedConv:
         self.bias = bias.float().contiguous().to(device)
         self.dev = device
         self._tabs = {}
+        # algorithmic flops per GEMM row (bench.py): the convolution's own 2*K*Cout; pixel-paired / grouped forms,
+        # whose packed K carries structured zeros, overwrite it with the flops of the convolution they compute
+        self.alg_flops_per_row = 2.0 * self.wt.shape[1] * cout
 
     def out_dims(self, dims):
         b, t, h, w = dims
@@ -134,6 +137,7 @@ class FusedConv:
                 sub = FusedConv(None, None, self.relu, self.dev,
                                 folded=(wg, bias.repeat(g), self.stride, (self.pad[0], self.pad[1], rg)))
                 sub._folded = None  # never re-group
+                sub.alg_flops_per_row = g * self.alg_flops_per_row
                 self._grouped[g] = sub
             b, t, h, w_ = x.dims
             od = self.out_dims(x.dims)
@@ -164,7 +168,7 @@ class FusedConv:
         else:
             m_out = od[0] * od[1] * od[2] * od[3]
             m_in = x.dims[0] * x.dims[1] * x.dims[2] * x.dims[3]
-            PROFILER("conv3d_igemm_bf16", launch, 2.0 * m_out * self.wt.shape[1] * self.cout,
+            PROFILER("conv3d_igemm_bf16", launch, m_out * self.alg_flops_per_row,
                      2.0 * (m_in * self.cin + m_out * self.cout * (2 if res is not None else 1)) + self.wt.numel() * 2)
         return out
 
@@ -194,10 +198,12 @@ def stem_conv(stem, device, tgroup=1):
                          packed=(wg.reshape(g * c, -1), bias.repeat(g), 8, (kt + g - 1, kh, 4), (g, 2, 1),
                                  (kt // 2, 3, 2), (0, 0, 1)))
         conv.tgroup, conv.frame_channels = g, c
+        conv.alg_flops_per_row = g * 2.0 * (kt * kh * kw * 3) * c
         return conv
     conv = FusedConv(None, None, True, device,
                      packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)))
     conv.tgroup, conv.frame_channels = 1, c
+    conv.alg_flops_per_row = 2.0 * (kt * kh * kw * 3) * c
     return conv
 
 

@@ -188,7 +188,8 @@ def main():
     conv_step_ms = 0.0
     if "conv3d_igemm_bf16" in ks:
         # the encoder's convolutions: many shapes, so "per launch" = sampled totals / sampled launches.
-        # algorithmic flops = 2*M*K*Cout of each launch as issued (K includes the stem's zero taps: +1.5 % overall)
+        # algorithmic flops = 2*M*K*Cout of the convolution each launch computes (the structured zeros of the
+        # pixel-paired / grouped weight forms are NOT counted): 100.6 GFLOP per clip per encoder in total
         n, avg_ms = ks["conv3d_igemm_bf16"]
         fl, by = timer.work["conv3d_igemm_bf16"]
         sampled_ms = n * avg_ms

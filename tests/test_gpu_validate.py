@@ -216,3 +216,31 @@ def test_validate_with_real_slowfast_on_mfma_encoder(avt, dev, capsys):
 
     ref_frames, _, _ = ref_py.stitch_walk(row_fn, len(video), W, S, 48, q_id=10, rng=np.random.RandomState(7))
     assert frames == ref_frames
+
+
+def test_sharded_build_single_rank_equals_engine(avt, dev):
+    """dist.sharded_transition_build (config 4 pipeline) at world 1 == the unsharded engine path, and a 2-way row
+    split of the same build gives the same survivors (no dependence on the shard boundary)."""
+    from avtex import dist as adist
+    from avtex.texture import TextureEngine
+
+    g = _gold("sf_th03")
+    n_frames, W, S, mbs, G, hw, L = [int(x) for x in g["cfg"][:7]]
+    m = _model(avt, g, dev)
+    eng = TextureEngine(m.q_encoder, m.t_encoder, None, window=W, stride=S, temp=0.1, img_size=hw, model_type=1,
+                        device=dev, enc_batch=16)
+    eng.set_video(torch.from_numpy(g["video"]))
+    sel, (lo, hi), sim = adist.sharded_transition_build(eng, L, 0.3, cap=L, precision="f32", rank=0, world=1)
+    assert (lo, hi) == (0, L)
+    eng.build_tables()
+    eng.normalise()
+    ref = eng.similarity("f32")
+    assert torch.equal(sim, ref)
+    full = eng.transitions(0.3, cap=L)
+    assert torch.equal(sel["seg"], full["seg"]) and torch.equal(sel["cnt"], full["cnt"])
+    for r in range(2):  # emulate two ranks in one process: rows [lo,hi) against the full (gathered) target table
+        lo, hi = adist.shard_range(L, r, 2)
+        q_ids = torch.arange(lo, hi, device=dev, dtype=torch.int64)
+        part = avt.ops.row_transition(avt.ops.sim_gemm_nt(eng.Qn[lo:hi].contiguous(), eng.Tn, 0.1, "f32"), q_ids=q_ids,
+                                      threshold=0.3, cap=L)
+        assert torch.equal(part["seg"], full["seg"][lo:hi]) and torch.equal(part["cnt"], full["cnt"][lo:hi])
