@@ -30,6 +30,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFFFF0u;  // byte offset beyond every buffer: the bounds check returns zeros
+constexpr int kMaxTabSteps = 128;        // tap table kept in LDS up to this many K-steps (8 KB)
 
 constexpr int LSTR = 144;  // LDS row stride (128 data bytes = 64 bf16 of K, + 16 pad)
 constexpr int BK = 64;
@@ -72,6 +75,7 @@ struct ConvArgs {
   int nk;
   int tiles_n, nblk;
   FastDiv dWo, dHo, dTo;
+  unsigned in_bytes, wt_bytes;  // extents for the buffer descriptors (hardware range check = free zero fill)
 };
 
 // waves per SIMD to keep: the register budget the allocator may use follows from it (guide §6 G1)
@@ -82,7 +86,7 @@ struct ConvArgs {
 // 8 rows x 128 B, unpadded), so the bank-conflict fix is an XOR swizzle applied on the SOURCE side: the lane that
 // fills slot p of row r fetches K-chunk p ^ (r & 7), and fragment reads use the same XOR (guide rule 21).
 // Out-of-bounds / K-tail chunks are fetched from 16 zero bytes kept behind the tap table.
-template <int BM, int BN, bool GLDS>
+template <int BM, int BN, bool GLDS, bool TABLDS>
 __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int RSTR = GLDS ? 128 : LSTR;  // LDS row stride of an operand slab
   constexpr int WAVES_M = BM / 64;
@@ -198,26 +202,46 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
       __syncthreads();
     }
   } else {
-    uint4 ra[AU], rb[BU];
+    // Buffer loads (SRSRC + 32-bit byte offset): padding taps, rows past M and the K tail get an offset beyond the
+    // descriptor's extent and the hardware range check returns zeros.  The selects are written as bit arithmetic so
+    // the K loop has no branch and no exec masking, and the tap table is read from LDS (filled once per workgroup):
+    // a global read of it would put a dependent ~500-cycle L2 round trip in front of every K-step's loads.
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+    int2* ltab = reinterpret_cast<int2*>(lds + STAGE);  // [nk*8] behind the operand slabs (when it fits)
+    if constexpr (TABLDS) {
+      for (int i = tid; i < a.nk * 8; i += 256) ltab[i] = a.ktab[i];
+    }
+    unsigned wsel[BU];  // all-ones where the weight row exists
+#pragma unroll
+    for (int u = 0; u < BU; ++u) wsel[u] = wrow[u] >= 0 ? 0xFFFFFFFFu : 0u;
+    i32x4 ra[AU], rb[BU];
     auto gload = [&](int kt) {
-      const int2 e = a.ktab[kt * 8 + c16];  // {offset, tap bits: 1<<dt | 1<<(8+dh) | 1<<(16+dw)} or {0, -1}
-      const bool kin = e.y >= 0;
+      // {offset, tap bits}; chunks past K carry bit 31, which no row mask has -> never "ok"
+      const int2 e = TABLDS ? ltab[kt * 8 + c16] : a.ktab[kt * 8 + c16];
+      const unsigned ebits = (unsigned)e.y;
 #pragma unroll
       for (int u = 0; u < AU; ++u) {
-        const bool ok = kin && ((rowmask[u] & (unsigned)e.y) == (unsigned)e.y);
-        ra[u] = ok ? *reinterpret_cast<const uint4*>(a.in + (rowoff[u] + e.x)) : make_uint4(0u, 0u, 0u, 0u);
+        const unsigned sel = ((rowmask[u] & ebits) == ebits) ? 0xFFFFFFFFu : 0u;
+        const unsigned off = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
+        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0);
       }
-      const int kc = (kt * 8 + c16) * 8;
+      const unsigned ksel = ~(unsigned)(e.y >> 31);  // all-ones for chunks inside K
+      const unsigned kc2 = (unsigned)((kt * 8 + c16) * 16);
 #pragma unroll
-      for (int u = 0; u < BU; ++u)
-        rb[u] = (kin && wrow[u] >= 0) ? *reinterpret_cast<const uint4*>(a.wt + (wrow[u] + kc)) : make_uint4(0u, 0u, 0u, 0u);
+      for (int u = 0; u < BU; ++u) {
+        const unsigned sel = ksel & wsel[u];
+        const unsigned off = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
+        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rwt, (int)off, 0, 0);
+      }
     };
     auto lstore = [&]() {
 #pragma unroll
-      for (int u = 0; u < AU; ++u) *reinterpret_cast<uint4*>(lds + (r0 + 32 * u) * LSTR + c16 * 16) = ra[u];
+      for (int u = 0; u < AU; ++u) *reinterpret_cast<i32x4*>(lds + (r0 + 32 * u) * LSTR + c16 * 16) = ra[u];
 #pragma unroll
-      for (int u = 0; u < BU; ++u) *reinterpret_cast<uint4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
+      for (int u = 0; u < BU; ++u) *reinterpret_cast<i32x4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
     };
+    if constexpr (TABLDS) __syncthreads();
     gload(0);
     lstore();
     __syncthreads();
@@ -301,23 +325,24 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
   }
 }
 
-template <int BM, int BN, bool GLDS>
+template <int BM, int BN, bool GLDS, bool TABLDS = true>
 int launch(ConvArgs& a, hipStream_t st) {
+  if (!GLDS && TABLDS && a.nk > kMaxTabSteps) return launch<BM, BN, false, false>(a, st);  // table stays in global memory
   const int tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
   a.nblk = tiles_m * a.tiles_n;
-  constexpr int lds_main = GLDS ? 2 * (BM + BN) * 128 : (BM + BN) * LSTR;
+  constexpr int lds_main = GLDS ? 2 * (BM + BN) * 128 : (BM + BN) * LSTR + (TABLDS ? kMaxTabSteps * 8 * 8 : 0);
   constexpr int lds_epi = BM * (BN * 2 + 16);
   constexpr int lds_bytes = lds_main > lds_epi ? lds_main : lds_epi;
   if (lds_bytes > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per kernel
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, GLDS>),
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, GLDS, TABLDS>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) {
       avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
       return AVT_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, GLDS>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, GLDS, TABLDS>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_bf16");
 }
 
@@ -339,7 +364,7 @@ extern "C" int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, in
       ktab[2 * kc + 1] = (1 << dt) | (1 << (8 + dh)) | (1 << (16 + dw));
     } else {
       ktab[2 * kc] = 0;
-      ktab[2 * kc + 1] = -1;
+      ktab[2 * kc + 1] = -1;  // bit 31 (and every other bit) set: matches no row mask
     }
   }
   return AVT_OK;
@@ -391,8 +416,11 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   a.ldr = ldr;
   a.relu = relu;
   const int64_t M = (int64_t)batch * a.To * a.Ho * a.Wo;
-  AVT_REQUIRE(M < (1ll << 31) && (int64_t)batch * t * h * w * ldi < (1ll << 31) && M * (int64_t)ldo < (1ll << 62),
-              "avt_conv3d_igemm_bf16: tensor too large for 32-bit element offsets");
+  AVT_REQUIRE(M < (1ll << 31) && (int64_t)batch * t * h * w * ldi < (1ll << 31) - 64 && M * (int64_t)ldo < (1ll << 62) &&
+                  (int64_t)cout * a.K < (1ll << 31) - 64,
+              "avt_conv3d_igemm_bf16: tensor too large for 32-bit offsets");
+  a.in_bytes = (unsigned)((int64_t)batch * t * h * w * ldi * 2);
+  a.wt_bytes = (unsigned)((int64_t)cout * a.K * 2);
   a.M = (int)M;
   a.nk = (a.K + BK - 1) / BK;
   a.dWo = make_fastdiv((uint32_t)a.Wo);

@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.3)
     ap.add_argument("--frame-hw", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-stream", action="store_true", help="run the q and t encoders back to back on one stream")
     ap.add_argument("--cpu-clips", type=int, default=4)
     args = ap.parse_args()
 
@@ -135,9 +136,13 @@ def main():
                 if timer.on and len(pack_bytes) < 4096:
                     pack_bytes.append((hi - lo) * args.frame_hw * args.frame_hw * 3 +
                                       (slow.numel() + fast.numel()) * slow.element_size())
+                # every 8th batch runs on ONE stream with per-launch HIP events around the convolutions (the events
+                # must sit on the launching stream); all other batches run q and t encoders on two streams
                 timer.sample_conv = (i // args.enc_batch) % 8 == 0
-                outs[0].append(eng._run(q_enc, slow, fast))
-                outs[1].append(eng._run(t_enc, slow, fast))
+                eng.two_streams = not (timer.on and timer.sample_conv) and not args.one_stream
+                o = eng.run_encoders([q_enc, t_enc], slow, fast)
+                outs[0].append(o[0])
+                outs[1].append(o[1])
                 timer.sample_conv = False
         qv, tv = torch.cat(outs[0], 0), torch.cat(outs[1], 0)
         qn, qh, ql = timer.run("l2norm_rows", lambda: ops.l2norm_rows(qv, want_split=split))
@@ -226,6 +231,7 @@ def main():
                    "encoder": "SlowFast-8x8-R50 x2 (random init), %s" % (
                        "hand-written MFMA implicit-GEMM convolutions" if args.encoder == "mfma" else "MIOpen"),
                    "sim_precision": args.precision,
+                   "encoder_streams": 1 if args.one_stream else 2,
                    "parallelism": "windows sharded x%d, all-gather(T_hat)" % world if world > 1 else "single GPU"},
         "roofline": roof,
         "roofline_all": kern,
