@@ -21,28 +21,31 @@ for b in [int(x) for x in (sys.argv[1:] or ["16", "32"])]:
     for _ in range(n): y = m.forward_ndhwc4(slow, fast)
     torch.cuda.synchronize(); per = (time.time() - t0) / n
     print("fused batch=%d: %.4fs/batch -> %.1f clips/s, %.1f TFLOP/s" % (b, per, b / per, b * 100.6e9 / per / 1e12), flush=True)
-# per-layer timing
+# per-layer timing through the launch observer (leaf launches only)
+import avtex.fused_slowfast as fsf
 b = int(os.environ.get('PROBE_B', '16'))
 slow = torch.randn(b, 8, 224, 224, 4, device=dev, dtype=torch.bfloat16); fast = torch.randn(b, 32, 224, 224, 4, device=dev, dtype=torch.bfloat16)
 recs = []
-orig = FusedConv.__call__
-def timed(self, x, out=None, res=None, relu=None):
+def hook(name, launch, flops, nbytes):
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); o = orig(self, x, out=out, res=res, relu=relu); e.record()
-    od = self.out_dims(x.dims); M = od[0] * od[1] * od[2] * od[3]
-    K = self.kernel[0] * self.kernel[1] * self.kernel[2] * self.cin
-    byt = (x.dims[0] * x.dims[1] * x.dims[2] * x.dims[3] * self.cin + M * self.cout * (2 if res is not None else 1)) * 2
-    recs.append((a, e, "cin%d cout%d k%s s%s M%d" % (self.cin, self.cout, self.kernel, self.stride, M), 2.0 * M * K * self.cout, byt))
-    return o
-FusedConv.__call__ = timed
+    a.record(); launch(); e.record()
+    recs.append((a, e, flops, nbytes))
+shapes = []
+orig = avtex.ops.conv3d_igemm
+def spy(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu, out_dims=(0, 0, 0)):
+    shapes.append("cin%d cout%d k%s s%s in%s%s" % (cin, cout, kernel, stride, tuple(dims), " +res" if res_ptr else ""))
+    return orig(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu, out_dims)
+avtex.ops.conv3d_igemm = spy
+fsf.ops.conv3d_igemm = spy
+fsf.PROFILER = hook
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); y = m.forward_ndhwc4(slow, fast); e1.record(); torch.cuda.synchronize()
 tot = e0.elapsed_time(e1)
 agg = collections.OrderedDict()
-for a, e, name, fl, byt in recs:
+for (a, e, fl, byt), name in zip(recs, shapes):
     t = a.elapsed_time(e)
     d = agg.setdefault(name, [0, 0.0, 0.0, 0.0]); d[0] += 1; d[1] += t; d[2] += fl; d[3] += byt
 conv_ms = sum(v[1] for v in agg.values())
-print("batch %d" % b + " forward %.2f ms; conv launches %.2f ms (%d launches); stem+glue %.2f ms" % (tot, conv_ms, len(recs), tot - conv_ms))
+print("batch %d forward %.2f ms; conv launches %.2f ms (%d launches); pools+head+glue %.2f ms" % (b, tot, conv_ms, len(recs), tot - conv_ms))
 for name, (n, t, fl, byt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print("%6.3f ms x%d  %-48s %7.1f TF/s %7.0f GB/s" % (t, n, name, fl / t / 1e9, byt / t / 1e6))
+    print("%6.3f ms x%d  %-62s %7.1f TF/s %7.0f GB/s" % (t, n, name, fl / t / 1e9, byt / t / 1e6))
