@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
       keep = pn[k] != 0.0f;
     }
     bal[k] = __ballot(keep);
-    if (keep) el += log((double)pn[k]);
+    el += keep ? (double)__logf(pn[k]) : 0.0;  // entropy is a reporting value: fast fp32 log, no divergent fp64 libm
     if (lane == 0) cnt_tab[k * 4 + wid] = __popcll(bal[k]);
   }
   if (tid == 0) red.f[0] = p0;

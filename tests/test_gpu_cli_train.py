@@ -1,0 +1,68 @@
+"""The drop-in entry points on the MI355X: `main.py -e` (CLI -> main() -> validate() with the real SlowFast on the MFMA
+convolutions) and one epoch of `train()` (dataset -> operator training branch -> HIP InfoNCE criterion -> SGD)."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tiny_encoders import TinySlowFast, seeded  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _video(n=70, hw=48, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand((n // 6 + 2, hw, hw, 3), generator=g)
+    t = torch.linspace(0, n / 6, n)
+    i0 = t.floor().long()
+    fr = (t - i0.float()).view(-1, 1, 1, 1)
+    return (((1 - fr) * base[i0] + fr * base[i0 + 1]).clamp(0, 1) * 255).to(torch.uint8)
+
+
+def test_cli_evaluate_end_to_end(avt, dev, tmp_path, capsys, monkeypatch):
+    """python main.py -vdata DIR -vl clip -ea slowfast -e --resume CKPT ...: reference flags, .npz media."""
+    from avtex.main import cli
+    from avtex.slowfast import SlowFast
+
+    vdir = tmp_path / "videos"
+    vdir.mkdir()
+    np.savez(vdir / "clip.npz", video=_video().numpy(), fps=10.0)
+    torch.manual_seed(0)
+    model = avt.ContrastivePredictionTemporal(SlowFast(), SlowFast(), avt.VGGish(), 1, 128, enc_arch="slowfast")
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.uniform_(0.5, 1.0)
+    ckpt = tmp_path / "ckpt.pth.tar"
+    torch.save({"epoch": 3, "arch": "slowfast", "state_dict": model.state_dict(), "best_loss": 0.5}, ckpt)
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(11)
+    cli(["-vdata", str(vdir), "-vl", "clip", "-ea", "slowfast", "-m", "1", "-e", "-nintp", "-th", "0.3", "-temp", "0.1",
+         "-mbs", "6", "-nvl", "3", "--resume", str(ckpt), "--stitch_mode", "compat", "--ref_num_gpus", "1",
+         "--enc_batch", "8", "--logdir", str(tmp_path / "logs")])
+    out = capsys.readouterr().out
+    assert "Stride 2 Window 5" in out  # fps 10 -> W = ceil(10/2), S = ceil(10/5): the reference's override (Q10)
+    assert "=> loaded checkpoint" in out and "Frames list: " in out
+    frames = [int(x) for x in out.split("Frames list: ")[1].split("]")[0].strip(" [").split(",")]
+    assert len(frames) >= 30 and max(frames) < 70 and frames[:5] == list(range(frames[0], frames[0] + 5))
+
+
+def test_train_one_epoch(avt, dev):
+    """config 5 in miniature: AudioVideoSegments -> DataLoader -> train(): finite, decreasing InfoNCE loss."""
+    args = SimpleNamespace(vdata="/tmp", adata=None, n_negs=6, img_size=32, enc_arch="slowfast", window=0, stride=0,
+                           print_freq=100, log_freq=100)
+    torch.manual_seed(1)
+    ds = avt.AudioVideoSegments(args, "x", split="train", video=(_video(90, 32), 10.0))
+    assert (args.window, args.stride) == (5, 2)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=True, num_workers=0, drop_last=True)
+    model = avt.ContrastivePredictionTemporal(seeded(TinySlowFast, 1), seeded(TinySlowFast, 2), None, 1, 128, temp=0.1,
+                                              window=5, stride=2, enc_arch="slowfast", img_size=32).to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    np.random.seed(0)
+    losses = [avt.train(loader, model, opt, args, epoch) for epoch in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert losses[0] < np.log(7) * 1.5  # starts near log(1 + negs)

@@ -93,7 +93,7 @@ def _check_transition(g, o, cap):
         assert np.array_equal(gp[r, :k].view(np.uint32), o["p"][r, :k].view(np.uint32))
     gst, ost = g["stats"].cpu().numpy(), o["stats"]
     assert np.array_equal(gst[:, :2].view(np.uint32), ost[:, :2].view(np.uint32))  # row_sum, row_max exact
-    np.testing.assert_allclose(gst[:, 2:], ost[:, 2:], rtol=2e-6, atol=1e-6)  # ce, entropy (exp/log)
+    np.testing.assert_allclose(gst[:, 2:], ost[:, 2:], rtol=5e-6, atol=2e-6)  # ce, entropy: reporting values (fast exp/log)
 
 
 @pytest.mark.parametrize("th", [0.0, 0.3, 0.9])
