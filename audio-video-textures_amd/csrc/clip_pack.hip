@@ -245,8 +245,9 @@ extern "C" int avt_clip_pack_plan(const int32_t* win_start, int n_win, int win_l
 extern "C" int avt_clip_pack_u8(const uint8_t* frames, int n_frames, int height, int width, const int32_t* dst_off,
                                 const int32_t* dst_slot, int n_win, int out_hw, float mean, float std, int bgr,
                                 void* slow, void* fast, int out_dtype, void* stream) {
-  AVT_REQUIRE(frames && dst_off && dst_slot && slow && fast, "avt_clip_pack_u8: NULL pointer");
   AVT_REQUIRE(n_frames > 0 && height > 0 && width > 0 && out_hw > 0 && n_win >= 0, "avt_clip_pack_u8: bad sizes");
+  if (n_win == 0) return AVT_OK;
+  AVT_REQUIRE(frames && dst_off && dst_slot && slow && fast, "avt_clip_pack_u8: NULL pointer");
   AVT_REQUIRE(out_hw <= 2048, "avt_clip_pack_u8: out_hw > 2048");
   AVT_REQUIRE(std != 0.0f, "avt_clip_pack_u8: std == 0");
   AVT_REQUIRE(out_dtype == AVT_DT_F32 || out_dtype == AVT_DT_BF16, "avt_clip_pack_u8: unknown out_dtype %d", out_dtype);
@@ -291,8 +292,9 @@ extern "C" int avt_clip_pack_u8(const uint8_t* frames, int n_frames, int height,
 extern "C" int avt_clip_pack_u8_ndhwc4(const uint8_t* frames, int n_frames, int height, int width,
                                        const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw, float mean,
                                        float std, int bgr, void* slow, void* fast, void* stream) {
-  AVT_REQUIRE(frames && dst_off && dst_slot && slow && fast, "avt_clip_pack_u8_ndhwc4: NULL pointer");
   AVT_REQUIRE(n_frames > 0 && height > 0 && width > 0 && out_hw > 0 && n_win >= 0, "avt_clip_pack_u8_ndhwc4: bad sizes");
+  if (n_win == 0) return AVT_OK;
+  AVT_REQUIRE(frames && dst_off && dst_slot && slow && fast, "avt_clip_pack_u8_ndhwc4: NULL pointer");
   AVT_REQUIRE(out_hw <= 1020 && out_hw % 2 == 0, "avt_clip_pack_u8_ndhwc4: out_hw must be even and <= 1020");
   AVT_REQUIRE(std != 0.0f, "avt_clip_pack_u8_ndhwc4: std == 0");
   AVT_REQUIRE(avt::aligned16(slow) && avt::aligned16(fast), "avt_clip_pack_u8_ndhwc4: outputs must be 16-byte aligned");

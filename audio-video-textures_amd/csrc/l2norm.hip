@@ -123,11 +123,11 @@ __global__ __launch_bounds__(256) void l2norm_scalar(Src s, int64_t n, float eps
 
 extern "C" int avt_l2norm_rows(const float* x0, int d0, const float* x1, int d1, int64_t n, float eps, float* y_f32,
                                void* y_hi, void* y_lo, void* stream) {
-  AVT_REQUIRE(x0 && d0 > 0, "avt_l2norm_rows: x0 is NULL or d0 <= 0");
-  AVT_REQUIRE((x1 != nullptr) == (d1 > 0) && d1 >= 0, "avt_l2norm_rows: x1/d1 mismatch");
-  AVT_REQUIRE(n >= 0, "avt_l2norm_rows: n < 0");
+  AVT_REQUIRE(n >= 0 && d0 > 0 && d1 >= 0, "avt_l2norm_rows: bad sizes n=%lld d0=%d d1=%d", (long long)n, d0, d1);
+  if (n == 0) return AVT_OK;  // empty table: nothing to do (pointers may be NULL)
+  AVT_REQUIRE(x0, "avt_l2norm_rows: x0 is NULL");
+  AVT_REQUIRE((x1 != nullptr) == (d1 > 0), "avt_l2norm_rows: x1/d1 mismatch");
   AVT_REQUIRE(y_f32 || y_hi || y_lo, "avt_l2norm_rows: no output requested");
-  if (n == 0) return AVT_OK;
   Src s{x0, x1, d0, d1};
   const int d = d0 + d1;
   const bool vec = (d0 % 4 == 0) && (d1 % 4 == 0) && avt::aligned16(x0) && (!x1 || avt::aligned16(x1)) &&

@@ -235,9 +235,10 @@ int launch(const Args& a, bool aligned, hipStream_t st) {
 
 extern "C" int avt_sim_gemm_nt(const void* q, const void* q_lo, const void* t, const void* t_lo, int64_t nq,
                                int64_t nt, int d, float temp, int precision, float* out, int64_t ldo, void* stream) {
-  AVT_REQUIRE(q && t && out, "avt_sim_gemm_nt: NULL q/t/out");
   AVT_REQUIRE(nq >= 0 && nt >= 0 && d > 0, "avt_sim_gemm_nt: bad sizes nq=%lld nt=%lld d=%d", (long long)nq,
               (long long)nt, d);
+  if (nq == 0 || nt == 0) return AVT_OK;  // empty matrix (pointers may be NULL)
+  AVT_REQUIRE(q && t && out, "avt_sim_gemm_nt: NULL q/t/out");
   AVT_REQUIRE(ldo >= nt, "avt_sim_gemm_nt: ldo < nt");
   AVT_REQUIRE(temp != 0.0f, "avt_sim_gemm_nt: temp == 0");
   AVT_REQUIRE(precision == AVT_SIM_BF16 || precision == AVT_SIM_BF16X3 || precision == AVT_SIM_F32,

@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __rest
 
 extern "C" int avt_softmax_ce_fwd(const float* logits, int64_t b, int64_t c, const int64_t* label, float* loss,
                                   float* prob, void* stream) {
-  AVT_REQUIRE(logits && (loss || prob), "avt_softmax_ce_fwd: NULL pointer");
   AVT_REQUIRE(b >= 0 && c > 0, "avt_softmax_ce_fwd: bad sizes");
   if (b == 0) return AVT_OK;
+  AVT_REQUIRE(logits && (loss || prob), "avt_softmax_ce_fwd: NULL pointer");
   hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3((unsigned)((b + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), logits, b, c, label, loss, prob);
   return avt::check_launch("avt_softmax_ce_fwd");
@@ -52,9 +52,9 @@ extern "C" int avt_softmax_ce_fwd(const float* logits, int64_t b, int64_t c, con
 
 extern "C" int avt_softmax_ce_bwd(const float* prob, const int64_t* label, int64_t b, int64_t c, float scale,
                                   float* dlogits, void* stream) {
-  AVT_REQUIRE(prob && dlogits, "avt_softmax_ce_bwd: NULL pointer");
   AVT_REQUIRE(b >= 0 && c > 0, "avt_softmax_ce_bwd: bad sizes");
   if (b == 0) return AVT_OK;
+  AVT_REQUIRE(prob && dlogits, "avt_softmax_ce_bwd: NULL pointer");
   hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3((unsigned)((b * c + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), prob, label, b, c, scale, dlogits);
   return avt::check_launch("avt_softmax_ce_bwd");

@@ -389,9 +389,10 @@ extern "C" int avt_row_transition(const float* sim, int64_t nq, int64_t nt, int6
                                   int64_t n_seg, const float* sim_a, int64_t ld_a, float alpha, float threshold,
                                   int cap, int32_t* surv_idx, int32_t* surv_seg, float* surv_p, int32_t* surv_cnt,
                                   float* stats, void* stream) {
-  AVT_REQUIRE(sim, "avt_row_transition: sim is NULL");
   AVT_REQUIRE(nq >= 0 && nt > 0 && ld >= nt, "avt_row_transition: bad sizes nq=%lld nt=%lld ld=%lld", (long long)nq,
               (long long)nt, (long long)ld);
+  if (nq == 0) return AVT_OK;
+  AVT_REQUIRE(sim, "avt_row_transition: sim is NULL");
   AVT_REQUIRE(!q_ids || (n_seg == nt && n_seg >= 2), "avt_row_transition: with q_ids, nt must equal n_seg >= 2");
   AVT_REQUIRE(!sim_a || ld_a >= nt, "avt_row_transition: ld_a < nt");
   AVT_REQUIRE(cap >= 0 && (cap == 0 || surv_idx || surv_seg || surv_p), "avt_row_transition: cap/outputs mismatch");
@@ -429,8 +430,9 @@ extern "C" int avt_row_transition(const float* sim, int64_t nq, int64_t nt, int6
 
 extern "C" int avt_row_topk(const float* sim, int64_t nq, int64_t nt, int64_t ld, const int64_t* self_col, int k,
                             int32_t* top_idx, float* top_val, void* stream) {
-  AVT_REQUIRE(sim && top_idx && top_val, "avt_row_topk: NULL pointer");
   AVT_REQUIRE(nq >= 0 && nt > 0 && ld >= nt && k > 0, "avt_row_topk: bad sizes");
+  if (nq == 0) return AVT_OK;
+  AVT_REQUIRE(sim && top_idx && top_val, "avt_row_topk: NULL pointer");
   if (nt > kMaxLds) {
     avt::set_error("avt_row_topk: nt=%lld exceeds the LDS-resident row limit %d", (long long)nt, kMaxLds);
     return AVT_ERR_UNSUPPORTED;

@@ -93,7 +93,7 @@ class TextureEngine:
         self._rows = {"q": None, "t": None}
         self._nrows = {"q": 0, "t": 0}
         self.encoded = 0  # windows pushed through an encoder (both encoders counted)
-        self.two_streams = True
+        self.n_streams = 2
         self._streams = None
 
     # ---- inputs -------------------------------------------------------------------
@@ -154,25 +154,29 @@ class TextureEngine:
         return enc([slow, fast]).float()
 
     def run_encoders(self, encoders, slow, fast):
-        """Every encoder on the same packed clips.  Two encoders (query / target) run on two HIP streams: their
+        """Every encoder on the same packed clips.  Two encoders (query / target) run on separate HIP streams: their
         kernels are independent, and interleaving them fills the tail of each ~0.2 ms convolution launch with the
-        other encoder's workgroups (+13 % windows/s measured, bit-identical outputs)."""
-        if len(encoders) != 2 or not self.two_streams:
+        other encoder's workgroups (+8-13 % windows/s measured, bit-identical outputs).  self.n_streams = 4 also
+        splits the clip batch in halves (four independent forward chains)."""
+        if len(encoders) != 2 or self.n_streams <= 1:
             return [self._run(e, slow, fast) for e in encoders]
         main = torch.cuda.current_stream()
-        if self._streams is None:
-            self._streams = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
-        outs = []
-        for st, enc in zip(self._streams, encoders):
+        if self._streams is None or len(self._streams) < self.n_streams:
+            self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)]
+        parts = 2 if self.n_streams >= 4 and slow.shape[0] >= 2 else 1
+        sl, fa = slow.chunk(parts), fast.chunk(parts)
+        tasks = [(e, k) for k in range(parts) for e in range(2)]
+        outs = {}
+        for st, (e, k) in zip(self._streams, tasks):
             st.wait_stream(main)  # the clips were packed on `main`
             with torch.cuda.stream(st):
-                outs.append(self._run(enc, slow, fast))
+                outs[(e, k)] = self._run(encoders[e], sl[k], fa[k])
             slow.record_stream(st)
             fast.record_stream(st)
-        for st, o in zip(self._streams, outs):
+        for st, key in zip(self._streams, tasks):
             main.wait_stream(st)
-            o.record_stream(main)
-        return outs
+            outs[key].record_stream(main)
+        return [outs[(e, 0)] if parts == 1 else torch.cat([outs[(e, k)] for k in range(parts)], 0) for e in range(2)]
 
     def embed_windows(self, encoders, starts=None, ids=None):
         """Packs each window ONCE and runs every encoder in `encoders` on it -> list of fp32 [n,D]."""

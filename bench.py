@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.3)
     ap.add_argument("--frame-hw", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--one-stream", action="store_true", help="run the q and t encoders back to back on one stream")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 4],
+                    help="HIP streams for the q / t encoders (4 also splits each clip batch in halves)")
     ap.add_argument("--cpu-clips", type=int, default=4)
     args = ap.parse_args()
 
@@ -139,7 +140,7 @@ def main():
                 # every 8th batch runs on ONE stream with per-launch HIP events around the convolutions (the events
                 # must sit on the launching stream); all other batches run q and t encoders on two streams
                 timer.sample_conv = (i // args.enc_batch) % 8 == 0
-                eng.two_streams = not (timer.on and timer.sample_conv) and not args.one_stream
+                eng.n_streams = 1 if (timer.on and timer.sample_conv) else args.streams
                 o = eng.run_encoders([q_enc, t_enc], slow, fast)
                 outs[0].append(o[0])
                 outs[1].append(o[1])
@@ -231,7 +232,7 @@ def main():
                    "encoder": "SlowFast-8x8-R50 x2 (random init), %s" % (
                        "hand-written MFMA implicit-GEMM convolutions" if args.encoder == "mfma" else "MIOpen"),
                    "sim_precision": args.precision,
-                   "encoder_streams": 1 if args.one_stream else 2,
+                   "encoder_streams": args.streams,
                    "parallelism": "windows sharded x%d, all-gather(T_hat)" % world if world > 1 else "single GPU"},
         "roofline": roof,
         "roofline_all": kern,

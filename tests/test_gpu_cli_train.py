@@ -53,7 +53,7 @@ def test_cli_evaluate_end_to_end(avt, dev, tmp_path, capsys, monkeypatch):
 
 def test_train_one_epoch(avt, dev):
     """config 5 in miniature: AudioVideoSegments -> DataLoader -> train(): finite, decreasing InfoNCE loss."""
-    args = SimpleNamespace(vdata="/tmp", adata=None, n_negs=6, img_size=32, enc_arch="slowfast", window=0, stride=0,
+    args = SimpleNamespace(vdata="/tmp", adata=None, n_negs=10, img_size=32, enc_arch="slowfast", window=0, stride=0,
                            print_freq=100, log_freq=100)
     torch.manual_seed(1)
     ds = avt.AudioVideoSegments(args, "x", split="train", video=(_video(90, 32), 10.0))
@@ -65,4 +65,4 @@ def test_train_one_epoch(avt, dev):
     np.random.seed(0)
     losses = [avt.train(loader, model, opt, args, epoch) for epoch in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
-    assert losses[0] < np.log(7) * 1.5  # starts near log(1 + negs)
+    assert losses[0] < np.log(11) * 1.5  # starts near log(1 + negs); n_negs >= 8 as in the reference (dataset.py:190 needs room for the hard negatives)

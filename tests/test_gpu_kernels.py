@@ -189,3 +189,28 @@ def test_errors_are_loud(avt, dev):
         avt.ops.l2norm_rows(torch.zeros(4, 8))  # CPU tensor: no fallback
     with pytest.raises(avt._lib.AvtError):
         avt.ops.sim_gemm_nt(torch.zeros(4, 8, device=dev), torch.zeros(4, 8, device=dev), 0.0, "f32")  # temp == 0
+
+
+def test_empty_inputs_are_no_ops(avt, dev):
+    """Edge cases: zero rows / zero windows return empty results instead of faulting."""
+    z = torch.zeros((0, 64), device=dev)
+    y, _, _ = avt.ops.l2norm_rows(z)
+    assert y.shape == (0, 64)
+    t = torch.randn((5, 64), device=dev)
+    assert avt.ops.sim_gemm_nt(z, t, 0.1, "f32").shape == (0, 5)
+    assert avt.ops.sim_gemm_nt(t, z, 0.1, "f32").shape == (5, 0)
+    sel = avt.ops.row_transition(torch.zeros((0, 7), device=dev), threshold=0.3, cap=4)
+    assert sel["cnt"].shape == (0,)
+    frames = torch.zeros((30, 16, 16, 3), dtype=torch.uint8, device=dev)
+    s, f = avt.ops.clip_pack(frames, np.zeros(0, np.int32), 20, out_hw=32)
+    assert s.shape == (0, 3, 8, 32, 32) and f.shape == (0, 3, 32, 32, 32)
+
+
+def test_single_window_and_two_segment_rows(avt, dev):
+    """Smallest legal shapes: n_seg = 2 (row length 1 or 2) and a one-row similarity."""
+    sim = np.array([[0.5, 2.0], [3.0, 1.0]], np.float32)
+    q_ids = np.array([0, 1], np.int64)
+    o = cref.row_transition(sim, q_ids=q_ids, threshold=0.0, cap=2)
+    g = avt.ops.row_transition(torch.from_numpy(sim).to(dev), q_ids=torch.from_numpy(q_ids).to(dev), threshold=0.0, cap=2)
+    _check_transition(g, o, 2)
+    assert o["cnt"].tolist() == [1, 1] and o["seg"][0, 0] == 1  # q=0: only target is segment 1; q=1 (last): [self, 0]
