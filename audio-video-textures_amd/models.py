@@ -54,15 +54,35 @@ def similarity_logits(q_v, t_v, temp, q_a=None, t_a=None):
 
 
 class _InfoNCELogits(torch.autograd.Function):
-    """Training branch (models.py:385-417): autograd-visible normalise -> bmm -> /temp.
-    Round 1 keeps stock device ops here (a fused fwd+bwd kernel is SURVEY §8(f) rank 3)."""
+    """Training branch (models.py:385-417): normalise -> bmm -> /temp as ONE fused HIP kernel forward and one
+    backward (csrc/infonce.hip).  CPU tensors (unit tests of the module without a GPU) use the stock ops."""
+
+    @staticmethod
+    def forward(ctx, q, t, temp):
+        q, t = q.contiguous().float(), t.contiguous().float()
+        logits, inv_q, inv_t = ops.infonce_fwd(q, t, temp)
+        ctx.save_for_backward(q, t, logits, inv_q, inv_t)
+        ctx.temp = temp
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        q, t, logits, inv_q, inv_t = ctx.saved_tensors
+        dq, dt = ops.infonce_bwd(q, t, logits, g.float(), inv_q, inv_t, ctx.temp)
+        return dq, dt, None
 
     @staticmethod
     def apply_ops(q, t, temp):
-        q = F.normalize(q, dim=1).unsqueeze(1)
-        t = F.normalize(t, dim=2).permute(0, 2, 1)
-        out = torch.bmm(q, t).squeeze(1)
-        return out / temp, q, t
+        """-> (logits [B,n], q_hat [B,1,D], t_hat [B,D,n]); the unit vectors are only materialised for cam_viz."""
+        if q.is_cuda:
+            out = _InfoNCELogits.apply(q, t, temp)
+            with torch.no_grad():
+                qh = F.normalize(q, dim=1).unsqueeze(1)
+                th = F.normalize(t, dim=2).permute(0, 2, 1)
+            return out, qh, th
+        qh = F.normalize(q, dim=1).unsqueeze(1)
+        th = F.normalize(t, dim=2).permute(0, 2, 1)
+        return torch.bmm(qh, th).squeeze(1) / temp, qh, th
 
 
 class InfoNCECriterion(nn.Module):

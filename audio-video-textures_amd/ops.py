@@ -220,3 +220,27 @@ def maxpool_hw3s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo, tgroup=1):
     _lib.check(_lib.lib().avt_maxpool_hw3s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),
                                                        int(c), int(ldi), int(ldo), int(tgroup), _stream()),
                "avt_maxpool_hw3s2_ndhwc_bf16")
+
+
+# ---- fused training branch ----------------------------------------------------------------
+def infonce_fwd(q, t, temp, eps=1e-12):
+    """q [b,d], t [b,n,d] fp32 -> (logits [b,n], inv_q [b], inv_t [b,n])."""
+    _dev(q, "q", torch.float32)
+    _dev(t, "t", torch.float32)
+    b, n, d = t.shape
+    logits = torch.empty((b, n), dtype=torch.float32, device=q.device)
+    inv_q = torch.empty((b,), dtype=torch.float32, device=q.device)
+    inv_t = torch.empty((b, n), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().avt_infonce_fwd(_p(q), _p(t), b, n, d, float(temp), float(eps), _p(logits), _p(inv_q), _p(inv_t),
+                                          _stream()), "avt_infonce_fwd")
+    return logits, inv_q, inv_t
+
+
+def infonce_bwd(q, t, logits, dlogits, inv_q, inv_t, temp):
+    b, n, d = t.shape
+    dq = torch.empty_like(q)
+    dt = torch.empty_like(t)
+    _lib.check(_lib.lib().avt_infonce_bwd(_p(q), _p(t), _p(logits), _p(_dev(dlogits.contiguous(), "dlogits", torch.float32)),
+                                          _p(inv_q), _p(inv_t), b, n, d, float(temp), _p(dq), _p(dt), _stream()),
+               "avt_infonce_bwd")
+    return dq, dt

@@ -176,6 +176,22 @@ int avt_softmax_ce_bwd(const float* prob, const int64_t* label, int64_t b,
                        int64_t c, float scale, float* dlogits, void* stream);
 
 /* ------------------------------------------------------------------------
+ * infonce_fwd / infonce_bwd — the operator's TRAINING branch fused: replaces F.normalize(q,1),
+ *   F.normalize(t,2), torch.bmm and `/= temp` (models.py:351, 412-417 under :385-417) and their
+ *   autograd backward.  q [b,d], t [b,n,d] fp32 (unnormalised embeddings, audio already
+ *   concatenated by the caller), logits [b,n] = cos(q_b, t_bj)/temp with F.normalize's eps clamp.
+ *   fwd also writes the inverse norms inv_q [b], inv_t [b,n] that bwd consumes;
+ *   bwd: dlogits [b,n] -> dq [b,d], dt [b,n,d].
+ * ---------------------------------------------------------------------- */
+int avt_infonce_fwd(const float* q, const float* t, int64_t b, int n, int d,
+                    float temp, float eps, float* logits, float* inv_q,
+                    float* inv_t, void* stream);
+int avt_infonce_bwd(const float* q, const float* t, const float* logits,
+                    const float* dlogits, const float* inv_q, const float* inv_t,
+                    int64_t b, int n, int d, float temp, float* dq, float* dt,
+                    void* stream);
+
+/* ------------------------------------------------------------------------
  * conv3d_igemm_bf16 — the encoder's convolutions on the matrix cores.  Replaces the
  *   Conv3d + BatchNorm3d + ReLU (+ residual add, + lateral-fusion concat) sequence the
  *   reference executes through the third-party SlowFast model for every clip window

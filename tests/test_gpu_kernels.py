@@ -214,3 +214,21 @@ def test_single_window_and_two_segment_rows(avt, dev):
     g = avt.ops.row_transition(torch.from_numpy(sim).to(dev), q_ids=torch.from_numpy(q_ids).to(dev), threshold=0.0, cap=2)
     _check_transition(g, o, 2)
     assert o["cnt"].tolist() == [1, 1] and o["seg"][0, 0] == 1  # q=0: only target is segment 1; q=1 (last): [self, 0]
+
+
+@pytest.mark.parametrize("b,n,d", [(8, 15, 2304), (3, 5, 48), (2, 21, 14592), (1, 1, 7)])
+def test_infonce_fused_fwd_bwd_matches_autograd(avt, dev, b, n, d):
+    """Fused training branch (normalise -> bmm -> /temp) vs torch autograd in fp64 on the same inputs."""
+    torch.manual_seed(b * 100 + n)
+    q = torch.randn(b, d, device=dev, requires_grad=True)
+    t = torch.randn(b, n, d, device=dev, requires_grad=True)
+    g = torch.randn(b, n, device=dev)
+    out, _, _ = avt.models._InfoNCELogits.apply_ops(q, t, 0.1)
+    out.backward(g)
+    q64, t64 = q.detach().double().requires_grad_(), t.detach().double().requires_grad_()
+    ref = torch.bmm(torch.nn.functional.normalize(q64, dim=1).unsqueeze(1),
+                    torch.nn.functional.normalize(t64, dim=2).permute(0, 2, 1)).squeeze(1) / 0.1
+    ref.backward(g.double())
+    assert (out.detach().double() - ref.detach()).abs().max() < 2e-5
+    assert (q.grad.double() - q64.grad).abs().max() < 1e-5 * max(1.0, q64.grad.abs().max().item())
+    assert (t.grad.double() - t64.grad).abs().max() < 1e-5 * max(1.0, t64.grad.abs().max().item())
