@@ -40,6 +40,16 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
   return __uint_as_float((uint32_t)h << 16);
 }
+// two fp32 -> packed bf16x2 (low half = a) in ONE instruction: v_cvt_pk_bf16_f32, round-to-nearest-even, NaN stays
+// NaN — the same rounding as f32_to_bf16_rne (which costs ~6 VALU per value and dominated the HBM-bound epilogues).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf16x2_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16x2_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 // 64-lane wave reductions
 __device__ __forceinline__ double wave_sum(double v) {

@@ -45,7 +45,7 @@ struct Out<float> {
 };
 template <>
 struct Out<uint16_t> {
-  static __device__ __forceinline__ uint16_t cvt(float v) { return avt::f32_to_bf16_rne(v); }
+  static __device__ __forceinline__ uint16_t cvt(float v) { return (uint16_t)(avt::pack_bf16x2(v, 0.0f) & 0xffffu); }
 };
 
 // torch area_pixel_compute_source_index(scale, dst, align_corners=False, cubic=False)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void clip_pack_nhwc4_kernel(PArgs a) {
       const float p00 = lut[r0[xa * 3 + sc]], p01 = lut[r0[xb * 3 + sc]];
       const float p10 = lut[r1[xa * 3 + sc]], p11 = lut[r1[xb * 3 + sc]];
       const float o = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
-      v[j * 4 + c] = (x < a.hw) ? avt::f32_to_bf16_rne(o) : (uint16_t)0;
+      v[j * 4 + c] = (x < a.hw) ? (uint16_t)(avt::pack_bf16x2(o, 0.0f) & 0xffffu) : (uint16_t)0;
     }
     v[j * 4 + 3] = 0;
   }

@@ -76,6 +76,7 @@ struct ConvArgs {
   int tiles_n, nblk;
   FastDiv dWo, dHo, dTo;
   unsigned in_bytes, wt_bytes;  // extents for the buffer descriptors (hardware range check = free zero fill)
+  int pointwise;                // 1x1x1 / stride 1 / pad 0: rows need no decode
 };
 
 // waves per SIMD to keep: the register budget the allocator may use follows from it (guide §6 G1)
@@ -86,8 +87,10 @@ struct ConvArgs {
 // 8 rows x 128 B, unpadded), so the bank-conflict fix is an XOR swizzle applied on the SOURCE side: the lane that
 // fills slot p of row r fetches K-chunk p ^ (r & 7), and fragment reads use the same XOR (guide rule 21).
 // Out-of-bounds / K-tail chunks are fetched from 16 zero bytes kept behind the tap table.
-template <int BM, int BN, bool GLDS, bool TABLDS>
-__global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_kernel(ConvArgs a) {
+// EARLYRES: short-K layers with a residual (1x1x1 + skip connection, HBM-bound) request the residual chunks BEFORE the
+// K loop, so a workgroup exposes one memory latency instead of two; costs 32 more VGPRs, hence its own instantiation.
+template <int BM, int BN, bool GLDS, bool TABLDS, bool EARLYRES = false>
+__global__ __launch_bounds__(256, EARLYRES ? 2 : AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int RSTR = GLDS ? 128 : LSTR;  // LDS row stride of an operand slab
   constexpr int WAVES_M = BM / 64;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -122,7 +125,11 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
     const int m = m0 + r0 + 32 * u;
     rowoff[u] = 0;
     rowmask[u] = 0u;
-    if (m < a.M) {
+    if (m < a.M && a.pointwise) {
+      // 1x1x1, stride 1, no padding: output position == input position, its single tap is always in bounds
+      rowoff[u] = m * a.ldi;
+      rowmask[u] = 0x010101u;
+    } else if (m < a.M) {
       const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
       const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
       const int b = (int)fastdiv((uint32_t)t2, a.dTo), to = t2 - b * a.To;
@@ -151,6 +158,23 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
     for (int j = 0; j < MT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  constexpr int CPR = BN / 8;  // 16-byte chunks per output row
+  constexpr int EU = (BM * CPR) / 256;
+  const bool has_res = a.res != nullptr;
+  uint4 rres[EU];
+  auto prefetch_res = [&]() {
+    if (has_res) {
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c = tid + 256 * u;
+        const int m = m0 + c / CPR, n = n0 + (c % CPR) * 8;
+        rres[u] = (m < a.M && n < a.Cout) ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n)
+                                          : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  if constexpr (EARLYRES) prefetch_res();
 
   auto compute = [&](const char* st) {
     const int xa = GLDS ? (lr & 7) : 0;  // swizzle key of this lane's fragment rows ((row & 7) = lr & 7)
@@ -256,21 +280,9 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
     }
   }
 
-  // ---- epilogue.  The residual chunks this thread will need are requested FIRST, so their HBM latency
-  // overlaps the staging of the accumulators through LDS instead of serialising 8 round trips per thread.
-  constexpr int CPR = BN / 8;  // 16-byte chunks per output row
-  constexpr int EU = (BM * CPR) / 256;
-  const bool has_res = a.res != nullptr;
-  uint4 rres[EU];
-  if (has_res) {
-#pragma unroll
-    for (int u = 0; u < EU; ++u) {
-      const int c = tid + 256 * u;
-      const int m = m0 + c / CPR, n = n0 + (c % CPR) * 8;
-      rres[u] = (m < a.M && n < a.Cout) ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n)
-                                        : make_uint4(0u, 0u, 0u, 0u);
-    }
-  }
+  // ---- epilogue.  The residual chunks this thread will need are requested before the accumulators are staged
+  // through LDS (or, EARLYRES, before the K loop), so their HBM latency is not serialised behind the staging.
+  if constexpr (!EARLYRES) prefetch_res();
   // phase 1: (+bias [, relu]) -> bf16 -> LDS staging tile [m][n]
   // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n  -> regs 4g..4g+3 are 4 consecutive n
 #pragma unroll
@@ -291,8 +303,8 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
           v3 = fmaxf(v3, 0.f);
         }
         uint2 pk;
-        pk.x = avt::f32_to_bf16_rne(v0) | ((uint32_t)avt::f32_to_bf16_rne(v1) << 16);
-        pk.y = avt::f32_to_bf16_rne(v2) | ((uint32_t)avt::f32_to_bf16_rne(v3) << 16);
+        pk.x = avt::pack_bf16x2(v0, v1);
+        pk.y = avt::pack_bf16x2(v2, v3);
         const int ml = wm * 64 + j * 32 + lr;
         *reinterpret_cast<uint2*>(lds + ml * ESTR + nl * 2) = pk;
       }
@@ -311,13 +323,13 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
         const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rres[u]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x0 = avt::bf16_bits_to_f32((uint16_t)(pv[e] & 0xffffu)) + avt::bf16_bits_to_f32((uint16_t)(pr[e] & 0xffffu));
-          float x1 = avt::bf16_bits_to_f32((uint16_t)(pv[e] >> 16)) + avt::bf16_bits_to_f32((uint16_t)(pr[e] >> 16));
+          float x0 = avt::bf16x2_lo(pv[e]) + avt::bf16x2_lo(pr[e]);
+          float x1 = avt::bf16x2_hi(pv[e]) + avt::bf16x2_hi(pr[e]);
           if (a.relu) {
             x0 = fmaxf(x0, 0.f);
             x1 = fmaxf(x1, 0.f);
           }
-          pv[e] = avt::f32_to_bf16_rne(x0) | ((uint32_t)avt::f32_to_bf16_rne(x1) << 16);
+          pv[e] = avt::pack_bf16x2(x0, x1);
         }
       }
       *reinterpret_cast<uint4*>(a.out + (int64_t)m * a.ldo + n) = v;
@@ -325,9 +337,18 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_ke
   }
 }
 
-template <int BM, int BN, bool GLDS, bool TABLDS = true>
+template <int BM, int BN, bool GLDS, bool TABLDS = true, bool EARLYRES = false>
 int launch(ConvArgs& a, hipStream_t st) {
   if (!GLDS && TABLDS && a.nk > kMaxTabSteps) return launch<BM, BN, false, false>(a, st);  // table stays in global memory
+  if constexpr (!GLDS && TABLDS && !EARLYRES) {
+    static const bool early = []() {
+      // measured (profiles/r01/probe_earlyres_ab.log): 3158 vs 3358 clips/s — the 32 extra VGPRs cost a resident
+      // workgroup per SIMD, which hurts more than the second latency exposure: OFF unless AVT_CONV_EARLYRES=1
+      const char* e = getenv("AVT_CONV_EARLYRES");
+      return e ? atoi(e) != 0 : false;
+    }();
+    if (early && a.res && a.nk <= 2) return launch<BM, BN, false, true, true>(a, st);
+  }
   const int tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
   a.nblk = tiles_m * a.tiles_n;
@@ -335,14 +356,14 @@ int launch(ConvArgs& a, hipStream_t st) {
   constexpr int lds_epi = BM * (BN * 2 + 16);
   constexpr int lds_bytes = lds_main > lds_epi ? lds_main : lds_epi;
   if (lds_bytes > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per kernel
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, GLDS, TABLDS>),
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, GLDS, TABLDS, EARLYRES>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) {
       avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
       return AVT_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, GLDS, TABLDS>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, GLDS, TABLDS, EARLYRES>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_bf16");
 }
 
@@ -423,6 +444,8 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   a.wt_bytes = (unsigned)((int64_t)cout * a.K * 2);
   a.M = (int)M;
   a.nk = (a.K + BK - 1) / BK;
+  a.pointwise = (kt == 1 && kh == 1 && kw == 1 && st == 1 && sh == 1 && sw == 1 && pt == 0 && ph == 0 && pw == 0 &&
+                 a.To == t && a.Ho == h && a.Wo == w) ? 1 : 0;
   a.dWo = make_fastdiv((uint32_t)a.Wo);
   a.dHo = make_fastdiv((uint32_t)a.Ho);
   a.dTo = make_fastdiv((uint32_t)a.To);

@@ -30,8 +30,9 @@ __device__ __forceinline__ float load1(const Src& s, int64_t row, int k) {
 }
 
 __device__ __forceinline__ void store_split(float v, uint16_t& hi, uint16_t& lo) {
-  hi = avt::f32_to_bf16_rne(v);
-  lo = avt::f32_to_bf16_rne(v - avt::bf16_bits_to_f32(hi));
+  const uint32_t h = avt::pack_bf16x2(v, 0.0f);  // hardware RNE, same rounding as the oracle's software one
+  hi = (uint16_t)(h & 0xffffu);
+  lo = (uint16_t)(avt::pack_bf16x2(v - avt::bf16x2_lo(h), 0.0f) & 0xffffu);
 }
 
 template <bool CACHED>

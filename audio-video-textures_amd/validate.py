@@ -275,7 +275,7 @@ def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_
     out_dir = os.path.join(results_folder, "video_{}_{}".format(video_name, new_video_id))
     os.makedirs(out_dir)
     for count, idx in enumerate(new_frames):
-        Image.fromarray(np.array(video[idx])).save(os.path.join(out_dir, "{:04d}.png".format(count + 1)))
+        Image.fromarray(video[idx].numpy() if hasattr(video[idx], "numpy") else np.asarray(video[idx])).save(os.path.join(out_dir, "{:04d}.png".format(count + 1)))
     audio_file = ""
     if driving_audio_name is not None and driving_audio_w is not None:
         from scipy.io import wavfile
