@@ -267,7 +267,7 @@ def attach_pmc_traffic(kern, args):
         return (2.0 * f + w) * 1024.0, n
 
     table = {"clip_pack": "clip_pack_nhwc4_kernel" if args.encoder == "mfma" else "clip_pack_kernel",
-             "l2norm_rows": "l2norm_vec4", "row_transition": "row_transition_kernel",
+             "l2norm_rows": "l2norm_vec4", "row_transition": "row_transition_reg_kernel",
              "sim_gemm_nt": {"f32": "sim_gemm_kernel<2", "bf16x3": "sim_gemm_kernel<1", "bf16": "sim_gemm_kernel<0"}[args.precision]}
     for k in kern:
         if k["kernel"] in table:
@@ -298,8 +298,10 @@ def cpu_baseline(video, W, S, N, D, temp, args):
     torch.manual_seed(0)
     enc = SlowFast().eval()
     with torch.no_grad():
-        # one fp32 encoder forward is ~20 s of CPU work per clip: it is timed once (no separate warm-up, the first-call
-        # overhead is < 5 % of it) and counted twice, the q and t encoders being the same architecture
+        # one fp32 encoder forward is ~20 s of CPU work per clip once warm (the first call is ~4x slower: oneDNN
+        # primitive creation), so: one untimed warm-up, one timed forward, counted twice (q and t encoders are the
+        # same architecture)
+        enc([slow, fast])
         t0 = time.perf_counter()
         enc([slow, fast])
         t_enc = time.perf_counter() - t0
