@@ -9,19 +9,28 @@
 //     Wt = BN-folded weights packed [Cout, K] bf16 (K contiguous), bias = folded BN shift, fp32.
 //
 // Both operands have K contiguous per row, so a 16-byte chunk of A is 8 consecutive input channels of ONE tap:
-// the "im2col" is only an address computation (per-row base offset + per-K-chunk tap offset from a small table,
-// validity from a per-row bitmask of in-bounds taps) — nothing is materialised.  The MFMA is issued with the
-// weights as the first operand (D = Wt * A^T), so each lane ends up holding 4 CONSECUTIVE CHANNELS of one output
-// position: the epilogue packs them to bf16 (8 B), stages the tile through LDS, and writes / reads (residual)
-// global memory in 16-byte row-contiguous chunks.  BN, ReLU, residual add and the channel-slice write of the
-// lateral-fusion concat are all fused here, so every activation tensor crosses HBM once per consumer.
+// the "im2col" is only an address computation — per-row base offset + per-K-chunk tap offset from a small table
+// (copied to LDS once per workgroup) + a per-row separable bitmask of in-bounds taps.  Operands are fetched with
+// SRSRC buffer loads: padding taps, rows past M and the K tail get an offset beyond the descriptor's extent and the
+// hardware range check returns zeros, so the K loop has no branch and no exec masking.  Rows are decoded with
+// magic-number division (1x1x1 stride-1 layers skip the decode).
 //
-// Tiles (256 threads = 4 waves, v_mfma_f32_32x32x16_bf16, fp32 accumulate):
-//   <128,128>: 2x2 waves, wave tile 64(m) x 64(n)      — wide layers
-//   <256, 64>: 4x1 waves, wave tile 64(m) x 64(n)      — Cout = 64
-//   <256, 32>: 4x1 waves, wave tile 64(m) x 32(n)      — fast-pathway layers with few channels
+// The MFMA is issued with the weights as the first operand (D = Wt * A^T), so each lane ends up holding 4
+// CONSECUTIVE CHANNELS of one output position: the epilogue packs them with v_cvt_pk_bf16_f32, stages the tile
+// through LDS, and writes / reads (residual, requested before the staging) global memory in 16-byte row-contiguous
+// chunks.  BN, ReLU, residual add and the channel-slice write of the lateral-fusion concat are fused here, so every
+// activation tensor crosses HBM once per consumer.
+//
+// Tiles (256 threads = 4 waves, v_mfma_f32_32x32x16_bf16, fp32 accumulate), <BM, BN, WTM = wave-tile rows>:
+//   <128,128, 64>: 2x2 waves, wave tile  64(m) x 64(n)   — wide layers
+//   <256,128,128>: 2x2 waves, wave tile 128(m) x 64(n)   — wide layers with many rows (AVT_CONV_BIG): 6 LDS fragment
+//                  reads per 8 MFMAs instead of 8 and half the ds_write bytes per MFMA (the K loop is LDS-bound)
+//   <256, 64, 64>: 4x1 waves, wave tile  64(m) x 64(n)   — Cout = 64
+//   <256, 32, 64>: 4x1 waves, wave tile  64(m) x 32(n)   — few output channels
 // LDS rows are padded to 144 B (conflict-free ds_read_b128, see sim_gemm.hip).  Roofline: MFMA for the wide
-// 3x3 layers, HBM for the 1x1x1 / few-channel layers (bytes = activations in + out (+ residual)).
+// 3x3 / temporal layers, HBM for the 1x1x1 (+ residual) layers (bytes = activations in + out (+ residual)).
+// Tried and measured slower (profiles/r01/probe_glds_ab.log, probe_earlyres_ab.log): LDS-DMA (global_load_lds)
+// staging with a source-side swizzle and two LDS stages; requesting the residual before the K loop (+32 VGPRs).
 #include <stdlib.h>
 
 #include "avt_common.h"
@@ -79,29 +88,29 @@ struct ConvArgs {
   int pointwise;                // 1x1x1 / stride 1 / pad 0: rows need no decode
 };
 
-// waves per SIMD to keep: the register budget the allocator may use follows from it (guide §6 G1)
-#define AVT_CONV_MIN_WAVES(BM, BN) ((BM) == 128 ? 3 : ((BN) == 64 ? 2 : 4))
 
-// GLDS = true: operand slabs go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write),
-// two LDS stages, ONE barrier per K-step.  The LDS image must then be lane-linear (1 KiB per wave-instruction =
-// 8 rows x 128 B, unpadded), so the bank-conflict fix is an XOR swizzle applied on the SOURCE side: the lane that
-// fills slot p of row r fetches K-chunk p ^ (r & 7), and fragment reads use the same XOR (guide rule 21).
-// Out-of-bounds / K-tail chunks are fetched from 16 zero bytes kept behind the tap table.
-// EARLYRES: short-K layers with a residual (1x1x1 + skip connection, HBM-bound) request the residual chunks BEFORE the
-// K loop, so a workgroup exposes one memory latency instead of two; costs 32 more VGPRs, hence its own instantiation.
-template <int BM, int BN, bool GLDS, bool TABLDS, bool EARLYRES = false>
-__global__ __launch_bounds__(256, EARLYRES ? 2 : AVT_CONV_MIN_WAVES(BM, BN)) void conv_igemm_kernel(ConvArgs a) {
-  constexpr int RSTR = GLDS ? 128 : LSTR;  // LDS row stride of an operand slab
-  constexpr int WAVES_M = BM / 64;
+
+// waves per SIMD to keep resident: bounds the register allocation (guide §6 G1)
+#define AVT_CONV_MIN_WAVES(BM, BN, WTM) ((WTM) == 128 ? 2 : ((BM) == 128 ? 3 : ((BN) == 64 ? 2 : 4)))
+
+template <int BM, int BN, int WTM, bool TABLDS>
+__global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN, WTM)) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int WAVES_M = BM / WTM;
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WN = BN / WAVES_N;  // wave tile width in n
-  constexpr int NT = WN / 32, MT = 2;
+  constexpr int NT = WN / 32, MT = WTM / 32;
   constexpr int AU = BM / 32, BU = BN / 32;  // 16-byte chunks per thread per K-step
-  constexpr int A_BYTES = BM * RSTR;
-  constexpr int STAGE = (BM + BN) * RSTR;  // one K-step of both operands
+  constexpr int A_BYTES = BM * LSTR;
+  constexpr int STAGE = (BM + BN) * LSTR;  // one K-step of both operands
   constexpr int ESTR = BN * 2 + 16;        // epilogue staging row stride (bytes)
+  // the epilogue stages EROWS rows at a time: the whole tile when it fits in the workgroup's LDS, else one wave-row
+  constexpr int EPASS = (BM * ESTR <= STAGE + (TABLDS ? kMaxTabSteps * 64 : 0)) ? 1 : WAVES_M;
+  constexpr int EROWS = BM / EPASS;
+  constexpr int CPR = BN / 8;  // 16-byte chunks per output row
+  constexpr int EU = (EROWS * CPR) / 256;
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
+  // XCD-aware tile order (see sim_gemm.hip): consecutive tiles of one XCD share the activation rows
   const int bid = blockIdx.x;
   const int qd = a.nblk / 8, rm = a.nblk % 8, xc = bid % 8;
   const int swz = (xc < rm ? xc * (qd + 1) : rm * (qd + 1) + (xc - rm) * qd) + bid / 8;
@@ -112,10 +121,7 @@ __global__ __launch_bounds__(256, EARLYRES ? 2 : AVT_CONV_MIN_WAVES(BM, BN)) voi
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int lr = lane & 31, lh = lane >> 5;
-  const int r0 = tid >> 3;
-  // K-chunk this thread stages: GLDS fills LDS slot (tid & 7) of its rows with chunk slot ^ (row & 7); every row a
-  // thread touches has the same (row & 7) = (tid >> 3) & 7, so the chunk index is a per-thread constant either way
-  const int c16 = GLDS ? ((tid & 7) ^ ((tid >> 3) & 7)) : (tid & 7);
+  const int r0 = tid >> 3, c16 = tid & 7;
 
   // ---- per-row state of the A gather: base element offset and the bitmask of in-bounds taps
   int rowoff[AU];
@@ -145,10 +151,12 @@ __global__ __launch_bounds__(256, EARLYRES ? 2 : AVT_CONV_MIN_WAVES(BM, BN)) voi
   }
   // rows of the weight tile this thread stages
   int wrow[BU];
+  unsigned wsel[BU];  // all-ones where the weight row exists
 #pragma unroll
   for (int u = 0; u < BU; ++u) {
     const int n = n0 + r0 + 32 * u;
-    wrow[u] = n < a.Cout ? n * a.K : -1;
+    wrow[u] = n < a.Cout ? n * a.K : 0;
+    wsel[u] = n < a.Cout ? 0xFFFFFFFFu : 0u;
   }
 
   f32x16 acc[NT][MT];
@@ -159,35 +167,17 @@ __global__ __launch_bounds__(256, EARLYRES ? 2 : AVT_CONV_MIN_WAVES(BM, BN)) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  constexpr int CPR = BN / 8;  // 16-byte chunks per output row
-  constexpr int EU = (BM * CPR) / 256;
-  const bool has_res = a.res != nullptr;
-  uint4 rres[EU];
-  auto prefetch_res = [&]() {
-    if (has_res) {
-#pragma unroll
-      for (int u = 0; u < EU; ++u) {
-        const int c = tid + 256 * u;
-        const int m = m0 + c / CPR, n = n0 + (c % CPR) * 8;
-        rres[u] = (m < a.M && n < a.Cout) ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n)
-                                          : make_uint4(0u, 0u, 0u, 0u);
-      }
-    }
-  };
-  if constexpr (EARLYRES) prefetch_res();
-
-  auto compute = [&](const char* st) {
-    const int xa = GLDS ? (lr & 7) : 0;  // swizzle key of this lane's fragment rows ((row & 7) = lr & 7)
+  auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 af[MT], wf[NT];
-      const int koff = GLDS ? (((ks * 2 + lh) ^ xa) * 16) : (ks * 32 + lh * 16);
+      const int koff = ks * 32 + lh * 16;
 #pragma unroll
       for (int j = 0; j < MT; ++j)
-        af[j] = *reinterpret_cast<const bf16x8*>(st + (wm * 64 + j * 32 + lr) * RSTR + koff);
+        af[j] = *reinterpret_cast<const bf16x8*>(lds + (wm * WTM + j * 32 + lr) * LSTR + koff);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
-        wf[i] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + (wn * WN + i * 32 + lr) * RSTR + koff);
+        wf[i] = *reinterpret_cast<const bf16x8*>(lds + A_BYTES + (wn * WN + i * 32 + lr) * LSTR + koff);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -196,174 +186,146 @@ __global__ __launch_bounds__(256, EARLYRES ? 2 : AVT_CONV_MIN_WAVES(BM, BN)) voi
     }
   };
 
-  if constexpr (GLDS) {
-    const uint16_t* zeros = reinterpret_cast<const uint16_t*>(a.ktab + a.nk * 8);  // 16 zero bytes (avt_conv3d_ktab)
-    auto stage = [&](int kt, char* st) {
-      const int2 e = a.ktab[kt * 8 + c16];
-      const bool kin = e.y >= 0;
-      const int kc = (kt * 8 + c16) * 8;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  int2* ltab = reinterpret_cast<int2*>(lds + STAGE);  // [nk*8] behind the operand slabs
+  if constexpr (TABLDS) {
+    for (int i = tid; i < a.nk * 8; i += 256) ltab[i] = a.ktab[i];
+  }
+  i32x4 ra[AU], rb[BU];
+  auto gload = [&](int kt) {
+    // {offset, tap bits}; chunks past K carry bit 31, which no row mask has -> never "ok".  A global read of the
+    // table here would put a dependent ~500-cycle L2 round trip in front of every K-step's loads: it lives in LDS.
+    const int2 e = TABLDS ? ltab[kt * 8 + c16] : a.ktab[kt * 8 + c16];
+    const unsigned ebits = (unsigned)e.y;
 #pragma unroll
-      for (int u = 0; u < AU; ++u) {
-        const bool ok = kin && ((rowmask[u] & (unsigned)e.y) == (unsigned)e.y);
-        const uint16_t* src = ok ? a.in + (rowoff[u] + e.x) : zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(st + (32 * u + 8 * wid) * 128), 16, 0, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < BU; ++u) {
-        const uint16_t* src = (kin && wrow[u] >= 0) ? a.wt + (wrow[u] + kc) : zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(st + A_BYTES + (32 * u + 8 * wid) * 128),
-                                         16, 0, 0);
-      }
-    };
-    stage(0, lds);
-    __syncthreads();  // (emits vmcnt(0) while LDS-DMA is in flight)
-    for (int kt = 0; kt < a.nk; ++kt) {
-      char* cur = lds + (kt & 1) * STAGE;
-      if (kt + 1 < a.nk) stage(kt + 1, lds + ((kt + 1) & 1) * STAGE);  // lands while this slab is multiplied
-      compute(cur);
-      __syncthreads();
+    for (int u = 0; u < AU; ++u) {
+      const unsigned sel = ((rowmask[u] & ebits) == ebits) ? 0xFFFFFFFFu : 0u;
+      const unsigned off = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
+      ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0);
     }
-  } else {
-    // Buffer loads (SRSRC + 32-bit byte offset): padding taps, rows past M and the K tail get an offset beyond the
-    // descriptor's extent and the hardware range check returns zeros.  The selects are written as bit arithmetic so
-    // the K loop has no branch and no exec masking, and the tap table is read from LDS (filled once per workgroup):
-    // a global read of it would put a dependent ~500-cycle L2 round trip in front of every K-step's loads.
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
-    int2* ltab = reinterpret_cast<int2*>(lds + STAGE);  // [nk*8] behind the operand slabs (when it fits)
-    if constexpr (TABLDS) {
-      for (int i = tid; i < a.nk * 8; i += 256) ltab[i] = a.ktab[i];
+    const unsigned ksel = ~(unsigned)(e.y >> 31);  // all-ones for chunks inside K
+    const unsigned kc2 = (unsigned)((kt * 8 + c16) * 16);
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      const unsigned sel = ksel & wsel[u];
+      const unsigned off = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
+      rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rwt, (int)off, 0, 0);
     }
-    unsigned wsel[BU];  // all-ones where the weight row exists
+  };
+  auto lstore = [&]() {
 #pragma unroll
-    for (int u = 0; u < BU; ++u) wsel[u] = wrow[u] >= 0 ? 0xFFFFFFFFu : 0u;
-    i32x4 ra[AU], rb[BU];
-    auto gload = [&](int kt) {
-      // {offset, tap bits}; chunks past K carry bit 31, which no row mask has -> never "ok"
-      const int2 e = TABLDS ? ltab[kt * 8 + c16] : a.ktab[kt * 8 + c16];
-      const unsigned ebits = (unsigned)e.y;
+    for (int u = 0; u < AU; ++u) *reinterpret_cast<i32x4*>(lds + (r0 + 32 * u) * LSTR + c16 * 16) = ra[u];
 #pragma unroll
-      for (int u = 0; u < AU; ++u) {
-        const unsigned sel = ((rowmask[u] & ebits) == ebits) ? 0xFFFFFFFFu : 0u;
-        const unsigned off = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
-        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0);
-      }
-      const unsigned ksel = ~(unsigned)(e.y >> 31);  // all-ones for chunks inside K
-      const unsigned kc2 = (unsigned)((kt * 8 + c16) * 16);
-#pragma unroll
-      for (int u = 0; u < BU; ++u) {
-        const unsigned sel = ksel & wsel[u];
-        const unsigned off = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
-        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rwt, (int)off, 0, 0);
-      }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-      for (int u = 0; u < AU; ++u) *reinterpret_cast<i32x4*>(lds + (r0 + 32 * u) * LSTR + c16 * 16) = ra[u];
-#pragma unroll
-      for (int u = 0; u < BU; ++u) *reinterpret_cast<i32x4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
-    };
-    if constexpr (TABLDS) __syncthreads();
-    gload(0);
-    lstore();
+    for (int u = 0; u < BU; ++u) *reinterpret_cast<i32x4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
+  };
+  if constexpr (TABLDS) __syncthreads();
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < a.nk; ++kt) {
+    if (kt + 1 < a.nk) gload(kt + 1);  // next slab's latency hides under this slab's MFMAs
+    compute();
     __syncthreads();
-    for (int kt = 0; kt < a.nk; ++kt) {
-      if (kt + 1 < a.nk) gload(kt + 1);
-      compute(lds);
+    if (kt + 1 < a.nk) {
+      lstore();
       __syncthreads();
-      if (kt + 1 < a.nk) {
-        lstore();
-        __syncthreads();
-      }
     }
   }
 
-  // ---- epilogue.  The residual chunks this thread will need are requested before the accumulators are staged
-  // through LDS (or, EARLYRES, before the K loop), so their HBM latency is not serialised behind the staging.
-  if constexpr (!EARLYRES) prefetch_res();
-  // phase 1: (+bias [, relu]) -> bf16 -> LDS staging tile [m][n]
-  // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n  -> regs 4g..4g+3 are 4 consecutive n
+  // ---- epilogue, EPASS passes of EROWS rows
+  const bool has_res = a.res != nullptr;
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int p = 0; p < EPASS; ++p) {
+    // the residual chunks this thread will need are requested before the accumulators are staged through LDS, so
+    // their HBM latency overlaps the staging instead of serialising one round trip per chunk
+    uint4 rres[EU];
+    if (has_res) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nl = wn * WN + i * 32 + 8 * g + 4 * lh;  // tile-local first channel of this group
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.bias && n0 + nl < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
-        float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-        if (a.relu && !has_res) {
-          v0 = fmaxf(v0, 0.f);
-          v1 = fmaxf(v1, 0.f);
-          v2 = fmaxf(v2, 0.f);
-          v3 = fmaxf(v3, 0.f);
-        }
-        uint2 pk;
-        pk.x = avt::pack_bf16x2(v0, v1);
-        pk.y = avt::pack_bf16x2(v2, v3);
-        const int ml = wm * 64 + j * 32 + lr;
-        *reinterpret_cast<uint2*>(lds + ml * ESTR + nl * 2) = pk;
+      for (int u = 0; u < EU; ++u) {
+        const int c = tid + 256 * u;
+        const int m = m0 + p * EROWS + c / CPR, n = n0 + (c % CPR) * 8;
+        rres[u] = (m < a.M && n < a.Cout) ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n)
+                                          : make_uint4(0u, 0u, 0u, 0u);
       }
     }
-  __syncthreads();
-  // phase 2: 16-byte row-contiguous chunks: (+residual, relu) -> global
+    // phase 1: (+bias [, relu]) -> bf16 -> LDS staging tile [m][n]
+    // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n -> regs 4g..4g+3 are 4 consecutive n
+    if (EPASS == 1 || wm == p) {
 #pragma unroll
-  for (int u = 0; u < EU; ++u) {
-    const int c = tid + 256 * u;
-    const int row = c / CPR, cc = c % CPR;
-    const int m = m0 + row, n = n0 + cc * 8;
-    if (m < a.M && n < a.Cout) {
-      uint4 v = *reinterpret_cast<const uint4*>(lds + row * ESTR + cc * 16);
-      if (has_res) {
-        uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
-        const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rres[u]);
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x0 = avt::bf16x2_lo(pv[e]) + avt::bf16x2_lo(pr[e]);
-          float x1 = avt::bf16x2_hi(pv[e]) + avt::bf16x2_hi(pr[e]);
-          if (a.relu) {
-            x0 = fmaxf(x0, 0.f);
-            x1 = fmaxf(x1, 0.f);
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn * WN + i * 32 + 8 * g + 4 * lh;  // tile-local first channel of this group
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.bias && n0 + nl < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+#pragma unroll
+          for (int j = 0; j < MT; ++j) {
+            float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+            float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+            if (a.relu && !has_res) {
+              v0 = fmaxf(v0, 0.f);
+              v1 = fmaxf(v1, 0.f);
+              v2 = fmaxf(v2, 0.f);
+              v3 = fmaxf(v3, 0.f);
+            }
+            uint2 pk;
+            pk.x = avt::pack_bf16x2(v0, v1);
+            pk.y = avt::pack_bf16x2(v2, v3);
+            const int ml = (EPASS == 1 ? wm * WTM : 0) + j * 32 + lr;
+            *reinterpret_cast<uint2*>(lds + ml * ESTR + nl * 2) = pk;
           }
-          pv[e] = avt::pack_bf16x2(x0, x1);
         }
-      }
-      *reinterpret_cast<uint4*>(a.out + (int64_t)m * a.ldo + n) = v;
     }
+    __syncthreads();
+    // phase 2: 16-byte row-contiguous chunks: (+residual, relu) -> global
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int c = tid + 256 * u;
+      const int row = c / CPR, cc = c % CPR;
+      const int m = m0 + p * EROWS + row, n = n0 + cc * 8;
+      if (m < a.M && n < a.Cout) {
+        uint4 v = *reinterpret_cast<const uint4*>(lds + row * ESTR + cc * 16);
+        if (has_res) {
+          uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
+          const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rres[u]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x0 = avt::bf16x2_lo(pv[e]) + avt::bf16x2_lo(pr[e]);
+            float x1 = avt::bf16x2_hi(pv[e]) + avt::bf16x2_hi(pr[e]);
+            if (a.relu) {
+              x0 = fmaxf(x0, 0.f);
+              x1 = fmaxf(x1, 0.f);
+            }
+            pv[e] = avt::pack_bf16x2(x0, x1);
+          }
+        }
+        *reinterpret_cast<uint4*>(a.out + (int64_t)m * a.ldo + n) = v;
+      }
+    }
+    if (p + 1 < EPASS) __syncthreads();  // the staging tile is reused by the next wave-row
   }
 }
 
-template <int BM, int BN, bool GLDS, bool TABLDS = true, bool EARLYRES = false>
+template <int BM, int BN, int WTM, bool TABLDS = true>
 int launch(ConvArgs& a, hipStream_t st) {
-  if (!GLDS && TABLDS && a.nk > kMaxTabSteps) return launch<BM, BN, false, false>(a, st);  // table stays in global memory
-  if constexpr (!GLDS && TABLDS && !EARLYRES) {
-    static const bool early = []() {
-      // measured (profiles/r01/probe_earlyres_ab.log): 3158 vs 3358 clips/s — the 32 extra VGPRs cost a resident
-      // workgroup per SIMD, which hurts more than the second latency exposure: OFF unless AVT_CONV_EARLYRES=1
-      const char* e = getenv("AVT_CONV_EARLYRES");
-      return e ? atoi(e) != 0 : false;
-    }();
-    if (early && a.res && a.nk <= 2) return launch<BM, BN, false, true, true>(a, st);
-  }
+  if (TABLDS && a.nk > kMaxTabSteps) return launch<BM, BN, WTM, false>(a, st);  // table stays in global memory
   const int tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
   a.nblk = tiles_m * a.tiles_n;
-  constexpr int lds_main = GLDS ? 2 * (BM + BN) * 128 : (BM + BN) * LSTR + (TABLDS ? kMaxTabSteps * 8 * 8 : 0);
-  constexpr int lds_epi = BM * (BN * 2 + 16);
+  constexpr int lds_main = (BM + BN) * LSTR + (TABLDS ? kMaxTabSteps * 8 * 8 : 0);
+  constexpr int epass = (BM * (BN * 2 + 16) <= lds_main) ? 1 : BM / WTM;
+  constexpr int lds_epi = (BM / epass) * (BN * 2 + 16);
   constexpr int lds_bytes = lds_main > lds_epi ? lds_main : lds_epi;
   if (lds_bytes > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per kernel
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, GLDS, TABLDS, EARLYRES>),
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WTM, TABLDS>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) {
       avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
       return AVT_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, GLDS, TABLDS, EARLYRES>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WTM, TABLDS>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_bf16");
 }
 
@@ -450,15 +412,14 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   a.dHo = make_fastdiv((uint32_t)a.Ho);
   a.dTo = make_fastdiv((uint32_t)a.To);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // LDS-DMA staging per tile shape: bit 0 = <128,128>, bit 1 = <256,64>, bit 2 = <256,32> (AVT_CONV_GLDS).
-  // Measured on MI355X, fused SlowFast, 64 clips (profiles/r01/probe_glds_ab.log): off 3009 clips/s, bit0 2767,
-  // bits0-1 2703, all 2532 -> OFF by default.  This single-stage-ahead form halves the resident workgroups
-  // (2 x 32 KB stages) and its unpadded image reads 2-way conflicted; register staging at 3 waves/SIMD wins.
-  static const int glds = []() {
-    const char* e = getenv("AVT_CONV_GLDS");
-    return e ? atoi(e) : 0;
+  if (cout <= 32) return launch<256, 32, 64>(a, s);
+  if (cout <= 64) return launch<256, 64, 64>(a, s);
+  // wide layers: the 256x128 tile (128x64 per wave) when there are enough tiles of it to fill the chip
+  // (2 workgroups per CU x 256 CUs).  AVT_CONV_BIG = minimum tile count, 0 = never.
+  static const int big = []() {
+    const char* e = getenv("AVT_CONV_BIG");
+    return e ? atoi(e) : 0;  // off: measured 7 % slower end to end (profiles/r01/probe_big_ab.log), 2 waves/SIMD hide less of the gather
   }();
-  if (cout <= 32) return (glds & 4) ? launch<256, 32, true>(a, s) : launch<256, 32, false>(a, s);
-  if (cout <= 64) return (glds & 2) ? launch<256, 64, true>(a, s) : launch<256, 64, false>(a, s);
-  return (glds & 1) ? launch<128, 128, true>(a, s) : launch<128, 128, false>(a, s);
+  if (big > 0 && (int64_t)((a.M + 255) / 256) * ((cout + 127) / 128) >= big) return launch<256, 128, 128>(a, s);
+  return launch<128, 128, 64>(a, s);
 }
