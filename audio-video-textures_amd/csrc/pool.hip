@@ -1,6 +1,8 @@
 // maxpool_hw3s2 — MaxPool3d((1,3,3), stride (1,2,2), padding (0,1,1)) on NDHWC bf16 rows, for the SlowFast
 // stems (the reference reaches it through the third-party SlowFast model,
-// contrastive_video_textures/models/models.py:335, 399).  HBM-bound: each thread owns 8 channels (16 bytes) of
+// contrastive_video_textures/models/models.py:335, 399).
+// maxpool_hw2s2 — MaxPool2d(2, stride 2), floor mode, of VGGish
+// (contrastive_video_textures/models/audio_models/vggish.py:15-33) on NHWC bf16 rows.  HBM-bound: each thread owns 8 channels (16 bytes) of
 // one output position, reads its <= 9 taps with 16-byte loads and writes one 16-byte chunk — optionally into a
 // channel slice of a wider row buffer (ldo), which is how the slow stem lands in the lateral-fusion concat.
 #include "avt_common.h"
@@ -15,6 +17,7 @@ __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) {
   return lo | (hi << 16);
 }
 
+template <int KS, int PAD>
 __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
                                                        int bt, int H, int W, int C, int ldi, int ldo, int Ho, int Wo, int tgroup) {
   const int cpr = C >> 3;
@@ -29,12 +32,12 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict
     uint4 m;
     bool first = true;
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int hi = 2 * ho - 1 + dh;
+    for (int dh = 0; dh < KS; ++dh) {
+      const int hi = 2 * ho - PAD + dh;
       if ((unsigned)hi >= (unsigned)H) continue;
 #pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const int wi = 2 * wo - 1 + dw;
+      for (int dw = 0; dw < KS; ++dw) {
+        const int wi = 2 * wo - PAD + dw;
         if ((unsigned)wi >= (unsigned)W) continue;
         const uint4 v = *reinterpret_cast<const uint4*>(in + (((int64_t)b * H + hi) * W + wi) * ldi + cc * 8);
         if (first) {
@@ -70,7 +73,22 @@ extern "C" int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, i
   const int64_t total = (int64_t)bt * ho * wo * (c / 8);
   const int64_t blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
-  hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL((maxpool_kernel<3, 1>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), bt, h, w, c, ldi, ldo, ho, wo, tgroup);
   return avt::check_launch("avt_maxpool_hw3s2_ndhwc_bf16");
+}
+
+extern "C" int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w, int c, int ldi, int ldo,
+                                            void* stream) {
+  AVT_REQUIRE(in && out, "avt_maxpool_hw2s2_ndhwc_bf16: NULL pointer");
+  AVT_REQUIRE(bt > 0 && h >= 2 && w >= 2 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldi >= c && ldo >= c,
+              "avt_maxpool_hw2s2_ndhwc_bf16: h, w >= 2; channels / leading dimensions must be multiples of 8");
+  AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(out), "avt_maxpool_hw2s2_ndhwc_bf16: pointers must be 16-byte aligned");
+  const int ho = h / 2, wo = w / 2;  // floor mode: an odd last row / column is dropped
+  const int64_t total = (int64_t)bt * ho * wo * (c / 8);
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+  hipLaunchKernelGGL((maxpool_kernel<2, 0>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), bt, h, w, c, ldi, ldo, ho, wo, 1);
+  return avt::check_launch("avt_maxpool_hw2s2_ndhwc_bf16");
 }

@@ -14,11 +14,12 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """torchrun / torch.distributed.run environment -> (rank, world, local_rank).  No-op at world 1."""
+    """torchrun / torch.distributed.run environment -> (rank, world, local_rank).  No-op at world 1, unless
+    AVT_FORCE_PG=1 asks for a one-rank process group (lets a 1-GPU box drive the RCCL calls of the N>1 path)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("AVT_FORCE_PG") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -39,9 +40,9 @@ def shard_range(n, rank, world):
 def all_gather_rows(local, n_total, group=None):
     """Rows [n_r, D] of every rank -> [n_total, D] on every rank, in rank order (ragged shards padded to
     the largest).  One collective; on a fully connected xGMI node RCCL drives all 7 links at once."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local
+    world = dist.get_world_size(group)
     sizes = [shard_range(n_total, r, world) for r in range(world)]
     width = max(hi - lo for lo, hi in sizes)
     pad = local
@@ -67,7 +68,7 @@ def gather_to_root(local, n_total, group=None, root=0):
 def barrier_max_time(seconds, device):
     """Max over ranks of a local wall time (bench contract)."""
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

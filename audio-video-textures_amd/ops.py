@@ -222,6 +222,13 @@ def maxpool_hw3s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo, tgroup=1):
                "avt_maxpool_hw3s2_ndhwc_bf16")
 
 
+def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
+    """MaxPool2d(2, 2), floor mode, on NHWC bf16 rows (raw device addresses) — VGGish (audio_models/vggish.py:15-33)."""
+    _lib.check(_lib.lib().avt_maxpool_hw2s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),
+                                                       int(c), int(ldi), int(ldo), _stream()),
+               "avt_maxpool_hw2s2_ndhwc_bf16")
+
+
 # ---- fused training branch ----------------------------------------------------------------
 def infonce_fwd(q, t, temp, eps=1e-12):
     """q [b,d], t [b,n,d] fp32 -> (logits [b,n], inv_q [b], inv_t [b,n])."""

@@ -173,7 +173,7 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
             if da_model is None:
                 raise AvtError("driving audio needs pytorch_vggish.pth (validate.py:266) or a model with an audio encoder")
             print("pytorch_vggish.pth not found: driving-audio branch uses the model's own audio encoder")
-    q_enc, t_enc = net.q_encoder, net.t_encoder
+    q_enc, t_enc, a_enc = net.q_encoder, net.t_encoder, getattr(net, "t_a_encoder", None)
     if getattr(args, "enc_impl", "auto") in ("auto", "mfma"):
         # real SlowFast encoders run on the hand-written MFMA convolutions (bf16, BN folded); plugin encoders of
         # any other class run as given
@@ -182,9 +182,16 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
 
         if isinstance(q_enc, SlowFast) and isinstance(t_enc, SlowFast):
             q_enc, t_enc = SlowFastMFMA(q_enc, dev), SlowFastMFMA(t_enc, dev)
+            # ... and so does VGGish (audio_models/vggish.py), for the model's audio branch and the driving branch
+            from .fused_vggish import VGGishMFMA
+
+            if isinstance(a_enc, VGGish):
+                a_enc = VGGishMFMA(a_enc, dev)
+            if isinstance(da_model, VGGish):
+                da_model = a_enc if da_model is getattr(net, "t_a_encoder", None) else VGGishMFMA(da_model, dev)
         elif getattr(args, "enc_impl", "auto") == "mfma":
             raise AvtError("enc_impl=mfma needs SlowFast encoders (got {})".format(type(q_enc).__name__))
-    eng = texture.TextureEngine(q_enc, t_enc, getattr(net, "t_a_encoder", None),
+    eng = texture.TextureEngine(q_enc, t_enc, a_enc,
                                 window=W, stride=S, temp=net.temp, img_size=args.img_size,
                                 model_type=net.model_type, device=dev,
                                 enc_batch=getattr(args, "enc_batch", 32),

@@ -159,7 +159,7 @@ def main():
         return sel
 
     def sync():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 

@@ -221,6 +221,11 @@ int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float* bias,
 int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w,
                                  int c, int ldi, int ldo, int tgroup, void* stream);
 
+/* MaxPool2d(2, stride 2), floor mode, of VGGish (audio_models/vggish.py:15-33: the "M" entries of
+ * its feature stack) on NHWC bf16 rows; bt = batch, out [bt, h/2, w/2, c] (row stride ldo). */
+int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w,
+                                 int c, int ldi, int ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,44 @@ def test_train_one_epoch(avt, dev):
     losses = [avt.train(loader, model, opt, args, epoch) for epoch in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert losses[0] < np.log(11) * 1.5  # starts near log(1 + negs); n_negs >= 8 as in the reference (dataset.py:190 needs room for the hard negatives)
+
+
+def test_validate_m2_driving_audio_on_mfma_encoders(avt, dev, capsys):
+    """Config 3 wiring with the production encoders: real SlowFast x2 AND VGGish run on the hand-written MFMA
+    convolutions (validate.py swaps both in), source + driving audio tables are built once, aligned N x N mode."""
+    from avtex.fused_vggish import VGGishMFMA
+    from avtex.slowfast import SlowFast
+    from avtex.texture import TextureEngine
+    from avtex.audio_frontend import waveform_to_examples
+
+    torch.manual_seed(0)
+    model = avt.ContrastivePredictionTemporal(SlowFast(), SlowFast(), avt.VGGish(), 2, 128, temp=0.1, window=5, stride=2,
+                                              threshold=0.3, mini_batchsize=8, enc_arch="slowfast", img_size=64)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.uniform_(0.5, 1.0)
+    model = model.to(dev).eval()
+    rng = np.random.default_rng(3)
+    wave, wave_da = (0.1 * rng.standard_normal(7 * 16000)).astype(np.float32), (0.1 * rng.standard_normal(3 * 16000)).astype(np.float32)
+    args = SimpleNamespace(vdata=None, adata=None, dadata=None, subsample_rate=1, fps=10, stride=2, window=5,
+                           enc_arch="slowfast", img_size=64, model_type=2, mini_batchsize=8, threshold=0.3, alpha=0.5,
+                           temp=0.1, driving_audio=None, da_feats="VGG", interpolation=False, new_video_length=2,
+                           results_folder=None, logname="exp", batch_size=8, stitch_mode="aligned", ref_num_gpus=1,
+                           enc_batch=8, enc_impl="auto")
+    np.random.seed(5)
+    frames = avt.validate(model, args, video_name="x", model_type=2, video=(_video(70, 48).numpy(), 10.0),
+                          audio=(wave, 16000), driving_audio=(wave_da, 16000))
+    out = capsys.readouterr().out
+    assert "Frames list: " in out and len(frames) >= 10 and 0 <= min(frames) and max(frames) < 70
+    # the audio tables of the engine are the MFMA VGGish's, within bf16 of the fp32 module's
+    eg = torch.from_numpy(np.asarray(waveform_to_examples(wave, 16000), dtype=np.float32)).unsqueeze(1)
+    fused = VGGishMFMA(model.t_a_encoder, dev)
+    tiny = seeded(TinySlowFast, 1).to(dev)
+    eng = TextureEngine(tiny, tiny, fused, window=5, stride=2, temp=0.1, img_size=64, model_type=2, device=dev)
+    eng.N = 32
+    eng.set_audio(eg)
+    with torch.no_grad():
+        ref = model.t_a_encoder(eg[:32].to(dev))
+    assert eng.A.shape == (32, 12288)
+    assert torch.nn.functional.cosine_similarity(eng.A, ref, dim=1).min() > 0.999

@@ -156,3 +156,52 @@ def test_stem_on_mfma_matches_torch(avt, dev):
         got = act.buf.float().cpu().view(*pd, conv.frame_channels).permute(0, 4, 1, 2, 3)
         assert got.shape == ref.shape
         assert (got - ref).abs().max() < 0.03 * max(ref.abs().max().item(), 1.0)
+
+
+def test_maxpool2x2_matches_torch(avt, dev):
+    """VGGish pool (MaxPool2d(2,2), floor mode: an odd last row is dropped) — exact."""
+    torch.manual_seed(5)
+    for h, w in ((100, 64), (25, 16), (7, 5)):
+        x = torch.randn(3, 24, h, w).to(torch.bfloat16)  # [B,C,H,W]
+        ref = F.max_pool2d(x.float(), 2, 2)
+        rows = x.permute(0, 2, 3, 1).reshape(-1, 24).contiguous().to(dev)
+        out = torch.empty((3 * (h // 2) * (w // 2), 24), dtype=torch.bfloat16, device=dev)
+        avt.ops.maxpool_hw2s2(rows.data_ptr(), out.data_ptr(), 3, h, w, 24, 24, 24)
+        torch.cuda.synchronize()
+        assert torch.equal(out.float().cpu().view(3, h // 2, w // 2, 24).permute(0, 3, 1, 2), ref)
+
+
+def test_fused_vggish_matches_module(avt, dev):
+    """VGGish feature stack on the MFMA convolution vs the fp32 plugin module (audio_models/vggish.py:42-46 contract:
+    NHWC flatten, fc skipped).  Tolerance: bf16 activations — compared with torch's own bf16 run of the module."""
+    from avtex.fused_vggish import VGGishMFMA
+    from avtex.vggish import VGGish
+
+    torch.manual_seed(6)
+    m = VGGish().eval()
+    with torch.no_grad():
+        for mod in m.features:
+            if isinstance(mod, nn.Conv2d):  # He-style init so activations neither vanish nor explode over 6 layers
+                nn.init.kaiming_normal_(mod.weight, nonlinearity="relu")
+                mod.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(5, 1, 100, 64) * 2 - 1  # log-mel range
+    fused = VGGishMFMA(m, dev)
+    y = fused(x).cpu()
+    with torch.no_grad():
+        ref = m.to(dev)(x.to(dev)).cpu()
+        ref16 = m.to(torch.bfloat16)(x.to(dev, torch.bfloat16)).float().cpu()
+    assert y.shape == (5, 12288) and torch.isfinite(y).all()
+    cos = F.cosine_similarity(y, ref, dim=1)
+    rel = ((y - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
+    rel16 = ((ref16 - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
+    print("vggish fused vs fp32: cos", cos.tolist(), "rel", rel, "| torch bf16 vs fp32 rel", rel16)
+    assert cos.min() > 0.9995 and rel < max(2.5 * rel16, 0.02)
+    # first layer alone (1 input channel, 8 mel bins per 16-byte chunk): bf16 inputs/weights, fp32 accumulate
+    conv, _, cout = fused.layers[0]
+    xb = x.to(torch.bfloat16)
+    w0 = m.features[0].weight.float().to(torch.bfloat16).float()  # the module is bf16 by now; same rounding as the packer
+    ref0 = F.relu(F.conv2d(xb.float().to(dev), w0.to(dev), m.features[0].bias.float().to(dev), padding=1)).cpu()
+    from avtex.fused_slowfast import Act
+    a = conv(Act(xb.to(dev).contiguous().view(5 * 100 * 8, 8), (5, 1, 100, 8)))
+    got = a.buf.view(5, 100, 64, cout).permute(0, 3, 1, 2).float().cpu()
+    assert (got - ref0).abs().max() < 0.01 * max(ref0.abs().max().item(), 1.0)
