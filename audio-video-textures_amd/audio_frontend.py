@@ -1,4 +1,8 @@
-"""Waveform -> VGGish log-mel examples (host NumPy, once per video).
+"""Waveform -> VGGish log-mel examples, once per video.
+
+`waveform_to_examples_device` is what validate() runs: the STFT / mel / log / framing arithmetic on the MI355X
+(csrc/logmel.hip, float64 like the reference) from tables built here.  `waveform_to_examples` is the same arithmetic
+in host NumPy for CPU-side callers (the training DataLoader's workers, dataset.py) where no device is bound.
 
 Same arithmetic as the reference's TF-VGGish front-end
 (contrastive_video_textures/utils/vggish_utils.py:27-69, mel_features.py:21-205,
@@ -83,3 +87,47 @@ def _resample(data, sr_in, sr_out):
 
     fr = Fraction(int(sr_out), int(sr_in)).limit_denominator(1000)
     return resample_poly(data, fr.numerator, fr.denominator)
+
+
+_TABLES = {}
+
+
+def _device_tables(device):
+    """Periodic Hann window and HTK mel matrix (float64) resident on `device`."""
+    key = str(device)
+    if key not in _TABLES:
+        import torch
+
+        win = int(round(SAMPLE_RATE * STFT_WINDOW_SECONDS))
+        fft_len = 2 ** int(np.ceil(np.log(win) / np.log(2.0)))
+        hann = 0.5 - (0.5 * np.cos(2 * np.pi / win * np.arange(win)))
+        mel = mel_matrix(NUM_MEL_BINS, fft_len // 2 + 1, SAMPLE_RATE, MEL_MIN_HZ, MEL_MAX_HZ)
+        _TABLES[key] = (torch.from_numpy(hann).to(device), torch.from_numpy(np.ascontiguousarray(mel)).to(device), fft_len)
+    return _TABLES[key]
+
+
+def log_mel_device(data, sample_rate, device):
+    """-> float64 device tensor [num_frames, 64] (mel_features.log_mel_spectrogram on the GPU)."""
+    import torch
+
+    from . import ops
+
+    data = np.asarray(data)
+    if data.ndim > 1:
+        data = np.mean(data, axis=1)
+    if sample_rate != SAMPLE_RATE:
+        data = _resample(data, sample_rate, SAMPLE_RATE)
+    if data.dtype not in (np.float32, np.float64):
+        data = data.astype(np.float64)
+    hann, mel, fft_len = _device_tables(device)
+    wave = torch.from_numpy(np.ascontiguousarray(data)).to(device)
+    return ops.logmel(wave, hann, mel, int(round(SAMPLE_RATE * STFT_HOP_SECONDS)), fft_len, LOG_OFFSET)
+
+
+def waveform_to_examples_device(data, sample_rate, device):
+    """-> float32 device tensor [num_examples, 100, 64]: waveform_to_examples + the .float() of validate.py:160-161."""
+    from . import ops
+
+    rate = 1.0 / STFT_HOP_SECONDS
+    return ops.logmel_examples(log_mel_device(data, sample_rate, device), int(round(EXAMPLE_WINDOW_SECONDS * rate)),
+                               int(round(EXAMPLE_HOP_SECONDS * rate)))

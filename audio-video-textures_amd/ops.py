@@ -229,6 +229,39 @@ def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
                "avt_maxpool_hw2s2_ndhwc_bf16")
 
 
+# ---- audio front-end ------------------------------------------------------------------------
+def logmel(wave, window, melmat, hop, fft_len, log_offset):
+    """wave [n] fp32/fp64, window [win] fp64, melmat [fft_len/2+1, n_mel] fp64 (device) -> log-mel [n_frames, n_mel]
+    fp64 (mel_features.py:176-205)."""
+    if wave.dtype not in (torch.float32, torch.float64):
+        raise _lib.AvtError("logmel: waveform must be float32 or float64, got %s" % wave.dtype)
+    _dev(wave, "wave", wave.dtype)
+    _dev(window, "window", torch.float64)
+    _dev(melmat, "melmat", torch.float64)
+    win, n_mel = int(window.numel()), int(melmat.shape[1])
+    if melmat.shape[0] != fft_len // 2 + 1:
+        raise _lib.AvtError("logmel: melmat has %d rows, fft_len/2+1 = %d" % (melmat.shape[0], fft_len // 2 + 1))
+    n = int(wave.numel())
+    n_frames = 1 + (n - win) // hop if n >= win else 0
+    out = torch.empty((n_frames, n_mel), dtype=torch.float64, device=wave.device)
+    _lib.check(_lib.lib().avt_logmel_f64(_p(wave), int(wave.dtype == torch.float64), n, _p(window), win, int(hop),
+                                         int(fft_len), _p(melmat), n_mel, float(log_offset), _p(out), _stream()),
+               "avt_logmel_f64")
+    return out
+
+
+def logmel_examples(lm, ex_len, ex_hop):
+    """log-mel [n_frames, n_mel] fp64 -> examples [n_ex, ex_len, n_mel] fp32 (vggish_utils.py:60-68 + the cast of
+    validate.py:160-161)."""
+    _dev(lm, "logmel", torch.float64)
+    n_frames, n_mel = int(lm.shape[0]), int(lm.shape[1])
+    n_ex = 1 + (n_frames - ex_len) // ex_hop if n_frames >= ex_len else 0
+    out = torch.empty((n_ex, ex_len, n_mel), dtype=torch.float32, device=lm.device)
+    _lib.check(_lib.lib().avt_logmel_examples_f32(_p(lm), n_frames, n_mel, int(ex_len), int(ex_hop), _p(out),
+                                                  _stream()), "avt_logmel_examples_f32")
+    return out
+
+
 # ---- fused training branch ----------------------------------------------------------------
 def infonce_fwd(q, t, temp, eps=1e-12):
     """q [b,d], t [b,n,d] fp32 -> (logits [b,n], inv_q [b], inv_t [b,n])."""

@@ -26,7 +26,7 @@ import torch
 
 from . import texture
 from ._lib import AvtError
-from .audio_frontend import waveform_to_examples
+from .audio_frontend import waveform_to_examples_device
 from .utils import AverageMeter, save_videos
 from .vggish import VGGish
 
@@ -124,7 +124,7 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
             audio_w, sr = audio if audio is not None else read_audio(path)
             apf = math.floor((sr * sub) / args.fps)
             audio_w = np.asarray(audio_w)[: n_in * apf]
-            audio_eg = torch.from_numpy(waveform_to_examples(audio_w, sr * sub)).unsqueeze(dim=1).float()
+            audio_eg = waveform_to_examples_device(audio_w, sr * sub, dev).unsqueeze(dim=1)  # STFT/mel/log on the GPU
     print("Preparing driving audio. ")
     driving_audio_name, driving_audio_eg, driving_audio_w = None, None, None
     if getattr(args, "driving_audio", None) is not None or driving_audio is not None:
@@ -134,8 +134,7 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
             assert os.path.exists(da_path), "No driving audio found at {}".format(da_path)
             driving_audio = read_audio(da_path)
         driving_audio_w, sr_da = driving_audio
-        driving_audio_eg = torch.from_numpy(waveform_to_examples(np.asarray(driving_audio_w), sr_da * sub))
-        driving_audio_eg = driving_audio_eg.unsqueeze(dim=1).float()
+        driving_audio_eg = waveform_to_examples_device(np.asarray(driving_audio_w), sr_da * sub, dev).unsqueeze(dim=1)
     print("Initializing interpolation model. ")
     if getattr(args, "interpolation", False):
         print("SuperSloMo interpolation at jumps is outside the hot-path scope; continuing without it (-nintp).")
@@ -149,7 +148,7 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         q_id = 10
         print("Start:", q_id)
     else:
-        q_id = audio_start_segment(audio_eg, driving_audio_eg[0])
+        q_id = audio_start_segment(audio_eg.cpu(), driving_audio_eg[0].cpu())
     new_frames, new_frame_ids, non_zero_counts, entropies = [], [], [], []
     jump_count, iter_count, p_q_id = 0, 1, -1
     max_length = math.ceil(args.fps) * args.new_video_length

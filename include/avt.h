@@ -226,6 +226,23 @@ int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w
 int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w,
                                  int c, int ldi, int ldo, void* stream);
 
+/* VGGish audio front-end (utils/mel_features.py:21-92, 176-205 log_mel_spectrogram; called once per
+ * video from utils/vggish_utils.py:27-69), float64 like the reference's NumPy code:
+ * frame f = wave[f*hop, f*hop+win) * window -> |DFT_fft_len| -> spec[fft_len/2+1] . melmat -> log(. + log_offset).
+ * wave: float32 (wave_is_f64 = 0) or float64 device samples; window [win] and melmat [fft_len/2+1, n_mel]
+ * are float64 device tables built by the caller with the reference's formulas (periodic Hann :41-43, HTK mel
+ * matrix :117-173).  logmel [n_frames, n_mel], n_frames = 1 + (n_samples - win) / hop (incomplete tail
+ * dropped, mel_features.py:21-45); n_samples < win writes nothing. */
+int avt_logmel_f64(const void* wave, int wave_is_f64, int64_t n_samples,
+                   const double* window, int win, int hop, int fft_len,
+                   const double* melmat, int n_mel, double log_offset,
+                   double* logmel, void* stream);
+
+/* Example framing of vggish_utils.py:60-68 with the float32 cast of validate.py:160-161:
+ * out[e, r, m] = (float) logmel[e*ex_hop + r, m], n_ex = 1 + (n_frames - ex_len) / ex_hop. */
+int avt_logmel_examples_f32(const double* logmel, int64_t n_frames, int n_mel,
+                            int ex_len, int ex_hop, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -276,3 +276,35 @@ class CompatOracle:
             sn, _, _ = self.cref.l2norm_rows(ta, want_split=False)
             out_a = self.cref.sim_f32(dn, sn, self.temp)[0]
         return out, out_a, seg_ids
+
+
+# ---- audio front-end (utils/mel_features.py:21-205, utils/vggish_utils.py:27-69, utils/vggish_params.py:27-38) ----
+def log_mel(wave, win=400, hop=160, n_mel=64, sr=16000.0, lo_hz=125.0, hi_hz=7500.0, offset=0.01):
+    """float64 [n_frames, n_mel]: frame (tail dropped, :21-45) * periodic Hann (:41-43) -> |DFT_512| (:48-68; written
+    as an explicit DFT matrix product, the definition np.fft.rfft implements) -> HTK mel matrix (:117-173, DC bin
+    zeroed :172) -> log(. + 0.01) (:176-205).  Pinned by G6 (the reference's own waveform_to_examples output)."""
+    x = np.asarray(wave, dtype=np.float64)
+    fft_len = 2 ** int(math.ceil(math.log(win) / math.log(2.0)))
+    n_frames = 1 + (len(x) - win) // hop if len(x) >= win else 0
+    nb = fft_len // 2 + 1
+    if n_frames == 0:
+        return np.zeros((0, n_mel))
+    idx = np.arange(n_frames)[:, None] * hop + np.arange(win)[None, :]
+    fr = x[idx] * (0.5 - 0.5 * np.cos(2 * np.pi / win * np.arange(win)))
+    ang = -2.0 * np.pi * ((np.arange(win)[:, None] * np.arange(nb)[None, :]) % fft_len) / fft_len
+    spec = np.abs(fr @ np.cos(ang) + 1j * (fr @ np.sin(ang)))
+    mel_of = lambda hz: 1127.0 * np.log(1.0 + hz / 700.0)
+    spec_mel = mel_of(np.linspace(0.0, sr / 2.0, nb))
+    edges = np.linspace(mel_of(lo_hz), mel_of(hi_hz), n_mel + 2)
+    m = np.zeros((nb, n_mel))
+    for i in range(n_mel):
+        lo, ce, hi = edges[i : i + 3]
+        m[:, i] = np.maximum(0.0, np.minimum((spec_mel - lo) / (ce - lo), (hi - spec_mel) / (hi - ce)))
+    m[0, :] = 0.0
+    return np.log(spec @ m + offset)
+
+
+def logmel_examples(lm, ex_len=100, ex_hop=10):
+    """vggish_utils.py:60-68 framing: [n_ex, ex_len, n_mel] float64 (incomplete tail dropped)."""
+    n = 1 + (len(lm) - ex_len) // ex_hop if len(lm) >= ex_len else 0
+    return np.stack([lm[e * ex_hop : e * ex_hop + ex_len] for e in range(n)]) if n else np.zeros((0, ex_len, lm.shape[1]))

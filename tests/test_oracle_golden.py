@@ -208,6 +208,16 @@ def test_g6_waveform_to_examples():
     np.testing.assert_allclose(ex, g["examples"], rtol=1e-12, atol=1e-12)
 
 
+def test_g6_oracle_log_mel():
+    """The oracle's own restatement (explicit DFT) against the reference's output: what the GPU front-end is checked
+    against in tests/test_gpu_audio.py."""
+    g = gold("g6_logmel.npz")
+    ex = ref_py.logmel_examples(ref_py.log_mel(g["wave"]))
+    assert ex.shape == g["examples"].shape
+    np.testing.assert_allclose(ex, g["examples"], rtol=0, atol=1e-10)
+    assert ref_py.log_mel(np.zeros(399)).shape == (0, 64) and ref_py.log_mel(np.zeros(400)).shape == (1, 64)
+
+
 # ------------------------------------------------------------------ G8 classic baseline (config 1)
 def test_g8_classic_d1_p1_d2():
     g = gold("g8_classic.npz")
