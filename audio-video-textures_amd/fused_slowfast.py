@@ -21,6 +21,10 @@ from . import ops
 from ._lib import AvtError
 
 
+import os
+
+_KW1_CAP = int(os.environ.get("AVT_GROUP_KW1_CAP", "32"))  # measured: profiles/r01/probe_layers.log
+
 # Optional launch observer for bench.py: PROFILER(name, launch_fn, flops, bytes) must call launch_fn().
 PROFILER = None
 
@@ -121,6 +125,10 @@ class FusedConv:
             return 1  # channel slices of wider rows cannot be re-viewed
         small = min(self.cin, self.cout)
         g = 4 if small <= 16 else (2 if small <= 32 else 1)
+        if self.kernel[2] == 1 and _KW1_CAP:
+            # no taps along W: grouping only fills the tile (block-diagonal weights), so stop at a 32-wide output
+            while g > 1 and g * self.cout > _KW1_CAP:
+                g //= 2
         while g > 1 and x.dims[3] % g:
             g //= 2
         return g

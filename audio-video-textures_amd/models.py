@@ -74,15 +74,14 @@ class _InfoNCELogits(torch.autograd.Function):
     @staticmethod
     def apply_ops(q, t, temp):
         """-> (logits [B,n], q_hat [B,1,D], t_hat [B,D,n]); the unit vectors are only materialised for cam_viz."""
-        if q.is_cuda:
-            out = _InfoNCELogits.apply(q, t, temp)
-            with torch.no_grad():
-                qh = F.normalize(q, dim=1).unsqueeze(1)
-                th = F.normalize(t, dim=2).permute(0, 2, 1)
-            return out, qh, th
-        qh = F.normalize(q, dim=1).unsqueeze(1)
-        th = F.normalize(t, dim=2).permute(0, 2, 1)
-        return torch.bmm(qh, th).squeeze(1) / temp, qh, th
+        if not q.is_cuda:
+            raise AvtError("ContrastivePredictionTemporal training needs the model on the MI355X (model.cuda()); "
+                           "the normalise/bmm/temperature branch runs on the HIP InfoNCE kernels, no CPU fallback")
+        out = _InfoNCELogits.apply(q, t, temp)
+        with torch.no_grad():
+            qh = F.normalize(q, dim=1).unsqueeze(1)
+            th = F.normalize(t, dim=2).permute(0, 2, 1)
+        return out, qh, th
 
 
 class InfoNCECriterion(nn.Module):

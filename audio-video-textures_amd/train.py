@@ -1,12 +1,12 @@
 """`train()` — one epoch of InfoNCE SGD, drop-in for contrastive_video_textures/train.py:39-210
 (same signature, same meters and prints; tensorboard images are skipped when no logger is given).
-The loss runs on the HIP softmax-CE kernels (models.InfoNCECriterion) when the logits are on the GPU."""
+The loss runs on the HIP softmax-CE kernels (models.InfoNCECriterion)."""
 import time
 from collections import OrderedDict
 
 import torch
-import torch.nn as nn
 
+from ._lib import AvtError
 from .models import InfoNCECriterion
 from .utils import AverageMeter
 
@@ -22,14 +22,14 @@ def to_cuda(item):
 def train(train_loader, model, optimizer, args, epoch, tb_logger=None):
     batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
     model.train()
-    on_gpu = next(model.parameters()).is_cuda
-    criterion = InfoNCECriterion() if on_gpu else nn.CrossEntropyLoss()
+    if not next(model.parameters()).is_cuda:
+        raise AvtError("train(): model must be on the MI355X (model.cuda()); the loss runs on the HIP kernels, no CPU fallback")
+    criterion = InfoNCECriterion()
     end = time.time()
     for i, batch_data in enumerate(train_loader):
         q_frames, q_audio_wav, q_audio_eg, t_frames, t_audio_wav, t_audio_eg = batch_data
-        if on_gpu:
-            q_frames, t_frames = to_cuda(q_frames), to_cuda(t_frames)
-            q_audio_eg, t_audio_eg = q_audio_eg.cuda(), t_audio_eg.cuda()
+        q_frames, t_frames = to_cuda(q_frames), to_cuda(t_frames)
+        q_audio_eg, t_audio_eg = q_audio_eg.cuda(), t_audio_eg.cuda()
         data_time.update(time.time() - end)
 
         output = model(q_frames, t_frames, q_audio_eg=q_audio_eg, t_audio_eg=t_audio_eg)  # train.py:114-116

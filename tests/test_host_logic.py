@@ -112,3 +112,26 @@ def test_checkpoint_keys_are_the_reference_prefixes(avt):
     assert "q_encoder.s1_fuse.conv_f2s.weight" in keys
     net, fc_dim = avt.ModelBuilder3D.build_network("resnet18", img_size=32, window=16, pretrained=False)
     assert fc_dim == 128 and net.eval()(torch.zeros(1, 3, 16, 32, 32)).shape[:2] == (1, 512)
+
+
+def test_operator_and_train_refuse_cpu(avt):
+    """No CPU fallback anywhere on the path: the operator (both branches), train() and the engine raise off-device."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tiny_encoders import TinySlowFast, seeded
+    from avtex._lib import AvtError
+
+    m = avt.ContrastivePredictionTemporal(seeded(TinySlowFast, 1), seeded(TinySlowFast, 2), None, 1, 128,
+                                          enc_arch="slowfast", img_size=32, window=5, stride=2, mini_batchsize=2)
+    q = [torch.zeros(2, 3, 8, 32, 32), torch.zeros(2, 3, 32, 32, 32)]
+    t = [torch.zeros(2, 3, 3, 8, 32, 32), torch.zeros(2, 3, 3, 32, 32, 32)]
+    m.train()
+    with pytest.raises(AvtError, match="no CPU fallback"):
+        m(q, t)
+    with pytest.raises(AvtError, match="no CPU fallback"):
+        avt.train([], m, None, None, 0)
+    m.eval()
+    with pytest.raises(AvtError, match="no CPU fallback"):
+        m(q, torch.zeros(1, 12, 32, 32, 3), is_inference=True)
+    with pytest.raises(AvtError, match="no CPU fallback"):
+        avt.ops.l2norm_rows(torch.zeros(4, 8))
