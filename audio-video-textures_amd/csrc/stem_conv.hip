@@ -1,0 +1,236 @@
+// stem_conv — the SlowFast stem convolutions (pixel-pair form) with the input patch resident in LDS.
+// Same arithmetic as conv3d_igemm on the packed stem weights of fused_slowfast.stem_conv (Conv3d(3, C, [kt,7,7],
+// stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU of the third-party SlowFast model the reference calls at
+// contrastive_video_textures/models/models.py:335, 399), for the production shape (224^2 clips).
+//
+// Why a second kernel: as an implicit GEMM the stem gathers every input element once per kernel tap — 16x (slow,
+// [1,7,4] pair taps) to 28x (time-grouped fast stem, [8,7,4]) its own size through L2/L1 and the LDS write port —
+// and that gather, not the MFMA work, bounds conv3d_igemm on these two layers (18 TB/s of L2 reads at 23 % MFMA
+// issue).  Here a workgroup owns 4 full output rows of one (clip, output frame): per input frame it stages the
+// 13 input rows those outputs touch ONCE (24 KB), and the MFMA operand of every (row tap dh, pair tap dp) is read
+// straight from that patch: with v_mfma_f32_16x16x32_bf16 one instruction's K = 32 is exactly the four pair taps x 8
+// channels of one (dt, dh), and a lane's operand is the 16-byte chunk at patch[(2r + dh), wo + dp] — 16 consecutive
+// output columns x 4 taps read overlapping consecutive chunks (conflict-free ds_read_b128, broadcast on overlap).
+// No im2col staging, no tap table, 5-8x fewer bytes gathered per output.
+//
+// Layout: in  [B, T, H, PW, 8] bf16 (the channels-last clip [B,T,H,W,4] read as pixel pairs, PW = W/2),
+//         wt  [Cout, KT, 7, 4, 8] bf16 (BN folded; Cout = frames-per-group x channels for the time-grouped form),
+//         out [B, To, Ho, Wo, Cout] bf16, Ho = H/2, Wo = PW; temporal stride st, temporal pad pt.
+// One wave per output row; the weights are the first MFMA operand (D = Wt * A^T) with the channel order permuted in
+// the LDS image so that a lane ends up with 8 consecutive channels of one position -> one 16-byte store, and the
+// four lane groups of an instruction complete a 64-byte row.  Input frames outside [0, T) are skipped, not zero-
+// filled (the time-grouped form has 8 frame taps of which 2-3 are padding at the clip ends).
+// Roofline: MFMA (structured zeros of the pixel-pair / time-group forms included in the issued work).
+#include <stdlib.h>
+
+#include "avt_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFFFF0u;
+
+struct StemArgs {
+  const uint16_t* in;
+  const uint16_t* wt;
+  const float* bias;
+  uint16_t* out;
+  int T, H, PW;
+  int To, Ho;
+  int KT, st, pt;
+  int Cout;
+  int relu;
+  unsigned in_bytes, wt_bytes;
+};
+
+constexpr int R = 4;              // output rows per workgroup = waves
+constexpr int PROWS = 2 * R + 5;  // input rows 2*ho0-3 .. 2*(ho0+R-1)+3
+constexpr int NT = 2;             // 16-channel tiles per workgroup (32 output channels; blockIdx.y walks the rest)
+constexpr int KF = 7 * 4 * 8;     // K per input frame: 7 row taps x 4 pair taps x 8 (pixel-in-pair, channel)
+constexpr int BCH = NT * 16 * 28;  // 16-byte weight chunks per frame
+constexpr int BU = (BCH + 255) / 256;
+
+template <int MT>
+__global__ __launch_bounds__(256, 3) void stem_kernel(StemArgs a) {
+  constexpr int WO = MT * 16;
+  constexpr int PWP = WO + 4;  // patch row: pairs -2 .. WO+1
+  constexpr int PCH = PROWS * PWP;
+  constexpr int PU = (PCH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* lp = lds;             // patch [PROWS][PWP] x 16 B
+  char* lb = lds + PCH * 16;  // weights [7 dh][NT][4 dp][16 rows] x 16 B
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int hgroups = a.Ho / R;
+  int bid = blockIdx.x;
+  const int hg = bid % hgroups;
+  bid /= hgroups;
+  const int to = bid % a.To, b = bid / a.To;
+  const int ho0 = hg * R;
+  const int n_base = blockIdx.y * (NT * 16);
+
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+
+  // per-thread patch chunks: byte offset inside a frame, or out of bounds (padding rows / pairs)
+  unsigned poff[PU];
+#pragma unroll
+  for (int u = 0; u < PU; ++u) {
+    const int c = tid + 256 * u;
+    const int j = c / PWP, col = c - j * PWP;
+    const int hi = 2 * ho0 - 3 + j, wi = col - 2;
+    const bool ok = c < PCH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.PW;
+    poff[u] = ok ? (unsigned)((hi * a.PW + wi) * 16) : kOob;
+  }
+  // per-thread weight chunks: global byte offset inside a frame's K range, and the LDS slot.  Channel order in the
+  // LDS image: tile nt, row 4q'+i  <-  channel 8q' + 4nt + i, so a lane's two accumulators are 8 consecutive channels
+  unsigned boff[BU];
+  int bslot[BU];
+#pragma unroll
+  for (int u = 0; u < BU; ++u) {
+    const int e = tid + 256 * u;
+    const int n = e / 28, rem = e - n * 28;  // rem = dh*4 + dp
+    const int dh = rem >> 2, dp = rem & 3;
+    const int qq = n >> 3, nt = (n >> 2) & 1, i = n & 3;
+    const bool ok = e < BCH && n_base + n < a.Cout;
+    boff[u] = ok ? (unsigned)(((n_base + n) * (a.KT * KF) + rem * 8) * 2) : kOob;
+    bslot[u] = (((dh * NT + nt) * 4 + dp) * 16 + 4 * qq + i) * 16;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // frame taps that fall inside the clip
+  const int t0 = to * a.st - a.pt;
+  const int dt_lo = t0 < 0 ? -t0 : 0;
+  const int dt_hi = (a.T - t0) < a.KT ? (a.T - t0) : a.KT;
+
+  i32x4 rp[PU], rb[BU];
+  auto gload = [&](int dt) {
+    const unsigned fbase = (unsigned)(((b * a.T + t0 + dt) * a.H) * a.PW) * 16u;
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const unsigned off = poff[u] == kOob ? kOob : fbase + poff[u];
+      rp[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0);
+    }
+    const unsigned kb = (unsigned)(dt * KF * 2);
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      const unsigned off = boff[u] == kOob ? kOob : boff[u] + kb;
+      rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rwt, (int)off, 0, 0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int c = tid + 256 * u;
+      if (c < PCH) *reinterpret_cast<i32x4*>(lp + c * 16) = rp[u];
+    }
+#pragma unroll
+    for (int u = 0; u < BU; ++u)
+      if (tid + 256 * u < BCH) *reinterpret_cast<i32x4*>(lb + bslot[u]) = rb[u];
+  };
+
+  if (dt_lo < dt_hi) gload(dt_lo);
+  for (int dt = dt_lo; dt < dt_hi; ++dt) {
+    lstore();
+    __syncthreads();
+    if (dt + 1 < dt_hi) gload(dt + 1);  // in flight under this frame's MFMAs
+#pragma unroll
+    for (int dh = 0; dh < 7; ++dh) {
+      bf16x8 bf[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        bf[n] = *reinterpret_cast<const bf16x8*>(lb + (((dh * NT + n) * 4 + q) * 16 + l15) * 16);
+      const char* prow = lp + ((2 * w + dh) * PWP + l15 + q) * 16;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(prow + m * 256);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[n], af, acc[m][n], 0, 0, 0);  // D[channel][position]
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane = position (mt*16 + l15) of row ho0 + w, channels n_base + 8q .. +7
+  const int c0 = n_base + 8 * q;
+  if (c0 < a.Cout) {
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (a.bias) {
+      b0 = *reinterpret_cast<const float4*>(a.bias + c0);
+      b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
+    }
+    uint16_t* orow = a.out + ((int64_t)((b * a.To + to) * a.Ho + ho0 + w) * WO) * a.Cout + c0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float v[8] = {acc[m][0][0] + b0.x, acc[m][0][1] + b0.y, acc[m][0][2] + b0.z, acc[m][0][3] + b0.w,
+                    acc[m][1][0] + b1.x, acc[m][1][1] + b1.y, acc[m][1][2] + b1.z, acc[m][1][3] + b1.w};
+      if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      uint4 pk;
+      pk.x = avt::pack_bf16x2(v[0], v[1]);
+      pk.y = avt::pack_bf16x2(v[2], v[3]);
+      pk.z = avt::pack_bf16x2(v[4], v[5]);
+      pk.w = avt::pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(orow + (int64_t)(m * 16 + l15) * a.Cout) = pk;
+    }
+  }
+}
+
+template <int MT>
+int launch(const StemArgs& a, int batch, hipStream_t st) {
+  constexpr int lds_bytes = (PROWS * (MT * 16 + 4) + BCH) * 16;
+  const dim3 grid((unsigned)(batch * a.To * (a.Ho / R)), (unsigned)((a.Cout + NT * 16 - 1) / (NT * 16)));
+  hipLaunchKernelGGL((stem_kernel<MT>), grid, dim3(256), lds_bytes, st, a);
+  return avt::check_launch("avt_stem_conv_bf16");
+}
+
+}  // namespace
+
+extern "C" int avt_stem_conv_supported(int h, int pw, int cout) {
+  return (h % 2 == 0 && (h / 2) % R == 0 && (pw == 112 || pw == 32) && cout % 8 == 0) ? 1 : 0;
+}
+
+extern "C" int avt_stem_conv_bf16(const void* in, const void* wt, const float* bias, void* out, int batch, int t, int h,
+                                  int pw, int cout, int kt, int st, int pt, int relu, void* stream) {
+  AVT_REQUIRE(in && wt && out, "avt_stem_conv_bf16: NULL pointer");
+  AVT_REQUIRE(batch > 0 && t > 0 && kt > 0 && st > 0 && pt >= 0 && pt < kt, "avt_stem_conv_bf16: bad sizes");
+  AVT_REQUIRE(avt_stem_conv_supported(h, pw, cout),
+              "avt_stem_conv_bf16: unsupported shape h=%d pairs=%d cout=%d (rows/2 %% 4 == 0, 112 or 32 pairs; use "
+              "avt_conv3d_igemm_bf16)", h, pw, cout);
+  AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(wt) && avt::aligned16(out) && (!bias || avt::aligned16(bias)),
+              "avt_stem_conv_bf16: pointers must be 16-byte aligned");
+  StemArgs a;
+  a.in = static_cast<const uint16_t*>(in);
+  a.wt = static_cast<const uint16_t*>(wt);
+  a.bias = bias;
+  a.out = static_cast<uint16_t*>(out);
+  a.T = t;
+  a.H = h;
+  a.PW = pw;
+  a.To = (t + 2 * pt - kt) / st + 1;
+  a.Ho = h / 2;
+  a.KT = kt;
+  a.st = st;
+  a.pt = pt;
+  a.Cout = cout;
+  a.relu = relu;
+  AVT_REQUIRE(a.To > 0, "avt_stem_conv_bf16: no output frames");
+  const int64_t in_b = (int64_t)batch * t * h * pw * 16, wt_b = (int64_t)cout * kt * KF * 2;
+  AVT_REQUIRE(in_b < (1ll << 32) - 64 && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
+              "avt_stem_conv_bf16: tensor too large for 32-bit offsets");
+  a.in_bytes = (unsigned)in_b;
+  a.wt_bytes = (unsigned)wt_b;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pw == 112 ? launch<7>(a, batch, s) : launch<2>(a, batch, s);
+}

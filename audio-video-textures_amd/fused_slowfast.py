@@ -23,6 +23,7 @@ from ._lib import AvtError
 
 import os
 
+_STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 _KW1_CAP = int(os.environ.get("AVT_GROUP_KW1_CAP", "32"))  # measured: profiles/r01/probe_layers.log
 
 # Optional launch observer for bench.py: PROFILER(name, launch_fn, flops, bytes) must call launch_fn().
@@ -265,7 +266,24 @@ class SlowFastMFMA(nn.Module):
         b, t, h, w, _ = clip.shape
         if t % conv.tgroup:
             raise AvtError("stem: %d frames do not split into groups of %d" % (t, conv.tgroup))
-        y = conv(Act(clip.view(b * t * h * (w // 2), 8), (b, t, h, w // 2)))
+        x = Act(clip.view(b * t * h * (w // 2), 8), (b, t, h, w // 2))
+        if _STEM_LDS and ops.stem_conv_supported(h, w // 2, conv.cout):
+            # production shape: the patch-resident stem kernel (5-8x fewer bytes gathered than the implicit GEMM)
+            od = conv.out_dims(x.dims)
+            y = Act(torch.empty((od[0] * od[1] * od[2] * od[3], conv.cout), dtype=torch.bfloat16, device=self.dev), od)
+            kt, st, pt = conv.kernel[0], conv.stride[0], conv.pad[0]
+
+            def launch():
+                ops.stem_conv(x.ptr, conv.wt, conv.bias, y.ptr, b, t, h, w // 2, conv.cout, kt, st, pt, relu=True)
+
+            if PROFILER is None:
+                launch()
+            else:
+                m_out = od[0] * od[1] * od[2] * od[3]
+                PROFILER("conv3d_igemm_bf16", launch, m_out * conv.alg_flops_per_row,
+                         2.0 * (x.buf.numel() + m_out * conv.cout) + conv.wt.numel() * 2)
+        else:
+            y = conv(x)
         _, tg, h2, w2 = y.dims
         pd = (b, t, (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1)
         cf = conv.frame_channels

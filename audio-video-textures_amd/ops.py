@@ -222,6 +222,20 @@ def maxpool_hw3s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo, tgroup=1):
                "avt_maxpool_hw3s2_ndhwc_bf16")
 
 
+def stem_conv_supported(h, pw, cout):
+    return bool(_lib.lib().avt_stem_conv_supported(int(h), int(pw), int(cout)))
+
+
+def stem_conv(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu=True):
+    """SlowFast stem in pixel-pair form, input patch resident in LDS (csrc/stem_conv.hip); raw device addresses for the
+    activations, wt [cout, kt*224] bf16, bias [cout] fp32."""
+    _dev(wt, "wt", torch.bfloat16)
+    _dev(bias, "bias", torch.float32)
+    _lib.check(_lib.lib().avt_stem_conv_bf16(C.c_void_p(x_ptr), _p(wt), _p(bias), C.c_void_p(out_ptr), int(batch), int(t),
+                                             int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(bool(relu)),
+                                             _stream()), "avt_stem_conv_bf16")
+
+
 def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
     """MaxPool2d(2, 2), floor mode, on NHWC bf16 rows (raw device addresses) — VGGish (audio_models/vggish.py:15-33)."""
     _lib.check(_lib.lib().avt_maxpool_hw2s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),

@@ -226,6 +226,19 @@ int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w
 int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w,
                                  int c, int ldi, int ldo, void* stream);
 
+/* SlowFast stem convolution in pixel-pair form with the input patch resident in LDS (csrc/stem_conv.hip):
+ * the Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU at the head of both pathways of
+ * the third-party SlowFast model the reference runs per clip window (models/models.py:335, 399).
+ * in  [batch, t, h, pw, 8] bf16 = the channels-last clip [.., w, 4] read as pixel pairs (pw = w/2),
+ * wt  [cout, kt, 7, 4, 8] bf16 (BN folded; kt frame taps, temporal stride st, temporal pad pt),
+ * out [batch, (t+2pt-kt)/st+1, h/2, pw, cout] bf16.  Same results as avt_conv3d_igemm_bf16 on the same
+ * packed weights up to fp32 summation order.  avt_stem_conv_supported() tells whether the shape is
+ * covered (production 224^2 clips: pw = 112, (h/2) % 4 == 0); other shapes go to the generic entry. */
+int avt_stem_conv_supported(int h, int pw, int cout);
+int avt_stem_conv_bf16(const void* in, const void* wt, const float* bias, void* out,
+                       int batch, int t, int h, int pw, int cout, int kt, int st, int pt,
+                       int relu, void* stream);
+
 /* VGGish audio front-end (utils/mel_features.py:21-92, 176-205 log_mel_spectrogram; called once per
  * video from utils/vggish_utils.py:27-69), float64 like the reference's NumPy code:
  * frame f = wave[f*hop, f*hop+win) * window -> |DFT_fft_len| -> spec[fft_len/2+1] . melmat -> log(. + log_offset).

@@ -205,3 +205,45 @@ def test_fused_vggish_matches_module(avt, dev):
     a = conv(Act(xb.to(dev).contiguous().view(5 * 100 * 8, 8), (5, 1, 100, 8)))
     got = a.buf.view(5, 100, 64, cout).permute(0, 3, 1, 2).float().cpu()
     assert (got - ref0).abs().max() < 0.01 * max(ref0.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("hw", [224, 64])
+def test_stem_lds_kernel_matches_generic_and_torch(avt, dev, hw):
+    """csrc/stem_conv.hip (input patch resident in LDS, 16x16x32 MFMA) against the implicit-GEMM kernel on the same
+    packed weights (same products, different fp32 summation order -> <= 1 bf16 ulp) and against the PyTorch stem
+    module, both pathways, including the clip's first/last frames (frame taps outside the clip are skipped)."""
+    from avtex.fused_slowfast import Act, SlowFastMFMA
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(8)
+    m = SlowFast().eval()
+    with torch.no_grad():
+        for mod in m.s1.modules():
+            if isinstance(mod, nn.BatchNorm3d):
+                mod.weight.uniform_(0.6, 1.2); mod.bias.uniform_(-0.2, 0.2)
+                mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.8, 1.2)
+    fused = SlowFastMFMA(m, dev)
+    for conv, stem, t in ((fused.stem_s, m.s1.pathway0_stem, 3), (fused.stem_f, m.s1.pathway1_stem, 8)):
+        assert avt.ops.stem_conv_supported(hw, hw // 2, conv.cout)
+        x = torch.randn(2, 3, t, hw, hw).to(torch.bfloat16)
+        clip = torch.zeros((2, t, hw, hw, 4), dtype=torch.bfloat16)
+        clip[..., :3] = x.permute(0, 2, 3, 4, 1)
+        clip = clip.to(dev)
+        xa = Act(clip.view(-1, 8), (2, t, hw, hw // 2))
+        gen = conv(xa)  # implicit GEMM
+        od = gen.dims
+        y = torch.full((od[0] * od[1] * od[2] * od[3], conv.cout), 7.0, dtype=torch.bfloat16, device=dev)
+        avt.ops.stem_conv(xa.ptr, conv.wt, conv.bias, y.data_ptr(), 2, t, hw, hw // 2, conv.cout, conv.kernel[0],
+                          conv.stride[0], conv.pad[0])
+        torch.cuda.synchronize()
+        a, g = y.float(), gen.buf.float()
+        scale = max(g.abs().max().item(), 1.0)
+        assert (a - g).abs().max().item() <= 0.01 * scale
+        assert (a != g).float().mean().item() < 0.05  # a few last-bit differences only
+        # through the pool, against torch (as test_stem_on_mfma_matches_torch does for the generic path)
+        act, pd = fused._stem(conv, clip)
+        with torch.no_grad():
+            ref = stem(x.float())
+        got = act.buf.float().cpu().view(*pd, conv.frame_channels).permute(0, 4, 1, 2, 3)
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max() < 0.03 * max(ref.abs().max().item(), 1.0)

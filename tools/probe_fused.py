@@ -35,6 +35,11 @@ orig = avtex.ops.conv3d_igemm
 def spy(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu, out_dims=(0, 0, 0)):
     shapes.append("cin%d cout%d k%s s%s in%s%s" % (cin, cout, kernel, stride, tuple(dims), " +res" if res_ptr else ""))
     return orig(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu, out_dims)
+orig_stem = avtex.ops.stem_conv
+def spy_stem(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu=True):
+    shapes.append("stem(LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)" % (cout, kt, st, batch, t, h, pw))
+    return orig_stem(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu)
+avtex.ops.stem_conv = spy_stem
 avtex.ops.conv3d_igemm = spy
 fsf.ops.conv3d_igemm = spy
 fsf.PROFILER = hook
