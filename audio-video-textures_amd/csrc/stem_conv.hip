@@ -14,7 +14,8 @@
 // No im2col staging, no tap table, 5-8x fewer bytes gathered per output.
 //
 // Layout: in  [B, T, H, PW, 8] bf16 (the channels-last clip [B,T,H,W,4] read as pixel pairs, PW = W/2),
-//         wt  [Cout, KT, 7, 4, 8] bf16 (BN folded; Cout = frames-per-group x channels for the time-grouped form),
+//         wt  [Cout/32, KT, 7, 2, 4, 16, 8] bf16 = the LDS image of each 32-channel group's frame-tap slab (BN folded;
+//             Cout = frames-per-group x channels for the time-grouped form), see include/avt.h,
 //         out [B, To, Ho, Wo, Cout] bf16, Ho = H/2, Wo = PW; temporal stride st, temporal pad pt.
 // One wave per output row; the weights are the first MFMA operand (D = Wt * A^T) with the channel order permuted in
 // the LDS image so that a lane ends up with 8 consecutive channels of one position -> one 16-byte store, and the
@@ -43,33 +44,46 @@ struct StemArgs {
   int Cout;
   int relu;
   unsigned in_bytes, wt_bytes;
+  // fused max-pool (POOL): out is the pooled tensor [B, To*tgroup, Ho/2, Wo/2, .] with row stride ldo (elements)
+  int tgroup, ldo;
 };
 
-constexpr int R = 4;              // output rows per workgroup = waves
-constexpr int PROWS = 2 * R + 5;  // input rows 2*ho0-3 .. 2*(ho0+R-1)+3
+constexpr int RB = 4;  // conv rows a workgroup OWNS (plain: computes these; pooled: computes one more above them)
 constexpr int NT = 2;             // 16-channel tiles per workgroup (32 output channels; blockIdx.y walks the rest)
 constexpr int KF = 7 * 4 * 8;     // K per input frame: 7 row taps x 4 pair taps x 8 (pixel-in-pair, channel)
 constexpr int BCH = NT * 16 * 28;  // 16-byte weight chunks per frame
-constexpr int BU = (BCH + 255) / 256;
 
-template <int MT>
-__global__ __launch_bounds__(256, 3) void stem_kernel(StemArgs a) {
+__device__ __forceinline__ uint32_t max2(uint32_t x, uint32_t y) {  // packed bf16x2 max
+  const uint32_t lo = (avt::bf16x2_lo(y) > avt::bf16x2_lo(x)) ? (y & 0xffffu) : (x & 0xffffu);
+  const uint32_t hi = (avt::bf16x2_hi(y) > avt::bf16x2_hi(x)) ? (y & 0xffff0000u) : (x & 0xffff0000u);
+  return lo | hi;
+}
+
+// POOL: the workgroup computes conv rows 4hg-1 .. 4hg+3 (5 waves; the first is recomputed by its upper neighbour's
+// lower edge) and writes the two MaxPool3d((1,3,3),(1,2,2),(0,1,1)) rows 2hg, 2hg+1 they complete — the conv output
+// never reaches HBM.  Needs ReLU (values >= 0, so the pool's padding can be 0).
+template <int MT, bool POOL>
+__global__ __launch_bounds__(POOL ? 320 : 256, POOL ? 2 : 3) void stem_kernel(StemArgs a) {
+  constexpr int R = POOL ? RB + 1 : RB;  // conv rows computed = waves
+  constexpr int NTHR = R * 64;
+  constexpr int PROWS = 2 * R + 5;  // input rows 2*r0-3 .. 2*(r0+R-1)+3
+  constexpr int BU = (BCH + NTHR - 1) / NTHR;
   constexpr int WO = MT * 16;
   constexpr int PWP = WO + 4;  // patch row: pairs -2 .. WO+1
   constexpr int PCH = PROWS * PWP;
-  constexpr int PU = (PCH + 255) / 256;
+  constexpr int PU = (PCH + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* lp = lds;             // patch [PROWS][PWP] x 16 B
   char* lb = lds + PCH * 16;  // weights [7 dh][NT][4 dp][16 rows] x 16 B
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
-  const int hgroups = a.Ho / R;
+  const int hgroups = a.Ho / RB;
   int bid = blockIdx.x;
   const int hg = bid % hgroups;
   bid /= hgroups;
   const int to = bid % a.To, b = bid / a.To;
-  const int ho0 = hg * R;
+  const int ho0 = hg * RB - (POOL ? 1 : 0);  // first conv row computed (may be -1: that wave's result is unused)
   const int n_base = blockIdx.y * (NT * 16);
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
@@ -79,26 +93,16 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemArgs a) {
   unsigned poff[PU];
 #pragma unroll
   for (int u = 0; u < PU; ++u) {
-    const int c = tid + 256 * u;
+    const int c = tid + NTHR * u;
     const int j = c / PWP, col = c - j * PWP;
     const int hi = 2 * ho0 - 3 + j, wi = col - 2;
     const bool ok = c < PCH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.PW;
     poff[u] = ok ? (unsigned)((hi * a.PW + wi) * 16) : kOob;
   }
-  // per-thread weight chunks: global byte offset inside a frame's K range, and the LDS slot.  Channel order in the
-  // LDS image: tile nt, row 4q'+i  <-  channel 8q' + 4nt + i, so a lane's two accumulators are 8 consecutive channels
-  unsigned boff[BU];
-  int bslot[BU];
-#pragma unroll
-  for (int u = 0; u < BU; ++u) {
-    const int e = tid + 256 * u;
-    const int n = e / 28, rem = e - n * 28;  // rem = dh*4 + dp
-    const int dh = rem >> 2, dp = rem & 3;
-    const int qq = n >> 3, nt = (n >> 2) & 1, i = n & 3;
-    const bool ok = e < BCH && n_base + n < a.Cout;
-    boff[u] = ok ? (unsigned)(((n_base + n) * (a.KT * KF) + rem * 8) * 2) : kOob;
-    bslot[u] = (((dh * NT + nt) * 4 + dp) * 16 + 4 * qq + i) * 16;
-  }
+  // weights arrive in the LDS image order [group of 32 channels][frame tap][7 dh][NT][4 dp][16 rows] x 16 B (host-side
+  // repack, see include/avt.h): staging them is a linear copy — coalesced global reads, conflict-free ds_write_b128.
+  // Row 4q'+i of tile nt holds channel 8q' + 4nt + i of the group, so a lane's two accumulators are 8 consecutive channels.
+  const unsigned gbase = (unsigned)(blockIdx.y * a.KT) * (unsigned)(BCH * 16);
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -119,22 +123,22 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemArgs a) {
       const unsigned off = poff[u] == kOob ? kOob : fbase + poff[u];
       rp[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0);
     }
-    const unsigned kb = (unsigned)(dt * KF * 2);
+    const unsigned kb = gbase + (unsigned)dt * (unsigned)(BCH * 16);
 #pragma unroll
     for (int u = 0; u < BU; ++u) {
-      const unsigned off = boff[u] == kOob ? kOob : boff[u] + kb;
-      rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rwt, (int)off, 0, 0);
+      const int e = tid + NTHR * u;
+      rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rwt, (int)(e < BCH ? kb + (unsigned)e * 16u : kOob), 0, 0);
     }
   };
   auto lstore = [&]() {
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
-      const int c = tid + 256 * u;
+      const int c = tid + NTHR * u;
       if (c < PCH) *reinterpret_cast<i32x4*>(lp + c * 16) = rp[u];
     }
 #pragma unroll
     for (int u = 0; u < BU; ++u)
-      if (tid + 256 * u < BCH) *reinterpret_cast<i32x4*>(lb + bslot[u]) = rb[u];
+      if (tid + NTHR * u < BCH) *reinterpret_cast<i32x4*>(lb + (tid + NTHR * u) * 16) = rb[u];
   };
 
   if (dt_lo < dt_hi) gload(dt_lo);
@@ -160,57 +164,88 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemArgs a) {
     __syncthreads();
   }
 
-  // epilogue: lane = position (mt*16 + l15) of row ho0 + w, channels n_base + 8q .. +7
+  // epilogue: lane = position (mt*16 + l15) of conv row ho0 + w, channels n_base + 8q .. +7
   const int c0 = n_base + 8 * q;
-  if (c0 < a.Cout) {
-    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-    if (a.bias) {
-      b0 = *reinterpret_cast<const float4*>(a.bias + c0);
-      b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (a.bias && c0 < a.Cout) {
+    b0 = *reinterpret_cast<const float4*>(a.bias + c0);
+    b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
+  }
+  auto packed = [&](int m) {
+    float v[8] = {acc[m][0][0] + b0.x, acc[m][0][1] + b0.y, acc[m][0][2] + b0.z, acc[m][0][3] + b0.w,
+                  acc[m][1][0] + b1.x, acc[m][1][1] + b1.y, acc[m][1][2] + b1.z, acc[m][1][3] + b1.w};
+    if (a.relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     }
-    uint16_t* orow = a.out + ((int64_t)((b * a.To + to) * a.Ho + ho0 + w) * WO) * a.Cout + c0;
+    uint4 pk;
+    pk.x = avt::pack_bf16x2(v[0], v[1]);
+    pk.y = avt::pack_bf16x2(v[2], v[3]);
+    pk.z = avt::pack_bf16x2(v[4], v[5]);
+    pk.w = avt::pack_bf16x2(v[6], v[7]);
+    return pk;
+  };
+  if constexpr (!POOL) {
+    if (c0 < a.Cout) {
+      uint16_t* orow = a.out + ((int64_t)((b * a.To + to) * a.Ho + ho0 + w) * WO) * a.Cout + c0;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      float v[8] = {acc[m][0][0] + b0.x, acc[m][0][1] + b0.y, acc[m][0][2] + b0.z, acc[m][0][3] + b0.w,
-                    acc[m][1][0] + b1.x, acc[m][1][1] + b1.y, acc[m][1][2] + b1.z, acc[m][1][3] + b1.w};
-      if (a.relu) {
+      for (int m = 0; m < MT; ++m) *reinterpret_cast<uint4*>(orow + (int64_t)(m * 16 + l15) * a.Cout) = packed(m);
+    }
+  } else {
+    // conv tile [R rows][WO][32 channels] bf16 in LDS (over the patch: every wave is past its last read of it)
+    constexpr int TROW = WO * 64;  // bytes per conv row
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    for (int m = 0; m < MT; ++m) *reinterpret_cast<uint4*>(lds + w * TROW + (m * 16 + l15) * 64 + q * 16) = packed(m);
+    __syncthreads();
+    constexpr int WP = WO / 2;
+    const int Hp = a.Ho / 2;
+    const int cf = a.Cout / a.tgroup;  // channels per output frame (time-grouped form: Cout = tgroup frames x cf)
+    for (int i = tid; i < 2 * WP * 4; i += NTHR) {
+      const int cc = i & 3, pw_ = (i >> 2) % WP, pl = (i >> 2) / WP;  // 8-channel chunk, pooled column, pooled row (0/1)
+      const int ch = n_base + cc * 8;
+      if (ch >= a.Cout) continue;
+      uint4 mx = make_uint4(0u, 0u, 0u, 0u);  // ReLU output >= 0 == bf16 +0
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) {
+        const int tr = 2 * pl + dh;  // tile row; conv row = ho0 + tr
+        if (ho0 + tr < 0) continue;
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+          const int wc = 2 * pw_ - 1 + dw;
+          if (wc < 0) continue;
+          const uint4 v = *reinterpret_cast<const uint4*>(lds + tr * TROW + wc * 64 + cc * 16);
+          mx.x = max2(mx.x, v.x);
+          mx.y = max2(mx.y, v.y);
+          mx.z = max2(mx.z, v.z);
+          mx.w = max2(mx.w, v.w);
+        }
       }
-      uint4 pk;
-      pk.x = avt::pack_bf16x2(v[0], v[1]);
-      pk.y = avt::pack_bf16x2(v[2], v[3]);
-      pk.z = avt::pack_bf16x2(v[4], v[5]);
-      pk.w = avt::pack_bf16x2(v[6], v[7]);
-      *reinterpret_cast<uint4*>(orow + (int64_t)(m * 16 + l15) * a.Cout) = pk;
+      const int j = ch / cf, cin_f = ch - j * cf;  // output frame within the time group, channel within the frame
+      const int64_t pos = ((int64_t)((b * a.To + to) * a.tgroup + j) * Hp + 2 * hg + pl) * WP + pw_;
+      *reinterpret_cast<uint4*>(a.out + pos * a.ldo + cin_f) = mx;
     }
   }
 }
 
-template <int MT>
-int launch(const StemArgs& a, int batch, hipStream_t st) {
-  constexpr int lds_bytes = (PROWS * (MT * 16 + 4) + BCH) * 16;
-  const dim3 grid((unsigned)(batch * a.To * (a.Ho / R)), (unsigned)((a.Cout + NT * 16 - 1) / (NT * 16)));
-  hipLaunchKernelGGL((stem_kernel<MT>), grid, dim3(256), lds_bytes, st, a);
-  return avt::check_launch("avt_stem_conv_bf16");
+template <int MT, bool POOL>
+int launch(const StemArgs& a, int batch, hipStream_t st, const char* what) {
+  constexpr int R = POOL ? RB + 1 : RB;
+  constexpr int patch = ((2 * R + 5) * (MT * 16 + 4) + BCH) * 16, tile = POOL ? R * MT * 16 * 64 : 0;
+  constexpr int lds_bytes = patch > tile ? patch : tile;
+  const dim3 grid((unsigned)(batch * a.To * (a.Ho / RB)), (unsigned)((a.Cout + NT * 16 - 1) / (NT * 16)));
+  hipLaunchKernelGGL((stem_kernel<MT, POOL>), grid, dim3(R * 64), lds_bytes, st, a);
+  return avt::check_launch(what);
 }
 
-}  // namespace
-
-extern "C" int avt_stem_conv_supported(int h, int pw, int cout) {
-  return (h % 2 == 0 && (h / 2) % R == 0 && (pw == 112 || pw == 32) && cout % 8 == 0) ? 1 : 0;
-}
-
-extern "C" int avt_stem_conv_bf16(const void* in, const void* wt, const float* bias, void* out, int batch, int t, int h,
-                                  int pw, int cout, int kt, int st, int pt, int relu, void* stream) {
-  AVT_REQUIRE(in && wt && out, "avt_stem_conv_bf16: NULL pointer");
-  AVT_REQUIRE(batch > 0 && t > 0 && kt > 0 && st > 0 && pt >= 0 && pt < kt, "avt_stem_conv_bf16: bad sizes");
+int fill(StemArgs& a, const char* what, const void* in, const void* wt, const float* bias, void* out, int batch, int t,
+         int h, int pw, int cout, int kt, int st, int pt, int relu) {
+  AVT_REQUIRE(in && wt && out, "%s: NULL pointer", what);
+  AVT_REQUIRE(batch > 0 && t > 0 && kt > 0 && st > 0 && pt >= 0 && pt < kt, "%s: bad sizes", what);
   AVT_REQUIRE(avt_stem_conv_supported(h, pw, cout),
-              "avt_stem_conv_bf16: unsupported shape h=%d pairs=%d cout=%d (rows/2 %% 4 == 0, 112 or 32 pairs; use "
-              "avt_conv3d_igemm_bf16)", h, pw, cout);
+              "%s: unsupported shape h=%d pairs=%d cout=%d (rows/2 %% 4 == 0, 112 or 32 pairs; use "
+              "avt_conv3d_igemm_bf16)", what, h, pw, cout);
   AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(wt) && avt::aligned16(out) && (!bias || avt::aligned16(bias)),
-              "avt_stem_conv_bf16: pointers must be 16-byte aligned");
-  StemArgs a;
+              "%s: pointers must be 16-byte aligned", what);
   a.in = static_cast<const uint16_t*>(in);
   a.wt = static_cast<const uint16_t*>(wt);
   a.bias = bias;
@@ -225,12 +260,43 @@ extern "C" int avt_stem_conv_bf16(const void* in, const void* wt, const float* b
   a.pt = pt;
   a.Cout = cout;
   a.relu = relu;
-  AVT_REQUIRE(a.To > 0, "avt_stem_conv_bf16: no output frames");
+  a.tgroup = 1;
+  a.ldo = cout;
+  AVT_REQUIRE(a.To > 0, "%s: no output frames", what);
   const int64_t in_b = (int64_t)batch * t * h * pw * 16, wt_b = (int64_t)cout * kt * KF * 2;
   AVT_REQUIRE(in_b < (1ll << 32) - 64 && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
-              "avt_stem_conv_bf16: tensor too large for 32-bit offsets");
+              "%s: tensor too large for 32-bit offsets", what);
   a.in_bytes = (unsigned)in_b;
   a.wt_bytes = (unsigned)wt_b;
+  return AVT_OK;
+}
+
+}  // namespace
+
+extern "C" int avt_stem_conv_supported(int h, int pw, int cout) {
+  return (h % 2 == 0 && (h / 2) % RB == 0 && (pw == 112 || pw == 32) && cout % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int avt_stem_conv_bf16(const void* in, const void* wt, const float* bias, void* out, int batch, int t, int h,
+                                  int pw, int cout, int kt, int st, int pt, int relu, void* stream) {
+  StemArgs a;
+  const int rc = fill(a, "avt_stem_conv_bf16", in, wt, bias, out, batch, t, h, pw, cout, kt, st, pt, relu);
+  if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return pw == 112 ? launch<7>(a, batch, s) : launch<2>(a, batch, s);
+  return pw == 112 ? launch<7, false>(a, batch, s, "avt_stem_conv_bf16") : launch<2, false>(a, batch, s, "avt_stem_conv_bf16");
+}
+
+extern "C" int avt_stem_conv_pool_bf16(const void* in, const void* wt, const float* bias, void* out, int batch, int t,
+                                       int h, int pw, int cout, int kt, int st, int pt, int tgroup, int ldo,
+                                       void* stream) {
+  StemArgs a;
+  const int rc = fill(a, "avt_stem_conv_pool_bf16", in, wt, bias, out, batch, t, h, pw, cout, kt, st, pt, 1);
+  if (rc) return rc;
+  AVT_REQUIRE(tgroup >= 1 && cout % tgroup == 0 && (cout / tgroup) % 8 == 0 && ldo % 8 == 0 && ldo >= cout / tgroup,
+              "avt_stem_conv_pool_bf16: tgroup must split the channels into multiples of 8; ldo >= channels per frame");
+  a.tgroup = tgroup;
+  a.ldo = ldo;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pw == 112 ? launch<7, true>(a, batch, s, "avt_stem_conv_pool_bf16")
+                   : launch<2, true>(a, batch, s, "avt_stem_conv_pool_bf16");
 }

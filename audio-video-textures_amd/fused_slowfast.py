@@ -24,6 +24,7 @@ from ._lib import AvtError
 import os
 
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
+_STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "0"))  # fused pool: bit-identical but slower (probe_stem_pool_ab.log)
 _KW1_CAP = int(os.environ.get("AVT_GROUP_KW1_CAP", "32"))  # measured: profiles/r01/probe_layers.log
 
 # Optional launch observer for bench.py: PROFILER(name, launch_fn, flops, bytes) must call launch_fn().
@@ -126,8 +127,9 @@ class FusedConv:
             return 1  # channel slices of wider rows cannot be re-viewed
         small = min(self.cin, self.cout)
         g = 4 if small <= 16 else (2 if small <= 32 else 1)
-        if self.kernel[2] == 1 and _KW1_CAP:
-            # no taps along W: grouping only fills the tile (block-diagonal weights), so stop at a 32-wide output
+        if self.kernel[2] == 1 and self.kernel[0] > 1 and _KW1_CAP:
+            # temporal taps only: grouping just fills the tile (block-diagonal weights), so stop at a 32-wide output
+            # (pointwise layers stay grouped: they are HBM-bound and gain from 4x fewer, fuller rows)
             while g > 1 and g * self.cout > _KW1_CAP:
                 g //= 2
         while g > 1 and x.dims[3] % g:
@@ -182,6 +184,14 @@ class FusedConv:
         return out
 
 
+def stem_lds_image(wt, kt):
+    """Packed stem weights [Cout, kt*7*4*8] -> the LDS image order of csrc/stem_conv.hip (include/avt.h):
+    [Cout/32, kt, 7 dh, 2 tiles, 4 dp, 16 rows, 8], channel = 32*group + 8*(row//4) + 4*tile + row%4."""
+    cout = wt.shape[0]
+    w = wt.reshape(cout // 32, 4, 2, 4, kt, 7, 4, 8)  # [G, q, tile, i, dt, dh, dp, 8]
+    return w.permute(0, 4, 5, 2, 6, 1, 3, 7).contiguous().reshape(cout // 32, -1)
+
+
 def stem_conv(stem, device, tgroup=1):
     """Stem Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU in pixel-pair form (see module doc).
 
@@ -208,11 +218,13 @@ def stem_conv(stem, device, tgroup=1):
                                  (kt // 2, 3, 2), (0, 0, 1)))
         conv.tgroup, conv.frame_channels = g, c
         conv.alg_flops_per_row = g * 2.0 * (kt * kh * kw * 3) * c
+        conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1) if conv.cout % 32 == 0 else None
         return conv
     conv = FusedConv(None, None, True, device,
                      packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)))
     conv.tgroup, conv.frame_channels = 1, c
     conv.alg_flops_per_row = 2.0 * (kt * kh * kw * 3) * c
+    conv.wt_lds = stem_lds_image(conv.wt, kt) if conv.cout % 32 == 0 else None
     return conv
 
 
@@ -267,19 +279,36 @@ class SlowFastMFMA(nn.Module):
         if t % conv.tgroup:
             raise AvtError("stem: %d frames do not split into groups of %d" % (t, conv.tgroup))
         x = Act(clip.view(b * t * h * (w // 2), 8), (b, t, h, w // 2))
-        if _STEM_LDS and ops.stem_conv_supported(h, w // 2, conv.cout):
-            # production shape: the patch-resident stem kernel (5-8x fewer bytes gathered than the implicit GEMM)
-            od = conv.out_dims(x.dims)
-            y = Act(torch.empty((od[0] * od[1] * od[2] * od[3], conv.cout), dtype=torch.bfloat16, device=self.dev), od)
-            kt, st, pt = conv.kernel[0], conv.stride[0], conv.pad[0]
+        lds_path = _STEM_LDS and conv.wt_lds is not None and ops.stem_conv_supported(h, w // 2, conv.cout)
+        kt, st, pt = conv.kernel[0], conv.stride[0], conv.pad[0]
+        od = conv.out_dims(x.dims)
+        m_out = od[0] * od[1] * od[2] * od[3]
+        if lds_path and _STEM_POOL:
+            # production shape: patch-resident stem kernel with the max-pool fused (the conv output stays on chip)
+            pd = (b, t, od[2] // 2, od[3] // 2)
+            cf = conv.frame_channels
+            if out is None:
+                out = Act(torch.empty((pd[0] * pd[1] * pd[2] * pd[3], cf), dtype=torch.bfloat16, device=self.dev), pd)
 
             def launch():
-                ops.stem_conv(x.ptr, conv.wt, conv.bias, y.ptr, b, t, h, w // 2, conv.cout, kt, st, pt, relu=True)
+                ops.stem_conv_pool(x.ptr, conv.wt_lds, conv.bias, out.ptr, b, t, h, w // 2, conv.cout, kt, st, pt,
+                                   conv.tgroup, out.ld)
 
             if PROFILER is None:
                 launch()
             else:
-                m_out = od[0] * od[1] * od[2] * od[3]
+                PROFILER("conv3d_igemm_bf16", launch, m_out * conv.alg_flops_per_row,
+                         2.0 * (x.buf.numel() + pd[0] * pd[1] * pd[2] * pd[3] * cf) + conv.wt.numel() * 2)
+            return out, pd
+        if lds_path:
+            y = Act(torch.empty((m_out, conv.cout), dtype=torch.bfloat16, device=self.dev), od)
+
+            def launch():
+                ops.stem_conv(x.ptr, conv.wt_lds, conv.bias, y.ptr, b, t, h, w // 2, conv.cout, kt, st, pt, relu=True)
+
+            if PROFILER is None:
+                launch()
+            else:
                 PROFILER("conv3d_igemm_bf16", launch, m_out * conv.alg_flops_per_row,
                          2.0 * (x.buf.numel() + m_out * conv.cout) + conv.wt.numel() * 2)
         else:

@@ -228,12 +228,21 @@ def stem_conv_supported(h, pw, cout):
 
 def stem_conv(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu=True):
     """SlowFast stem in pixel-pair form, input patch resident in LDS (csrc/stem_conv.hip); raw device addresses for the
-    activations, wt [cout, kt*224] bf16, bias [cout] fp32."""
+    activations, wt = fused_slowfast.stem_lds_image(packed weights) bf16, bias [cout] fp32."""
     _dev(wt, "wt", torch.bfloat16)
     _dev(bias, "bias", torch.float32)
     _lib.check(_lib.lib().avt_stem_conv_bf16(C.c_void_p(x_ptr), _p(wt), _p(bias), C.c_void_p(out_ptr), int(batch), int(t),
                                              int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(bool(relu)),
                                              _stream()), "avt_stem_conv_bf16")
+
+
+def stem_conv_pool(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, tgroup, ldo):
+    """stem_conv + ReLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) in one kernel; out = pooled rows (stride ldo elements)."""
+    _dev(wt, "wt", torch.bfloat16)
+    _dev(bias, "bias", torch.float32)
+    _lib.check(_lib.lib().avt_stem_conv_pool_bf16(C.c_void_p(x_ptr), _p(wt), _p(bias), C.c_void_p(out_ptr), int(batch),
+                                                  int(t), int(h), int(pw), int(cout), int(kt), int(st), int(pt),
+                                                  int(tgroup), int(ldo), _stream()), "avt_stem_conv_pool_bf16")
 
 
 def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):

@@ -230,14 +230,24 @@ int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w
  * the Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU at the head of both pathways of
  * the third-party SlowFast model the reference runs per clip window (models/models.py:335, 399).
  * in  [batch, t, h, pw, 8] bf16 = the channels-last clip [.., w, 4] read as pixel pairs (pw = w/2),
- * wt  [cout, kt, 7, 4, 8] bf16 (BN folded; kt frame taps, temporal stride st, temporal pad pt),
+ * wt  [cout/32, kt, 7, 2, 4, 16, 8] bf16: the packed stem weights W[n][dt][dh][dp][8] (BN folded; kt frame
+ *     taps, temporal stride st, temporal pad pt) re-ordered per 32-channel group into the kernel's LDS
+ *     image [dt][dh][tile][dp][row][8] with channel n = 32*group + 8*(row/4) + 4*tile + row%4, so that
+ *     staging is a linear copy (cout % 32 == 0),
  * out [batch, (t+2pt-kt)/st+1, h/2, pw, cout] bf16.  Same results as avt_conv3d_igemm_bf16 on the same
- * packed weights up to fp32 summation order.  avt_stem_conv_supported() tells whether the shape is
+ * weights up to fp32 summation order.  avt_stem_conv_supported() tells whether the shape is
  * covered (production 224^2 clips: pw = 112, (h/2) % 4 == 0); other shapes go to the generic entry. */
 int avt_stem_conv_supported(int h, int pw, int cout);
 int avt_stem_conv_bf16(const void* in, const void* wt, const float* bias, void* out,
                        int batch, int t, int h, int pw, int cout, int kt, int st, int pt,
                        int relu, void* stream);
+/* The same convolution + ReLU with the stem's MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused: the convolution
+ * output never reaches HBM.  out = pooled [batch, To*tgroup, h/4, pw/2, cout/tgroup] bf16 with row stride
+ * ldo elements (a channel slice of a wider buffer is allowed); tgroup > 1 un-groups the time-grouped
+ * fast stem exactly as avt_maxpool_hw3s2_ndhwc_bf16 does.  Results equal conv -> bf16 -> max-pool. */
+int avt_stem_conv_pool_bf16(const void* in, const void* wt, const float* bias, void* out,
+                            int batch, int t, int h, int pw, int cout, int kt, int st, int pt,
+                            int tgroup, int ldo, void* stream);
 
 /* VGGish audio front-end (utils/mel_features.py:21-92, 176-205 log_mel_spectrogram; called once per
  * video from utils/vggish_utils.py:27-69), float64 like the reference's NumPy code:

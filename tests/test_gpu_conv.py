@@ -233,13 +233,24 @@ def test_stem_lds_kernel_matches_generic_and_torch(avt, dev, hw):
         gen = conv(xa)  # implicit GEMM
         od = gen.dims
         y = torch.full((od[0] * od[1] * od[2] * od[3], conv.cout), 7.0, dtype=torch.bfloat16, device=dev)
-        avt.ops.stem_conv(xa.ptr, conv.wt, conv.bias, y.data_ptr(), 2, t, hw, hw // 2, conv.cout, conv.kernel[0],
+        avt.ops.stem_conv(xa.ptr, conv.wt_lds, conv.bias, y.data_ptr(), 2, t, hw, hw // 2, conv.cout, conv.kernel[0],
                           conv.stride[0], conv.pad[0])
         torch.cuda.synchronize()
         a, g = y.float(), gen.buf.float()
         scale = max(g.abs().max().item(), 1.0)
         assert (a - g).abs().max().item() <= 0.01 * scale
         assert (a != g).float().mean().item() < 0.05  # a few last-bit differences only
+        # fused max-pool variant == the unfused kernel followed by the pool kernel, bit for bit (into a channel slice)
+        tg, cf = conv.tgroup, conv.frame_channels
+        hp, wp = od[2] // 2, od[3] // 2
+        ref_pool = torch.empty((2 * t * hp * wp, cf), dtype=torch.bfloat16, device=dev)
+        avt.ops.maxpool_hw3s2(y.data_ptr(), ref_pool.data_ptr(), 2 * od[1], od[2], od[3], conv.cout, conv.cout, cf, tgroup=tg)
+        wide = torch.full((2 * t * hp * wp, cf + 16), 3.0, dtype=torch.bfloat16, device=dev)
+        avt.ops.stem_conv_pool(xa.ptr, conv.wt_lds, conv.bias, wide.data_ptr() + 2 * 8, 2, t, hw, hw // 2, conv.cout,
+                               conv.kernel[0], conv.stride[0], conv.pad[0], tg, cf + 16)
+        torch.cuda.synchronize()
+        assert torch.equal(wide[:, 8 : 8 + cf], ref_pool)
+        assert (wide[:, :8] == 3).all() and (wide[:, 8 + cf :] == 3).all()
         # through the pool, against torch (as test_stem_on_mfma_matches_torch does for the generic path)
         act, pd = fused._stem(conv, clip)
         with torch.no_grad():
