@@ -35,6 +35,7 @@ class KernelTimer:
     def __init__(self):
         self.ev = {}
         self.work = {}
+        self.per = {}
         self.on = False
         self.sample_conv = False  # conv launches are sampled (every 8th encoder batch) to keep the overhead < 1 %
 
@@ -46,6 +47,7 @@ class KernelTimer:
         out = fn()
         b.record()
         self.ev.setdefault(name, []).append((a, b))
+        self.per.setdefault(name, []).append((a, b, flops, nbytes))
         w = self.work.setdefault(name, [0.0, 0.0])
         w[0] += flops
         w[1] += nbytes
@@ -56,6 +58,14 @@ class KernelTimer:
             self.run(name, launch, flops, nbytes)
         else:
             launch()
+
+    def mixed_roof_frac(self, name, peak_tflops, peak_gbs):
+        """sum over launches of the time the BINDING roof of that launch allows (max of flops/peak, bytes/peak)
+        divided by the measured time: what fraction of its own per-layer roofline a many-shape kernel reaches."""
+        torch.cuda.synchronize()
+        ideal = sum(max(f / (peak_tflops * 1e12), b / (peak_gbs * 1e9)) for _, _, f, b in self.per.get(name, []))
+        real = sum(a.elapsed_time(b) for a, b, _, _ in self.per.get(name, [])) * 1e-3
+        return ideal / real if real > 0 else None
 
     def summary(self):
         torch.cuda.synchronize()
@@ -206,6 +216,10 @@ def main():
                      "avg_ms": avg_ms, "achieved": fl / (sampled_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS["bf16"],
                      "unit": "TFLOP/s", "frac": fl / (sampled_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16"], "traffic": None,
                      "algorithmic_per_launch": fl / n, "algorithmic_GBps": by / (sampled_ms * 1e-3) / 1e9,
+                     # SlowFast mixes MFMA-bound and HBM-bound layers in ONE kernel: per launch, the time its binding
+                     # roof allows (max of flops / 2.5 PF and bytes / 8 TB/s), summed, over the measured time
+                     "per_launch_roofline_frac": timer.mixed_roof_frac("conv3d_igemm_bf16", MFMA_PEAK_TFLOPS["bf16"],
+                                                                       HBM_PEAK_GBS),
                      "note": "sampled every 8th encoder batch; bytes = activations in+out(+residual)+weights"})
     add("clip_pack", "hbm", float(np.mean(pack_bytes)) if pack_bytes else 0.0, "GB/s", HBM_PEAK_GBS)
     add("l2norm_rows", "hbm", N * D * 4 + N * D * (4 + (4 if split else 0)), "GB/s", HBM_PEAK_GBS)
