@@ -67,6 +67,21 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
   return (t + ((n - t) >> 1)) >> f.shift;
 }
 
+#ifdef AVT_CONV_STAMP
+// diagnostic build only (tools/probe_stamps.sh): cycles per K-loop segment, summed over workgroups (wave 0, lane 0)
+__device__ unsigned long long g_stamp[8];
+#define STAMP(i)                                                          \
+  do {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    seg_[i] += now_ - last_;                                              \
+    last_ = now_;                                                         \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 struct ConvArgs {
   const uint16_t* in;
   const uint16_t* wt;
@@ -220,16 +235,26 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN, WTM)) void conv_ige
     for (int u = 0; u < BU; ++u) *reinterpret_cast<i32x4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
   };
   if constexpr (TABLDS) __syncthreads();
+#ifdef AVT_CONV_STAMP
+  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
   gload(0);
   lstore();
   __syncthreads();
+  STAMP(0);  // prologue: first slab
   for (int kt = 0; kt < a.nk; ++kt) {
     if (kt + 1 < a.nk) gload(kt + 1);  // next slab's latency hides under this slab's MFMAs
+    STAMP(1);  // issue of the next slab's loads
     compute();
+    STAMP(2);  // fragment reads + MFMAs
     __syncthreads();
+    STAMP(3);  // barrier after compute (includes the vmcnt(0) the compiler puts in front of it)
     if (kt + 1 < a.nk) {
       lstore();
+      STAMP(4);  // wait for the loads + ds_write
       __syncthreads();
+      STAMP(5);  // barrier after the stores
     }
   }
 
@@ -305,6 +330,13 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN, WTM)) void conv_ige
     }
     if (p + 1 < EPASS) __syncthreads();  // the staging tile is reused by the next wave-row
   }
+#ifdef AVT_CONV_STAMP
+  STAMP(6);  // epilogue
+  if (tid == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[i], seg_[i]);
+    atomicAdd(&g_stamp[7], 1ull);
+  }
+#endif
 }
 
 template <int BM, int BN, int WTM, bool TABLDS = true>
@@ -330,6 +362,17 @@ int launch(ConvArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef AVT_CONV_STAMP
+extern "C" int avt_debug_stamps(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, int ldi, int32_t* ktab, int n_entries) {
   AVT_REQUIRE(ktab && cin > 0 && cin % 8 == 0, "avt_conv3d_ktab: Cin must be a positive multiple of 8");
