@@ -99,6 +99,7 @@ struct ConvArgs {
   int nk;
   int tiles_n, nblk;
   FastDiv dWo, dHo, dTo;
+  FastDiv dCpt, dKHW, dKW;  // tap decode without the table (XL kernel): chunks per tap, KH*KW, KW
   unsigned in_bytes, wt_bytes;  // extents for the buffer descriptors (hardware range check = free zero fill)
   int pointwise;                // 1x1x1 / stride 1 / pad 0: rows need no decode
 };
@@ -361,6 +362,257 @@ int launch(ConvArgs& a, hipStream_t st) {
   return avt::check_launch("avt_conv3d_igemm_bf16");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// XL tile: 256(m) x 256(n), 512 threads = 8 waves as 2(m) x 4(n), wave tile 128 x 64 — for the GEMM-like layers
+// (Cout >= 256, long K).  Half the operand bytes per MFMA of the 128x128 tile (the vector-L1 / LDS-write path is
+// what bounds those layers), and no VGPR staging or ds_write at all: both operand slabs go
+// global -> LDS by LDS-DMA (global_load_lds, 16 B per lane) into a two-stage ring; a stage's loads stay in flight
+// across the barriers and under the previous stage's MFMAs, retired by a counted s_waitcnt vmcnt(8) (never 0 inside
+// the loop) followed by a raw s_barrier.  A DMA wave-instruction fills 1 KB of LDS lane-linearly = 8 rows x 128 B;
+// rows are unpadded, so the 16-byte slot of logical chunk c of row r is c ^ ((r >> 1) & 7): conflict-free for the
+// ds_read_b128 lane groups of a 32-row fragment, applied on the SOURCE side of the DMA (each lane picks the chunk
+// that belongs in its fixed destination slot).  Padding taps / tails read a 16-byte zero chunk (end of the table).
+constexpr int XBM = 256, XBN = 256, XT = 512;
+constexpr int XSTAGE = (XBM + XBN) * 128;  // 64 KB
+#ifndef XL_PRIO
+#define XL_PRIO 0
+#endif
+
+__global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
+  constexpr int ESTR = XBN * 2 + 16;
+  constexpr int EROWS = 128;  // epilogue pass = one wave-row
+  constexpr int CPR = XBN / 8;
+  constexpr int EU = (EROWS * CPR) / XT;  // 8
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int bid = blockIdx.x;
+  const int qd = a.nblk / 8, rm = a.nblk % 8, xc = bid % 8;
+  const int swz = (xc < rm ? xc * (qd + 1) : rm * (qd + 1) + (xc - rm) * qd) + bid / 8;
+  const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
+  const int m0 = tm * XBM, n0 = tn * XBN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  // staging role: DMA instruction u of wave wid fills rows u*64 + wid*8 + (lane >> 3), slot lane & 7
+  const int srow = wid * 8 + (lane >> 3);
+  const int c16 = (lane & 7) ^ ((srow >> 1) & 7);  // logical K-chunk that belongs in this lane's slot (same for all u)
+
+  int rowoff[4];
+  unsigned rowmask[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int m = m0 + u * 64 + srow;
+    rowoff[u] = 0;
+    rowmask[u] = 0u;
+    if (m < a.M && a.pointwise) {
+      rowoff[u] = m * a.ldi;
+      rowmask[u] = 0x010101u;
+    } else if (m < a.M) {
+      const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
+      const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
+      const int b = (int)fastdiv((uint32_t)t2, a.dTo), to = t2 - b * a.To;
+      const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+      rowoff[u] = (((b * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.ldi;
+      unsigned mask = 0u;
+      for (int dt = 0; dt < a.KT; ++dt) mask |= ((unsigned)(ti0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
+      for (int dh = 0; dh < a.KH; ++dh) mask |= ((unsigned)(hi0 + dh) < (unsigned)a.H ? 1u : 0u) << (8 + dh);
+      for (int dw = 0; dw < a.KW; ++dw) mask |= ((unsigned)(wi0 + dw) < (unsigned)a.W ? 1u : 0u) << (16 + dw);
+      rowmask[u] = mask;
+    }
+  }
+  int wrow[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int n = n0 + u * 64 + srow;
+    wrow[u] = n < a.Cout ? n * a.K : -1;
+  }
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // padding taps, rows past M / Cout and the K tail read the 16 zero bytes behind the tap table (avt_conv3d_ktab).  The
+  // choice is a 64-bit offset select on ONE vector address, not a branch between two load forms
+  const char* inb = reinterpret_cast<const char*>(a.in);
+  const char* wtb = reinterpret_cast<const char*>(a.wt);
+  const int64_t zin = reinterpret_cast<const char*>(a.ktab + a.nk * 8) - inb;
+  const int64_t zwt = reinterpret_cast<const char*>(a.ktab + a.nk * 8) - wtb;
+
+  auto stage = [&](int kt, char* st) {
+    // this lane's K-chunk -> (tap, channel chunk) -> element offset + tap bits, by constant division: a table read
+    // from LDS here would make the compiler drain vmcnt(0) (LDS-DMA in flight may alias it) and a global one would
+    // enter the vmcnt count
+    const int kci = kt * 8 + c16;
+    const int kc = kci * 8;
+    const bool kin = kc < a.K;
+    const int tap = (int)fastdiv((uint32_t)kci, a.dCpt), c8 = kci - tap * (int)a.dCpt.d;
+    const int dt = (int)fastdiv((uint32_t)tap, a.dKHW), r2 = tap - dt * (int)a.dKHW.d;
+    const int dh = (int)fastdiv((uint32_t)r2, a.dKW), dw = r2 - dh * (int)a.dKW.d;
+    int2 e;
+    e.x = ((dt * a.H + dh) * a.W + dw) * a.ldi + c8 * 8;
+    e.y = (1 << dt) | (1 << (8 + dh)) | (1 << (16 + dw));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = kin && ((rowmask[u] & (unsigned)e.y) == (unsigned)e.y);
+      const int64_t off = ok ? (int64_t)(rowoff[u] + e.x) * 2 : zin;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(inb + off),
+                                       (__attribute__((address_space(3))) void*)(st + (u * 64 + wid * 8) * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t off = (kin && wrow[u] >= 0) ? (int64_t)(wrow[u] + kc) * 2 : zwt;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wtb + off),
+                                       (__attribute__((address_space(3))) void*)(st + XBM * 128 + (u * 64 + wid * 8) * 128),
+                                       16, 0, 0);
+    }
+  };
+  const int xa = (lr >> 1) & 7;  // swizzle key of this lane's fragment rows (tile offsets are multiples of 16)
+  auto compute = [&](const char* st) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[4], wf[2];
+      const int koff = ((ks * 2 + lh) ^ xa) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + (wm * 128 + j * 32 + lr) * 128 + koff);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        wf[i] = *reinterpret_cast<const bf16x8*>(st + XBM * 128 + (wn * 64 + i * 32 + lr) * 128 + koff);
+      if (XL_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);  // D[n][m]
+      if (XL_PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+#ifdef AVT_CONV_STAMP
+  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+  stage(0, lds);
+  if (a.nk > 1) stage(1, lds + XSTAGE);
+  STAMP(0);  // prologue: issue of the first two stages
+  for (int kt = 0; kt < a.nk; ++kt) {
+    // this wave's DMA of stage kt has landed when at most the 8 loads of stage kt+1 are still outstanding
+    if (kt + 1 < a.nk)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(1);  // wait for this wave's DMA
+    __builtin_amdgcn_s_barrier();  // ... and so has everyone else's: the stage is complete
+    STAMP(3);  // barrier (stage complete)
+    compute(lds + (kt & 1) * XSTAGE);
+    STAMP(2);  // fragment reads + MFMAs
+    if (kt + 2 < a.nk) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done reading this slot: refill it (lands under the next MFMAs)
+      STAMP(5);  // barrier (slot free)
+      stage(kt + 2, lds + (kt & 1) * XSTAGE);
+      STAMP(4);  // DMA issue
+    }
+  }
+  __syncthreads();  // all MFMA operand reads done: the ring becomes the epilogue's staging tile
+
+  const bool has_res = a.res != nullptr;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    uint4 rres[EU];
+    if (has_res) {
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c = tid + XT * u;
+        const int m = m0 + p * EROWS + c / CPR, n = n0 + (c % CPR) * 8;
+        rres[u] = (m < a.M && n < a.Cout) ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n)
+                                          : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    if (wm == p) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn * 64 + i * 32 + 8 * g + 4 * lh;
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.bias && n0 + nl < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+            float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+            if (a.relu && !has_res) {
+              v0 = fmaxf(v0, 0.f);
+              v1 = fmaxf(v1, 0.f);
+              v2 = fmaxf(v2, 0.f);
+              v3 = fmaxf(v3, 0.f);
+            }
+            uint2 pk;
+            pk.x = avt::pack_bf16x2(v0, v1);
+            pk.y = avt::pack_bf16x2(v2, v3);
+            *reinterpret_cast<uint2*>(lds + (j * 32 + lr) * ESTR + nl * 2) = pk;
+          }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int c = tid + XT * u;
+      const int row = c / CPR, cc = c % CPR;
+      const int m = m0 + p * EROWS + row, n = n0 + cc * 8;
+      if (m < a.M && n < a.Cout) {
+        uint4 v = *reinterpret_cast<const uint4*>(lds + row * ESTR + cc * 16);
+        if (has_res) {
+          uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
+          const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rres[u]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x0 = avt::bf16x2_lo(pv[e]) + avt::bf16x2_lo(pr[e]);
+            float x1 = avt::bf16x2_hi(pv[e]) + avt::bf16x2_hi(pr[e]);
+            if (a.relu) {
+              x0 = fmaxf(x0, 0.f);
+              x1 = fmaxf(x1, 0.f);
+            }
+            pv[e] = avt::pack_bf16x2(x0, x1);
+          }
+        }
+        *reinterpret_cast<uint4*>(a.out + (int64_t)m * a.ldo + n) = v;
+      }
+    }
+    if (p == 0) __syncthreads();
+  }
+#ifdef AVT_CONV_STAMP
+  STAMP(6);  // epilogue
+  if (tid == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[i], seg_[i]);
+    atomicAdd(&g_stamp[7], 1ull);
+  }
+#endif
+}
+
+int launch_xl(ConvArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + XBM - 1) / XBM;
+  a.tiles_n = (a.Cout + XBN - 1) / XBN;
+  a.nblk = tiles_m * a.tiles_n;
+  a.dCpt = make_fastdiv((uint32_t)(a.K / (a.KT * a.KH * a.KW) / 8));
+  a.dKHW = make_fastdiv((uint32_t)(a.KH * a.KW));
+  a.dKW = make_fastdiv((uint32_t)a.KW);
+  constexpr int lds_bytes = 2 * XSTAGE;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(conv_xl_kernel, dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
+  return avt::check_launch("avt_conv3d_igemm_bf16");
+}
+
 }  // namespace
 
 #ifdef AVT_CONV_STAMP
@@ -455,6 +707,17 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   a.dHo = make_fastdiv((uint32_t)a.Ho);
   a.dTo = make_fastdiv((uint32_t)a.To);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // GEMM-like layers: the 256x256 LDS-DMA tile (AVT_CONV_XL = minimum number of its tiles, 0 = never)
+  static const int xl = []() {
+    const char* e = getenv("AVT_CONV_XL");
+    return e ? atoi(e) : 0;
+  }();
+  static const int xl_nk = []() {
+    const char* e = getenv("AVT_CONV_XL_NK");
+    return e ? atoi(e) : 4;
+  }();
+  if (xl > 0 && cout >= 256 && a.nk >= xl_nk && (int64_t)((a.M + 255) / 256) * ((cout + 255) / 256) >= xl)
+    return launch_xl(a, s);
   if (cout <= 32) return launch<256, 32, 64>(a, s);
   if (cout <= 64) return launch<256, 64, 64>(a, s);
   // wide layers: the 256x128 tile (128x64 per wave) when there are enough tiles of it to fill the chip

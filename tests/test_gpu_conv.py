@@ -55,6 +55,9 @@ def _run(avt, dev, cin, cout, k, s, p, dims, relu, with_res, ld_extra=0):
     (512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 7, 7)),
     (72, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 3, 9, 11)),      # wide tile (LDS-DMA path) with a K tail, ragged M
     (24, 136, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 5, 6, 7)),       # 27 taps, Cout not a tile multiple
+    (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 14, 14)),    # GEMM-like: 256x256 LDS-DMA tile when enabled
+    (128, 328, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 8, 9, 7)),      # ... with an N tail (328 = 256 + 72) and ragged M
+    (264, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 4, 10, 10)),    # ... K tail (264 = 4 K-steps + 8), strided
 ])
 @pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
 def test_conv_igemm_matches_torch(avt, dev, cin, cout, k, s, p, dims, relu, with_res):

@@ -2,7 +2,7 @@
 # diagnostic: rebuild libavt_hip.so with -DAVT_CONV_STAMP ON THE GPU BOX COPY and print where a K-step's cycles go
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 cd audio-video-textures_amd/csrc && touch conv_igemm.hip && make FLAGS="-O3 -ffp-contract=off -std=c++17 -fPIC --offload-arch=gfx950 -DAVT_CONV_STAMP" -j8 > /dev/null 2>&1; cd ../..
-for SHAPE in "256 256 1 3 3 64 8 14 14" "1024 256 3 1 1 64 8 14 14" "64 256 1 1 1 64 8 56 56 res" "64 64 1 3 3 64 8 56 56"; do
+IFS=";" read -ra ARR <<< "${SHAPES:-256 256 1 3 3 64 8 14 14;1024 256 3 1 1 64 8 14 14;64 256 1 1 1 64 8 56 56 res;64 64 1 3 3 64 8 56 56}"; for SHAPE in "${ARR[@]}"; do
 python - $SHAPE <<'PY'
 import sys, ctypes, subprocess
 sys.path.insert(0, ".")
@@ -17,10 +17,10 @@ runpy.run_path("tools/conv_layer_bench.py", run_name="__main__")
 torch.cuda.synchronize()
 lib.avt_debug_stamps(buf, 1)
 n = buf[7]
-names = ["prologue", "gload issue", "compute", "barrier1", "wait+ds_write", "barrier2", "epilogue"]
+names = ["prologue", "gload issue | XL: wait own DMA", "compute", "barrier1 | XL: barrier stage complete", "wait+ds_write | XL: DMA issue", "barrier2 | XL: barrier slot free", "epilogue"]
 tot = sum(buf[i] for i in range(7))
 print("  workgroups %d, cycles per workgroup %.0f" % (n, tot / max(n, 1)))
 for i, nm in enumerate(names):
-    print("    %-14s %6.1f %%  (%.0f cycles/workgroup)" % (nm, 100.0 * buf[i] / tot, buf[i] / max(n, 1)))
+    print("    %-40s %6.1f %%  (%.0f cycles/workgroup)" % (nm, 100.0 * buf[i] / tot, buf[i] / max(n, 1)))
 PY
 done
