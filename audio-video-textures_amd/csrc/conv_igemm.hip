@@ -366,17 +366,23 @@ int launch(ConvArgs& a, hipStream_t st) {
 // XL tile: 256(m) x 256(n), 512 threads = 8 waves as 2(m) x 4(n), wave tile 128 x 64 — for the GEMM-like layers
 // (Cout >= 256, long K).  Half the operand bytes per MFMA of the 128x128 tile (the vector-L1 / LDS-write path is
 // what bounds those layers), and no VGPR staging or ds_write at all: both operand slabs go
-// global -> LDS by LDS-DMA (global_load_lds, 16 B per lane) into a two-stage ring; a stage's loads stay in flight
-// across the barriers and under the previous stage's MFMAs, retired by a counted s_waitcnt vmcnt(8) (never 0 inside
-// the loop) followed by a raw s_barrier.  A DMA wave-instruction fills 1 KB of LDS lane-linearly = 8 rows x 128 B;
-// rows are unpadded, so the 16-byte slot of logical chunk c of row r is c ^ ((r >> 1) & 7): conflict-free for the
-// ds_read_b128 lane groups of a 32-row fragment, applied on the SOURCE side of the DMA (each lane picks the chunk
-// that belongs in its fixed destination slot).  Padding taps / tails read a 16-byte zero chunk (end of the table).
+// global -> LDS by LDS-DMA (global_load_lds, 16 B per lane).
+//
+// Pipeline unit = HALF a K-step (32 of K: A 256 rows x 64 B + B 256 rows x 64 B = 32 KB, 4 DMA instructions per
+// thread), ring of 4 units (128 KB), ONE raw s_barrier per unit.  While unit i is multiplied, units i+1 and i+2 are
+// landed or in flight and unit i+3 is being issued — two DMA instructions between the MFMA groups of each 16-wide
+// k-slice, so the vector-L1 address pipe (64 B/clk, what a DMA burst would otherwise serialise in front of the MFMAs:
+// measured 1,130 cycles per K-step, tools/probe_stamps.sh) works under the matrix pipe.  A unit is retired by a
+// counted s_waitcnt vmcnt(8) (its successors stay in flight; never 0 inside the loop) followed by the barrier, which
+// also proves every wave is done with unit i-1, whose slot unit i+3 then overwrites.
+// A DMA wave-instruction fills 1 KB of LDS lane-linearly = 16 rows x 64 B; rows are unpadded, so the 16-byte slot of
+// logical chunk c of row r is c ^ ((r >> 2) & 3): conflict-free for the ds_read_b128 lane groups of a 32-row fragment,
+// applied on the SOURCE side of the DMA (each lane fetches the chunk that belongs in its fixed destination slot).
+// Padding taps / tails read 16 zero bytes (behind the tap table); taps are decoded arithmetically (no table read in
+// the loop: an LDS read there makes the compiler drain vmcnt(0)).
 constexpr int XBM = 256, XBN = 256, XT = 512;
-constexpr int XSTAGE = (XBM + XBN) * 128;  // 64 KB
-#ifndef XL_PRIO
-#define XL_PRIO 0
-#endif
+constexpr int XUNIT = (XBM + XBN) * 64;  // 32 KB: one 32-wide K slice of both operands
+constexpr int XRING = 4;
 
 __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
   constexpr int ESTR = XBN * 2 + 16;
@@ -395,15 +401,15 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
   const int lr = lane & 31, lh = lane >> 5;
-  // staging role: DMA instruction u of wave wid fills rows u*64 + wid*8 + (lane >> 3), slot lane & 7
-  const int srow = wid * 8 + (lane >> 3);
-  const int c16 = (lane & 7) ^ ((srow >> 1) & 7);  // logical K-chunk that belongs in this lane's slot (same for all u)
+  // staging role: DMA instruction u (0/1) of wave wid fills rows u*128 + wid*16 + (lane >> 2), slot lane & 3
+  const int srow = wid * 16 + (lane >> 2);
+  const int c4 = (lane & 3) ^ ((lane >> 4) & 3);  // logical chunk (of the unit's 4) that belongs in this lane's slot
 
-  int rowoff[4];
-  unsigned rowmask[4];
+  int rowoff[2];
+  unsigned rowmask[2];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int m = m0 + u * 64 + srow;
+  for (int u = 0; u < 2; ++u) {
+    const int m = m0 + u * 128 + srow;
     rowoff[u] = 0;
     rowmask[u] = 0u;
     if (m < a.M && a.pointwise) {
@@ -422,10 +428,10 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
       rowmask[u] = mask;
     }
   }
-  int wrow[4];
+  int wrow[2];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int n = n0 + u * 64 + srow;
+  for (int u = 0; u < 2; ++u) {
+    const int n = n0 + u * 128 + srow;
     wrow[u] = n < a.Cout ? n * a.K : -1;
   }
 
@@ -437,88 +443,106 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // padding taps, rows past M / Cout and the K tail read the 16 zero bytes behind the tap table (avt_conv3d_ktab).  The
-  // choice is a 64-bit offset select on ONE vector address, not a branch between two load forms
-  const char* inb = reinterpret_cast<const char*>(a.in);
-  const char* wtb = reinterpret_cast<const char*>(a.wt);
-  const int64_t zin = reinterpret_cast<const char*>(a.ktab + a.nk * 8) - inb;
-  const int64_t zwt = reinterpret_cast<const char*>(a.ktab + a.nk * 8) - wtb;
+  // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): padding taps, rows past M / Cout and the K tail
+  // get an offset beyond the descriptor's extent and the hardware range check writes zeros — a 32-bit select per
+  // instruction, no 64-bit address arithmetic.  The tap decode of a unit is wave-uniform (Cin % 32 == 0: the unit's 4
+  // chunks share a tap), so it runs on the scalar unit; a lane adds its chunk.  Phase A is issue-bound (one wave,
+  // ~140 instructions against the other group's 16 MFMAs), so every VALU instruction here is on the critical path.
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const int nu = (a.K + 31) / 32;  // pipeline units
+  const int swid = __builtin_amdgcn_readfirstlane(wid);  // wave-uniform in an SGPR: LDS destinations stay scalar
+  unsigned rowb[2], wrowb[2];  // byte offsets of this lane's rows (+ its chunk within a unit), OOB when absent
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    rowb[u] = (unsigned)(rowoff[u] + c4 * 8) * 2u;
+    wrowb[u] = wrow[u] >= 0 ? (unsigned)(wrow[u] + c4 * 8) * 2u : kOob;
+  }
 
-  auto stage = [&](int kt, char* st) {
-    // this lane's K-chunk -> (tap, channel chunk) -> element offset + tap bits, by constant division: a table read
-    // from LDS here would make the compiler drain vmcnt(0) (LDS-DMA in flight may alias it) and a global one would
-    // enter the vmcnt count
-    const int kci = kt * 8 + c16;
-    const int kc = kci * 8;
-    const bool kin = kc < a.K;
-    const int tap = (int)fastdiv((uint32_t)kci, a.dCpt), c8 = kci - tap * (int)a.dCpt.d;
+  auto stage_a = [&](int i) {
+    char* st = lds + (i & (XRING - 1)) * XUNIT;
+    const int kcu = i * 4;  // first chunk of the unit: uniform
+    const int tap = (int)fastdiv((uint32_t)kcu, a.dCpt), c8 = kcu - tap * (int)a.dCpt.d;
     const int dt = (int)fastdiv((uint32_t)tap, a.dKHW), r2 = tap - dt * (int)a.dKHW.d;
     const int dh = (int)fastdiv((uint32_t)r2, a.dKW), dw = r2 - dh * (int)a.dKW.d;
-    int2 e;
-    e.x = ((dt * a.H + dh) * a.W + dw) * a.ldi + c8 * 8;
-    e.y = (1 << dt) | (1 << (8 + dh)) | (1 << (16 + dw));
+    const unsigned exb = (unsigned)(((dt * a.H + dh) * a.W + dw) * a.ldi + c8 * 8) * 2u;
+    const unsigned ey = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
+    const bool kin = (kcu + c4) * 8 < a.K;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool ok = kin && ((rowmask[u] & (unsigned)e.y) == (unsigned)e.y);
-      const int64_t off = ok ? (int64_t)(rowoff[u] + e.x) * 2 : zin;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(inb + off),
-                                       (__attribute__((address_space(3))) void*)(st + (u * 64 + wid * 8) * 128), 16, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t off = (kin && wrow[u] >= 0) ? (int64_t)(wrow[u] + kc) * 2 : zwt;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wtb + off),
-                                       (__attribute__((address_space(3))) void*)(st + XBM * 128 + (u * 64 + wid * 8) * 128),
-                                       16, 0, 0);
+    for (int u = 0; u < 2; ++u) {
+      const bool ok = kin && ((rowmask[u] & ey) == ey);
+      const unsigned off = ok ? rowb[u] + exb : kOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(st + (u * 128 + swid * 16) * 64),
+                                               16, (int)off, 0, 0, 0);
     }
   };
-  const int xa = (lr >> 1) & 7;  // swizzle key of this lane's fragment rows (tile offsets are multiples of 16)
-  auto compute = [&](const char* st) {
+  auto stage_b = [&](int i) {
+    char* st = lds + (i & (XRING - 1)) * XUNIT + XBM * 64;
+    const unsigned kb = (unsigned)(i * 64);  // byte offset of the unit inside a weight row
+    const bool kin = (i * 4 + c4) * 8 < a.K;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 af[4], wf[2];
-      const int koff = ((ks * 2 + lh) ^ xa) * 16;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + (wm * 128 + j * 32 + lr) * 128 + koff);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        wf[i] = *reinterpret_cast<const bf16x8*>(st + XBM * 128 + (wn * 64 + i * 32 + lr) * 128 + koff);
-      if (XL_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);  // D[n][m]
-      if (XL_PRIO) __builtin_amdgcn_s_setprio(0);
+    for (int u = 0; u < 2; ++u) {
+      const unsigned off = kin ? wrowb[u] + kb : kOob;  // kOob + kb stays beyond the extent (kb < 2^31)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (__attribute__((address_space(3))) void*)(st + (u * 128 + swid * 16) * 64),
+                                               16, (int)(wrowb[u] == kOob ? kOob : off), 0, 0, 0);
     }
   };
-
+  const int xa = (lr >> 2) & 3;  // swizzle key of this lane's fragment rows (tile offsets are multiples of 16)
 #ifdef AVT_CONV_STAMP
   unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
-  stage(0, lds);
-  if (a.nk > 1) stage(1, lds + XSTAGE);
-  STAMP(0);  // prologue: issue of the first two stages
-  for (int kt = 0; kt < a.nk; ++kt) {
-    // this wave's DMA of stage kt has landed when at most the 8 loads of stage kt+1 are still outstanding
-    if (kt + 1 < a.nk)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(1);  // wait for this wave's DMA
-    __builtin_amdgcn_s_barrier();  // ... and so has everyone else's: the stage is complete
-    STAMP(3);  // barrier (stage complete)
-    compute(lds + (kt & 1) * XSTAGE);
-    STAMP(2);  // fragment reads + MFMAs
-    if (kt + 2 < a.nk) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave is done reading this slot: refill it (lands under the next MFMAs)
-      STAMP(5);  // barrier (slot free)
-      stage(kt + 2, lds + (kt & 1) * XSTAGE);
-      STAMP(4);  // DMA issue
-    }
+  for (int i = 0; i < 3; ++i) {  // units past the end of K are all-zero fills (stage_*: kin false): uniform counting
+    stage_a(i);
+    stage_b(i);
   }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's part of unit 0
+  __builtin_amdgcn_s_barrier();
+  STAMP(0);  // prologue: first three units issued, unit 0 complete
+  // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE PHASE APART: a unit is phase A (12 fragment
+  // reads into registers, the 4 DMA instructions of unit i+3, address arithmetic) then phase B (16 MFMAs); while one
+  // group multiplies, the other reads, issues and computes addresses on the same SIMD.  Every phase ends in a barrier;
+  // the late group takes one extra barrier first, the early group one extra at the end.
+  // Hazards: a wave ends phase A(j) with vmcnt(8) — its part of unit j+1 has landed, one or two phases before anyone
+  // reads it — and lgkmcnt(0) — its reads of unit j are retired, so the DMA of unit j+4 (next phase A of either group
+  // at the earliest) may overwrite the slot.
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  for (int i = 0; i < nu; ++i) {
+    const char* st = lds + (i & (XRING - 1)) * XUNIT;
+    bf16x8 af[2][4], wf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int koff = ((ks * 2 + lh) ^ xa) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        af[ks][j] = *reinterpret_cast<const bf16x8*>(st + (wm * 128 + j * 32 + lr) * 64 + koff);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        wf[ks][n] = *reinterpret_cast<const bf16x8*>(st + XBM * 64 + (wn * 64 + n * 32 + lr) * 64 + koff);
+    }
+    stage_a(i + 3);
+    stage_b(i + 3);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(1);  // phase A: reads + DMA issue + waits
+    __builtin_amdgcn_sched_barrier(0);  // the phases are the schedule: nothing moves across their barriers
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(3);  // barrier after A
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
+    STAMP(2);  // phase B: MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(5);  // barrier after B
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-fill units
   __syncthreads();  // all MFMA operand reads done: the ring becomes the epilogue's staging tile
 
   const bool has_res = a.res != nullptr;
@@ -602,7 +626,7 @@ int launch_xl(ConvArgs& a, hipStream_t st) {
   a.dCpt = make_fastdiv((uint32_t)(a.K / (a.KT * a.KH * a.KW) / 8));
   a.dKHW = make_fastdiv((uint32_t)(a.KH * a.KW));
   a.dKW = make_fastdiv((uint32_t)a.KW);
-  constexpr int lds_bytes = 2 * XSTAGE;
+  constexpr int lds_bytes = XRING * XUNIT;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
@@ -707,16 +731,19 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   a.dHo = make_fastdiv((uint32_t)a.Ho);
   a.dTo = make_fastdiv((uint32_t)a.To);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // GEMM-like layers: the 256x256 LDS-DMA tile (AVT_CONV_XL = minimum number of its tiles, 0 = never)
+  // GEMM-like layers: the 256x256 LDS-DMA tile.  AVT_CONV_XL = minimum number of its tiles (0 = never),
+  // AVT_CONV_XL_NK = minimum number of 64-wide K-steps.  A unit of 32 K must not straddle two taps: one tap, or
+  // Cin % 32 == 0.
   static const int xl = []() {
     const char* e = getenv("AVT_CONV_XL");
     return e ? atoi(e) : 0;
   }();
   static const int xl_nk = []() {
     const char* e = getenv("AVT_CONV_XL_NK");
-    return e ? atoi(e) : 4;
+    return e ? atoi(e) : 8;
   }();
-  if (xl > 0 && cout >= 256 && a.nk >= xl_nk && (int64_t)((a.M + 255) / 256) * ((cout + 255) / 256) >= xl)
+  if (xl > 0 && cout >= 256 && a.nk >= xl_nk && (cin % 32 == 0 || kt * kh * kw == 1) &&
+      (int64_t)((a.M + 255) / 256) * ((cout + 255) / 256) >= xl)
     return launch_xl(a, s);
   if (cout <= 32) return launch<256, 32, 64>(a, s);
   if (cout <= 64) return launch<256, 64, 64>(a, s);
