@@ -459,15 +459,21 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
     wrowb[u] = wrow[u] >= 0 ? (unsigned)(wrow[u] + c4 * 8) * 2u : kOob;
   }
 
-  auto stage_a = [&](int i) {
-    char* st = lds + (i & (XRING - 1)) * XUNIT;
-    const int kcu = i * 4;  // first chunk of the unit: uniform
+  // tap decode of unit i: wave-uniform, all on the scalar unit (it is computed one unit ahead, inside the MFMA phase,
+  // where scalar issue slots are free; moving the per-lane offset selects there too measured slower: VALU work
+  // competes with the MFMA issue, profiles/r01/probe_xl_layers_v7.log)
+  unsigned exb_n = 0, ey_n = 0;
+  auto decode = [&](int i) {
+    const int kcu = i * 4;  // first chunk of the unit
     const int tap = (int)fastdiv((uint32_t)kcu, a.dCpt), c8 = kcu - tap * (int)a.dCpt.d;
     const int dt = (int)fastdiv((uint32_t)tap, a.dKHW), r2 = tap - dt * (int)a.dKHW.d;
     const int dh = (int)fastdiv((uint32_t)r2, a.dKW), dw = r2 - dh * (int)a.dKW.d;
-    const unsigned exb = (unsigned)(((dt * a.H + dh) * a.W + dw) * a.ldi + c8 * 8) * 2u;
-    const unsigned ey = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
-    const bool kin = (kcu + c4) * 8 < a.K;
+    exb_n = (unsigned)(((dt * a.H + dh) * a.W + dw) * a.ldi + c8 * 8) * 2u;
+    ey_n = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
+  };
+  auto stage_a = [&](int i, unsigned exb, unsigned ey) {
+    char* st = lds + (i & (XRING - 1)) * XUNIT;
+    const bool kin = (i * 4 + c4) * 8 < a.K;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const bool ok = kin && ((rowmask[u] & ey) == ey);
@@ -493,9 +499,11 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
   for (int i = 0; i < 3; ++i) {  // units past the end of K are all-zero fills (stage_*: kin false): uniform counting
-    stage_a(i);
+    decode(i);
+    stage_a(i, exb_n, ey_n);
     stage_b(i);
   }
+  decode(3);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's part of unit 0
   __builtin_amdgcn_s_barrier();
   STAMP(0);  // prologue: first three units issued, unit 0 complete
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
       for (int n = 0; n < 2; ++n)
         wf[ks][n] = *reinterpret_cast<const bf16x8*>(st + XBM * 64 + (wn * 64 + n * 32 + lr) * 64 + koff);
     }
-    stage_a(i + 3);
+    stage_a(i + 3, exb_n, ey_n);
     stage_b(i + 3);
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     STAMP(1);  // phase A: reads + DMA issue + waits
@@ -535,6 +543,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
+    decode(i + 4);  // scalar work for the next phase A, under this phase's MFMAs
     STAMP(2);  // phase B: MFMAs
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
