@@ -745,11 +745,11 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   // Cin % 32 == 0.
   static const int xl = []() {
     const char* e = getenv("AVT_CONV_XL");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 1;
   }();
   static const int xl_nk = []() {
     const char* e = getenv("AVT_CONV_XL_NK");
-    return e ? atoi(e) : 8;
+    return e ? atoi(e) : 16;  // shorter K loops (the 1x1x1 + residual layers) are faster on the 128x128 tile
   }();
   if (xl > 0 && cout >= 256 && a.nk >= xl_nk && (cin % 32 == 0 || kt * kh * kw == 1) &&
       (int64_t)((a.M + 255) / 256) * ((cout + 255) / 256) >= xl)
