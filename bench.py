@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 4],
                     help="HIP streams for the q / t encoders (4 also splits each clip batch in halves)")
-    ap.add_argument("--cpu-clips", type=int, default=1)
+    ap.add_argument("--cpu-clips", type=int, default=8, help="windows in the timed CPU-baseline sample")
     args = ap.parse_args()
 
     import avtex
@@ -303,8 +303,12 @@ def cpu_baseline(video, W, S, N, D, temp, args):
     from avtex.slowfast import SlowFast
     from oracle import cref, ref_py
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # threads: os.cpu_count() can exceed what the container may use (256 reported, far fewer schedulable: a 256-thread
+    # run measured 79 s per clip against 0.3 s with 32 threads), so the thread count is CHOSEN by a short probe
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     nclip = args.cpu_clips
     t0 = time.perf_counter()
     packs = [ref_py.pack_clip(video, i * S, W, out_hw=224) for i in range(nclip)]
@@ -313,18 +317,27 @@ def cpu_baseline(video, W, S, N, D, temp, args):
     t_pack = time.perf_counter() - t0
     torch.manual_seed(0)
     enc = SlowFast().eval()
+    cores, best = 1, None
     with torch.no_grad():
-        # one fp32 encoder forward is ~20 s of CPU work per clip once warm (the first call is ~4x slower: oneDNN
-        # primitive creation), so: one untimed warm-up, one timed forward, counted twice (q and t encoders are the
-        # same architecture)
-        enc([slow, fast])
+        for n in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+            torch.set_num_threads(n)
+            enc([slow[:1], fast[:1]])  # warm-up at this thread count (oneDNN primitive creation)
+            t0 = time.perf_counter()
+            enc([slow[:1], fast[:1]])
+            dt_ = time.perf_counter() - t0
+            if best is None or dt_ < best:
+                cores, best = n, dt_
+            if dt_ > 20.0:  # oversubscribed: larger counts only get worse
+                break
+        torch.set_num_threads(cores)
         t0 = time.perf_counter()
-        enc([slow, fast])
+        enc([slow, fast])  # the timed sample: nclip windows through one encoder, counted twice (q and t encoders)
         t_enc = time.perf_counter() - t0
     per_clip = t_pack / nclip + 2 * t_enc / nclip  # both encoders
     g = torch.Generator().manual_seed(0)
     q = torch.randn((N, D), generator=g).numpy()
     t = torch.randn((N, D), generator=torch.Generator().manual_seed(1)).numpy()
+    cref.set_threads(cores)
     t0 = time.perf_counter()
     qn, _, _ = cref.l2norm_rows(q, want_split=False)
     tn, _, _ = cref.l2norm_rows(t, want_split=False)
@@ -334,9 +347,9 @@ def cpu_baseline(video, W, S, N, D, temp, args):
     value = 1.0 / (per_clip + t_nxn / N)
     return {"value": value, "unit": "clip-windows/s", "cores": cores, "kind": "port",
             "sample": "%d window(s) packed (oracle/ref_py.pack_clip) and pushed through one fp32 SlowFast-8x8-R50 on CPU torch "
-                      "(%.2f s/clip/encoder, counted twice for the q and t encoders) + the full N=%d, D=%d NxN build with "
-                      "oracle/avt_oracle.c (%d OpenMP threads, %.2f s); extrapolated to windows/s"
-                      % (nclip, t_enc / nclip, N, D, cref.threads(), t_nxn),
+                      "(%d threads, the fastest of a short probe: %.2f s/clip/encoder, counted twice for the q and t encoders) + "
+                      "the full N=%d, D=%d NxN build with oracle/avt_oracle.c (%d OpenMP threads, %.2f s); extrapolated to "
+                      "windows/s" % (nclip, cores, t_enc / nclip, N, D, cref.threads(), t_nxn),
             "cpu_encode_s_per_clip": per_clip, "cpu_nxn_build_s": t_nxn}
 
 

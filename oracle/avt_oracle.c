@@ -38,6 +38,12 @@
 #include <omp.h>
 #endif
 
+void avt_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
 int avt_oracle_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -43,6 +43,11 @@ def threads():
     return int(_lib.avt_oracle_threads())
 
 
+def set_threads(n):
+    """OpenMP threads of the C oracle (bench.py's cpu_baseline picks the fastest count for the host)."""
+    _lib.avt_oracle_set_threads(int(n))
+
+
 def l2norm_rows(x0, x1=None, eps=1e-12, want_split=True):
     """-> (y_f32, y_hi(uint16 bf16 bits), y_lo)"""
     x0 = np.ascontiguousarray(x0, np.float32)
