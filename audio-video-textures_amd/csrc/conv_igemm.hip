@@ -62,9 +62,9 @@ inline FastDiv make_fastdiv(uint32_t d) {
   return f;
 }
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
-  if (f.d == 1) return n;
   const uint32_t t = __umulhi(n, f.magic);
-  return (t + ((n - t) >> 1)) >> f.shift;
+  const uint32_t q = (t + ((n - t) >> 1)) >> f.shift;
+  return f.d == 1 ? n : q;  // a select, not a branch: keeps the caller's loop body one scheduling region
 }
 
 #ifdef AVT_CONV_STAMP
@@ -528,9 +528,19 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
       for (int n = 0; n < 2; ++n)
         wf[ks][n] = *reinterpret_cast<const bf16x8*>(st + XBM * 64 + (wn * 64 + n * 32 + lr) * 64 + koff);
     }
+#ifdef AVT_CONV_STAMP_FINE
+    STAMP(4);  // fragment-read issue
+#endif
     stage_a(i + 3, exb_n, ey_n);
     stage_b(i + 3);
+#ifdef AVT_CONV_STAMP_FINE
+    STAMP(6);  // DMA issue (slot 6 is re-used: the epilogue share is lost in this mode)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    STAMP(0);  // vmcnt(8) wait (slot 0 re-used)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     STAMP(1);  // phase A: reads + DMA issue + waits
     __builtin_amdgcn_sched_barrier(0);  // the phases are the schedule: nothing moves across their barriers
     __builtin_amdgcn_s_barrier();
@@ -543,7 +553,12 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
-    decode(i + 4);  // scalar work for the next phase A, under this phase's MFMAs
+    decode(i + 4);  // scalar work for the next phase A, under this phase's MFMAs:
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // ... one MFMA, then a few of the decode's scalar instructions, 16 times
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+    }
     STAMP(2);  // phase B: MFMAs
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
