@@ -1,0 +1,262 @@
+// bottleneck_fused — one whole residual bottleneck of the SlowFast FAST pathway in a single kernel:
+//     out = relu( c( relu( b( relu( a(x) ) ) ) ) + x )
+//     a: Conv3d [3,1,1] C -> Cm  (temporal),  b: Conv3d [1,3,3] Cm -> Cm  (spatial),  c: Conv3d [1,1,1] Cm -> C
+// with the BatchNorms folded (the blocks of the third-party SlowFast model the reference runs per clip window,
+// contrastive_video_textures/models/models.py:335, 399; identity-shortcut, stride-1 blocks of the beta = 1/8 pathway:
+// C = 32 / 64, Cm = 8 / 16, 32 frames).
+//
+// Why: as three launches these layers are 12 % of the encoder's FLOPs but 26 % of its time — a and b run at 2-3 TB/s
+// on few-channel tensors, and every intermediate crosses HBM.  Fused, the block's HBM traffic is x once (+ a 2-row
+// halo per strip) and out once; the 8/16-channel intermediates never leave LDS and the residual is read from the
+// staged x.  The kernel is HBM-bound by construction (MFMA work: ~1,500 of ~6,800 cycles per step).
+//
+// Work decomposition: a workgroup (4 waves) owns one (clip, strip of HT rows, chunk of TC frames) and walks the
+// frames in order.  LDS holds a ring of 3 frames of the x strip (HT+2 rows, LDS-DMA with hardware zero fill for rows /
+// frames outside the tensor = the convolutions' zero padding), the a-output strip with a zero border column on each
+// side, and the b-output strip.  Per frame: [a] 16x16x32 MFMAs over the 3 ring frames -> relu -> bf16 -> LDS (rows
+// outside the image forced to zero: b pads with zeros, not with a(0)); barrier; DMA of frame t+2 into the slot of
+// t-1; [b] 9 taps as 5 tap-pair MFMAs read straight from the a strip at shifted addresses; barrier; [c] + bias +
+// residual (from the ring) -> relu -> 16-byte stores.  Weights arrive pre-packed in MFMA fragment order (1 KB per
+// fragment, lane-linear) and live in registers; the weights are the first MFMA operand, so a lane ends with 4
+// consecutive channels of one position, and c's channel order is permuted in the packing so two tiles give 8
+// consecutive channels (one 16-byte store), as in stem_conv.hip.
+// Cm is padded to 16 on the host (zero filters / zero taps): the structured zeros cost MFMA issue only.
+#include "avt_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFFFF0u;
+
+struct BArgs {
+  const uint16_t* x;
+  uint16_t* out;
+  const i32x4* wa;  // [3][C/32][64 lanes]
+  const i32x4* wb;  // [5][64]
+  const i32x4* wc;  // [C/16][64]
+  const float* ba;  // [16]
+  const float* bb;  // [16]
+  const float* bc;  // [C]
+  int T, H;
+  int strips, tchunks, TC;
+  unsigned x_bytes;
+};
+
+template <int C, int W, int HT>
+__global__ __launch_bounds__(256, 1) void bottleneck_kernel(BArgs a) {
+  constexpr int RX = HT + 2;            // x / a-output rows of a strip
+  constexpr int PX = RX * W;            // positions of the x strip
+  constexpr int REC = C * 2;            // bytes per x position
+  constexpr int CH = C / 8;             // 16-byte chunks per x position
+  constexpr int PPI = 1024 / REC;       // positions per DMA wave-instruction
+  constexpr int NDMA = (PX + PPI - 1) / PPI;  // DMA wave-instructions per frame
+  constexpr int XFRAME = NDMA * 1024;   // LDS bytes per ring frame (whole instructions)
+  constexpr int AW = W + 2;             // a-output row length (zero border columns)
+  constexpr int APOS = RX * AW;
+  constexpr int MTA = (PX + 15) / 16;   // a-stage M-tiles
+  constexpr int PB = HT * W;            // b / c positions
+  constexpr int MTB = (PB + 15) / 16;
+  constexpr int ABYTES = (APOS + 32) * 32;  // a strip + room for the last partial tile's stores
+  constexpr int KA = C / 32;            // k-steps per frame tap of a
+  constexpr int NTC = C / 16;           // N-tiles of c
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* xr = lds;                       // [3][XFRAME]
+  char* ao = lds + 3 * XFRAME;          // [APOS (+pad)][16 ch]
+  char* bo = ao + ABYTES;               // [MTB*16][16 ch] (bottleneck width padded to 16 on the host)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  int bid = blockIdx.x;
+  const int tch = bid % a.tchunks;
+  bid /= a.tchunks;
+  const int strip = bid % a.strips, b = bid / a.strips;
+  const int h0 = strip * HT, t0 = tch * a.TC;
+  const int t1 = (t0 + a.TC < a.T) ? t0 + a.TC : a.T;
+
+  // ---- weights: MFMA fragments in registers
+  bf16x8 wa[3][KA], wb[5], wc[NTC];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+    for (int k = 0; k < KA; ++k) wa[dt][k] = __builtin_bit_cast(bf16x8, a.wa[(dt * KA + k) * 64 + lane]);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) wb[j] = __builtin_bit_cast(bf16x8, a.wb[j * 64 + lane]);
+#pragma unroll
+  for (int n = 0; n < NTC; ++n) wc[n] = __builtin_bit_cast(bf16x8, a.wc[n * 64 + lane]);
+  const float4 bav = *reinterpret_cast<const float4*>(a.ba + 4 * q);
+  const float4 bbv = *reinterpret_cast<const float4*>(a.bb + 4 * q);
+
+  // ---- zero the a strip once: its border columns (and tile padding) stay zero for the whole walk
+  for (int i = tid * 16; i < ABYTES; i += 256 * 16) *reinterpret_cast<i32x4*>(ao + i) = i32x4{0, 0, 0, 0};
+
+  // ---- x ring DMA: instruction d of a frame fills positions d*PPI + lane/CH, slot lane%CH (chunk = slot ^ swizzle)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  constexpr int NDW = (NDMA + 3) / 4;  // DMA instructions per wave per frame
+  unsigned poff[NDW];                  // byte offset of this lane's chunk inside a frame, or OOB
+#pragma unroll
+  for (int u = 0; u < NDW; ++u) {
+    const int d = wid + 4 * u;
+    const int p = d * PPI + lane / CH, slot = lane % CH;
+    const int r = p / W, w = p - r * W;
+    const int chunk = slot ^ ((CH == 4 ? (p >> 2) : (p >> 1)) & (CH - 1));
+    const int h = h0 - 1 + r;
+    const bool ok = d < NDMA && p < PX && (unsigned)h < (unsigned)a.H;
+    poff[u] = ok ? (unsigned)(((h * W + w) * C + chunk * 8) * 2) : kOob;
+  }
+  auto dma_frame = [&](int tt) {  // frame tt of the clip -> ring slot tt mod 3 (zeros when tt is outside the clip)
+    const int slot = ((tt % 3) + 3) % 3;
+    const bool tin = (unsigned)tt < (unsigned)a.T;
+    const unsigned fbase = (unsigned)((b * a.T + tt) * a.H) * (unsigned)(W * REC);
+#pragma unroll
+    for (int u = 0; u < NDW; ++u) {
+      const int d = wid + 4 * u;
+      if (d < NDMA) {
+        const unsigned off = (tin && poff[u] != kOob) ? fbase + poff[u] : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xr + slot * XFRAME + d * 1024),
+                                                 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+  auto xaddr = [&](int slot, int p, int chunk) {  // LDS address of a 16-byte chunk of x position p in a ring slot
+    return xr + slot * XFRAME + p * REC + ((chunk ^ ((CH == 4 ? (p >> 2) : (p >> 1)) & (CH - 1))) * 16);
+  };
+
+  dma_frame(t0 - 1);
+  dma_frame(t0);
+  dma_frame(t0 + 1);
+  for (int t = t0; t < t1; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // frames t-1, t, t+1 are in the ring; every wave is done with the previous frame's c stage
+    const int sm = (((t - 1) % 3) + 3) % 3, s0 = t % 3, sp = (t + 1) % 3;
+    // ---- [a] temporal conv over the ring -> relu -> a strip
+    for (int mt = wid; mt < MTA; mt += 4) {
+      const int p = mt * 16 + l15;
+      const int pc = p < PX ? p : PX - 1;  // partial last tile: read a valid position, store to the padding
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KA; ++k) {
+        const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xaddr(sm, pc, k * 4 + q));
+        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xaddr(s0, pc, k * 4 + q));
+        const bf16x8 xp = *reinterpret_cast<const bf16x8*>(xaddr(sp, pc, k * 4 + q));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][k], xm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][k], x0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2][k], xp, acc, 0, 0, 0);
+      }
+      const int r = p / W, w = p - r * W;
+      const bool rowin = (unsigned)(h0 - 1 + r) < (unsigned)a.H;  // rows outside the image are b's ZERO padding
+      uint2 pk;
+      pk.x = rowin ? avt::pack_bf16x2(fmaxf(acc[0] + bav.x, 0.f), fmaxf(acc[1] + bav.y, 0.f)) : 0u;
+      pk.y = rowin ? avt::pack_bf16x2(fmaxf(acc[2] + bav.z, 0.f), fmaxf(acc[3] + bav.w, 0.f)) : 0u;
+      // position p -> a-strip index (r, w+1); tile padding (p >= PX) lands behind the strip
+      const int ai = p < PX ? r * AW + w + 1 : APOS + (p - PX);
+      *reinterpret_cast<uint2*>(ao + ai * 32 + q * 8) = pk;
+    }
+    __syncthreads();  // a strip complete; ring slot of frame t-1 is free
+    if (t + 2 <= t1) dma_frame(t + 2);  // lands under the b and c stages (frame t1 itself is the last halo needed)
+    // ---- [b] 3x3 spatial conv: 9 taps as 5 tap pairs, operands straight from the a strip
+    for (int mt = wid; mt < MTB; mt += 4) {
+      const int p = mt * 16 + l15;
+      const int pc = p < PB ? p : PB - 1;
+      const int r = pc / W, w = pc - r * W;
+      const char* base = ao + (r * AW + w) * 32 + (q & 1) * 16;  // tap (0,0) of this position, this lane's channel half
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int tap_lo = 2 * j, tap_hi = 2 * j + 1 < 9 ? 2 * j + 1 : 8;  // tap 9 has zero weights: any finite data
+        const int off_lo = ((tap_lo / 3) * AW + tap_lo % 3) * 32, off_hi = ((tap_hi / 3) * AW + tap_hi % 3) * 32;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + ((q >> 1) ? off_hi : off_lo));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], af, acc, 0, 0, 0);
+      }
+      uint2 pk;
+      pk.x = avt::pack_bf16x2(fmaxf(acc[0] + bbv.x, 0.f), fmaxf(acc[1] + bbv.y, 0.f));
+      pk.y = avt::pack_bf16x2(fmaxf(acc[2] + bbv.z, 0.f), fmaxf(acc[3] + bbv.w, 0.f));
+      *reinterpret_cast<uint2*>(bo + p * 32 + q * 8) = pk;
+    }
+    __syncthreads();  // b strip complete
+    // ---- [c] pointwise conv + bias + residual (x of frame t, from the ring) -> relu -> global
+    for (int mt = wid; mt < MTB; mt += 4) {
+      const int p = mt * 16 + l15;
+      const int pc = p < PB ? p : PB - 1;
+      const int r = pc / W, w = pc - r * W;
+      const int h = h0 + r;
+      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bo + pc * 32 + (q & 1) * 16);  // k >= 16: zero weights
+      const int px = (r + 1) * W + w;  // the same position in the x strip (one halo row above)
+      uint16_t* orow = a.out + ((int64_t)((b * a.T + t) * a.H + h) * W + w) * C;
+#pragma unroll
+      for (int np = 0; np < NTC / 2; ++np) {
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2 * np], bf, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2 * np + 1], bf, c1, 0, 0, 0);
+        const int ch = 32 * np + 8 * q;  // this lane's 8 consecutive channels
+        const float4 b0 = *reinterpret_cast<const float4*>(a.bc + ch), b1 = *reinterpret_cast<const float4*>(a.bc + ch + 4);
+        const uint4 rs = *reinterpret_cast<const uint4*>(xaddr(s0, px, ch / 8));
+        uint4 o;
+        o.x = avt::pack_bf16x2(fmaxf(c0[0] + b0.x + avt::bf16x2_lo(rs.x), 0.f), fmaxf(c0[1] + b0.y + avt::bf16x2_hi(rs.x), 0.f));
+        o.y = avt::pack_bf16x2(fmaxf(c0[2] + b0.z + avt::bf16x2_lo(rs.y), 0.f), fmaxf(c0[3] + b0.w + avt::bf16x2_hi(rs.y), 0.f));
+        o.z = avt::pack_bf16x2(fmaxf(c1[0] + b1.x + avt::bf16x2_lo(rs.z), 0.f), fmaxf(c1[1] + b1.y + avt::bf16x2_hi(rs.z), 0.f));
+        o.w = avt::pack_bf16x2(fmaxf(c1[2] + b1.z + avt::bf16x2_lo(rs.w), 0.f), fmaxf(c1[3] + b1.w + avt::bf16x2_hi(rs.w), 0.f));
+        if (p < PB && h < a.H) *reinterpret_cast<uint4*>(orow + ch) = o;
+      }
+    }
+  }
+}
+
+template <int C, int W, int HT>
+int launch(BArgs& a, int batch, int h, hipStream_t st) {
+  constexpr int RX = HT + 2, PX = RX * W, PPI = 1024 / (C * 2), NDMA = (PX + PPI - 1) / PPI;
+  constexpr int MTB = (HT * W + 15) / 16, AW = W + 2;
+  constexpr int lds_bytes = 3 * NDMA * 1024 + (RX * AW + 32) * 32 + MTB * 16 * 32;
+  static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
+  a.strips = (h + HT - 1) / HT;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_bottleneck_fused_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(256), lds_bytes, st, a);
+  return avt::check_launch("avt_bottleneck_fused_bf16");
+}
+
+}  // namespace
+
+extern "C" int avt_bottleneck_fused_supported(int c, int w) {
+  return ((c == 32 && w == 56) || (c == 64 && w == 28) || (c == 32 && w == 12) || (c == 64 && w == 10)) ? 1 : 0;
+}
+
+extern "C" int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const float* ba, const void* wb,
+                                         const float* bb, const void* wc, const float* bc, int batch, int t, int h, int w,
+                                         int c, int tchunk, void* stream) {
+  AVT_REQUIRE(x && out && wa && ba && wb && bb && wc && bc, "avt_bottleneck_fused_bf16: NULL pointer");
+  AVT_REQUIRE(batch > 0 && t > 0 && h > 0 && tchunk > 0, "avt_bottleneck_fused_bf16: bad sizes");
+  AVT_REQUIRE(avt_bottleneck_fused_supported(c, w),
+              "avt_bottleneck_fused_bf16: unsupported shape C=%d W=%d (fast-pathway identity blocks: 32x56, 64x28)", c, w);
+  AVT_REQUIRE(x != out, "avt_bottleneck_fused_bf16: in-place is not supported (neighbouring strips read x)");
+  AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(out) && avt::aligned16(wa) && avt::aligned16(wb) && avt::aligned16(wc) &&
+                  avt::aligned16(ba) && avt::aligned16(bb) && avt::aligned16(bc),
+              "avt_bottleneck_fused_bf16: pointers must be 16-byte aligned");
+  const int64_t xb = (int64_t)batch * t * h * w * c * 2;
+  AVT_REQUIRE(xb < (1ll << 32) - 64, "avt_bottleneck_fused_bf16: tensor too large for 32-bit offsets");
+  BArgs a;
+  a.x = static_cast<const uint16_t*>(x);
+  a.out = static_cast<uint16_t*>(out);
+  a.wa = static_cast<const i32x4*>(wa);
+  a.wb = static_cast<const i32x4*>(wb);
+  a.wc = static_cast<const i32x4*>(wc);
+  a.ba = ba;
+  a.bb = bb;
+  a.bc = bc;
+  a.T = t;
+  a.H = h;
+  a.TC = tchunk < t ? tchunk : t;
+  a.tchunks = (t + a.TC - 1) / a.TC;
+  a.x_bytes = (unsigned)xb;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c == 32 && w == 56) return launch<32, 56, 8>(a, batch, h, s);
+  if (c == 64 && w == 28) return launch<64, 28, 7>(a, batch, h, s);
+  if (c == 32 && w == 12) return launch<32, 12, 5>(a, batch, h, s);  // small shapes for the tests: ragged strips,
+  return launch<64, 10, 4>(a, batch, h, s);                          // partial tiles, partial DMA instructions
+}

@@ -23,6 +23,8 @@ from ._lib import AvtError
 
 import os
 
+_FUSE_BLOCK = int(os.environ.get("AVT_FUSE_BLOCK", "1"))    # fast-pathway identity bottlenecks as one kernel
+_FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "8"))  # frames walked per workgroup
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 _STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "0"))  # fused pool: bit-identical but slower (probe_stem_pool_ab.log)
 _KW1_CAP = int(os.environ.get("AVT_GROUP_KW1_CAP", "32"))  # measured: profiles/r01/probe_layers.log
@@ -228,6 +230,34 @@ def stem_conv(stem, device, tgroup=1):
     return conv
 
 
+def pack_bottleneck(wa, ba, wb, bb, wc, bc, device):
+    """BN-folded weights of a [3,1,1] -> [1,3,3] -> [1,1,1] bottleneck (wa [Cm,C,3,1,1], wb [Cm,Cm,1,3,3], wc [C,Cm,1,1,1])
+    -> the MFMA-fragment order of csrc/bottleneck_fused.hip (include/avt.h), bottleneck width zero-padded to 16."""
+    cm, c = wa.shape[0], wa.shape[1]
+    lane = torch.arange(64)
+    n, q = lane & 15, lane >> 4
+    e = torch.arange(8)
+    wa_p = torch.zeros((16, c, 3))
+    wa_p[:cm] = wa[:, :, :, 0, 0]
+    k_idx = (torch.arange(c // 32).view(-1, 1, 1) * 32 + q.view(1, -1, 1) * 8 + e.view(1, 1, -1))  # [K, 64, 8]
+    wa_f = torch.stack([wa_p[n.view(1, -1, 1).expand_as(k_idx), k_idx, dt] for dt in range(3)])  # [3, K, 64, 8]
+    wb_p = torch.zeros((16, 16, 10))  # [n, ch, tap]; tap 9 = zeros
+    wb_p[:cm, :cm, :9] = wb[:, :, 0].reshape(cm, cm, 9)
+    tap = (2 * torch.arange(5).view(-1, 1, 1) + (q >> 1).view(1, -1, 1)).expand(5, 64, 8)
+    ch = (8 * (q & 1).view(1, -1, 1) + e.view(1, 1, -1)).expand(5, 64, 8)
+    wb_f = wb_p[n.view(1, -1, 1).expand(5, 64, 8), ch, tap]
+    wc_p = torch.zeros((c, 32))
+    wc_p[:, :cm] = wc[:, :, 0, 0, 0]
+    nt = torch.arange(c // 16).view(-1, 1, 1)
+    chan = (32 * (nt // 2) + 8 * (n >> 2).view(1, -1, 1) + 4 * (nt % 2) + (n & 3).view(1, -1, 1)).expand(c // 16, 64, 8)
+    kk = (q.view(1, -1, 1) * 8 + e.view(1, 1, -1)).expand(c // 16, 64, 8)
+    wc_f = wc_p[chan, kk]
+    pad16 = lambda v: torch.cat([v.float(), torch.zeros(16 - v.numel())])
+    dev = lambda v, dt: v.to(dt).contiguous().to(device)
+    return (dev(wa_f, torch.bfloat16), dev(pad16(ba), torch.float32), dev(wb_f, torch.bfloat16), dev(pad16(bb), torch.float32),
+            dev(wc_f, torch.bfloat16), dev(bc.float(), torch.float32))
+
+
 class _Block:
     def __init__(self, blk, device):
         self.b1 = FusedConv(blk.branch1, blk.branch1_bn, False, device) if hasattr(blk, "branch1") else None
@@ -235,8 +265,31 @@ class _Block:
         self.a = FusedConv(t.a, t.a_bn, True, device)
         self.b = FusedConv(t.b, t.b_bn, True, device)
         self.c = FusedConv(t.c, t.c_bn, True, device)  # ReLU applied after the residual add (fused)
+        self.dev = device
+        # identity-shortcut fast-pathway blocks ([3,1,1] -> [1,3,3] -> [1,1,1], stride 1, width <= 16): one kernel
+        self.fused = None
+        if (_FUSE_BLOCK and self.b1 is None and self.a.kernel == (3, 1, 1) and self.b.kernel == (1, 3, 3) and
+                self.c.kernel == (1, 1, 1) and self.a.stride == (1, 1, 1) and self.b.stride == (1, 1, 1) and
+                self.a.cout <= 16 and self.c.cout == self.a.cin and self.c.cout in (32, 64)):
+            (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
+            self.fused = pack_bottleneck(wa, ba, wb, bb, wc, bc, device)
 
     def __call__(self, x, out=None):
+        if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
+                ops.bottleneck_fused_supported(x.C, x.dims[3])):
+            b, t, h, w = x.dims
+            y = Act(torch.empty((b * t * h * w, x.C), dtype=torch.bfloat16, device=self.dev), x.dims)
+
+            def launch():
+                ops.bottleneck_fused(x.ptr, y.ptr, self.fused, b, t, h, w, x.C, tchunk=_FUSE_TCHUNK)
+
+            if PROFILER is None:
+                launch()
+            else:
+                m = b * t * h * w
+                fl = m * (self.a.alg_flops_per_row + self.b.alg_flops_per_row + self.c.alg_flops_per_row)
+                PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * (2 * m * x.C))
+            return y
         sc = self.b1(x) if self.b1 is not None else x
         return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)
 

@@ -245,6 +245,19 @@ def stem_conv_pool(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, 
                                                   int(tgroup), int(ldo), _stream()), "avt_stem_conv_pool_bf16")
 
 
+def bottleneck_fused_supported(c, w):
+    return bool(_lib.lib().avt_bottleneck_fused_supported(int(c), int(w)))
+
+
+def bottleneck_fused(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk=8):
+    """One fast-pathway identity bottleneck (a [3,1,1] -> b [1,3,3] -> c [1,1,1] + x, ReLUs, BN folded) in one kernel;
+    packed = fused_slowfast.pack_bottleneck(...) = (wa, ba, wb, bb, wc, bc) device tensors; raw activation addresses."""
+    wa, ba, wb, bb, wc, bc = packed
+    _lib.check(_lib.lib().avt_bottleneck_fused_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), _p(wa), _p(ba), _p(wb), _p(bb),
+                                                    _p(wc), _p(bc), int(batch), int(t), int(h), int(w), int(c),
+                                                    int(tchunk), _stream()), "avt_bottleneck_fused_bf16")
+
+
 def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
     """MaxPool2d(2, 2), floor mode, on NHWC bf16 rows (raw device addresses) — VGGish (audio_models/vggish.py:15-33)."""
     _lib.check(_lib.lib().avt_maxpool_hw2s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),

@@ -249,6 +249,22 @@ int avt_stem_conv_pool_bf16(const void* in, const void* wt, const float* bias, v
                             int batch, int t, int h, int pw, int cout, int kt, int st, int pt,
                             int tgroup, int ldo, void* stream);
 
+/* One identity-shortcut bottleneck of the SlowFast FAST pathway in a single kernel (csrc/bottleneck_fused.hip):
+ *   out = relu(c(relu(b(relu(a(x))))) + x),  a: Conv3d[3,1,1] C->Cm, b: Conv3d[1,3,3] Cm->Cm, c: Conv3d[1,1,1] Cm->C,
+ * BatchNorms folded, stride 1 (blocks of the third-party SlowFast model the reference runs per clip window,
+ * models/models.py:335, 399).  x, out [batch, t, h, w, c] bf16 (NDHWC, distinct buffers); the intermediates
+ * stay in LDS.  Weights in MFMA fragment order, bf16, 1 KB per fragment (lane l: n = l & 15, k-group q = l >> 4,
+ * 8 values each), the bottleneck width Cm (8 or 16) zero-padded to 16:
+ *   wa [3 dt][c/32][64][8]: Wa[n][dt][32*k + 8*q + e];   ba [16] fp32
+ *   wb [5][64][8]: tap = 2*j + (q >> 1) (dh = tap/3, dw = tap%3; tap 9 = zeros), channel 8*(q & 1) + e;  bb [16]
+ *   wc [c/16][64][8]: tile nt, row r = l & 15 -> output channel 32*(nt/2) + 8*(r/4) + 4*(nt%2) + r%4, k = 8*q + e;  bc [c]
+ * tchunk = frames walked per workgroup (each re-reads one halo frame on either side).
+ * avt_bottleneck_fused_supported(c, w): (32, 56) and (64, 28) = the res2 / res3 blocks at 224^2 clips. */
+int avt_bottleneck_fused_supported(int c, int w);
+int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const float* ba,
+                              const void* wb, const float* bb, const void* wc, const float* bc,
+                              int batch, int t, int h, int w, int c, int tchunk, void* stream);
+
 /* VGGish audio front-end (utils/mel_features.py:21-92, 176-205 log_mel_spectrogram; called once per
  * video from utils/vggish_utils.py:27-69), float64 like the reference's NumPy code:
  * frame f = wave[f*hop, f*hop+win) * window -> |DFT_fft_len| -> spec[fft_len/2+1] . melmat -> log(. + log_offset).

@@ -261,3 +261,50 @@ def test_stem_lds_kernel_matches_generic_and_torch(avt, dev, hw):
         got = act.buf.float().cpu().view(*pd, conv.frame_channels).permute(0, 4, 1, 2, 3)
         assert got.shape == ref.shape
         assert (got - ref).abs().max() < 0.03 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("c,cm,dims,tchunk", [
+    (32, 8, (2, 7, 11, 12), 3),    # ragged strips (5+5+1 rows), frame chunks 3+3+1, partial tiles / DMA instructions
+    (64, 16, (1, 5, 9, 10), 8),    # 128-byte records, one chunk of frames
+    (32, 8, (1, 4, 56, 56), 2),    # the res2 fast-pathway shape
+    (64, 16, (1, 3, 28, 28), 8),   # the res3 fast-pathway shape
+])
+def test_bottleneck_fused_matches_module_and_unfused(avt, dev, c, cm, dims, tchunk):
+    """csrc/bottleneck_fused.hip: a whole identity bottleneck ([3,1,1] -> [1,3,3] -> [1,1,1] + x, BN folded, ReLUs) in one
+    kernel vs the PyTorch block in fp32 (bf16 intermediates: tolerance) and vs the three-launch MFMA path."""
+    import avtex.fused_slowfast as fsf
+    from avtex.slowfast import ResBlock
+
+    torch.manual_seed(c + dims[1])
+    blk = ResBlock(c, c, cm, 3, 1).eval()
+    with torch.no_grad():
+        for mod in blk.modules():
+            if isinstance(mod, nn.BatchNorm3d):
+                mod.weight.uniform_(0.6, 1.2); mod.bias.uniform_(-0.2, 0.2)
+                mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.8, 1.2)
+    assert not hasattr(blk, "branch1")
+    b, t, h, w = dims
+    x = torch.randn(b, c, t, h, w).to(torch.bfloat16)
+    with torch.no_grad():
+        ref = blk(x.float())
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous().to(dev)
+    fb = fsf._Block(blk, dev)
+    assert fb.fused is not None and avt.ops.bottleneck_fused_supported(c, w)
+    y = torch.full((rows.shape[0], c), 9.0, dtype=torch.bfloat16, device=dev)
+    avt.ops.bottleneck_fused(rows.data_ptr(), y.data_ptr(), fb.fused, b, t, h, w, c, tchunk=tchunk)
+    torch.cuda.synchronize()
+    got = y.float().cpu().view(b, t, h, w, c).permute(0, 4, 1, 2, 3)
+    scale = max(ref.abs().max().item(), 1.0)
+    assert (got - ref).abs().max().item() < 0.03 * scale
+    # the unfused path: same folded weights, intermediates rounded to bf16 in HBM instead of LDS -> near-identical
+    fused_flag, fb.fused = fb.fused, None
+    un = fb(fsf.Act(rows, dims)).buf.float().cpu().view(b, t, h, w, c).permute(0, 4, 1, 2, 3)
+    fb.fused = fused_flag
+    assert (got - un).abs().max().item() < 0.02 * scale
+    assert (got - un).abs().mean().item() < 1e-3 * scale
+    # through _Block.__call__ (dispatch) and independent of the frame chunking
+    y2 = fb(fsf.Act(rows, dims))
+    y3 = torch.empty_like(y)
+    avt.ops.bottleneck_fused(rows.data_ptr(), y3.data_ptr(), fb.fused, b, t, h, w, c, tchunk=t)
+    torch.cuda.synchronize()
+    assert torch.equal(y2.buf, y3) and torch.equal(y, y3)
