@@ -10,7 +10,7 @@
 // halo per strip) and out once; the 8/16-channel intermediates never leave LDS and the residual is read from the
 // staged x.  The kernel is HBM-bound by construction (MFMA work: ~1,500 of ~6,800 cycles per step).
 //
-// Work decomposition: a workgroup (4 waves) owns one (clip, strip of HT rows, chunk of TC frames) and walks the
+// Work decomposition: a workgroup (8 waves) owns one (clip, strip of HT rows, chunk of TC frames) and walks the
 // frames in order.  LDS holds a ring of 3 frames of the x strip (HT+2 rows, LDS-DMA with hardware zero fill for rows /
 // frames outside the tensor = the convolutions' zero padding), the a-output strip with a zero border column on each
 // side, and the b-output strip.  Per frame: [a] 16x16x32 MFMAs over the 3 ring frames -> relu -> bf16 -> LDS (rows
@@ -44,8 +44,10 @@ struct BArgs {
   unsigned x_bytes;
 };
 
+constexpr int NW = 8;  // waves per workgroup (2 per SIMD: the stages are latency-bound, not MFMA-bound)
+
 template <int C, int W, int HT>
-__global__ __launch_bounds__(256, 1) void bottleneck_kernel(BArgs a) {
+__global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   constexpr int RX = HT + 2;            // x / a-output rows of a strip
   constexpr int PX = RX * W;            // positions of the x strip
   constexpr int REC = C * 2;            // bytes per x position
@@ -61,6 +63,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BArgs a) {
   constexpr int ABYTES = (APOS + 32) * 32;  // a strip + room for the last partial tile's stores
   constexpr int KA = C / 32;            // k-steps per frame tap of a
   constexpr int NTC = C / 16;           // N-tiles of c
+  constexpr int CIT = (MTB + NW - 1) / NW;   // c-stage tiles per wave
+  constexpr int NST = CIT * (NTC / 2);       // ... = output store instructions per wave per frame
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* xr = lds;                       // [3][XFRAME]
   char* ao = lds + 3 * XFRAME;          // [APOS (+pad)][16 ch]
@@ -88,17 +92,23 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BArgs a) {
   for (int n = 0; n < NTC; ++n) wc[n] = __builtin_bit_cast(bf16x8, a.wc[n * 64 + lane]);
   const float4 bav = *reinterpret_cast<const float4*>(a.ba + 4 * q);
   const float4 bbv = *reinterpret_cast<const float4*>(a.bb + 4 * q);
+  float4 bcv[NTC / 2][2];
+#pragma unroll
+  for (int np = 0; np < NTC / 2; ++np) {
+    bcv[np][0] = *reinterpret_cast<const float4*>(a.bc + 32 * np + 8 * q);
+    bcv[np][1] = *reinterpret_cast<const float4*>(a.bc + 32 * np + 8 * q + 4);
+  }
 
   // ---- zero the a strip once: its border columns (and tile padding) stay zero for the whole walk
-  for (int i = tid * 16; i < ABYTES; i += 256 * 16) *reinterpret_cast<i32x4*>(ao + i) = i32x4{0, 0, 0, 0};
+  for (int i = tid * 16; i < ABYTES; i += NW * 64 * 16) *reinterpret_cast<i32x4*>(ao + i) = i32x4{0, 0, 0, 0};
 
   // ---- x ring DMA: instruction d of a frame fills positions d*PPI + lane/CH, slot lane%CH (chunk = slot ^ swizzle)
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  constexpr int NDW = (NDMA + 3) / 4;  // DMA instructions per wave per frame
+  constexpr int NDW = (NDMA + NW - 1) / NW;  // DMA instructions per wave per frame
   unsigned poff[NDW];                  // byte offset of this lane's chunk inside a frame, or OOB
 #pragma unroll
   for (int u = 0; u < NDW; ++u) {
-    const int d = wid + 4 * u;
+    const int d = wid + NW * u;
     const int p = d * PPI + lane / CH, slot = lane % CH;
     const int r = p / W, w = p - r * W;
     const int chunk = slot ^ ((CH == 4 ? (p >> 2) : (p >> 1)) & (CH - 1));
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BArgs a) {
     const unsigned fbase = (unsigned)((b * a.T + tt) * a.H) * (unsigned)(W * REC);
 #pragma unroll
     for (int u = 0; u < NDW; ++u) {
-      const int d = wid + 4 * u;
+      const int d = wid + NW * u;
       if (d < NDMA) {
         const unsigned off = (tin && poff[u] != kOob) ? fbase + poff[u] : kOob;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xr + slot * XFRAME + d * 1024),
@@ -120,85 +130,119 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BArgs a) {
       }
     }
   };
-  auto xaddr = [&](int slot, int p, int chunk) {  // LDS address of a 16-byte chunk of x position p in a ring slot
-    return xr + slot * XFRAME + p * REC + ((chunk ^ ((CH == 4 ? (p >> 2) : (p >> 1)) & (CH - 1))) * 16);
+  auto xoff = [&](int p, int chunk) {  // byte offset, inside a ring frame, of a 16-byte chunk of x position p
+    return p * REC + ((chunk ^ ((CH == 4 ? (p >> 2) : (p >> 1)) & (CH - 1))) * 16);
   };
+
+  // ---- per-lane addresses of every tile this wave owns, computed ONCE: the stages are instruction-issue bound
+  // (8 waves x ~900 instructions per frame before this table, ~350 after), not MFMA- or LDS-bound
+  constexpr int AIT = (MTA + NW - 1) / NW;  // a-stage tiles per wave
+  int a_rd[AIT][KA], a_st[AIT];
+  unsigned a_in = 0;  // bit it: the tile's row is inside the image (else b's zero padding)
+#pragma unroll
+  for (int it = 0; it < AIT; ++it) {
+    const int p = (wid + NW * it) * 16 + l15;
+    const int pc = p < PX ? p : PX - 1;  // partial last tile: read a valid position, store behind the strip
+#pragma unroll
+    for (int k = 0; k < KA; ++k) a_rd[it][k] = xoff(pc, k * 4 + q);
+    const int r = p / W, w = p - r * W;
+    a_st[it] = (p < PX ? r * AW + w + 1 : APOS + (p - PX)) * 32 + q * 8;
+    a_in |= ((unsigned)(h0 - 1 + r) < (unsigned)a.H ? 1u : 0u) << it;
+  }
+  int tapoff[5];  // b: byte offset of this lane's tap of pair j (k-groups 0,1 = tap 2j, 2,3 = tap 2j+1; tap 9 = zeros)
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int tap = (q >> 1) ? (2 * j + 1 < 9 ? 2 * j + 1 : 8) : 2 * j;
+    tapoff[j] = ((tap / 3) * AW + tap % 3) * 32 + (q & 1) * 16;
+  }
+  int b_rd[CIT], c_res[CIT][NTC / 2], c_out[CIT];
+  unsigned c_ok = 0;
+#pragma unroll
+  for (int it = 0; it < CIT; ++it) {
+    const int mt = wid + NW * it;
+    const int p = mt * 16 + l15;
+    const int pc = p < PB ? p : PB - 1;
+    const int r = pc / W, w = pc - r * W;
+    b_rd[it] = (r * AW + w) * 32;  // tap (0,0) of this position in the a strip
+#pragma unroll
+    for (int np = 0; np < NTC / 2; ++np) c_res[it][np] = xoff((r + 1) * W + w, (32 * np + 8 * q) / 8);
+    c_out[it] = ((h0 + r) * W + w) * C + 8 * q;
+    c_ok |= ((mt < MTB && p < PB && h0 + r < a.H) ? 1u : 0u) << it;
+  }
 
   dma_frame(t0 - 1);
   dma_frame(t0);
   dma_frame(t0 + 1);
   for (int t = t0; t < t1; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // frame t+1's DMA was issued BEFORE the previous frame's output stores: wait for it, not for the stores
+    if (t == t0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     __syncthreads();  // frames t-1, t, t+1 are in the ring; every wave is done with the previous frame's c stage
-    const int sm = (((t - 1) % 3) + 3) % 3, s0 = t % 3, sp = (t + 1) % 3;
+    const char* xm_ = xr + ((((t - 1) % 3) + 3) % 3) * XFRAME;
+    const char* x0_ = xr + (t % 3) * XFRAME;
+    const char* xp_ = xr + ((t + 1) % 3) * XFRAME;
     // ---- [a] temporal conv over the ring -> relu -> a strip
-    for (int mt = wid; mt < MTA; mt += 4) {
-      const int p = mt * 16 + l15;
-      const int pc = p < PX ? p : PX - 1;  // partial last tile: read a valid position, store to the padding
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < KA; ++k) {
-        const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xaddr(sm, pc, k * 4 + q));
-        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xaddr(s0, pc, k * 4 + q));
-        const bf16x8 xp = *reinterpret_cast<const bf16x8*>(xaddr(sp, pc, k * 4 + q));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][k], xm, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][k], x0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2][k], xp, acc, 0, 0, 0);
+    for (int it = 0; it < AIT; ++it) {
+      if (wid + NW * it < MTA) {  // wave-uniform
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+          const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xm_ + a_rd[it][k]);
+          const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(x0_ + a_rd[it][k]);
+          const bf16x8 xp = *reinterpret_cast<const bf16x8*>(xp_ + a_rd[it][k]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][k], xm, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][k], x0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2][k], xp, acc, 0, 0, 0);
+        }
+        const bool rowin = (a_in >> it) & 1u;  // rows outside the image are b's ZERO padding, not a(0)
+        uint2 pk;
+        pk.x = rowin ? avt::pack_bf16x2(fmaxf(acc[0] + bav.x, 0.f), fmaxf(acc[1] + bav.y, 0.f)) : 0u;
+        pk.y = rowin ? avt::pack_bf16x2(fmaxf(acc[2] + bav.z, 0.f), fmaxf(acc[3] + bav.w, 0.f)) : 0u;
+        *reinterpret_cast<uint2*>(ao + a_st[it]) = pk;
       }
-      const int r = p / W, w = p - r * W;
-      const bool rowin = (unsigned)(h0 - 1 + r) < (unsigned)a.H;  // rows outside the image are b's ZERO padding
-      uint2 pk;
-      pk.x = rowin ? avt::pack_bf16x2(fmaxf(acc[0] + bav.x, 0.f), fmaxf(acc[1] + bav.y, 0.f)) : 0u;
-      pk.y = rowin ? avt::pack_bf16x2(fmaxf(acc[2] + bav.z, 0.f), fmaxf(acc[3] + bav.w, 0.f)) : 0u;
-      // position p -> a-strip index (r, w+1); tile padding (p >= PX) lands behind the strip
-      const int ai = p < PX ? r * AW + w + 1 : APOS + (p - PX);
-      *reinterpret_cast<uint2*>(ao + ai * 32 + q * 8) = pk;
     }
     __syncthreads();  // a strip complete; ring slot of frame t-1 is free
     if (t + 2 <= t1) dma_frame(t + 2);  // lands under the b and c stages (frame t1 itself is the last halo needed)
     // ---- [b] 3x3 spatial conv: 9 taps as 5 tap pairs, operands straight from the a strip
-    for (int mt = wid; mt < MTB; mt += 4) {
-      const int p = mt * 16 + l15;
-      const int pc = p < PB ? p : PB - 1;
-      const int r = pc / W, w = pc - r * W;
-      const char* base = ao + (r * AW + w) * 32 + (q & 1) * 16;  // tap (0,0) of this position, this lane's channel half
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const int tap_lo = 2 * j, tap_hi = 2 * j + 1 < 9 ? 2 * j + 1 : 8;  // tap 9 has zero weights: any finite data
-        const int off_lo = ((tap_lo / 3) * AW + tap_lo % 3) * 32, off_hi = ((tap_hi / 3) * AW + tap_hi % 3) * 32;
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + ((q >> 1) ? off_hi : off_lo));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], af, acc, 0, 0, 0);
+    for (int it = 0; it < CIT; ++it) {
+      if (wid + NW * it < MTB) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(ao + b_rd[it] + tapoff[j]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], af, acc, 0, 0, 0);
+        }
+        uint2 pk;
+        pk.x = avt::pack_bf16x2(fmaxf(acc[0] + bbv.x, 0.f), fmaxf(acc[1] + bbv.y, 0.f));
+        pk.y = avt::pack_bf16x2(fmaxf(acc[2] + bbv.z, 0.f), fmaxf(acc[3] + bbv.w, 0.f));
+        *reinterpret_cast<uint2*>(bo + ((wid + NW * it) * 16 + l15) * 32 + q * 8) = pk;
       }
-      uint2 pk;
-      pk.x = avt::pack_bf16x2(fmaxf(acc[0] + bbv.x, 0.f), fmaxf(acc[1] + bbv.y, 0.f));
-      pk.y = avt::pack_bf16x2(fmaxf(acc[2] + bbv.z, 0.f), fmaxf(acc[3] + bbv.w, 0.f));
-      *reinterpret_cast<uint2*>(bo + p * 32 + q * 8) = pk;
     }
     __syncthreads();  // b strip complete
     // ---- [c] pointwise conv + bias + residual (x of frame t, from the ring) -> relu -> global
-    for (int mt = wid; mt < MTB; mt += 4) {
-      const int p = mt * 16 + l15;
-      const int pc = p < PB ? p : PB - 1;
-      const int r = pc / W, w = pc - r * W;
-      const int h = h0 + r;
-      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bo + pc * 32 + (q & 1) * 16);  // k >= 16: zero weights
-      const int px = (r + 1) * W + w;  // the same position in the x strip (one halo row above)
-      uint16_t* orow = a.out + ((int64_t)((b * a.T + t) * a.H + h) * W + w) * C;
+    uint16_t* oframe = a.out + (int64_t)((b * a.T + t) * a.H) * (W * C);
+#pragma unroll
+    for (int it = 0; it < CIT; ++it) {  // the same trip count in every wave: the stores are counted by s_waitcnt
+      const int mt = wid + NW * it;
+      const int pr = (mt < MTB ? mt : MTB - 1) * 16 + l15;
+      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bo + pr * 32 + (q & 1) * 16);  // k >= 16: zero weights
 #pragma unroll
       for (int np = 0; np < NTC / 2; ++np) {
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
         c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2 * np], bf, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2 * np + 1], bf, c1, 0, 0, 0);
-        const int ch = 32 * np + 8 * q;  // this lane's 8 consecutive channels
-        const float4 b0 = *reinterpret_cast<const float4*>(a.bc + ch), b1 = *reinterpret_cast<const float4*>(a.bc + ch + 4);
-        const uint4 rs = *reinterpret_cast<const uint4*>(xaddr(s0, px, ch / 8));
+        const float4 b0 = bcv[np][0], b1 = bcv[np][1];
+        const uint4 rs = *reinterpret_cast<const uint4*>(x0_ + c_res[it][np]);
         uint4 o;
         o.x = avt::pack_bf16x2(fmaxf(c0[0] + b0.x + avt::bf16x2_lo(rs.x), 0.f), fmaxf(c0[1] + b0.y + avt::bf16x2_hi(rs.x), 0.f));
         o.y = avt::pack_bf16x2(fmaxf(c0[2] + b0.z + avt::bf16x2_lo(rs.y), 0.f), fmaxf(c0[3] + b0.w + avt::bf16x2_hi(rs.y), 0.f));
         o.z = avt::pack_bf16x2(fmaxf(c1[0] + b1.x + avt::bf16x2_lo(rs.z), 0.f), fmaxf(c1[1] + b1.y + avt::bf16x2_hi(rs.z), 0.f));
         o.w = avt::pack_bf16x2(fmaxf(c1[2] + b1.z + avt::bf16x2_lo(rs.w), 0.f), fmaxf(c1[3] + b1.w + avt::bf16x2_hi(rs.w), 0.f));
-        if (p < PB && h < a.H) *reinterpret_cast<uint4*>(orow + ch) = o;
+        if ((c_ok >> it) & 1u) *reinterpret_cast<uint4*>(oframe + c_out[it] + 32 * np) = o;
       }
     }
   }
@@ -217,7 +261,7 @@ int launch(BArgs& a, int batch, int h, hipStream_t st) {
     avt::set_error("avt_bottleneck_fused_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64), lds_bytes, st, a);
   return avt::check_launch("avt_bottleneck_fused_bf16");
 }
 

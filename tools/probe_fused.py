@@ -40,6 +40,11 @@ def spy_stem(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu=T
     shapes.append("stem(LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)" % (cout, kt, st, batch, t, h, pw))
     return orig_stem(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu)
 avtex.ops.stem_conv = spy_stem
+orig_bn = avtex.ops.bottleneck_fused
+def spy_bn(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk=8):
+    shapes.append("fused bottleneck C%d in(%d, %d, %d, %d) tchunk %d" % (c, batch, t, h, w, tchunk))
+    return orig_bn(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk)
+avtex.ops.bottleneck_fused = spy_bn
 avtex.ops.conv3d_igemm = spy
 fsf.ops.conv3d_igemm = spy
 fsf.PROFILER = hook
