@@ -233,6 +233,7 @@ def stem_conv(stem, device, tgroup=1):
 def pack_bottleneck(wa, ba, wb, bb, wc, bc, device):
     """BN-folded weights of a [3,1,1] -> [1,3,3] -> [1,1,1] bottleneck (wa [Cm,C,3,1,1], wb [Cm,Cm,1,3,3], wc [C,Cm,1,1,1])
     -> the MFMA-fragment order of csrc/bottleneck_fused.hip (include/avt.h), bottleneck width zero-padded to 16."""
+    wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]  # packing is host work
     cm, c = wa.shape[0], wa.shape[1]
     lane = torch.arange(64)
     n, q = lane & 15, lane >> 4
