@@ -471,27 +471,26 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
     exb_n = (unsigned)(((dt * a.H + dh) * a.W + dw) * a.ldi + c8 * 8) * 2u;
     ey_n = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
   };
-  auto stage_a = [&](int i, unsigned exb, unsigned ey) {
-    char* st = lds + (i & (XRING - 1)) * XUNIT;
+  unsigned offa_c[2], offb_c[2];  // DMA offsets of the unit about to be issued (computed in phase A, issued in phase B)
+  auto offsets = [&](int i, unsigned exb, unsigned ey) {
     const bool kin = (i * 4 + c4) * 8 < a.K;
+    const unsigned kb = (unsigned)(i * 64);  // byte offset of the unit inside a weight row
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const bool ok = kin && ((rowmask[u] & ey) == ey);
-      const unsigned off = ok ? rowb[u] + exb : kOob;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(st + (u * 128 + swid * 16) * 64),
-                                               16, (int)off, 0, 0, 0);
+      offa_c[u] = (kin && ((rowmask[u] & ey) == ey)) ? rowb[u] + exb : kOob;
+      offb_c[u] = (kin && wrowb[u] != kOob) ? wrowb[u] + kb : kOob;
     }
   };
-  auto stage_b = [&](int i) {
-    char* st = lds + (i & (XRING - 1)) * XUNIT + XBM * 64;
-    const unsigned kb = (unsigned)(i * 64);  // byte offset of the unit inside a weight row
-    const bool kin = (i * 4 + c4) * 8 < a.K;
+  auto issue = [&](int i) {  // the four DMA instructions of unit i
+    char* st = lds + (i & (XRING - 1)) * XUNIT;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const unsigned off = kin ? wrowb[u] + kb : kOob;  // kOob + kb stays beyond the extent (kb < 2^31)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (__attribute__((address_space(3))) void*)(st + (u * 128 + swid * 16) * 64),
-                                               16, (int)(wrowb[u] == kOob ? kOob : off), 0, 0, 0);
-    }
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(st + (u * 128 + swid * 16) * 64),
+                                               16, (int)offa_c[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rwt, (__attribute__((address_space(3))) void*)(st + XBM * 64 + (u * 128 + swid * 16) * 64), 16, (int)offb_c[u], 0, 0, 0);
   };
   const int xa = (lr >> 2) & 3;  // swizzle key of this lane's fragment rows (tile offsets are multiples of 16)
 #ifdef AVT_CONV_STAMP
@@ -500,11 +499,11 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #endif
   for (int i = 0; i < 3; ++i) {  // units past the end of K are all-zero fills (stage_*: kin false): uniform counting
     decode(i);
-    stage_a(i, exb_n, ey_n);
-    stage_b(i);
+    offsets(i, exb_n, ey_n);
+    issue(i);
   }
   decode(3);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's part of unit 0
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's part of unit 0 (units 1, 2 stay in flight)
   __builtin_amdgcn_s_barrier();
   STAMP(0);  // prologue: first three units issued, unit 0 complete
   // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE PHASE APART: a unit is phase A (12 fragment
@@ -531,15 +530,15 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #ifdef AVT_CONV_STAMP_FINE
     STAMP(4);  // fragment-read issue
 #endif
-    stage_a(i + 3, exb_n, ey_n);
-    stage_b(i + 3);
+    offsets(i + 3, exb_n, ey_n);  // per-lane selects of the unit issued in the coming phase B
 #ifdef AVT_CONV_STAMP_FINE
-    STAMP(6);  // DMA issue (slot 6 is re-used: the epilogue share is lost in this mode)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    STAMP(0);  // vmcnt(8) wait (slot 0 re-used)
+    STAMP(6);  // offset selects (slot 6 is re-used: the epilogue share is lost in this mode)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    STAMP(0);  // vmcnt wait (slot 0 re-used)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    // this wave's part of unit i+1 has landed when only unit i+2's 4 DMAs are outstanding (unit i+3 is issued in B)
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     STAMP(1);  // phase A: reads + DMA issue + waits
     __builtin_amdgcn_sched_barrier(0);  // the phases are the schedule: nothing moves across their barriers
@@ -553,11 +552,13 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
-    decode(i + 4);  // scalar work for the next phase A, under this phase's MFMAs:
+    issue(i + 3);   // the DMA of unit i+3 and ...
+    decode(i + 4);  // ... the scalar tap decode for the next phase A ride under this phase's MFMAs:
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {  // ... one MFMA, then a few of the decode's scalar instructions, 16 times
+    for (int g = 0; g < 16; ++g) {  // one MFMA, a few scalar instructions, and every 4th time one DMA instruction
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x004, 5, 0);
+      if ((g & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     STAMP(2);  // phase B: MFMAs
     __builtin_amdgcn_sched_barrier(0);
