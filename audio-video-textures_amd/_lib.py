@@ -31,6 +31,7 @@ SIGNATURES = {
     "avt_clip_pack_u8_ndhwc4": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                 C.c_int, _vp, _vp, _vp],
     "avt_maxpool_hw3s2_ndhwc_bf16": [_vp, _vp] + [C.c_int] * 7 + [_vp],
+    "avt_mean_positions_bf16": [_vp] + [C.c_int] * 4 + [_vp, C.c_int, _vp],
     "avt_maxpool_hw2s2_ndhwc_bf16": [_vp, _vp] + [C.c_int] * 6 + [_vp],
     "avt_stem_conv_supported": [C.c_int] * 3,
     "avt_stem_conv_bf16": [_vp, _vp, _vp, _vp] + [C.c_int] * 9 + [_vp],

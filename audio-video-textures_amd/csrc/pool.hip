@@ -78,6 +78,51 @@ extern "C" int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, i
   return avt::check_launch("avt_maxpool_hw3s2_ndhwc_bf16");
 }
 
+// mean over the positions of a clip: the global average pool of the SlowFast head (AdaptiveAvgPool3d(1) per pathway
+// before the concat, models/models.py:576-580 head surgery) on NDHWC bf16 rows -> fp32, written straight into a
+// column slice of the [B, 2304] embedding table.  HBM-bound; deterministic: a workgroup owns (clip, 64 channels),
+// 32 row groups accumulate in fp32 and are reduced through LDS in a fixed order.
+__global__ __launch_bounds__(256) void mean_positions_kernel(const uint16_t* __restrict__ in, int P, int C, int ldi,
+                                                             float* __restrict__ out, int ldo) {
+  __shared__ float red[32][65];
+  const int b = blockIdx.x, c0 = blockIdx.y * 64;
+  const int cc = threadIdx.x & 7, rg = threadIdx.x >> 3;  // 8-channel chunk, row group
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int ch = c0 + cc * 8;
+  if (ch < C) {
+    const uint16_t* base = in + (int64_t)b * P * ldi + ch;
+    for (int r = rg; r < P; r += 32) {
+      const uint4 v = *reinterpret_cast<const uint4*>(base + (int64_t)r * ldi);
+      acc[0] += avt::bf16x2_lo(v.x);
+      acc[1] += avt::bf16x2_hi(v.x);
+      acc[2] += avt::bf16x2_lo(v.y);
+      acc[3] += avt::bf16x2_hi(v.y);
+      acc[4] += avt::bf16x2_lo(v.z);
+      acc[5] += avt::bf16x2_hi(v.z);
+      acc[6] += avt::bf16x2_lo(v.w);
+      acc[7] += avt::bf16x2_hi(v.w);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rg][cc * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+    float s = 0.f;
+    for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
+    out[(int64_t)b * ldo + c0 + threadIdx.x] = s / (float)P;
+  }
+}
+
+extern "C" int avt_mean_positions_bf16(const void* in, int batch, int p, int c, int ldi, float* out, int ldo, void* stream) {
+  AVT_REQUIRE(in && out, "avt_mean_positions_bf16: NULL pointer");
+  AVT_REQUIRE(batch > 0 && p > 0 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldi >= c && ldo >= c,
+              "avt_mean_positions_bf16: channels / input stride must be multiples of 8, strides must cover the channels");
+  AVT_REQUIRE(avt::aligned16(in), "avt_mean_positions_bf16: input must be 16-byte aligned");
+  hipLaunchKernelGGL(mean_positions_kernel, dim3((unsigned)batch, (unsigned)((c + 63) / 64)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint16_t*>(in), p, c, ldi, out, ldo);
+  return avt::check_launch("avt_mean_positions_bf16");
+}
+
 extern "C" int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w, int c, int ldi, int ldo,
                                             void* stream) {
   AVT_REQUIRE(in && out, "avt_maxpool_hw2s2_ndhwc_bf16: NULL pointer");

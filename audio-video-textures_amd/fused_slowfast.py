@@ -404,6 +404,7 @@ class SlowFastMFMA(nn.Module):
                 else:
                     s_act = blk(s_act)
         # head (models.py:576-580 surgery): global average pool per pathway, concat slow | fast
-        hs = s_act.buf.view(b, -1, s_act.buf.shape[1]).float().mean(1)
-        hf = f_act.buf.view(b, -1, f_act.buf.shape[1]).float().mean(1)
-        return torch.cat([hs, hf], 1)
+        emb = torch.empty((b, s_act.C + f_act.C), dtype=torch.float32, device=self.dev)
+        ops.mean_positions(s_act.ptr, b, s_act.buf.shape[0] // b, s_act.C, s_act.ld, emb, 0)
+        ops.mean_positions(f_act.ptr, b, f_act.buf.shape[0] // b, f_act.C, f_act.ld, emb, s_act.C)
+        return emb

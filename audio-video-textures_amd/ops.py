@@ -258,6 +258,14 @@ def bottleneck_fused(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk=8):
                                                     int(tchunk), _stream()), "avt_bottleneck_fused_bf16")
 
 
+def mean_positions(x_ptr, batch, p, c, ldi, out, col0=0):
+    """Head average pool: bf16 rows [batch*p, ldi] (raw address) -> out[:, col0:col0+c] fp32 (device tensor [batch, D])."""
+    _dev(out, "out", torch.float32)
+    _lib.check(_lib.lib().avt_mean_positions_bf16(C.c_void_p(x_ptr), int(batch), int(p), int(c), int(ldi),
+                                                  C.c_void_p(out.data_ptr() + 4 * int(col0)), int(out.shape[1]), _stream()),
+               "avt_mean_positions_bf16")
+
+
 def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
     """MaxPool2d(2, 2), floor mode, on NHWC bf16 rows (raw device addresses) — VGGish (audio_models/vggish.py:15-33)."""
     _lib.check(_lib.lib().avt_maxpool_hw2s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),

@@ -221,6 +221,12 @@ int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float* bias,
 int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w,
                                  int c, int ldi, int ldo, int tgroup, void* stream);
 
+/* Global average pool of the SlowFast head (AdaptiveAvgPool3d(1) per pathway, models/models.py:576-580 head
+ * surgery): in [batch, p positions, c] bf16 rows (stride ldi) -> out[b, 0..c) fp32 (row stride ldo: a column
+ * slice of the [batch, 2304] embedding table), mean in fp32, deterministic summation order. */
+int avt_mean_positions_bf16(const void* in, int batch, int p, int c, int ldi,
+                            float* out, int ldo, void* stream);
+
 /* MaxPool2d(2, stride 2), floor mode, of VGGish (audio_models/vggish.py:15-33: the "M" entries of
  * its feature stack) on NHWC bf16 rows; bt = batch, out [bt, h/2, w/2, c] (row stride ldo). */
 int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, int h, int w,

@@ -308,3 +308,17 @@ def test_bottleneck_fused_matches_module_and_unfused(avt, dev, c, cm, dims, tchu
     avt.ops.bottleneck_fused(rows.data_ptr(), y3.data_ptr(), fb.fused, b, t, h, w, c, tchunk=t)
     torch.cuda.synchronize()
     assert torch.equal(y2.buf, y3) and torch.equal(y, y3)
+
+
+def test_mean_positions_head_pool(avt, dev):
+    """The head's global average pool kernel: bf16 rows -> fp32 means into a column slice; deterministic."""
+    torch.manual_seed(12)
+    for b, p, c, ld in ((3, 392, 2048, 2048), (2, 1568, 256, 256), (2, 7, 24, 40)):
+        x = torch.randn(b * p, ld).to(torch.bfloat16).to(dev)
+        out = torch.full((b, c + 16), -1.0, dtype=torch.float32, device=dev)
+        avt.ops.mean_positions(x.data_ptr(), b, p, c, ld, out, 8)
+        out2 = torch.full_like(out, -1.0)
+        avt.ops.mean_positions(x.data_ptr(), b, p, c, ld, out2, 8)
+        ref = x[:, :c].float().view(b, p, c).double().mean(1).float()
+        assert torch.allclose(out[:, 8 : 8 + c], ref, rtol=1e-5, atol=1e-6)
+        assert (out[:, :8] == -1).all() and (out[:, 8 + c :] == -1).all() and torch.equal(out, out2)
