@@ -3,7 +3,7 @@
 //     a: Conv3d [3,1,1] C -> Cm  (temporal),  b: Conv3d [1,3,3] Cm -> Cm  (spatial),  c: Conv3d [1,1,1] Cm -> C
 // with the BatchNorms folded (the blocks of the third-party SlowFast model the reference runs per clip window,
 // contrastive_video_textures/models/models.py:335, 399; identity-shortcut, stride-1 blocks of the beta = 1/8 pathway:
-// C = 32 / 64, Cm = 8 / 16, 32 frames).
+// C = 32 / 64 / 128, Cm = 8 / 16 / 32, 32 frames).
 //
 // Why: as three launches these layers are 12 % of the encoder's FLOPs but 26 % of its time — a and b run at 2-3 TB/s
 // on few-channel tensors, and every intermediate crosses HBM.  Fused, the block's HBM traffic is x once (+ a 2-row
@@ -20,7 +20,8 @@
 // fragment, lane-linear) and live in registers; the weights are the first MFMA operand, so a lane ends with 4
 // consecutive channels of one position, and c's channel order is permuted in the packing so two tiles give 8
 // consecutive channels (one 16-byte store), as in stem_conv.hip.
-// Cm is padded to 16 on the host (zero filters / zero taps): the structured zeros cost MFMA issue only.
+// Cm = 8 is padded to 16 on the host (zero filters / zero taps): the structured zeros cost MFMA issue only.  For
+// Cm = 32 the a / b weight fragments (42 KB) live in LDS and b takes one tap per MFMA k-step.
 #include "avt_common.h"
 
 namespace {
@@ -46,7 +47,9 @@ struct BArgs {
 
 constexpr int NW = 8;  // waves per workgroup (2 per SIMD: the stages are latency-bound, not MFMA-bound)
 
-template <int C, int W, int HT>
+// CMP = bottleneck width as packed: 16 (Cm = 8 / 16: weights in registers, b's taps in pairs) or 32 (Cm = 32: the
+// a / b weight fragments live in LDS, one tap per MFMA k-step)
+template <int C, int W, int HT, int CMP>
 __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   constexpr int RX = HT + 2;            // x / a-output rows of a strip
   constexpr int PX = RX * W;            // positions of the x strip
@@ -60,15 +63,23 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   constexpr int MTA = (PX + 15) / 16;   // a-stage M-tiles
   constexpr int PB = HT * W;            // b / c positions
   constexpr int MTB = (PB + 15) / 16;
-  constexpr int ABYTES = (APOS + 32) * 32;  // a strip + room for the last partial tile's stores
+  constexpr int AREC = CMP * 2;         // bytes per position of the a / b strips
+  constexpr int NTA = CMP / 16;         // N-tiles of a and b
+  constexpr int NB = CMP == 16 ? 5 : 9;  // k-steps of b: tap pairs (16 channels) or single taps (32 channels)
+  constexpr bool WLDS = CMP > 16;
+  constexpr int ABYTES = (APOS + 32) * AREC;  // a strip + room for the last partial tile's stores
+  constexpr int BBYTES = MTB * 16 * AREC;
   constexpr int KA = C / 32;            // k-steps per frame tap of a
+  constexpr int NFA = 3 * KA * NTA, NFB = NB * NTA;  // weight fragments of a and b
   constexpr int NTC = C / 16;           // N-tiles of c
   constexpr int CIT = (MTB + NW - 1) / NW;   // c-stage tiles per wave
   constexpr int NST = CIT * (NTC / 2);       // ... = output store instructions per wave per frame
+  static_assert(CH == 4 || CH == 8 || CH == 16, "x records of 64 / 128 / 256 bytes");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* xr = lds;                       // [3][XFRAME]
-  char* ao = lds + 3 * XFRAME;          // [APOS (+pad)][16 ch]
-  char* bo = ao + ABYTES;               // [MTB*16][16 ch] (bottleneck width padded to 16 on the host)
+  char* ao = lds + 3 * XFRAME;          // [APOS (+pad)][CMP channels]
+  char* bo = ao + ABYTES;               // [MTB*16][CMP channels]
+  char* wl = bo + BBYTES;               // WLDS: [NFA + NFB] fragments of 1 KB
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,18 +91,35 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   const int h0 = strip * HT, t0 = tch * a.TC;
   const int t1 = (t0 + a.TC < a.T) ? t0 + a.TC : a.T;
 
-  // ---- weights: MFMA fragments in registers
-  bf16x8 wa[3][KA], wb[5], wc[NTC];
+  // ---- weights: MFMA fragments in registers (or, for the wide form, a's and b's in LDS)
+  bf16x8 wa_r[WLDS ? 1 : NFA], wb_r[WLDS ? 1 : NFB], wc[NTC];
+  if constexpr (WLDS) {
+    for (int f = wid; f < NFA + NFB; f += NW)
+      *reinterpret_cast<i32x4*>(wl + f * 1024 + lane * 16) = f < NFA ? a.wa[f * 64 + lane] : a.wb[(f - NFA) * 64 + lane];
+  } else {
 #pragma unroll
-  for (int dt = 0; dt < 3; ++dt)
+    for (int f = 0; f < NFA; ++f) wa_r[f] = __builtin_bit_cast(bf16x8, a.wa[f * 64 + lane]);
 #pragma unroll
-    for (int k = 0; k < KA; ++k) wa[dt][k] = __builtin_bit_cast(bf16x8, a.wa[(dt * KA + k) * 64 + lane]);
-#pragma unroll
-  for (int j = 0; j < 5; ++j) wb[j] = __builtin_bit_cast(bf16x8, a.wb[j * 64 + lane]);
+    for (int f = 0; f < NFB; ++f) wb_r[f] = __builtin_bit_cast(bf16x8, a.wb[f * 64 + lane]);
+  }
+  auto WA = [&](int dt, int k, int n) {
+    const int f = (dt * KA + k) * NTA + n;
+    if constexpr (WLDS) return *reinterpret_cast<const bf16x8*>(wl + f * 1024 + lane * 16);
+    else return wa_r[f];
+  };
+  auto WB = [&](int j, int n) {
+    const int f = j * NTA + n;
+    if constexpr (WLDS) return *reinterpret_cast<const bf16x8*>(wl + (NFA + f) * 1024 + lane * 16);
+    else return wb_r[f];
+  };
 #pragma unroll
   for (int n = 0; n < NTC; ++n) wc[n] = __builtin_bit_cast(bf16x8, a.wc[n * 64 + lane]);
-  const float4 bav = *reinterpret_cast<const float4*>(a.ba + 4 * q);
-  const float4 bbv = *reinterpret_cast<const float4*>(a.bb + 4 * q);
+  float4 bav[NTA], bbv[NTA];
+#pragma unroll
+  for (int n = 0; n < NTA; ++n) {
+    bav[n] = *reinterpret_cast<const float4*>(a.ba + 16 * n + 4 * q);
+    bbv[n] = *reinterpret_cast<const float4*>(a.bb + 16 * n + 4 * q);
+  }
   float4 bcv[NTC / 2][2];
 #pragma unroll
   for (int np = 0; np < NTC / 2; ++np) {
@@ -104,6 +132,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
 
   // ---- x ring DMA: instruction d of a frame fills positions d*PPI + lane/CH, slot lane%CH (chunk = slot ^ swizzle)
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  auto swz = [&](int p) { return (CH == 4 ? (p >> 2) : CH == 8 ? (p >> 1) : p) & (CH - 1); };
   constexpr int NDW = (NDMA + NW - 1) / NW;  // DMA instructions per wave per frame
   unsigned poff[NDW];                  // byte offset of this lane's chunk inside a frame, or OOB
 #pragma unroll
@@ -111,7 +140,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     const int d = wid + NW * u;
     const int p = d * PPI + lane / CH, slot = lane % CH;
     const int r = p / W, w = p - r * W;
-    const int chunk = slot ^ ((CH == 4 ? (p >> 2) : (p >> 1)) & (CH - 1));
+    const int chunk = slot ^ swz(p);
     const int h = h0 - 1 + r;
     const bool ok = d < NDMA && p < PX && (unsigned)h < (unsigned)a.H;
     poff[u] = ok ? (unsigned)(((h * W + w) * C + chunk * 8) * 2) : kOob;
@@ -131,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     }
   };
   auto xoff = [&](int p, int chunk) {  // byte offset, inside a ring frame, of a 16-byte chunk of x position p
-    return p * REC + ((chunk ^ ((CH == 4 ? (p >> 2) : (p >> 1)) & (CH - 1))) * 16);
+    return p * REC + ((chunk ^ swz(p)) * 16);
   };
 
   // ---- per-lane addresses of every tile this wave owns, computed ONCE: the stages are instruction-issue bound
@@ -146,15 +175,20 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
 #pragma unroll
     for (int k = 0; k < KA; ++k) a_rd[it][k] = xoff(pc, k * 4 + q);
     const int r = p / W, w = p - r * W;
-    a_st[it] = (p < PX ? r * AW + w + 1 : APOS + (p - PX)) * 32 + q * 8;
+    a_st[it] = (p < PX ? r * AW + w + 1 : APOS + (p - PX)) * AREC + q * 8;
     a_in |= ((unsigned)(h0 - 1 + r) < (unsigned)a.H ? 1u : 0u) << it;
   }
-  int tapoff[5];  // b: byte offset of this lane's tap of pair j (k-groups 0,1 = tap 2j, 2,3 = tap 2j+1; tap 9 = zeros)
+  int tapoff[NB];  // b: byte offset of this lane's operand chunk for k-step j, relative to tap (0,0) of its position
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int tap = (q >> 1) ? (2 * j + 1 < 9 ? 2 * j + 1 : 8) : 2 * j;
-    tapoff[j] = ((tap / 3) * AW + tap % 3) * 32 + (q & 1) * 16;
+  for (int j = 0; j < NB; ++j) {
+    if constexpr (CMP == 16) {  // k-groups 0,1 = tap 2j, 2,3 = tap 2j+1 (tap 9 has zero weights: any finite data)
+      const int tap = (q >> 1) ? (2 * j + 1 < 9 ? 2 * j + 1 : 8) : 2 * j;
+      tapoff[j] = ((tap / 3) * AW + tap % 3) * AREC + (q & 1) * 16;
+    } else {
+      tapoff[j] = ((j / 3) * AW + j % 3) * AREC + q * 16;
+    }
   }
+  const int cchunk = (CMP == 16 ? (q & 1) : q) * 16;  // c: this lane's k-group inside a b-strip record
   int b_rd[CIT], c_res[CIT][NTC / 2], c_out[CIT];
   unsigned c_ok = 0;
 #pragma unroll
@@ -163,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     const int p = mt * 16 + l15;
     const int pc = p < PB ? p : PB - 1;
     const int r = pc / W, w = pc - r * W;
-    b_rd[it] = (r * AW + w) * 32;  // tap (0,0) of this position in the a strip
+    b_rd[it] = (r * AW + w) * AREC;  // tap (0,0) of this position in the a strip
 #pragma unroll
     for (int np = 0; np < NTC / 2; ++np) c_res[it][np] = xoff((r + 1) * W + w, (32 * np + 8 * q) / 8);
     c_out[it] = ((h0 + r) * W + w) * C + 8 * q;
@@ -187,39 +221,53 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
 #pragma unroll
     for (int it = 0; it < AIT; ++it) {
       if (wid + NW * it < MTA) {  // wave-uniform
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NTA];
+#pragma unroll
+        for (int n = 0; n < NTA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KA; ++k) {
           const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xm_ + a_rd[it][k]);
           const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(x0_ + a_rd[it][k]);
           const bf16x8 xp = *reinterpret_cast<const bf16x8*>(xp_ + a_rd[it][k]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][k], xm, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][k], x0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2][k], xp, acc, 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < NTA; ++n) {
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(0, k, n), xm, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(1, k, n), x0, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(2, k, n), xp, acc[n], 0, 0, 0);
+          }
         }
         const bool rowin = (a_in >> it) & 1u;  // rows outside the image are b's ZERO padding, not a(0)
-        uint2 pk;
-        pk.x = rowin ? avt::pack_bf16x2(fmaxf(acc[0] + bav.x, 0.f), fmaxf(acc[1] + bav.y, 0.f)) : 0u;
-        pk.y = rowin ? avt::pack_bf16x2(fmaxf(acc[2] + bav.z, 0.f), fmaxf(acc[3] + bav.w, 0.f)) : 0u;
-        *reinterpret_cast<uint2*>(ao + a_st[it]) = pk;
+#pragma unroll
+        for (int n = 0; n < NTA; ++n) {
+          uint2 pk;
+          pk.x = rowin ? avt::pack_bf16x2(fmaxf(acc[n][0] + bav[n].x, 0.f), fmaxf(acc[n][1] + bav[n].y, 0.f)) : 0u;
+          pk.y = rowin ? avt::pack_bf16x2(fmaxf(acc[n][2] + bav[n].z, 0.f), fmaxf(acc[n][3] + bav[n].w, 0.f)) : 0u;
+          *reinterpret_cast<uint2*>(ao + a_st[it] + n * 32) = pk;
+        }
       }
     }
     __syncthreads();  // a strip complete; ring slot of frame t-1 is free
     if (t + 2 <= t1) dma_frame(t + 2);  // lands under the b and c stages (frame t1 itself is the last halo needed)
-    // ---- [b] 3x3 spatial conv: 9 taps as 5 tap pairs, operands straight from the a strip
+    // ---- [b] 3x3 spatial conv, operands straight from the a strip at tap-shifted addresses
 #pragma unroll
     for (int it = 0; it < CIT; ++it) {
       if (wid + NW * it < MTB) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NTA];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int n = 0; n < NTA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
           const bf16x8 af = *reinterpret_cast<const bf16x8*>(ao + b_rd[it] + tapoff[j]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], af, acc, 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < NTA; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB(j, n), af, acc[n], 0, 0, 0);
         }
-        uint2 pk;
-        pk.x = avt::pack_bf16x2(fmaxf(acc[0] + bbv.x, 0.f), fmaxf(acc[1] + bbv.y, 0.f));
-        pk.y = avt::pack_bf16x2(fmaxf(acc[2] + bbv.z, 0.f), fmaxf(acc[3] + bbv.w, 0.f));
-        *reinterpret_cast<uint2*>(bo + ((wid + NW * it) * 16 + l15) * 32 + q * 8) = pk;
+#pragma unroll
+        for (int n = 0; n < NTA; ++n) {
+          uint2 pk;
+          pk.x = avt::pack_bf16x2(fmaxf(acc[n][0] + bbv[n].x, 0.f), fmaxf(acc[n][1] + bbv[n].y, 0.f));
+          pk.y = avt::pack_bf16x2(fmaxf(acc[n][2] + bbv[n].z, 0.f), fmaxf(acc[n][3] + bbv[n].w, 0.f));
+          *reinterpret_cast<uint2*>(bo + ((wid + NW * it) * 16 + l15) * AREC + n * 32 + q * 8) = pk;
+        }
       }
     }
     __syncthreads();  // b strip complete
@@ -229,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     for (int it = 0; it < CIT; ++it) {  // the same trip count in every wave: the stores are counted by s_waitcnt
       const int mt = wid + NW * it;
       const int pr = (mt < MTB ? mt : MTB - 1) * 16 + l15;
-      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bo + pr * 32 + (q & 1) * 16);  // k >= 16: zero weights
+      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bo + pr * AREC + cchunk);  // CMP = 16: k >= 16 has zero weights
 #pragma unroll
       for (int np = 0; np < NTC / 2; ++np) {
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
@@ -248,27 +296,29 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   }
 }
 
-template <int C, int W, int HT>
+template <int C, int W, int HT, int CMP>
 int launch(BArgs& a, int batch, int h, hipStream_t st) {
   constexpr int RX = HT + 2, PX = RX * W, PPI = 1024 / (C * 2), NDMA = (PX + PPI - 1) / PPI;
-  constexpr int MTB = (HT * W + 15) / 16, AW = W + 2;
-  constexpr int lds_bytes = 3 * NDMA * 1024 + (RX * AW + 32) * 32 + MTB * 16 * 32;
+  constexpr int MTB = (HT * W + 15) / 16, AW = W + 2, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
+  constexpr int wfrags = CMP > 16 ? (3 * (C / 32) * NTA + NB * NTA) : 0;
+  constexpr int lds_bytes = 3 * NDMA * 1024 + (RX * AW + 32) * CMP * 2 + MTB * 16 * CMP * 2 + wfrags * 1024;
   static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
   a.strips = (h + HT - 1) / HT;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_bottleneck_fused_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT, CMP>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
+                     lds_bytes, st, a);
   return avt::check_launch("avt_bottleneck_fused_bf16");
 }
 
 }  // namespace
 
 extern "C" int avt_bottleneck_fused_supported(int c, int w) {
-  return ((c == 32 && w == 56) || (c == 64 && w == 28) || (c == 32 && w == 12) || (c == 64 && w == 10)) ? 1 : 0;
+  return ((c == 32 && (w == 56 || w == 12)) || (c == 64 && (w == 28 || w == 10)) || (c == 128 && (w == 14 || w == 6))) ? 1 : 0;
 }
 
 extern "C" int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const float* ba, const void* wb,
@@ -277,7 +327,7 @@ extern "C" int avt_bottleneck_fused_bf16(const void* x, void* out, const void* w
   AVT_REQUIRE(x && out && wa && ba && wb && bb && wc && bc, "avt_bottleneck_fused_bf16: NULL pointer");
   AVT_REQUIRE(batch > 0 && t > 0 && h > 0 && tchunk > 0, "avt_bottleneck_fused_bf16: bad sizes");
   AVT_REQUIRE(avt_bottleneck_fused_supported(c, w),
-              "avt_bottleneck_fused_bf16: unsupported shape C=%d W=%d (fast-pathway identity blocks: 32x56, 64x28)", c, w);
+              "avt_bottleneck_fused_bf16: unsupported shape C=%d W=%d (fast-pathway identity blocks: 32x56, 64x28, 128x14)", c, w);
   AVT_REQUIRE(x != out, "avt_bottleneck_fused_bf16: in-place is not supported (neighbouring strips read x)");
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(out) && avt::aligned16(wa) && avt::aligned16(wb) && avt::aligned16(wc) &&
                   avt::aligned16(ba) && avt::aligned16(bb) && avt::aligned16(bc),
@@ -299,8 +349,10 @@ extern "C" int avt_bottleneck_fused_bf16(const void* x, void* out, const void* w
   a.tchunks = (t + a.TC - 1) / a.TC;
   a.x_bytes = (unsigned)xb;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (c == 32 && w == 56) return launch<32, 56, 8>(a, batch, h, s);
-  if (c == 64 && w == 28) return launch<64, 28, 7>(a, batch, h, s);
-  if (c == 32 && w == 12) return launch<32, 12, 5>(a, batch, h, s);  // small shapes for the tests: ragged strips,
-  return launch<64, 10, 4>(a, batch, h, s);                          // partial tiles, partial DMA instructions
+  if (c == 32 && w == 56) return launch<32, 56, 8, 16>(a, batch, h, s);
+  if (c == 64 && w == 28) return launch<64, 28, 7, 16>(a, batch, h, s);
+  if (c == 128 && w == 14) return launch<128, 14, 7, 32>(a, batch, h, s);
+  if (c == 32 && w == 12) return launch<32, 12, 5, 16>(a, batch, h, s);  // small shapes for the tests: ragged strips,
+  if (c == 64 && w == 10) return launch<64, 10, 4, 16>(a, batch, h, s);  // partial tiles, partial DMA instructions
+  return launch<128, 6, 3, 32>(a, batch, h, s);
 }

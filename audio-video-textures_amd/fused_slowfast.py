@@ -232,30 +232,46 @@ def stem_conv(stem, device, tgroup=1):
 
 def pack_bottleneck(wa, ba, wb, bb, wc, bc, device):
     """BN-folded weights of a [3,1,1] -> [1,3,3] -> [1,1,1] bottleneck (wa [Cm,C,3,1,1], wb [Cm,Cm,1,3,3], wc [C,Cm,1,1,1])
-    -> the MFMA-fragment order of csrc/bottleneck_fused.hip (include/avt.h), bottleneck width zero-padded to 16."""
+    -> the MFMA-fragment order of csrc/bottleneck_fused.hip (include/avt.h); the bottleneck width is zero-padded to
+    CMP = 16 (Cm <= 16; b's taps packed in pairs) or 32 (Cm = 32; one tap per MFMA k-step)."""
     wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]  # packing is host work
     cm, c = wa.shape[0], wa.shape[1]
+    cmp_ = 16 if cm <= 16 else 32
+    nta = cmp_ // 16
     lane = torch.arange(64)
     n, q = lane & 15, lane >> 4
     e = torch.arange(8)
-    wa_p = torch.zeros((16, c, 3))
+    L, E = n.numel(), e.numel()
+    wa_p = torch.zeros((cmp_, c, 3))
     wa_p[:cm] = wa[:, :, :, 0, 0]
-    k_idx = (torch.arange(c // 32).view(-1, 1, 1) * 32 + q.view(1, -1, 1) * 8 + e.view(1, 1, -1))  # [K, 64, 8]
-    wa_f = torch.stack([wa_p[n.view(1, -1, 1).expand_as(k_idx), k_idx, dt] for dt in range(3)])  # [3, K, 64, 8]
-    wb_p = torch.zeros((16, 16, 10))  # [n, ch, tap]; tap 9 = zeros
+    ka = c // 32
+    # wa fragments [3 dt][ka][nta][64][8]: row nt*16 + n, k = 32*k + 8*q + e
+    k_idx = (torch.arange(ka).view(-1, 1, 1, 1) * 32 + q.view(1, 1, -1, 1) * 8 + e.view(1, 1, 1, -1)).expand(ka, nta, L, E)
+    r_idx = (torch.arange(nta).view(1, -1, 1, 1) * 16 + n.view(1, 1, -1, 1)).expand(ka, nta, L, E)
+    wa_f = torch.stack([wa_p[r_idx, k_idx, dt] for dt in range(3)])
+    # wb fragments [nb][nta][64][8]
+    wb_p = torch.zeros((cmp_, cmp_, 10))  # [n, ch, tap]; tap 9 = zeros
     wb_p[:cm, :cm, :9] = wb[:, :, 0].reshape(cm, cm, 9)
-    tap = (2 * torch.arange(5).view(-1, 1, 1) + (q >> 1).view(1, -1, 1)).expand(5, 64, 8)
-    ch = (8 * (q & 1).view(1, -1, 1) + e.view(1, 1, -1)).expand(5, 64, 8)
-    wb_f = wb_p[n.view(1, -1, 1).expand(5, 64, 8), ch, tap]
+    nb = 5 if cmp_ == 16 else 9
+    j = torch.arange(nb).view(-1, 1, 1, 1)
+    if cmp_ == 16:
+        tap = (2 * j + (q >> 1).view(1, 1, -1, 1)).expand(nb, nta, L, E)
+        ch = (8 * (q & 1).view(1, 1, -1, 1) + e.view(1, 1, 1, -1)).expand(nb, nta, L, E)
+    else:
+        tap = j.expand(nb, nta, L, E)
+        ch = (8 * q.view(1, 1, -1, 1) + e.view(1, 1, 1, -1)).expand(nb, nta, L, E)
+    rb = (torch.arange(nta).view(1, -1, 1, 1) * 16 + n.view(1, 1, -1, 1)).expand(nb, nta, L, E)
+    wb_f = wb_p[rb, ch, tap]
+    # wc fragments [c/16][64][8]: tile nt, row r -> channel 32*(nt//2) + 8*(r//4) + 4*(nt%2) + r%4, k = 8*q + e
     wc_p = torch.zeros((c, 32))
     wc_p[:, :cm] = wc[:, :, 0, 0, 0]
     nt = torch.arange(c // 16).view(-1, 1, 1)
-    chan = (32 * (nt // 2) + 8 * (n >> 2).view(1, -1, 1) + 4 * (nt % 2) + (n & 3).view(1, -1, 1)).expand(c // 16, 64, 8)
-    kk = (q.view(1, -1, 1) * 8 + e.view(1, 1, -1)).expand(c // 16, 64, 8)
+    chan = (32 * (nt // 2) + 8 * (n >> 2).view(1, -1, 1) + 4 * (nt % 2) + (n & 3).view(1, -1, 1)).expand(c // 16, L, E)
+    kk = (q.view(1, -1, 1) * 8 + e.view(1, 1, -1)).expand(c // 16, L, E)
     wc_f = wc_p[chan, kk]
-    pad16 = lambda v: torch.cat([v.float(), torch.zeros(16 - v.numel())])
+    padw = lambda v: torch.cat([v.float(), torch.zeros(cmp_ - v.numel())])
     dev = lambda v, dt: v.to(dt).contiguous().to(device)
-    return (dev(wa_f, torch.bfloat16), dev(pad16(ba), torch.float32), dev(wb_f, torch.bfloat16), dev(pad16(bb), torch.float32),
+    return (dev(wa_f, torch.bfloat16), dev(padw(ba), torch.float32), dev(wb_f, torch.bfloat16), dev(padw(bb), torch.float32),
             dev(wc_f, torch.bfloat16), dev(bc.float(), torch.float32))
 
 
@@ -267,11 +283,11 @@ class _Block:
         self.b = FusedConv(t.b, t.b_bn, True, device)
         self.c = FusedConv(t.c, t.c_bn, True, device)  # ReLU applied after the residual add (fused)
         self.dev = device
-        # identity-shortcut fast-pathway blocks ([3,1,1] -> [1,3,3] -> [1,1,1], stride 1, width <= 16): one kernel
+        # identity-shortcut fast-pathway blocks ([3,1,1] -> [1,3,3] -> [1,1,1], stride 1, width <= 32): one kernel
         self.fused = None
         if (_FUSE_BLOCK and self.b1 is None and self.a.kernel == (3, 1, 1) and self.b.kernel == (1, 3, 3) and
                 self.c.kernel == (1, 1, 1) and self.a.stride == (1, 1, 1) and self.b.stride == (1, 1, 1) and
-                self.a.cout <= 16 and self.c.cout == self.a.cin and self.c.cout in (32, 64)):
+                self.a.cout <= 32 and self.c.cout == self.a.cin and self.c.cout in (32, 64, 128)):
             (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
             self.fused = pack_bottleneck(wa, ba, wb, bb, wc, bc, device)
 

@@ -260,12 +260,13 @@ int avt_stem_conv_pool_bf16(const void* in, const void* wt, const float* bias, v
  * BatchNorms folded, stride 1 (blocks of the third-party SlowFast model the reference runs per clip window,
  * models/models.py:335, 399).  x, out [batch, t, h, w, c] bf16 (NDHWC, distinct buffers); the intermediates
  * stay in LDS.  Weights in MFMA fragment order, bf16, 1 KB per fragment (lane l: n = l & 15, k-group q = l >> 4,
- * 8 values each), the bottleneck width Cm (8 or 16) zero-padded to 16:
- *   wa [3 dt][c/32][64][8]: Wa[n][dt][32*k + 8*q + e];   ba [16] fp32
- *   wb [5][64][8]: tap = 2*j + (q >> 1) (dh = tap/3, dw = tap%3; tap 9 = zeros), channel 8*(q & 1) + e;  bb [16]
+ * 8 values each), the bottleneck width Cm zero-padded to CMP = 16 (Cm = 8, 16) or 32 (Cm = 32), NT = CMP/16:
+ *   wa [3 dt][c/32][NT][64][8]: Wa[16*nt + n][dt][32*k + 8*q + e];   ba [CMP] fp32
+ *   wb CMP 16: [5][1][64][8]: tap = 2*j + (q >> 1) (dh = tap/3, dw = tap%3; tap 9 = zeros), channel 8*(q & 1) + e
+ *      CMP 32: [9][2][64][8]: tap = j, channel 8*q + e, row 16*nt + n;   bb [CMP]
  *   wc [c/16][64][8]: tile nt, row r = l & 15 -> output channel 32*(nt/2) + 8*(r/4) + 4*(nt%2) + r%4, k = 8*q + e;  bc [c]
  * tchunk = frames walked per workgroup (each re-reads one halo frame on either side).
- * avt_bottleneck_fused_supported(c, w): (32, 56) and (64, 28) = the res2 / res3 blocks at 224^2 clips. */
+ * avt_bottleneck_fused_supported(c, w): (32, 56), (64, 28), (128, 14) = the res2 / res3 / res4 blocks at 224^2 clips. */
 int avt_bottleneck_fused_supported(int c, int w);
 int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const float* ba,
                               const void* wb, const float* bb, const void* wc, const float* bc,

@@ -268,6 +268,8 @@ def test_stem_lds_kernel_matches_generic_and_torch(avt, dev, hw):
     (64, 16, (1, 5, 9, 10), 8),    # 128-byte records, one chunk of frames
     (32, 8, (1, 4, 56, 56), 2),    # the res2 fast-pathway shape
     (64, 16, (1, 3, 28, 28), 8),   # the res3 fast-pathway shape
+    (128, 32, (2, 5, 7, 6), 2),    # wide form (weights in LDS, single-tap k-steps), ragged strips 3+3+1
+    (128, 32, (1, 4, 14, 14), 8),  # the res4 fast-pathway shape
 ])
 def test_bottleneck_fused_matches_module_and_unfused(avt, dev, c, cm, dims, tchunk):
     """csrc/bottleneck_fused.hip: a whole identity bottleneck ([3,1,1] -> [1,3,3] -> [1,1,1] + x, BN folded, ReLUs) in one
