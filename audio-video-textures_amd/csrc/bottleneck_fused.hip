@@ -37,6 +37,7 @@ struct BArgs {
   const i32x4* wa;  // [3][C/32][64 lanes]
   const i32x4* wb;  // [5][64]
   const i32x4* wc;  // [C/16][64]
+  const i32x4* wsc;  // first-block form: shortcut conv fragments [C/16][64]
   const float* ba;  // [16]
   const float* bb;  // [16]
   const float* bc;  // [C]
@@ -49,12 +50,15 @@ constexpr int NW = 8;  // waves per workgroup (2 per SIMD: the stages are latenc
 
 // CMP = bottleneck width as packed: 16 (Cm = 8 / 16: weights in registers, b's taps in pairs) or 32 (Cm = 32: the
 // a / b weight fragments live in LDS, one tap per MFMA k-step)
-template <int C, int W, int HT, int CMP>
+// CIN = input channels: C (identity shortcut: out = relu(c(..) + x)) or 8 (first block of res2: x has 8 channels, the
+// three frame taps of a are ONE MFMA k-step, and the shortcut is a 1x1x1 conv of x accumulated into c's MFMA tile)
+template <int C, int W, int HT, int CMP, int CIN = C>
 __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
+  constexpr bool FIRST = CIN != C;
   constexpr int RX = HT + 2;            // x / a-output rows of a strip
   constexpr int PX = RX * W;            // positions of the x strip
-  constexpr int REC = C * 2;            // bytes per x position
-  constexpr int CH = C / 8;             // 16-byte chunks per x position
+  constexpr int REC = CIN * 2;          // bytes per x position
+  constexpr int CH = CIN / 8;           // 16-byte chunks per x position
   constexpr int PPI = 1024 / REC;       // positions per DMA wave-instruction
   constexpr int NDMA = (PX + PPI - 1) / PPI;  // DMA wave-instructions per frame
   constexpr int XFRAME = NDMA * 1024;   // LDS bytes per ring frame (whole instructions)
@@ -69,12 +73,13 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   constexpr bool WLDS = CMP > 16;
   constexpr int ABYTES = (APOS + 32) * AREC;  // a strip + room for the last partial tile's stores
   constexpr int BBYTES = MTB * 16 * AREC;
-  constexpr int KA = C / 32;            // k-steps per frame tap of a
-  constexpr int NFA = 3 * KA * NTA, NFB = NB * NTA;  // weight fragments of a and b
+  constexpr int KA = FIRST ? 1 : C / 32;  // k-steps per frame tap of a (FIRST: one k-step holds all three taps)
+  constexpr int NFA = (FIRST ? 1 : 3) * KA * NTA, NFB = NB * NTA;  // weight fragments of a and b
   constexpr int NTC = C / 16;           // N-tiles of c
   constexpr int CIT = (MTB + NW - 1) / NW;   // c-stage tiles per wave
   constexpr int NST = CIT * (NTC / 2);       // ... = output store instructions per wave per frame
-  static_assert(CH == 4 || CH == 8 || CH == 16, "x records of 64 / 128 / 256 bytes");
+  static_assert(CH == 1 || CH == 4 || CH == 8 || CH == 16, "x records of 16 / 64 / 128 / 256 bytes");
+  static_assert(!FIRST || (CIN == 8 && CMP == 16), "first-block form: 8 input channels, width <= 16");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* xr = lds;                       // [3][XFRAME]
   char* ao = lds + 3 * XFRAME;          // [APOS (+pad)][CMP channels]
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   const int t1 = (t0 + a.TC < a.T) ? t0 + a.TC : a.T;
 
   // ---- weights: MFMA fragments in registers (or, for the wide form, a's and b's in LDS)
-  bf16x8 wa_r[WLDS ? 1 : NFA], wb_r[WLDS ? 1 : NFB], wc[NTC];
+  bf16x8 wa_r[WLDS ? 1 : NFA], wb_r[WLDS ? 1 : NFB], wc[NTC], wsc[FIRST ? NTC : 1];
   if constexpr (WLDS) {
     for (int f = wid; f < NFA + NFB; f += NW)
       *reinterpret_cast<i32x4*>(wl + f * 1024 + lane * 16) = f < NFA ? a.wa[f * 64 + lane] : a.wb[(f - NFA) * 64 + lane];
@@ -114,6 +119,10 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   };
 #pragma unroll
   for (int n = 0; n < NTC; ++n) wc[n] = __builtin_bit_cast(bf16x8, a.wc[n * 64 + lane]);
+  if constexpr (FIRST) {
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) wsc[n] = __builtin_bit_cast(bf16x8, a.wsc[n * 64 + lane]);
+  }
   float4 bav[NTA], bbv[NTA];
 #pragma unroll
   for (int n = 0; n < NTA; ++n) {
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
 
   // ---- x ring DMA: instruction d of a frame fills positions d*PPI + lane/CH, slot lane%CH (chunk = slot ^ swizzle)
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  auto swz = [&](int p) { return (CH == 4 ? (p >> 2) : CH == 8 ? (p >> 1) : p) & (CH - 1); };
+  auto swz = [&](int p) { return (CH == 4 ? (p >> 2) : CH == 8 ? (p >> 1) : p) & (CH - 1); };  // CH == 1: 0
   constexpr int NDW = (NDMA + NW - 1) / NW;  // DMA instructions per wave per frame
   unsigned poff[NDW];                  // byte offset of this lane's chunk inside a frame, or OOB
 #pragma unroll
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     const int chunk = slot ^ swz(p);
     const int h = h0 - 1 + r;
     const bool ok = d < NDMA && p < PX && (unsigned)h < (unsigned)a.H;
-    poff[u] = ok ? (unsigned)(((h * W + w) * C + chunk * 8) * 2) : kOob;
+    poff[u] = ok ? (unsigned)(((h * W + w) * CIN + chunk * 8) * 2) : kOob;
   }
   auto dma_frame = [&](int tt) {  // frame tt of the clip -> ring slot tt mod 3 (zeros when tt is outside the clip)
     const int slot = ((tt % 3) + 3) % 3;
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     const int p = (wid + NW * it) * 16 + l15;
     const int pc = p < PX ? p : PX - 1;  // partial last tile: read a valid position, store behind the strip
 #pragma unroll
-    for (int k = 0; k < KA; ++k) a_rd[it][k] = xoff(pc, k * 4 + q);
+    for (int k = 0; k < KA; ++k) a_rd[it][k] = FIRST ? pc * REC : xoff(pc, k * 4 + q);
     const int r = p / W, w = p - r * W;
     a_st[it] = (p < PX ? r * AW + w + 1 : APOS + (p - PX)) * AREC + q * 8;
     a_in |= ((unsigned)(h0 - 1 + r) < (unsigned)a.H ? 1u : 0u) << it;
@@ -199,7 +208,8 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     const int r = pc / W, w = pc - r * W;
     b_rd[it] = (r * AW + w) * AREC;  // tap (0,0) of this position in the a strip
 #pragma unroll
-    for (int np = 0; np < NTC / 2; ++np) c_res[it][np] = xoff((r + 1) * W + w, (32 * np + 8 * q) / 8);
+    for (int np = 0; np < NTC / 2; ++np)  // residual chunk of x(t) — FIRST: the position's one 8-channel record (shortcut operand)
+      c_res[it][np] = FIRST ? ((r + 1) * W + w) * REC : xoff((r + 1) * W + w, (32 * np + 8 * q) / 8);
     c_out[it] = ((h0 + r) * W + w) * C + 8 * q;
     c_ok |= ((mt < MTB && p < PB && h0 + r < a.H) ? 1u : 0u) << it;
   }
@@ -217,6 +227,8 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     const char* xm_ = xr + ((((t - 1) % 3) + 3) % 3) * XFRAME;
     const char* x0_ = xr + (t % 3) * XFRAME;
     const char* xp_ = xr + ((t + 1) % 3) * XFRAME;
+    const char* xq_ = q == 0 ? xm_ : (q == 2 ? xp_ : x0_);  // FIRST: this lane's frame tap
+    (void)xq_;
     // ---- [a] temporal conv over the ring -> relu -> a strip
 #pragma unroll
     for (int it = 0; it < AIT; ++it) {
@@ -224,16 +236,22 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
         f32x4 acc[NTA];
 #pragma unroll
         for (int n = 0; n < NTA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (FIRST) {  // k-groups 0,1,2 = frames t-1, t, t+1 (8 channels each); group 3 has zero weights
+          const bf16x8 xq = *reinterpret_cast<const bf16x8*>(xq_ + a_rd[it][0]);
 #pragma unroll
-        for (int k = 0; k < KA; ++k) {
-          const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xm_ + a_rd[it][k]);
-          const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(x0_ + a_rd[it][k]);
-          const bf16x8 xp = *reinterpret_cast<const bf16x8*>(xp_ + a_rd[it][k]);
+          for (int n = 0; n < NTA; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(0, 0, n), xq, acc[n], 0, 0, 0);
+        } else {
 #pragma unroll
-          for (int n = 0; n < NTA; ++n) {
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(0, k, n), xm, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(1, k, n), x0, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(2, k, n), xp, acc[n], 0, 0, 0);
+          for (int k = 0; k < KA; ++k) {
+            const bf16x8 xm = *reinterpret_cast<const bf16x8*>(xm_ + a_rd[it][k]);
+            const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(x0_ + a_rd[it][k]);
+            const bf16x8 xp = *reinterpret_cast<const bf16x8*>(xp_ + a_rd[it][k]);
+#pragma unroll
+            for (int n = 0; n < NTA; ++n) {
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(0, k, n), xm, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(1, k, n), x0, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WA(2, k, n), xp, acc[n], 0, 0, 0);
+            }
           }
         }
         const bool rowin = (a_in >> it) & 1u;  // rows outside the image are b's ZERO padding, not a(0)
@@ -284,7 +302,13 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
         c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2 * np], bf, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2 * np + 1], bf, c1, 0, 0, 0);
         const float4 b0 = bcv[np][0], b1 = bcv[np][1];
-        const uint4 rs = *reinterpret_cast<const uint4*>(x0_ + c_res[it][np]);
+        uint4 rs = *reinterpret_cast<const uint4*>(x0_ + c_res[it][np]);
+        if constexpr (FIRST) {  // shortcut = 1x1x1 conv of x(t) into the same tile (k-group 0 carries its 8 channels)
+          const bf16x8 xs = __builtin_bit_cast(bf16x8, rs);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsc[2 * np], xs, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsc[2 * np + 1], xs, c1, 0, 0, 0);
+          rs = make_uint4(0u, 0u, 0u, 0u);  // no identity term; bc already holds bc + b_shortcut
+        }
         uint4 o;
         o.x = avt::pack_bf16x2(fmaxf(c0[0] + b0.x + avt::bf16x2_lo(rs.x), 0.f), fmaxf(c0[1] + b0.y + avt::bf16x2_hi(rs.x), 0.f));
         o.y = avt::pack_bf16x2(fmaxf(c0[2] + b0.z + avt::bf16x2_lo(rs.y), 0.f), fmaxf(c0[3] + b0.w + avt::bf16x2_hi(rs.y), 0.f));
@@ -296,21 +320,22 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   }
 }
 
-template <int C, int W, int HT, int CMP>
+template <int C, int W, int HT, int CMP, int CIN = C>
 int launch(BArgs& a, int batch, int h, hipStream_t st) {
-  constexpr int RX = HT + 2, PX = RX * W, PPI = 1024 / (C * 2), NDMA = (PX + PPI - 1) / PPI;
+  constexpr int RX = HT + 2, PX = RX * W, PPI = 1024 / (CIN * 2), NDMA = (PX + PPI - 1) / PPI;
   constexpr int MTB = (HT * W + 15) / 16, AW = W + 2, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
   constexpr int wfrags = CMP > 16 ? (3 * (C / 32) * NTA + NB * NTA) : 0;
+  static_assert(CIN == C || CMP == 16, "first-block form keeps its weights in registers");
   constexpr int lds_bytes = 3 * NDMA * 1024 + (RX * AW + 32) * CMP * 2 + MTB * 16 * CMP * 2 + wfrags * 1024;
   static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
   a.strips = (h + HT - 1) / HT;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP, CIN>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_bottleneck_fused_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT, CMP>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
+  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT, CMP, CIN>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
                      lds_bytes, st, a);
   return avt::check_launch("avt_bottleneck_fused_bf16");
 }
@@ -321,25 +346,24 @@ extern "C" int avt_bottleneck_fused_supported(int c, int w) {
   return ((c == 32 && (w == 56 || w == 12)) || (c == 64 && (w == 28 || w == 10)) || (c == 128 && (w == 14 || w == 6))) ? 1 : 0;
 }
 
-extern "C" int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const float* ba, const void* wb,
-                                         const float* bb, const void* wc, const float* bc, int batch, int t, int h, int w,
-                                         int c, int tchunk, void* stream) {
-  AVT_REQUIRE(x && out && wa && ba && wb && bb && wc && bc, "avt_bottleneck_fused_bf16: NULL pointer");
-  AVT_REQUIRE(batch > 0 && t > 0 && h > 0 && tchunk > 0, "avt_bottleneck_fused_bf16: bad sizes");
-  AVT_REQUIRE(avt_bottleneck_fused_supported(c, w),
-              "avt_bottleneck_fused_bf16: unsupported shape C=%d W=%d (fast-pathway identity blocks: 32x56, 64x28, 128x14)", c, w);
-  AVT_REQUIRE(x != out, "avt_bottleneck_fused_bf16: in-place is not supported (neighbouring strips read x)");
+static int run_bottleneck(const char* what, const void* x, void* out, const void* wa, const float* ba, const void* wb,
+                          const float* bb, const void* wc, const void* wsc, const float* bc, int batch, int t, int h, int w,
+                          int cin, int c, int tchunk, void* stream) {
+  AVT_REQUIRE(x && out && wa && ba && wb && bb && wc && bc && (cin == c || wsc), "%s: NULL pointer", what);
+  AVT_REQUIRE(batch > 0 && t > 0 && h > 0 && tchunk > 0, "%s: bad sizes", what);
+  AVT_REQUIRE(x != out, "%s: in-place is not supported (neighbouring strips read x)", what);
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(out) && avt::aligned16(wa) && avt::aligned16(wb) && avt::aligned16(wc) &&
-                  avt::aligned16(ba) && avt::aligned16(bb) && avt::aligned16(bc),
-              "avt_bottleneck_fused_bf16: pointers must be 16-byte aligned");
-  const int64_t xb = (int64_t)batch * t * h * w * c * 2;
-  AVT_REQUIRE(xb < (1ll << 32) - 64, "avt_bottleneck_fused_bf16: tensor too large for 32-bit offsets");
+                  avt::aligned16(ba) && avt::aligned16(bb) && avt::aligned16(bc) && (!wsc || avt::aligned16(wsc)),
+              "%s: pointers must be 16-byte aligned", what);
+  const int64_t xb = (int64_t)batch * t * h * w * cin * 2, ob = (int64_t)batch * t * h * w * c * 2;
+  AVT_REQUIRE(xb < (1ll << 32) - 64 && ob < (1ll << 33), "%s: tensor too large for 32-bit offsets", what);
   BArgs a;
   a.x = static_cast<const uint16_t*>(x);
   a.out = static_cast<uint16_t*>(out);
   a.wa = static_cast<const i32x4*>(wa);
   a.wb = static_cast<const i32x4*>(wb);
   a.wc = static_cast<const i32x4*>(wc);
+  a.wsc = static_cast<const i32x4*>(wsc);
   a.ba = ba;
   a.bb = bb;
   a.bc = bc;
@@ -349,10 +373,35 @@ extern "C" int avt_bottleneck_fused_bf16(const void* x, void* out, const void* w
   a.tchunks = (t + a.TC - 1) / a.TC;
   a.x_bytes = (unsigned)xb;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (cin != c) {
+    if (w == 56) return launch<32, 56, 8, 16, 8>(a, batch, h, s);
+    return launch<32, 12, 5, 16, 8>(a, batch, h, s);
+  }
   if (c == 32 && w == 56) return launch<32, 56, 8, 16>(a, batch, h, s);
   if (c == 64 && w == 28) return launch<64, 28, 7, 16>(a, batch, h, s);
   if (c == 128 && w == 14) return launch<128, 14, 7, 32>(a, batch, h, s);
   if (c == 32 && w == 12) return launch<32, 12, 5, 16>(a, batch, h, s);  // small shapes for the tests: ragged strips,
   if (c == 64 && w == 10) return launch<64, 10, 4, 16>(a, batch, h, s);  // partial tiles, partial DMA instructions
   return launch<128, 6, 3, 32>(a, batch, h, s);
+}
+
+extern "C" int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const float* ba, const void* wb,
+                                         const float* bb, const void* wc, const float* bc, int batch, int t, int h, int w,
+                                         int c, int tchunk, void* stream) {
+  AVT_REQUIRE(avt_bottleneck_fused_supported(c, w),
+              "avt_bottleneck_fused_bf16: unsupported shape C=%d W=%d (fast-pathway identity blocks: 32x56, 64x28, 128x14)", c, w);
+  return run_bottleneck("avt_bottleneck_fused_bf16", x, out, wa, ba, wb, bb, wc, nullptr, bc, batch, t, h, w, c, c, tchunk,
+                        stream);
+}
+
+extern "C" int avt_bottleneck_first_supported(int cin, int c, int w) { return (cin == 8 && c == 32 && (w == 56 || w == 12)) ? 1 : 0; }
+
+extern "C" int avt_bottleneck_first_bf16(const void* x, void* out, const void* wa, const float* ba, const void* wb,
+                                         const float* bb, const void* wc, const void* wsc, const float* bc, int batch, int t,
+                                         int h, int w, int cin, int c, int tchunk, void* stream) {
+  AVT_REQUIRE(avt_bottleneck_first_supported(cin, c, w),
+              "avt_bottleneck_first_bf16: unsupported shape Cin=%d C=%d W=%d (first fast-pathway block of res2: 8 -> 32, W 56)",
+              cin, c, w);
+  return run_bottleneck("avt_bottleneck_first_bf16", x, out, wa, ba, wb, bb, wc, wsc, bc, batch, t, h, w, cin, c, tchunk,
+                        stream);
 }

@@ -230,25 +230,32 @@ def stem_conv(stem, device, tgroup=1):
     return conv
 
 
-def pack_bottleneck(wa, ba, wb, bb, wc, bc, device):
+def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):
     """BN-folded weights of a [3,1,1] -> [1,3,3] -> [1,1,1] bottleneck (wa [Cm,C,3,1,1], wb [Cm,Cm,1,3,3], wc [C,Cm,1,1,1])
     -> the MFMA-fragment order of csrc/bottleneck_fused.hip (include/avt.h); the bottleneck width is zero-padded to
     CMP = 16 (Cm <= 16; b's taps packed in pairs) or 32 (Cm = 32; one tap per MFMA k-step)."""
     wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]  # packing is host work
-    cm, c = wa.shape[0], wa.shape[1]
+    cm, c = wa.shape[0], wc.shape[0]
     cmp_ = 16 if cm <= 16 else 32
+    first = shortcut is not None  # res2's first block: 8 input channels, 1x1x1 shortcut conv (see include/avt.h)
     nta = cmp_ // 16
     lane = torch.arange(64)
     n, q = lane & 15, lane >> 4
     e = torch.arange(8)
     L, E = n.numel(), e.numel()
-    wa_p = torch.zeros((cmp_, c, 3))
-    wa_p[:cm] = wa[:, :, :, 0, 0]
-    ka = c // 32
-    # wa fragments [3 dt][ka][nta][64][8]: row nt*16 + n, k = 32*k + 8*q + e
-    k_idx = (torch.arange(ka).view(-1, 1, 1, 1) * 32 + q.view(1, 1, -1, 1) * 8 + e.view(1, 1, 1, -1)).expand(ka, nta, L, E)
-    r_idx = (torch.arange(nta).view(1, -1, 1, 1) * 16 + n.view(1, 1, -1, 1)).expand(ka, nta, L, E)
-    wa_f = torch.stack([wa_p[r_idx, k_idx, dt] for dt in range(3)])
+    if first:
+        # one k-step holds the three frame taps: k-group q = dt (q = 3: zeros), 8 channels each
+        wa_p = torch.zeros((cmp_, 8, 4))
+        wa_p[:cm, :, :3] = wa[:, :, :, 0, 0]
+        wa_f = wa_p[n.view(-1, 1).expand(L, E), e.view(1, -1).expand(L, E), q.view(-1, 1).expand(L, E)].view(1, 1, 1, L, E)
+    else:
+        wa_p = torch.zeros((cmp_, c, 3))
+        wa_p[:cm] = wa[:, :, :, 0, 0]
+        ka = c // 32
+        # wa fragments [3 dt][ka][nta][64][8]: row nt*16 + n, k = 32*k + 8*q + e
+        k_idx = (torch.arange(ka).view(-1, 1, 1, 1) * 32 + q.view(1, 1, -1, 1) * 8 + e.view(1, 1, 1, -1)).expand(ka, nta, L, E)
+        r_idx = (torch.arange(nta).view(1, -1, 1, 1) * 16 + n.view(1, 1, -1, 1)).expand(ka, nta, L, E)
+        wa_f = torch.stack([wa_p[r_idx, k_idx, dt] for dt in range(3)])
     # wb fragments [nb][nta][64][8]
     wb_p = torch.zeros((cmp_, cmp_, 10))  # [n, ch, tap]; tap 9 = zeros
     wb_p[:cm, :cm, :9] = wb[:, :, 0].reshape(cm, cm, 9)
@@ -271,8 +278,14 @@ def pack_bottleneck(wa, ba, wb, bb, wc, bc, device):
     wc_f = wc_p[chan, kk]
     padw = lambda v: torch.cat([v.float(), torch.zeros(cmp_ - v.numel())])
     dev = lambda v, dt: v.to(dt).contiguous().to(device)
-    return (dev(wa_f, torch.bfloat16), dev(padw(ba), torch.float32), dev(wb_f, torch.bfloat16), dev(padw(bb), torch.float32),
-            dev(wc_f, torch.bfloat16), dev(bc.float(), torch.float32))
+    out = (dev(wa_f, torch.bfloat16), dev(padw(ba), torch.float32), dev(wb_f, torch.bfloat16), dev(padw(bb), torch.float32),
+           dev(wc_f, torch.bfloat16))
+    if not first:
+        return out + (dev(bc.float(), torch.float32),)
+    wsc, bsc = [v.detach().float().cpu() for v in shortcut]  # [C, 8, 1, 1, 1], [C]
+    ws_p = torch.zeros((c, 32))
+    ws_p[:, :8] = wsc[:, :, 0, 0, 0]  # k-group 0 = the 8 input channels
+    return out + (dev((bc + bsc).float(), torch.float32), dev(ws_p[chan, kk], torch.bfloat16))
 
 
 class _Block:
@@ -290,6 +303,13 @@ class _Block:
                 self.a.cout <= 32 and self.c.cout == self.a.cin and self.c.cout in (32, 64, 128)):
             (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
             self.fused = pack_bottleneck(wa, ba, wb, bb, wc, bc, device)
+        # ... and res2's first fast block (8 -> 32 channels, 1x1x1 shortcut conv, stride 1)
+        self.fused_first = None
+        if (_FUSE_BLOCK and self.b1 is not None and self.a.kernel == (3, 1, 1) and self.b.kernel == (1, 3, 3) and
+                self.c.kernel == (1, 1, 1) and self.b.stride == (1, 1, 1) and self.b1.stride == (1, 1, 1) and
+                self.a.cin == 8 and self.a.cout <= 16 and self.c.cout == 32 and self.b1.kernel == (1, 1, 1)):
+            (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
+            self.fused_first = pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=self.b1._folded)
 
     def __call__(self, x, out=None):
         if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
@@ -306,6 +326,22 @@ class _Block:
                 m = b * t * h * w
                 fl = m * (self.a.alg_flops_per_row + self.b.alg_flops_per_row + self.c.alg_flops_per_row)
                 PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * (2 * m * x.C))
+            return y
+        if (self.fused_first is not None and out is None and x.c0 == 0 and x.ld == x.C and
+                ops.bottleneck_first_supported(x.C, self.c.cout, x.dims[3])):
+            b, t, h, w = x.dims
+            y = Act(torch.empty((b * t * h * w, self.c.cout), dtype=torch.bfloat16, device=self.dev), x.dims)
+
+            def launch():
+                ops.bottleneck_first(x.ptr, y.ptr, self.fused_first, b, t, h, w, x.C, self.c.cout, tchunk=_FUSE_TCHUNK)
+
+            if PROFILER is None:
+                launch()
+            else:
+                m = b * t * h * w
+                fl = m * (self.a.alg_flops_per_row + self.b.alg_flops_per_row + self.c.alg_flops_per_row +
+                          self.b1.alg_flops_per_row)
+                PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * m * (x.C + self.c.cout))
             return y
         sc = self.b1(x) if self.b1 is not None else x
         return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)

@@ -266,6 +266,19 @@ def mean_positions(x_ptr, batch, p, c, ldi, out, col0=0):
                "avt_mean_positions_bf16")
 
 
+def bottleneck_first_supported(cin, c, w):
+    return bool(_lib.lib().avt_bottleneck_first_supported(int(cin), int(c), int(w)))
+
+
+def bottleneck_first(x_ptr, out_ptr, packed, batch, t, h, w, cin, c, tchunk=8):
+    """First fast-pathway block of res2 (8 -> 32 channels, shortcut conv) in one kernel; packed =
+    fused_slowfast.pack_bottleneck(..., shortcut=(wsc, bsc)) = (wa, ba, wb, bb, wc, bc, wsc)."""
+    wa, ba, wb, bb, wc, bc, wsc = packed
+    _lib.check(_lib.lib().avt_bottleneck_first_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), _p(wa), _p(ba), _p(wb), _p(bb),
+                                                    _p(wc), _p(wsc), _p(bc), int(batch), int(t), int(h), int(w), int(cin),
+                                                    int(c), int(tchunk), _stream()), "avt_bottleneck_first_bf16")
+
+
 def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
     """MaxPool2d(2, 2), floor mode, on NHWC bf16 rows (raw device addresses) — VGGish (audio_models/vggish.py:15-33)."""
     _lib.check(_lib.lib().avt_maxpool_hw2s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),

@@ -268,6 +268,16 @@ int avt_stem_conv_pool_bf16(const void* in, const void* wt, const float* bias, v
  * tchunk = frames walked per workgroup (each re-reads one halo frame on either side).
  * avt_bottleneck_fused_supported(c, w): (32, 56), (64, 28), (128, 14) = the res2 / res3 / res4 blocks at 224^2 clips. */
 int avt_bottleneck_fused_supported(int c, int w);
+/* First block of the fast pathway's res2 stage (Cin = 8 -> C = 32, stride 1, 1x1x1 shortcut conv + BN instead of the
+ * identity): out = relu(c(relu(b(relu(a(x))))) + shortcut(x)).  Same kernel; differences in the packing:
+ *   wa [1][1][64][8]: k-group q = frame tap dt (q = 3: zeros), Wa[n][dt = q][e]  (all three taps in one MFMA k-step)
+ *   wsc [c/16][64][8]: shortcut weights in c's row order, k-group 0 = the 8 input channels, others zero
+ *   bc = c's bias + the shortcut's bias.  x [batch, t, h, w, 8] bf16. */
+int avt_bottleneck_first_supported(int cin, int c, int w);
+int avt_bottleneck_first_bf16(const void* x, void* out, const void* wa, const float* ba,
+                              const void* wb, const float* bb, const void* wc, const void* wsc,
+                              const float* bc, int batch, int t, int h, int w, int cin, int c,
+                              int tchunk, void* stream);
 int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const float* ba,
                               const void* wb, const float* bb, const void* wc, const float* bc,
                               int batch, int t, int h, int w, int c, int tchunk, void* stream);

@@ -45,6 +45,11 @@ def spy_bn(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk=8):
     shapes.append("fused bottleneck C%d in(%d, %d, %d, %d) tchunk %d" % (c, batch, t, h, w, tchunk))
     return orig_bn(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk)
 avtex.ops.bottleneck_fused = spy_bn
+orig_bf = avtex.ops.bottleneck_first
+def spy_bf(x_ptr, out_ptr, packed, batch, t, h, w, cin, c, tchunk=8):
+    shapes.append("fused first block %d->%d in(%d, %d, %d, %d) tchunk %d" % (cin, c, batch, t, h, w, tchunk))
+    return orig_bf(x_ptr, out_ptr, packed, batch, t, h, w, cin, c, tchunk)
+avtex.ops.bottleneck_first = spy_bf
 avtex.ops.conv3d_igemm = spy
 fsf.ops.conv3d_igemm = spy
 fsf.PROFILER = hook
