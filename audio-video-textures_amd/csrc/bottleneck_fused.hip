@@ -52,10 +52,15 @@ constexpr int NW = 8;  // waves per workgroup (2 per SIMD: the stages are latenc
 // a / b weight fragments live in LDS, one tap per MFMA k-step)
 // CIN = input channels: C (identity shortcut: out = relu(c(..) + x)) or 8 (first block of res2: x has 8 channels, the
 // three frame taps of a are ONE MFMA k-step, and the shortcut is a 1x1x1 conv of x accumulated into c's MFMA tile)
-template <int C, int W, int HT, int CMP, int CIN = C>
+// ST = 2: first block of res3 / res4 (CIN = C/2 >= 32): b has spatial stride 2 (the strip walks OUTPUT rows, a is
+// computed on the 2*HT+1 input rows they touch) and the 1x1x1 shortcut samples x at the even positions.
+template <int C, int W, int HT, int CMP, int CIN = C, int ST = 1>
 __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
-  constexpr bool FIRST = CIN != C;
-  constexpr int RX = HT + 2;            // x / a-output rows of a strip
+  constexpr bool SC = CIN != C;   // shortcut conv instead of the identity
+  constexpr bool FIRST = CIN == 8;  // ... with all three frame taps of a in one MFMA k-step
+  constexpr int WO = W / ST;        // output row length
+  constexpr int KS = FIRST ? 1 : CIN / 32;  // k-steps of the shortcut conv
+  constexpr int RX = ST * HT + (ST == 1 ? 2 : 1);  // x / a-output rows of a strip (input rows its outputs touch)
   constexpr int PX = RX * W;            // positions of the x strip
   constexpr int REC = CIN * 2;          // bytes per x position
   constexpr int CH = CIN / 8;           // 16-byte chunks per x position
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   constexpr int AW = W + 2;             // a-output row length (zero border columns)
   constexpr int APOS = RX * AW;
   constexpr int MTA = (PX + 15) / 16;   // a-stage M-tiles
-  constexpr int PB = HT * W;            // b / c positions
+  constexpr int PB = HT * WO;           // b / c positions
   constexpr int MTB = (PB + 15) / 16;
   constexpr int AREC = CMP * 2;         // bytes per position of the a / b strips
   constexpr int NTA = CMP / 16;         // N-tiles of a and b
@@ -73,13 +78,14 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   constexpr bool WLDS = CMP > 16;
   constexpr int ABYTES = (APOS + 32) * AREC;  // a strip + room for the last partial tile's stores
   constexpr int BBYTES = MTB * 16 * AREC;
-  constexpr int KA = FIRST ? 1 : C / 32;  // k-steps per frame tap of a (FIRST: one k-step holds all three taps)
+  constexpr int KA = FIRST ? 1 : CIN / 32;  // k-steps per frame tap of a (FIRST: one k-step holds all three taps)
   constexpr int NFA = (FIRST ? 1 : 3) * KA * NTA, NFB = NB * NTA;  // weight fragments of a and b
   constexpr int NTC = C / 16;           // N-tiles of c
   constexpr int CIT = (MTB + NW - 1) / NW;   // c-stage tiles per wave
   constexpr int NST = CIT * (NTC / 2);       // ... = output store instructions per wave per frame
   static_assert(CH == 1 || CH == 4 || CH == 8 || CH == 16, "x records of 16 / 64 / 128 / 256 bytes");
-  static_assert(!FIRST || (CIN == 8 && CMP == 16), "first-block form: 8 input channels, width <= 16");
+  static_assert(!FIRST || CMP == 16, "8-channel first-block form: width <= 16");
+  static_assert(ST == 1 || (SC && !FIRST && W % 2 == 0), "strided form: first block with a shortcut conv");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* xr = lds;                       // [3][XFRAME]
   char* ao = lds + 3 * XFRAME;          // [APOS (+pad)][CMP channels]
@@ -93,11 +99,12 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   const int tch = bid % a.tchunks;
   bid /= a.tchunks;
   const int strip = bid % a.strips, b = bid / a.strips;
-  const int h0 = strip * HT, t0 = tch * a.TC;
+  const int h0 = strip * HT, t0 = tch * a.TC;  // h0: first OUTPUT row of the strip
+  const int hin0 = ST * h0 - 1;                // ... and the input row of x-strip row 0
   const int t1 = (t0 + a.TC < a.T) ? t0 + a.TC : a.T;
 
   // ---- weights: MFMA fragments in registers (or, for the wide form, a's and b's in LDS)
-  bf16x8 wa_r[WLDS ? 1 : NFA], wb_r[WLDS ? 1 : NFB], wc[NTC], wsc[FIRST ? NTC : 1];
+  bf16x8 wa_r[WLDS ? 1 : NFA], wb_r[WLDS ? 1 : NFB], wc[NTC], wsc[SC ? NTC * KS : 1];
   if constexpr (WLDS) {
     for (int f = wid; f < NFA + NFB; f += NW)
       *reinterpret_cast<i32x4*>(wl + f * 1024 + lane * 16) = f < NFA ? a.wa[f * 64 + lane] : a.wb[(f - NFA) * 64 + lane];
@@ -119,9 +126,9 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   };
 #pragma unroll
   for (int n = 0; n < NTC; ++n) wc[n] = __builtin_bit_cast(bf16x8, a.wc[n * 64 + lane]);
-  if constexpr (FIRST) {
+  if constexpr (SC) {
 #pragma unroll
-    for (int n = 0; n < NTC; ++n) wsc[n] = __builtin_bit_cast(bf16x8, a.wsc[n * 64 + lane]);
+    for (int n = 0; n < NTC * KS; ++n) wsc[n] = __builtin_bit_cast(bf16x8, a.wsc[n * 64 + lane]);
   }
   float4 bav[NTA], bbv[NTA];
 #pragma unroll
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     const int p = d * PPI + lane / CH, slot = lane % CH;
     const int r = p / W, w = p - r * W;
     const int chunk = slot ^ swz(p);
-    const int h = h0 - 1 + r;
+    const int h = hin0 + r;
     const bool ok = d < NDMA && p < PX && (unsigned)h < (unsigned)a.H;
     poff[u] = ok ? (unsigned)(((h * W + w) * CIN + chunk * 8) * 2) : kOob;
   }
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     for (int k = 0; k < KA; ++k) a_rd[it][k] = FIRST ? pc * REC : xoff(pc, k * 4 + q);
     const int r = p / W, w = p - r * W;
     a_st[it] = (p < PX ? r * AW + w + 1 : APOS + (p - PX)) * AREC + q * 8;
-    a_in |= ((unsigned)(h0 - 1 + r) < (unsigned)a.H ? 1u : 0u) << it;
+    a_in |= ((unsigned)(hin0 + r) < (unsigned)a.H ? 1u : 0u) << it;
   }
   int tapoff[NB];  // b: byte offset of this lane's operand chunk for k-step j, relative to tap (0,0) of its position
 #pragma unroll
@@ -198,20 +205,26 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     }
   }
   const int cchunk = (CMP == 16 ? (q & 1) : q) * 16;  // c: this lane's k-group inside a b-strip record
-  int b_rd[CIT], c_res[CIT][NTC / 2], c_out[CIT];
+  int b_rd[CIT], c_res[CIT][SC ? KS : NTC / 2], c_out[CIT];
   unsigned c_ok = 0;
+  const int Ho = a.H / ST;
 #pragma unroll
   for (int it = 0; it < CIT; ++it) {
     const int mt = wid + NW * it;
     const int p = mt * 16 + l15;
     const int pc = p < PB ? p : PB - 1;
-    const int r = pc / W, w = pc - r * W;
-    b_rd[it] = (r * AW + w) * AREC;  // tap (0,0) of this position in the a strip
+    const int r = pc / WO, w = pc - r * WO;
+    b_rd[it] = (ST * r * AW + ST * w) * AREC;  // tap (0,0) of this output position in the a strip
+    const int px = (ST * r + 1) * W + ST * w;   // x-strip position of the output's centre tap (residual / shortcut operand)
+    if constexpr (SC) {
 #pragma unroll
-    for (int np = 0; np < NTC / 2; ++np)  // residual chunk of x(t) — FIRST: the position's one 8-channel record (shortcut operand)
-      c_res[it][np] = FIRST ? ((r + 1) * W + w) * REC : xoff((r + 1) * W + w, (32 * np + 8 * q) / 8);
-    c_out[it] = ((h0 + r) * W + w) * C + 8 * q;
-    c_ok |= ((mt < MTB && p < PB && h0 + r < a.H) ? 1u : 0u) << it;
+      for (int k = 0; k < KS; ++k) c_res[it][k] = FIRST ? px * REC : xoff(px, k * 4 + q);
+    } else {
+#pragma unroll
+      for (int np = 0; np < NTC / 2; ++np) c_res[it][np] = xoff(px, (32 * np + 8 * q) / 8);
+    }
+    c_out[it] = ((h0 + r) * WO + w) * C + 8 * q;
+    c_ok |= ((mt < MTB && p < PB && h0 + r < Ho) ? 1u : 0u) << it;
   }
 
   dma_frame(t0 - 1);
@@ -290,24 +303,32 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
     }
     __syncthreads();  // b strip complete
     // ---- [c] pointwise conv + bias + residual (x of frame t, from the ring) -> relu -> global
-    uint16_t* oframe = a.out + (int64_t)((b * a.T + t) * a.H) * (W * C);
+    uint16_t* oframe = a.out + (int64_t)((b * a.T + t) * Ho) * (WO * C);
 #pragma unroll
     for (int it = 0; it < CIT; ++it) {  // the same trip count in every wave: the stores are counted by s_waitcnt
       const int mt = wid + NW * it;
       const int pr = (mt < MTB ? mt : MTB - 1) * 16 + l15;
       const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bo + pr * AREC + cchunk);  // CMP = 16: k >= 16 has zero weights
+      bf16x8 xs[SC ? KS : 1];  // shortcut conv operand: x(t) at the output's centre tap
+      if constexpr (SC) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) xs[k] = *reinterpret_cast<const bf16x8*>(x0_ + c_res[it][k]);
+      }
 #pragma unroll
       for (int np = 0; np < NTC / 2; ++np) {
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
         c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2 * np], bf, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2 * np + 1], bf, c1, 0, 0, 0);
         const float4 b0 = bcv[np][0], b1 = bcv[np][1];
-        uint4 rs = *reinterpret_cast<const uint4*>(x0_ + c_res[it][np]);
-        if constexpr (FIRST) {  // shortcut = 1x1x1 conv of x(t) into the same tile (k-group 0 carries its 8 channels)
-          const bf16x8 xs = __builtin_bit_cast(bf16x8, rs);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsc[2 * np], xs, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsc[2 * np + 1], xs, c1, 0, 0, 0);
-          rs = make_uint4(0u, 0u, 0u, 0u);  // no identity term; bc already holds bc + b_shortcut
+        uint4 rs = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (SC) {  // shortcut = 1x1x1 conv of x(t) accumulated into the same tile; bc holds bc + b_shortcut
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsc[(2 * np) * KS + k], xs[k], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsc[(2 * np + 1) * KS + k], xs[k], c1, 0, 0, 0);
+          }
+        } else {
+          rs = *reinterpret_cast<const uint4*>(x0_ + c_res[it][np]);  // identity: the residual from the staged x
         }
         uint4 o;
         o.x = avt::pack_bf16x2(fmaxf(c0[0] + b0.x + avt::bf16x2_lo(rs.x), 0.f), fmaxf(c0[1] + b0.y + avt::bf16x2_hi(rs.x), 0.f));
@@ -320,22 +341,21 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   }
 }
 
-template <int C, int W, int HT, int CMP, int CIN = C>
+template <int C, int W, int HT, int CMP, int CIN = C, int ST = 1>
 int launch(BArgs& a, int batch, int h, hipStream_t st) {
-  constexpr int RX = HT + 2, PX = RX * W, PPI = 1024 / (CIN * 2), NDMA = (PX + PPI - 1) / PPI;
-  constexpr int MTB = (HT * W + 15) / 16, AW = W + 2, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
-  constexpr int wfrags = CMP > 16 ? (3 * (C / 32) * NTA + NB * NTA) : 0;
-  static_assert(CIN == C || CMP == 16, "first-block form keeps its weights in registers");
+  constexpr int RX = ST * HT + (ST == 1 ? 2 : 1), PX = RX * W, PPI = 1024 / (CIN * 2), NDMA = (PX + PPI - 1) / PPI;
+  constexpr int MTB = (HT * (W / ST) + 15) / 16, AW = W + 2, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
+  constexpr int wfrags = CMP > 16 ? (3 * (CIN / 32) * NTA + NB * NTA) : 0;
   constexpr int lds_bytes = 3 * NDMA * 1024 + (RX * AW + 32) * CMP * 2 + MTB * 16 * CMP * 2 + wfrags * 1024;
   static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
-  a.strips = (h + HT - 1) / HT;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP, CIN>),
+  a.strips = (h / ST + HT - 1) / HT;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP, CIN, ST>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_bottleneck_fused_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT, CMP, CIN>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
+  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT, CMP, CIN, ST>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
                      lds_bytes, st, a);
   return avt::check_launch("avt_bottleneck_fused_bf16");
 }
@@ -373,9 +393,15 @@ static int run_bottleneck(const char* what, const void* x, void* out, const void
   a.tchunks = (t + a.TC - 1) / a.TC;
   a.x_bytes = (unsigned)xb;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (cin != c) {
+  if (cin == 8) {
     if (w == 56) return launch<32, 56, 8, 16, 8>(a, batch, h, s);
     return launch<32, 12, 5, 16, 8>(a, batch, h, s);
+  }
+  if (cin != c) {  // strided first blocks (w = input width)
+    if (c == 64 && w == 56) return launch<64, 56, 4, 16, 32, 2>(a, batch, h, s);
+    if (c == 128 && w == 28) return launch<128, 28, 4, 32, 64, 2>(a, batch, h, s);
+    if (c == 64 && w == 12) return launch<64, 12, 3, 16, 32, 2>(a, batch, h, s);
+    return launch<128, 8, 2, 32, 64, 2>(a, batch, h, s);
   }
   if (c == 32 && w == 56) return launch<32, 56, 8, 16>(a, batch, h, s);
   if (c == 64 && w == 28) return launch<64, 28, 7, 16>(a, batch, h, s);
@@ -394,13 +420,16 @@ extern "C" int avt_bottleneck_fused_bf16(const void* x, void* out, const void* w
                         stream);
 }
 
-extern "C" int avt_bottleneck_first_supported(int cin, int c, int w) { return (cin == 8 && c == 32 && (w == 56 || w == 12)) ? 1 : 0; }
+extern "C" int avt_bottleneck_first_supported(int cin, int c, int w) {
+  return ((cin == 8 && c == 32 && (w == 56 || w == 12)) || (cin == 32 && c == 64 && (w == 56 || w == 12)) ||
+          (cin == 64 && c == 128 && (w == 28 || w == 8))) ? 1 : 0;
+}
 
 extern "C" int avt_bottleneck_first_bf16(const void* x, void* out, const void* wa, const float* ba, const void* wb,
                                          const float* bb, const void* wc, const void* wsc, const float* bc, int batch, int t,
                                          int h, int w, int cin, int c, int tchunk, void* stream) {
   AVT_REQUIRE(avt_bottleneck_first_supported(cin, c, w),
-              "avt_bottleneck_first_bf16: unsupported shape Cin=%d C=%d W=%d (first fast-pathway block of res2: 8 -> 32, W 56)",
+              "avt_bottleneck_first_bf16: unsupported shape Cin=%d C=%d W=%d (first fast-pathway blocks: 8->32 W 56; strided 32->64 W 56, 64->128 W 28)",
               cin, c, w);
   return run_bottleneck("avt_bottleneck_first_bf16", x, out, wa, ba, wb, bb, wc, wsc, bc, batch, t, h, w, cin, c, tchunk,
                         stream);

@@ -235,9 +235,9 @@ def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):
     -> the MFMA-fragment order of csrc/bottleneck_fused.hip (include/avt.h); the bottleneck width is zero-padded to
     CMP = 16 (Cm <= 16; b's taps packed in pairs) or 32 (Cm = 32; one tap per MFMA k-step)."""
     wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]  # packing is host work
-    cm, c = wa.shape[0], wc.shape[0]
+    cm, c, cin = wa.shape[0], wc.shape[0], wa.shape[1]
     cmp_ = 16 if cm <= 16 else 32
-    first = shortcut is not None  # res2's first block: 8 input channels, 1x1x1 shortcut conv (see include/avt.h)
+    first = cin == 8  # res2's first block: 8 input channels, the three frame taps share one k-step (see include/avt.h)
     nta = cmp_ // 16
     lane = torch.arange(64)
     n, q = lane & 15, lane >> 4
@@ -249,9 +249,9 @@ def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):
         wa_p[:cm, :, :3] = wa[:, :, :, 0, 0]
         wa_f = wa_p[n.view(-1, 1).expand(L, E), e.view(1, -1).expand(L, E), q.view(-1, 1).expand(L, E)].view(1, 1, 1, L, E)
     else:
-        wa_p = torch.zeros((cmp_, c, 3))
+        wa_p = torch.zeros((cmp_, cin, 3))
         wa_p[:cm] = wa[:, :, :, 0, 0]
-        ka = c // 32
+        ka = cin // 32
         # wa fragments [3 dt][ka][nta][64][8]: row nt*16 + n, k = 32*k + 8*q + e
         k_idx = (torch.arange(ka).view(-1, 1, 1, 1) * 32 + q.view(1, 1, -1, 1) * 8 + e.view(1, 1, 1, -1)).expand(ka, nta, L, E)
         r_idx = (torch.arange(nta).view(1, -1, 1, 1) * 16 + n.view(1, 1, -1, 1)).expand(ka, nta, L, E)
@@ -280,12 +280,16 @@ def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):
     dev = lambda v, dt: v.to(dt).contiguous().to(device)
     out = (dev(wa_f, torch.bfloat16), dev(padw(ba), torch.float32), dev(wb_f, torch.bfloat16), dev(padw(bb), torch.float32),
            dev(wc_f, torch.bfloat16))
-    if not first:
+    if shortcut is None:
         return out + (dev(bc.float(), torch.float32),)
-    wsc, bsc = [v.detach().float().cpu() for v in shortcut]  # [C, 8, 1, 1, 1], [C]
-    ws_p = torch.zeros((c, 32))
-    ws_p[:, :8] = wsc[:, :, 0, 0, 0]  # k-group 0 = the 8 input channels
-    return out + (dev((bc + bsc).float(), torch.float32), dev(ws_p[chan, kk], torch.bfloat16))
+    # shortcut conv fragments [c/16][ks][64][8] in c's row order, k = 32*ks + 8*q + e over the input channels
+    wsc, bsc = [v.detach().float().cpu() for v in shortcut]  # [C, Cin, 1, 1, 1], [C]
+    ks = max(cin // 32, 1)
+    ws_p = torch.zeros((c, ks * 32))
+    ws_p[:, :cin] = wsc[:, :, 0, 0, 0]
+    chan4 = chan.view(c // 16, 1, L, E).expand(c // 16, ks, L, E)
+    kk4 = (torch.arange(ks).view(1, -1, 1, 1) * 32 + kk.view(c // 16, 1, L, E)).expand(c // 16, ks, L, E)
+    return out + (dev((bc + bsc).float(), torch.float32), dev(ws_p[chan4, kk4], torch.bfloat16))
 
 
 class _Block:
@@ -303,11 +307,14 @@ class _Block:
                 self.a.cout <= 32 and self.c.cout == self.a.cin and self.c.cout in (32, 64, 128)):
             (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
             self.fused = pack_bottleneck(wa, ba, wb, bb, wc, bc, device)
-        # ... and res2's first fast block (8 -> 32 channels, 1x1x1 shortcut conv, stride 1)
+        # ... and the first fast blocks with a 1x1x1 shortcut conv: res2 (8 -> 32, stride 1), res3 / res4 (32 -> 64,
+        # 64 -> 128: b and the shortcut have spatial stride 2)
         self.fused_first = None
+        first8 = self.a.cin == 8 and self.c.cout == 32 and self.b.stride == (1, 1, 1)
+        strided = self.a.cin in (32, 64) and self.c.cout == 2 * self.a.cin and self.b.stride == (1, 2, 2)
         if (_FUSE_BLOCK and self.b1 is not None and self.a.kernel == (3, 1, 1) and self.b.kernel == (1, 3, 3) and
-                self.c.kernel == (1, 1, 1) and self.b.stride == (1, 1, 1) and self.b1.stride == (1, 1, 1) and
-                self.a.cin == 8 and self.a.cout <= 16 and self.c.cout == 32 and self.b1.kernel == (1, 1, 1)):
+                self.c.kernel == (1, 1, 1) and self.a.stride == (1, 1, 1) and self.b1.stride == self.b.stride and
+                (first8 or strided) and self.a.cout <= 32 and self.b1.kernel == (1, 1, 1)):
             (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
             self.fused_first = pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=self.b1._folded)
 
@@ -328,9 +335,12 @@ class _Block:
                 PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * (2 * m * x.C))
             return y
         if (self.fused_first is not None and out is None and x.c0 == 0 and x.ld == x.C and
-                ops.bottleneck_first_supported(x.C, self.c.cout, x.dims[3])):
+                ops.bottleneck_first_supported(x.C, self.c.cout, x.dims[3]) and x.dims[2] % self.b.stride[1] == 0):
             b, t, h, w = x.dims
-            y = Act(torch.empty((b * t * h * w, self.c.cout), dtype=torch.bfloat16, device=self.dev), x.dims)
+            st = self.b.stride[1]
+            od = (b, t, h // st, w // st)
+            mo = od[0] * od[1] * od[2] * od[3]
+            y = Act(torch.empty((mo, self.c.cout), dtype=torch.bfloat16, device=self.dev), od)
 
             def launch():
                 ops.bottleneck_first(x.ptr, y.ptr, self.fused_first, b, t, h, w, x.C, self.c.cout, tchunk=_FUSE_TCHUNK)
@@ -339,9 +349,9 @@ class _Block:
                 launch()
             else:
                 m = b * t * h * w
-                fl = m * (self.a.alg_flops_per_row + self.b.alg_flops_per_row + self.c.alg_flops_per_row +
-                          self.b1.alg_flops_per_row)
-                PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * m * (x.C + self.c.cout))
+                fl = (m * self.a.alg_flops_per_row +
+                      mo * (self.b.alg_flops_per_row + self.c.alg_flops_per_row + self.b1.alg_flops_per_row))
+                PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * (m * x.C + mo * self.c.cout))
             return y
         sc = self.b1(x) if self.b1 is not None else x
         return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)

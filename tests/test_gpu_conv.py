@@ -326,14 +326,18 @@ def test_mean_positions_head_pool(avt, dev):
         assert (out[:, :8] == -1).all() and (out[:, 8 + c :] == -1).all() and torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("dims,tchunk", [((2, 7, 11, 12), 3), ((1, 4, 56, 56), 8)])
-def test_bottleneck_first_block_matches_module_and_unfused(avt, dev, dims, tchunk):
-    """The first fast-pathway block of res2 (8 -> 32 channels, 1x1x1 shortcut conv) through the fused kernel."""
+@pytest.mark.parametrize("cin,c,cm,stride,dims,tchunk", [
+    (8, 32, 8, 1, (2, 7, 11, 12), 3), (8, 32, 8, 1, (1, 4, 56, 56), 8),           # res2's first fast block
+    (32, 64, 16, 2, (2, 5, 10, 12), 2), (32, 64, 16, 2, (1, 3, 56, 56), 8),        # res3's: b and shortcut stride 2
+    (64, 128, 32, 2, (1, 4, 6, 8), 3), (64, 128, 32, 2, (1, 3, 28, 28), 8),        # res4's (wide form)
+])
+def test_bottleneck_first_block_matches_module_and_unfused(avt, dev, cin, c, cm, stride, dims, tchunk):
+    """The first fast-pathway blocks (1x1x1 shortcut conv; res3 / res4: spatial stride 2) through the fused kernel."""
     import avtex.fused_slowfast as fsf
     from avtex.slowfast import ResBlock
 
-    torch.manual_seed(dims[2])
-    blk = ResBlock(8, 32, 8, 3, 1).eval()
+    torch.manual_seed(dims[2] + cin)
+    blk = ResBlock(cin, c, cm, 3, stride).eval()
     with torch.no_grad():
         for mod in blk.modules():
             if isinstance(mod, nn.BatchNorm3d):
@@ -341,22 +345,24 @@ def test_bottleneck_first_block_matches_module_and_unfused(avt, dev, dims, tchun
                 mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.8, 1.2)
     assert hasattr(blk, "branch1")
     b, t, h, w = dims
-    x = torch.randn(b, 8, t, h, w).to(torch.bfloat16)
+    x = torch.randn(b, cin, t, h, w).to(torch.bfloat16)
     with torch.no_grad():
         ref = blk(x.float())
-    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, 8).contiguous().to(dev)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, cin).contiguous().to(dev)
     fb = fsf._Block(blk, dev)
     assert fb.fused_first is not None and fb.fused is None
     y = fb(fsf.Act(rows, dims))
     torch.cuda.synchronize()
-    got = y.buf.float().cpu().view(b, t, h, w, 32).permute(0, 4, 1, 2, 3)
+    ho, wo = h // stride, w // stride
+    assert y.dims == (b, t, ho, wo)
+    got = y.buf.float().cpu().view(b, t, ho, wo, c).permute(0, 4, 1, 2, 3)
     scale = max(ref.abs().max().item(), 1.0)
     assert (got - ref).abs().max().item() < 0.03 * scale
     keep, fb.fused_first = fb.fused_first, None
-    un = fb(fsf.Act(rows, dims)).buf.float().cpu().view(b, t, h, w, 32).permute(0, 4, 1, 2, 3)
+    un = fb(fsf.Act(rows, dims)).buf.float().cpu().view(b, t, ho, wo, c).permute(0, 4, 1, 2, 3)
     fb.fused_first = keep
     assert (got - un).abs().max().item() < 0.02 * scale and (got - un).abs().mean().item() < 1e-3 * scale
     y2 = torch.empty_like(y.buf)
-    avt.ops.bottleneck_first(rows.data_ptr(), y2.data_ptr(), fb.fused_first, b, t, h, w, 8, 32, tchunk=tchunk)
+    avt.ops.bottleneck_first(rows.data_ptr(), y2.data_ptr(), fb.fused_first, b, t, h, w, cin, c, tchunk=tchunk)
     torch.cuda.synchronize()
     assert torch.equal(y.buf, y2)  # independent of the frame chunking
