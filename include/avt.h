@@ -272,7 +272,10 @@ int avt_bottleneck_fused_supported(int c, int w);
  * identity): out = relu(c(relu(b(relu(a(x))))) + shortcut(x)).  Same kernel; differences in the packing:
  *   wa [1][1][64][8]: k-group q = frame tap dt (q = 3: zeros), Wa[n][dt = q][e]  (all three taps in one MFMA k-step)
  *   wsc [c/16][64][8]: shortcut weights in c's row order, k-group 0 = the 8 input channels, others zero
- *   bc = c's bias + the shortcut's bias.  x [batch, t, h, w, 8] bf16. */
+ *   bc = c's bias + the shortcut's bias.  x [batch, t, h, w, 8] bf16.
+ * Strided first blocks (res3: Cin 32 -> C 64 at w = 56; res4: 64 -> 128 at w = 28): b and the shortcut have spatial
+ * stride 2, out [batch, t, h/2, w/2, c]; wa as for the identity form over Cin, wsc [c/16][Cin/32][64][8] with
+ * k = 32*ks + 8*q + e over the input channels (h, w = INPUT extent, h even). */
 int avt_bottleneck_first_supported(int cin, int c, int w);
 int avt_bottleneck_first_bf16(const void* x, void* out, const void* wa, const float* ba,
                               const void* wb, const float* bb, const void* wc, const void* wsc,
