@@ -24,6 +24,7 @@ from ._lib import AvtError
 import os
 
 _FUSE_BLOCK = int(os.environ.get("AVT_FUSE_BLOCK", "1"))    # fast-pathway identity bottlenecks as one kernel
+_FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
 _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "8"))  # frames walked per workgroup
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 _STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "0"))  # fused pool: bit-identical but slower (probe_stem_pool_ab.log)
@@ -318,7 +319,23 @@ class _Block:
             (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
             self.fused_first = pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=self.b1._folded)
 
+        # first block of a stage with a stride-1 1x1x1 shortcut conv and pointwise a (slow res2): c and the shortcut are
+        # ONE GEMM over K = [x | b-output] when b writes its output into spare columns of x's row buffer — no shortcut
+        # launch, no residual read (self.extra = columns the caller must leave free behind x)
+        self.ccat, self.extra = None, 0
+        if (_FUSE_KCAT and self.b1 is not None and self.fused_first is None and self.a.kernel == (1, 1, 1) and
+                self.c.kernel == (1, 1, 1) and self.b1.kernel == (1, 1, 1) and self.a.stride == (1, 1, 1) and
+                self.b.stride == (1, 1, 1) and self.b1.stride == (1, 1, 1) and self.c.stride == (1, 1, 1)):
+            (wsc, bsc), (wc, bc) = self.b1._folded, self.c._folded
+            self.ccat = FusedConv(None, None, True, device,
+                                  folded=(torch.cat([wsc, wc], 1), bc + bsc, (1, 1, 1), (0, 0, 0)))
+            self.ccat.alg_flops_per_row = self.c.alg_flops_per_row + self.b1.alg_flops_per_row
+            self.extra = self.c.cin
+
     def __call__(self, x, out=None):
+        if self.ccat is not None and x.c0 == 0 and x.ld >= x.C + self.extra and x.C == self.a.cin:
+            self.b(self.a(x), out=Act(x.buf, x.dims, x.C, self.extra))  # b's output lands behind x in the same rows
+            return self.ccat(Act(x.buf, x.dims, 0, x.C + self.extra), out=out)
         if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
                 ops.bottleneck_fused_supported(x.C, x.dims[3])):
             b, t, h, w = x.dims
@@ -446,10 +463,11 @@ class SlowFastMFMA(nn.Module):
         hs, ws = (slow.shape[2] // 2 - 1) // 2 + 1, (slow.shape[3] // 2 - 1) // 2 + 1
         ds = (b, slow.shape[1], hs, ws)
         # the slow stem is pooled straight into the concat buffer of the first lateral fusion
-        sbuf = torch.empty((ds[0] * ds[1] * ds[2] * ds[3], cs + 2 * cf), dtype=torch.bfloat16, device=self.dev)
+        extra = self.stages[0][0][0].extra  # spare columns for the first slow block's K-concatenated c (see _Block)
+        sbuf = torch.empty((ds[0] * ds[1] * ds[2] * ds[3], cs + 2 * cf + extra), dtype=torch.bfloat16, device=self.dev)
         self._stem(self.stem_s, slow, out=Act(sbuf, ds, 0, cs))
         self.fuse[0](f_act, out=Act(sbuf, ds, cs, 2 * cf))
-        s_act = Act(sbuf, ds)
+        s_act = Act(sbuf, ds, 0, cs + 2 * cf)
         for k, (slow_blocks, fast_blocks) in enumerate(self.stages):
             for blk in fast_blocks:
                 f_act = blk(f_act)
