@@ -383,6 +383,9 @@ int launch(ConvArgs& a, hipStream_t st) {
 constexpr int XBM = 256, XBN = 256, XT = 512;
 constexpr int XUNIT = (XBM + XBN) * 64;  // 32 KB: one 32-wide K slice of both operands
 constexpr int XRING = 4;
+#ifndef XL_DECODE_IN_B
+#define XL_DECODE_IN_B 1  // where the scalar tap decode runs: 0 = the read phase (A), 1 = under the MFMAs (B); measured equal
+#endif
 
 __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
   constexpr int ESTR = XBN * 2 + 16;
@@ -502,7 +505,9 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
     offsets(i, exb_n, ey_n);
     issue(i);
   }
+#if XL_DECODE_IN_B
   decode(3);
+#endif
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's part of unit 0 (units 1, 2 stay in flight)
   __builtin_amdgcn_s_barrier();
   STAMP(0);  // prologue: first three units issued, unit 0 complete
@@ -530,7 +535,10 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #ifdef AVT_CONV_STAMP_FINE
     STAMP(4);  // fragment-read issue
 #endif
-    offsets(i + 3, exb_n, ey_n);  // per-lane selects of the unit issued in the coming phase B
+#if !XL_DECODE_IN_B
+    decode(i + 3);  // scalar tap decode of the unit issued in the coming phase B (phase A has the slack: stamps)
+#endif
+    offsets(i + 3, exb_n, ey_n);  // per-lane selects of that unit
 #ifdef AVT_CONV_STAMP_FINE
     STAMP(6);  // offset selects (slot 6 is re-used: the epilogue share is lost in this mode)
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -552,12 +560,14 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
-    issue(i + 3);   // the DMA of unit i+3 and ...
-    decode(i + 4);  // ... the scalar tap decode for the next phase A ride under this phase's MFMAs:
+    issue(i + 3);  // the DMA of unit i+3 rides under this phase's MFMAs
+#if XL_DECODE_IN_B
+    decode(i + 4);  // ... and so does the scalar tap decode for the next phase A
+#endif
 #pragma unroll
     for (int g = 0; g < 16; ++g) {  // one MFMA, a few scalar instructions, and every 4th time one DMA instruction
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x004, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x004, XL_DECODE_IN_B ? 5 : 2, 0);
       if ((g & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     STAMP(2);  // phase B: MFMAs
