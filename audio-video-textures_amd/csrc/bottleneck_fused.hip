@@ -22,6 +22,8 @@
 // consecutive channels (one 16-byte store), as in stem_conv.hip.
 // Cm = 8 is padded to 16 on the host (zero filters / zero taps): the structured zeros cost MFMA issue only.  For
 // Cm = 32 the a / b weight fragments (42 KB) live in LDS and b takes one tap per MFMA k-step.
+#include <stdlib.h>
+
 #include "avt_common.h"
 
 namespace {
@@ -46,15 +48,14 @@ struct BArgs {
   unsigned x_bytes;
 };
 
-constexpr int NW = 8;  // waves per workgroup (2 per SIMD: the stages are latency-bound, not MFMA-bound)
-
 // CMP = bottleneck width as packed: 16 (Cm = 8 / 16: weights in registers, b's taps in pairs) or 32 (Cm = 32: the
 // a / b weight fragments live in LDS, one tap per MFMA k-step)
 // CIN = input channels: C (identity shortcut: out = relu(c(..) + x)) or 8 (first block of res2: x has 8 channels, the
 // three frame taps of a are ONE MFMA k-step, and the shortcut is a 1x1x1 conv of x accumulated into c's MFMA tile)
 // ST = 2: first block of res3 / res4 (CIN = C/2 >= 32): b has spatial stride 2 (the strip walks OUTPUT rows, a is
 // computed on the 2*HT+1 input rows they touch) and the 1x1x1 shortcut samples x at the even positions.
-template <int C, int W, int HT, int CMP, int CIN = C, int ST = 1>
+// NW = waves per workgroup (2-4 per SIMD: the stages are latency- / issue-bound, not MFMA-bound)
+template <int C, int W, int HT, int CMP, int CIN = C, int ST = 1, int NW = 8>
 __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   constexpr bool SC = CIN != C;   // shortcut conv instead of the identity
   constexpr bool FIRST = CIN == 8;  // ... with all three frame taps of a in one MFMA k-step
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   }
 }
 
-template <int C, int W, int HT, int CMP, int CIN = C, int ST = 1>
+template <int C, int W, int HT, int CMP, int CIN = C, int ST = 1, int NW = 8>
 int launch(BArgs& a, int batch, int h, hipStream_t st) {
   constexpr int RX = ST * HT + (ST == 1 ? 2 : 1), PX = RX * W, PPI = 1024 / (CIN * 2), NDMA = (PX + PPI - 1) / PPI;
   constexpr int MTB = (HT * (W / ST) + 15) / 16, AW = W + 2, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
@@ -349,13 +350,13 @@ int launch(BArgs& a, int batch, int h, hipStream_t st) {
   constexpr int lds_bytes = 3 * NDMA * 1024 + (RX * AW + 32) * CMP * 2 + MTB * 16 * CMP * 2 + wfrags * 1024;
   static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
   a.strips = (h / ST + HT - 1) / HT;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP, CIN, ST>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP, CIN, ST, NW>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_bottleneck_fused_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT, CMP, CIN, ST>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
+  hipLaunchKernelGGL((bottleneck_kernel<C, W, HT, CMP, CIN, ST, NW>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
                      lds_bytes, st, a);
   return avt::check_launch("avt_bottleneck_fused_bf16");
 }
@@ -394,7 +395,7 @@ static int run_bottleneck(const char* what, const void* x, void* out, const void
   a.x_bytes = (unsigned)xb;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (cin == 8) {
-    if (w == 56) return launch<32, 56, 8, 16, 8>(a, batch, h, s);
+    if (w == 56) return launch<32, 56, 8, 16, 8, 1, 16>(a, batch, h, s);
     return launch<32, 12, 5, 16, 8>(a, batch, h, s);
   }
   if (cin != c) {  // strided first blocks (w = input width)
@@ -403,7 +404,11 @@ static int run_bottleneck(const char* what, const void* x, void* out, const void
     if (c == 64 && w == 12) return launch<64, 12, 3, 16, 32, 2>(a, batch, h, s);
     return launch<128, 8, 2, 32, 64, 2>(a, batch, h, s);
   }
-  if (c == 32 && w == 56) return launch<32, 56, 8, 16>(a, batch, h, s);
+  static const int nw32 = []() {
+    const char* e = getenv("AVT_BN_NW32");
+    return e ? atoi(e) : 16;  // 16 waves (4 per SIMD, <= 128 VGPRs) hide the stages' latencies better: +10 %
+  }();
+  if (c == 32 && w == 56) return nw32 == 16 ? launch<32, 56, 8, 16, 32, 1, 16>(a, batch, h, s) : launch<32, 56, 8, 16>(a, batch, h, s);
   if (c == 64 && w == 28) return launch<64, 28, 7, 16>(a, batch, h, s);
   if (c == 128 && w == 14) return launch<128, 14, 7, 32>(a, batch, h, s);
   if (c == 32 && w == 12) return launch<32, 12, 5, 16>(a, batch, h, s);  // small shapes for the tests: ragged strips,
