@@ -394,23 +394,27 @@ static int run_bottleneck(const char* what, const void* x, void* out, const void
   a.tchunks = (t + a.TC - 1) / a.TC;
   a.x_bytes = (unsigned)xb;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // 16 waves (4 per SIMD, <= 128 VGPRs) hide the stages' latencies better than 8 (+10 % on the C = 32 form) where the
+  // kernel fits them without spilling (C <= 64); AVT_BN_NW=8 selects the 8-wave builds
+  static const int nw = []() {
+    const char* e = getenv("AVT_BN_NW");
+    return e ? atoi(e) : 16;
+  }();
+#define AVT_BN_LAUNCH(...) (nw == 16 ? launch<__VA_ARGS__, 16>(a, batch, h, s) : launch<__VA_ARGS__, 8>(a, batch, h, s))
   if (cin == 8) {
-    if (w == 56) return launch<32, 56, 8, 16, 8, 1, 16>(a, batch, h, s);
+    if (w == 56) return AVT_BN_LAUNCH(32, 56, 8, 16, 8, 1);
     return launch<32, 12, 5, 16, 8>(a, batch, h, s);
   }
   if (cin != c) {  // strided first blocks (w = input width)
-    if (c == 64 && w == 56) return launch<64, 56, 4, 16, 32, 2>(a, batch, h, s);
-    if (c == 128 && w == 28) return launch<128, 28, 4, 32, 64, 2>(a, batch, h, s);
+    if (c == 64 && w == 56) return AVT_BN_LAUNCH(64, 56, 4, 16, 32, 2);
+    if (c == 128 && w == 28) return launch<128, 28, 4, 32, 64, 2>(a, batch, h, s);  // wide form: 16 waves would spill
     if (c == 64 && w == 12) return launch<64, 12, 3, 16, 32, 2>(a, batch, h, s);
     return launch<128, 8, 2, 32, 64, 2>(a, batch, h, s);
   }
-  static const int nw32 = []() {
-    const char* e = getenv("AVT_BN_NW32");
-    return e ? atoi(e) : 16;  // 16 waves (4 per SIMD, <= 128 VGPRs) hide the stages' latencies better: +10 %
-  }();
-  if (c == 32 && w == 56) return nw32 == 16 ? launch<32, 56, 8, 16, 32, 1, 16>(a, batch, h, s) : launch<32, 56, 8, 16>(a, batch, h, s);
-  if (c == 64 && w == 28) return launch<64, 28, 7, 16>(a, batch, h, s);
+  if (c == 32 && w == 56) return AVT_BN_LAUNCH(32, 56, 8, 16, 32, 1);
+  if (c == 64 && w == 28) return AVT_BN_LAUNCH(64, 28, 7, 16, 64, 1);
   if (c == 128 && w == 14) return launch<128, 14, 7, 32>(a, batch, h, s);
+#undef AVT_BN_LAUNCH
   if (c == 32 && w == 12) return launch<32, 12, 5, 16>(a, batch, h, s);  // small shapes for the tests: ragged strips,
   if (c == 64 && w == 10) return launch<64, 10, 4, 16>(a, batch, h, s);  // partial tiles, partial DMA instructions
   return launch<128, 6, 3, 32>(a, batch, h, s);
