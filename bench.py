@@ -81,9 +81,9 @@ def main():
     ap.add_argument("--enc-dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--encoder", default="mfma", choices=["mfma", "miopen"],
                     help="mfma: hand-written implicit-GEMM convolutions (fused_slowfast); miopen: stock nn.Module")
-    ap.add_argument("--enc-batch", type=int, default=80,
-                    help="clips per encoder launch; 80 fills the 256 CUs with whole rounds of the 256x256 conv tiles "
-                         "(res4: 490 tiles, res5: 245) where 64 leaves 23 %% of the last round idle")
+    ap.add_argument("--enc-batch", type=int, default=128,
+                    help="clips per encoder launch (4096 windows = 32 full batches of 128; measured 64..128: within 2 %%, "
+                         "128 best, profiles/r01/probe_bench_sweep.log)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"], help="similarity MFMA mode")
     ap.add_argument("--threshold", type=float, default=0.3)
     ap.add_argument("--frame-hw", type=int, default=128)
@@ -268,7 +268,7 @@ def attach_pmc_traffic(kern, args):
     runs of tools/pmc_kernels.py at these shapes, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes);
     the committed summary is read here because counters cannot be collected inside a timed run."""
     path = os.path.join(ROOT, "profiles", "r01", "pmc_fetch_write_summary.json")
-    if not os.path.exists(path) or args.windows != 4096 or args.enc_batch not in (64, 80):
+    if not os.path.exists(path) or args.windows != 4096 or args.enc_batch != 128:
         return
     pmc = json.load(open(path))
 

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import avtex
 from avtex import ops
 dev = torch.device("cuda:0")
-N, D, W, S, B = 4096, 2304, 20, 4, 80  # B = bench.py's --enc-batch default
+N, D, W, S, B = 4096, 2304, 20, 4, 128  # B = bench.py's --enc-batch default
 g = torch.Generator().manual_seed(123)
 video = torch.randint(0, 256, (B * S + W, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
 starts = np.arange(B, dtype=np.int64) * S
@@ -26,7 +26,7 @@ for _ in range(3):
     ops.sim_gemm_nt(qh, th, 0.1, "bf16x3", q_lo=ql, t_lo=tl)
     ops.sim_gemm_nt(qh, th, 0.1, "bf16")
     ops.row_transition(sim, q_ids=q_ids, threshold=0.3, cap=64)
-# one fused-encoder forward at the bench batch (80 clips): the conv3d_igemm / maxpool launches of a forward
+# one fused-encoder forward at the bench batch (128 clips): the conv3d_igemm / maxpool launches of a forward
 from avtex.slowfast import SlowFast
 from avtex.fused_slowfast import SlowFastMFMA
 torch.manual_seed(0)
