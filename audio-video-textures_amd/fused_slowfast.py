@@ -27,7 +27,7 @@ _FUSE_BLOCK = int(os.environ.get("AVT_FUSE_BLOCK", "1"))    # fast-pathway ident
 _FUSE_BC = int(os.environ.get("AVT_FUSE_BC", "0"))          # slow res2 identity blocks: b + c + residual in one kernel
 #   (bit-compatible with the 3-launch path, but 0.84 ms against 0.75 ms: one 7-wave workgroup per CU is latency-bound)
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
-_FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "8"))  # frames walked per workgroup
+_FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "16"))  # frames walked per workgroup (2 halo frames each)
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 _STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "0"))  # fused pool: bit-identical but slower (probe_stem_pool_ab.log)
 _KW1_CAP = int(os.environ.get("AVT_GROUP_KW1_CAP", "32"))  # measured: profiles/r01/probe_layers.log
