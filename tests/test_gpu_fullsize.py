@@ -102,3 +102,25 @@ def test_clip_pack_frame_sharing_and_checksum(avt, dev):
     s4, f4 = avt.ops.clip_pack(frames, starts, W, dtype=torch.bfloat16, layout="ndhwc4")
     assert torch.equal(f4[..., :3].permute(0, 4, 1, 2, 3), fast)
     assert abs(float(fast.float().sum()) - float(f4.float().sum())) < 1e-3 * fast.numel()
+
+
+def test_n2048_audio_video_width(avt, dev):
+    """SURVEY §8d's other sizes: N=2048 at D=14592 (model_type 2: 2304 video + 12288 VGGish columns, normalised
+    jointly through the two-source l2norm): a 96-row block of the N x N matrix and its survivors, bit for bit."""
+    n, dv, da = 2048, 2304, 12288
+    qv, qa = _emb(n, dv, 20), np.abs(_emb(n, da, 21))  # VGGish features are post-ReLU
+    tv, ta = _emb(n, dv, 22), np.abs(_emb(n, da, 23))
+    to_dev = lambda x: torch.from_numpy(x).to(dev)
+    qn, _, _ = avt.ops.l2norm_rows(to_dev(qv), x1=to_dev(qa))
+    tn, _, _ = avt.ops.l2norm_rows(to_dev(tv), x1=to_dev(ta))
+    assert qn.shape == (n, dv + da)
+    sim = avt.ops.sim_gemm_nt(qn, tn, 0.1, "f32")
+    rows = np.arange(700, 796)
+    oq, _, _ = cref.l2norm_rows(np.concatenate([qv[rows], qa[rows]], 1), want_split=False)
+    ot, _, _ = cref.l2norm_rows(np.concatenate([tv, ta], 1), want_split=False)
+    assert np.array_equal(qn[rows].cpu().numpy(), oq) and np.array_equal(tn.cpu().numpy(), ot)
+    ref = cref.sim_f32(oq, ot, 0.1)
+    assert np.array_equal(sim[rows].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    sel = avt.ops.row_transition(sim[rows].contiguous(), q_ids=torch.from_numpy(rows).to(dev), threshold=0.3, cap=64)
+    o = cref.row_transition(ref, q_ids=rows, n_seg=n, threshold=0.3, cap=64)
+    assert np.array_equal(sel["cnt"].cpu().numpy(), o["cnt"]) and np.array_equal(sel["seg"].cpu().numpy(), o["seg"])
