@@ -1,6 +1,7 @@
 """Classic (Schoedl-style) video textures — BASELINE config 1, CPU plumbing only.
 
-Restates baselines/classic_video_textures/computeD1.py:47-96 + :240-247 (pairwise L2 D1, sigma,
+`compute_D1_device` runs the distance matrix on the GPU (csrc/pairwise.hip); the rest restates
+baselines/classic_video_textures/computeD1.py:47-96 + :240-247 (pairwise L2 D1, sigma,
 P1 shifted by one row and row-normalised), computeD2.py:21-52 (diagonal binomial filter) and
 q_learning.py:27-68 (future-cost iteration) on CPU torch, without the `.cuda()` calls and the missing
 `utils`/`models` modules that make the shipped scripts unrunnable.  Not a GPU target.
@@ -23,6 +24,21 @@ def compute_D1(frames, sigma_factor, batch_size=128):
         for j in range(0, n, batch_size):
             b = f[j : j + batch_size]
             d1[i : i + batch_size, j : j + batch_size] = torch.norm(a.unsqueeze(1) - b.unsqueeze(0), dim=2)
+    nz = torch.nonzero(d1).size(0)
+    sigma = sigma_factor * (d1.sum() / nz)
+    p1 = torch.exp(-d1 / sigma)
+    p1 = torch.cat((p1[1:, :], p1[-1, :].unsqueeze(0)), dim=0)
+    p1 = p1 / p1.sum(1, keepdim=True)
+    return d1, p1, sigma
+
+
+def compute_D1_device(frames, sigma_factor, device="cuda"):
+    """compute_D1 on the MI355X: the N x N distance matrix on the hand-written pairwise kernel (csrc/pairwise.hip), the
+    N x N post-processing (sigma, exp, shift, row-normalise: computeD1.py:240-247) as device tensor ops."""
+    from . import ops
+
+    f = torch.as_tensor(frames).float().reshape(len(frames), -1).contiguous().to(device)
+    d1 = ops.pairwise_l2(f)
     nz = torch.nonzero(d1).size(0)
     sigma = sigma_factor * (d1.sum() / nz)
     p1 = torch.exp(-d1 / sigma)

@@ -298,6 +298,16 @@ def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
                "avt_maxpool_hw2s2_ndhwc_bf16")
 
 
+# ---- classic baseline -----------------------------------------------------------------------
+def pairwise_l2(x):
+    """x [n, d] fp32 (device) -> D1 [n, n] fp32, D1[i, j] = ||x_i - x_j||_2 (computeD1.py:47-96)."""
+    _dev(x, "x", torch.float32)
+    n, d = x.shape
+    out = torch.empty((n, n), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().avt_pairwise_l2_f32(_p(x), int(n), int(d), _p(out), _stream()), "avt_pairwise_l2_f32")
+    return out
+
+
 # ---- audio front-end ------------------------------------------------------------------------
 def logmel(wave, window, melmat, hop, fft_len, log_offset):
     """wave [n] fp32/fp64, window [win] fp64, melmat [fft_len/2+1, n_mel] fp64 (device) -> log-mel [n_frames, n_mel]

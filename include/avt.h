@@ -298,6 +298,11 @@ int avt_bc_fused_bf16(const void* m, const void* res, void* out, const void* wb,
                       const void* wc, const float* bc, int batch, int t, int h, int w, int cm, int c,
                       int ldr, int ldo, void* stream);
 
+/* D1[i, j] = || x_i - x_j ||_2 of the classic video-texture baseline (baselines/classic_video_textures/
+ * computeD1.py:47-96; BASELINE config 1): x [n, d] fp32 device rows (flattened frames), out [n, n] fp32.
+ * fp64 accumulation in a fixed order, one sqrt, one rounding. */
+int avt_pairwise_l2_f32(const float* x, int n, int64_t d, float* out, void* stream);
+
 /* VGGish audio front-end (utils/mel_features.py:21-92, 176-205 log_mel_spectrogram; called once per
  * video from utils/vggish_utils.py:27-69), float64 like the reference's NumPy code:
  * frame f = wave[f*hop, f*hop+win) * window -> |DFT_fft_len| -> spec[fft_len/2+1] . melmat -> log(. + log_offset).

@@ -3,6 +3,8 @@
 Bar: bit-exact for indices, counts and for the canonical fp32 paths (l2norm,
 AVT_SIM_F32, survivor probabilities); stated tolerances for the bf16 MFMA modes
 and for transcendental reporting values (ce, entropy)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -232,3 +234,20 @@ def test_infonce_fused_fwd_bwd_matches_autograd(avt, dev, b, n, d):
     assert (out.detach().double() - ref.detach()).abs().max() < 2e-5
     assert (q.grad.double() - q64.grad).abs().max() < 1e-5 * max(1.0, q64.grad.abs().max().item())
     assert (t.grad.double() - t64.grad).abs().max() < 1e-5 * max(1.0, t64.grad.abs().max().item())
+
+
+def test_classic_pairwise_l2_matches_reference_fixture(avt, dev):
+    """BASELINE config 1 on the GPU: D1 / P1 of the classic baseline vs the reference's own output (G8) and, at the
+    config's full size (200 frames of 128x128x3), vs the oracle."""
+    from oracle import ref_py
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_classic.npz"))
+    d1, p1, s1 = avt.classic.compute_D1_device(g["frames"], 0.1, dev)
+    np.testing.assert_allclose(d1.cpu().numpy(), g["d1"], rtol=2e-6, atol=1e-3)
+    np.testing.assert_allclose(p1.cpu().numpy(), g["p1"], rtol=1e-4, atol=1e-6)
+    frames = torch.randint(0, 256, (200, 128, 128, 3), generator=torch.Generator().manual_seed(7), dtype=torch.uint8)
+    d_gpu = avt.ops.pairwise_l2(frames.float().reshape(200, -1).to(dev)).cpu().numpy()
+    d_ref, _, _ = ref_py.classic_d1_p1(frames.numpy(), 0.1)
+    # uint8 inputs: every squared difference and the whole sum are exact in fp64 -> identical up to the final rounding
+    assert np.array_equal(d_gpu, d_ref)
+    assert (np.diag(d_gpu) == 0).all() and np.array_equal(d_gpu, d_gpu.T)
