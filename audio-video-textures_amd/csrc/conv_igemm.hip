@@ -33,6 +33,8 @@
 // staging with a source-side swizzle and two LDS stages; requesting the residual before the K loop (+32 VGPRs).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "avt_common.h"
 
 namespace {
@@ -380,18 +382,28 @@ int launch(ConvArgs& a, hipStream_t st) {
 // applied on the SOURCE side of the DMA (each lane fetches the chunk that belongs in its fixed destination slot).
 // Padding taps / tails read 16 zero bytes (behind the tap table); taps are decoded arithmetically (no table read in
 // the loop: an LDS read there makes the compiler drain vmcnt(0)).
-constexpr int XBM = 256, XBN = 256, XT = 512;
-constexpr int XUNIT = (XBM + XBN) * 64;  // 32 KB: one 32-wide K slice of both operands
-constexpr int XRING = 4;
+constexpr int XT = 512;   // 8 waves
+constexpr int XRING = 4;  // pipeline units in the LDS ring
 #ifndef XL_DECODE_IN_B
 #define XL_DECODE_IN_B 1  // where the scalar tap decode runs: 0 = the read phase (A), 1 = under the MFMAs (B); measured equal
 #endif
 
+// Tile shapes <XBM, XBN, WM = waves along m>: <256,256,2> (wave tile 128x64) for Cout >= 256; <256,128,4> and <512,64,8>
+// (wave tile 64x64) for the 128- and 64-channel layers.  The unit is (XBM + XBN) x 64 bytes in every shape.
+template <int XBM, int XBN, int WM>
 __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
+  constexpr int WN = 8 / WM, WTM = XBM / WM, WTN = XBN / WN, MT = WTM / 32, NT = WTN / 32;
+  constexpr int XUNIT = (XBM + XBN) * 64;  // one 32-wide K slice of both operands
+  constexpr int AIW = XBM / 128;           // A-operand DMA instructions per wave and unit (16 rows each)
+  constexpr bool BHALF = XBN < 128;        // fewer B rows than 8 waves x 16: only waves 0 .. XBN/16-1 stage B
+  constexpr int BIW = BHALF ? 1 : XBN / 128;
+  constexpr int NMF = 2 * NT * MT;         // MFMAs of a phase B
   constexpr int ESTR = XBN * 2 + 16;
-  constexpr int EROWS = 128;  // epilogue pass = one wave-row
+  constexpr int EPASS = (XBM * ESTR <= XRING * XUNIT) ? 1 : 2;  // epilogue staging passes through the ring's LDS
+  constexpr int EROWS = XBM / EPASS;
   constexpr int CPR = XBN / 8;
-  constexpr int EU = (EROWS * CPR) / XT;  // 8
+  constexpr int EU = (EROWS * CPR) / XT;
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0 && EROWS * ESTR <= XRING * XUNIT, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   const int bid = blockIdx.x;
@@ -402,16 +414,17 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3;
+  const int wm = wid / WN, wn = wid % WN;
+  const int grp = wid >> 2;  // the two waves of a SIMD (w, w+4) are in different phase groups
   const int lr = lane & 31, lh = lane >> 5;
   // staging role: DMA instruction u (0/1) of wave wid fills rows u*128 + wid*16 + (lane >> 2), slot lane & 3
   const int srow = wid * 16 + (lane >> 2);
   const int c4 = (lane & 3) ^ ((lane >> 4) & 3);  // logical chunk (of the unit's 4) that belongs in this lane's slot
 
-  int rowoff[2];
-  unsigned rowmask[2];
+  int rowoff[AIW];
+  unsigned rowmask[AIW];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < AIW; ++u) {
     const int m = m0 + u * 128 + srow;
     rowoff[u] = 0;
     rowmask[u] = 0u;
@@ -431,18 +444,18 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
       rowmask[u] = mask;
     }
   }
-  int wrow[2];
+  int wrow[BIW];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < BIW; ++u) {
     const int n = n0 + u * 128 + srow;
-    wrow[u] = n < a.Cout ? n * a.K : -1;
+    wrow[u] = (n < a.Cout && u * 128 + srow < XBN) ? n * a.K : -1;
   }
 
-  f32x16 acc[2][4];
+  f32x16 acc[NT][MT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < MT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -455,12 +468,12 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
   const int nu = (a.K + 31) / 32;  // pipeline units
   const int swid = __builtin_amdgcn_readfirstlane(wid);  // wave-uniform in an SGPR: LDS destinations stay scalar
-  unsigned rowb[2], wrowb[2];  // byte offsets of this lane's rows (+ its chunk within a unit), OOB when absent
+  unsigned rowb[AIW], wrowb[BIW];  // byte offsets of this lane's rows (+ its chunk within a unit), OOB when absent
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    rowb[u] = (unsigned)(rowoff[u] + c4 * 8) * 2u;
-    wrowb[u] = wrow[u] >= 0 ? (unsigned)(wrow[u] + c4 * 8) * 2u : kOob;
-  }
+  for (int u = 0; u < AIW; ++u) rowb[u] = (unsigned)(rowoff[u] + c4 * 8) * 2u;
+#pragma unroll
+  for (int u = 0; u < BIW; ++u) wrowb[u] = wrow[u] >= 0 ? (unsigned)(wrow[u] + c4 * 8) * 2u : kOob;
+  const bool stage_b = !BHALF || swid < XBN / 16;  // wave-uniform: this wave owns B rows
 
   // tap decode of unit i: wave-uniform, all on the scalar unit (it is computed one unit ahead, inside the MFMA phase,
   // where scalar issue slots are free; moving the per-lane offset selects there too measured slower: VALU work
@@ -474,26 +487,36 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
     exb_n = (unsigned)(((dt * a.H + dh) * a.W + dw) * a.ldi + c8 * 8) * 2u;
     ey_n = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
   };
-  unsigned offa_c[2], offb_c[2];  // DMA offsets of the unit about to be issued (computed in phase A, issued in phase B)
+  unsigned offa_c[AIW], offb_c[BIW];  // DMA offsets of the unit about to be issued (computed in phase A, issued in phase B)
   auto offsets = [&](int i, unsigned exb, unsigned ey) {
     const bool kin = (i * 4 + c4) * 8 < a.K;
     const unsigned kb = (unsigned)(i * 64);  // byte offset of the unit inside a weight row
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      offa_c[u] = (kin && ((rowmask[u] & ey) == ey)) ? rowb[u] + exb : kOob;
-      offb_c[u] = (kin && wrowb[u] != kOob) ? wrowb[u] + kb : kOob;
-    }
+    for (int u = 0; u < AIW; ++u) offa_c[u] = (kin && ((rowmask[u] & ey) == ey)) ? rowb[u] + exb : kOob;
+#pragma unroll
+    for (int u = 0; u < BIW; ++u) offb_c[u] = (kin && wrowb[u] != kOob) ? wrowb[u] + kb : kOob;
   };
-  auto issue = [&](int i) {  // the four DMA instructions of unit i
+  auto issue = [&](int i) {  // this wave's DMA instructions of unit i
     char* st = lds + (i & (XRING - 1)) * XUNIT;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < AIW; ++u)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(st + (u * 128 + swid * 16) * 64),
                                                16, (int)offa_c[u], 0, 0, 0);
+    if (stage_b) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rwt, (__attribute__((address_space(3))) void*)(st + XBM * 64 + (u * 128 + swid * 16) * 64), 16, (int)offb_c[u], 0, 0, 0);
+      for (int u = 0; u < BIW; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rwt, (__attribute__((address_space(3))) void*)(st + XBM * 64 + (u * 128 + swid * 16) * 64), 16, (int)offb_c[u], 0, 0,
+            0);
+    }
+  };
+  // counted waits: "all but my youngest `units` units' DMAs have landed"
+  auto wait_units = [&](auto units) {
+    constexpr int U = decltype(units)::value;
+    if (stage_b)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U * (AIW + BIW)) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U * AIW) : "memory");
   };
   const int xa = (lr >> 2) & 3;  // swizzle key of this lane's fragment rows (tile offsets are multiples of 16)
 #ifdef AVT_CONV_STAMP
@@ -508,7 +531,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #if XL_DECODE_IN_B
   decode(3);
 #endif
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's part of unit 0 (units 1, 2 stay in flight)
+  wait_units(std::integral_constant<int, 2>{});  // this wave's part of unit 0 (units 1, 2 stay in flight)
   __builtin_amdgcn_s_barrier();
   STAMP(0);  // prologue: first three units issued, unit 0 complete
   // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE PHASE APART: a unit is phase A (12 fragment
@@ -518,19 +541,19 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
   // Hazards: a wave ends phase A(j) with vmcnt(8) — its part of unit j+1 has landed, one or two phases before anyone
   // reads it — and lgkmcnt(0) — its reads of unit j are retired, so the DMA of unit j+4 (next phase A of either group
   // at the earliest) may overwrite the slot.
-  if (wm == 1) __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
   for (int i = 0; i < nu; ++i) {
     const char* st = lds + (i & (XRING - 1)) * XUNIT;
-    bf16x8 af[2][4], wf[2][2];
+    bf16x8 af[2][MT], wf[2][NT];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int koff = ((ks * 2 + lh) ^ xa) * 16;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        af[ks][j] = *reinterpret_cast<const bf16x8*>(st + (wm * 128 + j * 32 + lr) * 64 + koff);
+      for (int j = 0; j < MT; ++j)
+        af[ks][j] = *reinterpret_cast<const bf16x8*>(st + (wm * WTM + j * 32 + lr) * 64 + koff);
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-        wf[ks][n] = *reinterpret_cast<const bf16x8*>(st + XBM * 64 + (wn * 64 + n * 32 + lr) * 64 + koff);
+      for (int n = 0; n < NT; ++n)
+        wf[ks][n] = *reinterpret_cast<const bf16x8*>(st + XBM * 64 + (wn * WTN + n * 32 + lr) * 64 + koff);
     }
 #ifdef AVT_CONV_STAMP_FINE
     STAMP(4);  // fragment-read issue
@@ -541,12 +564,13 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
     offsets(i + 3, exb_n, ey_n);  // per-lane selects of that unit
 #ifdef AVT_CONV_STAMP_FINE
     STAMP(6);  // offset selects (slot 6 is re-used: the epilogue share is lost in this mode)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    wait_units(std::integral_constant<int, 1>{});
     STAMP(0);  // vmcnt wait (slot 0 re-used)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
     // this wave's part of unit i+1 has landed when only unit i+2's 4 DMAs are outstanding (unit i+3 is issued in B)
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_units(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     STAMP(1);  // phase A: reads + DMA issue + waits
     __builtin_amdgcn_sched_barrier(0);  // the phases are the schedule: nothing moves across their barriers
@@ -556,19 +580,20 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < MT; ++j)
           acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
     issue(i + 3);  // the DMA of unit i+3 rides under this phase's MFMAs
 #if XL_DECODE_IN_B
     decode(i + 4);  // ... and so does the scalar tap decode for the next phase A
 #endif
+    constexpr int DSTEP = NMF / (AIW + BIW) > 0 ? NMF / (AIW + BIW) : 1;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {  // one MFMA, a few scalar instructions, and every 4th time one DMA instruction
+    for (int g = 0; g < NMF; ++g) {  // one MFMA, a few scalar instructions, and every DSTEP-th time one DMA instruction
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x004, XL_DECODE_IN_B ? 5 : 2, 0);
-      if ((g & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x004, XL_DECODE_IN_B ? (80 / NMF) : 2, 0);
+      if (g % DSTEP == DSTEP / 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     STAMP(2);  // phase B: MFMAs
     __builtin_amdgcn_sched_barrier(0);
@@ -576,13 +601,13 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     STAMP(5);  // barrier after B
   }
-  if (wm == 0) __builtin_amdgcn_s_barrier();
+  if (grp == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-fill units
   __syncthreads();  // all MFMA operand reads done: the ring becomes the epilogue's staging tile
 
   const bool has_res = a.res != nullptr;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < EPASS; ++p) {
     uint4 rres[EU];
     if (has_res) {
 #pragma unroll
@@ -593,16 +618,16 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
                                           : make_uint4(0u, 0u, 0u, 0u);
       }
     }
-    if (wm == p) {
+    if ((wm * WTM) / EROWS == p) {  // this wave's rows belong to this pass
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int nl = wn * 64 + i * 32 + 8 * g + 4 * lh;
+          const int nl = wn * WTN + i * 32 + 8 * g + 4 * lh;
           float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
           if (a.bias && n0 + nl < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < MT; ++j) {
             float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
             float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
             if (a.relu && !has_res) {
@@ -614,7 +639,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
             uint2 pk;
             pk.x = avt::pack_bf16x2(v0, v1);
             pk.y = avt::pack_bf16x2(v2, v3);
-            *reinterpret_cast<uint2*>(lds + (j * 32 + lr) * ESTR + nl * 2) = pk;
+            *reinterpret_cast<uint2*>(lds + (wm * WTM - p * EROWS + j * 32 + lr) * ESTR + nl * 2) = pk;
           }
         }
     }
@@ -643,7 +668,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
         *reinterpret_cast<uint4*>(a.out + (int64_t)m * a.ldo + n) = v;
       }
     }
-    if (p == 0) __syncthreads();
+    if (p + 1 < EPASS) __syncthreads();
   }
 #ifdef AVT_CONV_STAMP
   STAMP(6);  // epilogue
@@ -654,6 +679,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #endif
 }
 
+template <int XBM, int XBN, int WM>
 int launch_xl(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + XBM - 1) / XBM;
   a.tiles_n = (a.Cout + XBN - 1) / XBN;
@@ -661,14 +687,14 @@ int launch_xl(ConvArgs& a, hipStream_t st) {
   a.dCpt = make_fastdiv((uint32_t)(a.K / (a.KT * a.KH * a.KW) / 8));
   a.dKHW = make_fastdiv((uint32_t)(a.KH * a.KW));
   a.dKW = make_fastdiv((uint32_t)a.KW);
-  constexpr int lds_bytes = XRING * XUNIT;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel),
+  constexpr int lds_bytes = XRING * (XBM + XBN) * 64;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<XBM, XBN, WM>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(conv_xl_kernel, dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_xl_kernel<XBM, XBN, WM>), dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_bf16");
 }
 
@@ -779,7 +805,21 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   }();
   if (xl > 0 && cout >= 256 && a.nk >= xl_nk && (cin % 32 == 0 || kt * kh * kw == 1) &&
       (int64_t)((a.M + 255) / 256) * ((cout + 255) / 256) >= xl)
-    return launch_xl(a, s);
+    return launch_xl<256, 256, 2>(a, s);
+  // ... and its 64x64-per-wave forms for the 64- / 128-channel layers (AVT_CONV_XLS: bit 0 = <512,64>, bit 1 = <256,128>)
+  static const int xls = []() {
+    const char* e = getenv("AVT_CONV_XLS");
+    return e ? atoi(e) : 0;
+  }();
+  static const int xls_tiles = []() {  // minimum tile count (tests set 1)
+    const char* e = getenv("AVT_CONV_XLS_TILES");
+    return e ? atoi(e) : 256;
+  }();
+  if (xl > 0 && (cin % 32 == 0 || kt * kh * kw == 1)) {
+    if ((xls & 1) && cout == 64 && a.nk >= 8 && (a.M + 511) / 512 >= xls_tiles) return launch_xl<512, 64, 8>(a, s);
+    if ((xls & 2) && cout > 64 && cout <= 128 && a.nk >= 16 && (a.M + 255) / 256 >= xls_tiles)
+      return launch_xl<256, 128, 4>(a, s);
+  }
   if (cout <= 32) return launch<256, 32, 64>(a, s);
   if (cout <= 64) return launch<256, 64, 64>(a, s);
   // wide layers: the 256x128 tile (128x64 per wave) when there are enough tiles of it to fill the chip
