@@ -24,6 +24,7 @@ from ._lib import AvtError
 import os
 
 _FUSE_BLOCK = int(os.environ.get("AVT_FUSE_BLOCK", "1"))    # fast-pathway identity bottlenecks as one kernel
+_C33 = int(os.environ.get("AVT_C33", "1"))                  # slow res2 b conv on the strip-resident kernel
 _FUSE_BC = int(os.environ.get("AVT_FUSE_BC", "0"))          # slow res2 identity blocks: b + c + residual in one kernel
 #   (bit-compatible with the 3-launch path, but 0.84 ms against 0.75 ms: one 7-wave workgroup per CU is latency-bound)
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
@@ -295,6 +296,24 @@ def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):
     return out + (dev((bc + bsc).float(), torch.float32), dev(ws_p[chan4, kk4], torch.bfloat16))
 
 
+def pack_c33(wb, device):
+    """BN-folded [64,64,1,3,3] weights -> csrc/conv33_c64.hip's fragment order (output rows permuted so a lane ends
+    with 8 consecutive channels, include/avt.h)."""
+    wb = wb.detach().float().cpu()
+    cm = wb.shape[0]
+    lane = torch.arange(64)
+    n, q = lane & 15, lane >> 4
+    e = torch.arange(8)
+    wb9 = wb[:, :, 0].reshape(cm, cm, 9)  # [out, in, tap]
+    shape = (9, 2, cm // 16, 64, 8)
+    tap = torch.arange(9).view(-1, 1, 1, 1, 1).expand(shape)
+    kh = torch.arange(2).view(1, -1, 1, 1, 1)
+    nt = torch.arange(cm // 16).view(1, 1, -1, 1, 1)
+    row = (32 * (nt // 2) + 8 * (n >> 2).view(1, 1, 1, -1, 1) + 4 * (nt % 2) + (n & 3).view(1, 1, 1, -1, 1)).expand(shape)
+    ch = (kh * 32 + q.view(1, 1, 1, -1, 1) * 8 + e.view(1, 1, 1, 1, -1)).expand(shape)
+    return wb9[row, ch, tap].to(torch.bfloat16).contiguous().to(device)
+
+
 def pack_bc(wb, bb, wc, bc, device):
     """BN-folded b [64,64,1,3,3] and c [256,64,1,1,1] of a slow res2 bottleneck -> the MFMA-fragment order of
     csrc/bc_fused.hip (include/avt.h)."""
@@ -348,6 +367,11 @@ class _Block:
             (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
             self.fused_first = pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=self.b1._folded)
 
+        # slow res2: b ([1,3,3] 64 -> 64, stride 1) on the strip-resident kernel
+        self.c33 = None
+        if (_C33 and self.b.kernel == (1, 3, 3) and self.b.stride == (1, 1, 1) and self.b.cin == 64 and self.b.cout == 64 and
+                self.b._folded is not None):
+            self.c33 = (pack_c33(self.b._folded[0], device), self.b.bias)
         # slow res2 identity blocks (a 1x1x1, b [1,3,3] 64 -> 64, c 64 -> 256): b, c and the residual add in one kernel
         self.bc = None
         if (_FUSE_BC and self.b1 is None and self.a.kernel == (1, 1, 1) and self.b.kernel == (1, 3, 3) and
@@ -368,9 +392,27 @@ class _Block:
             self.ccat.alg_flops_per_row = self.c.alg_flops_per_row + self.b1.alg_flops_per_row
             self.extra = self.c.cin
 
+    def _b(self, m, out=None):
+        """The block's b conv: the strip-resident kernel for 64 -> 64 at the production width, else the implicit GEMM."""
+        if (self.c33 is not None and m.c0 == 0 and m.ld == m.C and ops.conv33_c64_supported(m.C, self.b.cout, m.dims[3])):
+            b, t, h, w = m.dims
+            if out is None:
+                out = Act(torch.empty((b * t * h * w, self.b.cout), dtype=torch.bfloat16, device=self.dev), m.dims)
+
+            def launch():
+                ops.conv33_c64(m.ptr, self.c33[0], self.c33[1], out.ptr, b, t, h, w, out.ld, relu=True)
+
+            if PROFILER is None:
+                launch()
+            else:
+                rows = b * t * h * w
+                PROFILER("conv3d_igemm_bf16", launch, rows * self.b.alg_flops_per_row, 2.0 * rows * 2 * self.b.cout)
+            return out
+        return self.b(m, out=out)
+
     def __call__(self, x, out=None):
         if self.ccat is not None and x.c0 == 0 and x.ld >= x.C + self.extra and x.C == self.a.cin:
-            self.b(self.a(x), out=Act(x.buf, x.dims, x.C, self.extra))  # b's output lands behind x in the same rows
+            self._b(self.a(x), out=Act(x.buf, x.dims, x.C, self.extra))  # b's output lands behind x in the same rows
             return self.ccat(Act(x.buf, x.dims, 0, x.C + self.extra), out=out)
         if (self.bc is not None and x.c0 == 0 and ops.bc_fused_supported(self.b.cin, self.c.cout, x.dims[3]) and
                 x.C == self.c.cout):
@@ -424,7 +466,7 @@ class _Block:
                 PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * (m * x.C + mo * self.c.cout))
             return y
         sc = self.b1(x) if self.b1 is not None else x
-        return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)
+        return self.c(self._b(self.a(x)), out=out, res=sc, relu=True)
 
 
 class SlowFastMFMA(nn.Module):

@@ -291,6 +291,18 @@ def bc_fused(m_ptr, res_ptr, out_ptr, packed, batch, t, h, w, cm, c, ldr, ldo):
                                             int(ldo), _stream()), "avt_bc_fused_bf16")
 
 
+def conv33_c64_supported(cin, cout, w):
+    return bool(_lib.lib().avt_conv33_c64_supported(int(cin), int(cout), int(w)))
+
+
+def conv33_c64(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu=True):
+    """[1,3,3] 64 -> 64 conv with the input strip resident in LDS; wb = fused_slowfast.pack_c33(...)."""
+    _dev(wb, "wb", torch.bfloat16)
+    _dev(bias, "bias", torch.float32)
+    _lib.check(_lib.lib().avt_conv33_c64_bf16(C.c_void_p(x_ptr), _p(wb), _p(bias), C.c_void_p(out_ptr), int(batch), int(t),
+                                              int(h), int(w), int(ldo), int(bool(relu)), _stream()), "avt_conv33_c64_bf16")
+
+
 def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):
     """MaxPool2d(2, 2), floor mode, on NHWC bf16 rows (raw device addresses) — VGGish (audio_models/vggish.py:15-33)."""
     _lib.check(_lib.lib().avt_maxpool_hw2s2_ndhwc_bf16(C.c_void_p(x_ptr), C.c_void_p(out_ptr), int(bt), int(h), int(w),

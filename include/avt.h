@@ -303,6 +303,15 @@ int avt_bc_fused_bf16(const void* m, const void* res, void* out, const void* wb,
  * fp64 accumulation in a fixed order, one sqrt, one rounding. */
 int avt_pairwise_l2_f32(const float* x, int n, int64_t d, float* out, void* stream);
 
+/* Conv3d [1,3,3] 64 -> 64, stride 1, pad 1 (+ BN folded, optional ReLU) of the slow res2 blocks with the input
+ * strip resident in LDS (csrc/conv33_c64.hip; same model, models/models.py:335, 399).  in [batch, t, h, w, 64],
+ * out [batch, t, h, w, .] with row stride ldo elements, bf16.  wb [9 taps][2][4][64][8] in MFMA fragment order with
+ * the output rows permuted: tile nt, row r -> channel 32*(nt/2) + 8*(r/4) + 4*(nt%2) + r%4, k = 32*kh + 8*q + e;
+ * bias [64] fp32 in channel order.  avt_conv33_c64_supported(cin, cout, w): (64, 64, 56). */
+int avt_conv33_c64_supported(int cin, int cout, int w);
+int avt_conv33_c64_bf16(const void* in, const void* wb, const float* bias, void* out, int batch, int t,
+                        int h, int w, int ldo, int relu, void* stream);
+
 /* VGGish audio front-end (utils/mel_features.py:21-92, 176-205 log_mel_spectrogram; called once per
  * video from utils/vggish_utils.py:27-69), float64 like the reference's NumPy code:
  * frame f = wave[f*hop, f*hop+win) * window -> |DFT_fft_len| -> spec[fft_len/2+1] . melmat -> log(. + log_offset).

@@ -404,3 +404,35 @@ def test_bc_fused_slow_res2_tail(avt, dev, dims):
     fb(fsf.Act(rows, dims), out=fsf.Act(wide, dims, 0, 256))                               # writes the concat slice
     torch.cuda.synchronize()
     assert torch.equal(wide[:, :256], y.buf) and (wide[:, 256:] == 5).all()
+
+
+@pytest.mark.parametrize("dims,relu", [((2, 3, 10, 16), True), ((1, 2, 56, 56), True), ((1, 1, 7, 16), False)])
+def test_conv33_c64_matches_igemm_and_torch(avt, dev, dims, relu):
+    """csrc/conv33_c64.hip ([1,3,3] 64 -> 64 with the input strip resident in LDS) vs the implicit-GEMM kernel on the same
+    folded weights and vs torch; ragged last strip, writes into a channel slice."""
+    from avtex.fused_slowfast import Act, FusedConv, pack_c33
+
+    torch.manual_seed(dims[2] * 7)
+    conv = nn.Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1), bias=False)
+    bn = nn.BatchNorm3d(64).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.6, 1.2); bn.bias.uniform_(-0.2, 0.2)
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.8, 1.2)
+    fc = FusedConv(conv, bn, relu, dev)
+    b, t, h, w = dims
+    x = torch.randn(b, 64, t, h, w).to(torch.bfloat16)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, 64).contiguous().to(dev)
+    gen = fc(Act(rows, dims)).buf
+    wide = torch.full((rows.shape[0], 64 + 16), 4.0, dtype=torch.bfloat16, device=dev)
+    avt.ops.conv33_c64(rows.data_ptr(), pack_c33(fc._folded[0], dev), fc.bias, wide.data_ptr() + 2 * 8, b, t, h, w, 80, relu=relu)
+    torch.cuda.synchronize()
+    got = wide[:, 8:72]
+    assert (wide[:, :8] == 4).all() and (wide[:, 72:] == 4).all()
+    scale = max(gen.float().abs().max().item(), 1.0)
+    assert (got.float() - gen.float()).abs().max().item() <= 0.01 * scale
+    assert (got != gen).float().mean().item() < 0.05  # same products, different fp32 summation order
+    with torch.no_grad():
+        ref = bn(conv(x.float()))
+        ref = F.relu(ref) if relu else ref
+    g5 = got.float().cpu().view(b, t, h, w, 64).permute(0, 4, 1, 2, 3)
+    assert (g5 - ref).abs().max().item() < 0.02 * max(ref.abs().max().item(), 1.0)

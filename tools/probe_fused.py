@@ -55,6 +55,11 @@ def spy_bc(m_ptr, res_ptr, out_ptr, packed, batch, t, h, w, cm, c, ldr, ldo):
     shapes.append("fused b+c slow res2 %d->%d in(%d, %d, %d, %d)" % (cm, c, batch, t, h, w))
     return orig_bc(m_ptr, res_ptr, out_ptr, packed, batch, t, h, w, cm, c, ldr, ldo)
 avtex.ops.bc_fused = spy_bc
+orig_c33 = avtex.ops.conv33_c64
+def spy_c33(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu=True):
+    shapes.append("strip-resident 3x3 64->64 in(%d, %d, %d, %d)" % (batch, t, h, w))
+    return orig_c33(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu)
+avtex.ops.conv33_c64 = spy_c33
 avtex.ops.conv3d_igemm = spy
 fsf.ops.conv3d_igemm = spy
 fsf.PROFILER = hook
