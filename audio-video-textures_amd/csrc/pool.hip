@@ -29,27 +29,27 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict
     p /= Wo;
     const int ho = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    uint4 m;
-    bool first = true;
+    // taps outside the image are clamped onto the nearest valid tap (a duplicate does not change a max): nine
+    // unconditional 16-byte loads in flight instead of a branch per tap
+    uint4 v[KS * KS];
 #pragma unroll
     for (int dh = 0; dh < KS; ++dh) {
-      const int hi = 2 * ho - PAD + dh;
-      if ((unsigned)hi >= (unsigned)H) continue;
+      int hi = 2 * ho - PAD + dh;
+      hi = hi < 0 ? 0 : (hi > H - 1 ? H - 1 : hi);
 #pragma unroll
       for (int dw = 0; dw < KS; ++dw) {
-        const int wi = 2 * wo - PAD + dw;
-        if ((unsigned)wi >= (unsigned)W) continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(in + (((int64_t)b * H + hi) * W + wi) * ldi + cc * 8);
-        if (first) {
-          m = v;
-          first = false;
-        } else {
-          m.x = max2(m.x, v.x);
-          m.y = max2(m.y, v.y);
-          m.z = max2(m.z, v.z);
-          m.w = max2(m.w, v.w);
-        }
+        int wi = 2 * wo - PAD + dw;
+        wi = wi < 0 ? 0 : (wi > W - 1 ? W - 1 : wi);
+        v[dh * KS + dw] = *reinterpret_cast<const uint4*>(in + (((int64_t)b * H + hi) * W + wi) * ldi + cc * 8);
       }
+    }
+    uint4 m = v[0];
+#pragma unroll
+    for (int k = 1; k < KS * KS; ++k) {
+      m.x = max2(m.x, v[k].x);
+      m.y = max2(m.y, v[k].y);
+      m.z = max2(m.z, v[k].z);
+      m.w = max2(m.w, v[k].w);
     }
     // tgroup > 1: the C channels are `tgroup` consecutive frames of C/tgroup channels each (the time-grouped stem):
     // un-group while writing, so the result is plain NDHWC with bt*tgroup frames
