@@ -9,26 +9,34 @@
 
 namespace {
 
-__device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) {
-  const float a0 = avt::bf16_bits_to_f32((uint16_t)(a & 0xffffu)), a1 = avt::bf16_bits_to_f32((uint16_t)(a >> 16));
-  const float b0 = avt::bf16_bits_to_f32((uint16_t)(b & 0xffffu)), b1 = avt::bf16_bits_to_f32((uint16_t)(b >> 16));
-  const uint32_t lo = (b0 > a0) ? (b & 0xffffu) : (a & 0xffffu);
-  const uint32_t hi = (b1 > a1) ? (b >> 16) : (a >> 16);
-  return lo | (hi << 16);
+// bf16 pairs -> order-preserving signed 16-bit keys (negative values get their magnitude bits flipped; an involution),
+// so the 3x3 max is v_pk_max_i16 on two channels at once instead of unpack / compare / select per channel: the kernel
+// was VALU-bound (~700 VALU instructions per 16-byte output with the 64-bit index divisions), not HBM-bound.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t order_key(uint32_t x) {
+  uint32_t m = (x >> 15) & 0x00010001u;
+  m = (m << 15) - m;  // 0x7fff in every negative half
+  return x ^ m;
+}
+__device__ __forceinline__ uint32_t kmax(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
 
+// Flat 32-bit index over (frame, ho, wo, 8-channel chunk): three 32-bit divisions instead of three 64-bit ones.
 template <int KS, int PAD>
 __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
                                                        int bt, int H, int W, int C, int ldi, int ldo, int Ho, int Wo, int tgroup) {
-  const int cpr = C >> 3;
-  const int64_t total = (int64_t)bt * Ho * Wo * cpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    int64_t p = i / cpr;
-    const int wo = (int)(p % Wo);
-    p /= Wo;
-    const int ho = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+  const unsigned cpr = (unsigned)C >> 3;
+  const unsigned cg = (unsigned)(C / tgroup);
+  const unsigned total = (unsigned)bt * Ho * Wo * cpr;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned p = i / cpr;
+    const unsigned cc = i - p * cpr;
+    const unsigned q = p / (unsigned)Wo;
+    const int wo = (int)(p - q * Wo);
+    const unsigned b = q / (unsigned)Ho;
+    const int ho = (int)(q - b * Ho);
+    const uint16_t* frame = in + (int64_t)b * H * W * ldi + cc * 8;
     // taps outside the image are clamped onto the nearest valid tap (a duplicate does not change a max): nine
     // unconditional 16-byte loads in flight instead of a branch per tap
     uint4 v[KS * KS];
@@ -40,21 +48,24 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict
       for (int dw = 0; dw < KS; ++dw) {
         int wi = 2 * wo - PAD + dw;
         wi = wi < 0 ? 0 : (wi > W - 1 ? W - 1 : wi);
-        v[dh * KS + dw] = *reinterpret_cast<const uint4*>(in + (((int64_t)b * H + hi) * W + wi) * ldi + cc * 8);
+        v[dh * KS + dw] = *reinterpret_cast<const uint4*>(frame + (int64_t)(hi * W + wi) * ldi);
       }
     }
-    uint4 m = v[0];
+    uint4 m = {order_key(v[0].x), order_key(v[0].y), order_key(v[0].z), order_key(v[0].w)};
 #pragma unroll
     for (int k = 1; k < KS * KS; ++k) {
-      m.x = max2(m.x, v[k].x);
-      m.y = max2(m.y, v[k].y);
-      m.z = max2(m.z, v[k].z);
-      m.w = max2(m.w, v[k].w);
+      m.x = kmax(m.x, order_key(v[k].x));
+      m.y = kmax(m.y, order_key(v[k].y));
+      m.z = kmax(m.z, order_key(v[k].z));
+      m.w = kmax(m.w, order_key(v[k].w));
     }
+    m.x = order_key(m.x);
+    m.y = order_key(m.y);
+    m.z = order_key(m.z);
+    m.w = order_key(m.w);
     // tgroup > 1: the C channels are `tgroup` consecutive frames of C/tgroup channels each (the time-grouped stem):
     // un-group while writing, so the result is plain NDHWC with bt*tgroup frames
-    const int cg = C / tgroup;
-    const int j = (cc * 8) / cg, c0 = (cc * 8) - j * cg;
+    const unsigned j = (cc * 8) / cg, c0 = (cc * 8) - j * cg;
     *reinterpret_cast<uint4*>(out + ((((int64_t)b * tgroup + j) * Ho + ho) * Wo + wo) * ldo + c0) = m;
   }
 }
@@ -71,6 +82,7 @@ extern "C" int avt_maxpool_hw3s2_ndhwc_bf16(const void* in, void* out, int bt, i
               "avt_maxpool_hw3s2_ndhwc_bf16: tgroup must split the channels into multiples of 8");
   const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
   const int64_t total = (int64_t)bt * ho * wo * (c / 8);
+  AVT_REQUIRE(total < (1ll << 31), "avt_maxpool_hw3s2_ndhwc_bf16: more than 2^31 output chunks");
   const int64_t blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
   hipLaunchKernelGGL((maxpool_kernel<3, 1>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -131,6 +143,7 @@ extern "C" int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, i
   AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(out), "avt_maxpool_hw2s2_ndhwc_bf16: pointers must be 16-byte aligned");
   const int ho = h / 2, wo = w / 2;  // floor mode: an odd last row / column is dropped
   const int64_t total = (int64_t)bt * ho * wo * (c / 8);
+  AVT_REQUIRE(total < (1ll << 31), "avt_maxpool_hw2s2_ndhwc_bf16: more than 2^31 output chunks");
   const int64_t blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
   hipLaunchKernelGGL((maxpool_kernel<2, 0>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -1,0 +1,208 @@
+// pw_chain — two pointwise (1x1x1) layers of consecutive SLOW-pathway bottlenecks in one pass over the positions:
+//   y = ReLU(W1 x1 + b1 [+ r])      block i's c conv (+ BN) + residual + ReLU      -> block i+1's input (written)
+//   z = ReLU(W2 bf16(y) + b2)       block i+1's a conv (+ BN + ReLU)                -> block i+1's b input (written)
+// (blocks of the third-party SlowFast model the reference runs per clip window,
+// contrastive_video_textures/models/models.py:335, 399).
+//
+// Why: as separate launches both layers sit at the HBM roof (4.7-5.3 TB/s, profiles/r01/probe_fused_per_layer_b128.log)
+// and the second re-reads the y the first has just written — 25 % of the pair's bytes.  Both layers are pointwise, so
+// there is no halo: a wave owns 16 positions from load to store.  The MFMA D layout of the first GEMM (weights as the
+// first operand, output rows permuted in the packing so a lane ends with 8 consecutive channels, include/avt.h) IS the
+// second GEMM's B-operand layout — lane (position n, k-group q) holds channels 32 j + 8 q .. + 7 of k-step j — so y
+// never leaves the registers between the two GEMMs: no LDS round trip, no barrier in the position loop.  Weights are
+// MFMA fragments resident in LDS for the whole launch (workgroups are persistent); where both sets do not fit
+// (512-wide res3) the first layer's fragments come from L2.  HBM-bound by construction:
+// bytes/position = 2 (K1 + N1 [+ N1] + N2).
+#include <stdlib.h>
+
+#include "avt_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct PwArgs {
+  const uint16_t* x1;   // [M, ldx]   first layer's input rows (k1c valid 16-byte chunks each)
+  const uint16_t* res;  // [M, ldr]   residual (HAS_RES)
+  uint16_t* y;          // [M, ldy]
+  uint16_t* z;          // [M, ldz]
+  const i32x4* w1;      // [N1/16][K1S][64 lanes] fragments
+  const i32x4* w2;      // [N2/16][N1/32][64 lanes]
+  const float* b1;      // [N1]
+  const float* b2;      // [N2]
+  int M, ldx, ldr, ldy, ldz, k1c, ntiles;
+};
+
+template <int K1S, int N1, int N2, bool HAS_RES, bool W1_LDS, int NW>
+__global__ __launch_bounds__(NW * 64) void pw_chain_kernel(PwArgs a) {
+  constexpr int NT1 = N1 / 16, NJ = N1 / 32, NT2 = N2 / 16, NCH = N1 / 256;
+  static_assert(N1 % 256 == 0 && N2 % 32 == 0, "first layer in chunks of 256 channels");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* w2l = lds;                                                 // [NT2][NJ] fragments of 1 KB
+  char* w1l = w2l + NT2 * NJ * 1024;                               // [NT1][K1S] (W1_LDS)
+  float* b1l = reinterpret_cast<float*>(w1l + (W1_LDS ? NT1 * K1S * 1024 : 0));
+  float* b2l = b1l + N1;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  for (int f = wid; f < NT2 * NJ; f += NW) *reinterpret_cast<i32x4*>(w2l + f * 1024 + lane * 16) = a.w2[f * 64 + lane];
+  if (W1_LDS)
+    for (int f = wid; f < NT1 * K1S; f += NW) *reinterpret_cast<i32x4*>(w1l + f * 1024 + lane * 16) = a.w1[f * 64 + lane];
+  for (int i = tid; i < N1; i += NW * 64) b1l[i] = a.b1[i];
+  for (int i = tid; i < N2; i += NW * 64) b2l[i] = a.b2[i];
+  __syncthreads();
+
+  for (int tile = blockIdx.x * NW + wid; tile < a.ntiles; tile += gridDim.x * NW) {
+    const int p = tile * 16 + l15;
+    const bool ok = p < a.M;
+    int lofs = lane * 16;  // opaque per tile: the fragment reads are loop-invariant and would be hoisted into (spilled) registers
+    asm volatile("" : "+v"(lofs));
+    const int64_t pc = ok ? p : a.M - 1;
+    bf16x8 xf[K1S];
+    const uint16_t* xrow = a.x1 + pc * a.ldx;
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks) {
+      int chunk = 4 * ks + q;  // past the row's end the weights are zero: any finite value will do
+      chunk = chunk < a.k1c ? chunk : a.k1c - 1;
+      xf[ks] = *reinterpret_cast<const bf16x8*>(xrow + chunk * 8);
+    }
+    f32x4 acc2[NT2];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) acc2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      uint4 rf[8];
+      if (HAS_RES) {
+        const uint16_t* rrow = a.res + pc * a.ldr + c * 256 + 8 * q;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rf[j] = *reinterpret_cast<const uint4*>(rrow + 32 * j);
+      }
+      f32x4 acc1[16];
+#pragma unroll
+      for (int n = 0; n < 16; ++n) acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < K1S; ++ks) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          const int f = (c * 16 + n) * K1S + ks;
+          const bf16x8 wf = W1_LDS ? *reinterpret_cast<const bf16x8*>(w1l + f * 1024 + lofs)
+                                   : *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(a.w1) + f * 1024 + lofs);
+          acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[ks], acc1[n], 0, 0, 0);
+        }
+      }
+      uint16_t* yrow = a.y + pc * a.ldy + c * 256 + 8 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // tiles 2j, 2j+1 -> channels 256 c + 32 j + 8 q .. + 7
+        const float4 ba = *reinterpret_cast<const float4*>(b1l + c * 256 + 32 * j + 8 * q);
+        const float4 bb = *reinterpret_cast<const float4*>(b1l + c * 256 + 32 * j + 8 * q + 4);
+        float v[8] = {acc1[2 * j][0] + ba.x,     acc1[2 * j][1] + ba.y,     acc1[2 * j][2] + ba.z,     acc1[2 * j][3] + ba.w,
+                      acc1[2 * j + 1][0] + bb.x, acc1[2 * j + 1][1] + bb.y, acc1[2 * j + 1][2] + bb.z, acc1[2 * j + 1][3] + bb.w};
+        if (HAS_RES) {
+          v[0] += avt::bf16x2_lo(rf[j].x); v[1] += avt::bf16x2_hi(rf[j].x);
+          v[2] += avt::bf16x2_lo(rf[j].y); v[3] += avt::bf16x2_hi(rf[j].y);
+          v[4] += avt::bf16x2_lo(rf[j].z); v[5] += avt::bf16x2_hi(rf[j].z);
+          v[6] += avt::bf16x2_lo(rf[j].w); v[7] += avt::bf16x2_hi(rf[j].w);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        uint4 o;
+        o.x = avt::pack_bf16x2(v[0], v[1]);
+        o.y = avt::pack_bf16x2(v[2], v[3]);
+        o.z = avt::pack_bf16x2(v[4], v[5]);
+        o.w = avt::pack_bf16x2(v[6], v[7]);
+        if (ok) *reinterpret_cast<uint4*>(yrow + 32 * j) = o;
+        const bf16x8 yf = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+        for (int n = 0; n < NT2; ++n) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w2l + (n * NJ + c * 8 + j) * 1024 + lofs);
+          acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, yf, acc2[n], 0, 0, 0);
+        }
+      }
+    }
+    uint16_t* zrow = a.z + pc * a.ldz + 8 * q;
+#pragma unroll
+    for (int np = 0; np < NT2 / 2; ++np) {
+      const float4 ba = *reinterpret_cast<const float4*>(b2l + 32 * np + 8 * q);
+      const float4 bb = *reinterpret_cast<const float4*>(b2l + 32 * np + 8 * q + 4);
+      float v[8] = {acc2[2 * np][0] + ba.x,     acc2[2 * np][1] + ba.y,     acc2[2 * np][2] + ba.z,     acc2[2 * np][3] + ba.w,
+                    acc2[2 * np + 1][0] + bb.x, acc2[2 * np + 1][1] + bb.y, acc2[2 * np + 1][2] + bb.z, acc2[2 * np + 1][3] + bb.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+      uint4 o;
+      o.x = avt::pack_bf16x2(v[0], v[1]);
+      o.y = avt::pack_bf16x2(v[2], v[3]);
+      o.z = avt::pack_bf16x2(v[4], v[5]);
+      o.w = avt::pack_bf16x2(v[6], v[7]);
+      if (ok) *reinterpret_cast<uint4*>(zrow + 32 * np) = o;
+    }
+  }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+template <int K1S, int N1, int N2, bool HAS_RES, bool W1_LDS, int NW>
+int launch(PwArgs& a, hipStream_t st) {
+  constexpr int lds_bytes = (N2 / 16) * (N1 / 32) * 1024 + (W1_LDS ? (N1 / 16) * K1S * 1024 : 0) + (N1 + N2) * 4;
+  static_assert(lds_bytes <= 160 * 1024, "weights do not fit the LDS");
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_chain_kernel<K1S, N1, N2, HAS_RES, W1_LDS, NW>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_pw_chain_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  static const int per_cu = env_int("AVT_PWC_WGS", (160 * 1024) / lds_bytes >= 2 ? 2 : 1);
+  int grid = 256 * per_cu;
+  const int need = (a.ntiles + NW - 1) / NW;
+  if (grid > need) grid = need;
+  hipLaunchKernelGGL((pw_chain_kernel<K1S, N1, N2, HAS_RES, W1_LDS, NW>), dim3((unsigned)grid), dim3(NW * 64), lds_bytes, st, a);
+  return avt::check_launch("avt_pw_chain_bf16");
+}
+
+}  // namespace
+
+extern "C" int avt_pw_chain_supported(int k1, int n1, int n2, int has_res) {
+  if (k1 == 64 && n1 == 256 && n2 == 64 && has_res) return 1;    // slow res2, identity blocks
+  if (k1 == 144 && n1 == 256 && n2 == 64 && !has_res) return 1;  // slow res2, first block (shortcut folded into K)
+  if (k1 == 128 && n1 == 512 && n2 == 128 && has_res) return 1;  // slow res3
+  return 0;
+}
+
+extern "C" int avt_pw_chain_bf16(const void* x1, int ldx, int k1, const void* w1, const float* b1, const void* res, int ldr,
+                                 void* y, int ldy, int n1, const void* w2, const float* b2, void* z, int ldz, int n2,
+                                 int64_t m, void* stream) {
+  AVT_REQUIRE(x1 && w1 && b1 && y && w2 && b2 && z, "avt_pw_chain_bf16: NULL pointer");
+  AVT_REQUIRE(avt_pw_chain_supported(k1, n1, n2, res != nullptr),
+              "avt_pw_chain_bf16: unsupported shape K1=%d N1=%d N2=%d residual=%d", k1, n1, n2, res != nullptr);
+  AVT_REQUIRE(m > 0 && m < (1ll << 31) - 16, "avt_pw_chain_bf16: bad row count");
+  AVT_REQUIRE(ldx >= k1 && ldy >= n1 && ldz >= n2 && (!res || ldr >= n1) && ldx % 8 == 0 && ldy % 8 == 0 && ldz % 8 == 0 &&
+                  ldr % 8 == 0, "avt_pw_chain_bf16: row strides must cover the channels and be multiples of 8");
+  AVT_REQUIRE(avt::aligned16(x1) && avt::aligned16(w1) && avt::aligned16(b1) && avt::aligned16(res) && avt::aligned16(y) &&
+                  avt::aligned16(w2) && avt::aligned16(b2) && avt::aligned16(z),
+              "avt_pw_chain_bf16: pointers must be 16-byte aligned");
+  PwArgs a;
+  a.x1 = static_cast<const uint16_t*>(x1);
+  a.res = static_cast<const uint16_t*>(res);
+  a.y = static_cast<uint16_t*>(y);
+  a.z = static_cast<uint16_t*>(z);
+  a.w1 = static_cast<const i32x4*>(w1);
+  a.w2 = static_cast<const i32x4*>(w2);
+  a.b1 = b1;
+  a.b2 = b2;
+  a.M = (int)m;
+  a.ldx = ldx;
+  a.ldr = ldr;
+  a.ldy = ldy;
+  a.ldz = ldz;
+  a.k1c = k1 / 8;
+  a.ntiles = (int)((m + 15) / 16);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k1 == 64) return launch<2, 256, 64, true, true, 6>(a, s);    // 146 VGPRs: 3 waves/SIMD = two 6-wave workgroups per CU
+  if (k1 == 144) return launch<5, 256, 64, false, true, 12>(a, s);  // 112 KB of weights: one 12-wave workgroup per CU
+  return launch<4, 512, 128, true, false, 8>(a, s);
+}

@@ -27,6 +27,9 @@ _FUSE_BLOCK = int(os.environ.get("AVT_FUSE_BLOCK", "1"))    # fast-pathway ident
 _C33 = int(os.environ.get("AVT_C33", "1"))                  # slow res2 b conv on the strip-resident kernel
 _FUSE_BC = int(os.environ.get("AVT_FUSE_BC", "0"))          # slow res2 identity blocks: b + c + residual in one kernel
 #   (bit-compatible with the 3-launch path, but 0.84 ms against 0.75 ms: one 7-wave workgroup per CU is latency-bound)
+_CHAIN = int(os.environ.get("AVT_PW_CHAIN", "1"))            # slow res2: c (+ residual) of block i and a of block i+1 in one pass
+_CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "256"))  # widest c to chain (res3's 512: 256 KB of weights do not fit
+#                                                                the LDS, its first layer streams from L2: 0.73 ms vs 0.61 ms)
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
 _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "16"))  # frames walked per workgroup (2 halo frames each)
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
@@ -314,6 +317,24 @@ def pack_c33(wb, device):
     return wb9[row, ch, tap].to(torch.bfloat16).contiguous().to(device)
 
 
+def pack_pw(w, device):
+    """BN-folded pointwise weights [N, K(,1,1,1)] -> csrc/pw_chain.hip's fragments [N/16][ceil(K/32)][64][8]: output
+    rows permuted so a lane ends with 8 consecutive channels (include/avt.h), K zero-padded to whole 32-wide k-steps."""
+    w = w.detach().float().cpu().reshape(w.shape[0], -1)
+    n_out, k = w.shape
+    ks = -(-k // 32)
+    wp = torch.zeros((n_out, ks * 32))
+    wp[:, :k] = w
+    lane = torch.arange(64)
+    n, q = lane & 15, lane >> 4
+    e = torch.arange(8)
+    shape = (n_out // 16, ks, 64, 8)
+    nt = torch.arange(n_out // 16).view(-1, 1, 1, 1)
+    row = (32 * (nt // 2) + 8 * (n >> 2).view(1, 1, -1, 1) + 4 * (nt % 2) + (n & 3).view(1, 1, -1, 1)).expand(shape)
+    col = (torch.arange(ks).view(1, -1, 1, 1) * 32 + q.view(1, 1, -1, 1) * 8 + e.view(1, 1, 1, -1)).expand(shape)
+    return wp[row, col].to(torch.bfloat16).contiguous().to(device)
+
+
 def pack_bc(wb, bb, wc, bc, device):
     """BN-folded b [64,64,1,3,3] and c [256,64,1,1,1] of a slow res2 bottleneck -> the MFMA-fragment order of
     csrc/bc_fused.hip (include/avt.h)."""
@@ -382,7 +403,7 @@ class _Block:
         # first block of a stage with a stride-1 1x1x1 shortcut conv and pointwise a (slow res2): c and the shortcut are
         # ONE GEMM over K = [x | b-output] when b writes its output into spare columns of x's row buffer — no shortcut
         # launch, no residual read (self.extra = columns the caller must leave free behind x)
-        self.ccat, self.extra = None, 0
+        self.ccat, self.extra, self._pw = None, 0, {}
         if (_FUSE_KCAT and self.b1 is not None and self.fused_first is None and self.a.kernel == (1, 1, 1) and
                 self.c.kernel == (1, 1, 1) and self.b1.kernel == (1, 1, 1) and self.a.stride == (1, 1, 1) and
                 self.b.stride == (1, 1, 1) and self.b1.stride == (1, 1, 1) and self.c.stride == (1, 1, 1)):
@@ -391,6 +412,42 @@ class _Block:
                                   folded=(torch.cat([wsc, wc], 1), bc + bsc, (1, 1, 1), (0, 0, 0)))
             self.ccat.alg_flops_per_row = self.c.alg_flops_per_row + self.b1.alg_flops_per_row
             self.extra = self.c.cin
+
+    def can_chain(self, nxt, x):
+        """True when this block's c (+ residual) and the next block's a run as ONE pointwise pass (csrc/pw_chain.hip)."""
+        if not _CHAIN or nxt is None or nxt.b1 is not None or nxt.a.kernel != (1, 1, 1) or nxt.a.stride != (1, 1, 1):
+            return False
+        if self.c.kernel != (1, 1, 1) or self.c._folded is None or nxt.a._folded is None or nxt.a.cin != self.c.cout:
+            return False
+        if self.c.cout > _CHAIN_MAXN:
+            return False
+        if self.fused is not None or self.fused_first is not None or self.bc is not None:
+            return False
+        kcat = self.ccat is not None and x.c0 == 0 and x.ld >= x.C + self.extra and x.C == self.a.cin
+        k1 = x.C + self.extra if kcat else self.c.cin
+        return ops.pw_chain_supported(k1, self.c.cout, nxt.a.cout, not kcat)
+
+    def _chain(self, x1, k1, first, res, nxt, dims):
+        """-> (y, z): y = relu(first(x1) [+ res]) (this block's output), z = relu(nxt.a(y)) (the next block's a)."""
+        key = id(first)
+        if self._pw.get("key") != (key, id(nxt)):
+            self._pw = {"key": (key, id(nxt)), "w1": pack_pw(first._folded[0], self.dev),
+                        "w2": pack_pw(nxt.a._folded[0], self.dev)}
+        m = dims[0] * dims[1] * dims[2] * dims[3]
+        n1, n2 = first.cout, nxt.a.cout
+        y = Act(torch.empty((m, n1), dtype=torch.bfloat16, device=self.dev), dims)
+        z = Act(torch.empty((m, n2), dtype=torch.bfloat16, device=self.dev), dims)
+
+        def launch():
+            ops.pw_chain(x1.ptr, x1.ld, k1, self._pw["w1"], first.bias, res.ptr if res is not None else 0,
+                         res.ld if res is not None else 0, y.ptr, y.ld, n1, self._pw["w2"], nxt.a.bias, z.ptr, z.ld, n2, m)
+
+        if PROFILER is None:
+            launch()
+        else:
+            PROFILER("conv3d_igemm_bf16", launch, m * (first.alg_flops_per_row + nxt.a.alg_flops_per_row),
+                     2.0 * m * (k1 + n1 * (2 if res is not None else 1) + n2))
+        return y, z
 
     def _b(self, m, out=None):
         """The block's b conv: the strip-resident kernel for 64 -> 64 at the production width, else the implicit GEMM."""
@@ -410,10 +467,20 @@ class _Block:
             return out
         return self.b(m, out=out)
 
-    def __call__(self, x, out=None):
+    def __call__(self, x, out=None, chain=None, a_pre=None):
+        """chain = the next block (can_chain(...) holds): returns (y, a-output of the next block); a_pre = this block's
+        a-output when the previous block's chained pass has already produced it."""
         if self.ccat is not None and x.c0 == 0 and x.ld >= x.C + self.extra and x.C == self.a.cin:
             self._b(self.a(x), out=Act(x.buf, x.dims, x.C, self.extra))  # b's output lands behind x in the same rows
+            if chain is not None:
+                return self._chain(Act(x.buf, x.dims, 0, x.C + self.extra), x.C + self.extra, self.ccat, None, chain, x.dims)
             return self.ccat(Act(x.buf, x.dims, 0, x.C + self.extra), out=out)
+        if chain is not None or a_pre is not None:
+            sc = self.b1(x) if self.b1 is not None else x
+            m = self._b(a_pre if a_pre is not None else self.a(x))
+            if chain is not None:
+                return self._chain(m, self.c.cin, self.c, sc, chain, m.dims)
+            return self.c(m, out=out, res=sc, relu=True)
         if (self.bc is not None and x.c0 == 0 and ops.bc_fused_supported(self.b.cin, self.c.cout, x.dims[3]) and
                 x.C == self.c.cout):
             b, t, h, w = x.dims
@@ -567,17 +634,23 @@ class SlowFastMFMA(nn.Module):
             for blk in fast_blocks:
                 f_act = blk(f_act)
             last = k == len(self.stages) - 1
+            pre = None  # the a-output of the coming block, when the previous block's chained pass produced it
             for i, blk in enumerate(slow_blocks):
+                nxt = slow_blocks[i + 1] if i + 1 < len(slow_blocks) else None
+                if blk.can_chain(nxt, s_act):
+                    s_act, pre = blk(s_act, chain=nxt, a_pre=pre)
+                    continue
+                a_pre, pre = pre, None
                 if i == len(slow_blocks) - 1 and not last:
                     # last slow block of the stage writes straight into the next fusion's concat buffer
                     od = blk.b.out_dims(blk.a.out_dims(s_act.dims))
                     cs, cf = blk.c.cout, f_act.C
                     sbuf = torch.empty((od[0] * od[1] * od[2] * od[3], cs + 2 * cf), dtype=torch.bfloat16, device=self.dev)
-                    blk(s_act, out=Act(sbuf, od, 0, cs))
+                    blk(s_act, out=Act(sbuf, od, 0, cs), a_pre=a_pre)
                     self.fuse[k + 1](f_act, out=Act(sbuf, od, cs, 2 * cf))
                     s_act = Act(sbuf, od)
                 else:
-                    s_act = blk(s_act)
+                    s_act = blk(s_act, a_pre=a_pre)
         # head (models.py:576-580 surgery): global average pool per pathway, concat slow | fast
         emb = torch.empty((b, s_act.C + f_act.C), dtype=torch.float32, device=self.dev)
         ops.mean_positions(s_act.ptr, b, s_act.buf.shape[0] // b, s_act.C, s_act.ld, emb, 0)

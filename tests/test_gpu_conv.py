@@ -436,3 +436,66 @@ def test_conv33_c64_matches_igemm_and_torch(avt, dev, dims, relu):
         ref = F.relu(ref) if relu else ref
     g5 = got.float().cpu().view(b, t, h, w, 64).permute(0, 4, 1, 2, 3)
     assert (g5 - ref).abs().max().item() < 0.02 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("k1,n1,n2,has_res,m", [(64, 256, 64, True, 16 * 50 + 5), (144, 256, 64, False, 16 * 37 + 11),
+                                                 (128, 512, 128, True, 16 * 41 + 1), (64, 256, 64, True, 7)])
+def test_pw_chain_matches_two_launches_and_torch(avt, dev, k1, n1, n2, has_res, m):
+    """csrc/pw_chain.hip (block i's c + residual + ReLU and block i+1's a + ReLU in one pass, y in registers between
+    the GEMMs) vs the two implicit-GEMM launches on the same folded weights and vs fp32 torch; ragged last tile,
+    row strides wider than the channels, nothing written outside the slices."""
+    from avtex.fused_slowfast import Act, FusedConv, pack_pw
+
+    torch.manual_seed(k1 + m)
+    def layer(cin, cout):
+        conv = nn.Conv3d(cin, cout, 1, bias=False)
+        bn = nn.BatchNorm3d(cout).eval()
+        with torch.no_grad():
+            bn.weight.uniform_(0.6, 1.2); bn.bias.uniform_(-0.2, 0.2)
+            bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.8, 1.2)
+        return conv, bn
+    (c1, bn1), (c2, bn2) = layer(k1, n1), layer(n1, n2)
+    f1, f2 = FusedConv(c1, bn1, True, dev), FusedConv(c2, bn2, True, dev)
+    dims = (1, 1, 1, m)
+    ldx, ldr, ldy, ldz = k1 + 16, n1 + 8, n1 + 24, n2 + 8
+    xw = torch.randn(m, ldx).to(torch.bfloat16).to(dev)
+    rw = torch.randn(m, ldr).to(torch.bfloat16).to(dev)
+    x, r = Act(xw, dims, 8, k1), Act(rw, dims, 8, n1)
+    y_ref = f1(x, res=r if has_res else None, relu=True)
+    z_ref = f2(y_ref)
+    yw = torch.full((m, ldy), 3.0, dtype=torch.bfloat16, device=dev)
+    zw = torch.full((m, ldz), 3.0, dtype=torch.bfloat16, device=dev)
+    assert avt.ops.pw_chain_supported(k1, n1, n2, has_res)
+    avt.ops.pw_chain(x.ptr, ldx, k1, pack_pw(f1._folded[0], dev), f1.bias, r.ptr if has_res else 0, ldr if has_res else 0,
+                     yw.data_ptr() + 2 * 16, ldy, n1, pack_pw(f2._folded[0], dev), f2.bias, zw.data_ptr() + 2 * 8, ldz, n2, m)
+    torch.cuda.synchronize()
+    assert (yw[:, :16] == 3).all() and (yw[:, 16 + n1:] == 3).all() and (zw[:, :8] == 3).all()
+    y, z = yw[:, 16:16 + n1], zw[:, 8:8 + n2]
+    for got, ref in ((y, y_ref.buf), (z, z_ref.buf)):
+        scale = max(ref.float().abs().max().item(), 1.0)
+        assert (got.float() - ref.float()).abs().max().item() <= 0.02 * scale
+    # the implicit GEMM rounds conv + bias to bf16 BEFORE the residual add (two roundings); the chained pass adds the
+    # residual in fp32 (one rounding).  Pin it against an fp64 evaluation on the same bf16 weights instead:
+    ye = xw[:, 8:8 + k1].double() @ f1.wt.double().t() + f1.bias.double()
+    if has_res:
+        ye = ye + rw[:, 8:8 + n1].double()
+    ye = ye.clamp_min(0).float().to(torch.bfloat16)
+    assert (y != ye).float().mean().item() < 0.01  # only fp32 summation-order effects at rounding boundaries
+    ze = (y.double() @ f2.wt.double().t() + f2.bias.double()).clamp_min(0).float().to(torch.bfloat16)
+    assert (z != ze).float().mean().item() < 0.01
+    if not has_res:
+        assert (y != y_ref.buf).float().mean().item() < 0.05  # same products, different fp32 summation order
+    with torch.no_grad():
+        xin = xw[:, 8:8 + k1].float().cpu().t().reshape(1, k1, 1, 1, m)
+        t = bn1(c1(xin))
+        if has_res:
+            t = t + rw[:, 8:8 + n1].float().cpu().t().reshape(1, n1, 1, 1, m)
+        t = F.relu(t)
+        t2 = F.relu(bn2(c2(t)))
+    assert (y.float().cpu().t().reshape(1, n1, 1, 1, m) - t).abs().max().item() < 0.03 * max(t.abs().max().item(), 1.0)
+    assert (z.float().cpu().t().reshape(1, n2, 1, 1, m) - t2).abs().max().item() < 0.03 * max(t2.abs().max().item(), 1.0)
+    assert not avt.ops.pw_chain_supported(64, 256, 64, False)
+    from avtex._lib import AvtError
+    with pytest.raises(AvtError):
+        avt.ops.pw_chain(x.ptr, ldx, 72, pack_pw(f1._folded[0], dev), f1.bias, 0, 0, yw.data_ptr(), ldy, n1,
+                         pack_pw(f2._folded[0], dev), f2.bias, zw.data_ptr(), ldz, n2, m)

@@ -60,6 +60,11 @@ def spy_c33(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu=True):
     shapes.append("strip-resident 3x3 64->64 in(%d, %d, %d, %d)" % (batch, t, h, w))
     return orig_c33(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu)
 avtex.ops.conv33_c64 = spy_c33
+orig_pw = avtex.ops.pw_chain
+def spy_pw(x1_ptr, ldx, k1, w1, b1, res_ptr, ldr, y_ptr, ldy, n1, w2, b2, z_ptr, ldz, n2, m_):
+    shapes.append("pointwise chain %d->%d%s ->%d rows %d" % (k1, n1, " +res" if res_ptr else "", n2, m_))
+    return orig_pw(x1_ptr, ldx, k1, w1, b1, res_ptr, ldr, y_ptr, ldy, n1, w2, b2, z_ptr, ldz, n2, m_)
+avtex.ops.pw_chain = spy_pw
 avtex.ops.conv3d_igemm = spy
 fsf.ops.conv3d_igemm = spy
 fsf.PROFILER = hook
