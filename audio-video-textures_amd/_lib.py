@@ -45,9 +45,9 @@ SIGNATURES = {
     "avt_pairwise_l2_f32": [_vp, C.c_int, C.c_int64, _vp, _vp],
     "avt_conv33_c64_supported": [C.c_int] * 3,
     "avt_conv33_c64_bf16": [_vp] * 4 + [C.c_int] * 6 + [_vp],
-    "avt_pw_chain_supported": [C.c_int] * 4,
-    "avt_pw_chain_bf16": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int,
-                          C.c_int, C.c_int64, _vp],
+    "avt_pw_chain_supported": [C.c_int] * 5,
+    "avt_pw_chain_bf16": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int,
+                          _vp, _vp, _vp, C.c_int, C.c_int, C.c_int64, _vp],
     "avt_logmel_f64": [_vp, C.c_int, C.c_int64, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp],
     "avt_logmel_examples_f32": [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "avt_infonce_fwd": [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp, _vp],

@@ -1,6 +1,8 @@
 // pw_chain — two pointwise (1x1x1) layers of consecutive SLOW-pathway bottlenecks in one pass over the positions:
 //   y = ReLU(W1 x1 + b1 [+ r])      block i's c conv (+ BN) + residual + ReLU      -> block i+1's input (written)
-//   z = ReLU(W2 bf16(y) + b2)       block i+1's a conv (+ BN + ReLU)                -> block i+1's b input (written)
+//   z = ReLU(W2 [bf16(y) | x2] + b2) block i+1's a conv (+ BN + ReLU)                -> block i+1's b input (written)
+// (x2: further input channels of the second layer that sit next to y in the row — the lateral fast->slow features of
+// the stage boundary res2 -> res3, where a consumes the concat [y | lateral])
 // (blocks of the third-party SlowFast model the reference runs per clip window,
 // contrastive_video_textures/models/models.py:335, 399).
 //
@@ -26,18 +28,19 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 struct PwArgs {
   const uint16_t* x1;   // [M, ldx]   first layer's input rows (k1c valid 16-byte chunks each)
   const uint16_t* res;  // [M, ldr]   residual (HAS_RES)
+  const uint16_t* x2;   // [M, ldx2]  K2X*32 more input channels of the second layer (K2X > 0)
   uint16_t* y;          // [M, ldy]
   uint16_t* z;          // [M, ldz]
   const i32x4* w1;      // [N1/16][K1S][64 lanes] fragments
-  const i32x4* w2;      // [N2/16][N1/32][64 lanes]
+  const i32x4* w2;      // [N2/16][N1/32 + K2X][64 lanes]
   const float* b1;      // [N1]
   const float* b2;      // [N2]
-  int M, ldx, ldr, ldy, ldz, k1c, ntiles;
+  int M, ldx, ldr, ldy, ldz, ldx2, k1c, ntiles;
 };
 
-template <int K1S, int N1, int N2, bool HAS_RES, bool W1_LDS, int NW>
+template <int K1S, int N1, int N2, bool HAS_RES, bool W1_LDS, int NW, int K2X>
 __global__ __launch_bounds__(NW * 64) void pw_chain_kernel(PwArgs a) {
-  constexpr int NT1 = N1 / 16, NJ = N1 / 32, NT2 = N2 / 16, NCH = N1 / 256;
+  constexpr int NT1 = N1 / 16, NJ = N1 / 32 + K2X, NT2 = N2 / 16, NCH = N1 / 256;
   static_assert(N1 % 256 == 0 && N2 % 32 == 0, "first layer in chunks of 256 channels");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* w2l = lds;                                                 // [NT2][NJ] fragments of 1 KB
@@ -68,6 +71,11 @@ __global__ __launch_bounds__(NW * 64) void pw_chain_kernel(PwArgs a) {
       int chunk = 4 * ks + q;  // past the row's end the weights are zero: any finite value will do
       chunk = chunk < a.k1c ? chunk : a.k1c - 1;
       xf[ks] = *reinterpret_cast<const bf16x8*>(xrow + chunk * 8);
+    }
+    bf16x8 x2f[K2X > 0 ? K2X : 1];
+    if (K2X > 0) {
+#pragma unroll
+      for (int ks = 0; ks < K2X; ++ks) x2f[ks] = *reinterpret_cast<const bf16x8*>(a.x2 + pc * a.ldx2 + 32 * ks + 8 * q);
     }
     f32x4 acc2[NT2];
 #pragma unroll
@@ -122,6 +130,16 @@ __global__ __launch_bounds__(NW * 64) void pw_chain_kernel(PwArgs a) {
         }
       }
     }
+    if (K2X > 0) {
+#pragma unroll
+      for (int ks = 0; ks < K2X; ++ks) {
+#pragma unroll
+        for (int n = 0; n < NT2; ++n) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w2l + (n * NJ + N1 / 32 + ks) * 1024 + lofs);
+          acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, x2f[ks], acc2[n], 0, 0, 0);
+        }
+      }
+    }
     uint16_t* zrow = a.z + pc * a.ldz + 8 * q;
 #pragma unroll
     for (int np = 0; np < NT2 / 2; ++np) {
@@ -146,11 +164,11 @@ int env_int(const char* name, int dflt) {
   return s ? atoi(s) : dflt;
 }
 
-template <int K1S, int N1, int N2, bool HAS_RES, bool W1_LDS, int NW>
+template <int K1S, int N1, int N2, bool HAS_RES, bool W1_LDS, int NW, int K2X = 0>
 int launch(PwArgs& a, hipStream_t st) {
-  constexpr int lds_bytes = (N2 / 16) * (N1 / 32) * 1024 + (W1_LDS ? (N1 / 16) * K1S * 1024 : 0) + (N1 + N2) * 4;
+  constexpr int lds_bytes = (N2 / 16) * (N1 / 32 + K2X) * 1024 + (W1_LDS ? (N1 / 16) * K1S * 1024 : 0) + (N1 + N2) * 4;
   static_assert(lds_bytes <= 160 * 1024, "weights do not fit the LDS");
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_chain_kernel<K1S, N1, N2, HAS_RES, W1_LDS, NW>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_chain_kernel<K1S, N1, N2, HAS_RES, W1_LDS, NW, K2X>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_pw_chain_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
@@ -160,34 +178,39 @@ int launch(PwArgs& a, hipStream_t st) {
   int grid = 256 * per_cu;
   const int need = (a.ntiles + NW - 1) / NW;
   if (grid > need) grid = need;
-  hipLaunchKernelGGL((pw_chain_kernel<K1S, N1, N2, HAS_RES, W1_LDS, NW>), dim3((unsigned)grid), dim3(NW * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((pw_chain_kernel<K1S, N1, N2, HAS_RES, W1_LDS, NW, K2X>), dim3((unsigned)grid), dim3(NW * 64), lds_bytes, st, a);
   return avt::check_launch("avt_pw_chain_bf16");
 }
 
 }  // namespace
 
-extern "C" int avt_pw_chain_supported(int k1, int n1, int n2, int has_res) {
-  if (k1 == 64 && n1 == 256 && n2 == 64 && has_res) return 1;    // slow res2, identity blocks
-  if (k1 == 144 && n1 == 256 && n2 == 64 && !has_res) return 1;  // slow res2, first block (shortcut folded into K)
-  if (k1 == 128 && n1 == 512 && n2 == 128 && has_res) return 1;  // slow res3
+extern "C" int avt_pw_chain_supported(int k1, int n1, int n2, int has_res, int k2x) {
+  if (k1 == 64 && n1 == 256 && n2 == 64 && has_res && !k2x) return 1;    // slow res2, identity blocks
+  if (k1 == 144 && n1 == 256 && n2 == 64 && !has_res && !k2x) return 1;  // slow res2, first block (shortcut folded into K)
+  if (k1 == 64 && n1 == 256 && n2 == 128 && has_res && k2x == 64) return 1;  // res2 -> res3: a reads [y | lateral]
+  if (k1 == 128 && n1 == 512 && n2 == 128 && has_res && !k2x) return 1;  // slow res3
   return 0;
 }
 
 extern "C" int avt_pw_chain_bf16(const void* x1, int ldx, int k1, const void* w1, const float* b1, const void* res, int ldr,
-                                 void* y, int ldy, int n1, const void* w2, const float* b2, void* z, int ldz, int n2,
-                                 int64_t m, void* stream) {
+                                 void* y, int ldy, int n1, const void* x2, int ldx2, int k2x, const void* w2, const float* b2,
+                                 void* z, int ldz, int n2, int64_t m, void* stream) {
   AVT_REQUIRE(x1 && w1 && b1 && y && w2 && b2 && z, "avt_pw_chain_bf16: NULL pointer");
-  AVT_REQUIRE(avt_pw_chain_supported(k1, n1, n2, res != nullptr),
-              "avt_pw_chain_bf16: unsupported shape K1=%d N1=%d N2=%d residual=%d", k1, n1, n2, res != nullptr);
+  AVT_REQUIRE(avt_pw_chain_supported(k1, n1, n2, res != nullptr, x2 ? k2x : 0),
+              "avt_pw_chain_bf16: unsupported shape K1=%d N1=%d N2=%d residual=%d K2X=%d", k1, n1, n2, res != nullptr,
+              x2 ? k2x : 0);
   AVT_REQUIRE(m > 0 && m < (1ll << 31) - 16, "avt_pw_chain_bf16: bad row count");
   AVT_REQUIRE(ldx >= k1 && ldy >= n1 && ldz >= n2 && (!res || ldr >= n1) && ldx % 8 == 0 && ldy % 8 == 0 && ldz % 8 == 0 &&
-                  ldr % 8 == 0, "avt_pw_chain_bf16: row strides must cover the channels and be multiples of 8");
+                  ldr % 8 == 0 && (!x2 || (ldx2 >= k2x && ldx2 % 8 == 0)),
+              "avt_pw_chain_bf16: row strides must cover the channels and be multiples of 8");
   AVT_REQUIRE(avt::aligned16(x1) && avt::aligned16(w1) && avt::aligned16(b1) && avt::aligned16(res) && avt::aligned16(y) &&
-                  avt::aligned16(w2) && avt::aligned16(b2) && avt::aligned16(z),
+                  avt::aligned16(w2) && avt::aligned16(b2) && avt::aligned16(z) && avt::aligned16(x2),
               "avt_pw_chain_bf16: pointers must be 16-byte aligned");
   PwArgs a;
   a.x1 = static_cast<const uint16_t*>(x1);
   a.res = static_cast<const uint16_t*>(res);
+  a.x2 = static_cast<const uint16_t*>(x2);
+  a.ldx2 = ldx2;
   a.y = static_cast<uint16_t*>(y);
   a.z = static_cast<uint16_t*>(z);
   a.w1 = static_cast<const i32x4*>(w1);
@@ -202,6 +225,7 @@ extern "C" int avt_pw_chain_bf16(const void* x1, int ldx, int k1, const void* w1
   a.k1c = k1 / 8;
   a.ntiles = (int)((m + 15) / 16);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k1 == 64 && x2) return launch<2, 256, 128, true, true, 12, 2>(a, s);  // 112 KB of weights
   if (k1 == 64) return launch<2, 256, 64, true, true, 6>(a, s);    // 146 VGPRs: 3 waves/SIMD = two 6-wave workgroups per CU
   if (k1 == 144) return launch<5, 256, 64, false, true, 12>(a, s);  // 112 KB of weights: one 12-wave workgroup per CU
   return launch<4, 512, 128, true, false, 8>(a, s);

@@ -414,39 +414,44 @@ class _Block:
             self.extra = self.c.cin
 
     def can_chain(self, nxt, x):
-        """True when this block's c (+ residual) and the next block's a run as ONE pointwise pass (csrc/pw_chain.hip)."""
-        if not _CHAIN or nxt is None or nxt.b1 is not None or nxt.a.kernel != (1, 1, 1) or nxt.a.stride != (1, 1, 1):
+        """True when this block's c (+ residual) and the next block's a run as ONE pointwise pass (csrc/pw_chain.hip).
+        nxt may be the first block of the next stage: its a then also reads the lateral features behind y (x2)."""
+        if not _CHAIN or nxt is None or nxt.a.kernel != (1, 1, 1) or nxt.a.stride != (1, 1, 1):
             return False
-        if self.c.kernel != (1, 1, 1) or self.c._folded is None or nxt.a._folded is None or nxt.a.cin != self.c.cout:
+        if self.c.kernel != (1, 1, 1) or self.c._folded is None or nxt.a._folded is None or nxt.a.cin < self.c.cout:
             return False
         if self.c.cout > _CHAIN_MAXN:
             return False
-        if self.fused is not None or self.fused_first is not None or self.bc is not None:
+        if any(v is not None for v in (self.fused, self.fused_first, self.bc, nxt.fused, nxt.fused_first, nxt.bc, nxt.ccat)):
             return False
         kcat = self.ccat is not None and x.c0 == 0 and x.ld >= x.C + self.extra and x.C == self.a.cin
         k1 = x.C + self.extra if kcat else self.c.cin
-        return ops.pw_chain_supported(k1, self.c.cout, nxt.a.cout, not kcat)
+        return ops.pw_chain_supported(k1, self.c.cout, nxt.a.cout, not kcat, nxt.a.cin - self.c.cout)
 
-    def _chain(self, x1, k1, first, res, nxt, dims):
-        """-> (y, z): y = relu(first(x1) [+ res]) (this block's output), z = relu(nxt.a(y)) (the next block's a)."""
-        key = id(first)
-        if self._pw.get("key") != (key, id(nxt)):
-            self._pw = {"key": (key, id(nxt)), "w1": pack_pw(first._folded[0], self.dev),
-                        "w2": pack_pw(nxt.a._folded[0], self.dev)}
+    def _chain(self, x1, k1, first, res, nxt, dims, y=None, x2=None):
+        """-> (y, z): y = relu(first(x1) [+ res]) (this block's output), z = relu(nxt.a([y | x2])) (the next block's a)."""
+        key = (id(first), id(nxt))
+        if self._pw.get("key") != key:
+            self._pw = {"key": key, "w1": pack_pw(first._folded[0], self.dev), "w2": pack_pw(nxt.a._folded[0], self.dev)}
         m = dims[0] * dims[1] * dims[2] * dims[3]
         n1, n2 = first.cout, nxt.a.cout
-        y = Act(torch.empty((m, n1), dtype=torch.bfloat16, device=self.dev), dims)
+        k2x = nxt.a.cin - n1
+        if (k2x > 0) != (x2 is not None) or (x2 is not None and x2.C != k2x):
+            raise AvtError("pw_chain: the next a conv reads %d channels, got y (%d) + x2 (%s)" % (nxt.a.cin, n1, x2 and x2.C))
+        if y is None:
+            y = Act(torch.empty((m, n1), dtype=torch.bfloat16, device=self.dev), dims)
         z = Act(torch.empty((m, n2), dtype=torch.bfloat16, device=self.dev), dims)
 
         def launch():
             ops.pw_chain(x1.ptr, x1.ld, k1, self._pw["w1"], first.bias, res.ptr if res is not None else 0,
-                         res.ld if res is not None else 0, y.ptr, y.ld, n1, self._pw["w2"], nxt.a.bias, z.ptr, z.ld, n2, m)
+                         res.ld if res is not None else 0, y.ptr, y.ld, n1, self._pw["w2"], nxt.a.bias, z.ptr, z.ld, n2, m,
+                         x2_ptr=x2.ptr if x2 is not None else 0, ldx2=x2.ld if x2 is not None else 0, k2x=k2x)
 
         if PROFILER is None:
             launch()
         else:
             PROFILER("conv3d_igemm_bf16", launch, m * (first.alg_flops_per_row + nxt.a.alg_flops_per_row),
-                     2.0 * m * (k1 + n1 * (2 if res is not None else 1) + n2))
+                     2.0 * m * (k1 + n1 * (2 if res is not None else 1) + k2x + n2))
         return y, z
 
     def _b(self, m, out=None):
@@ -467,9 +472,10 @@ class _Block:
             return out
         return self.b(m, out=out)
 
-    def __call__(self, x, out=None, chain=None, a_pre=None):
-        """chain = the next block (can_chain(...) holds): returns (y, a-output of the next block); a_pre = this block's
-        a-output when the previous block's chained pass has already produced it."""
+    def __call__(self, x, out=None, chain=None, a_pre=None, x2=None):
+        """chain = the next block (can_chain(...) holds): returns (y, a-output of the next block) — y written to `out`
+        when given, x2 = the further inputs of that a conv (stage boundary); a_pre = this block's a-output when the
+        previous block's chained pass has already produced it."""
         if self.ccat is not None and x.c0 == 0 and x.ld >= x.C + self.extra and x.C == self.a.cin:
             self._b(self.a(x), out=Act(x.buf, x.dims, x.C, self.extra))  # b's output lands behind x in the same rows
             if chain is not None:
@@ -479,7 +485,7 @@ class _Block:
             sc = self.b1(x) if self.b1 is not None else x
             m = self._b(a_pre if a_pre is not None else self.a(x))
             if chain is not None:
-                return self._chain(m, self.c.cin, self.c, sc, chain, m.dims)
+                return self._chain(m, self.c.cin, self.c, sc, chain, m.dims, y=out, x2=x2)
             return self.c(m, out=out, res=sc, relu=True)
         if (self.bc is not None and x.c0 == 0 and ops.bc_fused_supported(self.b.cin, self.c.cout, x.dims[3]) and
                 x.C == self.c.cout):
@@ -630,11 +636,11 @@ class SlowFastMFMA(nn.Module):
         self._stem(self.stem_s, slow, out=Act(sbuf, ds, 0, cs))
         self.fuse[0](f_act, out=Act(sbuf, ds, cs, 2 * cf))
         s_act = Act(sbuf, ds, 0, cs + 2 * cf)
+        pre = None  # the a-output of the coming slow block, when the previous block's chained pass produced it
         for k, (slow_blocks, fast_blocks) in enumerate(self.stages):
             for blk in fast_blocks:
                 f_act = blk(f_act)
             last = k == len(self.stages) - 1
-            pre = None  # the a-output of the coming block, when the previous block's chained pass produced it
             for i, blk in enumerate(slow_blocks):
                 nxt = slow_blocks[i + 1] if i + 1 < len(slow_blocks) else None
                 if blk.can_chain(nxt, s_act):
@@ -646,8 +652,14 @@ class SlowFastMFMA(nn.Module):
                     od = blk.b.out_dims(blk.a.out_dims(s_act.dims))
                     cs, cf = blk.c.cout, f_act.C
                     sbuf = torch.empty((od[0] * od[1] * od[2] * od[3], cs + 2 * cf), dtype=torch.bfloat16, device=self.dev)
-                    blk(s_act, out=Act(sbuf, od, 0, cs), a_pre=a_pre)
-                    self.fuse[k + 1](f_act, out=Act(sbuf, od, cs, 2 * cf))
+                    nxt0 = self.stages[k + 1][0][0]
+                    if blk.can_chain(nxt0, s_act):
+                        # ... and the next stage's first a conv reads [y | lateral]: lateral first, then one chained pass
+                        self.fuse[k + 1](f_act, out=Act(sbuf, od, cs, 2 * cf))
+                        _, pre = blk(s_act, out=Act(sbuf, od, 0, cs), chain=nxt0, a_pre=a_pre, x2=Act(sbuf, od, cs, 2 * cf))
+                    else:
+                        blk(s_act, out=Act(sbuf, od, 0, cs), a_pre=a_pre)
+                        self.fuse[k + 1](f_act, out=Act(sbuf, od, cs, 2 * cf))
                     s_act = Act(sbuf, od)
                 else:
                     s_act = blk(s_act, a_pre=a_pre)

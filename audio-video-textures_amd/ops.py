@@ -303,21 +303,22 @@ def conv33_c64(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu=True):
                                               int(h), int(w), int(ldo), int(bool(relu)), _stream()), "avt_conv33_c64_bf16")
 
 
-def pw_chain_supported(k1, n1, n2, has_res):
-    return bool(_lib.lib().avt_pw_chain_supported(int(k1), int(n1), int(n2), int(bool(has_res))))
+def pw_chain_supported(k1, n1, n2, has_res, k2x=0):
+    return bool(_lib.lib().avt_pw_chain_supported(int(k1), int(n1), int(n2), int(bool(has_res)), int(k2x)))
 
 
-def pw_chain(x1_ptr, ldx, k1, w1, b1, res_ptr, ldr, y_ptr, ldy, n1, w2, b2, z_ptr, ldz, n2, m):
-    """y = relu(W1 x1 + b1 [+ res]); z = relu(W2 y + b2) in one pass (csrc/pw_chain.hip); w1, w2 =
-    fused_slowfast.pack_pw(...) fragments; res_ptr 0 = no residual."""
+def pw_chain(x1_ptr, ldx, k1, w1, b1, res_ptr, ldr, y_ptr, ldy, n1, w2, b2, z_ptr, ldz, n2, m, x2_ptr=0, ldx2=0, k2x=0):
+    """y = relu(W1 x1 + b1 [+ res]); z = relu(W2 [y | x2] + b2) in one pass (csrc/pw_chain.hip); w1, w2 =
+    fused_slowfast.pack_pw(...) fragments; res_ptr 0 = no residual; x2_ptr 0 = the second layer reads y only."""
     _dev(w1, "w1", torch.bfloat16)
     _dev(w2, "w2", torch.bfloat16)
     _dev(b1, "b1", torch.float32)
     _dev(b2, "b2", torch.float32)
     _lib.check(_lib.lib().avt_pw_chain_bf16(C.c_void_p(x1_ptr), int(ldx), int(k1), _p(w1), _p(b1),
                                             C.c_void_p(res_ptr) if res_ptr else None, int(ldr), C.c_void_p(y_ptr), int(ldy),
-                                            int(n1), _p(w2), _p(b2), C.c_void_p(z_ptr), int(ldz), int(n2), int(m),
-                                            _stream()), "avt_pw_chain_bf16")
+                                            int(n1), C.c_void_p(x2_ptr) if x2_ptr else None, int(ldx2), int(k2x), _p(w2),
+                                            _p(b2), C.c_void_p(z_ptr), int(ldz), int(n2), int(m), _stream()),
+               "avt_pw_chain_bf16")
 
 
 def maxpool_hw2s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo):

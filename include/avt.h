@@ -314,16 +314,18 @@ int avt_conv33_c64_bf16(const void* in, const void* wb, const float* bias, void*
 
 /* Two pointwise layers of consecutive slow-pathway bottlenecks in one pass over the rows (csrc/pw_chain.hip; same
  * model, models/models.py:335, 399):  y = ReLU(W1 x1 + b1 [+ res])  (block i's c conv + BN + residual + ReLU) and
- * z = ReLU(W2 bf16(y) + b2)  (block i+1's a conv + BN + ReLU); y stays in registers between the two GEMMs.
- * x1 [m, ldx] (k1 channels used), res [m, ldr] or NULL, y [m, ldy] (n1 channels), z [m, ldz] (n2 channels), bf16
- * rows, strides in elements.  w1 [n1/16][ceil(k1/32)][64][8], w2 [n2/16][n1/32][64][8]: MFMA fragments with the
+ * z = ReLU(W2 [bf16(y) | x2] + b2)  (block i+1's a conv + BN + ReLU); y stays in registers between the two GEMMs.
+ * x1 [m, ldx] (k1 channels used), res [m, ldr] or NULL, y [m, ldy] (n1 channels), x2 [m, ldx2] or NULL (k2x more
+ * input channels of the second layer: the lateral features at the res2 -> res3 boundary), z [m, ldz] (n2 channels),
+ * bf16 rows, strides in elements.  w1 [n1/16][ceil(k1/32)][64][8], w2 [n2/16][(n1 + k2x)/32][64][8]: MFMA fragments with the
  * output rows permuted (tile nt, row r -> channel 32*(nt/2) + 8*(r/4) + 4*(nt%2) + r%4, k = 32*ks + 8*q + e,
  * zero beyond k1); b1 [n1], b2 [n2] fp32 in channel order.
- * avt_pw_chain_supported(k1, n1, n2, has_res): (64, 256, 64, 1), (144, 256, 64, 0), (128, 512, 128, 1). */
-int avt_pw_chain_supported(int k1, int n1, int n2, int has_res);
+ * avt_pw_chain_supported(k1, n1, n2, has_res, k2x): (64, 256, 64, 1, 0), (144, 256, 64, 0, 0), (64, 256, 128, 1, 64),
+ * (128, 512, 128, 1, 0). */
+int avt_pw_chain_supported(int k1, int n1, int n2, int has_res, int k2x);
 int avt_pw_chain_bf16(const void* x1, int ldx, int k1, const void* w1, const float* b1, const void* res, int ldr,
-                      void* y, int ldy, int n1, const void* w2, const float* b2, void* z, int ldz, int n2,
-                      int64_t m, void* stream);
+                      void* y, int ldy, int n1, const void* x2, int ldx2, int k2x, const void* w2, const float* b2,
+                      void* z, int ldz, int n2, int64_t m, void* stream);
 
 /* VGGish audio front-end (utils/mel_features.py:21-92, 176-205 log_mel_spectrogram; called once per
  * video from utils/vggish_utils.py:27-69), float64 like the reference's NumPy code:

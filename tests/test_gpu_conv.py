@@ -438,9 +438,10 @@ def test_conv33_c64_matches_igemm_and_torch(avt, dev, dims, relu):
     assert (g5 - ref).abs().max().item() < 0.02 * max(ref.abs().max().item(), 1.0)
 
 
-@pytest.mark.parametrize("k1,n1,n2,has_res,m", [(64, 256, 64, True, 16 * 50 + 5), (144, 256, 64, False, 16 * 37 + 11),
-                                                 (128, 512, 128, True, 16 * 41 + 1), (64, 256, 64, True, 7)])
-def test_pw_chain_matches_two_launches_and_torch(avt, dev, k1, n1, n2, has_res, m):
+@pytest.mark.parametrize("k1,n1,n2,has_res,m,k2x", [(64, 256, 64, True, 16 * 50 + 5, 0), (144, 256, 64, False, 16 * 37 + 11, 0),
+                                                     (128, 512, 128, True, 16 * 41 + 1, 0), (64, 256, 64, True, 7, 0),
+                                                     (64, 256, 128, True, 16 * 23 + 9, 64)])
+def test_pw_chain_matches_two_launches_and_torch(avt, dev, k1, n1, n2, has_res, m, k2x):
     """csrc/pw_chain.hip (block i's c + residual + ReLU and block i+1's a + ReLU in one pass, y in registers between
     the GEMMs) vs the two implicit-GEMM launches on the same folded weights and vs fp32 torch; ragged last tile,
     row strides wider than the channels, nothing written outside the slices."""
@@ -454,22 +455,32 @@ def test_pw_chain_matches_two_launches_and_torch(avt, dev, k1, n1, n2, has_res, 
             bn.weight.uniform_(0.6, 1.2); bn.bias.uniform_(-0.2, 0.2)
             bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.8, 1.2)
         return conv, bn
-    (c1, bn1), (c2, bn2) = layer(k1, n1), layer(n1, n2)
+    (c1, bn1), (c2, bn2) = layer(k1, n1), layer(n1 + k2x, n2)
     f1, f2 = FusedConv(c1, bn1, True, dev), FusedConv(c2, bn2, True, dev)
     dims = (1, 1, 1, m)
-    ldx, ldr, ldy, ldz = k1 + 16, n1 + 8, n1 + 24, n2 + 8
+    ldx, ldr, ldy, ldz = k1 + 16, n1 + 8, n1 + 24 + k2x, n2 + 8
     xw = torch.randn(m, ldx).to(torch.bfloat16).to(dev)
     rw = torch.randn(m, ldr).to(torch.bfloat16).to(dev)
     x, r = Act(xw, dims, 8, k1), Act(rw, dims, 8, n1)
-    y_ref = f1(x, res=r if has_res else None, relu=True)
-    z_ref = f2(y_ref)
     yw = torch.full((m, ldy), 3.0, dtype=torch.bfloat16, device=dev)
+    if k2x:  # the second layer reads [y | x2] from one row buffer (the stage-boundary concat)
+        yw[:, 16 + n1:16 + n1 + k2x] = torch.randn(m, k2x).to(torch.bfloat16).to(dev)
+    x2 = Act(yw, dims, 16 + n1, k2x) if k2x else None
+    x2_keep = yw[:, 16 + n1:16 + n1 + k2x].clone()
+    y_ref = f1(x, res=r if has_res else None, relu=True)
+    if k2x:
+        cat = torch.cat([y_ref.buf, x2_keep], 1).contiguous()
+        z_ref = f2(Act(cat, dims))
+    else:
+        z_ref = f2(y_ref)
     zw = torch.full((m, ldz), 3.0, dtype=torch.bfloat16, device=dev)
-    assert avt.ops.pw_chain_supported(k1, n1, n2, has_res)
+    assert avt.ops.pw_chain_supported(k1, n1, n2, has_res, k2x)
     avt.ops.pw_chain(x.ptr, ldx, k1, pack_pw(f1._folded[0], dev), f1.bias, r.ptr if has_res else 0, ldr if has_res else 0,
-                     yw.data_ptr() + 2 * 16, ldy, n1, pack_pw(f2._folded[0], dev), f2.bias, zw.data_ptr() + 2 * 8, ldz, n2, m)
+                     yw.data_ptr() + 2 * 16, ldy, n1, pack_pw(f2._folded[0], dev), f2.bias, zw.data_ptr() + 2 * 8, ldz, n2, m,
+                     x2_ptr=x2.ptr if k2x else 0, ldx2=ldy if k2x else 0, k2x=k2x)
     torch.cuda.synchronize()
-    assert (yw[:, :16] == 3).all() and (yw[:, 16 + n1:] == 3).all() and (zw[:, :8] == 3).all()
+    assert (yw[:, :16] == 3).all() and (yw[:, 16 + n1 + k2x:] == 3).all() and (zw[:, :8] == 3).all()
+    assert torch.equal(yw[:, 16 + n1:16 + n1 + k2x], x2_keep)
     y, z = yw[:, 16:16 + n1], zw[:, 8:8 + n2]
     for got, ref in ((y, y_ref.buf), (z, z_ref.buf)):
         scale = max(ref.float().abs().max().item(), 1.0)
@@ -481,7 +492,7 @@ def test_pw_chain_matches_two_launches_and_torch(avt, dev, k1, n1, n2, has_res, 
         ye = ye + rw[:, 8:8 + n1].double()
     ye = ye.clamp_min(0).float().to(torch.bfloat16)
     assert (y != ye).float().mean().item() < 0.01  # only fp32 summation-order effects at rounding boundaries
-    ze = (y.double() @ f2.wt.double().t() + f2.bias.double()).clamp_min(0).float().to(torch.bfloat16)
+    ze = (torch.cat([y, x2_keep], 1).double() @ f2.wt.double().t() + f2.bias.double()).clamp_min(0).float().to(torch.bfloat16)
     assert (z != ze).float().mean().item() < 0.01
     if not has_res:
         assert (y != y_ref.buf).float().mean().item() < 0.05  # same products, different fp32 summation order
@@ -491,10 +502,13 @@ def test_pw_chain_matches_two_launches_and_torch(avt, dev, k1, n1, n2, has_res, 
         if has_res:
             t = t + rw[:, 8:8 + n1].float().cpu().t().reshape(1, n1, 1, 1, m)
         t = F.relu(t)
+        if k2x:
+            t = torch.cat([t, x2_keep.float().cpu().t().reshape(1, k2x, 1, 1, m)], 1)
         t2 = F.relu(bn2(c2(t)))
+        t = t[:, :n1]
     assert (y.float().cpu().t().reshape(1, n1, 1, 1, m) - t).abs().max().item() < 0.03 * max(t.abs().max().item(), 1.0)
     assert (z.float().cpu().t().reshape(1, n2, 1, 1, m) - t2).abs().max().item() < 0.03 * max(t2.abs().max().item(), 1.0)
-    assert not avt.ops.pw_chain_supported(64, 256, 64, False)
+    assert not avt.ops.pw_chain_supported(64, 256, 64, False) and not avt.ops.pw_chain_supported(64, 256, 64, True, 64)
     from avtex._lib import AvtError
     with pytest.raises(AvtError):
         avt.ops.pw_chain(x.ptr, ldx, 72, pack_pw(f1._folded[0], dev), f1.bias, 0, 0, yw.data_ptr(), ldy, n1,
