@@ -159,6 +159,140 @@ __global__ __launch_bounds__(NW * 64) void pw_chain_kernel(PwArgs a) {
   }
 }
 
+// Wide form (res3: 128 -> 512 (+ residual) -> 128): 256 KB of weight fragments do not fit the LDS, and streaming one set
+// from L2 costs 8 KB per position against 2.5 KB of activations (0.73 ms vs 0.61 ms for the two launches).  Here the
+// FIRST layer's weights live in registers, split by output channel across the 8 waves of a workgroup (64 channels =
+// 16 fragments = 64 VGPRs each), the second layer's in LDS (128 KB); a workgroup owns 32 positions per iteration, every
+// wave computes its 64-channel slice of y for all 32, writes it to HBM and (swizzled) to a 32 KB LDS tile, and after a
+// barrier wave w computes z for position tile w / 4, channels 32 (w % 4) .. + 31 from that tile.  The next tile's loads
+// are issued before the barrier, so HBM stays busy while the workgroup multiplies.
+template <int K1S, int N1, int N2, int NW>
+__global__ __launch_bounds__(NW * 64) void pw_chain_wide_kernel(PwArgs a) {
+  constexpr int NJ = N1 / 32, NT2 = N2 / 16, PT = NW / (N2 / 32), NS = N1 / NW / 16;  // NS N-tiles of y per wave
+  static_assert(N1 / NW == 64 && PT == 2 && NT2 * NJ * 1024 + PT * 16 * N1 * 2 <= 160 * 1024, "res3 shape");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* w2l = lds;                    // [NT2][NJ] fragments of 1 KB
+  char* yl = w2l + NT2 * NJ * 1024;   // [PT * 16 positions][N1] bf16, 16-byte chunks XOR-swizzled by position
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  for (int f = wid; f < NT2 * NJ; f += NW) *reinterpret_cast<i32x4*>(w2l + f * 1024 + lane * 16) = a.w2[f * 64 + lane];
+  bf16x8 w1f[NS][K1S];
+#pragma unroll
+  for (int n = 0; n < NS; ++n)
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks) w1f[n][ks] = __builtin_bit_cast(bf16x8, a.w1[((wid * NS + n) * K1S + ks) * 64 + lane]);
+  float4 b1v[NS / 2][2];
+#pragma unroll
+  for (int jp = 0; jp < NS / 2; ++jp) {
+    b1v[jp][0] = *reinterpret_cast<const float4*>(a.b1 + wid * 64 + 32 * jp + 8 * q);
+    b1v[jp][1] = *reinterpret_cast<const float4*>(a.b1 + wid * 64 + 32 * jp + 8 * q + 4);
+  }
+  const int pt2 = wid / (N2 / 32), np2 = wid % (N2 / 32);  // second GEMM: position tile, channel pair of this wave
+  const float4 b2a = *reinterpret_cast<const float4*>(a.b2 + 32 * np2 + 8 * q);
+  const float4 b2b = *reinterpret_cast<const float4*>(a.b2 + 32 * np2 + 8 * q + 4);
+  __syncthreads();
+
+  bf16x8 xf[PT][K1S];
+  uint4 rf[PT][NS / 2];
+  auto load_x = [&](int tile) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int p = tile * (PT * 16) + pt * 16 + l15;
+      const int64_t pc = p < a.M ? p : a.M - 1;
+#pragma unroll
+      for (int ks = 0; ks < K1S; ++ks) xf[pt][ks] = *reinterpret_cast<const bf16x8*>(a.x1 + pc * a.ldx + 32 * ks + 8 * q);
+    }
+  };
+  auto load_r = [&](int tile) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int p = tile * (PT * 16) + pt * 16 + l15;
+      const int64_t pc = p < a.M ? p : a.M - 1;
+#pragma unroll
+      for (int jp = 0; jp < NS / 2; ++jp)
+        rf[pt][jp] = *reinterpret_cast<const uint4*>(a.res + pc * a.ldr + wid * 64 + 32 * jp + 8 * q);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) {
+    load_x(tile);
+    load_r(tile);
+  }
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x < a.ntiles ? tile + gridDim.x : tile;  // (the last iteration re-loads its own tile)
+    f32x4 acc1[PT][NS];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int n = 0; n < NS; ++n) acc1[pt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc1[pt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[n][ks], xf[pt][ks], acc1[pt][n], 0, 0, 0);
+    load_x(next);
+    uint4 yo[PT][NS / 2];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int p = tile * (PT * 16) + pt * 16 + l15;
+#pragma unroll
+      for (int jp = 0; jp < NS / 2; ++jp) {
+        const f32x4 t0 = acc1[pt][2 * jp], t1 = acc1[pt][2 * jp + 1];
+        const uint4 r = rf[pt][jp];
+        float v[8] = {t0[0] + b1v[jp][0].x + avt::bf16x2_lo(r.x), t0[1] + b1v[jp][0].y + avt::bf16x2_hi(r.x),
+                      t0[2] + b1v[jp][0].z + avt::bf16x2_lo(r.y), t0[3] + b1v[jp][0].w + avt::bf16x2_hi(r.y),
+                      t1[0] + b1v[jp][1].x + avt::bf16x2_lo(r.z), t1[1] + b1v[jp][1].y + avt::bf16x2_hi(r.z),
+                      t1[2] + b1v[jp][1].z + avt::bf16x2_lo(r.w), t1[3] + b1v[jp][1].w + avt::bf16x2_hi(r.w)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        uint4 o;
+        o.x = avt::pack_bf16x2(v[0], v[1]);
+        o.y = avt::pack_bf16x2(v[2], v[3]);
+        o.z = avt::pack_bf16x2(v[4], v[5]);
+        o.w = avt::pack_bf16x2(v[6], v[7]);
+        yo[pt][jp] = o;
+        if (p < a.M) *reinterpret_cast<uint4*>(a.y + (int64_t)p * a.ldy + wid * 64 + 32 * jp + 8 * q) = o;
+      }
+    }
+    load_r(next);
+    __syncthreads();  // every wave is done reading the previous tile's y
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int jp = 0; jp < NS / 2; ++jp) {
+        const int chunk = wid * 8 + 4 * jp + q;
+        *reinterpret_cast<uint4*>(yl + (pt * 16 + l15) * (N1 * 2) + ((chunk ^ l15) * 16)) = yo[pt][jp];
+      }
+    __syncthreads();  // the y tile is complete
+    f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < NJ; ++ks) {
+      const bf16x8 yf = *reinterpret_cast<const bf16x8*>(yl + (pt2 * 16 + l15) * (N1 * 2) + (((4 * ks + q) ^ l15) * 16));
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w2l + ((2 * np2 + n) * NJ + ks) * 1024 + lane * 16);
+        acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, yf, acc2[n], 0, 0, 0);
+      }
+    }
+    {
+      const int p = tile * (PT * 16) + pt2 * 16 + l15;
+      float v[8] = {acc2[0][0] + b2a.x, acc2[0][1] + b2a.y, acc2[0][2] + b2a.z, acc2[0][3] + b2a.w,
+                    acc2[1][0] + b2b.x, acc2[1][1] + b2b.y, acc2[1][2] + b2b.z, acc2[1][3] + b2b.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+      uint4 o;
+      o.x = avt::pack_bf16x2(v[0], v[1]);
+      o.y = avt::pack_bf16x2(v[2], v[3]);
+      o.z = avt::pack_bf16x2(v[4], v[5]);
+      o.w = avt::pack_bf16x2(v[6], v[7]);
+      if (p < a.M) *reinterpret_cast<uint4*>(a.z + (int64_t)p * a.ldz + 32 * np2 + 8 * q) = o;
+    }
+  }
+}
+
 int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
@@ -179,6 +313,20 @@ int launch(PwArgs& a, hipStream_t st) {
   const int need = (a.ntiles + NW - 1) / NW;
   if (grid > need) grid = need;
   hipLaunchKernelGGL((pw_chain_kernel<K1S, N1, N2, HAS_RES, W1_LDS, NW, K2X>), dim3((unsigned)grid), dim3(NW * 64), lds_bytes, st, a);
+  return avt::check_launch("avt_pw_chain_bf16");
+}
+
+int launch_wide(PwArgs& a, hipStream_t st) {
+  constexpr int lds_bytes = 160 * 1024;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_chain_wide_kernel<4, 512, 128, 8>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_pw_chain_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  a.ntiles = (a.M + 31) / 32;
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  hipLaunchKernelGGL((pw_chain_wide_kernel<4, 512, 128, 8>), dim3((unsigned)grid), dim3(512), lds_bytes, st, a);
   return avt::check_launch("avt_pw_chain_bf16");
 }
 
@@ -228,5 +376,7 @@ extern "C" int avt_pw_chain_bf16(const void* x1, int ldx, int k1, const void* w1
   if (k1 == 64 && x2) return launch<2, 256, 128, true, true, 12, 2>(a, s);  // 112 KB of weights
   if (k1 == 64) return launch<2, 256, 64, true, true, 6>(a, s);    // 146 VGPRs: 3 waves/SIMD = two 6-wave workgroups per CU
   if (k1 == 144) return launch<5, 256, 64, false, true, 12>(a, s);  // 112 KB of weights: one 12-wave workgroup per CU
+  static const int wide = env_int("AVT_PWC_WIDE", 1);
+  if (wide) return launch_wide(a, s);
   return launch<4, 512, 128, true, false, 8>(a, s);
 }

@@ -27,9 +27,8 @@ _FUSE_BLOCK = int(os.environ.get("AVT_FUSE_BLOCK", "1"))    # fast-pathway ident
 _C33 = int(os.environ.get("AVT_C33", "1"))                  # slow res2 b conv on the strip-resident kernel
 _FUSE_BC = int(os.environ.get("AVT_FUSE_BC", "0"))          # slow res2 identity blocks: b + c + residual in one kernel
 #   (bit-compatible with the 3-launch path, but 0.84 ms against 0.75 ms: one 7-wave workgroup per CU is latency-bound)
-_CHAIN = int(os.environ.get("AVT_PW_CHAIN", "1"))            # slow res2: c (+ residual) of block i and a of block i+1 in one pass
-_CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "256"))  # widest c to chain (res3's 512: 256 KB of weights do not fit
-#                                                                the LDS, its first layer streams from L2: 0.73 ms vs 0.61 ms)
+_CHAIN = int(os.environ.get("AVT_PW_CHAIN", "1"))            # slow res2 / res3: c (+ residual) of block i and a of block i+1 in one pass
+_CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "512"))  # widest c to chain
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
 _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "16"))  # frames walked per workgroup (2 halo frames each)
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))

@@ -61,9 +61,9 @@ def spy_c33(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu=True):
     return orig_c33(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu)
 avtex.ops.conv33_c64 = spy_c33
 orig_pw = avtex.ops.pw_chain
-def spy_pw(x1_ptr, ldx, k1, w1, b1, res_ptr, ldr, y_ptr, ldy, n1, w2, b2, z_ptr, ldz, n2, m_):
-    shapes.append("pointwise chain %d->%d%s ->%d rows %d" % (k1, n1, " +res" if res_ptr else "", n2, m_))
-    return orig_pw(x1_ptr, ldx, k1, w1, b1, res_ptr, ldr, y_ptr, ldy, n1, w2, b2, z_ptr, ldz, n2, m_)
+def spy_pw(x1_ptr, ldx, k1, w1, b1, res_ptr, ldr, y_ptr, ldy, n1, w2, b2, z_ptr, ldz, n2, m_, x2_ptr=0, ldx2=0, k2x=0):
+    shapes.append("pointwise chain %d->%d%s%s ->%d rows %d" % (k1, n1, " +res" if res_ptr else "", " |%d" % k2x if k2x else "", n2, m_))
+    return orig_pw(x1_ptr, ldx, k1, w1, b1, res_ptr, ldr, y_ptr, ldy, n1, w2, b2, z_ptr, ldz, n2, m_, x2_ptr, ldx2, k2x)
 avtex.ops.pw_chain = spy_pw
 avtex.ops.conv3d_igemm = spy
 fsf.ops.conv3d_igemm = spy
