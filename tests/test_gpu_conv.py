@@ -513,3 +513,32 @@ def test_pw_chain_matches_two_launches_and_torch(avt, dev, k1, n1, n2, has_res, 
     with pytest.raises(AvtError):
         avt.ops.pw_chain(x.ptr, ldx, 72, pack_pw(f1._folded[0], dev), f1.bias, 0, 0, yw.data_ptr(), ldy, n1,
                          pack_pw(f2._folded[0], dev), f2.bias, zw.data_ptr(), ldz, n2, m)
+
+
+def test_chained_pointwise_passes_are_used_and_agree_with_unchained(avt, dev, monkeypatch):
+    """The slow pathway's chained passes (csrc/pw_chain.hip) against the same runner with AVT_PW_CHAIN off: six passes
+    per forward (res2: first block, identity block, the res2 -> res3 boundary; res3: three), embeddings agree to bf16
+    rounding (the chained pass adds the residual before its one rounding, the implicit GEMM after its first)."""
+    import avtex.fused_slowfast as fsf
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(11)
+    m = SlowFast().eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm3d):
+                mod.weight.uniform_(0.6, 1.2); mod.bias.uniform_(-0.1, 0.1)
+                mod.running_mean.uniform_(-0.1, 0.1); mod.running_var.uniform_(0.8, 1.2)
+    slow, fast = torch.randn(2, 3, 8, 96, 64).to(dev), torch.randn(2, 3, 32, 96, 64).to(dev)
+    fused = fsf.SlowFastMFMA(m, dev)
+    calls = []
+    orig = fsf.ops.pw_chain
+    monkeypatch.setattr(fsf.ops, "pw_chain", lambda *a, **k: (calls.append((a[2], a[9], a[14], k.get("k2x", 0))), orig(*a, **k))[1])
+    y1 = fused([slow, fast]).cpu()
+    assert sorted(calls) == sorted([(144, 256, 64, 0), (64, 256, 64, 0), (64, 256, 128, 64)] + [(128, 512, 128, 0)] * 3)
+    monkeypatch.setattr(fsf, "_CHAIN", 0)
+    n = len(calls)
+    y0 = fused([slow, fast]).cpu()
+    assert len(calls) == n
+    cos = F.cosine_similarity(y1, y0, dim=1)
+    assert cos.min() > 0.9999 and ((y1 - y0).norm(dim=1) / y0.norm(dim=1)).max().item() < 0.01
