@@ -48,7 +48,8 @@ struct StemArgs {
   int tgroup, ldo;
 };
 
-constexpr int RB = 4;  // conv rows a workgroup OWNS (plain: computes these; pooled: computes one more above them)
+constexpr int RB = 4;   // conv rows a workgroup owns in the plain form (pooled: RBP = 8, plus one recomputed row above them)
+constexpr int RBP = 8;
 constexpr int NT = 2;             // 16-channel tiles per workgroup (32 output channels; blockIdx.y walks the rest)
 constexpr int KF = 7 * 4 * 8;     // K per input frame: 7 row taps x 4 pair taps x 8 (pixel-in-pair, channel)
 constexpr int BCH = NT * 16 * 28;  // 16-byte weight chunks per frame
@@ -59,13 +60,19 @@ __device__ __forceinline__ uint32_t max2(uint32_t x, uint32_t y) {  // packed bf
   return lo | hi;
 }
 
-// POOL: the workgroup computes conv rows 4hg-1 .. 4hg+3 (5 waves; the first is recomputed by its upper neighbour's
-// lower edge) and writes the two MaxPool3d((1,3,3),(1,2,2),(0,1,1)) rows 2hg, 2hg+1 they complete — the conv output
-// never reaches HBM.  Needs ReLU (values >= 0, so the pool's padding can be 0).
+// POOL: the workgroup computes conv rows 8hg-1 .. 8hg+7 (the first is recomputed by its upper neighbour's lower edge)
+// and writes the four MaxPool3d((1,3,3),(1,2,2),(0,1,1)) rows 4hg .. 4hg+3 they complete — the conv output never
+// reaches HBM.  Needs ReLU (values >= 0, so the pool's padding can be 0).
+// Work split: the R x MT (conv row, 16-position tile) units are dealt out evenly to the waves (plain: 4 rows x 7 tiles
+// on 4 waves = one row each; pooled: 9 x 7 = 63 units on 8 waves) — the kernel is MFMA-bound, and one wave per row
+// with 5 or 9 rows leaves one SIMD with twice the work of the others (measured 2.4x slower than stem + pool).
 template <int MT, bool POOL>
-__global__ __launch_bounds__(POOL ? 320 : 256, POOL ? 2 : 3) void stem_kernel(StemArgs a) {
-  constexpr int R = POOL ? RB + 1 : RB;  // conv rows computed = waves
-  constexpr int NTHR = R * 64;
+__global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(StemArgs a) {
+  constexpr int R = POOL ? RBP + 1 : RB;  // conv rows computed
+  constexpr int OWN = POOL ? RBP : RB;    // conv rows owned
+  constexpr int NWV = POOL ? 8 : 4;
+  constexpr int NTHR = NWV * 64;
+  constexpr int TPW = (R * MT + NWV - 1) / NWV;  // (row, tile) units per wave
   constexpr int PROWS = 2 * R + 5;  // input rows 2*r0-3 .. 2*(r0+R-1)+3
   constexpr int BU = (BCH + NTHR - 1) / NTHR;
   constexpr int WO = MT * 16;
@@ -76,14 +83,15 @@ __global__ __launch_bounds__(POOL ? 320 : 256, POOL ? 2 : 3) void stem_kernel(St
   char* lp = lds;             // patch [PROWS][PWP] x 16 B
   char* lb = lds + PCH * 16;  // weights [7 dh][NT][4 dp][16 rows] x 16 B
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = POOL ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;  // pooled: the unit offsets below stay in SGPRs
   const int l15 = lane & 15, q = lane >> 4;
-  const int hgroups = a.Ho / RB;
+  const int hgroups = a.Ho / OWN;
   int bid = blockIdx.x;
   const int hg = bid % hgroups;
   bid /= hgroups;
   const int to = bid % a.To, b = bid / a.To;
-  const int ho0 = hg * RB - (POOL ? 1 : 0);  // first conv row computed (may be -1: that wave's result is unused)
+  const int ho0 = hg * OWN - (POOL ? 1 : 0);  // first conv row computed (may be -1: its result is unused)
   const int n_base = blockIdx.y * (NT * 16);
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
@@ -104,11 +112,23 @@ __global__ __launch_bounds__(POOL ? 320 : 256, POOL ? 2 : 3) void stem_kernel(St
   // Row 4q'+i of tile nt holds channel 8q' + 4nt + i of the group, so a lane's two accumulators are 8 consecutive channels.
   const unsigned gbase = (unsigned)(blockIdx.y * a.KT) * (unsigned)(BCH * 16);
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[TPW][NT];
+  const int lane_off = (l15 + q) * 16;
+  int ubase[TPW];  // this wave's units (conv row 0 .. R-1, tile): patch byte offset of tap (0, 0)
+  auto unit_row = [&](int i) {
+    const int u = w * TPW + i;
+    return (u < R * MT ? u : R * MT - 1) / MT;  // (a surplus unit repeats the last one; its result is not written)
+  };
+  auto unit_mt = [&](int i) {
+    const int u = w * TPW + i;
+    return (u < R * MT ? u : R * MT - 1) % MT;
+  };
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int i = 0; i < TPW; ++i) {
+    ubase[i] = ((2 * unit_row(i)) * PWP + unit_mt(i) * 16) * 16;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NT; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // frame taps that fall inside the clip
   const int t0 = to * a.st - a.pt;
@@ -141,30 +161,35 @@ __global__ __launch_bounds__(POOL ? 320 : 256, POOL ? 2 : 3) void stem_kernel(St
       if (tid + NTHR * u < BCH) *reinterpret_cast<i32x4*>(lb + (tid + NTHR * u) * 16) = rb[u];
   };
 
-  if (dt_lo < dt_hi) gload(dt_lo);
+  // plain: the next frame's patch is fetched into registers under this frame's MFMAs.  pooled: no register prefetch
+  // (its 32 VGPRs would cost the second resident workgroup, which is what hides the fetch there; the slow stem it is
+  // used for has a single frame tap anyway)
+  if (!POOL && dt_lo < dt_hi) gload(dt_lo);
   for (int dt = dt_lo; dt < dt_hi; ++dt) {
+    if (POOL) gload(dt);
     lstore();
     __syncthreads();
-    if (dt + 1 < dt_hi) gload(dt + 1);  // in flight under this frame's MFMAs
+    if (!POOL && dt + 1 < dt_hi) gload(dt + 1);  // in flight under this frame's MFMAs
 #pragma unroll
     for (int dh = 0; dh < 7; ++dh) {
       bf16x8 bf[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n)
         bf[n] = *reinterpret_cast<const bf16x8*>(lb + (((dh * NT + n) * 4 + q) * 16 + l15) * 16);
-      const char* prow = lp + ((2 * w + dh) * PWP + l15 + q) * 16;
+      const char* prow = lp + ((2 * w + dh) * PWP + l15 + q) * 16;  // plain: unit i = tile i of row w
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(prow + m * 256);
+      for (int i = 0; i < TPW; ++i) {
+        const bf16x8 af = POOL ? *reinterpret_cast<const bf16x8*>(lp + lane_off + ubase[i] + dh * (PWP * 16))
+                               : *reinterpret_cast<const bf16x8*>(prow + i * 256);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[n], af, acc[m][n], 0, 0, 0);  // D[channel][position]
+          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[n], af, acc[i][n], 0, 0, 0);  // D[channel][position]
       }
     }
     __syncthreads();
   }
 
-  // epilogue: lane = position (mt*16 + l15) of conv row ho0 + w, channels n_base + 8q .. +7
+  // epilogue: lane = position (tile*16 + l15) of conv row ho0 + urow, channels n_base + 8q .. +7
   const int c0 = n_base + 8 * q;
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   if (a.bias && c0 < a.Cout) {
@@ -187,21 +212,24 @@ __global__ __launch_bounds__(POOL ? 320 : 256, POOL ? 2 : 3) void stem_kernel(St
   };
   if constexpr (!POOL) {
     if (c0 < a.Cout) {
-      uint16_t* orow = a.out + ((int64_t)((b * a.To + to) * a.Ho + ho0 + w) * WO) * a.Cout + c0;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) *reinterpret_cast<uint4*>(orow + (int64_t)(m * 16 + l15) * a.Cout) = packed(m);
+      for (int i = 0; i < TPW; ++i) {
+        uint16_t* orow = a.out + ((int64_t)((b * a.To + to) * a.Ho + ho0 + unit_row(i)) * WO) * a.Cout + c0;
+        if (w * TPW + i < R * MT) *reinterpret_cast<uint4*>(orow + (int64_t)(unit_mt(i) * 16 + l15) * a.Cout) = packed(i);
+      }
     }
   } else {
     // conv tile [R rows][WO][32 channels] bf16 in LDS (over the patch: every wave is past its last read of it)
     constexpr int TROW = WO * 64;  // bytes per conv row
 #pragma unroll
-    for (int m = 0; m < MT; ++m) *reinterpret_cast<uint4*>(lds + w * TROW + (m * 16 + l15) * 64 + q * 16) = packed(m);
+    for (int i = 0; i < TPW; ++i)
+      *reinterpret_cast<uint4*>(lds + unit_row(i) * TROW + (unit_mt(i) * 16 + l15) * 64 + q * 16) = packed(i);  // (a repeat rewrites the same bytes)
     __syncthreads();
     constexpr int WP = WO / 2;
     const int Hp = a.Ho / 2;
     const int cf = a.Cout / a.tgroup;  // channels per output frame (time-grouped form: Cout = tgroup frames x cf)
-    for (int i = tid; i < 2 * WP * 4; i += NTHR) {
-      const int cc = i & 3, pw_ = (i >> 2) % WP, pl = (i >> 2) / WP;  // 8-channel chunk, pooled column, pooled row (0/1)
+    for (int i = tid; i < (OWN / 2) * WP * 4; i += NTHR) {
+      const int cc = i & 3, pw_ = (i >> 2) % WP, pl = (i >> 2) / WP;  // 8-channel chunk, pooled column, pooled row of the group
       const int ch = n_base + cc * 8;
       if (ch >= a.Cout) continue;
       uint4 mx = make_uint4(0u, 0u, 0u, 0u);  // ReLU output >= 0 == bf16 +0
@@ -221,7 +249,7 @@ __global__ __launch_bounds__(POOL ? 320 : 256, POOL ? 2 : 3) void stem_kernel(St
         }
       }
       const int j = ch / cf, cin_f = ch - j * cf;  // output frame within the time group, channel within the frame
-      const int64_t pos = ((int64_t)((b * a.To + to) * a.tgroup + j) * Hp + 2 * hg + pl) * WP + pw_;
+      const int64_t pos = ((int64_t)((b * a.To + to) * a.tgroup + j) * Hp + (OWN / 2) * hg + pl) * WP + pw_;
       *reinterpret_cast<uint4*>(a.out + pos * a.ldo + cin_f) = mx;
     }
   }
@@ -229,11 +257,17 @@ __global__ __launch_bounds__(POOL ? 320 : 256, POOL ? 2 : 3) void stem_kernel(St
 
 template <int MT, bool POOL>
 int launch(const StemArgs& a, int batch, hipStream_t st, const char* what) {
-  constexpr int R = POOL ? RB + 1 : RB;
+  constexpr int R = POOL ? RBP + 1 : RB;
   constexpr int patch = ((2 * R + 5) * (MT * 16 + 4) + BCH) * 16, tile = POOL ? R * MT * 16 * 64 : 0;
   constexpr int lds_bytes = patch > tile ? patch : tile;
-  const dim3 grid((unsigned)(batch * a.To * (a.Ho / RB)), (unsigned)((a.Cout + NT * 16 - 1) / (NT * 16)));
-  hipLaunchKernelGGL((stem_kernel<MT, POOL>), grid, dim3(R * 64), lds_bytes, st, a);
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_kernel<MT, POOL>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  const dim3 grid((unsigned)(batch * a.To * (a.Ho / (POOL ? RBP : RB))), (unsigned)((a.Cout + NT * 16 - 1) / (NT * 16)));
+  hipLaunchKernelGGL((stem_kernel<MT, POOL>), grid, dim3(POOL ? 512 : 256), lds_bytes, st, a);
   return avt::check_launch(what);
 }
 
@@ -294,6 +328,7 @@ extern "C" int avt_stem_conv_pool_bf16(const void* in, const void* wt, const flo
   if (rc) return rc;
   AVT_REQUIRE(tgroup >= 1 && cout % tgroup == 0 && (cout / tgroup) % 8 == 0 && ldo % 8 == 0 && ldo >= cout / tgroup,
               "avt_stem_conv_pool_bf16: tgroup must split the channels into multiples of 8; ldo >= channels per frame");
+  AVT_REQUIRE((h / 2) % RBP == 0, "avt_stem_conv_pool_bf16: conv rows (%d) must be a multiple of %d", h / 2, RBP);
   a.tgroup = tgroup;
   a.ldo = ldo;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -32,7 +32,8 @@ _CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "512"))  # widest c to cha
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
 _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "16"))  # frames walked per workgroup (2 halo frames each)
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
-_STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "0"))  # fused pool: bit-identical but slower (probe_stem_pool_ab.log)
+_STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "1"))  # max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both
+#                                                         (the MFMA-bound fast stem loses 4 % to the recomputed ninth row)
 _KW1_CAP = int(os.environ.get("AVT_GROUP_KW1_CAP", "32"))  # measured: profiles/r01/probe_layers.log
 
 # Optional launch observer for bench.py: PROFILER(name, launch_fn, flops, bytes) must call launch_fn().
@@ -583,7 +584,7 @@ class SlowFastMFMA(nn.Module):
         kt, st, pt = conv.kernel[0], conv.stride[0], conv.pad[0]
         od = conv.out_dims(x.dims)
         m_out = od[0] * od[1] * od[2] * od[3]
-        if lds_path and _STEM_POOL:
+        if lds_path and _STEM_POOL and (kt == 1 or _STEM_POOL > 1) and (h // 2) % 8 == 0:
             # production shape: patch-resident stem kernel with the max-pool fused (the conv output stays on chip)
             pd = (b, t, od[2] // 2, od[3] // 2)
             cf = conv.frame_channels

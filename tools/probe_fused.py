@@ -40,6 +40,19 @@ def spy_stem(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu=T
     shapes.append("stem(LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)" % (cout, kt, st, batch, t, h, pw))
     return orig_stem(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu)
 avtex.ops.stem_conv = spy_stem
+orig_stemp = avtex.ops.stem_conv_pool
+def spy_stemp(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, tgroup, ldo):
+    shapes.append("stem+pool (LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)" % (cout, kt, st, batch, t, h, pw))
+    return orig_stemp(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, tgroup, ldo)
+avtex.ops.stem_conv_pool = spy_stemp
+pool_recs = []
+orig_pool = avtex.ops.maxpool_hw3s2
+def spy_pool(x_ptr, out_ptr, bt, h, w, c, ldi, ldo, tgroup=1):
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); r = orig_pool(x_ptr, out_ptr, bt, h, w, c, ldi, ldo, tgroup); e.record()
+    pool_recs.append((a, e, "maxpool 3x3/2 in(%d, %d, %d, %d)" % (bt, h, w, c), 2.0 * bt * c * (h * w + (h // 2) * (w // 2))))
+    return r
+avtex.ops.maxpool_hw3s2 = spy_pool
 orig_bn = avtex.ops.bottleneck_fused
 def spy_bn(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk=8):
     shapes.append("fused bottleneck C%d in(%d, %d, %d, %d) tchunk %d" % (c, batch, t, h, w, tchunk))
@@ -79,3 +92,6 @@ conv_ms = sum(v[1] for v in agg.values())
 print("batch %d forward %.2f ms; conv launches %.2f ms (%d launches); pools+head+glue %.2f ms" % (b, tot, conv_ms, len(recs), tot - conv_ms))
 for name, (n, t, fl, byt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%6.3f ms x%d  %-62s %7.1f TF/s %7.0f GB/s" % (t, n, name, fl / t / 1e9, byt / t / 1e6))
+for a, e, name, byt in pool_recs:
+    t = a.elapsed_time(e)
+    print("%6.3f ms     %-62s %7s      %7.0f GB/s" % (t, name, "", byt / t / 1e6))
