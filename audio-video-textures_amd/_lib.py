@@ -54,6 +54,7 @@ SIGNATURES = {
     "avt_infonce_bwd": [_vp] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp],
     "avt_conv3d_ktab": [C.c_int] * 7 + [_vp, C.c_int],
     "avt_conv3d_igemm_bf16": [_vp] * 6 + [C.c_int] * 22 + [_vp],
+    "avt_conv3d_igemm_rows_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp],
 }
 
 

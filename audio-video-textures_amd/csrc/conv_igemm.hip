@@ -104,9 +104,20 @@ struct ConvArgs {
   FastDiv dCpt, dKHW, dKW;  // tap decode without the table (XL kernel): chunks per tap, KH*KW, KW
   unsigned in_bytes, wt_bytes;  // extents for the buffer descriptors (hardware range check = free zero fill)
   int pointwise;                // 1x1x1 / stride 1 / pad 0: rows need no decode
+  int ors, oH, oW;              // output row remap: position (f, ho, wo) -> row (f * oH + ors * ho) * oW + ors * wo (ors = 1: none)
 };
 
 
+
+// Row of the output buffer an output position lands in.  ors > 1: the layer writes into (a channel slice of) a buffer
+// laid out over a `ors`x finer grid — a stride-2 [1,3,3] conv writing behind the channels of ITS OWN input's rows, so
+// that the block's c conv and strided shortcut conv become one GEMM over K = [x | b-output] (fused_slowfast._Block).
+__device__ __forceinline__ int out_row(const ConvArgs& a, int m) {
+  if (a.ors == 1) return m;
+  const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
+  const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
+  return (t2 * a.oH + ho * a.ors) * a.oW + wo * a.ors;
+}
 
 // waves per SIMD to keep resident: bounds the register allocation (guide §6 G1)
 #define AVT_CONV_MIN_WAVES(BM, BN, WTM) ((WTM) == 128 ? 2 : ((BM) == 128 ? 3 : ((BN) == 64 ? 2 : 4)))
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN, WTM)) void conv_ige
             pv[e] = avt::pack_bf16x2(x0, x1);
           }
         }
-        *reinterpret_cast<uint4*>(a.out + (int64_t)m * a.ldo + n) = v;
+        *reinterpret_cast<uint4*>(a.out + (int64_t)out_row(a, m) * a.ldo + n) = v;
       }
     }
     if (p + 1 < EPASS) __syncthreads();  // the staging tile is reused by the next wave-row
@@ -665,7 +676,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
             pv[e] = avt::pack_bf16x2(x0, x1);
           }
         }
-        *reinterpret_cast<uint4*>(a.out + (int64_t)m * a.ldo + n) = v;
+        *reinterpret_cast<uint4*>(a.out + (int64_t)out_row(a, m) * a.ldo + n) = v;
       }
     }
     if (p + 1 < EPASS) __syncthreads();
@@ -737,6 +748,15 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
                                      const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
                                      int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho,
                                      int wo, int ldi, int ldo, int ldr, int relu, void* stream) {
+  return avt_conv3d_igemm_rows_bf16(in, wt, bias, res, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw, st, sh, sw, pt, ph,
+                                    pw, to, ho, wo, ldi, ldo, ldr, relu, 1, 0, 0, stream);
+}
+
+extern "C" int avt_conv3d_igemm_rows_bf16(const void* in, const void* wt, const float* bias, const void* res, void* out,
+                                          const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
+                                          int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho,
+                                          int wo, int ldi, int ldo, int ldr, int relu, int out_row_stride, int out_h,
+                                          int out_w, void* stream) {
   AVT_REQUIRE(in && wt && out && ktab, "avt_conv3d_igemm_bf16: NULL pointer");
   AVT_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 8 == 0, "avt_conv3d_igemm_bf16: Cin/Cout must be multiples of 8");
   AVT_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && kt <= 8 && kh <= 8 && kw <= 8, "avt_conv3d_igemm_bf16: kernel extents must be 1..8");
@@ -791,6 +811,15 @@ extern "C" int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float
   a.dWo = make_fastdiv((uint32_t)a.Wo);
   a.dHo = make_fastdiv((uint32_t)a.Ho);
   a.dTo = make_fastdiv((uint32_t)a.To);
+  AVT_REQUIRE(out_row_stride >= 1 && (out_row_stride == 1 || (!res && out_h >= out_row_stride * (a.Ho - 1) + 1 &&
+                                                               out_w >= out_row_stride * (a.Wo - 1) + 1)),
+              "avt_conv3d_igemm_rows_bf16: the remapped rows need an out_h x out_w grid that holds %d x (%d x %d), no residual",
+              out_row_stride, a.Ho, a.Wo);
+  AVT_REQUIRE(out_row_stride == 1 || (int64_t)batch * a.To * out_h * out_w < (1ll << 31),
+              "avt_conv3d_igemm_rows_bf16: output buffer too large for 32-bit rows");
+  a.ors = out_row_stride;
+  a.oH = out_h;
+  a.oW = out_w;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // GEMM-like layers: the 256x256 LDS-DMA tile.  AVT_CONV_XL = minimum number of its tiles (0 = never),
   // AVT_CONV_XL_NK = minimum number of 64-wide K-steps.  A unit of 32 K must not straddle two taps: one tap, or

@@ -30,6 +30,7 @@ _FUSE_BC = int(os.environ.get("AVT_FUSE_BC", "0"))          # slow res2 identity
 _CHAIN = int(os.environ.get("AVT_PW_CHAIN", "1"))            # slow res2 / res3: c (+ residual) of block i and a of block i+1 in one pass
 _CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "512"))  # widest c to chain
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
+_FUSE_SCAT = int(os.environ.get("AVT_FUSE_SCAT", "1"))      # slow res3-5 first blocks: strided shortcut folded into c's GEMM
 _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "16"))  # frames walked per workgroup (2 halo frames each)
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 _STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "1"))  # max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both
@@ -145,10 +146,11 @@ class FusedConv:
             g //= 2
         return g
 
-    def __call__(self, x, out=None, res=None, relu=None):
+    def __call__(self, x, out=None, res=None, relu=None, out_rows=None):
+        """out_rows = (stride, H, W): write output position (f, ho, wo) to row (f*H + stride*ho)*W + stride*wo of `out`."""
         if x.C != self.cin:
             raise AvtError("FusedConv: input has %d channels, conv expects %d" % (x.C, self.cin))
-        g = self.group_factor(x, out, res)
+        g = 1 if out_rows is not None else self.group_factor(x, out, res)
         if g > 1:
             sub = self._grouped.get(g)
             if sub is None:
@@ -181,7 +183,7 @@ class FusedConv:
             ops.conv3d_igemm(x.ptr, self.wt, self.bias, res.ptr if res is not None else 0, out.ptr, tab, x.dims,
                              self.cin, self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld,
                              res.ld if res is not None else 0, self.relu if relu is None else relu,
-                             out_dims=od[1:] if any(self.crop) else (0, 0, 0))
+                             out_dims=od[1:] if any(self.crop) else (0, 0, 0), out_rows=out_rows)
 
         if PROFILER is None:
             launch()
@@ -412,6 +414,23 @@ class _Block:
                                   folded=(torch.cat([wsc, wc], 1), bc + bsc, (1, 1, 1), (0, 0, 0)))
             self.ccat.alg_flops_per_row = self.c.alg_flops_per_row + self.b1.alg_flops_per_row
             self.extra = self.c.cin
+        # first block of a stage with a STRIDED 1x1x1 shortcut (slow res3 / res4 / res5): b ([1,3,3], stride 2) writes its
+        # output behind x's channels in x's OWN rows (2 ho, 2 wo) (avt_conv3d_igemm_rows_bf16), so c and the shortcut are one
+        # stride-2 pointwise GEMM over K = [x | b-output]: no shortcut launch, no shortcut tensor written and re-read
+        self.scat = None
+        if (_FUSE_SCAT and self.b1 is not None and self.fused_first is None and self.ccat is None and
+                self.c.kernel == (1, 1, 1) and self.b1.kernel == (1, 1, 1) and self.b.kernel == (1, 3, 3) and
+                self.b.stride == (1, 2, 2) and self.b1.stride == (1, 2, 2) and self.a.stride == (1, 1, 1) and
+                self.c.stride == (1, 1, 1) and self.a.kernel[1:] == (1, 1) and self.b1._folded is not None):
+            (wsc, bsc), (wc, bc) = self.b1._folded, self.c._folded
+            self.scat = FusedConv(None, None, True, device,
+                                  folded=(torch.cat([wsc, wc], 1), bc + bsc, (1, 2, 2), (0, 0, 0)))
+            self.scat.alg_flops_per_row = self.c.alg_flops_per_row + self.b1.alg_flops_per_row
+            self.extra = self.c.cin
+
+    def _scat_ok(self, x):
+        return (self.scat is not None and x.c0 == 0 and x.ld >= x.C + self.extra and x.C == self.a.cin and
+                x.dims[2] % 2 == 0 and x.dims[3] % 2 == 0)
 
     def can_chain(self, nxt, x):
         """True when this block's c (+ residual) and the next block's a run as ONE pointwise pass (csrc/pw_chain.hip).
@@ -420,7 +439,7 @@ class _Block:
             return False
         if self.c.kernel != (1, 1, 1) or self.c._folded is None or nxt.a._folded is None or nxt.a.cin < self.c.cout:
             return False
-        if self.c.cout > _CHAIN_MAXN:
+        if self.c.cout > _CHAIN_MAXN or self._scat_ok(x):
             return False
         if any(v is not None for v in (self.fused, self.fused_first, self.bc, nxt.fused, nxt.fused_first, nxt.bc, nxt.ccat)):
             return False
@@ -481,6 +500,10 @@ class _Block:
             if chain is not None:
                 return self._chain(Act(x.buf, x.dims, 0, x.C + self.extra), x.C + self.extra, self.ccat, None, chain, x.dims)
             return self.ccat(Act(x.buf, x.dims, 0, x.C + self.extra), out=out)
+        if self._scat_ok(x):
+            m = a_pre if a_pre is not None else self.a(x)
+            self.b(m, out=Act(x.buf, x.dims, x.C, self.extra), out_rows=(2, x.dims[2], x.dims[3]))
+            return self.scat(Act(x.buf, x.dims, 0, x.C + self.extra), out=out)
         if chain is not None or a_pre is not None:
             sc = self.b1(x) if self.b1 is not None else x
             m = self._b(a_pre if a_pre is not None else self.a(x))
@@ -651,8 +674,9 @@ class SlowFastMFMA(nn.Module):
                     # last slow block of the stage writes straight into the next fusion's concat buffer
                     od = blk.b.out_dims(blk.a.out_dims(s_act.dims))
                     cs, cf = blk.c.cout, f_act.C
-                    sbuf = torch.empty((od[0] * od[1] * od[2] * od[3], cs + 2 * cf), dtype=torch.bfloat16, device=self.dev)
                     nxt0 = self.stages[k + 1][0][0]
+                    sbuf = torch.empty((od[0] * od[1] * od[2] * od[3], cs + 2 * cf + nxt0.extra), dtype=torch.bfloat16,
+                                       device=self.dev)  # (+ spare columns for the next block's K-concatenated c)
                     if blk.can_chain(nxt0, s_act):
                         # ... and the next stage's first a conv reads [y | lateral]: lateral first, then one chained pass
                         self.fuse[k + 1](f_act, out=Act(sbuf, od, cs, 2 * cf))
@@ -660,7 +684,7 @@ class SlowFastMFMA(nn.Module):
                     else:
                         blk(s_act, out=Act(sbuf, od, 0, cs), a_pre=a_pre)
                         self.fuse[k + 1](f_act, out=Act(sbuf, od, cs, 2 * cf))
-                    s_act = Act(sbuf, od)
+                    s_act = Act(sbuf, od, 0, cs + 2 * cf)
                 else:
                     s_act = blk(s_act, a_pre=a_pre)
         # head (models.py:576-580 surgery): global average pool per pathway, concat slow | fast

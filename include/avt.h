@@ -213,6 +213,18 @@ int avt_conv3d_igemm_bf16(const void* in, const void* wt, const float* bias,
                           int kt, int kh, int kw, int st, int sh, int sw,
                           int pt, int ph, int pw, int to, int ho, int wo,
                           int ldi, int ldo, int ldr, int relu, void* stream);
+/* The same convolution with its output rows REMAPPED: output position (frame f, ho, wo) is written to row
+ * (f * out_h + out_row_stride * ho) * out_w + out_row_stride * wo of `out` (no residual).  This lets the stride-2
+ * [1,3,3] conv of a slow-pathway stage's first bottleneck write behind the channels of its own INPUT's rows, so that
+ * the block's c conv and its strided 1x1x1 shortcut conv run as ONE strided GEMM over K = [x | b-output]
+ * (fused_slowfast._Block; same model, models.py:335, 399).  out_row_stride = 1 is avt_conv3d_igemm_bf16. */
+int avt_conv3d_igemm_rows_bf16(const void* in, const void* wt, const float* bias,
+                               const void* res, void* out, const int32_t* ktab,
+                               int batch, int t, int h, int w, int cin, int cout,
+                               int kt, int kh, int kw, int st, int sh, int sw,
+                               int pt, int ph, int pw, int to, int ho, int wo,
+                               int ldi, int ldo, int ldr, int relu,
+                               int out_row_stride, int out_h, int out_w, void* stream);
 
 /* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) of the SlowFast stems on NDHWC bf16 rows
  * (bt = batch*frames); out may be a channel slice of a wider row buffer (ldo).

@@ -534,11 +534,18 @@ def test_chained_pointwise_passes_are_used_and_agree_with_unchained(avt, dev, mo
     calls = []
     orig = fsf.ops.pw_chain
     monkeypatch.setattr(fsf.ops, "pw_chain", lambda *a, **k: (calls.append((a[2], a[9], a[14], k.get("k2x", 0))), orig(*a, **k))[1])
+    rows = []
+    orig_conv = fsf.ops.conv3d_igemm
+    monkeypatch.setattr(fsf.ops, "conv3d_igemm", lambda *a, **k: (rows.append(k.get("out_rows")), orig_conv(*a, **k))[1])
     y1 = fused([slow, fast]).cpu()
-    assert sorted(calls) == sorted([(144, 256, 64, 0), (64, 256, 64, 0), (64, 256, 128, 64)] + [(128, 512, 128, 0)] * 3)
+    # res3's first block folds its strided shortcut into c (K-concatenation), so only blocks 1->2 and 2->3 chain there
+    assert sorted(calls) == sorted([(144, 256, 64, 0), (64, 256, 64, 0), (64, 256, 128, 64)] + [(128, 512, 128, 0)] * 2)
+    assert sorted(r for r in rows if r is not None) == [(2, 6, 4), (2, 12, 8), (2, 24, 16)]  # the strided b convs of res5, res4, res3
     monkeypatch.setattr(fsf, "_CHAIN", 0)
-    n = len(calls)
-    y0 = fused([slow, fast]).cpu()
-    assert len(calls) == n
+    monkeypatch.setattr(fsf, "_FUSE_SCAT", 0)
+    plain = fsf.SlowFastMFMA(m, dev)
+    n, rows[:] = len(calls), []
+    y0 = plain([slow, fast]).cpu()
+    assert len(calls) == n and all(r is None for r in rows)
     cos = F.cosine_similarity(y1, y0, dim=1)
     assert cos.min() > 0.9999 and ((y1 - y0).norm(dim=1) / y0.norm(dim=1)).max().item() < 0.01
