@@ -262,7 +262,8 @@ int avt_stem_conv_bf16(const void* in, const void* wt, const float* bias, void* 
 /* The same convolution + ReLU with the stem's MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused: the convolution
  * output never reaches HBM.  out = pooled [batch, To*tgroup, h/4, pw/2, cout/tgroup] bf16 with row stride
  * ldo elements (a channel slice of a wider buffer is allowed); tgroup > 1 un-groups the time-grouped
- * fast stem exactly as avt_maxpool_hw3s2_ndhwc_bf16 does.  Results equal conv -> bf16 -> max-pool. */
+ * fast stem exactly as avt_maxpool_hw3s2_ndhwc_bf16 does.  Results equal conv -> bf16 -> max-pool.
+ * Needs (h/2) % 8 == 0 (a workgroup owns 8 conv rows = 4 pooled rows). */
 int avt_stem_conv_pool_bf16(const void* in, const void* wt, const float* bias, void* out,
                             int batch, int t, int h, int pw, int cout, int kt, int st, int pt,
                             int tgroup, int ldo, void* stream);
