@@ -102,6 +102,8 @@ struct ConvArgs {
   int tiles_n, nblk;
   FastDiv dWo, dHo, dTo;
   FastDiv dCpt, dKHW, dKW;  // tap decode without the table (XL kernel): chunks per tap, KH*KW, KW
+  FastDiv dNT;              // taps (XL kernel, taps-innermost K walk)
+  int tapinner;
   unsigned in_bytes, wt_bytes;  // extents for the buffer descriptors (hardware range check = free zero fill)
   int pointwise;                // 1x1x1 / stride 1 / pad 0: rows need no decode
   int ors, oH, oW;              // output row remap: position (f, ho, wo) -> row (f * oH + ors * ho) * oW + ors * wo (ors = 1: none)
@@ -489,19 +491,32 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
   // tap decode of unit i: wave-uniform, all on the scalar unit (it is computed one unit ahead, inside the MFMA phase,
   // where scalar issue slots are free; moving the per-lane offset selects there too measured slower: VALU work
   // competes with the MFMA issue, profiles/r01/probe_xl_layers_v7.log)
-  unsigned exb_n = 0, ey_n = 0;
+  // K is walked TAPS INNERMOST (unit i = tap i % ntaps of the 32-channel chunk i / ntaps; the sum over K does not care):
+  // a tap-major walk re-reads every input row once per tap, a whole tap phase (32 tiles x 128+ KB per XCD) apart — more
+  // than the 4 MB L2 holds, so 26 % of the L2 requests of the [3,1,1] layers missed (profiles/r01/conv_l2_1024.log) and
+  // the DMA ring waited on HBM latency.  Taps innermost, the re-reads of a chunk follow each other within a few units.
+  unsigned exb_n = 0, ey_n = 0, kb_n = 0;
+  int cc_n = 0;
   auto decode = [&](int i) {
-    const int kcu = i * 4;  // first chunk of the unit
-    const int tap = (int)fastdiv((uint32_t)kcu, a.dCpt), c8 = kcu - tap * (int)a.dCpt.d;
+    int tap, cc;  // 32-channel chunk of the input, tap
+    if (a.tapinner) {
+      cc = (int)fastdiv((uint32_t)i, a.dNT);
+      tap = i - cc * (int)a.dNT.d;
+    } else {
+      tap = (int)fastdiv((uint32_t)(i * 4), a.dCpt);
+      cc = i - tap * ((int)a.dCpt.d >> 2);
+    }
     const int dt = (int)fastdiv((uint32_t)tap, a.dKHW), r2 = tap - dt * (int)a.dKHW.d;
     const int dh = (int)fastdiv((uint32_t)r2, a.dKW), dw = r2 - dh * (int)a.dKW.d;
-    exb_n = (unsigned)(((dt * a.H + dh) * a.W + dw) * a.ldi + c8 * 8) * 2u;
+    exb_n = (unsigned)(((dt * a.H + dh) * a.W + dw) * a.ldi + cc * 32) * 2u;
     ey_n = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
+    kb_n = (unsigned)(tap * (int)a.dCpt.d * 8 + cc * 32) * 2u;  // byte offset of the unit inside a weight row
+    cc_n = cc;
   };
   unsigned offa_c[AIW], offb_c[BIW];  // DMA offsets of the unit about to be issued (computed in phase A, issued in phase B)
   auto offsets = [&](int i, unsigned exb, unsigned ey) {
-    const bool kin = (i * 4 + c4) * 8 < a.K;
-    const unsigned kb = (unsigned)(i * 64);  // byte offset of the unit inside a weight row
+    const bool kin = (cc_n * 4 + c4) < (int)a.dCpt.d && i < nu;  // chunk inside the input channels (K tail / trailing units)
+    const unsigned kb = kb_n;
 #pragma unroll
     for (int u = 0; u < AIW; ++u) offa_c[u] = (kin && ((rowmask[u] & ey) == ey)) ? rowb[u] + exb : kOob;
 #pragma unroll
@@ -698,6 +713,12 @@ int launch_xl(ConvArgs& a, hipStream_t st) {
   a.dCpt = make_fastdiv((uint32_t)(a.K / (a.KT * a.KH * a.KW) / 8));
   a.dKHW = make_fastdiv((uint32_t)(a.KH * a.KW));
   a.dKW = make_fastdiv((uint32_t)a.KW);
+  a.dNT = make_fastdiv((uint32_t)(a.KT * a.KH * a.KW));
+  static const int tapinner = []() {
+    const char* e = getenv("AVT_XL_TAPINNER");
+    return e ? atoi(e) : 1;
+  }();
+  a.tapinner = (tapinner && a.KT * a.KH * a.KW > 1) ? 1 : 0;
   constexpr int lds_bytes = XRING * (XBM + XBN) * 64;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<XBM, XBN, WM>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
