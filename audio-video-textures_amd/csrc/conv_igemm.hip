@@ -71,7 +71,7 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
 
 #ifdef AVT_CONV_STAMP
 // diagnostic build only (tools/probe_stamps.sh): cycles per K-loop segment, summed over workgroups (wave 0, lane 0)
-__device__ unsigned long long g_stamp[8];
+__device__ unsigned long long g_stamp[10];  // [0..6] segments, [7] workgroups, [8] s_memtime ticks, [9] s_memrealtime ticks (100 MHz)
 #define STAMP(i)                                                          \
   do {                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                    \
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN, WTM)) void conv_ige
 #ifdef AVT_CONV_STAMP
   unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long t0_ = last_, r0_ = __builtin_amdgcn_s_memrealtime();
 #endif
   gload(0);
   lstore();
@@ -351,6 +352,8 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN, WTM)) void conv_ige
   if (tid == 0) {
     for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[i], seg_[i]);
     atomicAdd(&g_stamp[7], 1ull);
+    atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - t0_);
+    atomicAdd(&g_stamp[9], __builtin_amdgcn_s_memrealtime() - r0_);
   }
 #endif
 }
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #ifdef AVT_CONV_STAMP
   unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long t0_ = last_, r0_ = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int i = 0; i < 3; ++i) {  // units past the end of K are all-zero fills (stage_*: kin false): uniform counting
     decode(i);
@@ -701,6 +705,8 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
   if (tid == 0) {
     for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[i], seg_[i]);
     atomicAdd(&g_stamp[7], 1ull);
+    atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - t0_);
+    atomicAdd(&g_stamp[9], __builtin_amdgcn_s_memrealtime() - r0_);
   }
 #endif
 }
@@ -734,9 +740,9 @@ int launch_xl(ConvArgs& a, hipStream_t st) {
 
 #ifdef AVT_CONV_STAMP
 extern "C" int avt_debug_stamps(unsigned long long* out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 10);
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
   }
   return 0;

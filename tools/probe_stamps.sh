@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 import torch, avtex
 from avtex import _lib
 lib = _lib.lib()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 10)()
 sys.argv = ["x"] + sys.argv[1:]
 import runpy
 lib.avt_debug_stamps(buf, 1)
@@ -19,7 +19,7 @@ lib.avt_debug_stamps(buf, 1)
 n = buf[7]
 names = ["prologue", "gload issue | XL: wait own DMA", "compute", "barrier1 | XL: barrier stage complete", "wait+ds_write | XL: DMA issue", "barrier2 | XL: barrier slot free", "epilogue"]
 tot = sum(buf[i] for i in range(7))
-print("  workgroups %d, cycles per workgroup %.0f" % (n, tot / max(n, 1)))
+print("  workgroups %d, cycles per workgroup %.0f; shader clock while resident %.0f MHz (s_memtime / s_memrealtime x 100 MHz)" % (n, tot / max(n, 1), 100.0 * buf[8] / max(buf[9], 1)))
 for i, nm in enumerate(names):
     print("    %-40s %6.1f %%  (%.0f cycles/workgroup)" % (nm, 100.0 * buf[i] / tot, buf[i] / max(n, 1)))
 PY
