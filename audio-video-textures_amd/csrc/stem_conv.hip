@@ -46,6 +46,8 @@ struct StemArgs {
   unsigned in_bytes, wt_bytes;
   // fused max-pool (POOL): out is the pooled tensor [B, To*tgroup, Ho/2, Wo/2, .] with row stride ldo (elements)
   int tgroup, ldo;
+  int ncg;  // 32-channel groups
+  int swz;  // XCD-aware work order (AVT_STEM_SWZ, default 1)
 };
 
 constexpr int RB = 4;   // conv rows a workgroup owns in the plain form (pooled: RBP = 8, plus one recomputed row above them)
@@ -87,12 +89,20 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
   const int w = POOL ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;  // pooled: the unit offsets below stay in SGPRs
   const int l15 = lane & 15, q = lane >> 4;
   const int hgroups = a.Ho / OWN;
-  int bid = blockIdx.x;
+  // XCD-aware order: workgroup ids round-robin over the 8 XCDs, so give every XCD a CONTIGUOUS range of the work list
+  // (channel group fastest, then row group, output frame, clip): the workgroups that share input — the channel groups of
+  // one patch, the row groups above / below (5 halo rows of 13), the neighbouring output frames of the time-grouped stem
+  // (4 of 8 frame taps) — then run on one XCD at about the same time and meet in its L2.  Without it the fast stem
+  // fetched 5.8 GB per 128 clips for 2.5 GB algorithmic (PMC) and ran at the HBM roof instead of the MFMA one.
+  const int nblk = gridDim.x, xc = blockIdx.x % 8, qd = nblk / 8, rmd = nblk % 8;
+  int bid = a.swz ? (xc < rmd ? xc * (qd + 1) : rmd * (qd + 1) + (xc - rmd) * qd) + blockIdx.x / 8 : (int)blockIdx.x;
+  const int cgi = bid % a.ncg;
+  bid /= a.ncg;
   const int hg = bid % hgroups;
   bid /= hgroups;
   const int to = bid % a.To, b = bid / a.To;
   const int ho0 = hg * OWN - (POOL ? 1 : 0);  // first conv row computed (may be -1: its result is unused)
-  const int n_base = blockIdx.y * (NT * 16);
+  const int n_base = cgi * (NT * 16);
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
   // weights arrive in the LDS image order [group of 32 channels][frame tap][7 dh][NT][4 dp][16 rows] x 16 B (host-side
   // repack, see include/avt.h): staging them is a linear copy — coalesced global reads, conflict-free ds_write_b128.
   // Row 4q'+i of tile nt holds channel 8q' + 4nt + i of the group, so a lane's two accumulators are 8 consecutive channels.
-  const unsigned gbase = (unsigned)(blockIdx.y * a.KT) * (unsigned)(BCH * 16);
+  const unsigned gbase = (unsigned)(cgi * a.KT) * (unsigned)(BCH * 16);
 
   f32x4 acc[TPW][NT];
   const int lane_off = (l15 + q) * 16;
@@ -266,8 +276,15 @@ int launch(const StemArgs& a, int batch, hipStream_t st, const char* what) {
     avt::set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  const dim3 grid((unsigned)(batch * a.To * (a.Ho / (POOL ? RBP : RB))), (unsigned)((a.Cout + NT * 16 - 1) / (NT * 16)));
-  hipLaunchKernelGGL((stem_kernel<MT, POOL>), grid, dim3(POOL ? 512 : 256), lds_bytes, st, a);
+  StemArgs b = a;
+  b.ncg = (a.Cout + NT * 16 - 1) / (NT * 16);
+  static const int swz = []() {
+    const char* e = getenv("AVT_STEM_SWZ");
+    return e ? atoi(e) : 1;
+  }();
+  b.swz = swz;
+  const dim3 grid((unsigned)(batch * a.To * (a.Ho / (POOL ? RBP : RB)) * b.ncg));
+  hipLaunchKernelGGL((stem_kernel<MT, POOL>), grid, dim3(POOL ? 512 : 256), lds_bytes, st, b);
   return avt::check_launch(what);
 }
 
