@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/avt.h"
 
@@ -50,6 +51,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 }
 __device__ __forceinline__ float bf16x2_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16x2_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Map them so that every XCD walks a
+// CONTIGUOUS range of the work list: neighbours in the list — which share halo rows / frames or operand chunks — then run
+// on one XCD at about the same time and meet in its L2 (the stem kernels' HBM fetch fell 3x with this, PMC).
+__device__ __forceinline__ int xcd_contiguous(int bid, int nblk) {
+  const int xc = bid % 8, qd = nblk / 8, rm = nblk % 8;
+  return (xc < rm ? xc * (qd + 1) : rm * (qd + 1) + (xc - rm) * qd) + bid / 8;
+}
+inline int env_int_flag(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 
 // 64-lane wave reductions
 __device__ __forceinline__ double wave_sum(double v) {

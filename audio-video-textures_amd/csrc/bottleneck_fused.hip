@@ -45,6 +45,7 @@ struct BArgs {
   const float* bc;  // [C]
   int T, H;
   int strips, tchunks, TC;
+  int swz;  // XCD-contiguous work order (AVT_XCD_SWZ, default 1)
   unsigned x_bytes;
 };
 
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bottleneck_kernel(BArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
-  int bid = blockIdx.x;
+  int bid = a.swz ? avt::xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tch = bid % a.tchunks;
   bid /= a.tchunks;
   const int strip = bid % a.strips, b = bid / a.strips;
@@ -350,6 +351,8 @@ int launch(BArgs& a, int batch, int h, hipStream_t st) {
   constexpr int lds_bytes = 3 * NDMA * 1024 + (RX * AW + 32) * CMP * 2 + MTB * 16 * CMP * 2 + wfrags * 1024;
   static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
   a.strips = (h / ST + HT - 1) / HT;
+  static const int swz = avt::env_int_flag("AVT_XCD_SWZ", 1);
+  a.swz = swz;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP, CIN, ST, NW>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {

@@ -28,6 +28,7 @@ struct C33Args {
   const i32x4* wb;      // [NFB][64 lanes]
   const float* bias;    // [64]
   int T, H, strips, ldo, relu;
+  int swz;  // XCD-contiguous work order (AVT_XCD_SWZ, default 1)
   unsigned in_bytes;
 };
 
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(((HT * W + 15) / 16) * 64, 1) void c33_kernel(C33Ar
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
-  const int strip = blockIdx.x % a.strips, b = blockIdx.x / a.strips;
+  const int bid = a.swz ? avt::xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int strip = bid % a.strips, b = bid / a.strips;
   const int h0 = strip * HT;
 
   for (int f = wid; f < NFB; f += NWV) *reinterpret_cast<i32x4*>(wbl + f * 1024 + lane * 16) = a.wb[f * 64 + lane];
@@ -157,6 +159,8 @@ int launch(C33Args& a, int batch, int h, hipStream_t st) {
   constexpr int lds_bytes = NFB * 1024 + 2 * (((HT + 2) * (W + 1) + 1) * 128);
   static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
   a.strips = (h + HT - 1) / HT;
+  static const int swz = avt::env_int_flag("AVT_XCD_SWZ", 1);
+  a.swz = swz;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c33_kernel<W, HT>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
