@@ -549,3 +549,32 @@ def test_chained_pointwise_passes_are_used_and_agree_with_unchained(avt, dev, mo
     assert len(calls) == n and all(r is None for r in rows)
     cos = F.cosine_similarity(y1, y0, dim=1)
     assert cos.min() > 0.9999 and ((y1 - y0).norm(dim=1) / y0.norm(dim=1)).max().item() < 0.01
+
+
+@pytest.mark.parametrize("c,dims", [(128, (1, 2, 12, 8)), (256, (2, 1, 10, 6))])
+def test_conv_rows_remap_writes_behind_the_input_channels(avt, dev, c, dims):
+    """avt_conv3d_igemm_rows_bf16: a stride-2 [1,3,3] conv writing output position (f, ho, wo) to row (f*H + 2ho)*W + 2wo
+    of a wider buffer (128 channels: the 128x128 tile; 256: the LDS-DMA tile) — equal to the plain launch scattered by
+    hand, every other byte untouched; a residual or a grid too small for the remap is refused."""
+    from avtex.fused_slowfast import Act, FusedConv
+    from avtex._lib import AvtError
+
+    torch.manual_seed(c)
+    conv = nn.Conv3d(c, c, (1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1), bias=False)
+    bn = nn.BatchNorm3d(c).eval()
+    fc = FusedConv(conv, bn, True, dev)
+    b, t, h, w = dims
+    x = torch.randn(b * t * h * w, c).to(torch.bfloat16).to(dev)
+    plain = fc(Act(x, dims))
+    ho, wo = plain.dims[2], plain.dims[3]
+    wide = torch.full((b * t * h * w, c + 24), 7.0, dtype=torch.bfloat16, device=dev)
+    fc(Act(x, dims), out=Act(wide, dims, 8, c), out_rows=(2, h, w))
+    torch.cuda.synchronize()
+    want = torch.full_like(wide, 7.0)
+    rows = ((torch.arange(b * t).view(-1, 1, 1) * h + 2 * torch.arange(ho).view(1, -1, 1)) * w + 2 * torch.arange(wo).view(1, 1, -1)).reshape(-1)
+    want[rows.to(dev), 8:8 + c] = plain.buf
+    assert torch.equal(wide, want)
+    with pytest.raises(AvtError):
+        fc(Act(x, dims), out=Act(wide, dims, 8, c), out_rows=(2, ho, wo))  # grid too small for 2 x (ho, wo)
+    with pytest.raises(AvtError):
+        fc(Act(x, dims), out=Act(wide, dims, 8, c), res=plain, out_rows=(2, h, w))
