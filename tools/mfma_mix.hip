@@ -9,7 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
+template <int NRD, int NDMA, int NGL>
 __global__ __launch_bounds__(512, 2) void mix_kernel(const unsigned* seed, const char* src, unsigned bytes, float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -32,26 +32,25 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const unsigned* seed, const
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   i32x4 sink = {0, 0, 0, 0};
   for (int it = 0; it < iters; ++it) {
-    i32x4 fr[12];
-    if (MODE & 1) {
+    i32x4 fr[NRD > 0 ? NRD : 1], gl[NGL > 0 ? NGL : 1];
 #pragma unroll
-      for (int u = 0; u < 12; ++u) fr[u] = *reinterpret_cast<const i32x4*>(lds + ((it * 12 + u) & 63) * 1024 + lane * 16);
-    }
-    if (MODE & 2) {
+    for (int u = 0; u < NRD; ++u) fr[u] = *reinterpret_cast<const i32x4*>(lds + ((it * NRD + u) & 63) * 1024 + lane * 16);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned off = (base + (unsigned)(it * 4 + u) * 64u) % (bytes - 4096u);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + 65536 + ((u & 3) * 8 + wid) * 1024), 16,
-                                                 (int)(off & ~15u), 0, 0, 0);
-      }
+    for (int u = 0; u < NDMA; ++u) {
+      const unsigned off = (base + (unsigned)(it * NDMA + u) * 64u) % (bytes - 4096u);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + 65536 + ((u & 3) * 8 + wid) * 1024), 16,
+                                               (int)(off & ~15u), 0, 0, 0);
     }
+#pragma unroll
+    for (int u = 0; u < NGL; ++u)  // packed fragments: 1 KB contiguous per wave instruction
+      gl[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((((unsigned)(it * NGL + u) * 8u + wid) * 1024u + lane * 16u) % (bytes - 4096u)), 0, 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3].v, b[(i >> 2) & 3].v, acc[i & 7], 0, 0, 0);
-    if (MODE & 1) {
 #pragma unroll
-      for (int u = 0; u < 12; ++u) sink ^= fr[u];
-    }
-    if (MODE & 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int u = 0; u < NRD; ++u) sink ^= fr[u];
+#pragma unroll
+    for (int u = 0; u < NGL; ++u) sink ^= gl[u];
+    if (NDMA > 0 && NGL == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   }
   float sum = (float)(sink[0] ^ sink[1] ^ sink[2] ^ sink[3]);
   for (int i = 0; i < 8; ++i)
@@ -59,16 +58,16 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const unsigned* seed, const
   if (sum == 123.456f) out[lane] = sum;
 }
 
-template <int MODE>
+template <int NRD, int NDMA, int NGL>
 void run(const unsigned* seed, const char* buf, float* out, int iters, const char* what) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  hipLaunchKernelGGL(mix_kernel<MODE>, dim3(256), dim3(512), 128 * 1024, 0, seed, buf, 16u << 20, out, 100);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel<NRD, NDMA, NGL>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipLaunchKernelGGL((mix_kernel<NRD, NDMA, NGL>), dim3(256), dim3(512), 128 * 1024, 0, seed, buf, 16u << 20, out, 100);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL(mix_kernel<MODE>, dim3(256), dim3(512), 128 * 1024, 0, seed, buf, 16u << 20, out, iters);
+  hipLaunchKernelGGL((mix_kernel<NRD, NDMA, NGL>), dim3(256), dim3(512), 128 * 1024, 0, seed, buf, 16u << 20, out, iters);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -89,9 +88,12 @@ int main(int argc, char** argv) {
   unsigned h[1024];
   for (int i = 0; i < 1024; ++i) h[i] = 12345u + 7919u * i;
   hipMemcpy(seed, h, 4096, hipMemcpyHostToDevice);
-  run<0>(seed, buf, out, iters, "16 MFMA per iteration, 2 waves per SIMD");
-  run<1>(seed, buf, out, iters, "  + 12 ds_read_b128 per wave and iteration");
-  run<2>(seed, buf, out, iters, "  + 4 LDS-DMA instructions (1 KB each) per wave and iteration");
-  run<3>(seed, buf, out, iters, "  + both (the XL tile's mix)");
+  run<0, 0, 0>(seed, buf, out, iters, "16 MFMA per iteration, 2 waves per SIMD");
+  run<12, 0, 0>(seed, buf, out, iters, "  + 12 ds_read_b128 per wave and iteration");
+  run<0, 4, 0>(seed, buf, out, iters, "  + 4 LDS-DMA instructions (1 KB each) per wave and iteration");
+  run<12, 4, 0>(seed, buf, out, iters, "  + both (the XL tile's mix)");
+  run<8, 2, 4>(seed, buf, out, iters, "  8 ds_read + 2 LDS-DMA + 4 packed global loads (B from registers)");
+  run<8, 2, 0>(seed, buf, out, iters, "  8 ds_read + 2 LDS-DMA");
+  run<6, 4, 0>(seed, buf, out, iters, "  6 ds_read + 4 LDS-DMA (128x128 wave tiles)");
   return 0;
 }
