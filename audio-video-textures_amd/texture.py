@@ -17,6 +17,8 @@ Data layout in HBM (N windows, D_v = 2304, D_a = 12288):
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -95,6 +97,7 @@ class TextureEngine:
         self.encoded = 0  # windows pushed through an encoder (both encoders counted)
         self.n_streams = 2
         self._streams = None
+        self._pending, self._inflight = [], []  # run_encoders(join=False): outputs / per-batch events not yet joined
 
     # ---- inputs -------------------------------------------------------------------
     def set_video(self, video_u8):
@@ -153,11 +156,15 @@ class TextureEngine:
             return enc.forward_ndhwc4(slow, fast).float()
         return enc([slow, fast]).float()
 
-    def run_encoders(self, encoders, slow, fast):
+    def run_encoders(self, encoders, slow, fast, join=True):
         """Every encoder on the same packed clips.  Two encoders (query / target) run on separate HIP streams: their
         kernels are independent, and interleaving them fills the tail of each ~0.2 ms convolution launch with the
         other encoder's workgroups (+8-13 % windows/s measured, bit-identical outputs).  self.n_streams = 4 also
-        splits the clip batch in halves (four independent forward chains)."""
+        splits the clip batch in halves (four independent forward chains).
+        join=False: the caller's stream does NOT wait for the encoder streams — it goes on packing the next batch while
+        they work, and each encoder stream runs its batches back to back (no per-batch rendezvous of the two streams,
+        which idles one of them at every batch end and keeps the two forwards in lockstep).  The outputs may then only be
+        used after join_streams().  At most two batches of packed clips are in flight."""
         if len(encoders) != 2 or self.n_streams <= 1:
             return [self._run(e, slow, fast) for e in encoders]
         main = torch.cuda.current_stream()
@@ -167,16 +174,38 @@ class TextureEngine:
         sl, fa = slow.chunk(parts), fast.chunk(parts)
         tasks = [(e, k) for k in range(parts) for e in range(2)]
         outs = {}
+        done = []
         for st, (e, k) in zip(self._streams, tasks):
             st.wait_stream(main)  # the clips were packed on `main`
             with torch.cuda.stream(st):
                 outs[(e, k)] = self._run(encoders[e], sl[k], fa[k])
+                if not join:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done.append(ev)
             slow.record_stream(st)
             fast.record_stream(st)
-        for st, key in zip(self._streams, tasks):
-            main.wait_stream(st)
-            outs[key].record_stream(main)
+        if join:
+            for st, key in zip(self._streams, tasks):
+                main.wait_stream(st)
+                outs[key].record_stream(main)
+        else:
+            self._pending.extend(outs.values())
+            self._inflight.append(done)
+            if len(self._inflight) > 2:  # bound the packed clips in flight: the NEXT pack waits for the batch before last
+                for ev in self._inflight.pop(0):
+                    main.wait_event(ev)
         return [outs[(e, 0)] if parts == 1 else torch.cat([outs[(e, k)] for k in range(parts)], 0) for e in range(2)]
+
+    def join_streams(self):
+        """After run_encoders(..., join=False): the current stream waits for every encoder stream; the outputs returned
+        since the last join become usable on it."""
+        main = torch.cuda.current_stream()
+        for st in self._streams or []:
+            main.wait_stream(st)
+        for o in self._pending:
+            o.record_stream(main)
+        self._pending, self._inflight = [], []
 
     def embed_windows(self, encoders, starts=None, ids=None):
         """Packs each window ONCE and runs every encoder in `encoders` on it -> list of fp32 [n,D]."""
@@ -204,9 +233,10 @@ class TextureEngine:
                     flat = torch.from_numpy(np.where(part < 0, self.F, part).reshape(-1)).to(self.dev)
                     scratch = self._frames_pad.index_select(0, flat)
                     slow, fast = self._pack(scratch, np.arange(len(part), dtype=np.int64) * self.W)
-                for k, o in enumerate(self.run_encoders(encoders, slow, fast)):
+                for k, o in enumerate(self.run_encoders(encoders, slow, fast, join=False)):
                     outs[k].append(o)
                 self.encoded += slow.shape[0] * len(encoders)
+            self.join_streams()
         return [torch.cat(o, 0).contiguous() for o in outs]
 
     # ---- aligned mode: tables + one N x N GEMM --------------------------------------------

@@ -153,10 +153,13 @@ def main():
                 # must sit on the launching stream); all other batches run q and t encoders on two streams
                 timer.sample_conv = (i // args.enc_batch) % 8 == 0
                 eng.n_streams = 1 if (timer.on and timer.sample_conv) else args.streams
-                o = eng.run_encoders([q_enc, t_enc], slow, fast)
+                if eng.n_streams == 1:
+                    eng.join_streams()  # the sampled batch is timed alone on the device
+                o = eng.run_encoders([q_enc, t_enc], slow, fast, join=JOIN_EVERY_BATCH)
                 outs[0].append(o[0])
                 outs[1].append(o[1])
                 timer.sample_conv = False
+            eng.join_streams()
         qv, tv = torch.cat(outs[0], 0), torch.cat(outs[1], 0)
         qn, qh, ql = timer.run("l2norm_rows", lambda: ops.l2norm_rows(qv, want_split=split))
         tn, th, tl = timer.run("l2norm_rows", lambda: ops.l2norm_rows(tv, want_split=split))
@@ -269,6 +272,11 @@ def baseline_metric():
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
         return "clip-windows/sec encoded + N\u00d7N transition build, N=4096; HBM GB/s achieved"
+
+
+# AVT_BENCH_JOIN=1: rendezvous the two encoder streams after every batch (the earlier behaviour); default: the streams run
+# their batches back to back and are joined once per step (texture.TextureEngine.run_encoders(join=False))
+JOIN_EVERY_BATCH = os.environ.get("AVT_BENCH_JOIN", "0") == "1"
 
 
 def attach_pmc_traffic(kern, args):
