@@ -8,8 +8,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NRD, int NDMA, int NGL>
+template <int NRD, int NDMA, int NGL, bool S16 = false>
 __global__ __launch_bounds__(512, 2) void mix_kernel(const unsigned* seed, const char* src, unsigned bytes, float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -44,8 +45,20 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const unsigned* seed, const
 #pragma unroll
     for (int u = 0; u < NGL; ++u)  // packed fragments: 1 KB contiguous per wave instruction
       gl[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((((unsigned)(it * NGL + u) * 8u + wid) * 1024u + lane * 16u) % (bytes - 4096u)), 0, 0);
+    if (S16) {  // the same FLOPs as 32 MFMAs of the 16x16x32 shape (16 independent 16x16 accumulators)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3].v, b[(i >> 2) & 3].v, acc[i & 7], 0, 0, 0);
+      for (int i = 0; i < 32; ++i) {
+        f32x4 t = {acc[i & 7][(i >> 3) * 4 + 0], acc[i & 7][(i >> 3) * 4 + 1], acc[i & 7][(i >> 3) * 4 + 2], acc[i & 7][(i >> 3) * 4 + 3]};
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3].v, b[(i >> 2) & 3].v, t, 0, 0, 0);
+        acc[i & 7][(i >> 3) * 4 + 0] = t[0];
+        acc[i & 7][(i >> 3) * 4 + 1] = t[1];
+        acc[i & 7][(i >> 3) * 4 + 2] = t[2];
+        acc[i & 7][(i >> 3) * 4 + 3] = t[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3].v, b[(i >> 2) & 3].v, acc[i & 7], 0, 0, 0);
+    }
 #pragma unroll
     for (int u = 0; u < NRD; ++u) sink ^= fr[u];
 #pragma unroll
@@ -58,16 +71,16 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const unsigned* seed, const
   if (sum == 123.456f) out[lane] = sum;
 }
 
-template <int NRD, int NDMA, int NGL>
+template <int NRD, int NDMA, int NGL, bool S16 = false>
 void run(const unsigned* seed, const char* buf, float* out, int iters, const char* what) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel<NRD, NDMA, NGL>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  hipLaunchKernelGGL((mix_kernel<NRD, NDMA, NGL>), dim3(256), dim3(512), 128 * 1024, 0, seed, buf, 16u << 20, out, 100);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel<NRD, NDMA, NGL, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipLaunchKernelGGL((mix_kernel<NRD, NDMA, NGL, S16>), dim3(256), dim3(512), 128 * 1024, 0, seed, buf, 16u << 20, out, 100);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((mix_kernel<NRD, NDMA, NGL>), dim3(256), dim3(512), 128 * 1024, 0, seed, buf, 16u << 20, out, iters);
+  hipLaunchKernelGGL((mix_kernel<NRD, NDMA, NGL, S16>), dim3(256), dim3(512), 128 * 1024, 0, seed, buf, 16u << 20, out, iters);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -95,5 +108,7 @@ int main(int argc, char** argv) {
   run<8, 2, 4>(seed, buf, out, iters, "  8 ds_read + 2 LDS-DMA + 4 packed global loads (B from registers)");
   run<8, 2, 0>(seed, buf, out, iters, "  8 ds_read + 2 LDS-DMA");
   run<6, 4, 0>(seed, buf, out, iters, "  6 ds_read + 4 LDS-DMA (128x128 wave tiles)");
+  run<0, 0, 0, true>(seed, buf, out, iters, "32 MFMA 16x16x32 per iteration (same FLOPs), 2 waves per SIMD");
+  run<12, 4, 0, true>(seed, buf, out, iters, "  + 12 ds_read + 4 LDS-DMA (the XL mix on the 16x16x32 shape)");
   return 0;
 }
