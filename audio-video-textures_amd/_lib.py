@@ -55,6 +55,8 @@ SIGNATURES = {
     "avt_conv3d_ktab": [C.c_int] * 7 + [_vp, C.c_int],
     "avt_conv3d_igemm_bf16": [_vp] * 6 + [C.c_int] * 22 + [_vp],
     "avt_conv3d_igemm_rows_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp],
+    "avt_conv3d_igemm_wfrag_supported": [C.c_int] * 5,
+    "avt_conv3d_igemm_wfrag_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp, C.c_int, _vp],
 }
 
 

@@ -106,6 +106,9 @@ struct ConvArgs {
   int tapinner;
   unsigned in_bytes, wt_bytes;  // extents for the buffer descriptors (hardware range check = free zero fill)
   int pointwise;                // 1x1x1 / stride 1 / pad 0: rows need no decode
+  const uint16_t* wfrag;        // XB kernel: weights in MFMA-fragment order [Cout/32][nup][2][64][8] (walk order of K), or NULL
+  int nup;                      // ... units per 32-row tile in that array (>= units walked + 3)
+  unsigned wf_bytes;
   int ors, oH, oW;              // output row remap: position (f, ho, wo) -> row (f * oH + ors * ho) * oW + ors * wo (ors = 1: none)
 };
 
@@ -711,6 +714,266 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// XB tile: the XL tile with the WEIGHT operand bypassing the LDS.  What caps the XL tile is the price of its LDS-DMA
+// pieces — 4 per wave per 16 MFMAs (profiles/r01/mfma_peak.log: that mix sustains 1.33 PFLOP/s, 8 reads + 2 pieces
+// 1.62).  Here only the activations go through the DMA ring (2 pieces per wave and unit, 16 KB units); the weights are
+// pre-packed on the host in MFMA-fragment order along the K walk, so a wave fetches its four fragments of a unit with
+// four fully coalesced 1 KB loads straight into registers, three units ahead (a ring of four register sets; the loop is
+// unrolled by four so every index is static).  Same two-phase wave groups, same epilogue.
+template <int UNUSED>
+__global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
+  constexpr int XBM = 256, XBN = 256, WN = 4, WTM = 128, WTN = 64, MT = 4, NT = 2;
+  constexpr int XUNIT = XBM * 64;  // one 32-wide K slice of the activations
+  constexpr int XR = 4;
+  constexpr int AIW = 2, BLD = 2 * NT, UOPS = AIW + BLD;  // vector-memory operations per wave and unit
+  constexpr int NMF = 2 * NT * MT;
+  constexpr int ESTR = XBN * 2 + 16;
+  constexpr int EPASS = 2, EROWS = XBM / EPASS, CPR = XBN / 8, EU = (EROWS * CPR) / XT;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // max(XR * XUNIT, EROWS * ESTR) bytes
+
+  const int bid = blockIdx.x;
+  const int qd = a.nblk / 8, rm = a.nblk % 8, xc = bid % 8;
+  const int swz = (xc < rm ? xc * (qd + 1) : rm * (qd + 1) + (xc - rm) * qd) + bid / 8;
+  const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
+  const int m0 = tm * XBM, n0 = tn * XBN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int grp = wid >> 2;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int srow = wid * 16 + (lane >> 2);
+  const int c4 = (lane & 3) ^ ((lane >> 4) & 3);
+
+  unsigned rowb[AIW], rowmask[AIW];
+#pragma unroll
+  for (int u = 0; u < AIW; ++u) {
+    const int m = m0 + u * 128 + srow;
+    int ro = 0;
+    unsigned mask = 0u;
+    if (m < a.M && a.pointwise) {
+      ro = m * a.ldi;
+      mask = 0x010101u;
+    } else if (m < a.M) {
+      const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
+      const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
+      const int b = (int)fastdiv((uint32_t)t2, a.dTo), to = t2 - b * a.To;
+      const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+      ro = (((b * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.ldi;
+      for (int dt = 0; dt < a.KT; ++dt) mask |= ((unsigned)(ti0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
+      for (int dh = 0; dh < a.KH; ++dh) mask |= ((unsigned)(hi0 + dh) < (unsigned)a.H ? 1u : 0u) << (8 + dh);
+      for (int dw = 0; dw < a.KW; ++dw) mask |= ((unsigned)(wi0 + dw) < (unsigned)a.W ? 1u : 0u) << (16 + dw);
+    }
+    rowb[u] = (unsigned)(ro + c4 * 8) * 2u;
+    rowmask[u] = mask;
+  }
+
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwf = __builtin_amdgcn_make_buffer_rsrc((void*)a.wfrag, 0, a.wf_bytes, 0x00020000);
+  const int nu = (a.K + 31) / 32;
+  const int swid = __builtin_amdgcn_readfirstlane(wid);
+  // this wave's weight fragments of unit i: tile (n0/32 + 2 wn + n), k-slice ks -> byte ((tile * nup + i) * 2 + ks) * 1024
+  const unsigned wfb = (unsigned)(((n0 >> 5) + wn * NT) * a.nup) * 2048u + (unsigned)lane * 16u;
+  const unsigned wft = (unsigned)a.nup * 2048u;  // next 32-row tile
+
+  unsigned exb_n = 0, ey_n = 0;
+  int cc_n = 0;
+  auto decode = [&](int i) {  // taps innermost (the host packs the weight fragments along the same walk)
+    const int cc = (int)fastdiv((uint32_t)i, a.dNT), tap = i - cc * (int)a.dNT.d;
+    const int dt = (int)fastdiv((uint32_t)tap, a.dKHW), r2 = tap - dt * (int)a.dKHW.d;
+    const int dh = (int)fastdiv((uint32_t)r2, a.dKW), dw = r2 - dh * (int)a.dKW.d;
+    exb_n = (unsigned)(((dt * a.H + dh) * a.W + dw) * a.ldi + cc * 32) * 2u;
+    ey_n = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
+    cc_n = cc;
+  };
+  unsigned offa_c[AIW];
+  auto offsets = [&](int i, unsigned exb, unsigned ey) {
+    const bool kin = (cc_n * 4 + c4) < (int)a.dCpt.d && i < nu;
+#pragma unroll
+    for (int u = 0; u < AIW; ++u) offa_c[u] = (kin && ((rowmask[u] & ey) == ey)) ? rowb[u] + exb : kOob;
+  };
+  auto issue = [&](int slot) {
+    char* st = lds + slot * XUNIT;
+#pragma unroll
+    for (int u = 0; u < AIW; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(st + (u * 128 + swid * 16) * 64),
+                                               16, (int)offa_c[u], 0, 0, 0);
+  };
+  bf16x8 wq[XR][2][NT];  // weight fragments of units i .. i+3
+  auto loadb = [&](auto sc, int i) {
+    constexpr int S = decltype(sc)::value;
+    const unsigned ub = wfb + (unsigned)i * 2048u;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        wq[S][ks][n] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rwf, (int)(ub + n * wft + ks * 1024u), 0, 0));
+  };
+  const int xa = (lr >> 2) & 3;
+
+  // One unit with every ring index static.  Phase A: fragment reads of the activations, offsets of unit i+3, waits;
+  // phase B: 16 MFMAs with the DMA pieces and weight-fragment loads of unit i+3 and the scalar decode in their shadow.
+  auto body = [&](auto sc, int i) {
+    constexpr int S = decltype(sc)::value;
+    const char* st = lds + S * XUNIT;
+    bf16x8 af[2][MT];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int koff = ((ks * 2 + lh) ^ xa) * 16;
+#pragma unroll
+      for (int j = 0; j < MT; ++j) af[ks][j] = *reinterpret_cast<const bf16x8*>(st + (wm * WTM + j * 32 + lr) * 64 + koff);
+    }
+    offsets(i + 3, exb_n, ey_n);
+    // my part of unit i+1 (pieces and fragments) is done when only unit i+2's operations are outstanding
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UOPS) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S][ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
+    issue((S + 3) & (XR - 1));
+    loadb(std::integral_constant<int, (S + 3) & (XR - 1)>{}, i + 3);
+    decode(i + 4);
+#pragma unroll
+    for (int g = 0; g < NMF; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+      if (g % 2 == 1 && g < 2 * UOPS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  decode(0);
+  offsets(0, exb_n, ey_n);
+  issue(0);
+  loadb(std::integral_constant<int, 0>{}, 0);
+  decode(1);
+  offsets(1, exb_n, ey_n);
+  issue(1);
+  loadb(std::integral_constant<int, 1>{}, 1);
+  decode(2);
+  offsets(2, exb_n, ey_n);
+  issue(2);
+  loadb(std::integral_constant<int, 2>{}, 2);
+  decode(3);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UOPS) : "memory");  // my part of unit 0
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  for (int i = 0; i < nu; i += 4) {  // (a K that is not a multiple of 128 multiplies up to three all-zero units)
+    body(std::integral_constant<int, 0>{}, i);
+    body(std::integral_constant<int, 1>{}, i + 1);
+    body(std::integral_constant<int, 2>{}, i + 2);
+    body(std::integral_constant<int, 3>{}, i + 3);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const bool has_res = a.res != nullptr;
+#pragma unroll 1
+  for (int p = 0; p < EPASS; ++p) {
+    uint4 rres[EU];
+    if (has_res) {
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c = tid + XT * u;
+        const int m = m0 + p * EROWS + c / CPR, n = n0 + (c % CPR) * 8;
+        rres[u] = (m < a.M && n < a.Cout) ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n)
+                                          : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    if (wm == p) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn * WTN + i * 32 + 8 * g + 4 * lh;
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.bias && n0 + nl < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+#pragma unroll
+          for (int j = 0; j < MT; ++j) {
+            float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+            float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+            if (a.relu && !has_res) {
+              v0 = fmaxf(v0, 0.f);
+              v1 = fmaxf(v1, 0.f);
+              v2 = fmaxf(v2, 0.f);
+              v3 = fmaxf(v3, 0.f);
+            }
+            uint2 pk;
+            pk.x = avt::pack_bf16x2(v0, v1);
+            pk.y = avt::pack_bf16x2(v2, v3);
+            *reinterpret_cast<uint2*>(lds + (j * 32 + lr) * ESTR + nl * 2) = pk;
+          }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int c = tid + XT * u;
+      const int row = c / CPR, cc = c % CPR;
+      const int m = m0 + p * EROWS + row, n = n0 + cc * 8;
+      if (m < a.M && n < a.Cout) {
+        uint4 v = *reinterpret_cast<const uint4*>(lds + row * ESTR + cc * 16);
+        if (has_res) {
+          uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
+          const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rres[u]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x0 = avt::bf16x2_lo(pv[e]) + avt::bf16x2_lo(pr[e]);
+            float x1 = avt::bf16x2_hi(pv[e]) + avt::bf16x2_hi(pr[e]);
+            if (a.relu) {
+              x0 = fmaxf(x0, 0.f);
+              x1 = fmaxf(x1, 0.f);
+            }
+            pv[e] = avt::pack_bf16x2(x0, x1);
+          }
+        }
+        *reinterpret_cast<uint4*>(a.out + (int64_t)out_row(a, m) * a.ldo + n) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int launch_xb(ConvArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.Cout + 255) / 256;
+  a.nblk = tiles_m * a.tiles_n;
+  a.dCpt = make_fastdiv((uint32_t)(a.K / (a.KT * a.KH * a.KW) / 8));
+  a.dKHW = make_fastdiv((uint32_t)(a.KH * a.KW));
+  a.dKW = make_fastdiv((uint32_t)a.KW);
+  a.dNT = make_fastdiv((uint32_t)(a.KT * a.KH * a.KW));
+  a.tapinner = 1;
+  constexpr int lds_bytes = 128 * (256 * 2 + 16) > 4 * 256 * 64 ? 128 * (256 * 2 + 16) : 4 * 256 * 64;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<0>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((conv_xb_kernel<0>), dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
+  return avt::check_launch("avt_conv3d_igemm_bf16");
+}
+
+
 template <int XBM, int XBN, int WM>
 int launch_xl(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + XBM - 1) / XBM;
@@ -784,6 +1047,20 @@ extern "C" int avt_conv3d_igemm_rows_bf16(const void* in, const void* wt, const 
                                           int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho,
                                           int wo, int ldi, int ldo, int ldr, int relu, int out_row_stride, int out_h,
                                           int out_w, void* stream) {
+  return avt_conv3d_igemm_wfrag_bf16(in, wt, bias, res, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw, st, sh, sw, pt, ph,
+                                     pw, to, ho, wo, ldi, ldo, ldr, relu, out_row_stride, out_h, out_w, nullptr, 0, stream);
+}
+
+extern "C" int avt_conv3d_igemm_wfrag_supported(int cin, int cout, int kt, int kh, int kw) {
+  const int taps = kt * kh * kw;
+  return (cout >= 256 && (taps * cin + 63) / 64 >= 16 && cin % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int avt_conv3d_igemm_wfrag_bf16(const void* in, const void* wt, const float* bias, const void* res, void* out,
+                                           const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
+                                           int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho,
+                                           int wo, int ldi, int ldo, int ldr, int relu, int out_row_stride, int out_h,
+                                           int out_w, const void* wfrag, int nup, void* stream) {
   AVT_REQUIRE(in && wt && out && ktab, "avt_conv3d_igemm_bf16: NULL pointer");
   AVT_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 8 == 0, "avt_conv3d_igemm_bf16: Cin/Cout must be multiples of 8");
   AVT_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && kt <= 8 && kh <= 8 && kw <= 8, "avt_conv3d_igemm_bf16: kernel extents must be 1..8");
@@ -847,7 +1124,19 @@ extern "C" int avt_conv3d_igemm_rows_bf16(const void* in, const void* wt, const 
   a.ors = out_row_stride;
   a.oH = out_h;
   a.oW = out_w;
+  a.wfrag = static_cast<const uint16_t*>(wfrag);
+  a.nup = nup;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (wfrag) {
+    const int nu = (a.K + 31) / 32;
+    AVT_REQUIRE(avt_conv3d_igemm_wfrag_supported(cin, cout, kt, kh, kw) && avt::aligned16(wfrag) && nup >= ((nu + 3) / 4) * 4 + 3,
+                "avt_conv3d_igemm_wfrag_bf16: fragment-order weights need Cout >= 256, K >= 1024, Cin %% 32 == 0 and nup >= %d units",
+                ((nu + 3) / 4) * 4 + 3);
+    const int64_t wfb = (int64_t)((cout + 255) / 256) * 8 * nup * 2048;
+    AVT_REQUIRE(wfb < (1ll << 31), "avt_conv3d_igemm_wfrag_bf16: fragment array too large for 32-bit offsets");
+    a.wf_bytes = (unsigned)wfb;
+    return launch_xb(a, s);
+  }
   // GEMM-like layers: the 256x256 LDS-DMA tile.  AVT_CONV_XL = minimum number of its tiles (0 = never),
   // AVT_CONV_XL_NK = minimum number of 64-wide K-steps.  A unit of 32 K must not straddle two taps: one tap, or
   // Cin % 32 == 0.

@@ -30,6 +30,7 @@ _FUSE_BC = int(os.environ.get("AVT_FUSE_BC", "0"))          # slow res2 identity
 _CHAIN = int(os.environ.get("AVT_PW_CHAIN", "1"))            # slow res2 / res3: c (+ residual) of block i and a of block i+1 in one pass
 _CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "512"))  # widest c to chain
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
+_XB = int(os.environ.get("AVT_CONV_XB", "1"))                # long-K layers: fragment-order weights that bypass the LDS (XB tile)
 _FUSE_SCAT = int(os.environ.get("AVT_FUSE_SCAT", "1"))      # slow res3-5 first blocks: strided shortcut folded into c's GEMM
 _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "16"))  # frames walked per workgroup (2 halo frames each)
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
@@ -90,6 +91,27 @@ def group_weights_w(w, g):
     return wg.reshape(g * cout, g * cin, kt, kh, kwg), rg
 
 
+def pack_wfrag(wt, cin, taps):
+    """[Cout, taps*cin] (tap-major K, cin innermost) -> the XB tile's fragment order (include/avt.h): [tiles of 32 rows,
+    nup units, 2 k-slices, 64 lanes, 8]; unit i = tap i % taps of channel chunk i // taps (single tap: chunk i)."""
+    wt = wt.detach().float().cpu()
+    cout, k = wt.shape
+    nu = -(-k // 32)
+    nup = -(-nu // 4) * 4 + 4
+    tiles = -(-cout // 256) * 8
+    wp = torch.zeros((tiles * 32, k + 1))  # column k = the zero that masked positions read
+    wp[:cout, :k] = wt
+    i = torch.arange(nup).view(-1, 1, 1, 1)
+    cc, tap = (i // taps, i % taps) if taps > 1 else (i, torch.zeros_like(i))
+    ks = torch.arange(2).view(1, -1, 1, 1)
+    lane = torch.arange(64).view(1, 1, -1, 1)
+    e = torch.arange(8).view(1, 1, 1, -1)
+    cch = cc * 32 + ks * 16 + (lane >> 5) * 8 + e  # input channel
+    kidx = torch.where((cch < cin) & (i < nu), tap * cin + cch, torch.full_like(cch, k)).expand(nup, 2, 64, 8)
+    rows = (torch.arange(tiles).view(-1, 1, 1, 1, 1) * 32 + (lane & 31).view(1, 1, 1, 64, 1)).expand(tiles, nup, 2, 64, 8)
+    return wp[rows, kidx.unsqueeze(0).expand(tiles, nup, 2, 64, 8)].to(torch.bfloat16).contiguous()
+
+
 class FusedConv:
     def __init__(self, conv, bn, relu, device, packed=None, folded=None):
         """packed = (wt [Cout, taps*Cin] fp32, bias, cin, kernel, stride, pad, crop) overrides the module;
@@ -116,6 +138,10 @@ class FusedConv:
         if cout % 8:  # pad the output channels with zero filters (the caller's buffer must be that wide)
             raise AvtError("FusedConv: output channels must be a multiple of 8 (got %d)" % cout)
         self.wt = wt.to(torch.bfloat16).contiguous().to(device)
+        self.wfrag = None
+        taps = self.kernel[0] * self.kernel[1] * self.kernel[2]
+        if _XB and ops.conv3d_wfrag_supported(self.cin, cout, self.kernel):
+            self.wfrag = pack_wfrag(self.wt.float().cpu(), self.cin, taps).to(device)
         self.bias = bias.float().contiguous().to(device)
         self.dev = device
         self._tabs = {}
@@ -183,7 +209,7 @@ class FusedConv:
             ops.conv3d_igemm(x.ptr, self.wt, self.bias, res.ptr if res is not None else 0, out.ptr, tab, x.dims,
                              self.cin, self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld,
                              res.ld if res is not None else 0, self.relu if relu is None else relu,
-                             out_dims=od[1:] if any(self.crop) else (0, 0, 0), out_rows=out_rows)
+                             out_dims=od[1:] if any(self.crop) else (0, 0, 0), out_rows=out_rows, wfrag=self.wfrag)
 
         if PROFILER is None:
             launch()

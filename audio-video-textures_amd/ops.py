@@ -204,12 +204,27 @@ def conv3d_ktab(cin, kernel, h, w, ldi):
     return tab
 
 
+def conv3d_wfrag_supported(cin, cout, kernel):
+    return bool(_lib.lib().avt_conv3d_igemm_wfrag_supported(int(cin), int(cout), *[int(k) for k in kernel]))
+
+
 def conv3d_igemm(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu,
-                 out_dims=(0, 0, 0), out_rows=None):
+                 out_dims=(0, 0, 0), out_rows=None, wfrag=None):
     """Raw launch: x_ptr/res_ptr/out_ptr are device addresses (int) of bf16 NDHWC rows; dims = (B,T,H,W).
     out_rows = (stride, H, W): output position (f, ho, wo) goes to row (f*H + stride*ho)*W + stride*wo of the output
     buffer (avt_conv3d_igemm_rows_bf16)."""
     b, t, h, w = dims
+    if wfrag is not None:  # (fragment-order weights [tiles, nup, 2, 64, 8]: the XB tile, weights bypass the LDS)
+        _dev(wfrag, "wfrag", torch.bfloat16)
+        orr = out_rows if out_rows is not None else (1, 0, 0)
+        _lib.check(_lib.lib().avt_conv3d_igemm_wfrag_bf16(C.c_void_p(x_ptr), _p(wt), _p(bias),
+                                                          C.c_void_p(res_ptr) if res_ptr else None, C.c_void_p(out_ptr),
+                                                          _p(ktab), b, t, h, w, int(cin), int(cout), *kernel, *stride, *pad,
+                                                          *out_dims, int(ldi), int(ldo), int(ldr), 1 if relu else 0,
+                                                          int(orr[0]), int(orr[1]), int(orr[2]), _p(wfrag),
+                                                          int(wfrag.shape[1]), _stream()),
+                   "avt_conv3d_igemm_wfrag_bf16")
+        return
     if out_rows is not None:
         _lib.check(_lib.lib().avt_conv3d_igemm_rows_bf16(C.c_void_p(x_ptr), _p(wt), _p(bias),
                                                          C.c_void_p(res_ptr) if res_ptr else None, C.c_void_p(out_ptr),

@@ -226,6 +226,22 @@ int avt_conv3d_igemm_rows_bf16(const void* in, const void* wt, const float* bias
                                int ldi, int ldo, int ldr, int relu,
                                int out_row_stride, int out_h, int out_w, void* stream);
 
+/* The same convolution for the GEMM-like layers (Cout >= 256, K >= 1024, Cin % 32 == 0) with the weights ALSO given in
+ * MFMA-fragment order along the kernel's K walk (taps innermost): wfrag [ceil(Cout/256)*8 tiles of 32 rows][nup units of
+ * 32 K][2 k-slices][64 lanes][8] bf16 — lane = row (lane & 31), k-half (lane >> 5); unit i = tap i % taps of input-channel
+ * chunk i / taps; element k = 16*slice + 8*half + e; zero beyond Cout / Cin / the last unit; nup >= 4*ceil(units/4) + 3
+ * (fused_slowfast.pack_wfrag).  The weight operand then bypasses the LDS (csrc/conv_igemm.hip, XB tile).
+ * wfrag = NULL is avt_conv3d_igemm_rows_bf16. */
+int avt_conv3d_igemm_wfrag_supported(int cin, int cout, int kt, int kh, int kw);
+int avt_conv3d_igemm_wfrag_bf16(const void* in, const void* wt, const float* bias,
+                                const void* res, void* out, const int32_t* ktab,
+                                int batch, int t, int h, int w, int cin, int cout,
+                                int kt, int kh, int kw, int st, int sh, int sw,
+                                int pt, int ph, int pw, int to, int ho, int wo,
+                                int ldi, int ldo, int ldr, int relu,
+                                int out_row_stride, int out_h, int out_w,
+                                const void* wfrag, int nup, void* stream);
+
 /* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) of the SlowFast stems on NDHWC bf16 rows
  * (bt = batch*frames); out may be a channel slice of a wider row buffer (ldo).
  * tgroup > 1: each input row holds `tgroup` consecutive frames of c/tgroup channels (the

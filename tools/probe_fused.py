@@ -32,9 +32,9 @@ def hook(name, launch, flops, nbytes):
     recs.append((a, e, flops, nbytes))
 shapes = []
 orig = avtex.ops.conv3d_igemm
-def spy(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu, out_dims=(0, 0, 0), out_rows=None):
-    shapes.append("cin%d cout%d k%s s%s in%s%s%s" % (cin, cout, kernel, stride, tuple(dims), " +res" if res_ptr else "", " ->rows x2" if out_rows else ""))
-    return orig(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu, out_dims, out_rows)
+def spy(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu, out_dims=(0, 0, 0), out_rows=None, wfrag=None):
+    shapes.append("cin%d cout%d k%s s%s in%s%s%s%s" % (cin, cout, kernel, stride, tuple(dims), " +res" if res_ptr else "", " ->rows x2" if out_rows else "", " XB" if wfrag is not None else ""))
+    return orig(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu, out_dims, out_rows, wfrag)
 orig_stem = avtex.ops.stem_conv
 def spy_stem(x_ptr, wt, bias, out_ptr, batch, t, h, pw, cout, kt, st, pt, relu=True):
     shapes.append("stem(LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)" % (cout, kt, st, batch, t, h, pw))
