@@ -1053,7 +1053,11 @@ extern "C" int avt_conv3d_igemm_rows_bf16(const void* in, const void* wt, const 
 
 extern "C" int avt_conv3d_igemm_wfrag_supported(int cin, int cout, int kt, int kh, int kw) {
   const int taps = kt * kh * kw;
-  return (cout >= 256 && (taps * cin + 63) / 64 >= 16 && cin % 32 == 0) ? 1 : 0;
+  static const int min_nk = []() {  // shortest K loop (64-wide steps) the XB tile is used for
+    const char* e = getenv("AVT_CONV_XB_NK");
+    return e ? atoi(e) : 16;
+  }();
+  return (cout >= 256 && (taps * cin + 63) / 64 >= min_nk && cin % 32 == 0) ? 1 : 0;
 }
 
 extern "C" int avt_conv3d_igemm_wfrag_bf16(const void* in, const void* wt, const float* bias, const void* res, void* out,
@@ -1130,7 +1134,7 @@ extern "C" int avt_conv3d_igemm_wfrag_bf16(const void* in, const void* wt, const
   if (wfrag) {
     const int nu = (a.K + 31) / 32;
     AVT_REQUIRE(avt_conv3d_igemm_wfrag_supported(cin, cout, kt, kh, kw) && avt::aligned16(wfrag) && nup >= ((nu + 3) / 4) * 4 + 3,
-                "avt_conv3d_igemm_wfrag_bf16: fragment-order weights need Cout >= 256, K >= 1024, Cin %% 32 == 0 and nup >= %d units",
+                "avt_conv3d_igemm_wfrag_bf16: fragment-order weights need Cout >= 256, a long K, Cin %% 32 == 0 and nup >= %d units",
                 ((nu + 3) / 4) * 4 + 3);
     const int64_t wfb = (int64_t)((cout + 255) / 256) * 8 * nup * 2048;
     AVT_REQUIRE(wfb < (1ll << 31), "avt_conv3d_igemm_wfrag_bf16: fragment array too large for 32-bit offsets");

@@ -110,5 +110,7 @@ int main(int argc, char** argv) {
   run<6, 4, 0>(seed, buf, out, iters, "  6 ds_read + 4 LDS-DMA (128x128 wave tiles)");
   run<0, 0, 0, true>(seed, buf, out, iters, "32 MFMA 16x16x32 per iteration (same FLOPs), 2 waves per SIMD");
   run<12, 4, 0, true>(seed, buf, out, iters, "  + 12 ds_read + 4 LDS-DMA (the XL mix on the 16x16x32 shape)");
+  run<8, 2, 0, true>(seed, buf, out, iters, "  + 8 ds_read + 2 LDS-DMA (the XB mix without its register loads) on 16x16x32");
+  run<8, 2, 4, true>(seed, buf, out, iters, "  + 8 ds_read + 2 LDS-DMA + 4 packed loads on 16x16x32");
   return 0;
 }
