@@ -58,6 +58,9 @@ def _run(avt, dev, cin, cout, k, s, p, dims, relu, with_res, ld_extra=0):
     (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 14, 14)),    # GEMM-like: 256x256 LDS-DMA tile when enabled
     (128, 328, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 8, 9, 7)),      # ... with an N tail (328 = 256 + 72) and ragged M
     (264, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 4, 10, 10)),    # ... K tail (264 = 4 K-steps + 8), strided
+    (1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 4, 5, 5)),     # XB tile (fragment-order weights in registers): temporal
+    (256, 328, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 9, 7)),      # ... N tail, ragged M
+    (160, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 12, 10)),    # ... 45 K units (three all-zero trailing units), strided
 ])
 @pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
 def test_conv_igemm_matches_torch(avt, dev, cin, cout, k, s, p, dims, relu, with_res):

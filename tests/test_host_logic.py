@@ -135,3 +135,24 @@ def test_operator_and_train_refuse_cpu(avt):
         m(q, torch.zeros(1, 12, 32, 32, 3), is_inference=True)
     with pytest.raises(AvtError, match="no CPU fallback"):
         avt.ops.l2norm_rows(torch.zeros(4, 8))
+
+
+def test_pack_wfrag_is_the_documented_fragment_order(avt):
+    """fused_slowfast.pack_wfrag against include/avt.h's description of avt_conv3d_igemm_wfrag_bf16's weight array, element
+    by element on small shapes (host code: runs without a GPU)."""
+    import torch
+    from avtex.fused_slowfast import pack_wfrag
+
+    for cout, cin, taps in ((40, 64, 3), (264, 32, 1), (32, 96, 9)):
+        g = torch.Generator().manual_seed(cout + taps)
+        w = torch.randn(cout, taps * cin, generator=g)
+        f = pack_wfrag(w, cin, taps)
+        nu = -(-taps * cin // 32)
+        assert f.shape == (-(-cout // 256) * 8, -(-nu // 4) * 4 + 4, 2, 64, 8) and f.dtype == torch.bfloat16
+        wb = w.to(torch.bfloat16)
+        for tile, unit, ks, lane, e in ((0, 0, 0, 0, 0), (1, 2, 1, 37, 3), (0, nu - 1, 1, 63, 7), (1, nu, 0, 5, 1), (7, 1, 0, 31, 2)):
+            row = tile * 32 + (lane & 31)
+            cc, tap = (unit // taps, unit % taps) if taps > 1 else (unit, 0)
+            ch = cc * 32 + ks * 16 + (lane >> 5) * 8 + e
+            want = wb[row, tap * cin + ch] if (row < cout and unit < nu and ch < cin) else torch.tensor(0.0, dtype=torch.bfloat16)
+            assert f[tile, unit, ks, lane, e] == want, (cout, cin, taps, tile, unit, ks, lane, e)
