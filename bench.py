@@ -306,7 +306,7 @@ def attach_pmc_traffic(kern, args):
             b, _ = kb(table[k["kernel"]])
             k["traffic"] = b or None
         elif k["kernel"] == "conv3d_igemm_bf16":
-            b, n = kb(("conv_igemm_kernel", "conv_xl_kernel", "stem_kernel", "bottleneck_kernel", "c33_kernel", "pw_chain"), "total")  # every launch the hook counts
+            b, n = kb(("conv_igemm_kernel", "conv_xl_kernel", "conv_xb_kernel", "stem_kernel", "bottleneck_kernel", "c33_kernel", "pw_chain"), "total")  # every launch the hook counts
             k["traffic"] = b / n if n else None  # average over the launches of a forward
         if k["traffic"]:
             k["traffic_source"] = "profiles/r01/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE)"
