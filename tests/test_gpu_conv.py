@@ -581,3 +581,30 @@ def test_conv_rows_remap_writes_behind_the_input_channels(avt, dev, c, dims):
         fc(Act(x, dims), out=Act(wide, dims, 8, c), out_rows=(2, ho, wo))  # grid too small for 2 x (ho, wo)
     with pytest.raises(AvtError):
         fc(Act(x, dims), out=Act(wide, dims, 8, c), res=plain, out_rows=(2, h, w))
+
+
+@pytest.mark.parametrize("cin,cout,k,p,dims", [(256, 256, (1, 3, 3), (0, 1, 1), (2, 3, 14, 14)),
+                                                (1024, 264, (3, 1, 1), (1, 0, 0), (1, 4, 6, 5))])
+def test_xb_and_xl_tiles_agree(avt, dev, cin, cout, k, p, dims):
+    """The two long-K tiles on the same layer: XB (fragment-order weights straight into registers, the default) and XL (both
+    operands through the LDS-DMA ring, what a caller without packed weights gets) — same products, different fp32
+    summation order only in the K walk they share, so the bf16 outputs agree almost everywhere; + residual path."""
+    from avtex.fused_slowfast import Act, FusedConv
+
+    torch.manual_seed(cin + cout)
+    conv = nn.Conv3d(cin, cout, k, padding=p, bias=False)
+    bn = nn.BatchNorm3d(cout).eval()
+    fc = FusedConv(conv, bn, True, dev)
+    assert fc.wfrag is not None and avt.ops.conv3d_wfrag_supported(cin, cout, k)
+    b, t, h, w = dims
+    x = Act(torch.randn(b * t * h * w, cin).to(torch.bfloat16).to(dev), dims)
+    res = Act(torch.randn(b * t * h * w, cout).to(torch.bfloat16).to(dev), dims)
+    xb, xb_r = fc(x).buf.clone(), fc(x, res=res).buf.clone()
+    keep, fc.wfrag = fc.wfrag, None
+    xl, xl_r = fc(x).buf.clone(), fc(x, res=res).buf.clone()
+    fc.wfrag = keep
+    torch.cuda.synchronize()
+    for got, ref in ((xb, xl), (xb_r, xl_r)):
+        scale = max(ref.float().abs().max().item(), 1.0)
+        assert (got.float() - ref.float()).abs().max().item() <= 0.01 * scale
+        assert (got != ref).float().mean().item() < 0.02
