@@ -819,6 +819,11 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
         wq[S][ks][n] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rwf, (int)(ub + n * wft + ks * 1024u), 0, 0));
   };
   const int xa = (lr >> 2) & 3;
+#ifdef AVT_CONV_STAMP
+  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long t0_ = last_, r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // One unit with every ring index static.  Phase A: fragment reads of the activations, offsets of unit i+3, waits;
   // phase B: 16 MFMAs with the DMA pieces and weight-fragment loads of unit i+3 and the scalar decode in their shadow.
@@ -836,9 +841,11 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
     // my part of unit i+1 (pieces and fragments) is done when only unit i+2's operations are outstanding
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UOPS) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(1);  // phase A: reads, offsets, waits
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(3);  // barrier after A
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -855,9 +862,11 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
       if (g % 2 == 1 && g < 2 * UOPS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
+    STAMP(2);  // phase B: MFMAs + DMA pieces + fragment loads + decode
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(5);  // barrier after B
   };
 
   decode(0);
@@ -875,6 +884,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
   decode(3);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UOPS) : "memory");  // my part of unit 0
   __builtin_amdgcn_s_barrier();
+  STAMP(0);  // prologue
   if (grp == 1) __builtin_amdgcn_s_barrier();
   for (int i = 0; i < nu; i += 4) {  // (a K that is not a multiple of 128 multiplies up to three all-zero units)
     body(std::integral_constant<int, 0>{}, i);
@@ -951,6 +961,15 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
     }
     __syncthreads();
   }
+#ifdef AVT_CONV_STAMP
+  STAMP(6);  // epilogue
+  if (tid == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[i], seg_[i]);
+    atomicAdd(&g_stamp[7], 1ull);
+    atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - t0_);
+    atomicAdd(&g_stamp[9], __builtin_amdgcn_s_memrealtime() - r0_);
+  }
+#endif
 }
 
 int launch_xb(ConvArgs& a, hipStream_t st) {
