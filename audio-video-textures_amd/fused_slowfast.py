@@ -32,7 +32,8 @@ _CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "512"))  # widest c to cha
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
 _XB = int(os.environ.get("AVT_CONV_XB", "1"))                # long-K layers: fragment-order weights that bypass the LDS (XB tile)
 _FUSE_SCAT = int(os.environ.get("AVT_FUSE_SCAT", "1"))      # slow res3-5 first blocks: strided shortcut folded into c's GEMM
-_FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "16"))  # frames walked per workgroup (2 halo frames each)
+_FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "0"))   # frames walked per workgroup (2 halo frames each); 0 = by width:
+#                                                              16 at 56 columns (more workgroups), the whole clip (32) below
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 _STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "1"))  # max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both
 #                                                         (the MFMA-bound fast stem loses 4 % to the recomputed ninth row)
@@ -559,7 +560,7 @@ class _Block:
             y = Act(torch.empty((b * t * h * w, x.C), dtype=torch.bfloat16, device=self.dev), x.dims)
 
             def launch():
-                ops.bottleneck_fused(x.ptr, y.ptr, self.fused, b, t, h, w, x.C, tchunk=_FUSE_TCHUNK)
+                ops.bottleneck_fused(x.ptr, y.ptr, self.fused, b, t, h, w, x.C, tchunk=_FUSE_TCHUNK or (16 if w >= 56 else 32))
 
             if PROFILER is None:
                 launch()
@@ -577,7 +578,8 @@ class _Block:
             y = Act(torch.empty((mo, self.c.cout), dtype=torch.bfloat16, device=self.dev), od)
 
             def launch():
-                ops.bottleneck_first(x.ptr, y.ptr, self.fused_first, b, t, h, w, x.C, self.c.cout, tchunk=_FUSE_TCHUNK)
+                ops.bottleneck_first(x.ptr, y.ptr, self.fused_first, b, t, h, w, x.C, self.c.cout,
+                                     tchunk=_FUSE_TCHUNK or (16 if w >= 56 else 32))
 
             if PROFILER is None:
                 launch()
