@@ -109,6 +109,7 @@ struct ConvArgs {
   const uint16_t* wfrag;        // XB kernel: weights in MFMA-fragment order [Cout/32][nup][2][64][8] (walk order of K), or NULL
   int nup;                      // ... units per 32-row tile in that array (>= units walked + 3)
   unsigned wf_bytes;
+  int issue_a;                  // XB kernel: DMA pieces issued in the read phase
   int ors, oH, oW;              // output row remap: position (f, ho, wo) -> row (f * oH + ors * ho) * oW + ors * wo (ors = 1: none)
 };
 
@@ -838,8 +839,15 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
       for (int j = 0; j < MT; ++j) af[ks][j] = *reinterpret_cast<const bf16x8*>(st + (wm * WTM + j * 32 + lr) * 64 + koff);
     }
     offsets(i + 3, exb_n, ey_n);
-    // my part of unit i+1 (pieces and fragments) is done when only unit i+2's operations are outstanding
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UOPS) : "memory");
+    if (a.issue_a) {
+      // the two DMA pieces of unit i+3 are issued HERE (a piece costs 60-185 issue cycles: in the read phase they overlap
+      // the counted wait instead of stretching the MFMA phase); unit i+2's operations + these two stay outstanding
+      issue((S + 3) & (XR - 1));
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UOPS + AIW) : "memory");
+    } else {
+      // my part of unit i+1 (pieces and fragments) is done when only unit i+2's operations are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UOPS) : "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     STAMP(1);  // phase A: reads, offsets, waits
     __builtin_amdgcn_sched_barrier(0);
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j)
           acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S][ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
-    issue((S + 3) & (XR - 1));
+    if (!a.issue_a) issue((S + 3) & (XR - 1));
     loadb(std::integral_constant<int, (S + 3) & (XR - 1)>{}, i + 3);
     decode(i + 4);
 #pragma unroll
@@ -981,6 +989,11 @@ int launch_xb(ConvArgs& a, hipStream_t st) {
   a.dKW = make_fastdiv((uint32_t)a.KW);
   a.dNT = make_fastdiv((uint32_t)(a.KT * a.KH * a.KW));
   a.tapinner = 1;
+  static const int issue_a = []() {
+    const char* e = getenv("AVT_XB_ISSUE_A");
+    return e ? atoi(e) : 1;  // +1-5 % per layer (profiles/r01/probe_ab_chain.log)
+  }();
+  a.issue_a = issue_a;
   constexpr int lds_bytes = 128 * (256 * 2 + 16) > 4 * 256 * 64 ? 128 * (256 * 2 + 16) : 4 * 256 * 64;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<0>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
