@@ -12,7 +12,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/convpmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "conv_igemm" in row["Kernel_Name"] or "conv_xl" in row["Kernel_Name"] or "stem_kernel" in row["Kernel_Name"]:
+        if "conv_igemm" in row["Kernel_Name"] or "conv_xl" in row["Kernel_Name"] or "conv_xb" in row["Kernel_Name"] or "stem_kernel" in row["Kernel_Name"]:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print("%-28s mean %.4g (n=%d)" % (k, sum(v) / len(v), len(v)))
