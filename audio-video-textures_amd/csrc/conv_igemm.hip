@@ -109,7 +109,6 @@ struct ConvArgs {
   const uint16_t* wfrag;        // XB kernel: weights in MFMA-fragment order [Cout/32][nup][2][64][8] (walk order of K), or NULL
   int nup;                      // ... units per 32-row tile in that array (>= units walked + 3)
   unsigned wf_bytes;
-  int issue_a;                  // XB kernel: DMA pieces issued in the read phase
   int ors, oH, oW;              // output row remap: position (f, ho, wo) -> row (f * oH + ors * ho) * oW + ors * wo (ors = 1: none)
 };
 
@@ -722,7 +721,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
 // pre-packed on the host in MFMA-fragment order along the K walk, so a wave fetches its four fragments of a unit with
 // four fully coalesced 1 KB loads straight into registers, three units ahead (a ring of four register sets; the loop is
 // unrolled by four so every index is static).  Same two-phase wave groups, same epilogue.
-template <int UNUSED>
+template <bool ISSUE_A>  // the DMA pieces of unit i+3 are issued in the read phase (true) or under the MFMAs
 __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
   constexpr int XBM = 256, XBN = 256, WN = 4, WTM = 128, WTN = 64, MT = 4, NT = 2;
   constexpr int XUNIT = XBM * 64;  // one 32-wide K slice of the activations
@@ -839,7 +838,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
       for (int j = 0; j < MT; ++j) af[ks][j] = *reinterpret_cast<const bf16x8*>(st + (wm * WTM + j * 32 + lr) * 64 + koff);
     }
     offsets(i + 3, exb_n, ey_n);
-    if (a.issue_a) {
+    if constexpr (ISSUE_A) {
       // the two DMA pieces of unit i+3 are issued HERE (a piece costs 60-185 issue cycles: in the read phase they overlap
       // the counted wait instead of stretching the MFMA phase); unit i+2's operations + these two stay outstanding
       issue((S + 3) & (XR - 1));
@@ -861,14 +860,14 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j)
           acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S][ks][n], af[ks][j], acc[n][j], 0, 0, 0);  // D[n][m]
-    if (!a.issue_a) issue((S + 3) & (XR - 1));
+    if constexpr (!ISSUE_A) issue((S + 3) & (XR - 1));
     loadb(std::integral_constant<int, (S + 3) & (XR - 1)>{}, i + 3);
     decode(i + 4);
 #pragma unroll
     for (int g = 0; g < NMF; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
-      if (g % 2 == 1 && g < 2 * UOPS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (g % 2 == 1 && g < 2 * (ISSUE_A ? BLD : UOPS)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     STAMP(2);  // phase B: MFMAs + DMA pieces + fragment loads + decode
     __builtin_amdgcn_sched_barrier(0);
@@ -993,15 +992,19 @@ int launch_xb(ConvArgs& a, hipStream_t st) {
     const char* e = getenv("AVT_XB_ISSUE_A");
     return e ? atoi(e) : 1;  // +1-5 % per layer (profiles/r01/probe_ab_chain.log)
   }();
-  a.issue_a = issue_a;
   constexpr int lds_bytes = 128 * (256 * 2 + 16) > 4 * 256 * 64 ? 128 * (256 * 2 + 16) : 4 * 256 * 64;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<0>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  static const hipError_t e = issue_a ? hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
+                                     : hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<false>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((conv_xb_kernel<0>), dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
+  if (issue_a)
+    hipLaunchKernelGGL((conv_xb_kernel<true>), dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((conv_xb_kernel<false>), dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_bf16");
 }
 
