@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavt_hip.so")
+# AVT_HIP_LIB selects another build of the same ABI (the diagnostic libavt_hip_stamp.so of `make stamp`); default = the product
+LIB_PATH = os.environ.get("AVT_HIP_LIB") or os.path.join(_HERE, "libavt_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avt.h")
 
 _i32p, _i64p, _f32p, _vp = (C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_void_p)
@@ -40,8 +41,6 @@ SIGNATURES = {
     "avt_bottleneck_fused_bf16": [_vp] * 8 + [C.c_int] * 6 + [_vp],
     "avt_bottleneck_first_supported": [C.c_int] * 3,
     "avt_bottleneck_first_bf16": [_vp] * 9 + [C.c_int] * 7 + [_vp],
-    "avt_bc_fused_supported": [C.c_int] * 3,
-    "avt_bc_fused_bf16": [_vp] * 7 + [C.c_int] * 8 + [_vp],
     "avt_pairwise_l2_f32": [_vp, C.c_int, C.c_int64, _vp, _vp],
     "avt_conv33_c64_supported": [C.c_int] * 3,
     "avt_conv33_c64_bf16": [_vp] * 4 + [C.c_int] * 6 + [_vp],

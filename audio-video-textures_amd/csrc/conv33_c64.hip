@@ -8,7 +8,7 @@
 // strip of 4 rows of one clip and walks its frames: the 72 weight fragments stay in LDS for the whole walk, the input
 // strip (6 rows, LDS-DMA with hardware zero fill, double-buffered: frame t+1 lands under frame t's MFMAs) is read at
 // tap-shifted addresses — every input byte crosses HBM / L2 once (+ the 2-row halo) — and the K loop is 18 MFMA
-// k-steps on register/LDS operands.  HBM-bound by construction.  Same strip layout as csrc/bc_fused.hip.
+// k-steps on register/LDS operands.  HBM-bound by construction.
 #include <stdlib.h>
 
 #include "avt_common.h"

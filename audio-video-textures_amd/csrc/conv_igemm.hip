@@ -70,18 +70,13 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
 }
 
 #ifdef AVT_CONV_STAMP
-// diagnostic build only (tools/probe_stamps.sh): cycles per K-loop segment, summed over workgroups (wave 0, lane 0)
-__device__ unsigned long long g_stamp[10];  // [0..6] segments, [7] workgroups, [8] s_memtime ticks, [9] s_memrealtime ticks (100 MHz)
-#define STAMP(i)                                                          \
-  do {                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    seg_[i] += now_ - last_;                                              \
-    last_ = now_;                                                         \
-  } while (0)
+// diagnostic build only (`make stamp` -> libavt_hip_stamp.so, never the shipped library): the hooks live in tools/diag
+#include "../../tools/diag/conv_stamp.h"
 #else
+#define STAMP_BEGIN()
 #define STAMP(i)
+#define STAMP_FINE(i)
+#define STAMP_END()
 #endif
 
 struct ConvArgs {
@@ -254,11 +249,7 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN, WTM)) void conv_ige
     for (int u = 0; u < BU; ++u) *reinterpret_cast<i32x4*>(lds + A_BYTES + (r0 + 32 * u) * LSTR + c16 * 16) = rb[u];
   };
   if constexpr (TABLDS) __syncthreads();
-#ifdef AVT_CONV_STAMP
-  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long last_ = __builtin_amdgcn_s_memtime();
-  const unsigned long long t0_ = last_, r0_ = __builtin_amdgcn_s_memrealtime();
-#endif
+  STAMP_BEGIN();
   gload(0);
   lstore();
   __syncthreads();
@@ -350,15 +341,7 @@ __global__ __launch_bounds__(256, AVT_CONV_MIN_WAVES(BM, BN, WTM)) void conv_ige
     }
     if (p + 1 < EPASS) __syncthreads();  // the staging tile is reused by the next wave-row
   }
-#ifdef AVT_CONV_STAMP
-  STAMP(6);  // epilogue
-  if (tid == 0) {
-    for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[i], seg_[i]);
-    atomicAdd(&g_stamp[7], 1ull);
-    atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - t0_);
-    atomicAdd(&g_stamp[9], __builtin_amdgcn_s_memrealtime() - r0_);
-  }
-#endif
+  STAMP_END();
 }
 
 template <int BM, int BN, int WTM, bool TABLDS = true>
@@ -551,11 +534,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U * AIW) : "memory");
   };
   const int xa = (lr >> 2) & 3;  // swizzle key of this lane's fragment rows (tile offsets are multiples of 16)
-#ifdef AVT_CONV_STAMP
-  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long last_ = __builtin_amdgcn_s_memtime();
-  const unsigned long long t0_ = last_, r0_ = __builtin_amdgcn_s_memrealtime();
-#endif
+  STAMP_BEGIN();
   for (int i = 0; i < 3; ++i) {  // units past the end of K are all-zero fills (stage_*: kin false): uniform counting
     decode(i);
     offsets(i, exb_n, ey_n);
@@ -588,23 +567,16 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
       for (int n = 0; n < NT; ++n)
         wf[ks][n] = *reinterpret_cast<const bf16x8*>(st + XBM * 64 + (wn * WTN + n * 32 + lr) * 64 + koff);
     }
-#ifdef AVT_CONV_STAMP_FINE
-    STAMP(4);  // fragment-read issue
-#endif
+    STAMP_FINE(4);  // fragment-read issue
 #if !XL_DECODE_IN_B
     decode(i + 3);  // scalar tap decode of the unit issued in the coming phase B (phase A has the slack: stamps)
 #endif
     offsets(i + 3, exb_n, ey_n);  // per-lane selects of that unit
-#ifdef AVT_CONV_STAMP_FINE
-    STAMP(6);  // offset selects (slot 6 is re-used: the epilogue share is lost in this mode)
-    wait_units(std::integral_constant<int, 1>{});
-    STAMP(0);  // vmcnt wait (slot 0 re-used)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
+    STAMP_FINE(6);  // offset selects (slot 6 is re-used: the epilogue share is lost in this mode)
     // this wave's part of unit i+1 has landed when only unit i+2's 4 DMAs are outstanding (unit i+3 is issued in B)
     wait_units(std::integral_constant<int, 1>{});
+    STAMP_FINE(0);  // vmcnt wait (slot 0 re-used)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     STAMP(1);  // phase A: reads + DMA issue + waits
     __builtin_amdgcn_sched_barrier(0);  // the phases are the schedule: nothing moves across their barriers
     __builtin_amdgcn_s_barrier();
@@ -703,15 +675,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xl_kernel(ConvArgs a) {
     }
     if (p + 1 < EPASS) __syncthreads();
   }
-#ifdef AVT_CONV_STAMP
-  STAMP(6);  // epilogue
-  if (tid == 0) {
-    for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[i], seg_[i]);
-    atomicAdd(&g_stamp[7], 1ull);
-    atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - t0_);
-    atomicAdd(&g_stamp[9], __builtin_amdgcn_s_memrealtime() - r0_);
-  }
-#endif
+  STAMP_END();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -819,11 +783,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
         wq[S][ks][n] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rwf, (int)(ub + n * wft + ks * 1024u), 0, 0));
   };
   const int xa = (lr >> 2) & 3;
-#ifdef AVT_CONV_STAMP
-  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long last_ = __builtin_amdgcn_s_memtime();
-  const unsigned long long t0_ = last_, r0_ = __builtin_amdgcn_s_memrealtime();
-#endif
+  STAMP_BEGIN();
 
   // One unit with every ring index static.  Phase A: fragment reads of the activations, offsets of unit i+3, waits;
   // phase B: 16 MFMAs with the DMA pieces and weight-fragment loads of unit i+3 and the scalar decode in their shadow.
@@ -968,15 +928,7 @@ __global__ __launch_bounds__(XT, 2) void conv_xb_kernel(ConvArgs a) {
     }
     __syncthreads();
   }
-#ifdef AVT_CONV_STAMP
-  STAMP(6);  // epilogue
-  if (tid == 0) {
-    for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[i], seg_[i]);
-    atomicAdd(&g_stamp[7], 1ull);
-    atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - t0_);
-    atomicAdd(&g_stamp[9], __builtin_amdgcn_s_memrealtime() - r0_);
-  }
-#endif
+  STAMP_END();
 }
 
 int launch_xb(ConvArgs& a, hipStream_t st) {
@@ -1035,17 +987,6 @@ int launch_xl(ConvArgs& a, hipStream_t st) {
 }
 
 }  // namespace
-
-#ifdef AVT_CONV_STAMP
-extern "C" int avt_debug_stamps(unsigned long long* out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 10);
-  if (reset) {
-    unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
-  }
-  return 0;
-}
-#endif
 
 extern "C" int avt_conv3d_ktab(int cin, int kt, int kh, int kw, int h, int w, int ldi, int32_t* ktab, int n_entries) {
   AVT_REQUIRE(ktab && cin > 0 && cin % 8 == 0, "avt_conv3d_ktab: Cin must be a positive multiple of 8");

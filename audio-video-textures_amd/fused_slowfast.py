@@ -25,8 +25,6 @@ import os
 
 _FUSE_BLOCK = int(os.environ.get("AVT_FUSE_BLOCK", "1"))    # fast-pathway identity bottlenecks as one kernel
 _C33 = int(os.environ.get("AVT_C33", "1"))                  # slow res2 b conv on the strip-resident kernel
-_FUSE_BC = int(os.environ.get("AVT_FUSE_BC", "0"))          # slow res2 identity blocks: b + c + residual in one kernel
-#   (bit-compatible with the 3-launch path, but 0.84 ms against 0.75 ms: one 7-wave workgroup per CU is latency-bound)
 _CHAIN = int(os.environ.get("AVT_PW_CHAIN", "1"))            # slow res2 / res3: c (+ residual) of block i and a of block i+1 in one pass
 _CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "512"))  # widest c to chain
 _FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
@@ -364,33 +362,6 @@ def pack_pw(w, device):
     return wp[row, col].to(torch.bfloat16).contiguous().to(device)
 
 
-def pack_bc(wb, bb, wc, bc, device):
-    """BN-folded b [64,64,1,3,3] and c [256,64,1,1,1] of a slow res2 bottleneck -> the MFMA-fragment order of
-    csrc/bc_fused.hip (include/avt.h)."""
-    wb, bb, wc, bc = [v.detach().float().cpu() for v in (wb, bb, wc, bc)]
-    cm, c = wb.shape[0], wc.shape[0]
-    lane = torch.arange(64)
-    n, q = lane & 15, lane >> 4
-    e = torch.arange(8)
-    L, E = 64, 8
-    wb9 = wb[:, :, 0].reshape(cm, cm, 9)  # [n, ch, tap]
-    tap = torch.arange(9).view(-1, 1, 1, 1, 1)
-    kh = torch.arange(2).view(1, -1, 1, 1, 1)
-    nt = torch.arange(cm // 16).view(1, 1, -1, 1, 1)
-    shape = (9, 2, cm // 16, L, E)
-    row = (nt * 16 + n.view(1, 1, 1, -1, 1)).expand(shape)
-    ch = (kh * 32 + q.view(1, 1, 1, -1, 1) * 8 + e.view(1, 1, 1, 1, -1)).expand(shape)
-    wb_f = wb9[row, ch, tap.expand(shape)]
-    ntc = torch.arange(c // 16).view(-1, 1, 1, 1)
-    kk = torch.arange(cm // 32).view(1, -1, 1, 1)
-    shc = (c // 16, cm // 32, L, E)
-    chan = (32 * (ntc // 2) + 8 * (n >> 2).view(1, 1, -1, 1) + 4 * (ntc % 2) + (n & 3).view(1, 1, -1, 1)).expand(shc)
-    kc = (kk * 32 + q.view(1, 1, -1, 1) * 8 + e.view(1, 1, 1, -1)).expand(shc)
-    wc_f = wc[:, :, 0, 0, 0][chan, kc]
-    dev = lambda v, dt: v.to(dt).contiguous().to(device)
-    return dev(wb_f, torch.bfloat16), dev(bb, torch.float32), dev(wc_f, torch.bfloat16), dev(bc, torch.float32)
-
-
 class _Block:
     def __init__(self, blk, device):
         self.b1 = FusedConv(blk.branch1, blk.branch1_bn, False, device) if hasattr(blk, "branch1") else None
@@ -422,13 +393,6 @@ class _Block:
         if (_C33 and self.b.kernel == (1, 3, 3) and self.b.stride == (1, 1, 1) and self.b.cin == 64 and self.b.cout == 64 and
                 self.b._folded is not None):
             self.c33 = (pack_c33(self.b._folded[0], device), self.b.bias)
-        # slow res2 identity blocks (a 1x1x1, b [1,3,3] 64 -> 64, c 64 -> 256): b, c and the residual add in one kernel
-        self.bc = None
-        if (_FUSE_BC and self.b1 is None and self.a.kernel == (1, 1, 1) and self.b.kernel == (1, 3, 3) and
-                self.c.kernel == (1, 1, 1) and self.b.stride == (1, 1, 1) and self.b.cin == 64 and self.b.cout == 64 and
-                self.c.cout == 256):
-            (wb, bb), (wc, bc) = self.b._folded, self.c._folded
-            self.bc = pack_bc(wb, bb, wc, bc, device)
         # first block of a stage with a stride-1 1x1x1 shortcut conv and pointwise a (slow res2): c and the shortcut are
         # ONE GEMM over K = [x | b-output] when b writes its output into spare columns of x's row buffer — no shortcut
         # launch, no residual read (self.extra = columns the caller must leave free behind x)
@@ -468,7 +432,7 @@ class _Block:
             return False
         if self.c.cout > _CHAIN_MAXN or self._scat_ok(x):
             return False
-        if any(v is not None for v in (self.fused, self.fused_first, self.bc, nxt.fused, nxt.fused_first, nxt.bc, nxt.ccat)):
+        if any(v is not None for v in (self.fused, self.fused_first, nxt.fused, nxt.fused_first, nxt.ccat)):
             return False
         kcat = self.ccat is not None and x.c0 == 0 and x.ld >= x.C + self.extra and x.C == self.a.cin
         k1 = x.C + self.extra if kcat else self.c.cin
@@ -537,23 +501,6 @@ class _Block:
             if chain is not None:
                 return self._chain(m, self.c.cin, self.c, sc, chain, m.dims, y=out, x2=x2)
             return self.c(m, out=out, res=sc, relu=True)
-        if (self.bc is not None and x.c0 == 0 and ops.bc_fused_supported(self.b.cin, self.c.cout, x.dims[3]) and
-                x.C == self.c.cout):
-            b, t, h, w = x.dims
-            m1 = self.a(x)
-            if out is None:
-                out = Act(torch.empty((b * t * h * w, self.c.cout), dtype=torch.bfloat16, device=self.dev), x.dims)
-
-            def launch():
-                ops.bc_fused(m1.ptr, x.ptr, out.ptr, self.bc, b, t, h, w, self.b.cin, self.c.cout, x.ld, out.ld)
-
-            if PROFILER is None:
-                launch()
-            else:
-                m = b * t * h * w
-                PROFILER("conv3d_igemm_bf16", launch, m * (self.b.alg_flops_per_row + self.c.alg_flops_per_row),
-                         2.0 * m * (self.b.cin + 2 * self.c.cout))
-            return out
         if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
                 ops.bottleneck_fused_supported(x.C, x.dims[3])):
             b, t, h, w = x.dims

@@ -139,7 +139,12 @@ def main(args, video_name, itr=0):
         for enc in (model.q_encoder, model.t_encoder):
             enc.to(torch.bfloat16).to(memory_format=torch.channels_last_3d)
     if world > 1 and not args.evaluate:  # weights resident per rank, gradients all-reduced over RCCL
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+        # q_a_mlp / t_a_mlp exist only so reference checkpoints load by key and are never called (models.py:267-284):
+        # frozen here, or DDP's reducer would wait for gradients that never come (DataParallel tolerated them)
+        for name in ("q_a_mlp", "t_a_mlp"):
+            if hasattr(model, name):
+                getattr(model, name).requires_grad_(False)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local] if device.type == "cuda" else None)
     torch.backends.cudnn.benchmark = True
     tb_logdir = os.path.join(args.logdir, logname)
     os.makedirs(tb_logdir, exist_ok=True)

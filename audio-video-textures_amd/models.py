@@ -72,15 +72,18 @@ class _InfoNCELogits(torch.autograd.Function):
         return dq, dt, None
 
     @staticmethod
-    def apply_ops(q, t, temp):
-        """-> (logits [B,n], q_hat [B,1,D], t_hat [B,D,n]); the unit vectors are only materialised for cam_viz."""
+    def apply_ops(q, t, temp, want_unit=False):
+        """-> (logits [B,n], q_hat [B,1,D] | None, t_hat [B,D,n] | None); the unit vectors are only materialised when the
+        caller returns them (cam_viz) — the fused kernel never needs them."""
         if not q.is_cuda:
             raise AvtError("ContrastivePredictionTemporal training needs the model on the MI355X (model.cuda()); "
                            "the normalise/bmm/temperature branch runs on the HIP InfoNCE kernels, no CPU fallback")
         out = _InfoNCELogits.apply(q, t, temp)
-        with torch.no_grad():
-            qh = F.normalize(q, dim=1).unsqueeze(1)
-            th = F.normalize(t, dim=2).permute(0, 2, 1)
+        qh = th = None
+        if want_unit:
+            with torch.no_grad():
+                qh = F.normalize(q, dim=1).unsqueeze(1)
+                th = F.normalize(t, dim=2).permute(0, 2, 1)
         return out, qh, th
 
 
@@ -193,7 +196,7 @@ class ContrastivePredictionTemporal(nn.Module):
         if self.training:
             qc = q_v if q_a is None else torch.cat((q_v, q_a), dim=1)
             tc = t_v if t_a is None else torch.cat((t_v, t_a), dim=2)
-            output, q, t = _InfoNCELogits.apply_ops(qc, tc, self.temp)
+            output, q, t = _InfoNCELogits.apply_ops(qc, tc, self.temp, want_unit=cam_viz)
         else:
             if not q_v.is_cuda:
                 raise AvtError("ContrastivePredictionTemporal inference needs the model on the MI355X "

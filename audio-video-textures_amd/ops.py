@@ -304,18 +304,6 @@ def bottleneck_first(x_ptr, out_ptr, packed, batch, t, h, w, cin, c, tchunk=8):
                                                     int(c), int(tchunk), _stream()), "avt_bottleneck_first_bf16")
 
 
-def bc_fused_supported(cm, c, w):
-    return bool(_lib.lib().avt_bc_fused_supported(int(cm), int(c), int(w)))
-
-
-def bc_fused(m_ptr, res_ptr, out_ptr, packed, batch, t, h, w, cm, c, ldr, ldo):
-    """Slow res2 bottleneck tail: relu(c(relu(b(m))) + res) in one kernel; packed = fused_slowfast.pack_bc(...)."""
-    wb, bb, wc, bc = packed
-    _lib.check(_lib.lib().avt_bc_fused_bf16(C.c_void_p(m_ptr), C.c_void_p(res_ptr), C.c_void_p(out_ptr), _p(wb), _p(bb),
-                                            _p(wc), _p(bc), int(batch), int(t), int(h), int(w), int(cm), int(c), int(ldr),
-                                            int(ldo), _stream()), "avt_bc_fused_bf16")
-
-
 def conv33_c64_supported(cin, cout, w):
     return bool(_lib.lib().avt_conv33_c64_supported(int(cin), int(cout), int(w)))
 

@@ -173,29 +173,43 @@ class TextureEngine:
         parts = 2 if self.n_streams >= 4 and slow.shape[0] >= 2 else 1
         sl, fa = slow.chunk(parts), fast.chunk(parts)
         tasks = [(e, k) for k in range(parts) for e in range(2)]
-        outs = {}
-        done = []
+        outs, on = {}, {}
         for st, (e, k) in zip(self._streams, tasks):
             st.wait_stream(main)  # the clips were packed on `main`
             with torch.cuda.stream(st):
                 outs[(e, k)] = self._run(encoders[e], sl[k], fa[k])
-                if not join:
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                    done.append(ev)
+            on[(e, k)] = st
             slow.record_stream(st)
             fast.record_stream(st)
+        res = []
+        for e in range(2):
+            if parts == 1:
+                res.append(outs[(e, 0)])
+                continue
+            # the two halves of encoder e are concatenated on the stream of its FIRST half, after that stream has waited
+            # for the second half's: never on the caller's stream, which (join=False) has not waited for either
+            s0, s1 = on[(e, 0)], on[(e, 1)]
+            s0.wait_stream(s1)
+            with torch.cuda.stream(s0):
+                res.append(torch.cat([outs[(e, 0)], outs[(e, 1)]], 0))
+            outs[(e, 1)].record_stream(s0)
         if join:
-            for st, key in zip(self._streams, tasks):
+            for st in self._streams[: len(tasks)]:
                 main.wait_stream(st)
-                outs[key].record_stream(main)
+            for o in res:
+                o.record_stream(main)
         else:
-            self._pending.extend(outs.values())
+            done = []
+            for st in self._streams[: len(tasks)]:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                done.append(ev)
+            self._pending.extend(res)
             self._inflight.append(done)
             if len(self._inflight) > 2:  # bound the packed clips in flight: the NEXT pack waits for the batch before last
                 for ev in self._inflight.pop(0):
                     main.wait_event(ev)
-        return [outs[(e, 0)] if parts == 1 else torch.cat([outs[(e, k)] for k in range(parts)], 0) for e in range(2)]
+        return res
 
     def join_streams(self):
         """After run_encoders(..., join=False): the current stream waits for every encoder stream; the outputs returned
@@ -263,7 +277,10 @@ class TextureEngine:
     def driving_similarity(self):
         """sim_a[k, j] = <vgg(driving_k), vgg(audio_j)>/temp (models.py:424-439, :457)."""
         dn, _, _ = ops.l2norm_rows(self.Ad)
-        an, _, _ = ops.l2norm_rows(self.A_da)
+        a = self.A_da
+        if a.shape[0] < self.N:  # audio_eg[min(idx, max_audio_segment_id)] (validate.py:346, 398-401), as normalise() does
+            a = a[torch.clamp(torch.arange(self.N, device=self.dev), max=a.shape[0] - 1)].contiguous()
+        an, _, _ = ops.l2norm_rows(a)
         self.sim_a = ops.sim_gemm_nt(dn, an, self.temp, "f32")
         return self.sim_a
 

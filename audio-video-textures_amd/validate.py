@@ -231,7 +231,10 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         q_id = int(os_ids_t[rdm_id])
         print("Chosen next frame:", q_id)
         losses.update(loss, 1)
-        accs.update(1.0 if (len(choices) and choices[0] == 0 and non_zero_count == 1) else 0.0, 1)
+        # validate.py:533-536: acc = 1 when the PRE-threshold row's argmax is position 0.  The maximum always survives the
+        # cut and renormalising is monotonic, so that is "the first survivor is position 0 and carries the largest p"
+        surv_p = sel["p"][0, :non_zero_count]
+        accs.update(1.0 if (non_zero_count and choices[0] == 0 and bool(surv_p[0] == surv_p.max())) else 0.0, 1)
 
         # frame bookkeeping (validate.py:580-615)
         if p_q_id == -1:

@@ -314,19 +314,6 @@ int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const fl
                               const void* wb, const float* bb, const void* wc, const float* bc,
                               int batch, int t, int h, int w, int c, int tchunk, void* stream);
 
-/* Spatial + expanding conv of a SLOW-pathway res2 bottleneck in one kernel (csrc/bc_fused.hip):
- *   out = relu(c(relu(b(m))) + res),  b: Conv3d[1,3,3] 64 -> 64 (stride 1, pad 1), c: Conv3d[1,1,1] 64 -> 256, BN folded
- * (the same model, models/models.py:335, 399).  m [batch, t, h, w, 64] (the block's a-output), res / out
- * [batch, t, h, w, 256] with row strides ldr / ldo elements (channel slices of wider buffers allowed), all bf16.
- * Weights in MFMA fragment order (1 KB per fragment; lane l: row l & 15, k-group q = l >> 4, 8 values):
- *   wb [9 taps][2][4][64][8]: Wb[16*nt + n][tap][32*kh + 8*q + e];  bb [64] fp32
- *   wc [16][2][64][8]: tile nt, row r -> output channel 32*(nt/2) + 8*(r/4) + 4*(nt%2) + r%4, k = 32*kk + 8*q + e;  bc [256]
- * avt_bc_fused_supported(cm, c, w): (64, 256, 56) = slow res2 at 224^2 clips. */
-int avt_bc_fused_supported(int cm, int c, int w);
-int avt_bc_fused_bf16(const void* m, const void* res, void* out, const void* wb, const float* bb,
-                      const void* wc, const float* bc, int batch, int t, int h, int w, int cm, int c,
-                      int ldr, int ldo, void* stream);
-
 /* D1[i, j] = || x_i - x_j ||_2 of the classic video-texture baseline (baselines/classic_video_textures/
  * computeD1.py:47-96; BASELINE config 1): x [n, d] fp32 device rows (flattened frames), out [n, n] fp32.
  * fp64 accumulation in a fixed order, one sqrt, one rounding. */

@@ -107,3 +107,62 @@ def test_validate_m2_driving_audio_on_mfma_encoders(avt, dev, capsys):
         ref = model.t_a_encoder(eg[:32].to(dev))
     assert eng.A.shape == (32, 12288)
     assert torch.nn.functional.cosine_similarity(eng.A, ref, dim=1).min() > 0.999
+
+
+def test_four_streams_unjoined_equals_one_stream(avt, dev):
+    """run_encoders(join=False) with n_streams=4 (clip batch split in halves): the halves are concatenated on an encoder
+    stream, not on the caller's un-joined stream — tables bit-identical to the single-stream run."""
+    from avtex.fused_slowfast import SlowFastMFMA
+    from avtex.slowfast import SlowFast
+    from avtex.texture import TextureEngine
+
+    torch.manual_seed(0)
+    q, t = SlowFastMFMA(SlowFast(), dev), SlowFastMFMA(SlowFast(), dev)
+    video = _video(20 + 4 * 24, 64, seed=2)
+    tabs = []
+    for n_streams in (1, 4):
+        eng = TextureEngine(q, t, None, window=20, stride=4, temp=0.1, img_size=224, model_type=1, device=dev, enc_batch=6)
+        eng.n_streams = n_streams
+        eng.set_video(video)
+        tabs.append([x.clone() for x in eng.build_tables()])
+        torch.cuda.synchronize()
+    assert torch.equal(tabs[0][0], tabs[1][0]) and torch.equal(tabs[0][1], tabs[1][1])
+
+
+def test_ddp_training_with_unused_audio_mlps(avt, dev, tmp_path):
+    """model_type 2 under DistributedDataParallel (one-rank RCCL group): q_a_mlp / t_a_mlp are never called
+    (models.py:267-284) and must not stall DDP's reducer on the second step (main.py wraps with them frozen)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import avtex
+from tiny_encoders import TinySlowFast, seeded
+from avtex import dist as adist
+rank, world, local = adist.init_from_env()
+dev = torch.device("cuda", local)
+model = avtex.ContrastivePredictionTemporal(seeded(TinySlowFast, 1), seeded(TinySlowFast, 2), avtex.VGGish(), 2, 128,
+                                            temp=0.1, window=5, stride=2, enc_arch="slowfast", img_size=32).to(dev)
+for name in ("q_a_mlp", "t_a_mlp"):
+    getattr(model, name).requires_grad_(False)
+model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.01)
+crit = avtex.InfoNCECriterion()
+g = torch.Generator().manual_seed(0)
+for step in range(3):
+    qf = [torch.randn(2, 3, 8, 32, 32, generator=g).to(dev), torch.randn(2, 3, 32, 32, 32, generator=g).to(dev)]
+    tf = [torch.randn(2, 4, 3, 8, 32, 32, generator=g).to(dev), torch.randn(2, 4, 3, 32, 32, 32, generator=g).to(dev)]
+    qa, ta = torch.randn(2, 1, 100, 64, generator=g).to(dev), torch.randn(2, 4, 1, 100, 64, generator=g).to(dev)
+    model.train()
+    out = model(qf, tf, q_audio_eg=qa, t_audio_eg=ta)
+    loss = crit(out, torch.zeros(2, dtype=torch.long, device=dev))
+    opt.zero_grad(); loss.backward(); opt.step()
+    assert torch.isfinite(loss)
+print("DDP_OK", float(loss))
+''' % (root, root)
+    env = dict(os.environ, AVT_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP_OK" in r.stdout, r.stderr[-3000:]

@@ -63,11 +63,6 @@ def spy_bf(x_ptr, out_ptr, packed, batch, t, h, w, cin, c, tchunk=8):
     shapes.append("fused first block %d->%d in(%d, %d, %d, %d) tchunk %d" % (cin, c, batch, t, h, w, tchunk))
     return orig_bf(x_ptr, out_ptr, packed, batch, t, h, w, cin, c, tchunk)
 avtex.ops.bottleneck_first = spy_bf
-orig_bc = avtex.ops.bc_fused
-def spy_bc(m_ptr, res_ptr, out_ptr, packed, batch, t, h, w, cm, c, ldr, ldo):
-    shapes.append("fused b+c slow res2 %d->%d in(%d, %d, %d, %d)" % (cm, c, batch, t, h, w))
-    return orig_bc(m_ptr, res_ptr, out_ptr, packed, batch, t, h, w, cm, c, ldr, ldo)
-avtex.ops.bc_fused = spy_bc
 orig_c33 = avtex.ops.conv33_c64
 def spy_c33(x_ptr, wb, bias, out_ptr, batch, t, h, w, ldo, relu=True):
     shapes.append("strip-resident 3x3 64->64 in(%d, %d, %d, %d)" % (batch, t, h, w))

@@ -1,7 +1,9 @@
 #!/bin/bash
-# diagnostic: rebuild libavt_hip.so with -DAVT_CONV_STAMP ON THE GPU BOX COPY and print where a K-step's cycles go
+# diagnostic: build libavt_hip_stamp.so (-DAVT_CONV_STAMP, a SEPARATE library: the product .so is untouched) on the GPU
+# box copy and print where a K-step's cycles go
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-cd audio-video-textures_amd/csrc && touch conv_igemm.hip && make FLAGS="-O3 -ffp-contract=off -std=c++17 -fPIC --offload-arch=gfx950 -DAVT_CONV_STAMP ${STAMP_EXTRA}" -j8 > /dev/null 2>&1; cd ../..
+make -C audio-video-textures_amd/csrc stamp STAMP_EXTRA="${STAMP_EXTRA}" -j8 > /dev/null 2>&1
+export AVT_HIP_LIB=$PWD/audio-video-textures_amd/libavt_hip_stamp.so
 IFS=";" read -ra ARR <<< "${SHAPES:-256 256 1 3 3 64 8 14 14;1024 256 3 1 1 64 8 14 14;64 256 1 1 1 64 8 56 56 res;64 64 1 3 3 64 8 56 56}"; for SHAPE in "${ARR[@]}"; do
 python - $SHAPE <<'PY'
 import sys, ctypes, subprocess
