@@ -54,6 +54,11 @@ SIGNATURES = {
     "avt_conv3d_ktab": [C.c_int] * 7 + [_vp, C.c_int],
     "avt_conv3d_igemm_bf16": [_vp] * 6 + [C.c_int] * 22 + [_vp],
     "avt_conv3d_igemm_rows_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp],
+    "avt_conv3d_igemm_x3": [_vp] * 10 + [C.c_int] * 26 + [_vp, _vp],
+    "avt_clip_pack_u8_ndhwc4_x3": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
+                                   C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp],
+    "avt_maxpool_hw3s2_ndhwc_x3": [_vp] * 4 + [C.c_int] * 8 + [_vp],
+    "avt_mean_positions_x3": [_vp, _vp] + [C.c_int] * 4 + [_vp, C.c_int, C.c_int, _vp],
     "avt_conv3d_igemm_wfrag_supported": [C.c_int] * 5,
     "avt_conv3d_igemm_wfrag_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp, C.c_int, _vp],
 }

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "avt_common.h"
+#include "split_planes.h"
 
 namespace {
 
@@ -31,6 +32,8 @@ struct PArgs {
   int bgr;
   void* slow;
   void* fast;
+  void* slow_lo;  // split-plane packing only
+  void* fast_lo;
   int cpr;    // 8-pixel chunks per output row
   int rpb;    // output rows per workgroup
   int tiles;  // row strips per plane
@@ -133,6 +136,9 @@ __global__ __launch_bounds__(256) void clip_pack_kernel(PArgs a) {
 // Channels-last variant for the MFMA stem: slow [n,8,hw,hw,4], fast [n,32,hw,hw,4] bf16 (NDHWC, C padded
 // 3 -> 4 with a zero).  A workgroup resizes a strip of one source frame for all three channels; each lane owns
 // 4 consecutive output pixels = 32 contiguous bytes per destination.
+// PL = 0: one bf16 plane (the fast bf16 encoder); PL = 1 / 2: (hi, lo) bf16 / fp16 planes for the split-plane ("x3")
+// contract-grade encoder (a.slow_lo / a.fast_lo = the low-order planes, same geometry).
+template <int PL>
 __global__ __launch_bounds__(256) void clip_pack_nhwc4_kernel(PArgs a) {
   __shared__ float lut[256];
   lut[threadIdx.x] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)threadIdx.x, 255.0f), a.mean), a.std);
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void clip_pack_nhwc4_kernel(PArgs a) {
   const float hy = 1.0f - ly;
   const uint8_t* r0 = a.frames + ((int64_t)f * a.H + y0) * a.W * 3;
   const uint8_t* r1 = a.frames + ((int64_t)f * a.H + y1) * a.W * 3;
-  uint16_t v[16];
+  uint16_t v[16], vlo[16];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int x = x0 + j;
@@ -166,9 +172,17 @@ __global__ __launch_bounds__(256) void clip_pack_nhwc4_kernel(PArgs a) {
       const float p00 = lut[r0[xa * 3 + sc]], p01 = lut[r0[xb * 3 + sc]];
       const float p10 = lut[r1[xa * 3 + sc]], p11 = lut[r1[xb * 3 + sc]];
       const float o = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
-      v[j * 4 + c] = (x < a.hw) ? (uint16_t)(avt::pack_bf16x2(o, 0.0f) & 0xffffu) : (uint16_t)0;
+      if constexpr (PL == 0) {
+        v[j * 4 + c] = (x < a.hw) ? (uint16_t)(avt::pack_bf16x2(o, 0.0f) & 0xffffu) : (uint16_t)0;
+      } else {
+        uint32_t h2, l2;
+        avt::split2<PL == 2>(o, 0.0f, h2, l2);
+        v[j * 4 + c] = (x < a.hw) ? (uint16_t)(h2 & 0xffffu) : (uint16_t)0;
+        vlo[j * 4 + c] = (x < a.hw) ? (uint16_t)(l2 & 0xffffu) : (uint16_t)0;
+      }
     }
     v[j * 4 + 3] = 0;
+    vlo[j * 4 + 3] = 0;
   }
   const int64_t plane = (int64_t)a.hw * a.hw * 4;
   const int64_t inplane = ((int64_t)y * a.hw + x0) * 4;
@@ -186,6 +200,19 @@ __global__ __launch_bounds__(256) void clip_pack_nhwc4_kernel(PArgs a) {
     } else {
       for (int j = 0; j < 16; ++j)
         if (x0 + j / 4 < a.hw) dst[j] = v[j];
+    }
+    if constexpr (PL != 0) {
+      uint16_t* dl = slot < AVT_SLOW_T
+                         ? static_cast<uint16_t*>(a.slow_lo) + ((int64_t)n * AVT_SLOW_T + slot) * plane
+                         : static_cast<uint16_t*>(a.fast_lo) + ((int64_t)n * AVT_FAST_T + (slot - AVT_SLOW_T)) * plane;
+      dl += inplane;
+      if (full) {
+        reinterpret_cast<uint4*>(dl)[0] = reinterpret_cast<const uint4*>(vlo)[0];
+        reinterpret_cast<uint4*>(dl)[1] = reinterpret_cast<const uint4*>(vlo)[1];
+      } else {
+        for (int j = 0; j < 16; ++j)
+          if (x0 + j / 4 < a.hw) dl[j] = vlo[j];
+      }
     }
   }
 }
@@ -289,9 +316,9 @@ extern "C" int avt_clip_pack_u8(const uint8_t* frames, int n_frames, int height,
   return avt::check_launch("avt_clip_pack_u8");
 }
 
-extern "C" int avt_clip_pack_u8_ndhwc4(const uint8_t* frames, int n_frames, int height, int width,
-                                       const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw, float mean,
-                                       float std, int bgr, void* slow, void* fast, void* stream) {
+static int clip_pack_ndhwc4_impl(const uint8_t* frames, int n_frames, int height, int width, const int32_t* dst_off,
+                                 const int32_t* dst_slot, int n_win, int out_hw, float mean, float std, int bgr, void* slow,
+                                 void* fast, void* slow_lo, void* fast_lo, int planes, void* stream) {
   AVT_REQUIRE(n_frames > 0 && height > 0 && width > 0 && out_hw > 0 && n_win >= 0, "avt_clip_pack_u8_ndhwc4: bad sizes");
   if (n_win == 0) return AVT_OK;
   AVT_REQUIRE(frames && dst_off && dst_slot && slow && fast, "avt_clip_pack_u8_ndhwc4: NULL pointer");
@@ -312,6 +339,8 @@ extern "C" int avt_clip_pack_u8_ndhwc4(const uint8_t* frames, int n_frames, int 
   a.bgr = bgr;
   a.slow = slow;
   a.fast = fast;
+  a.slow_lo = slow_lo;
+  a.fast_lo = fast_lo;
   a.cpr = (out_hw + 3) / 4;
   a.rpb = 256 / a.cpr;
   a.tiles = (out_hw + a.rpb - 1) / a.rpb;
@@ -319,6 +348,30 @@ extern "C" int avt_clip_pack_u8_ndhwc4(const uint8_t* frames, int n_frames, int 
   a.scale_w = (float)width / (float)out_hw;
   const int64_t nblk = (int64_t)a.tiles * n_frames;
   AVT_REQUIRE(nblk < (1ll << 31), "avt_clip_pack_u8_ndhwc4: grid too large");
-  hipLaunchKernelGGL(clip_pack_nhwc4_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (planes == 0)
+    hipLaunchKernelGGL(clip_pack_nhwc4_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else if (planes == 1)
+    hipLaunchKernelGGL(clip_pack_nhwc4_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(clip_pack_nhwc4_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, a);
   return avt::check_launch("avt_clip_pack_u8_ndhwc4");
+}
+
+extern "C" int avt_clip_pack_u8_ndhwc4(const uint8_t* frames, int n_frames, int height, int width,
+                                       const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw, float mean,
+                                       float std, int bgr, void* slow, void* fast, void* stream) {
+  return clip_pack_ndhwc4_impl(frames, n_frames, height, width, dst_off, dst_slot, n_win, out_hw, mean, std, bgr, slow, fast,
+                               nullptr, nullptr, 0, stream);
+}
+
+extern "C" int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, int width,
+                                          const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw, float mean,
+                                          float std, int bgr, void* slow_hi, void* slow_lo, void* fast_hi, void* fast_lo,
+                                          int plane_dtype, void* stream) {
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_clip_pack_u8_ndhwc4_x3: bad plane_dtype");
+  AVT_REQUIRE(n_win == 0 || (slow_lo && fast_lo && avt::aligned16(slow_lo) && avt::aligned16(fast_lo)),
+              "avt_clip_pack_u8_ndhwc4_x3: the low-order planes must be 16-byte aligned device buffers");
+  return clip_pack_ndhwc4_impl(frames, n_frames, height, width, dst_off, dst_slot, n_win, out_hw, mean, std, bgr, slow_hi,
+                               fast_hi, slow_lo, fast_lo, plane_dtype == AVT_X3_F16 ? 2 : 1, stream);
 }

@@ -36,39 +36,13 @@
 #include <type_traits>
 
 #include "avt_common.h"
+#include "conv_args.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOob = 0xFFFFFFF0u;  // byte offset beyond every buffer: the bounds check returns zeros
-constexpr int kMaxTabSteps = 128;        // tap table kept in LDS up to this many K-steps (8 KB)
-
-constexpr int LSTR = 144;  // LDS row stride (128 data bytes = 64 bf16 of K, + 16 pad)
-constexpr int BK = 64;
-
-// unsigned division by a launch-time constant without the ~40-instruction runtime divide: the row decode of a
-// short-K layer (1x1x1, few channels) would otherwise cost more than its whole K loop.
-struct FastDiv {
-  uint32_t d, magic, shift;
-};
-inline FastDiv make_fastdiv(uint32_t d) {
-  FastDiv f{d, 0u, 0u};
-  if (d > 1) {
-    uint32_t s = 0;
-    while ((1ull << s) < d) ++s;
-    f.magic = (uint32_t)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
-    f.shift = s - 1;
-  }
-  return f;
-}
-__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
-  const uint32_t t = __umulhi(n, f.magic);
-  const uint32_t q = (t + ((n - t) >> 1)) >> f.shift;
-  return f.d == 1 ? n : q;  // a select, not a branch: keeps the caller's loop body one scheduling region
-}
-
 #ifdef AVT_CONV_STAMP
 // diagnostic build only (`make stamp` -> libavt_hip_stamp.so, never the shipped library): the hooks live in tools/diag
 #include "../../tools/diag/conv_stamp.h"
@@ -78,46 +52,6 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
 #define STAMP_FINE(i)
 #define STAMP_END()
 #endif
-
-struct ConvArgs {
-  const uint16_t* in;
-  const uint16_t* wt;
-  const float* bias;
-  const uint16_t* res;
-  uint16_t* out;
-  const int2* ktab;  // [nk*8] {element offset of the chunk's tap+channel relative to the row base, tap bits or -1}
-  int T, H, W;       // input extent
-  int To, Ho, Wo;
-  int Cout, K;
-  int KT, KH, KW, st, sh, sw, pt, ph, pw;
-  int ldi, ldo, ldr;
-  int relu;
-  int M;  // output positions (B*To*Ho*Wo)
-  int nk;
-  int tiles_n, nblk;
-  FastDiv dWo, dHo, dTo;
-  FastDiv dCpt, dKHW, dKW;  // tap decode without the table (XL kernel): chunks per tap, KH*KW, KW
-  FastDiv dNT;              // taps (XL kernel, taps-innermost K walk)
-  int tapinner;
-  unsigned in_bytes, wt_bytes;  // extents for the buffer descriptors (hardware range check = free zero fill)
-  int pointwise;                // 1x1x1 / stride 1 / pad 0: rows need no decode
-  const uint16_t* wfrag;        // XB kernel: weights in MFMA-fragment order [Cout/32][nup][2][64][8] (walk order of K), or NULL
-  int nup;                      // ... units per 32-row tile in that array (>= units walked + 3)
-  unsigned wf_bytes;
-  int ors, oH, oW;              // output row remap: position (f, ho, wo) -> row (f * oH + ors * ho) * oW + ors * wo (ors = 1: none)
-};
-
-
-
-// Row of the output buffer an output position lands in.  ors > 1: the layer writes into (a channel slice of) a buffer
-// laid out over a `ors`x finer grid — a stride-2 [1,3,3] conv writing behind the channels of ITS OWN input's rows, so
-// that the block's c conv and strided shortcut conv become one GEMM over K = [x | b-output] (fused_slowfast._Block).
-__device__ __forceinline__ int out_row(const ConvArgs& a, int m) {
-  if (a.ors == 1) return m;
-  const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
-  const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
-  return (t2 * a.oH + ho * a.ors) * a.oW + wo * a.ors;
-}
 
 // waves per SIMD to keep resident: bounds the register allocation (guide §6 G1)
 #define AVT_CONV_MIN_WAVES(BM, BN, WTM) ((WTM) == 128 ? 2 : ((BM) == 128 ? 3 : ((BN) == 64 ? 2 : 4)))
@@ -1041,69 +975,10 @@ extern "C" int avt_conv3d_igemm_wfrag_bf16(const void* in, const void* wt, const
                                            int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho,
                                            int wo, int ldi, int ldo, int ldr, int relu, int out_row_stride, int out_h,
                                            int out_w, const void* wfrag, int nup, void* stream) {
-  AVT_REQUIRE(in && wt && out && ktab, "avt_conv3d_igemm_bf16: NULL pointer");
-  AVT_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 8 == 0, "avt_conv3d_igemm_bf16: Cin/Cout must be multiples of 8");
-  AVT_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && kt <= 8 && kh <= 8 && kw <= 8, "avt_conv3d_igemm_bf16: kernel extents must be 1..8");
-  AVT_REQUIRE(ldi % 8 == 0 && ldo % 8 == 0 && (!res || ldr % 8 == 0) && ldi >= cin && ldo >= cout,
-              "avt_conv3d_igemm_bf16: leading dimensions must be multiples of 8 and cover the channels");
-  AVT_REQUIRE(avt::aligned16(in) && avt::aligned16(wt) && avt::aligned16(out) && (!res || avt::aligned16(res)) &&
-                  (!bias || avt::aligned16(bias)),
-              "avt_conv3d_igemm_bf16: pointers must be 16-byte aligned");
   ConvArgs a;
-  a.in = static_cast<const uint16_t*>(in);
-  a.wt = static_cast<const uint16_t*>(wt);
-  a.bias = bias;
-  a.res = static_cast<const uint16_t*>(res);
-  a.out = static_cast<uint16_t*>(out);
-  a.ktab = reinterpret_cast<const int2*>(ktab);
-  a.T = t;
-  a.H = h;
-  a.W = w;
-  // output extent: 0 = the symmetric-padding formula; a smaller explicit extent crops the far edge
-  // (used by the stem, whose pixel-pair form needs padding 2 on the left and 1 on the right)
-  const int fto = (t + 2 * pt - kt) / st + 1, fho = (h + 2 * ph - kh) / sh + 1, fwo = (w + 2 * pw - kw) / sw + 1;
-  a.To = to > 0 ? to : fto;
-  a.Ho = ho > 0 ? ho : fho;
-  a.Wo = wo > 0 ? wo : fwo;
-  AVT_REQUIRE(a.To > 0 && a.Ho > 0 && a.Wo > 0 && batch > 0 && a.To <= fto && a.Ho <= fho && a.Wo <= fwo,
-              "avt_conv3d_igemm_bf16: bad output extent %dx%dx%d (max %dx%dx%d)", a.To, a.Ho, a.Wo, fto, fho, fwo);
-  a.Cout = cout;
-  a.K = kt * kh * kw * cin;
-  a.KT = kt;
-  a.KH = kh;
-  a.KW = kw;
-  a.st = st;
-  a.sh = sh;
-  a.sw = sw;
-  a.pt = pt;
-  a.ph = ph;
-  a.pw = pw;
-  a.ldi = ldi;
-  a.ldo = ldo;
-  a.ldr = ldr;
-  a.relu = relu;
-  const int64_t M = (int64_t)batch * a.To * a.Ho * a.Wo;
-  AVT_REQUIRE(M < (1ll << 31) && (int64_t)batch * t * h * w * ldi < (1ll << 31) - 64 && M * (int64_t)ldo < (1ll << 62) &&
-                  (int64_t)cout * a.K < (1ll << 31) - 64,
-              "avt_conv3d_igemm_bf16: tensor too large for 32-bit offsets");
-  a.in_bytes = (unsigned)((int64_t)batch * t * h * w * ldi * 2);
-  a.wt_bytes = (unsigned)((int64_t)cout * a.K * 2);
-  a.M = (int)M;
-  a.nk = (a.K + BK - 1) / BK;
-  a.pointwise = (kt == 1 && kh == 1 && kw == 1 && st == 1 && sh == 1 && sw == 1 && pt == 0 && ph == 0 && pw == 0 &&
-                 a.To == t && a.Ho == h && a.Wo == w) ? 1 : 0;
-  a.dWo = make_fastdiv((uint32_t)a.Wo);
-  a.dHo = make_fastdiv((uint32_t)a.Ho);
-  a.dTo = make_fastdiv((uint32_t)a.To);
-  AVT_REQUIRE(out_row_stride >= 1 && (out_row_stride == 1 || (!res && out_h >= out_row_stride * (a.Ho - 1) + 1 &&
-                                                               out_w >= out_row_stride * (a.Wo - 1) + 1)),
-              "avt_conv3d_igemm_rows_bf16: the remapped rows need an out_h x out_w grid that holds %d x (%d x %d), no residual",
-              out_row_stride, a.Ho, a.Wo);
-  AVT_REQUIRE(out_row_stride == 1 || (int64_t)batch * a.To * out_h * out_w < (1ll << 31),
-              "avt_conv3d_igemm_rows_bf16: output buffer too large for 32-bit rows");
-  a.ors = out_row_stride;
-  a.oH = out_h;
-  a.oW = out_w;
+  const int rc = conv_args_fill(a, "avt_conv3d_igemm_bf16", in, wt, bias, res, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw,
+                                st, sh, sw, pt, ph, pw, to, ho, wo, ldi, ldo, ldr, relu, out_row_stride, out_h, out_w);
+  if (rc != AVT_OK) return rc;
   a.wfrag = static_cast<const uint16_t*>(wfrag);
   a.nup = nup;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -1,0 +1,315 @@
+// conv3d_igemm_x3 — the CONTRACT-GRADE form of the encoder convolution: split-bf16 ("bf16x3") implicit GEMM.
+//
+// The reference's encoders compute in fp32 (contrastive_video_textures/models/models.py:335, 399) and its contract on
+// this path is "similarity within 1e-3" = 1e-4 on a cosine: plain bf16 activations (2^-9 per element, every layer) are
+// two orders of magnitude away from that.  The f32-input MFMA runs at 1/16 of the bf16 rate, so this kernel keeps the
+// bf16 matrix pipe and splits every operand in two bf16 planes instead:
+//     x = hi + lo,  hi = bf16(x),  lo = bf16(x - hi)            (|x - hi - lo| <= 2^-18 |x|)
+//     sum_k a_k w_k  ~=  sum_k ( wh*ah + wh*al + wl*ah )         (the dropped wl*al term is <= 2^-18 |a w|)
+// three v_mfma_f32_32x32x16_bf16 per (n, m, k) sub-tile into ONE fp32 accumulator: 1/3 of the bf16 MFMA rate, 5x the
+// f32 MFMA rate, and ~1e-5 relative per product instead of 4e-3.
+//
+// Activations travel between layers as TWO bf16 planes of identical geometry (NDHWC rows [M, ld]): the producing
+// layer's epilogue splits each fp32 result once, so the K loop of every consumer is the plain bf16 gather of
+// conv_igemm.hip done twice (same tap table, same row masks, same SRSRC zero fill) — no conversion in the loop, and a
+// 3x3 consumer does not re-split its input nine times.  Bias, residual add (hi + lo of the residual planes, summed in
+// fp32), ReLU and the concat-slice write are fused in the epilogue like in the bf16 kernel; the tile is staged through
+// LDS in fp32 so the split happens on the final value (one rounding to 2^-18, not two).
+//
+// Tiles (256 threads = 4 waves): <128,128,64> wide layers, <128,64,64> Cout <= 64, <128,32,32> Cout <= 32; BK = 64;
+// LDS per workgroup 2 x (BM + BN) x 144 B (two planes per operand) + the tap table: 82 / 63 / 54 KB.  Per K-step a wave
+// of the wide tile reads 8 fragments per 16-wide k-slice for 12 MFMAs (the bf16 tile: 4 for 4), so this form is much
+// closer to MFMA-bound than the bf16 one.  Roofline: MFMA at 1/3 of the bf16 peak (833 TFLOP/s algorithmic).
+#include <stdlib.h>
+
+#include "avt_common.h"
+#include "conv_args.h"
+#include "split_planes.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma(i32x4 w, i32x4 x, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+
+template <int BM, int BN, int WTM, bool F16>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
+  constexpr int WAVES_M = BM / WTM;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WN = BN / WAVES_N;
+  constexpr int NT = WN / 32, MT = WTM / 32;
+  constexpr int AU = BM / 32, BU = BN / 32;  // 16-byte chunks per thread, plane and K-step
+  constexpr int A_BYTES = BM * LSTR, B_BYTES = BN * LSTR;
+  constexpr int A_LO = A_BYTES, B_HI = 2 * A_BYTES, B_LO = 2 * A_BYTES + B_BYTES;
+  constexpr int STAGE = 2 * (A_BYTES + B_BYTES);
+  constexpr int ESTR = BN * 4 + 16;  // fp32 epilogue staging row stride (bytes)
+  constexpr int CPR = BN / 8;        // 8-channel chunks per output row
+  constexpr int EU = (BM * CPR) / 256;
+  static_assert(NT >= 1 && MT >= 1 && BM * ESTR <= STAGE + kMaxTabSteps * 64 && EU >= 1, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int swz = avt::xcd_contiguous(blockIdx.x, a.nblk);  // consecutive tiles of one XCD share activation rows
+  const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int r0 = tid >> 3, c16 = tid & 7;
+
+  int rowoff[AU];
+  unsigned rowmask[AU];
+#pragma unroll
+  for (int u = 0; u < AU; ++u) {
+    const int m = m0 + r0 + 32 * u;
+    rowoff[u] = 0;
+    rowmask[u] = 0u;
+    if (m < a.M && a.pointwise) {
+      rowoff[u] = m * a.ldi;
+      rowmask[u] = 0x010101u;
+    } else if (m < a.M) {
+      const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
+      const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
+      const int b = (int)fastdiv((uint32_t)t2, a.dTo), to = t2 - b * a.To;
+      const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+      rowoff[u] = (((b * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.ldi;
+      unsigned mask = 0u;
+      for (int dt = 0; dt < a.KT; ++dt) mask |= ((unsigned)(ti0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
+      for (int dh = 0; dh < a.KH; ++dh) mask |= ((unsigned)(hi0 + dh) < (unsigned)a.H ? 1u : 0u) << (8 + dh);
+      for (int dw = 0; dw < a.KW; ++dw) mask |= ((unsigned)(wi0 + dw) < (unsigned)a.W ? 1u : 0u) << (16 + dw);
+      rowmask[u] = mask;
+    }
+  }
+  int wrow[BU];
+  unsigned wsel[BU];
+#pragma unroll
+  for (int u = 0; u < BU; ++u) {
+    const int n = n0 + r0 + 32 * u;
+    wrow[u] = n < a.Cout ? n * a.K : 0;
+    wsel[u] = n < a.Cout ? 0xFFFFFFFFu : 0u;
+  }
+
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      i32x4 ah[MT], al[MT], wh[NT], wl[NT];
+      const int koff = ks * 32 + lh * 16;
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int o = (wm * WTM + j * 32 + lr) * LSTR + koff;
+        ah[j] = *reinterpret_cast<const i32x4*>(lds + o);
+        al[j] = *reinterpret_cast<const i32x4*>(lds + A_LO + o);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int o = (wn * WN + i * 32 + lr) * LSTR + koff;
+        wh[i] = *reinterpret_cast<const i32x4*>(lds + B_HI + o);
+        wl[i] = *reinterpret_cast<const i32x4*>(lds + B_LO + o);
+      }
+      // small terms first, the leading product last: D[n][m] += wl*ah + wh*al + wh*ah
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          acc[i][j] = mfma<F16>(wl[i], ah[j], acc[i][j]);
+          acc[i][j] = mfma<F16>(wh[i], al[j], acc[i][j]);
+          acc[i][j] = mfma<F16>(wh[i], ah[j], acc[i][j]);
+        }
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t rih = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ril = __builtin_amdgcn_make_buffer_rsrc((void*)a.in_lo, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt_lo, 0, a.wt_bytes, 0x00020000);
+  int2* ltab = reinterpret_cast<int2*>(lds + STAGE);
+  const bool tab_lds = a.nk <= kMaxTabSteps;  // uniform
+  if (tab_lds)
+    for (int i = tid; i < a.nk * 8; i += 256) ltab[i] = a.ktab[i];
+  i32x4 rah[AU], ral[AU], rbh[BU], rbl[BU];
+  auto gload = [&](int kt) {
+    const int2 e = tab_lds ? ltab[kt * 8 + c16] : a.ktab[kt * 8 + c16];
+    const unsigned ebits = (unsigned)e.y;
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const unsigned sel = ((rowmask[u] & ebits) == ebits) ? 0xFFFFFFFFu : 0u;
+      const unsigned off = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
+      rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)off, 0, 0);
+      ral[u] = __builtin_amdgcn_raw_buffer_load_b128(ril, (int)off, 0, 0);
+    }
+    const unsigned ksel = ~(unsigned)(e.y >> 31);
+    const unsigned kc2 = (unsigned)((kt * 8 + c16) * 16);
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      const unsigned sel = ksel & wsel[u];
+      const unsigned off = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
+      rbh[u] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)off, 0, 0);
+      rbl[u] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)off, 0, 0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const int o = (r0 + 32 * u) * LSTR + c16 * 16;
+      *reinterpret_cast<i32x4*>(lds + o) = rah[u];
+      *reinterpret_cast<i32x4*>(lds + A_LO + o) = ral[u];
+    }
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      const int o = (r0 + 32 * u) * LSTR + c16 * 16;
+      *reinterpret_cast<i32x4*>(lds + B_HI + o) = rbh[u];
+      *reinterpret_cast<i32x4*>(lds + B_LO + o) = rbl[u];
+    }
+  };
+  __syncthreads();
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < a.nk; ++kt) {
+    if (kt + 1 < a.nk) gload(kt + 1);  // next slab's latency hides under this slab's 48 MFMAs per wave
+    compute();
+    __syncthreads();
+    if (kt + 1 < a.nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: residual planes requested first, tile staged in fp32, split on the final value
+  const bool has_res = a.res != nullptr;
+  uint4 rrh[EU], rrl[EU];
+  if (has_res) {
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int c = tid + 256 * u;
+      const int m = m0 + c / CPR, n = n0 + (c % CPR) * 8;
+      const bool ok = m < a.M && n < a.Cout;
+      rrh[u] = ok ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
+      rrl[u] = ok ? *reinterpret_cast<const uint4*>(a.res_lo + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n -> regs 4g..4g+3 are 4 consecutive n
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = wn * WN + i * 32 + 8 * g + 4 * lh;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (a.bias && n0 + nl < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+      if (a.wscale && n0 + nl < a.Cout) sv = *reinterpret_cast<const float4*>(a.wscale + n0 + nl);  // exact powers of two
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        float4 v;
+        v.x = acc[i][j][4 * g + 0] * sv.x + bv.x;
+        v.y = acc[i][j][4 * g + 1] * sv.y + bv.y;
+        v.z = acc[i][j][4 * g + 2] * sv.z + bv.z;
+        v.w = acc[i][j][4 * g + 3] * sv.w + bv.w;
+        const int ml = wm * WTM + j * 32 + lr;
+        *reinterpret_cast<float4*>(lds + ml * ESTR + nl * 4) = v;
+      }
+    }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < EU; ++u) {
+    const int c = tid + 256 * u;
+    const int row = c / CPR, cc = c % CPR;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m < a.M && n < a.Cout) {
+      const float4 v0 = *reinterpret_cast<const float4*>(lds + row * ESTR + cc * 32);
+      const float4 v1 = *reinterpret_cast<const float4*>(lds + row * ESTR + cc * 32 + 16);
+      float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (has_res) {
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(&rrh[u]);
+        const uint32_t* pl = reinterpret_cast<const uint32_t*>(&rrl[u]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const avt::f32x2 r = avt::join2<F16>(ph[e], pl[e]);
+          x[2 * e] += r.x;
+          x[2 * e + 1] += r.y;
+        }
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+      }
+      uint4 oh, ol;
+      avt::split2<F16>(x[0], x[1], oh.x, ol.x);
+      avt::split2<F16>(x[2], x[3], oh.y, ol.y);
+      avt::split2<F16>(x[4], x[5], oh.z, ol.z);
+      avt::split2<F16>(x[6], x[7], oh.w, ol.w);
+      const int64_t o = (int64_t)out_row(a, m) * a.ldo + n;
+      *reinterpret_cast<uint4*>(a.out + o) = oh;
+      *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
+    }
+  }
+}
+
+template <int BM, int BN, int WTM, bool F16>
+int launch_x3(ConvArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.Cout + BN - 1) / BN;
+  a.nblk = tiles_m * a.tiles_n;
+  constexpr int lds_bytes = 2 * (BM + BN) * LSTR + kMaxTabSteps * 64;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<BM, BN, WTM, F16>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WTM, F16>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
+  return avt::check_launch("avt_conv3d_igemm_x3");
+}
+
+}  // namespace
+
+extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
+                                   const float* bias, const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
+                                   const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                                   int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi,
+                                   int ldo, int ldr, int relu, int out_row_stride, int out_h, int out_w, int plane_dtype,
+                                   const float* wscale, void* stream) {
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_conv3d_igemm_x3: plane_dtype must be 0 (bf16) or 1 (fp16)");
+  AVT_REQUIRE(!wscale || avt::aligned16(wscale), "avt_conv3d_igemm_x3: wscale must be 16-byte aligned");
+  AVT_REQUIRE(in_lo && wt_lo && out_lo && (!res_hi == !res_lo), "avt_conv3d_igemm_x3: every tensor needs both planes");
+  AVT_REQUIRE(avt::aligned16(in_lo) && avt::aligned16(wt_lo) && avt::aligned16(out_lo) && (!res_lo || avt::aligned16(res_lo)),
+              "avt_conv3d_igemm_x3: pointers must be 16-byte aligned");
+  ConvArgs a;
+  const int rc = conv_args_fill(a, "avt_conv3d_igemm_x3", in_hi, wt_hi, bias, res_hi, out_hi, ktab, batch, t, h, w, cin, cout,
+                                kt, kh, kw, st, sh, sw, pt, ph, pw, to, ho, wo, ldi, ldo, ldr, relu, out_row_stride, out_h,
+                                out_w);
+  if (rc != AVT_OK) return rc;
+  a.in_lo = static_cast<const uint16_t*>(in_lo);
+  a.wt_lo = static_cast<const uint16_t*>(wt_lo);
+  a.res_lo = static_cast<const uint16_t*>(res_lo);
+  a.out_lo = static_cast<uint16_t*>(out_lo);
+  a.wscale = wscale;
+  a.wfrag = nullptr;
+  a.nup = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plane_dtype == AVT_X3_F16) {
+    if (cout <= 32) return launch_x3<128, 32, 32, true>(a, s);
+    if (cout <= 64) return launch_x3<128, 64, 64, true>(a, s);
+    return launch_x3<128, 128, 64, true>(a, s);
+  }
+  if (cout <= 32) return launch_x3<128, 32, 32, false>(a, s);
+  if (cout <= 64) return launch_x3<128, 64, 64, false>(a, s);
+  return launch_x3<128, 128, 64, false>(a, s);
+}

@@ -6,6 +6,7 @@
 // one output position, reads its <= 9 taps with 16-byte loads and writes one 16-byte chunk — optionally into a
 // channel slice of a wider row buffer (ldo), which is how the slow stem lands in the lateral-fusion concat.
 #include "avt_common.h"
+#include "split_planes.h"
 
 namespace {
 
@@ -149,4 +150,138 @@ extern "C" int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, i
   hipLaunchKernelGGL((maxpool_kernel<2, 0>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), bt, h, w, c, ldi, ldo, ho, wo, 1);
   return avt::check_launch("avt_maxpool_hw2s2_ndhwc_bf16");
+}
+
+// ---- split-plane ("x3") forms for the contract-grade encoder: every tensor is a (hi, lo) pair of 16-bit planes ------
+// The max is taken on the fp32 values hi + lo and split again (value-preserving: hi + lo is exact in fp32); the mean
+// sums them in fp32 in the same fixed order as the bf16 kernel.
+namespace {
+
+template <bool F16>
+__global__ __launch_bounds__(256) void maxpool3_x3_kernel(const uint16_t* __restrict__ in_hi, const uint16_t* __restrict__ in_lo,
+                                                           uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int bt,
+                                                           int H, int W, int C, int ldi, int ldo, int Ho, int Wo, int tgroup) {
+  const unsigned cpr = (unsigned)C >> 3;
+  const unsigned cg = (unsigned)(C / tgroup);
+  const unsigned total = (unsigned)bt * Ho * Wo * cpr;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned p = i / cpr;
+    const unsigned cc = i - p * cpr;
+    const unsigned q = p / (unsigned)Wo;
+    const int wo = (int)(p - q * Wo);
+    const unsigned b = q / (unsigned)Ho;
+    const int ho = (int)(q - b * Ho);
+    const int64_t frame = (int64_t)b * H * W * ldi + cc * 8;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      int hi = 2 * ho - 1 + dh;
+      hi = hi < 0 ? 0 : (hi > H - 1 ? H - 1 : hi);  // clamped taps duplicate a valid one: a max does not care
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        int wi = 2 * wo - 1 + dw;
+        wi = wi < 0 ? 0 : (wi > W - 1 ? W - 1 : wi);
+        const int64_t o = frame + (int64_t)(hi * W + wi) * ldi;
+        const uint4 vh = *reinterpret_cast<const uint4*>(in_hi + o);
+        const uint4 vl = *reinterpret_cast<const uint4*>(in_lo + o);
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(&vh);
+        const uint32_t* pl = reinterpret_cast<const uint32_t*>(&vl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const avt::f32x2 v = avt::join2<F16>(ph[e], pl[e]);
+          m[2 * e] = fmaxf(m[2 * e], v.x);
+          m[2 * e + 1] = fmaxf(m[2 * e + 1], v.y);
+        }
+      }
+    }
+    uint4 oh, ol;
+    avt::split2<F16>(m[0], m[1], oh.x, ol.x);
+    avt::split2<F16>(m[2], m[3], oh.y, ol.y);
+    avt::split2<F16>(m[4], m[5], oh.z, ol.z);
+    avt::split2<F16>(m[6], m[7], oh.w, ol.w);
+    const unsigned j = (cc * 8) / cg, c0 = (cc * 8) - j * cg;
+    const int64_t o = ((((int64_t)b * tgroup + j) * Ho + ho) * Wo + wo) * ldo + c0;
+    *reinterpret_cast<uint4*>(out_hi + o) = oh;
+    *reinterpret_cast<uint4*>(out_lo + o) = ol;
+  }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void mean_positions_x3_kernel(const uint16_t* __restrict__ in_hi,
+                                                                 const uint16_t* __restrict__ in_lo, int P, int C, int ldi,
+                                                                 float* __restrict__ out, int ldo) {
+  __shared__ float red[32][65];
+  const int b = blockIdx.x, c0 = blockIdx.y * 64;
+  const int cc = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int ch = c0 + cc * 8;
+  if (ch < C) {
+    const int64_t base = (int64_t)b * P * ldi + ch;
+    for (int r = rg; r < P; r += 32) {
+      const uint4 vh = *reinterpret_cast<const uint4*>(in_hi + base + (int64_t)r * ldi);
+      const uint4 vl = *reinterpret_cast<const uint4*>(in_lo + base + (int64_t)r * ldi);
+      const uint32_t* ph = reinterpret_cast<const uint32_t*>(&vh);
+      const uint32_t* pl = reinterpret_cast<const uint32_t*>(&vl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const avt::f32x2 v = avt::join2<F16>(ph[e], pl[e]);
+        acc[2 * e] += v.x;
+        acc[2 * e + 1] += v.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rg][cc * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+    float s = 0.f;
+    for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
+    out[(int64_t)b * ldo + c0 + threadIdx.x] = s / (float)P;
+  }
+}
+
+}  // namespace
+
+extern "C" int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h,
+                                          int w, int c, int ldi, int ldo, int tgroup, int plane_dtype, void* stream) {
+  AVT_REQUIRE(in_hi && in_lo && out_hi && out_lo, "avt_maxpool_hw3s2_ndhwc_x3: NULL pointer");
+  AVT_REQUIRE(bt > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldi >= c,
+              "avt_maxpool_hw3s2_ndhwc_x3: channels / leading dimensions must be multiples of 8");
+  AVT_REQUIRE(avt::aligned16(in_hi) && avt::aligned16(in_lo) && avt::aligned16(out_hi) && avt::aligned16(out_lo),
+              "avt_maxpool_hw3s2_ndhwc_x3: pointers must be 16-byte aligned");
+  AVT_REQUIRE(tgroup >= 1 && c % tgroup == 0 && (c / tgroup) % 8 == 0 && ldo >= c / tgroup,
+              "avt_maxpool_hw3s2_ndhwc_x3: tgroup must split the channels into multiples of 8");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_maxpool_hw3s2_ndhwc_x3: bad plane_dtype");
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)bt * ho * wo * (c / 8);
+  AVT_REQUIRE(total < (1ll << 31), "avt_maxpool_hw3s2_ndhwc_x3: more than 2^31 output chunks");
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+  auto ih = static_cast<const uint16_t*>(in_hi), il = static_cast<const uint16_t*>(in_lo);
+  auto oh = static_cast<uint16_t*>(out_hi), ol = static_cast<uint16_t*>(out_lo);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (plane_dtype == AVT_X3_F16)
+    hipLaunchKernelGGL((maxpool3_x3_kernel<true>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, tgroup);
+  else
+    hipLaunchKernelGGL((maxpool3_x3_kernel<false>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, tgroup);
+  return avt::check_launch("avt_maxpool_hw3s2_ndhwc_x3");
+}
+
+extern "C" int avt_mean_positions_x3(const void* in_hi, const void* in_lo, int batch, int p, int c, int ldi, float* out, int ldo,
+                                     int plane_dtype, void* stream) {
+  AVT_REQUIRE(in_hi && in_lo && out, "avt_mean_positions_x3: NULL pointer");
+  AVT_REQUIRE(batch > 0 && p > 0 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldi >= c && ldo >= c,
+              "avt_mean_positions_x3: channels / input stride must be multiples of 8, strides must cover the channels");
+  AVT_REQUIRE(avt::aligned16(in_hi) && avt::aligned16(in_lo), "avt_mean_positions_x3: input must be 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_mean_positions_x3: bad plane_dtype");
+  const dim3 grid((unsigned)batch, (unsigned)((c + 63) / 64));
+  auto ih = static_cast<const uint16_t*>(in_hi), il = static_cast<const uint16_t*>(in_lo);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (plane_dtype == AVT_X3_F16)
+    hipLaunchKernelGGL((mean_positions_x3_kernel<true>), grid, dim3(256), 0, st, ih, il, p, c, ldi, out, ldo);
+  else
+    hipLaunchKernelGGL((mean_positions_x3_kernel<false>), grid, dim3(256), 0, st, ih, il, p, c, ldi, out, ldo);
+  return avt::check_launch("avt_mean_positions_x3");
 }

@@ -1,0 +1,42 @@
+// Split-plane ("x3") number format shared by the contract-grade encoder kernels (conv_x3.hip, pool.hip, clip_pack.hip):
+// an fp32 value travels as TWO 16-bit planes, x = hi + lo.
+#pragma once
+#include "avt_common.h"
+
+namespace avt {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// fp32 pair -> packed (hi, lo) planes, both round-to-nearest-even; x - hi is exact in fp32.
+// F16 = false: bf16 planes (8 + 8 significant bits, |x - hi - lo| <= 2^-18 |x| at every magnitude).
+// F16 = true : fp16 planes (11 + 11 bits, <= 2^-23 |x| while lo stays a normal fp16, i.e. |x| >= 2^-3; below that the
+//              ABSOLUTE error is <= 2^-25) — values are clamped to the fp16 range first (an activation beyond 65504 would
+//              otherwise become inf - inf).
+template <bool F16>
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  if constexpr (F16) {
+    const f32x2 v = {fminf(fmaxf(x0, -65504.0f), 65504.0f), fminf(fmaxf(x1, -65504.0f), 65504.0f)};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f32x2 r = {v.x - hf.x, v.y - hf.y};
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  } else {
+    hi = avt::pack_bf16x2(x0, x1);
+    lo = avt::pack_bf16x2(x0 - avt::bf16x2_lo(hi), x1 - avt::bf16x2_hi(hi));
+  }
+}
+// packed (hi, lo) planes -> the fp32 pair they stand for
+template <bool F16>
+__device__ __forceinline__ f32x2 join2(uint32_t hi, uint32_t lo) {
+  if constexpr (F16) {
+    const f32x2 h = __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2);
+    const f32x2 l = __builtin_convertvector(__builtin_bit_cast(f16x2, lo), f32x2);
+    return f32x2{h.x + l.x, h.y + l.y};
+  } else {
+    return f32x2{avt::bf16x2_lo(hi) + avt::bf16x2_lo(lo), avt::bf16x2_hi(hi) + avt::bf16x2_hi(lo)};
+  }
+}
+
+}  // namespace avt

@@ -42,12 +42,13 @@ PROFILER = None
 
 
 class Act:
-    """A [M, C] channel slice of a row-major bf16 buffer [M, ld] holding NDHWC activations of extent dims."""
+    """A [M, C] channel slice of a row-major bf16 buffer [M, ld] holding NDHWC activations of extent dims.
+    Split-plane ("x3") activations carry a second buffer `lo` of identical geometry (value = buf + lo, include/avt.h)."""
 
-    __slots__ = ("buf", "dims", "c0", "C")
+    __slots__ = ("buf", "dims", "c0", "C", "lo")
 
-    def __init__(self, buf, dims, c0=0, C=None):
-        self.buf, self.dims, self.c0 = buf, dims, c0
+    def __init__(self, buf, dims, c0=0, C=None, lo=None):
+        self.buf, self.dims, self.c0, self.lo = buf, dims, c0, lo
         self.C = buf.shape[1] - c0 if C is None else C
 
     @property
@@ -55,8 +56,34 @@ class Act:
         return self.buf.data_ptr() + 2 * self.c0
 
     @property
+    def ptrs(self):
+        return (self.buf.data_ptr() + 2 * self.c0, self.lo.data_ptr() + 2 * self.c0)
+
+    @property
     def ld(self):
         return self.buf.shape[1]
+
+    def float(self, plane_dtype=None):
+        """fp32 [M, C] copy of the slice (plane_dtype = ops.X3_* for split-plane activations)."""
+        if self.lo is None:
+            return self.buf[:, self.c0 : self.c0 + self.C].float()
+        dt = torch.float16 if plane_dtype == ops.X3_F16 else torch.bfloat16
+        sl = slice(self.c0, self.c0 + self.C)
+        return self.buf.view(dt)[:, sl].float() + self.lo.view(dt)[:, sl].float()
+
+
+def new_act(m, c, dims, device, x3=False):
+    buf = torch.empty((m, c), dtype=torch.bfloat16, device=device)
+    return Act(buf, dims, lo=torch.empty_like(buf) if x3 else None)
+
+
+def split_planes(w, plane_dtype):
+    """fp32 tensor -> (hi, lo) 16-bit planes typed bfloat16 (raw bits; fp16 planes are bit-cast), value = hi + lo."""
+    w = w.detach().float()
+    dt = torch.float16 if plane_dtype == ops.X3_F16 else torch.bfloat16
+    hi = w.to(dt)
+    lo = (w - hi.float()).to(dt)
+    return hi.view(torch.bfloat16).contiguous(), lo.view(torch.bfloat16).contiguous()
 
 
 def fold_bn(conv, bn):
@@ -112,10 +139,12 @@ def pack_wfrag(wt, cin, taps):
 
 
 class FusedConv:
-    def __init__(self, conv, bn, relu, device, packed=None, folded=None):
+    def __init__(self, conv, bn, relu, device, packed=None, folded=None, x3=None):
         """packed = (wt [Cout, taps*Cin] fp32, bias, cin, kernel, stride, pad, crop) overrides the module;
-        folded = (w [Cout,Cin,kt,kh,kw] fp32, bias, stride, pad) is a BN-folded weight in conv layout."""
+        folded = (w [Cout,Cin,kt,kh,kw] fp32, bias, stride, pad) is a BN-folded weight in conv layout;
+        x3 = None (bf16) | ops.X3_BF16 | ops.X3_F16: contract-grade split-plane arithmetic (csrc/conv_x3.hip)."""
         self.crop = (0, 0, 0)
+        self.x3 = x3
         self._folded = None
         self._grouped = {}
         if packed is None:
@@ -136,11 +165,24 @@ class FusedConv:
             raise AvtError("FusedConv: input channels must be a multiple of 8 (got %d)" % self.cin)
         if cout % 8:  # pad the output channels with zero filters (the caller's buffer must be that wide)
             raise AvtError("FusedConv: output channels must be a multiple of 8 (got %d)" % cout)
-        self.wt = wt.to(torch.bfloat16).contiguous().to(device)
-        self.wfrag = None
+        self.wfrag = self.wt_lo = self.wscale = None
         taps = self.kernel[0] * self.kernel[1] * self.kernel[2]
-        if _XB and ops.conv3d_wfrag_supported(self.cin, cout, self.kernel):
-            self.wfrag = pack_wfrag(self.wt.float().cpu(), self.cin, taps).to(device)
+        if x3 is not None:
+            wf = wt.detach().float()
+            if x3 == ops.X3_F16:
+                # fp16 planes: each output channel's weights are scaled by a power of two into [2^9, 2^10) so that the low
+                # plane of every weight that matters is a normal fp16; the kernel multiplies the accumulator back (exact)
+                mx = wf.abs().amax(dim=1).clamp_min(1e-30)
+                e = torch.floor(torch.log2(mx))
+                sc = torch.pow(2.0, 9.0 - e)
+                wf = wf * sc.view(-1, 1)
+                self.wscale = (1.0 / sc).float().contiguous().to(device)
+            hi, lo = split_planes(wf, x3)
+            self.wt, self.wt_lo = hi.to(device), lo.to(device)
+        else:
+            self.wt = wt.to(torch.bfloat16).contiguous().to(device)
+            if _XB and ops.conv3d_wfrag_supported(self.cin, cout, self.kernel):
+                self.wfrag = pack_wfrag(self.wt.float().cpu(), self.cin, taps).to(device)
         self.bias = bias.float().contiguous().to(device)
         self.dev = device
         self._tabs = {}
@@ -182,7 +224,7 @@ class FusedConv:
                 w, bias = self._folded
                 wg, rg = group_weights_w(w, g)
                 sub = FusedConv(None, None, self.relu, self.dev,
-                                folded=(wg, bias.repeat(g), self.stride, (self.pad[0], self.pad[1], rg)))
+                                folded=(wg, bias.repeat(g), self.stride, (self.pad[0], self.pad[1], rg)), x3=self.x3)
                 sub._folded = None  # never re-group
                 sub.alg_flops_per_row = g * self.alg_flops_per_row
                 self._grouped[g] = sub
@@ -190,8 +232,9 @@ class FusedConv:
             od = self.out_dims(x.dims)
             m_out = od[0] * od[1] * od[2] * od[3]
             if out is None:
-                out = Act(torch.empty((m_out, self.cout), dtype=torch.bfloat16, device=self.dev), od)
-            view = lambda a, d, c: Act(a.buf.view(-1, g * c), (d[0], d[1], d[2], d[3] // g))
+                out = new_act(m_out, self.cout, od, self.dev, self.x3 is not None)
+            view = lambda a, d, c: Act(a.buf.view(-1, g * c), (d[0], d[1], d[2], d[3] // g),
+                                       lo=a.lo.view(-1, g * c) if a.lo is not None else None)
             sub(view(x, x.dims, self.cin), out=view(out, od, self.cout),
                 res=view(res, od, self.cout) if res is not None else None, relu=relu)
             return out
@@ -203,8 +246,17 @@ class FusedConv:
         od = self.out_dims(x.dims)
         if out is None:
             m = od[0] * od[1] * od[2] * od[3]
-            out = Act(torch.empty((m, self.cout), dtype=torch.bfloat16, device=self.dev), od)
+            out = new_act(m, self.cout, od, self.dev, self.x3 is not None)
+
+        def launch_x3():
+            ops.conv3d_igemm_x3(x.ptrs, self.wt, self.wt_lo, self.bias, res.ptrs if res is not None else None, out.ptrs, tab,
+                                x.dims, self.cin, self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld,
+                                res.ld if res is not None else 0, self.relu if relu is None else relu, self.x3,
+                                wscale=self.wscale, out_dims=od[1:] if any(self.crop) else (0, 0, 0), out_rows=out_rows)
+
         def launch():
+            if self.x3 is not None:
+                return launch_x3()
             ops.conv3d_igemm(x.ptr, self.wt, self.bias, res.ptr if res is not None else 0, out.ptr, tab, x.dims,
                              self.cin, self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld,
                              res.ld if res is not None else 0, self.relu if relu is None else relu,
@@ -215,8 +267,9 @@ class FusedConv:
         else:
             m_out = od[0] * od[1] * od[2] * od[3]
             m_in = x.dims[0] * x.dims[1] * x.dims[2] * x.dims[3]
-            PROFILER("conv3d_igemm_bf16", launch, m_out * self.alg_flops_per_row,
-                     2.0 * (m_in * self.cin + m_out * self.cout * (2 if res is not None else 1)) + self.wt.numel() * 2)
+            nb = 2.0 * (m_in * self.cin + m_out * self.cout * (2 if res is not None else 1)) + self.wt.numel() * 2
+            PROFILER("conv3d_igemm_x3" if self.x3 is not None else "conv3d_igemm_bf16", launch,
+                     m_out * self.alg_flops_per_row, nb * (2 if self.x3 is not None else 1))
         return out
 
 
@@ -228,7 +281,7 @@ def stem_lds_image(wt, kt):
     return w.permute(0, 4, 5, 2, 6, 1, 3, 7).contiguous().reshape(cout // 32, -1)
 
 
-def stem_conv(stem, device, tgroup=1):
+def stem_conv(stem, device, tgroup=1, x3=None):
     """Stem Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU in pixel-pair form (see module doc).
 
     tgroup = g > 1 (fast stem, C = 8): g consecutive output frames are computed as g*C channels of ONE output row
@@ -251,16 +304,16 @@ def stem_conv(stem, device, tgroup=1):
             wg[j, :, j : j + kt] = wp
         conv = FusedConv(None, None, True, device,
                          packed=(wg.reshape(g * c, -1), bias.repeat(g), 8, (kt + g - 1, kh, 4), (g, 2, 1),
-                                 (kt // 2, 3, 2), (0, 0, 1)))
+                                 (kt // 2, 3, 2), (0, 0, 1)), x3=x3)
         conv.tgroup, conv.frame_channels = g, c
         conv.alg_flops_per_row = g * 2.0 * (kt * kh * kw * 3) * c
-        conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1) if conv.cout % 32 == 0 else None
+        conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1) if conv.cout % 32 == 0 and x3 is None else None
         return conv
     conv = FusedConv(None, None, True, device,
-                     packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)))
+                     packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)), x3=x3)
     conv.tgroup, conv.frame_channels = 1, c
     conv.alg_flops_per_row = 2.0 * (kt * kh * kw * 3) * c
-    conv.wt_lds = stem_lds_image(conv.wt, kt) if conv.cout % 32 == 0 else None
+    conv.wt_lds = stem_lds_image(conv.wt, kt) if conv.cout % 32 == 0 and x3 is None else None
     return conv
 
 
@@ -540,32 +593,66 @@ class _Block:
         return self.c(self._b(self.a(x)), out=out, res=sc, relu=True)
 
 
+class _BlockX3:
+    """A residual block in the contract-grade mode: four plain split-plane convolutions (shortcut, a, b, c + residual);
+    none of the bf16 path's fused forms — this mode trades speed for fp32-grade arithmetic."""
+
+    def __init__(self, blk, device, x3):
+        self.b1 = FusedConv(blk.branch1, blk.branch1_bn, False, device, x3=x3) if hasattr(blk, "branch1") else None
+        t = blk.branch2
+        self.a = FusedConv(t.a, t.a_bn, True, device, x3=x3)
+        self.b = FusedConv(t.b, t.b_bn, True, device, x3=x3)
+        self.c = FusedConv(t.c, t.c_bn, True, device, x3=x3)  # ReLU after the residual add (fused)
+
+    def __call__(self, x, out=None):
+        sc = self.b1(x) if self.b1 is not None else x
+        return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)
+
+
+PRECISIONS = {"bf16": None, "bf16x3": ops.X3_BF16, "f16x3": ops.X3_F16}
+
+
 class SlowFastMFMA(nn.Module):
-    """Drop-in for a `SlowFast` module at inference time (eval-mode BatchNorm statistics)."""
+    """Drop-in for a `SlowFast` module at inference time (eval-mode BatchNorm statistics).
+
+    precision = "bf16"  : the fast path — bf16 activations and weights, every fused kernel (2^-9 per element and layer:
+                          embeddings ~5 % from the fp32 module's on BN-calibrated weights, scores off by up to 1e-1);
+                "bf16x3": contract grade — split-bf16 planes, three MFMA passes per product (csrc/conv_x3.hip);
+                "f16x3" : the same with fp16 planes (11 + 11 bits instead of 8 + 8; assumes |activation| < 65504)."""
 
     out_dim = 2304
 
     input_layout = "ndhwc4"  # what ops.clip_pack should emit for forward_ndhwc4
 
-    def __init__(self, model, device):
+    def __init__(self, model, device, precision="bf16"):
         super().__init__()
+        if precision not in PRECISIONS:
+            raise AvtError("SlowFastMFMA: precision must be one of %s" % sorted(PRECISIONS))
         self.dev = torch.device(device)
+        self.precision = precision
+        self.x3 = x3 = PRECISIONS[precision]
+        self.planes = precision if x3 is not None else None  # ops.clip_pack(planes=...) for forward_ndhwc4's input
         model = model.eval()
-        self.stem_s = stem_conv(model.s1.pathway0_stem, self.dev)
-        self.stem_f = stem_conv(model.s1.pathway1_stem, self.dev, tgroup=4)
+        self.stem_s = stem_conv(model.s1.pathway0_stem, self.dev, x3=x3)
+        self.stem_f = stem_conv(model.s1.pathway1_stem, self.dev, tgroup=4, x3=x3)
         self._anchor = nn.Parameter(torch.zeros(1, dtype=torch.bfloat16, device=self.dev), requires_grad=False)
-        self.fuse = [FusedConv(f.conv_f2s, f.bn, True, self.dev) for f in (model.s1_fuse, model.s2_fuse, model.s3_fuse,
-                                                                            model.s4_fuse)]
+        self.fuse = [FusedConv(f.conv_f2s, f.bn, True, self.dev, x3=x3) for f in (model.s1_fuse, model.s2_fuse,
+                                                                                   model.s3_fuse, model.s4_fuse)]
         self.stages = []
         for s in (model.s2, model.s3, model.s4, model.s5):
-            self.stages.append([[_Block(getattr(s, "pathway%d_res%d" % (p, i)), self.dev) for i in range(s.depth)]
-                                for p in range(2)])
+            mk = (lambda blk: _BlockX3(blk, self.dev, x3)) if x3 is not None else (lambda blk: _Block(blk, self.dev))
+            self.stages.append([[mk(getattr(s, "pathway%d_res%d" % (p, i))) for i in range(s.depth)] for p in range(2)])
 
     @torch.no_grad()
     def forward(self, x):
         """[slow [B,3,8,H,W], fast [B,3,32,H,W]] (the plugin contract): one layout copy, then forward_ndhwc4."""
         def cl4(v):
             b, c, t, h, w = v.shape
+            if self.x3 is not None:  # split the fp32 clip into its two planes
+                f = torch.zeros((b, t, h, w, 4), dtype=torch.float32, device=self.dev)
+                f[..., :3] = v.to(self.dev, torch.float32).permute(0, 2, 3, 4, 1)
+                hi, lo = split_planes(f, self.x3)
+                return ops.SplitClip(hi, lo, self.x3)
             o = torch.zeros((b, t, h, w, 4), dtype=torch.bfloat16, device=self.dev)
             o[..., :3] = v.to(self.dev, torch.bfloat16).permute(0, 2, 3, 4, 1)
             return o
@@ -620,9 +707,57 @@ class SlowFastMFMA(nn.Module):
         ops.maxpool_hw3s2(y.ptr, out.ptr, b * tg, h2, w2, conv.cout, y.ld, out.ld, tgroup=conv.tgroup)
         return out, pd
 
+    def _stem_x3(self, conv, clip, out=None):
+        """Contract-grade stem: pixel-pair convolution on the plain split-plane kernel, then the plane-pair max-pool."""
+        b, t, h, w, _ = clip.shape
+        x = Act(clip.hi.view(b * t * h * (w // 2), 8), (b, t, h, w // 2), lo=clip.lo.view(b * t * h * (w // 2), 8))
+        y = conv(x)
+        _, tg, h2, w2 = y.dims
+        pd = (b, t, (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1)
+        cf = conv.frame_channels
+        if out is None:
+            out = new_act(pd[0] * pd[1] * pd[2] * pd[3], cf, pd, self.dev, True)
+        ops.maxpool_hw3s2_x3(y.ptrs, out.ptrs, b * tg, h2, w2, conv.cout, y.ld, out.ld, self.x3, tgroup=conv.tgroup)
+        return out, pd
+
+    @torch.no_grad()
+    def _forward_x3(self, slow, fast):
+        """The contract-grade forward: the module's layers one by one on split-plane activations (no fused forms)."""
+        b = slow.shape[0]
+        f_act, df = self._stem_x3(self.stem_f, fast)
+        cs, cf = self.stem_s.frame_channels, self.stem_f.frame_channels
+        hs, ws = (slow.shape[2] // 2 - 1) // 2 + 1, (slow.shape[3] // 2 - 1) // 2 + 1
+        ds = (b, slow.shape[1], hs, ws)
+        cat = new_act(ds[0] * ds[1] * ds[2] * ds[3], cs + 2 * cf, ds, self.dev, True)
+        sl = lambda a, c0, c: Act(a.buf, a.dims, c0, c, lo=a.lo)
+        self._stem_x3(self.stem_s, slow, out=sl(cat, 0, cs))
+        self.fuse[0](f_act, out=sl(cat, cs, 2 * cf))
+        s_act = cat
+        for k, (slow_blocks, fast_blocks) in enumerate(self.stages):
+            for blk in fast_blocks:
+                f_act = blk(f_act)
+            last = k == len(self.stages) - 1
+            for i, blk in enumerate(slow_blocks):
+                if i == len(slow_blocks) - 1 and not last:  # straight into the next fusion's concat buffer
+                    od = blk.b.out_dims(blk.a.out_dims(s_act.dims))
+                    cs, cf = blk.c.cout, f_act.C
+                    cat = new_act(od[0] * od[1] * od[2] * od[3], cs + 2 * cf, od, self.dev, True)
+                    blk(s_act, out=sl(cat, 0, cs))
+                    self.fuse[k + 1](f_act, out=sl(cat, cs, 2 * cf))
+                    s_act = cat
+                else:
+                    s_act = blk(s_act)
+        emb = torch.empty((b, s_act.C + f_act.C), dtype=torch.float32, device=self.dev)
+        ops.mean_positions_x3(s_act.ptrs, b, s_act.buf.shape[0] // b, s_act.C, s_act.ld, emb, 0, self.x3)
+        ops.mean_positions_x3(f_act.ptrs, b, f_act.buf.shape[0] // b, f_act.C, f_act.ld, emb, s_act.C, self.x3)
+        return emb
+
     @torch.no_grad()
     def forward_ndhwc4(self, slow, fast):
-        """slow [B,8,H,W,4], fast [B,32,H,W,4] bf16 channels-last clips (ops.clip_pack layout "ndhwc4")."""
+        """slow [B,8,H,W,4], fast [B,32,H,W,4] bf16 channels-last clips (ops.clip_pack layout "ndhwc4"); ops.SplitClip
+        pairs (clip_pack(..., planes=self.planes)) in the contract-grade modes."""
+        if self.x3 is not None:
+            return self._forward_x3(slow, fast)
         b = slow.shape[0]
         f_act, df = self._stem(self.stem_f, fast)
         cs, cf = self.stem_s.frame_channels, self.stem_f.frame_channels

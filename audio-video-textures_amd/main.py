@@ -77,7 +77,9 @@ def build_parser():
     a("--stitch_mode", default="compat", choices=["compat", "aligned"],
       help="compat: the shipped reference's window/label map; aligned: the N x N matrix the labels claim")
     a("--ref_num_gpus", default=None, type=int, help="reference GPU count to emulate in compat mode")
-    a("--enc_dtype", default="fp32", choices=["fp32", "bf16"], help="encoder compute dtype")
+    a("--enc_dtype", default="fp32", choices=["fp32", "bf16", "bf16x3", "f16x3"],
+      help="encoder arithmetic at -e: fp32 (default; on the MFMA kernels = the contract-grade split-plane mode f16x3), "
+           "bf16 (fast path: 5x the throughput, scores off by up to 1e-1), or a split-plane mode by name")
     a("--enc_batch", default=32, type=int, help="windows per encoder batch")
     a("--enc_impl", default="auto", choices=["auto", "mfma", "module"],
       help="SlowFast at -e: hand-written MFMA convolutions (auto/mfma) or the nn.Module on MIOpen (module)")
@@ -135,16 +137,11 @@ def main(args, video_name, itr=0):
         args.start_epoch = 0
 
     model = model.to(device)
-    if args.evaluate and args.enc_dtype == "bf16":
+    if args.evaluate and args.enc_dtype == "bf16" and args.enc_impl == "module":
         for enc in (model.q_encoder, model.t_encoder):
             enc.to(torch.bfloat16).to(memory_format=torch.channels_last_3d)
     if world > 1 and not args.evaluate:  # weights resident per rank, gradients all-reduced over RCCL
-        # q_a_mlp / t_a_mlp exist only so reference checkpoints load by key and are never called (models.py:267-284):
-        # frozen here, or DDP's reducer would wait for gradients that never come (DataParallel tolerated them)
-        for name in ("q_a_mlp", "t_a_mlp"):
-            if hasattr(model, name):
-                getattr(model, name).requires_grad_(False)
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local] if device.type == "cuda" else None)
+        model = wrap_ddp(model, device, local)
     torch.backends.cudnn.benchmark = True
     tb_logdir = os.path.join(args.logdir, logname)
     os.makedirs(tb_logdir, exist_ok=True)
@@ -172,6 +169,24 @@ def main(args, video_name, itr=0):
         if loss < 0.07:
             print("Loss {}. Stopping at epoch {}.".format(loss, epoch))
             break
+
+
+def wrap_ddp(model, device, local):
+    """DistributedDataParallel over RCCL in place of the reference's DataParallel (main.py:420): weights resident per rank,
+    gradients all-reduced.  Modules that exist only so reference checkpoints load by key and are never applied — q_a_mlp /
+    t_a_mlp (models.py:267-284) and VGGish's fc stack (vggish.py:45) — are frozen first: DDP's reducer would otherwise wait
+    for gradients that never come (DataParallel tolerated them), and ~300 M dead parameters would be all-reduced every
+    step.  find_unused_parameters covers plugin encoders with dead parameters of their own."""
+    net = model
+    for name in ("q_a_mlp", "t_a_mlp"):
+        if hasattr(net, name):
+            getattr(net, name).requires_grad_(False)
+    for name in ("q_a_encoder", "t_a_encoder"):
+        enc = getattr(net, name, None)
+        if isinstance(enc, VGGish) and hasattr(enc, "fc"):
+            enc.fc.requires_grad_(False)
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=[local] if device.type == "cuda" else None,
+                                                     find_unused_parameters=True)
 
 
 def save_checkpoint(state, is_best, filename):

@@ -61,10 +61,38 @@ def clip_pack_plan(win_start, win_len, n_frames):
     return off, slot[: n_win * SLOTS]
 
 
+class SplitClip:
+    """A packed clip batch in the split-plane ("x3") format: two 16-bit planes hi / lo of identical geometry
+    [n, T, hw, hw, 4], value = hi + lo (include/avt.h).  Quacks like the tensor the bf16 path passes around."""
+
+    def __init__(self, hi, lo, plane_dtype):
+        self.hi, self.lo, self.plane_dtype = hi, lo, plane_dtype
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def chunk(self, parts):
+        return [SplitClip(h, l, self.plane_dtype) for h, l in zip(self.hi.chunk(parts), self.lo.chunk(parts))]
+
+    def record_stream(self, st):
+        self.hi.record_stream(st)
+        self.lo.record_stream(st)
+
+    def float(self):
+        dt = torch.float16 if self.plane_dtype == X3_F16 else torch.bfloat16
+        return self.hi.view(dt).float() + self.lo.view(dt).float()
+
+
+X3_BF16, X3_F16 = 0, 1
+_X3 = {"bf16x3": X3_BF16, "f16x3": X3_F16}
+
+
 def clip_pack(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0.225, bgr=True,
-              dtype=torch.bfloat16, plan=None, layout="ncthw"):
+              dtype=torch.bfloat16, plan=None, layout="ncthw", planes=None):
     """frames_u8 [F,H,W,3] uint8 RGB (device) -> slow [n,3,8,hw,hw], fast [n,3,32,hw,hw] (layout "ncthw"),
-    or slow [n,8,hw,hw,4], fast [n,32,hw,hw,4] bf16 with a zero 4th channel (layout "ndhwc4", MFMA stem)."""
+    or slow [n,8,hw,hw,4], fast [n,32,hw,hw,4] bf16 with a zero 4th channel (layout "ndhwc4", MFMA stem);
+    planes = "bf16x3" | "f16x3" (ndhwc4 only): SplitClip pairs for the contract-grade encoder."""
     _dev(frames_u8, "frames_u8", torch.uint8)
     assert frames_u8.dim() == 4 and frames_u8.shape[3] == 3
     n_frames, h, w, _ = frames_u8.shape
@@ -77,8 +105,16 @@ def clip_pack(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0.225, b
     if layout == "ndhwc4":
         if dtype != torch.bfloat16:
             raise _lib.AvtError("clip_pack: layout ndhwc4 is bf16 only")
-        slow = torch.empty((n_win, SLOW_T, out_hw, out_hw, 4), dtype=dtype, device=frames_u8.device)
-        fast = torch.empty((n_win, FAST_T, out_hw, out_hw, 4), dtype=dtype, device=frames_u8.device)
+        mk = lambda t_: torch.empty((n_win, t_, out_hw, out_hw, 4), dtype=dtype, device=frames_u8.device)
+        if planes is not None:
+            pd = _X3[planes]
+            slow, fast = SplitClip(mk(SLOW_T), mk(SLOW_T), pd), SplitClip(mk(FAST_T), mk(FAST_T), pd)
+            _lib.check(_lib.lib().avt_clip_pack_u8_ndhwc4_x3(_p(frames_u8), n_frames, h, w, _p(d_off), _p(d_slot), n_win,
+                                                             int(out_hw), float(mean), float(std), 1 if bgr else 0,
+                                                             _p(slow.hi), _p(slow.lo), _p(fast.hi), _p(fast.lo), pd,
+                                                             _stream()), "avt_clip_pack_u8_ndhwc4_x3")
+            return slow, fast
+        slow, fast = mk(SLOW_T), mk(FAST_T)
         _lib.check(_lib.lib().avt_clip_pack_u8_ndhwc4(_p(frames_u8), n_frames, h, w, _p(d_off), _p(d_slot), n_win,
                                                       int(out_hw), float(mean), float(std), 1 if bgr else 0, _p(slow),
                                                       _p(fast), _stream()), "avt_clip_pack_u8_ndhwc4")
@@ -238,6 +274,37 @@ def conv3d_igemm(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kerne
                                                 b, t, h, w, int(cin), int(cout), *kernel, *stride, *pad, *out_dims,
                                                 int(ldi), int(ldo), int(ldr), 1 if relu else 0, _stream()),
                "avt_conv3d_igemm_bf16")
+
+
+def conv3d_igemm_x3(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo,
+                    ldr, relu, plane_dtype, wscale=None, out_dims=(0, 0, 0), out_rows=None):
+    """Contract-grade (split-plane) convolution: x_ptrs / res_ptrs / out_ptrs = (hi, lo) device addresses of the two
+    16-bit planes (res_ptrs None = no residual); wt_hi / wt_lo bf16-typed [Cout, K] planes; see include/avt.h."""
+    b, t, h, w = dims
+    _dev(wt_hi, "wt_hi", torch.bfloat16)
+    _dev(wt_lo, "wt_lo", torch.bfloat16)
+    orr = out_rows if out_rows is not None else (1, 0, 0)
+    rh, rl = res_ptrs if res_ptrs is not None else (0, 0)
+    _lib.check(_lib.lib().avt_conv3d_igemm_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(wt_hi), _p(wt_lo), _p(bias),
+                                              C.c_void_p(rh) if rh else None, C.c_void_p(rl) if rl else None,
+                                              C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]), _p(ktab), b, t, h, w,
+                                              int(cin), int(cout), *kernel, *stride, *pad, *out_dims, int(ldi), int(ldo),
+                                              int(ldr), 1 if relu else 0, int(orr[0]), int(orr[1]), int(orr[2]),
+                                              int(plane_dtype), _p(wscale), _stream()), "avt_conv3d_igemm_x3")
+
+
+def maxpool_hw3s2_x3(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1):
+    _lib.check(_lib.lib().avt_maxpool_hw3s2_ndhwc_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), C.c_void_p(out_ptrs[0]),
+                                                     C.c_void_p(out_ptrs[1]), int(bt), int(h), int(w), int(c), int(ldi),
+                                                     int(ldo), int(tgroup), int(plane_dtype), _stream()),
+               "avt_maxpool_hw3s2_ndhwc_x3")
+
+
+def mean_positions_x3(x_ptrs, batch, p, c, ldi, out, col0, plane_dtype):
+    _dev(out, "out", torch.float32)
+    _lib.check(_lib.lib().avt_mean_positions_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), int(batch), int(p), int(c),
+                                                int(ldi), C.c_void_p(out.data_ptr() + 4 * int(col0)), int(out.shape[1]),
+                                                int(plane_dtype), _stream()), "avt_mean_positions_x3")
 
 
 def maxpool_hw3s2(x_ptr, out_ptr, bt, h, w, c, ldi, ldo, tgroup=1):

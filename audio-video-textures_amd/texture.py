@@ -89,6 +89,10 @@ class TextureEngine:
         # encoders built on the MFMA conv kernel take channels-last clips directly (fused_slowfast.SlowFastMFMA)
         self.layout = "ndhwc4" if all(getattr(e, "input_layout", None) == "ndhwc4" for e in (q_encoder, t_encoder)) \
             else "ncthw"
+        # contract-grade MFMA encoders read split-plane clips (ops.SplitClip); both encoders must agree on the format
+        self.planes = getattr(q_encoder, "planes", None) if self.layout == "ndhwc4" else None
+        if self.layout == "ndhwc4" and getattr(t_encoder, "planes", None) != self.planes:
+            raise AvtError("q and t encoders must use the same precision mode (they share the packed clips)")
         self.frames = None
         self.A = self.A_da = self.Ad = None
         self._cache = {"q": {}, "t": {}}
@@ -149,7 +153,7 @@ class TextureEngine:
     def _pack(self, frames, starts):
         lo, hi = int(starts.min()), int(starts.max()) + self.W
         return ops.clip_pack(frames[lo:hi], starts - lo, self.W, out_hw=self.hw, mean=self.mean, std=self.std,
-                             bgr=True, dtype=self.pack_dtype, layout=self.layout)
+                             bgr=True, dtype=self.pack_dtype, layout=self.layout, planes=self.planes)
 
     def _run(self, enc, slow, fast):
         if self.layout == "ndhwc4":

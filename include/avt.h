@@ -314,6 +314,36 @@ int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const fl
                               const void* wb, const float* bb, const void* wc, const float* bc,
                               int batch, int t, int h, int w, int c, int tchunk, void* stream);
 
+/* ---- contract-grade encoder: split-plane ("x3") kernels ------------------------------------------------------------
+ * The reference's encoders compute in fp32 (models/models.py:335, 399) and north_star asks for scores within 1e-3 of
+ * them ON THE SAME FRAMES; bf16 activations are ~100x away from that (profiles/r02/precision_*.json).  In this mode every
+ * activation / weight tensor is a PAIR of 16-bit planes of identical geometry, x = hi + lo:
+ *   AVT_X3_BF16: bf16 planes, |x - hi - lo| <= 2^-18 |x| at every magnitude
+ *   AVT_X3_F16 : fp16 planes, <= 2^-23 |x| for |x| >= 2^-3 (absolute 2^-25 below); values clamped to +-65504; weights
+ *                are stored pre-scaled by a power of two per output channel (wscale[n] undoes it on the accumulator)
+ * and a product is three MFMA passes into one fp32 accumulator: wl*ah + wh*al + wh*ah (csrc/conv_x3.hip).
+ * Arguments as avt_conv3d_igemm_rows_bf16, each tensor given as its two planes; res_hi/res_lo both NULL = no residual;
+ * wscale [cout] fp32 or NULL. */
+#define AVT_X3_BF16 0
+#define AVT_X3_F16  1
+int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
+                        const float* bias, const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
+                        const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout,
+                        int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw,
+                        int to, int ho, int wo, int ldi, int ldo, int ldr, int relu,
+                        int out_row_stride, int out_h, int out_w, int plane_dtype, const float* wscale,
+                        void* stream);
+/* avt_clip_pack_u8_ndhwc4 writing (hi, lo) planes: slow_* [n,8,hw,hw,4], fast_* [n,32,hw,hw,4]. */
+int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, int width,
+                               const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw,
+                               float mean, float std, int bgr, void* slow_hi, void* slow_lo,
+                               void* fast_hi, void* fast_lo, int plane_dtype, void* stream);
+/* avt_maxpool_hw3s2_ndhwc_bf16 / avt_mean_positions_bf16 on plane pairs (max / sum of the fp32 values hi + lo). */
+int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h,
+                               int w, int c, int ldi, int ldo, int tgroup, int plane_dtype, void* stream);
+int avt_mean_positions_x3(const void* in_hi, const void* in_lo, int batch, int p, int c, int ldi,
+                          float* out, int ldo, int plane_dtype, void* stream);
+
 /* D1[i, j] = || x_i - x_j ||_2 of the classic video-texture baseline (baselines/classic_video_textures/
  * computeD1.py:47-96; BASELINE config 1): x [n, d] fp32 device rows (flattened frames), out [n, n] fp32.
  * fp64 accumulation in a fixed order, one sqrt, one rounding. */

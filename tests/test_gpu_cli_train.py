@@ -90,7 +90,7 @@ def test_validate_m2_driving_audio_on_mfma_encoders(avt, dev, capsys):
                            enc_arch="slowfast", img_size=64, model_type=2, mini_batchsize=8, threshold=0.3, alpha=0.5,
                            temp=0.1, driving_audio=None, da_feats="VGG", interpolation=False, new_video_length=2,
                            results_folder=None, logname="exp", batch_size=8, stitch_mode="aligned", ref_num_gpus=1,
-                           enc_batch=8, enc_impl="auto")
+                           enc_batch=8, enc_impl="auto", enc_dtype="bf16")
     np.random.seed(5)
     frames = avt.validate(model, args, video_name="x", model_type=2, video=(_video(70, 48).numpy(), 10.0),
                           audio=(wave, 16000), driving_audio=(wave_da, 16000))
@@ -131,7 +131,7 @@ def test_four_streams_unjoined_equals_one_stream(avt, dev):
 
 def test_ddp_training_with_unused_audio_mlps(avt, dev, tmp_path):
     """model_type 2 under DistributedDataParallel (one-rank RCCL group): q_a_mlp / t_a_mlp are never called
-    (models.py:267-284) and must not stall DDP's reducer on the second step (main.py wraps with them frozen)."""
+    (models.py:267-284), nor is VGGish's fc stack (vggish.py:45): main.wrap_ddp freezes them so DDP's reducer does not stall."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -145,9 +145,8 @@ rank, world, local = adist.init_from_env()
 dev = torch.device("cuda", local)
 model = avtex.ContrastivePredictionTemporal(seeded(TinySlowFast, 1), seeded(TinySlowFast, 2), avtex.VGGish(), 2, 128,
                                             temp=0.1, window=5, stride=2, enc_arch="slowfast", img_size=32).to(dev)
-for name in ("q_a_mlp", "t_a_mlp"):
-    getattr(model, name).requires_grad_(False)
-model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+from avtex.main import wrap_ddp
+model = wrap_ddp(model, dev, local)
 opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.01)
 crit = avtex.InfoNCECriterion()
 g = torch.Generator().manual_seed(0)

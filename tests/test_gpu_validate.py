@@ -197,7 +197,7 @@ def test_validate_with_real_slowfast_on_mfma_encoder(avt, dev, capsys):
                            enc_arch="slowfast", img_size=224, model_type=1, mini_batchsize=8, threshold=0.3, alpha=0.5,
                            temp=0.1, driving_audio=None, da_feats="VGG", interpolation=False, new_video_length=12,
                            results_folder=None, logname="exp", batch_size=24, stitch_mode="aligned", enc_batch=8,
-                           enc_impl="mfma")
+                           enc_impl="mfma", enc_dtype="bf16")
     np.random.seed(7)
     frames = avt.validate(model, args, video_name="x", model_type=1, video=(video, 4.0))
     assert "Frames list: " in capsys.readouterr().out and len(frames) >= 48
