@@ -195,6 +195,20 @@ class FusedConv:
         o = [(n + 2 * p - k) // s + 1 - c for n, p, k, s, c in zip((t, h, w), self.pad, self.kernel, self.stride, self.crop)]
         return (b, o[0], o[1], o[2])
 
+    def kernel_symbol(self, m_out):
+        """The device kernel the dispatcher of csrc/conv_igemm.hip / conv_x3.hip picks for this layer (bench.py names its
+        roofline rows by it; mirrors avt_conv3d_igemm_wfrag_bf16 / avt_conv3d_igemm_x3)."""
+        if self.x3 is not None:
+            tile = "128,32,32" if self.cout <= 32 else ("128,64,64" if self.cout <= 64 else "128,128,64")
+            return "conv_x3_kernel<%s,%s>" % (tile, "f16" if self.x3 == ops.X3_F16 else "bf16")
+        if self.wfrag is not None:
+            return "conv_xb_kernel"
+        taps = self.kernel[0] * self.kernel[1] * self.kernel[2]
+        nk = -(-self.wt.shape[1] // 64)
+        if self.cout >= 256 and nk >= 16 and (self.cin % 32 == 0 or taps == 1):
+            return "conv_xl_kernel<256,256,2>"
+        return "conv_igemm_kernel<%s>" % ("256,32,64" if self.cout <= 32 else ("256,64,64" if self.cout <= 64 else "128,128,64"))
+
     def group_factor(self, x, out, res):
         """Pixel-group factor along W for few-channel layers (see group_weights_w); 1 = plain."""
         if self._folded is None or self.stride[2] != 1 or self.pad[2] != self.kernel[2] // 2:
@@ -268,8 +282,8 @@ class FusedConv:
             m_out = od[0] * od[1] * od[2] * od[3]
             m_in = x.dims[0] * x.dims[1] * x.dims[2] * x.dims[3]
             nb = 2.0 * (m_in * self.cin + m_out * self.cout * (2 if res is not None else 1)) + self.wt.numel() * 2
-            PROFILER("conv3d_igemm_x3" if self.x3 is not None else "conv3d_igemm_bf16", launch,
-                     m_out * self.alg_flops_per_row, nb * (2 if self.x3 is not None else 1))
+            PROFILER(self.kernel_symbol(m_out), launch, m_out * self.alg_flops_per_row,
+                     nb * (2 if self.x3 is not None else 1))
         return out
 
 
@@ -513,7 +527,7 @@ class _Block:
         if PROFILER is None:
             launch()
         else:
-            PROFILER("conv3d_igemm_bf16", launch, m * (first.alg_flops_per_row + nxt.a.alg_flops_per_row),
+            PROFILER("pw_chain_kernel", launch, m * (first.alg_flops_per_row + nxt.a.alg_flops_per_row),
                      2.0 * m * (k1 + n1 * (2 if res is not None else 1) + k2x + n2))
         return y, z
 
@@ -531,7 +545,7 @@ class _Block:
                 launch()
             else:
                 rows = b * t * h * w
-                PROFILER("conv3d_igemm_bf16", launch, rows * self.b.alg_flops_per_row, 2.0 * rows * 2 * self.b.cout)
+                PROFILER("c33_kernel", launch, rows * self.b.alg_flops_per_row, 2.0 * rows * 2 * self.b.cout)
             return out
         return self.b(m, out=out)
 
@@ -567,7 +581,7 @@ class _Block:
             else:
                 m = b * t * h * w
                 fl = m * (self.a.alg_flops_per_row + self.b.alg_flops_per_row + self.c.alg_flops_per_row)
-                PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * (2 * m * x.C))
+                PROFILER("bottleneck_kernel", launch, fl, 2.0 * (2 * m * x.C))
             return y
         if (self.fused_first is not None and out is None and x.c0 == 0 and x.ld == x.C and
                 ops.bottleneck_first_supported(x.C, self.c.cout, x.dims[3]) and x.dims[2] % self.b.stride[1] == 0):
@@ -587,7 +601,7 @@ class _Block:
                 m = b * t * h * w
                 fl = (m * self.a.alg_flops_per_row +
                       mo * (self.b.alg_flops_per_row + self.c.alg_flops_per_row + self.b1.alg_flops_per_row))
-                PROFILER("conv3d_igemm_bf16", launch, fl, 2.0 * (m * x.C + mo * self.c.cout))
+                PROFILER("bottleneck_kernel", launch, fl, 2.0 * (m * x.C + mo * self.c.cout))
             return y
         sc = self.b1(x) if self.b1 is not None else x
         return self.c(self._b(self.a(x)), out=out, res=sc, relu=True)
@@ -683,7 +697,7 @@ class SlowFastMFMA(nn.Module):
             if PROFILER is None:
                 launch()
             else:
-                PROFILER("conv3d_igemm_bf16", launch, m_out * conv.alg_flops_per_row,
+                PROFILER("stem_kernel", launch, m_out * conv.alg_flops_per_row,
                          2.0 * (x.buf.numel() + pd[0] * pd[1] * pd[2] * pd[3] * cf) + conv.wt.numel() * 2)
             return out, pd
         if lds_path:
@@ -695,7 +709,7 @@ class SlowFastMFMA(nn.Module):
             if PROFILER is None:
                 launch()
             else:
-                PROFILER("conv3d_igemm_bf16", launch, m_out * conv.alg_flops_per_row,
+                PROFILER("stem_kernel", launch, m_out * conv.alg_flops_per_row,
                          2.0 * (x.buf.numel() + m_out * conv.cout) + conv.wt.numel() * 2)
         else:
             y = conv(x)

@@ -12,8 +12,8 @@ import torch
 import torch.nn as nn
 
 
-def structured_video(seed, n_frames, h, w, scene_len=24):
-    """uint8 [n_frames, h, w, 3] RGB."""
+def structured_video(seed, n_frames, h, w, scene_len=24, device="cpu", chunk=2048):
+    """uint8 [n_frames, h, w, 3] RGB (on `device`; generated in chunks so a 16k-frame video never exists in fp32)."""
     g = torch.Generator().manual_seed(seed)
     n_key = n_frames // scene_len + 2
     yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
@@ -26,14 +26,19 @@ def structured_video(seed, n_frames, h, w, scene_len=24):
         chans = [colour[c] + contrast * torch.sin(2 * math.pi * (fx * xx + fy * yy) + ph[c]) *
                  torch.cos(2 * math.pi * (fy * xx - fx * yy) * 0.5 + ph[(c + 1) % 3]) for c in range(3)]
         keys.append(torch.stack(chans, -1))
-    keys = torch.stack(keys)  # [n_key, h, w, 3]
-    t = torch.arange(n_frames, dtype=torch.float32) / scene_len
-    i0 = t.floor().long()
-    fr = (t - i0.float()).view(-1, 1, 1, 1)
-    fr = fr * fr * (3 - 2 * fr)  # smooth cross-fade
-    vid = (1 - fr) * keys[i0] + fr * keys[i0 + 1]
-    vid = vid + 0.03 * torch.randn(vid.shape, generator=g)
-    return (vid.clamp(0, 1) * 255).round().to(torch.uint8)
+    keys = torch.stack(keys).to(device)  # [n_key, h, w, 3]
+    out = torch.empty((n_frames, h, w, 3), dtype=torch.uint8, device=device)
+    for f0 in range(0, n_frames, chunk):
+        f1 = min(f0 + chunk, n_frames)
+        t = torch.arange(f0, f1, dtype=torch.float32, device=device) / scene_len
+        i0 = t.floor().long()
+        fr = (t - i0.float()).view(-1, 1, 1, 1)
+        fr = fr * fr * (3 - 2 * fr)  # smooth cross-fade
+        vid = (1 - fr) * keys[i0] + fr * keys[i0 + 1]
+        noise = torch.randn(vid.shape, generator=g) if str(device) == "cpu" else \
+            torch.randn(vid.shape, device=device, generator=torch.Generator(device=device).manual_seed(seed * 1000003 + f0))
+        out[f0:f1] = ((vid + 0.03 * noise).clamp(0, 1) * 255).round().to(torch.uint8)
+    return out
 
 
 def randomise_bn(model, seed, sparsity=1.0):

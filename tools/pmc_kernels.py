@@ -34,5 +34,11 @@ enc = SlowFastMFMA(SlowFast(), dev)
 slow, fast = ops.clip_pack(video, starts, W, out_hw=224, dtype=torch.bfloat16, layout="ndhwc4")
 for _ in range(2):
     enc.forward_ndhwc4(slow, fast)
+# ... and one forward of each contract-grade mode (split-plane kernels: conv_x3_kernel, the plane-pair pool / mean / pack)
+for mode in ("f16x3", "bf16x3"):
+    encx = SlowFastMFMA(SlowFast(), dev, precision=mode)
+    sx, fx = ops.clip_pack(video, starts, W, out_hw=224, layout="ndhwc4", planes=mode)
+    for _ in range(2):
+        encx.forward_ndhwc4(sx, fx)
 torch.cuda.synchronize()
 print("done")

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""GPU probe: contract-grade (split-plane) SlowFast throughput and per-layer time (HIP events around every launch).
+usage: probe_x3.py [mode=f16x3] [batch=64]"""
+import collections
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import avtex  # noqa: E402
+import avtex.fused_slowfast as fsf  # noqa: E402
+from avtex import ops  # noqa: E402
+from avtex.slowfast import SlowFast  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+m = fsf.SlowFastMFMA(SlowFast(), dev, precision=mode)
+pd = fsf.PRECISIONS[mode]
+mk = lambda t_: ops.SplitClip(*fsf.split_planes(torch.randn(b, t_, 224, 224, 4, device=dev), pd), pd)
+slow, fast = mk(8), mk(32)
+for _ in range(2):
+    y = m.forward_ndhwc4(slow, fast)
+torch.cuda.synchronize()
+t0 = time.time()
+n = 3
+for _ in range(n):
+    y = m.forward_ndhwc4(slow, fast)
+torch.cuda.synchronize()
+per = (time.time() - t0) / n
+print("%s batch=%d: %.4fs/batch -> %.1f clips/s, %.1f TFLOP/s algorithmic (%.3f of %d)" % (
+    mode, b, per, b / per, b * 100.6e9 / per / 1e12, b * 100.6e9 / per / 1e12 / 833.3, 833), flush=True)
+recs, shapes = [], []
+orig = ops.conv3d_igemm_x3
+
+
+def spy(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu,
+        plane_dtype, wscale=None, out_dims=(0, 0, 0), out_rows=None):
+    shapes.append("cin%d cout%d k%s s%s in%s%s" % (cin, cout, kernel, stride, tuple(dims), " +res" if res_ptrs else ""))
+    return orig(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr,
+                relu, plane_dtype, wscale, out_dims, out_rows)
+
+
+def hook(name, launch, flops, nbytes):
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    launch()
+    e.record()
+    recs.append((a, e, flops, nbytes, name))
+
+
+ops.conv3d_igemm_x3 = spy
+fsf.PROFILER = hook
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+y = m.forward_ndhwc4(slow, fast)
+e1.record()
+torch.cuda.synchronize()
+tot = e0.elapsed_time(e1)
+agg = collections.OrderedDict()
+for (a, e, fl, byt, sym), name in zip(recs, shapes):
+    t = a.elapsed_time(e)
+    d = agg.setdefault(name + "  " + sym.split("<")[1].split(",f")[0].split(",b")[0], [0, 0.0, 0.0, 0.0])
+    d[0] += 1
+    d[1] += t
+    d[2] += fl
+    d[3] += byt
+conv_ms = sum(v[1] for v in agg.values())
+print("batch %d forward %.2f ms; conv launches %.2f ms (%d launches); pools+head+glue %.2f ms" % (b, tot, conv_ms, len(recs), tot - conv_ms))
+for name, (n_, t, fl, byt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%7.3f ms x%d  %-74s %7.1f TF/s %7.0f GB/s" % (t, n_, name, fl / t / 1e9, byt / t / 1e6))
