@@ -73,6 +73,67 @@ def barrier_max_time(seconds, device):
     return float(t.item())
 
 
+class HipCompute:
+    """The device arithmetic of the sharded build: the C-ABI kernels (include/avt.h).  The orchestration below only
+    needs these three calls; tests/test_dist_gloo.py injects the CPU oracle in their place to run the collectives and
+    the index math under gloo (the product never does: ops.* reject host tensors)."""
+
+    def __init__(self, temp, precision="f32"):
+        self.temp, self.precision = temp, precision
+
+    def l2norm(self, v, a=None):
+        """-> the planes that travel: (fp32,) in f32 mode, (bf16 hi[, bf16 lo]) in the bf16 MFMA modes."""
+        from . import ops
+
+        n, hi, lo = ops.l2norm_rows(v, a, want_f32=self.precision == "f32", want_split=self.precision != "f32")
+        return (n,) if self.precision == "f32" else ((hi, lo) if self.precision == "bf16x3" else (hi,))
+
+    def sim(self, q, t):
+        from . import ops
+
+        if self.precision == "f32":
+            return ops.sim_gemm_nt(q[0], t[0], self.temp, "f32")
+        return ops.sim_gemm_nt(q[0], t[0], self.temp, self.precision, q_lo=q[1] if len(q) > 1 else None,
+                               t_lo=t[1] if len(t) > 1 else None)
+
+    def select(self, sim, q_ids, threshold, cap):
+        from . import ops
+
+        return ops.row_transition(sim, q_ids=q_ids, threshold=threshold, cap=cap)
+
+
+def sharded_survivors(encode_block, n_total, threshold, compute, rank=0, world=1, want_sim=False):
+    """The N x N build of validate() sharded over `world` ranks (replaces the DataParallel scatter/gather
+    of validate.py:320, 349-363, 442-445, 481-493): rank r encodes windows [lo, hi) with both encoders
+    (encode_block(lo, hi) -> (q_rows, t_rows, audio_rows | None)), normalises them, ONE all-gather of the normalised
+    target planes, its row block of sim = Q_r T^T / temp, the row select, and only the survivors travel to rank 0:
+    the widest survivor list is agreed by an all-reduce(MAX) so nothing is truncated.
+    -> on rank 0 a dict of host arrays (idx, seg, p [N, kmax], cnt [N], stats [N, 4][, sim [N, N] when want_sim]);
+    None on the other ranks."""
+    lo, hi = shard_range(n_total, rank, world)
+    qv, tv, av = encode_block(lo, hi)
+    qn = compute.l2norm(qv, av)
+    tn = compute.l2norm(tv, av)
+    t_all = tuple(all_gather_rows(p, n_total) for p in tn)
+    sim = compute.sim(qn, t_all)
+    q_ids = torch.arange(lo, hi, device=sim.device, dtype=torch.int64)
+    sel = compute.select(sim, q_ids, threshold, n_total)
+    kmax = sel["cnt"].max().to(torch.int64).reshape(1) if hi > lo else torch.zeros(1, dtype=torch.int64, device=sim.device)
+    if dist.is_initialized():
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    k = max(int(kmax.item()), 1)
+    out = {}
+    for key in ("idx", "seg", "p"):
+        out[key] = gather_to_root(sel[key][:, :k].contiguous(), n_total)
+    for key in ("cnt", "stats"):
+        out[key] = gather_to_root(sel[key], n_total)
+    if want_sim:
+        out["sim"] = gather_to_root(sim, n_total)
+    if dist.is_initialized() and dist.get_rank() != 0:
+        return None
+    return {key: v.cpu().numpy() for key, v in out.items()}
+
+
 def sharded_transition_build(engine, n_total, threshold, cap, precision="f32", rank=0, world=1, starts=None):
     """Config 4 pipeline on one rank: encode own window block with both encoders -> all-gather T (and the
     audio table) -> own row block of sim = Q_r T^T / temp -> select.  Returns the rank's survivor dict and

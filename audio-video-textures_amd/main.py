@@ -148,7 +148,9 @@ def main(args, video_name, itr=0):
     tb_logger = Logger(tb_logdir) if rank == 0 else None
 
     if args.evaluate:
-        if rank == 0:
+        # aligned mode: every rank takes part (its block of windows / rows, dist.sharded_survivors); compat mode keeps
+        # the reference's per-step window map, which is one rank's work
+        if rank == 0 or (world > 1 and args.stitch_mode == "aligned"):
             validate(model, args, video_name=video_name, tb_logger=tb_logger, model_type=args.model_type, itr=itr)
         return
     optimizer = torch.optim.SGD(params=model.parameters(), lr=args.lr, momentum=args.momentum,

@@ -144,6 +144,16 @@ class TextureEngine:
                 self.A_da = self.A if (da is self.a_enc and self.A is not None) else self._vgg(da, eg)
                 self.Ad = self._vgg(da, torch.as_tensor(driving_eg))
 
+    def audio_block(self, audio_eg, lo, hi):
+        """Rows [lo, hi) of the m=2 source-audio table: VGGish(audio_eg[min(j, max_audio_segment_id)]) (validate.py:346,
+        398-401) — what a rank of the sharded build needs, instead of set_audio()'s whole table."""
+        if self.a_enc is None:
+            raise AvtError("model_type 2 needs an audio encoder")
+        eg = torch.as_tensor(audio_eg)[: self.N]
+        j = torch.clamp(torch.arange(lo, hi), max=eg.shape[0] - 1)
+        with torch.no_grad():
+            return self._vgg(self.a_enc, eg[j.to(eg.device)])
+
     def _vgg(self, enc, eg, batch=256):
         p = next(enc.parameters())
         outs = [enc(eg[i : i + batch].to(self.dev, p.dtype)).float() for i in range(0, len(eg), batch)]

@@ -15,6 +15,7 @@ Reference quirks handled explicitly: Q1 (input_frames is prepared for every mode
 (args.vcam defaults to False), Q8 (dummy audio consumes torch RNG), Q11 (the reference's final
 save_videos() call crashes under -nintp; here it is simply skipped when nothing was interpolated).
 """
+import builtins
 import copy
 import math
 import os
@@ -97,6 +98,15 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
     video = (uint8 [F,H,W,3], fps); audio = (waveform, sr); driving_audio = (waveform, sr).
     Returns the list of source frame ids of the new video (the reference returns None and prints it)."""
     batch_time, losses, accs = AverageMeter(), AverageMeter(), AverageMeter()
+    import torch.distributed as tdist
+
+    mode = getattr(args, "stitch_mode", "compat")
+    # one process per GPU (torch.distributed.run) instead of the reference's DataParallel (main.py:420): in aligned mode
+    # every rank encodes its block of windows and owns the matching rows of the N x N matrix; rank 0 walks and prints
+    sharded = mode == "aligned" and tdist.is_available() and tdist.is_initialized()
+    rank = tdist.get_rank() if sharded else 0
+    world = tdist.get_world_size() if sharded else 1
+    print = builtins.print if rank == 0 else (lambda *a, **k: None)  # noqa: A001 — the reference's prints, on rank 0 only
     model.eval()
     net = _unwrap(model)
     S, W = args.stride, args.window
@@ -156,7 +166,6 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         max_length = min(max_length, np.ceil(args.fps) * np.floor(len(driving_audio_eg) * S + W))
 
     # ---- engine: everything device-side is set up once ---------------------------------------------
-    mode = getattr(args, "stitch_mode", "compat")
     ref_gpus = getattr(args, "ref_num_gpus", None) or max(torch.cuda.device_count(), 1)
     da_model = None
     if driving_audio_name is not None:
@@ -205,13 +214,37 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
                                 enc_batch=getattr(args, "enc_batch", 32),
                                 enc_arch=getattr(args, "enc_arch", "slowfast"))
     assert eng.set_video(input_video) == L
-    if net.model_type == 2 or driving_audio_name is not None:
-        if audio_eg.dim() != 4:
-            raise AvtError("model_type 2 / driving audio need real source audio (-adata); the reference crashes "
-                           "here too [Q8] (models.py:341)")
-        eng.set_audio(audio_eg, driving_audio_eg, da_encoder=da_model)
+    need_audio = net.model_type == 2 or driving_audio_name is not None
+    if need_audio and audio_eg.dim() != 4:
+        raise AvtError("model_type 2 / driving audio need real source audio (-adata); the reference crashes "
+                       "here too [Q8] (models.py:341)")
+    if need_audio and (not sharded or rank == 0 or net.model_type == 2):
+        # sharded: ranks > 0 only need the source-audio examples (their block of the m=2 table); the driving branch's
+        # two small tables live on rank 0
+        if not sharded:
+            eng.set_audio(audio_eg, driving_audio_eg, da_encoder=da_model)
+        elif rank == 0 and driving_audio_eg is not None:
+            keep, eng.model_type = eng.model_type, 1  # (the m=2 source table is built per block below, not here)
+            eng.set_audio(audio_eg, driving_audio_eg, da_encoder=da_model)
+            eng.model_type = keep
     end = time.time()
-    if mode == "aligned":
+    surv = None
+    if sharded:
+        from . import dist as adist
+
+        def encode_block(lo, hi):
+            qv, tv = eng.embed_windows([eng.q_enc, eng.t_enc], starts=np.arange(lo, hi, dtype=np.int64) * S)
+            av = eng.audio_block(audio_eg, lo, hi) if net.model_type == 2 else None
+            return qv, tv, av
+
+        surv = adist.sharded_survivors(encode_block, L, args.threshold, adist.HipCompute(net.temp, "f32"), rank, world,
+                                       want_sim=driving_audio_name is not None)
+        if rank != 0:
+            return None  # this rank's rows are with rank 0; the serial walk (validate.py:324, 572) is rank 0's
+        if driving_audio_name is not None:
+            eng.sim = torch.from_numpy(surv["sim"]).to(dev)
+            surv = None  # the audio blend depends on (row, step): rank 0 selects per step from the gathered matrix
+    elif mode == "aligned":
         eng.build_tables()
         eng.normalise()
         eng.similarity("f32")
@@ -224,11 +257,18 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         if mode == "compat":
             out, out_a, os_ids_t = eng.compat_row(q_id, iter_count, args.mini_batchsize, ref_gpus)
             choices, sel = eng.select(out, out_a, args.threshold, args.alpha)
+            stats, non_zero_count = sel["stats"][0].cpu().numpy(), int(sel["cnt"][0])
+            surv_p = sel["p"][0, :non_zero_count].cpu().numpy()
+        elif surv is not None:  # rows selected on their owning ranks, gathered once
+            non_zero_count = int(surv["cnt"][q_id])
+            choices, surv_p, stats = surv["idx"][q_id, :non_zero_count], surv["p"][q_id, :non_zero_count], surv["stats"][q_id]
+            os_ids_t = texture.target_segment_ids(q_id, L)
         else:
             choices, _, sel = eng.aligned_row(q_id, iter_count, args.threshold, args.alpha)
             os_ids_t = texture.target_segment_ids(q_id, L)
-        stats = sel["stats"][0].cpu().numpy()
-        loss, entropy, non_zero_count = float(stats[2]), float(stats[3]), int(sel["cnt"][0])
+            stats, non_zero_count = sel["stats"][0].cpu().numpy(), int(sel["cnt"][0])
+            surv_p = sel["p"][0, :non_zero_count].cpu().numpy()
+        loss, entropy = float(stats[2]), float(stats[3])
         print("Original Next Frame: {}".format(os_ids_t[0]))
         print(choices)
         print("Entropy: ", entropy)
@@ -242,7 +282,6 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         losses.update(loss, 1)
         # validate.py:533-536: acc = 1 when the PRE-threshold row's argmax is position 0.  The maximum always survives the
         # cut and renormalising is monotonic, so that is "the first survivor is position 0 and carries the largest p"
-        surv_p = sel["p"][0, :non_zero_count]
         accs.update(1.0 if (non_zero_count and choices[0] == 0 and bool(surv_p[0] == surv_p.max())) else 0.0, 1)
 
         # frame bookkeeping (validate.py:580-615)
