@@ -54,6 +54,9 @@ SIGNATURES = {
     "avt_conv3d_ktab": [C.c_int] * 7 + [_vp, C.c_int],
     "avt_conv3d_igemm_bf16": [_vp] * 6 + [C.c_int] * 22 + [_vp],
     "avt_conv3d_igemm_rows_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp],
+    "avt_negative_sample_mt19937": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
+    "avt_clip_pack_gather_u8": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                C.c_int, _vp, _vp, C.c_int, _vp],
     "avt_conv3d_igemm_x3": [_vp] * 10 + [C.c_int] * 26 + [_vp, _vp],
     "avt_clip_pack_u8_ndhwc4_x3": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                    C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp],

@@ -133,6 +133,71 @@ __global__ __launch_bounds__(256) void clip_pack_kernel(PArgs a) {
   }
 }
 
+// Gather form for TRAINING batches (config 5: a query, its positive and the sampled negatives are scattered windows with
+// little frame reuse): organised by DESTINATION — one workgroup per (window, slot, channel, row strip) — with the window
+// starts read from a DEVICE array, so a step needs no host-built plan and no host round trip between the device-side
+// negative sampling (negsample.hip) and the packing.  Same arithmetic as clip_pack_kernel, value for value.
+struct GArgs {
+  const uint8_t* frames;
+  int n_frames, H, W;
+  const int32_t* win_start;  // [n_win] device
+  int n_win, win_len;
+  int hw;
+  float mean, std;
+  int bgr;
+  void* slow;
+  void* fast;
+  int cpr, rpb, tiles;
+  float scale_h, scale_w;
+  int fast_idx[AVT_FAST_T], slow_idx[AVT_SLOW_T];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void clip_pack_gather_kernel(GArgs a) {
+  __shared__ float lut[256];
+  lut[threadIdx.x] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)threadIdx.x, 255.0f), a.mean), a.std);
+  __syncthreads();
+  int b = blockIdx.x;
+  const int tile = b % a.tiles;
+  b /= a.tiles;
+  const int c = b % 3;
+  b /= 3;
+  const int slot = b % AVT_SLOTS;
+  const int n = b / AVT_SLOTS;
+  int f = a.win_start[n] + (slot < AVT_SLOW_T ? a.slow_idx[slot] : a.fast_idx[slot - AVT_SLOW_T]);
+  f = f < 0 ? 0 : (f > a.n_frames - 1 ? a.n_frames - 1 : f);  // a bad start cannot fault; the host wrapper validates ids
+  const int tid = threadIdx.x;
+  const int ry = tid / a.cpr, cx = tid - ry * a.cpr;
+  const int y = tile * a.rpb + ry;
+  if (ry >= a.rpb || y >= a.hw) return;
+  const int x0 = cx * 8;
+  int y0, y1;
+  float ly;
+  src_index(a.scale_h, y, a.H, y0, y1, ly);
+  const float hy = 1.0f - ly;
+  const int sc = a.bgr ? 2 - c : c;
+  const uint8_t* r0 = a.frames + ((int64_t)f * a.H + y0) * a.W * 3 + sc;
+  const uint8_t* r1 = a.frames + ((int64_t)f * a.H + y1) * a.W * 3 + sc;
+  const int64_t plane = (int64_t)a.hw * a.hw;
+  T* dst = slot < AVT_SLOW_T
+               ? static_cast<T*>(a.slow) + (((int64_t)n * 3 + c) * AVT_SLOW_T + slot) * plane
+               : static_cast<T*>(a.fast) + (((int64_t)n * 3 + c) * AVT_FAST_T + (slot - AVT_SLOW_T)) * plane;
+  dst += (int64_t)y * a.hw + x0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int x = x0 + j;
+    if (x < a.hw) {
+      int xa, xb;
+      float lx;
+      src_index(a.scale_w, x, a.W, xa, xb, lx);
+      const float hx = 1.0f - lx;
+      const float p00 = lut[r0[xa * 3]], p01 = lut[r0[xb * 3]];
+      const float p10 = lut[r1[xa * 3]], p11 = lut[r1[xb * 3]];
+      dst[j] = Out<T>::cvt(hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11));
+    }
+  }
+}
+
 // Channels-last variant for the MFMA stem: slow [n,8,hw,hw,4], fast [n,32,hw,hw,4] bf16 (NDHWC, C padded
 // 3 -> 4 with a zero).  A workgroup resizes a strip of one source frame for all three channels; each lane owns
 // 4 consecutive output pixels = 32 contiguous bytes per destination.
@@ -374,4 +439,43 @@ extern "C" int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, i
               "avt_clip_pack_u8_ndhwc4_x3: the low-order planes must be 16-byte aligned device buffers");
   return clip_pack_ndhwc4_impl(frames, n_frames, height, width, dst_off, dst_slot, n_win, out_hw, mean, std, bgr, slow_hi,
                                fast_hi, slow_lo, fast_lo, plane_dtype == AVT_X3_F16 ? 2 : 1, stream);
+}
+
+extern "C" int avt_clip_pack_gather_u8(const uint8_t* frames, int n_frames, int height, int width, const int32_t* win_start,
+                                       int n_win, int win_len, int out_hw, float mean, float std, int bgr, void* slow,
+                                       void* fast, int out_dtype, void* stream) {
+  AVT_REQUIRE(n_frames > 0 && height > 0 && width > 0 && out_hw > 0 && n_win >= 0 && win_len > 0 && win_len <= n_frames,
+              "avt_clip_pack_gather_u8: bad sizes");
+  if (n_win == 0) return AVT_OK;
+  AVT_REQUIRE(frames && win_start && slow && fast, "avt_clip_pack_gather_u8: NULL pointer");
+  AVT_REQUIRE(out_hw <= 2048 && std != 0.0f, "avt_clip_pack_gather_u8: out_hw > 2048 or std == 0");
+  AVT_REQUIRE(out_dtype == AVT_DT_F32 || out_dtype == AVT_DT_BF16, "avt_clip_pack_gather_u8: unknown out_dtype %d", out_dtype);
+  GArgs a;
+  a.frames = frames;
+  a.n_frames = n_frames;
+  a.H = height;
+  a.W = width;
+  a.win_start = win_start;
+  a.n_win = n_win;
+  a.win_len = win_len;
+  a.hw = out_hw;
+  a.mean = mean;
+  a.std = std;
+  a.bgr = bgr;
+  a.slow = slow;
+  a.fast = fast;
+  a.cpr = (out_hw + 7) / 8;
+  a.rpb = 256 / a.cpr;
+  a.tiles = (out_hw + a.rpb - 1) / a.rpb;
+  a.scale_h = (float)height / (float)out_hw;
+  a.scale_w = (float)width / (float)out_hw;
+  avt_clip_sample_table(win_len, a.fast_idx, a.slow_idx);
+  const int64_t nblk = (int64_t)a.tiles * 3 * AVT_SLOTS * n_win;
+  AVT_REQUIRE(nblk < (1ll << 31), "avt_clip_pack_gather_u8: grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (out_dtype == AVT_DT_BF16)
+    hipLaunchKernelGGL(clip_pack_gather_kernel<uint16_t>, dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(clip_pack_gather_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, st, a);
+  return avt::check_launch("avt_clip_pack_gather_u8");
 }

@@ -126,3 +126,64 @@ class AudioVideoSegments(Dataset):
             return (q_v, q_aw, q_ae, t_v, t_aw, t_ae)
         ordering = torch.cat((torch.tensor([pos]), torch.tensor(neg)))
         return (q_v, q_aw, q_ae, t_v, t_aw, t_ae, idx, ordering)
+
+
+class DeviceSegmentBatcher:
+    """Training batches assembled ON the MI355X — the video part of `AudioVideoSegments.__getitem__` + default collate
+    (dataset.py:121-253) without its per-item CPU preprocessing (dataset.py:145-209: process_cv2_inputs + interpolate per
+    segment in DataLoader workers) and without a host round trip per step:
+
+      * the uint8 video (and the log-mel examples) stay resident in HBM;
+      * negatives are drawn by the device MT19937 kernel from NumPy's own stream (ops.negative_sample: the state of
+        np.random is uploaded once by `seed_from_numpy()` and can be handed back by `sync_to_numpy()`), with the
+        reference's hard-negative overwrite (dataset.py:183-190);
+      * query / positive / negative windows are packed by the gather kernel (ops.clip_pack_gather), starts read on device.
+
+    batch(idx) -> (q_frames, t_frames, q_audio_eg, t_audio_eg) with the shapes the DataLoader would deliver:
+    q_frames [slow [B,3,8,hw,hw], fast [B,3,32,hw,hw]], t_frames [slow [B,1+negs,3,8,hw,hw], fast [B,1+negs,3,32,hw,hw]]."""
+
+    def __init__(self, dataset, device, dtype=torch.float32):
+        from . import ops
+
+        if dataset.enc_arch != "slowfast" or dataset.split != "train":
+            raise ValueError("DeviceSegmentBatcher packs SlowFast training items")
+        self.ops, self.ds, self.dev, self.dtype = ops, dataset, torch.device(device), dtype
+        self.frames = dataset.video_u8.to(self.dev).contiguous()
+        self.audio_eg = dataset.audio_eg.to(self.dev) if dataset.audio_eg.dim() == 4 else None
+        self.state = None
+
+    def seed_from_numpy(self):
+        st = np.random.get_state()
+        words = np.concatenate([np.asarray(st[1], np.uint32), np.array([st[2]], np.uint32)])
+        self.state = torch.from_numpy(words.view(np.int32).copy()).to(self.dev)
+        return self
+
+    def sync_to_numpy(self):
+        """Hands the advanced stream back to np.random (one D2H of 2.5 KB; only needed when host code draws next)."""
+        words = self.state.cpu().numpy().view(np.uint32)
+        np.random.set_state(("MT19937", words[:624].copy(), int(words[624]), 0, 0.0))
+
+    def sample(self, idx):
+        """idx int64 [B] -> (positive ids [B], negative ids [B, n_negs]) on the device."""
+        if self.state is None:
+            self.seed_from_numpy()
+        idx = torch.as_tensor(idx, dtype=torch.int64).to(self.dev).contiguous()
+        neg = self.ops.negative_sample(self.state, idx, len(self.ds), self.ds.n_negs)
+        return idx + 1, neg
+
+    def batch(self, idx):
+        ds, S, W = self.ds, self.ds.stride, self.ds.window
+        idx = torch.as_tensor(idx, dtype=torch.int64).to(self.dev).contiguous()
+        b = idx.numel()
+        pos, neg = self.sample(idx)
+        tgt = torch.cat((pos.view(b, 1), neg.to(torch.int64)), 1)  # [B, 1 + negs] segment ids
+        starts = (torch.cat((idx, tgt.reshape(-1))) * S).to(torch.int32).contiguous()
+        slow, fast = self.ops.clip_pack_gather(self.frames, starts, W, out_hw=ds.img_size, dtype=self.dtype)
+        hw, n = ds.img_size, tgt.shape[1]
+        q_frames = [slow[:b], fast[:b]]
+        t_frames = [slow[b:].view(b, n, 3, 8, hw, hw), fast[b:].view(b, n, 3, 32, hw, hw)]
+        q_ae = t_ae = None
+        if self.audio_eg is not None:
+            q_ae = self.audio_eg[idx]
+            t_ae = self.audio_eg[tgt.reshape(-1)].view(b, n, *self.audio_eg.shape[1:])
+        return q_frames, t_frames, q_ae, t_ae

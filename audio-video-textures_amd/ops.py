@@ -129,6 +129,33 @@ def clip_pack(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0.225, b
     return slow, fast
 
 
+def clip_pack_gather(frames_u8, win_start_dev, win_len, out_hw=224, mean=0.45, std=0.225, bgr=True, dtype=torch.float32):
+    """clip_pack for scattered windows whose starts are a DEVICE int32 tensor (training batches): no host plan."""
+    _dev(frames_u8, "frames_u8", torch.uint8)
+    _dev(win_start_dev, "win_start", torch.int32)
+    n_frames, h, w, _ = frames_u8.shape
+    n_win = int(win_start_dev.numel())
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise _lib.AvtError("clip_pack_gather: dtype must be bfloat16 or float32")
+    slow = torch.empty((n_win, 3, SLOW_T, out_hw, out_hw), dtype=dtype, device=frames_u8.device)
+    fast = torch.empty((n_win, 3, FAST_T, out_hw, out_hw), dtype=dtype, device=frames_u8.device)
+    _lib.check(_lib.lib().avt_clip_pack_gather_u8(_p(frames_u8), n_frames, h, w, _p(win_start_dev), n_win, int(win_len),
+                                                  int(out_hw), float(mean), float(std), 1 if bgr else 0, _p(slow), _p(fast),
+                                                  1 if dtype == torch.bfloat16 else 0, _stream()), "avt_clip_pack_gather_u8")
+    return slow, fast
+
+
+def negative_sample(mt_state, idx, n_len, n_negs):
+    """mt_state int32/uint32-bits [625] device tensor (np.random.get_state() key + pos), advanced in place; idx int64 [B]
+    device -> negatives int32 [B, n_negs] (dataset.py:181-190 semantics, NumPy's stream)."""
+    _dev(mt_state, "mt_state", torch.int32)
+    _dev(idx, "idx", torch.int64)
+    out = torch.empty((idx.numel(), int(n_negs)), dtype=torch.int32, device=idx.device)
+    _lib.check(_lib.lib().avt_negative_sample_mt19937(_p(mt_state), _p(idx), int(idx.numel()), int(n_len), int(n_negs),
+                                                      _p(out), _stream()), "avt_negative_sample_mt19937")
+    return out
+
+
 # ---- l2norm --------------------------------------------------------------------
 def l2norm_rows(x0, x1=None, eps=1e-12, want_f32=True, want_split=False):
     """y = [x0|x1] / max(||.||, eps) row-wise -> (y_f32 | None, y_hi | None, y_lo | None)."""

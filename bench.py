@@ -256,6 +256,153 @@ def run_mode(args, precision, video, q_mod, t_mod, rank, world, dev):
     }
 
 
+def nxn_legs(dev, reps=5):
+    """The N x N transition build on its own, at the sizes SURVEY.md §8(d) lists, on seeded embeddings (Q = randn seed 0,
+    T = the clustered variant Q.roll(-1) + 0.1 randn, so next-segment positives exist): l2norm x2 -> similarity -> select,
+    HIP-event times per kernel with their roofline fractions.  Legs: threshold 0.3 / 0.0 (argmax) / top-k k=8, the three
+    MFMA modes, N = 2048 / 4096, D = 2304 / 14592 (m=2), and one rank's share of config 4 (2048 x 16384)."""
+    from avtex import ops
+
+    def timed(fn):
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            out = fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps, out
+
+    legs = []
+    cases = [("N=4096 D=2304", 4096, 4096, 2304, ("f32", "bf16x3", "bf16")), ("N=2048 D=2304", 2048, 2048, 2304, ("f32",)),
+             ("N=4096 D=14592 (m=2)", 4096, 4096, 14592, ("f32",)),
+             ("config 4 shard: 2048 of 16384 rows, D=2304", 2048, 16384, 2304, ("f32", "bf16x3"))]
+    for name, nq, nt, d, modes in cases:
+        q_all = torch.randn((nt, d), generator=torch.Generator().manual_seed(0))
+        t_all = q_all.roll(-1, 0) + 0.1 * torch.randn((nt, d), generator=torch.Generator().manual_seed(1))
+        q, t = q_all[:nq].contiguous().to(dev), t_all.to(dev)
+        del q_all, t_all
+        q_ids = torch.arange(nq, device=dev, dtype=torch.int64)
+        for mode in modes:
+            split = mode != "f32"
+            ms_nq, (qn, qh, ql) = timed(lambda: ops.l2norm_rows(q, want_f32=not split, want_split=split))
+            ms_nt, (tn, th, tl) = timed(lambda: ops.l2norm_rows(t, want_f32=not split, want_split=split))
+            if mode == "f32":
+                ms_sim, sim = timed(lambda: ops.sim_gemm_nt(qn, tn, 0.1, "f32"))
+            else:
+                ms_sim, sim = timed(lambda: ops.sim_gemm_nt(qh, th, 0.1, mode, q_lo=ql, t_lo=tl))
+            leg = {"case": name, "sim_mode": mode, "l2norm_ms": ms_nq + ms_nt,
+                   "l2norm_GBps": (nq + nt) * d * (4 + (4 if split else 4)) / ((ms_nq + ms_nt) * 1e-3) / 1e9,
+                   "sim_ms": ms_sim, "sim_TFLOPs": 2.0 * nq * nt * d / (ms_sim * 1e-3) / 1e12,
+                   "sim_frac_of_mfma_peak": 2.0 * nq * nt * d / (ms_sim * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[mode]}
+            for th_ in (0.3, 0.0):
+                ms_sel, sel = timed(lambda: ops.row_transition(sim, q_ids=q_ids, threshold=th_, cap=64))
+                leg["select_th%.1f_ms" % th_] = ms_sel
+                leg["select_th%.1f_GBps" % th_] = nq * nt * 4.0 / (ms_sel * 1e-3) / 1e9
+                leg["select_th%.1f_mean_survivors" % th_] = float(sel["cnt"].float().mean())
+            ms_top, (ti, tv) = timed(lambda: ops.row_topk(sim, 8, self_col=q_ids))
+            leg["topk8_ms"], leg["topk8_GBps"] = ms_top, nq * nt * 4.0 / (ms_top * 1e-3) / 1e9
+            leg["argmax_is_next_segment"] = float((ti[:, 0].long() == (q_ids + 1) % nt).float().mean())
+            leg["build_ms_th0.0"] = leg["l2norm_ms"] + ms_sim + leg["select_th0.0_ms"]
+            legs.append(leg)
+            del sim
+        del q, t
+        torch.cuda.empty_cache()
+    return legs
+
+
+def train_bench(args, rank, world, dev):
+    """--mode train: BASELINE config 5 — contrastive training (train.py:114-141) at size: InfoNCE, negs=14, temp=0.1,
+    batch of 8 items data-parallel.  One step = the global batch: every rank takes 8/world items; EACH item is its own
+    forward/backward of 1 query + 15 target clips through the real SlowFast-8x8-R50 encoders in train mode, which is what
+    the reference's DataParallel scatter gives every replica (per-replica BatchNorm statistics, main.py:420) — gradients
+    accumulate over the rank's items (DDP no_sync) and are all-reduced once per step over RCCL.  Input path on the device:
+    resident uint8 video, MT19937 negative sampling, gather packing (dataset.DeviceSegmentBatcher); fused HIP
+    normalise->bmm->/temp forward/backward + HIP softmax-CE (models._InfoNCELogits, InfoNCECriterion); encoder
+    forward/backward = MIOpen autograd (see DESIGN.md for why the BN-folded MFMA kernels do not apply in train mode)."""
+    import contextlib
+    from types import SimpleNamespace
+
+    import avtex
+    from avtex import dist as adist, synth
+    from avtex.dataset import DeviceSegmentBatcher
+    from avtex.main import wrap_ddp
+    from avtex.slowfast import SlowFast
+
+    B, negs, fps = 8, 14, 30.0
+    assert B % world == 0, "the batch of 8 items splits over 1, 2, 4 or 8 ranks"
+    video = synth.structured_video(123 + rank, 1500, args.frame_hw, args.frame_hw)
+    dargs = SimpleNamespace(vdata="/tmp", adata=None, n_negs=negs, img_size=224, enc_arch="slowfast", window=0, stride=0)
+    torch.manual_seed(5)
+    ds = avtex.AudioVideoSegments(dargs, "synthetic", split="train", video=(video, fps))
+    torch.manual_seed(0)
+    model = avtex.ContrastivePredictionTemporal(SlowFast(), SlowFast(), None, 1, 128, temp=0.1, window=dargs.window,
+                                                stride=dargs.stride, enc_arch="slowfast", img_size=224).to(dev).train()
+    if args.train_channels_last:
+        model = model.to(memory_format=torch.channels_last_3d)
+    net = wrap_ddp(model, dev, dev.index) if world > 1 else model
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, weight_decay=1e-4)  # README.md:38 / main.py:440-446
+    crit = avtex.InfoNCECriterion()
+    bat = DeviceSegmentBatcher(ds, dev)
+    np.random.seed(1 + rank)
+    bat.seed_from_numpy()
+    items = B // world
+    rng = np.random.RandomState(99 + rank)
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if args.train_dtype == "bf16" else contextlib.nullcontext
+    losses = []
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        idxs = rng.randint(0, len(ds), size=items)
+        for k, i in enumerate(idxs):
+            q, t, _, _ = bat.batch(torch.tensor([int(i)]))
+            if args.train_channels_last:
+                q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
+            sync = contextlib.nullcontext() if (world == 1 or k == items - 1) else net.no_sync()
+            with sync:
+                with amp():
+                    out = net(q, t)
+                loss = crit(out.float(), torch.zeros(1, dtype=torch.long, device=dev)) / items
+                loss.backward()
+            losses.append(float(loss.detach()) * items)
+        opt.step()
+
+    def sync_all():
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    total_s = adist.barrier_max_time(time.perf_counter() - t0, dev)
+    if rank != 0:
+        return
+    clips = B * (1 + 1 + negs)  # query + positive + negatives per item
+    flops = 3.0 * 100.6e9 * clips  # forward + dgrad + wgrad of the convolutions
+    value = clips * args.steps / total_s
+    peak = 157.3 if args.train_dtype == "fp32" else 2500.0
+    print(json.dumps({
+        "metric": "contrastive training (train.py) InfoNCE negs=14 temp=0.1, batch of 8 items: encoder clips/s through forward+backward",
+        "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": total_s / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.train_dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE config 5: batch 8 x (1 query + 1 positive + 14 negatives) = 128 clips/step at 224^2 "
+                               "through SlowFast-8x8-R50 q/t encoders (train-mode BatchNorm per item = per DataParallel "
+                               "replica), HIP InfoNCE + CE, SGD; inputs sampled and packed on the device",
+                   "items_per_rank": items, "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
+                   "encoder_backend": "MIOpen autograd (%s%s)" % (args.train_dtype, ", channels_last_3d" if args.train_channels_last else ""),
+                   "parallelism": "dp%d, gradient all-reduce once per step" % world},
+        "training_steps_per_s": args.steps / total_s, "items_per_s": B * args.steps / total_s,
+        "loss_first_last": [losses[0], losses[-1]],
+        "roofline": {"kernel": "MIOpen conv3d fwd/dgrad/wgrad (library)", "bound": "mfma", "achieved": flops * args.steps / total_s / 1e12,
+                     "peak": peak, "unit": "TFLOP/s", "frac": flops * args.steps / total_s / 1e12 / peak, "traffic": None}}))
+
+
 def precision_block(args, video, q_mod, t_mod, dev, modes):
     """Deviation of each encoder mode from fp32 nn.Module encoders ON THE SAME FRAMES (the north_star contract: scores
     within 1e-3, stitch indices identical), measured on the first `--precision-windows` windows of the bench video."""
@@ -299,6 +446,11 @@ def main():
     ap.add_argument("--frame-hw", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precision-block", action="store_true")
+    ap.add_argument("--no-nxn-legs", action="store_true")
+    ap.add_argument("--mode", default="synth", choices=["synth", "train"],
+                    help="synth: the synthesis hot path (headline); train: BASELINE config 5, contrastive training at size")
+    ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="--mode train: encoder autocast dtype")
+    ap.add_argument("--train-channels-last", action="store_true")
     ap.add_argument("--precision-windows", type=int, default=128)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 4],
                     help="HIP streams for the q / t encoders (4 also splits each clip batch in halves)")
@@ -314,6 +466,8 @@ def main():
     torch.cuda.set_device(dev)
     torch.backends.cudnn.benchmark = True  # MIOpen find mode, as the reference sets it (main.py:421)
     ops.device_check()
+    if args.mode == "train":
+        return train_bench(args, rank, world, dev)
     video, q_mod, t_mod = build_inputs(args, rank, dev)
     main_res = run_mode(args, args.precision, video, q_mod, t_mod, rank, world, dev)
     fast_res = None
@@ -348,6 +502,8 @@ def main():
     if world == 1 and not args.no_precision_block and args.encoder == "mfma":
         modes = [args.precision] + (["bf16"] if args.precision != "bf16" else [])
         out["precision"] = precision_block(args, video, q_mod, t_mod, dev, modes)
+    if world == 1 and not args.no_nxn_legs:
+        out["nxn_legs"] = nxn_legs(dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(video.cpu(), q_mod, t_mod, 20, 4, N, D, 0.1, args)
     print(json.dumps(out))

@@ -344,6 +344,20 @@ int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_h
 int avt_mean_positions_x3(const void* in_hi, const void* in_lo, int batch, int p, int c, int ldi,
                           float* out, int ldo, int plane_dtype, void* stream);
 
+/* ---- training input path on the device (config 5; dataset/dataset.py:121-253) ----------------------------------------
+ * avt_negative_sample_mt19937: the dataset's negative sampling (dataset.py:128-139, 181-190) from a DEVICE-resident
+ * MT19937 state, stream-for-stream what NumPy's legacy np.random.choice(others, n_negs, replace=False) draws, then the
+ * hard negatives idx-4..idx-1, idx+2..idx+5 (clipped to [0, len]) overwrite the head.  mt_state [625] uint32 = the 624
+ * key words + position of np.random.get_state(), advanced in place; idx [batch] int64 query segment ids; n_len =
+ * len(dataset) (train split); neg_out [batch, n_negs] int32.  Items are drawn in batch order.
+ * avt_clip_pack_gather_u8: avt_clip_pack_u8 organised by destination, window starts read from a DEVICE array (no host
+ * plan): slow [n_win,3,8,hw,hw], fast [n_win,3,32,hw,hw] in out_dtype. */
+int avt_negative_sample_mt19937(uint32_t* mt_state, const int64_t* idx, int batch, int n_len, int n_negs,
+                                int32_t* neg_out, void* stream);
+int avt_clip_pack_gather_u8(const uint8_t* frames, int n_frames, int height, int width,
+                            const int32_t* win_start, int n_win, int win_len, int out_hw, float mean,
+                            float std, int bgr, void* slow, void* fast, int out_dtype, void* stream);
+
 /* D1[i, j] = || x_i - x_j ||_2 of the classic video-texture baseline (baselines/classic_video_textures/
  * computeD1.py:47-96; BASELINE config 1): x [n, d] fp32 device rows (flattened frames), out [n, n] fp32.
  * fp64 accumulation in a fixed order, one sqrt, one rounding. */
