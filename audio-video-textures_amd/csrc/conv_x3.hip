@@ -267,11 +267,17 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
   a.nblk = tiles_m * a.tiles_n;
-  constexpr int lds_bytes = 2 * (BM + BN) * LSTR + kMaxTabSteps * 64;
+  // operand slabs + the tap table of THIS layer (not the 128-step maximum): the wide tile then needs 73.7 + <= 6 KB for
+  // every K loop of up to 96 steps, so two workgroups (2 waves per SIMD) share a CU's 160 KB
+  constexpr int lds_max = 2 * (BM + BN) * LSTR + kMaxTabSteps * 64;
+  const int tab_bytes = (a.nk <= kMaxTabSteps ? a.nk : 0) * 64;
+  int lds_bytes = 2 * (BM + BN) * LSTR + tab_bytes;
+  constexpr int epi_bytes = BM * (BN * 4 + 16);
+  if (lds_bytes < epi_bytes) lds_bytes = epi_bytes;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<BM, BN, WTM, F16>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
-    avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_max, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WTM, F16>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
