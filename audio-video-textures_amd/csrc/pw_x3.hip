@@ -1,0 +1,262 @@
+// pw_x3 — the pointwise (1x1x1, stride 1) layers of the SlowFast encoder in the contract-grade split-plane arithmetic
+// (see conv_x3.hip for the number format):  y = act( W x + b [+ r] )  on (hi, lo) plane pairs.
+//
+// Why a second x3 kernel: these layers — the bottlenecks' reducing / expanding convs (+ residual), 42 % of the x3
+// encoder's time on the general tile — are HBM-bound (bytes/row = 4 (K + N [+ N]), two planes each), and the general
+// tile serves them phase by phase (operands -> LDS -> MFMA -> fp32 staging -> residual -> stores, two barriers per tile,
+// 2 workgroups per CU) at 2.5-3.7 TB/s.  Here, as in the bf16 path's pw_chain.hip, a WAVE owns 16 positions from load to
+// store and nothing is staged: the input fragments (lane = position l & 15, k-group l >> 4: 16 contiguous bytes of a row)
+// are the MFMA B operand as loaded; the weights are the first operand, resident in LDS as MFMA fragments for the whole
+// launch (persistent workgroups), with their output rows permuted in the packing so that a lane ends up holding 8
+// CONSECUTIVE channels of its position — one 16-byte store per plane, one 16-byte load per plane of the residual; no
+// barrier in the position loop, 8 waves per CU keep ~20 KB of loads in flight each.
+// A workgroup holds the fragments of NT1 x 16 output channels (both planes: NT1 x K1S x 2 KB <= 128 KB); wider layers
+// are split into channel chunks handled by workgroups that are adjacent in the grid AND on one XCD (block b and b + 8
+// share an XCD), so the chunks' re-reads of the same input rows meet in that XCD's L2.
+// v_mfma_f32_16x16x32_{f16,bf16}: three passes per product, wl*xh + wh*xl + wh*xh, fp32 accumulate.
+#include <stdlib.h>
+
+#include "avt_common.h"
+#include "split_planes.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct PxArgs {
+  const uint16_t* xh;  // [M, ldx] input planes
+  const uint16_t* xl;
+  const uint16_t* rh;  // [M, ldr] residual planes or NULL
+  const uint16_t* rl;
+  uint16_t* yh;        // [M, ldy]
+  uint16_t* yl;
+  const i32x4* wh;     // [N/16][K1S][64 lanes] fragments (fused_slowfast.pack_pw_planes)
+  const i32x4* wl;
+  const float* bias;   // [N]
+  const float* wscale; // [N] or NULL
+  int M, ldx, ldr, ldy, k1c, ntiles, relu;
+  int n_chunks, n_rg;  // channel chunks per row group, row groups (grid = 8-aligned n_rg * n_chunks)
+};
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(i32x4 w, i32x4 x, f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+
+constexpr int PX_NW = 8;
+
+template <int K1S, int NT1, bool F16>
+__global__ __launch_bounds__(PX_NW * 64) void pw_x3_kernel(PxArgs a) {
+  constexpr int NC = NT1 * 16;  // output channels of this workgroup's chunk
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* whl = lds;                                   // [NT1][K1S] fragments of 1 KB
+  char* wll = whl + NT1 * K1S * 1024;
+  float* bl = reinterpret_cast<float*>(wll + NT1 * K1S * 1024);  // [NC] bias, [NC] scale
+  float* sl = bl + NC;
+
+  // block -> (row group, channel chunk): the chunks of one row group are consecutive blocks of ONE XCD
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int chunk = j % a.n_chunks;
+  const int rg = (j / a.n_chunks) * 8 + xcd;
+  if (rg >= a.n_rg) return;
+  const int c0 = chunk * NC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int f0 = chunk * NT1 * K1S;  // first fragment of the chunk
+  for (int f = wid; f < NT1 * K1S; f += PX_NW) {
+    *reinterpret_cast<i32x4*>(whl + f * 1024 + lane * 16) = a.wh[(f0 + f) * 64 + lane];
+    *reinterpret_cast<i32x4*>(wll + f * 1024 + lane * 16) = a.wl[(f0 + f) * 64 + lane];
+  }
+  for (int i = tid; i < NC; i += PX_NW * 64) {
+    bl[i] = a.bias ? a.bias[c0 + i] : 0.0f;
+    sl[i] = a.wscale ? a.wscale[c0 + i] : 1.0f;
+  }
+  __syncthreads();
+  const bool has_res = a.rh != nullptr;
+
+  for (int tile = rg * PX_NW + wid; tile < a.ntiles; tile += a.n_rg * PX_NW) {
+    const int p = tile * 16 + l15;
+    const bool ok = p < a.M;
+    int lofs = lane * 16;  // opaque per tile: keeps the loop-invariant fragment reads from being hoisted into registers
+    asm volatile("" : "+v"(lofs));
+    const int64_t pc = ok ? p : a.M - 1;
+    i32x4 xh[K1S], xl[K1S];
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks) {
+      int ch = 4 * ks + q;  // past the row's end the weights are zero: any finite value will do
+      ch = ch < a.k1c ? ch : a.k1c - 1;
+      xh[ks] = *reinterpret_cast<const i32x4*>(a.xh + pc * a.ldx + ch * 8);
+      xl[ks] = *reinterpret_cast<const i32x4*>(a.xl + pc * a.ldx + ch * 8);
+    }
+    uint4 rfh[NT1 / 2], rfl[NT1 / 2];
+    if (has_res) {
+#pragma unroll
+      for (int jj = 0; jj < NT1 / 2; ++jj) {
+        const int64_t o = pc * a.ldr + c0 + 32 * jj + 8 * q;
+        rfh[jj] = *reinterpret_cast<const uint4*>(a.rh + o);
+        rfl[jj] = *reinterpret_cast<const uint4*>(a.rl + o);
+      }
+    }
+    f32x4 acc[NT1];
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks) {
+#pragma unroll
+      for (int n = 0; n < NT1; ++n) {
+        const int f = n * K1S + ks;
+        const i32x4 wh = *reinterpret_cast<const i32x4*>(whl + f * 1024 + lofs);
+        const i32x4 wl = *reinterpret_cast<const i32x4*>(wll + f * 1024 + lofs);
+        acc[n] = mfma16<F16>(wl, xh[ks], acc[n]);
+        acc[n] = mfma16<F16>(wh, xl[ks], acc[n]);
+        acc[n] = mfma16<F16>(wh, xh[ks], acc[n]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < NT1 / 2; ++jj) {  // tiles 2jj, 2jj+1 -> channels c0 + 32 jj + 8 q .. + 7
+      const int cl = 32 * jj + 8 * q;
+      const float4 ba = *reinterpret_cast<const float4*>(bl + cl), bb = *reinterpret_cast<const float4*>(bl + cl + 4);
+      const float4 sa = *reinterpret_cast<const float4*>(sl + cl), sb = *reinterpret_cast<const float4*>(sl + cl + 4);
+      float v[8] = {acc[2 * jj][0] * sa.x + ba.x,     acc[2 * jj][1] * sa.y + ba.y,
+                    acc[2 * jj][2] * sa.z + ba.z,     acc[2 * jj][3] * sa.w + ba.w,
+                    acc[2 * jj + 1][0] * sb.x + bb.x, acc[2 * jj + 1][1] * sb.y + bb.y,
+                    acc[2 * jj + 1][2] * sb.z + bb.z, acc[2 * jj + 1][3] * sb.w + bb.w};
+      if (has_res) {
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(&rfh[jj]);
+        const uint32_t* pl = reinterpret_cast<const uint32_t*>(&rfl[jj]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const avt::f32x2 r = avt::join2<F16>(ph[e], pl[e]);
+          v[2 * e] += r.x;
+          v[2 * e + 1] += r.y;
+        }
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      uint4 oh, ol;
+      avt::split2<F16>(v[0], v[1], oh.x, ol.x);
+      avt::split2<F16>(v[2], v[3], oh.y, ol.y);
+      avt::split2<F16>(v[4], v[5], oh.z, ol.z);
+      avt::split2<F16>(v[6], v[7], oh.w, ol.w);
+      if (ok) {
+        const int64_t o = pc * a.ldy + c0 + cl;
+        *reinterpret_cast<uint4*>(a.yh + o) = oh;
+        *reinterpret_cast<uint4*>(a.yl + o) = ol;
+      }
+    }
+  }
+}
+
+// tiles per workgroup chunk for (K1S, N): the widest of 16 / 8 / 4 / 2 that divides N/16 and keeps both planes' fragments
+// within 128 KB of LDS; 0 = unsupported
+int pick_nt1(int k1s, int n) {
+  if (n % 32) return 0;
+  const int nt = n / 16;
+  for (int t : {16, 8, 4, 2})
+    if (nt % t == 0 && 2 * t * k1s <= 128) return t;
+  return 0;
+}
+
+template <int K1S, int NT1, bool F16>
+int launch_px(PxArgs& a, hipStream_t st) {
+  constexpr int lds_bytes = 2 * NT1 * K1S * 1024 + 2 * NT1 * 16 * 4;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_x3_kernel<K1S, NT1, F16>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_pw_x3: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  // persistent workgroups: as many as stay resident (LDS-limited), split into row groups x channel chunks
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 52 * 1024 ? 2 : 3);
+  int n_rg = (256 * per_cu) / a.n_chunks;
+  n_rg = n_rg < 8 ? 8 : (n_rg / 8) * 8;
+  const int max_rg = (a.ntiles + PX_NW - 1) / PX_NW;
+  if (n_rg > ((max_rg + 7) / 8) * 8) n_rg = ((max_rg + 7) / 8) * 8;
+  a.n_rg = n_rg;  // a multiple of 8: blocks of one XCD (b % 8) form whole row groups
+  hipLaunchKernelGGL((pw_x3_kernel<K1S, NT1, F16>), dim3((unsigned)(n_rg * a.n_chunks)), dim3(PX_NW * 64), lds_bytes, st, a);
+  return avt::check_launch("avt_pw_x3");
+}
+
+template <int K1S, bool F16>
+int dispatch_nt(PxArgs& a, int nt1, hipStream_t st) {
+  switch (nt1) {
+    case 16: if constexpr (K1S <= 4) return launch_px<K1S, 16, F16>(a, st); break;
+    case 8: if constexpr (K1S <= 8) return launch_px<K1S, 8, F16>(a, st); break;
+    case 4: return launch_px<K1S, 4, F16>(a, st);
+    case 2: return launch_px<K1S, 2, F16>(a, st);
+  }
+  avt::set_error("avt_pw_x3: no kernel for K steps %d, tiles %d", K1S, nt1);
+  return AVT_ERR_UNSUPPORTED;
+}
+
+template <bool F16>
+int dispatch_k(PxArgs& a, int k1s, int nt1, hipStream_t st) {
+  switch (k1s) {
+    case 1: return dispatch_nt<1, F16>(a, nt1, st);
+    case 2: return dispatch_nt<2, F16>(a, nt1, st);
+    case 3: return dispatch_nt<3, F16>(a, nt1, st);
+    case 4: return dispatch_nt<4, F16>(a, nt1, st);
+    case 8: return dispatch_nt<8, F16>(a, nt1, st);
+    case 10: return dispatch_nt<10, F16>(a, nt1, st);
+    case 16: return dispatch_nt<16, F16>(a, nt1, st);
+  }
+  avt::set_error("avt_pw_x3: unsupported K (%d steps of 32)", k1s);
+  return AVT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int avt_pw_x3_supported(int k, int n) {
+  const int k1s = (k + 31) / 32;
+  if (k % 8 || !(k1s == 1 || k1s == 2 || k1s == 3 || k1s == 4 || k1s == 8 || k1s == 10 || k1s == 16)) return 0;
+  const int nt1 = pick_nt1(k1s, n);
+  if (!nt1) return 0;
+  if ((nt1 == 16 && k1s > 4) || (nt1 == 8 && k1s > 8)) return 0;
+  return n / (16 * nt1) <= 8 ? 1 : 0;  // more than 8 channel chunks re-read the input too often: the general tile is better
+}
+
+extern "C" int avt_pw_x3(const void* x_hi, const void* x_lo, int ldx, int k, const void* w_hi, const void* w_lo, const float* bias,
+                         const float* wscale, const void* res_hi, const void* res_lo, int ldr, void* y_hi, void* y_lo, int ldy,
+                         int n, int64_t m, int relu, int plane_dtype, void* stream) {
+  AVT_REQUIRE(x_hi && x_lo && w_hi && w_lo && y_hi && y_lo && (!res_hi == !res_lo), "avt_pw_x3: NULL pointer / half a plane pair");
+  AVT_REQUIRE(avt_pw_x3_supported(k, n), "avt_pw_x3: unsupported layer K=%d N=%d", k, n);
+  AVT_REQUIRE(m > 0 && m < (1ll << 31) - 16 && ldx >= k && ldy >= n && ldx % 8 == 0 && ldy % 8 == 0 && (!res_hi || (ldr >= n && ldr % 8 == 0)),
+              "avt_pw_x3: bad sizes / leading dimensions");
+  AVT_REQUIRE(avt::aligned16(x_hi) && avt::aligned16(x_lo) && avt::aligned16(w_hi) && avt::aligned16(w_lo) && avt::aligned16(y_hi) &&
+                  avt::aligned16(y_lo) && (!res_hi || (avt::aligned16(res_hi) && avt::aligned16(res_lo))) &&
+                  (!bias || avt::aligned16(bias)) && (!wscale || avt::aligned16(wscale)),
+              "avt_pw_x3: pointers must be 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_pw_x3: bad plane_dtype");
+  const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  PxArgs a;
+  a.xh = static_cast<const uint16_t*>(x_hi);
+  a.xl = static_cast<const uint16_t*>(x_lo);
+  a.rh = static_cast<const uint16_t*>(res_hi);
+  a.rl = static_cast<const uint16_t*>(res_lo);
+  a.yh = static_cast<uint16_t*>(y_hi);
+  a.yl = static_cast<uint16_t*>(y_lo);
+  a.wh = static_cast<const i32x4*>(w_hi);
+  a.wl = static_cast<const i32x4*>(w_lo);
+  a.bias = bias;
+  a.wscale = wscale;
+  a.M = (int)m;
+  a.ldx = ldx;
+  a.ldr = ldr;
+  a.ldy = ldy;
+  a.k1c = k / 8;
+  a.ntiles = (int)((m + 15) / 16);
+  a.relu = relu;
+  a.n_chunks = n / (16 * nt1);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return plane_dtype == AVT_X3_F16 ? dispatch_k<true>(a, k1s, nt1, st) : dispatch_k<false>(a, k1s, nt1, st);
+}

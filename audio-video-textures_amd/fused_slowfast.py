@@ -32,6 +32,7 @@ _XB = int(os.environ.get("AVT_CONV_XB", "1"))                # long-K layers: fr
 _FUSE_SCAT = int(os.environ.get("AVT_FUSE_SCAT", "1"))      # slow res3-5 first blocks: strided shortcut folded into c's GEMM
 _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "0"))   # frames walked per workgroup (2 halo frames each); 0 = by width:
 #                                                              16 at 56 columns (more workgroups), the whole clip (32) below
+_PW_X3 = int(os.environ.get("AVT_PW_X3", "1"))               # contract-grade mode: pointwise layers on the streaming kernel
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 _STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "1"))  # max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both
 #                                                         (the MFMA-bound fast stem loses 4 % to the recomputed ninth row)
@@ -179,6 +180,11 @@ class FusedConv:
                 self.wscale = (1.0 / sc).float().contiguous().to(device)
             hi, lo = split_planes(wf, x3)
             self.wt, self.wt_lo = hi.to(device), lo.to(device)
+            # pointwise stride-1 layers: the streaming kernel (csrc/pw_x3.hip) with LDS-resident weight fragments
+            self.pw = None
+            if (_PW_X3 and self.kernel == (1, 1, 1) and self.stride == (1, 1, 1) and self.pad == (0, 0, 0) and
+                    not any(self.crop) and cout % 32 == 0 and ops.pw_x3_supported(self.cin, cout)):
+                self.pw = (pack_pw_planes(hi).to(device), pack_pw_planes(lo).to(device))
         else:
             self.wt = wt.to(torch.bfloat16).contiguous().to(device)
             if _XB and ops.conv3d_wfrag_supported(self.cin, cout, self.kernel):
@@ -199,6 +205,8 @@ class FusedConv:
         """The device kernel the dispatcher of csrc/conv_igemm.hip / conv_x3.hip picks for this layer (bench.py names its
         roofline rows by it; mirrors avt_conv3d_igemm_wfrag_bf16 / avt_conv3d_igemm_x3)."""
         if self.x3 is not None:
+            if getattr(self, "pw", None) is not None:
+                return "pw_x3_kernel<%s>" % ("f16" if self.x3 == ops.X3_F16 else "bf16")
             tile = "128,32,32" if self.cout <= 32 else ("128,64,64" if self.cout <= 64 else "128,128,64")
             return "conv_x3_kernel<%s,%s>" % (tile, "f16" if self.x3 == ops.X3_F16 else "bf16")
         if self.wfrag is not None:
@@ -268,9 +276,15 @@ class FusedConv:
                                 res.ld if res is not None else 0, self.relu if relu is None else relu, self.x3,
                                 wscale=self.wscale, out_dims=od[1:] if any(self.crop) else (0, 0, 0), out_rows=out_rows)
 
+        def launch_pw():
+            m_rows = x.dims[0] * x.dims[1] * x.dims[2] * x.dims[3]
+            ops.pw_x3(x.ptrs, x.ld, self.cin, self.pw[0], self.pw[1], self.bias, self.wscale,
+                      res.ptrs if res is not None else None, res.ld if res is not None else 0, out.ptrs, out.ld, self.cout,
+                      m_rows, self.relu if relu is None else relu, self.x3)
+
         def launch():
             if self.x3 is not None:
-                return launch_x3()
+                return launch_pw() if (self.pw is not None and out_rows is None) else launch_x3()
             ops.conv3d_igemm(x.ptr, self.wt, self.bias, res.ptr if res is not None else 0, out.ptr, tab, x.dims,
                              self.cin, self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld,
                              res.ld if res is not None else 0, self.relu if relu is None else relu,
@@ -329,6 +343,24 @@ def stem_conv(stem, device, tgroup=1, x3=None):
     conv.alg_flops_per_row = 2.0 * (kt * kh * kw * 3) * c
     conv.wt_lds = stem_lds_image(conv.wt, kt) if conv.cout % 32 == 0 and x3 is None else None
     return conv
+
+
+def pack_pw_planes(plane):
+    """A split-plane weight plane [N, K] (16-bit raw, typed bfloat16) -> csrc/pw_x3.hip's fragments [N/16][ceil(K/32)][64][8]
+    (pack_pw's order: output rows permuted so a lane ends with 8 consecutive channels; K zero-padded to whole k-steps)."""
+    raw = plane.detach().cpu().view(torch.int16)
+    n_out, k = raw.shape
+    ks = -(-k // 32)
+    wp = torch.zeros((n_out, ks * 32), dtype=torch.int16)
+    wp[:, :k] = raw
+    lane = torch.arange(64)
+    n, q = lane & 15, lane >> 4
+    e = torch.arange(8)
+    shape = (n_out // 16, ks, 64, 8)
+    nt = torch.arange(n_out // 16).view(-1, 1, 1, 1)
+    row = (32 * (nt // 2) + 8 * (n >> 2).view(1, 1, -1, 1) + 4 * (nt % 2) + (n & 3).view(1, 1, -1, 1)).expand(shape)
+    col = (torch.arange(ks).view(1, -1, 1, 1) * 32 + q.view(1, 1, -1, 1) * 8 + e.view(1, 1, 1, -1)).expand(shape)
+    return wp[row, col].contiguous().view(torch.bfloat16)
 
 
 def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):

@@ -320,6 +320,21 @@ def conv3d_igemm_x3(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, 
                                               int(plane_dtype), _p(wscale), _stream()), "avt_conv3d_igemm_x3")
 
 
+def pw_x3_supported(k, n):
+    return bool(_lib.lib().avt_pw_x3_supported(int(k), int(n)))
+
+
+def pw_x3(x_ptrs, ldx, k, w_hi, w_lo, bias, wscale, res_ptrs, ldr, y_ptrs, ldy, n, m, relu, plane_dtype):
+    """Streaming pointwise layer on plane pairs (csrc/pw_x3.hip); w_hi / w_lo = fused_slowfast.pack_pw_planes(...)."""
+    _dev(w_hi, "w_hi", torch.bfloat16)
+    _dev(w_lo, "w_lo", torch.bfloat16)
+    rh, rl = res_ptrs if res_ptrs is not None else (0, 0)
+    _lib.check(_lib.lib().avt_pw_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), int(ldx), int(k), _p(w_hi), _p(w_lo),
+                                    _p(bias), _p(wscale), C.c_void_p(rh) if rh else None, C.c_void_p(rl) if rl else None,
+                                    int(ldr), C.c_void_p(y_ptrs[0]), C.c_void_p(y_ptrs[1]), int(ldy), int(n), int(m),
+                                    1 if relu else 0, int(plane_dtype), _stream()), "avt_pw_x3")
+
+
 def maxpool_hw3s2_x3(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1):
     _lib.check(_lib.lib().avt_maxpool_hw3s2_ndhwc_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), C.c_void_p(out_ptrs[0]),
                                                      C.c_void_p(out_ptrs[1]), int(bt), int(h), int(w), int(c), int(ldi),

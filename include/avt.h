@@ -333,6 +333,16 @@ int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi,
                         int to, int ho, int wo, int ldi, int ldo, int ldr, int relu,
                         int out_row_stride, int out_h, int out_w, int plane_dtype, const float* wscale,
                         void* stream);
+/* Pointwise (1x1x1, stride 1) layers in the same arithmetic, streaming form (csrc/pw_x3.hip): a wave owns 16 rows from
+ * load to store, weights are LDS-resident MFMA fragments of persistent workgroups.  y = act(W x + b [+ res]) on plane pairs;
+ * x [m, ldx] (k valid channels), y / res [m, ldy / ldr] (n channels); w_hi / w_lo = fragments [n/16][ceil(k/32)][64 lanes][8]
+ * with output rows permuted so a lane ends with 8 consecutive channels: tile nt, row r -> channel
+ * 32*(nt/2) + 8*(r/4) + 4*(nt%2) + r%4, k = 32*ks + 8*(lane>>4) + e, zero beyond k (fused_slowfast.pack_pw_planes).
+ * avt_pw_x3_supported(k, n): k in 32-steps {1,2,3,4,8,10,16}, n % 32 == 0, at most 8 channel chunks. */
+int avt_pw_x3_supported(int k, int n);
+int avt_pw_x3(const void* x_hi, const void* x_lo, int ldx, int k, const void* w_hi, const void* w_lo,
+              const float* bias, const float* wscale, const void* res_hi, const void* res_lo, int ldr,
+              void* y_hi, void* y_lo, int ldy, int n, int64_t m, int relu, int plane_dtype, void* stream);
 /* avt_clip_pack_u8_ndhwc4 writing (hi, lo) planes: slow_* [n,8,hw,hw,4], fast_* [n,32,hw,hw,4]. */
 int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, int width,
                                const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw,

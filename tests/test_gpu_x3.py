@@ -33,7 +33,16 @@ def _planes(x, pd, dev):
     (8, 16, (7, 1, 1), (4, 1, 1), (3, 0, 0), (2, 32, 6, 6), False),       # lateral fusion conv, Cout <= 32 tile
     (24, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 5, 6, 7), True),        # 27 taps, K tail
     (1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 4, 5, 5), True),     # long K (table in global memory above 128 steps: no)
-    (512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 7, 7), True),
+    (512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 7, 7), True),      # 32 channel chunks: stays on the general tile
+    # pointwise layers on the streaming kernel (csrc/pw_x3.hip): every (K steps, chunk width) form the encoder uses
+    (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 3, 9, 11), True),       # res2 c + residual: K1S 2, one chunk of 16 tiles
+    (128, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 7, 9), True),       # res3 c: two chunks
+    (256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 7, 7), True),      # res4 c: eight chunks of 8 tiles
+    (256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 10, 9), False),      # res2 a: K1S 8
+    (320, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 3, 9, 9), False),      # res3 first a (after fusion): K1S 10
+    (512, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 9, 9), False),      # K1S 16
+    (32, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 6, 10), True),       # fast pathway (pixel-grouped): K1S 1
+    (80, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 3, 7, 9), False),       # shortcut conv after the first fusion: K 80 -> 96
 ])
 def test_conv_x3_matches_fp32(avt, dev, mode, cin, cout, k, s, p, dims, with_res):
     from avtex.fused_slowfast import Act, FusedConv
@@ -111,6 +120,36 @@ def test_pool_mean_pack_x3(avt, dev, mode):
         assert (j[..., 3] == 0).all()
         d = (j[..., :3].permute(0, 4, 1, 2, 3) - ref32).abs().max().item()
         assert d < (1e-5 if pd == 0 else 1e-6) * 3
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_pw_x3_slices_and_agreement_with_general_tile(avt, dev, mode):
+    """The streaming pointwise kernel reads and writes channel slices of wider row buffers (the lateral-fusion concat) and
+    leaves their neighbours alone; its result agrees with the general x3 tile's to the last few bits of fp32."""
+    import avtex.fused_slowfast as fsf
+
+    pd = X3[mode]
+    torch.manual_seed(4)
+    conv = nn.Conv3d(80, 64, (1, 1, 1), bias=False)
+    dims, m = (2, 3, 7, 5), 2 * 3 * 7 * 5
+    x = torch.randn(m, 96)
+    xh, xl = _planes(x, pd, dev)
+    outs = []
+    for flag in (1, 0):
+        keep, fsf._PW_X3 = fsf._PW_X3, flag
+        fc = fsf.FusedConv(conv, None, True, dev, x3=pd)
+        fsf._PW_X3 = keep
+        assert (fc.pw is not None) == bool(flag)
+        wide = fsf.new_act(m, 160, dims, dev, True)
+        wide.buf.fill_(3.0)
+        wide.lo.fill_(3.0)
+        fc(fsf.Act(xh, dims, 8, 80, lo=xl), out=fsf.Act(wide.buf, dims, 32, 64, lo=wide.lo))
+        torch.cuda.synchronize()
+        assert (wide.buf[:, :32] == 3).all() and (wide.buf[:, 96:] == 3).all() and (wide.lo[:, :32] == 3).all()
+        outs.append(fsf.Act(wide.buf, dims, 32, 64, lo=wide.lo).float(pd).cpu())
+    ref = torch.relu(x[:, 8:88].double() @ conv.weight.detach().view(64, 80).double().t())
+    assert (outs[0].double() - ref).abs().max() < TOL[mode] * max(ref.abs().max().item(), 1.0)
+    assert (outs[0] - outs[1]).abs().max() < 2 * TOL[mode] * max(ref.abs().max().item(), 1.0)
 
 
 def _calibrated_pair(dev, n, hw_src=128):

@@ -51,7 +51,16 @@ def hook(name, launch, flops, nbytes):
     recs.append((a, e, flops, nbytes, name))
 
 
+orig_pw = ops.pw_x3
+
+
+def spy_pw(x_ptrs, ldx, k, w_hi, w_lo, bias, wscale, res_ptrs, ldr, y_ptrs, ldy, n, m_, relu, plane_dtype):
+    shapes.append("pointwise cin%d cout%d rows %d%s" % (k, n, m_, " +res" if res_ptrs else ""))
+    return orig_pw(x_ptrs, ldx, k, w_hi, w_lo, bias, wscale, res_ptrs, ldr, y_ptrs, ldy, n, m_, relu, plane_dtype)
+
+
 ops.conv3d_igemm_x3 = spy
+ops.pw_x3 = spy_pw
 fsf.PROFILER = hook
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -62,7 +71,7 @@ tot = e0.elapsed_time(e1)
 agg = collections.OrderedDict()
 for (a, e, fl, byt, sym), name in zip(recs, shapes):
     t = a.elapsed_time(e)
-    d = agg.setdefault(name + "  " + sym.split("<")[1].split(",f")[0].split(",b")[0], [0, 0.0, 0.0, 0.0])
+    d = agg.setdefault(name + "  " + sym.split(",f16")[0].split(",bf16")[0].replace("conv_x3_kernel", "tile").replace("<f16>", "").replace("<bf16>", ""), [0, 0.0, 0.0, 0.0])
     d[0] += 1
     d[1] += t
     d[2] += fl
