@@ -302,7 +302,8 @@ def nxn_legs(dev, reps=5):
                 leg["select_th%.1f_mean_survivors" % th_] = float(sel["cnt"].float().mean())
             ms_top, (ti, tv) = timed(lambda: ops.row_topk(sim, 8, self_col=q_ids))
             leg["topk8_ms"], leg["topk8_GBps"] = ms_top, nq * nt * 4.0 / (ms_top * 1e-3) / 1e9
-            leg["argmax_is_next_segment"] = float((ti[:, 0].long() == (q_ids + 1) % nt).float().mean())
+            # T[j] = Q[j + 1] + noise, so row i's best target is j = i - 1 (the planted "positive")
+            leg["argmax_is_planted_positive"] = float((ti[:, 0].long() == (q_ids - 1) % nt).float().mean())
             leg["build_ms_th0.0"] = leg["l2norm_ms"] + ms_sim + leg["select_th0.0_ms"]
             legs.append(leg)
             del sim

@@ -12,7 +12,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/convpmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "conv_igemm" in row["Kernel_Name"] or "conv_xl" in row["Kernel_Name"] or "conv_xb" in row["Kernel_Name"] or "stem_kernel" in row["Kernel_Name"]:
+        if any(k in row["Kernel_Name"] for k in ("conv_igemm", "conv_xl", "conv_xb", "stem_kernel", "conv_x3", "pw_x3")):
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print("%-28s mean %.4g (n=%d)" % (k, sum(v) / len(v), len(v)))
