@@ -20,6 +20,10 @@
 // LDS per workgroup 2 x (BM + BN) x 144 B (two planes per operand) + the tap table: 82 / 63 / 54 KB.  Per K-step a wave
 // of the wide tile reads 8 fragments per 16-wide k-slice for 12 MFMAs (the bf16 tile: 4 for 4), so this form is much
 // closer to MFMA-bound than the bf16 one.  Roofline: MFMA at 1/3 of the bf16 peak (833 TFLOP/s algorithmic).
+// Measured and not kept (profiles/r02/probe_x3_wide_pipelined_tile_slower.log): a software-pipelined form of the wide
+// tile — 32-wide steps in two swizzled LDS buffers, ds_writes of step kt+1 under the MFMAs of step kt, one barrier per
+// step — was correct but 10 % SLOWER on every long-K layer (296 vs 328 TFLOP/s): twice the barriers and the fragment-read
+// latency at every step start cost more than the store phase it removed (the second workgroup of the CU already hides it).
 #include <stdlib.h>
 
 #include "avt_common.h"
@@ -107,33 +111,56 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  auto compute = [&]() {
+  // Fragments are double-buffered in registers: the eight ds_read_b128 of k-slice ks + 1 are issued BEFORE the twelve
+  // MFMAs of slice ks, so the matrix pipe never waits on an LDS round trip inside a K-step (with one register set the
+  // compiler re-used 24 registers and parked an s_waitcnt lgkmcnt(0) in front of every other MFMA group: the pipe idled
+  // ~half of each slice, profiles/r02/conv_x3_pmc_1024_256.log).
+  struct Frags {
+    i32x4 ah[MT], al[MT], wh[NT], wl[NT];
+  };
+  auto fload = [&](Frags& f, int ks) {
+    const int koff = ks * 32 + lh * 16;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      i32x4 ah[MT], al[MT], wh[NT], wl[NT];
-      const int koff = ks * 32 + lh * 16;
+    for (int j = 0; j < MT; ++j) {
+      const int o = (wm * WTM + j * 32 + lr) * LSTR + koff;
+      f.ah[j] = *reinterpret_cast<const i32x4*>(lds + o);
+      f.al[j] = *reinterpret_cast<const i32x4*>(lds + A_LO + o);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int o = (wn * WN + i * 32 + lr) * LSTR + koff;
+      f.wh[i] = *reinterpret_cast<const i32x4*>(lds + B_HI + o);
+      f.wl[i] = *reinterpret_cast<const i32x4*>(lds + B_LO + o);
+    }
+  };
+  auto fmul = [&](const Frags& f) {
+    // small terms first, the leading product last: D[n][m] += wl*ah + wh*al + wh*ah
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
-        const int o = (wm * WTM + j * 32 + lr) * LSTR + koff;
-        ah[j] = *reinterpret_cast<const i32x4*>(lds + o);
-        al[j] = *reinterpret_cast<const i32x4*>(lds + A_LO + o);
+        acc[i][j] = mfma<F16>(f.wl[i], f.ah[j], acc[i][j]);
+        acc[i][j] = mfma<F16>(f.wh[i], f.al[j], acc[i][j]);
+        acc[i][j] = mfma<F16>(f.wh[i], f.ah[j], acc[i][j]);
       }
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int o = (wn * WN + i * 32 + lr) * LSTR + koff;
-        wh[i] = *reinterpret_cast<const i32x4*>(lds + B_HI + o);
-        wl[i] = *reinterpret_cast<const i32x4*>(lds + B_LO + o);
-      }
-      // small terms first, the leading product last: D[n][m] += wl*ah + wh*al + wh*ah
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          acc[i][j] = mfma<F16>(wl[i], ah[j], acc[i][j]);
-          acc[i][j] = mfma<F16>(wh[i], al[j], acc[i][j]);
-          acc[i][j] = mfma<F16>(wh[i], ah[j], acc[i][j]);
-        }
-    }
+  };
+  auto compute = [&]() {
+    // (sched_barrier: without it the machine scheduler sinks every read back to just before its first use)
+    Frags f0, f1;
+    fload(f0, 0);
+    fload(f1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fmul(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    fload(f0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    fmul(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    fload(f1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    fmul(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    fmul(f1);
   };
 
   const __amdgpu_buffer_rsrc_t rih = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
