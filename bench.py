@@ -534,10 +534,17 @@ def attach_pmc_traffic(kern, args, precision):
         return
     pmc = json.load(open(PMC_SUMMARY))
 
-    def kb(prefix):
+    def kb(sym):
+        """sym: a device kernel symbol as bench names it; template tails are open ("conv_igemm_kernel<256,32,64" matches
+        "...<256, 32, 64, true>"), and "pw_x3_kernel<f16>" means every pw_x3_kernel<K, NT, true>."""
+        want_tail = None
+        if sym.startswith("pw_x3_kernel<"):
+            want_tail, sym = ("true>" if "f16" in sym and "bf16" not in sym else "false>"), "pw_x3_kernel<"
+        sym = sym.rstrip(">")
         f = w = n = 0.0
         for name, v in pmc.items():
-            if name.startswith("_") or prefix not in name.replace(" ", ""):
+            flat = name.replace(" ", "")
+            if name.startswith("_") or sym not in flat or (want_tail and want_tail + "(" not in flat):
                 continue
             f += v.get("FETCH_SIZE", {}).get("total", 0.0)
             w += v.get("WRITE_SIZE", {}).get("total", 0.0)

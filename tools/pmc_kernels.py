@@ -20,9 +20,11 @@ q_ids = torch.arange(N, device=dev, dtype=torch.int64)
 for _ in range(3):
     ops.clip_pack(video, starts, W, out_hw=224, dtype=torch.bfloat16, layout="ndhwc4")
     ops.clip_pack(video, starts, W, out_hw=224, dtype=torch.bfloat16, layout="ncthw")
-    qn, qh, ql = ops.l2norm_rows(q, want_split=True)
-    tn, th, tl = ops.l2norm_rows(t, want_split=True)
+    qn, _, _ = ops.l2norm_rows(q)  # (as bench.py's default f32 similarity mode calls it: fp32 rows only)
+    tn, _, _ = ops.l2norm_rows(t)
     sim = ops.sim_gemm_nt(qn, tn, 0.1, "f32")
+    _, qh, ql = ops.l2norm_rows(q, want_f32=False, want_split=True)
+    _, th, tl = ops.l2norm_rows(t, want_f32=False, want_split=True)
     ops.sim_gemm_nt(qh, th, 0.1, "bf16x3", q_lo=ql, t_lo=tl)
     ops.sim_gemm_nt(qh, th, 0.1, "bf16")
     ops.row_transition(sim, q_ids=q_ids, threshold=0.3, cap=64)
