@@ -25,13 +25,25 @@
 #include <stdlib.h>
 
 #include "avt_common.h"
+#include "split_planes.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr unsigned kOob = 0xFFFFFFF0u;
+
+// PL = 0: bf16 (one plane per tensor).  PL = 1 / 2: the contract-grade split-plane arithmetic (conv_x3.hip) with bf16 /
+// fp16 planes: the patch and the weight slab are staged for both planes and every product is three MFMAs.
+template <int PL>
+__device__ __forceinline__ f32x4 mfma16(i32x4 w, i32x4 x, f32x4 c) {
+  if constexpr (PL == 2)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
 
 struct StemArgs {
   const uint16_t* in;
@@ -48,6 +60,11 @@ struct StemArgs {
   int tgroup, ldo;
   int ncg;  // 32-channel groups
   int swz;  // XCD-aware work order (AVT_STEM_SWZ, default 1)
+  // split-plane form (PL > 0): the low-order planes, same geometry, and the fp16 planes' per-channel weight scale
+  const uint16_t* in_lo;
+  const uint16_t* wt_lo;
+  uint16_t* out_lo;
+  const float* wscale;
 };
 
 constexpr int RB = 4;   // conv rows a workgroup owns in the plain form (pooled: RBP = 8, plus one recomputed row above them)
@@ -68,8 +85,9 @@ __device__ __forceinline__ uint32_t max2(uint32_t x, uint32_t y) {  // packed bf
 // Work split: the R x MT (conv row, 16-position tile) units are dealt out evenly to the waves (plain: 4 rows x 7 tiles
 // on 4 waves = one row each; pooled: 9 x 7 = 63 units on 8 waves) — the kernel is MFMA-bound, and one wave per row
 // with 5 or 9 rows leaves one SIMD with twice the work of the others (measured 2.4x slower than stem + pool).
-template <int MT, bool POOL>
-__global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(StemArgs a) {
+template <int MT, bool POOL, int PL = 0>
+__global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void stem_kernel(StemArgs a) {
+  static_assert(!(POOL && PL), "the pooled form is bf16 only (the split-plane mode pools with maxpool_hw3s2_ndhwc_x3)");
   constexpr int R = POOL ? RBP + 1 : RB;  // conv rows computed
   constexpr int OWN = POOL ? RBP : RB;    // conv rows owned
   constexpr int NWV = POOL ? 8 : 4;
@@ -84,6 +102,8 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* lp = lds;             // patch [PROWS][PWP] x 16 B
   char* lb = lds + PCH * 16;  // weights [7 dh][NT][4 dp][16 rows] x 16 B
+  char* lpl = lb + BCH * 16;  // (PL) the low-order planes of both
+  char* lbl = lpl + PCH * 16;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = POOL ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;  // pooled: the unit offsets below stay in SGPRs
@@ -106,6 +126,8 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rinl = __builtin_amdgcn_make_buffer_rsrc((void*)(PL ? a.in_lo : a.in), 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwtl = __builtin_amdgcn_make_buffer_rsrc((void*)(PL ? a.wt_lo : a.wt), 0, a.wt_bytes, 0x00020000);
 
   // per-thread patch chunks: byte offset inside a frame, or out of bounds (padding rows / pairs)
   unsigned poff[PU];
@@ -145,30 +167,40 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
   const int dt_lo = t0 < 0 ? -t0 : 0;
   const int dt_hi = (a.T - t0) < a.KT ? (a.T - t0) : a.KT;
 
-  i32x4 rp[PU], rb[BU];
+  constexpr int NPL = PL ? 2 : 1;
+  i32x4 rp[NPL][PU], rb[NPL][BU];
   auto gload = [&](int dt) {
     const unsigned fbase = (unsigned)(((b * a.T + t0 + dt) * a.H) * a.PW) * 16u;
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
       const unsigned off = poff[u] == kOob ? kOob : fbase + poff[u];
-      rp[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0);
+      rp[0][u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0);
+      if constexpr (PL != 0) rp[1][u] = __builtin_amdgcn_raw_buffer_load_b128(rinl, (int)off, 0, 0);
     }
     const unsigned kb = gbase + (unsigned)dt * (unsigned)(BCH * 16);
 #pragma unroll
     for (int u = 0; u < BU; ++u) {
       const int e = tid + NTHR * u;
-      rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rwt, (int)(e < BCH ? kb + (unsigned)e * 16u : kOob), 0, 0);
+      const int off = (int)(e < BCH ? kb + (unsigned)e * 16u : kOob);
+      rb[0][u] = __builtin_amdgcn_raw_buffer_load_b128(rwt, off, 0, 0);
+      if constexpr (PL != 0) rb[1][u] = __builtin_amdgcn_raw_buffer_load_b128(rwtl, off, 0, 0);
     }
   };
   auto lstore = [&]() {
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
       const int c = tid + NTHR * u;
-      if (c < PCH) *reinterpret_cast<i32x4*>(lp + c * 16) = rp[u];
+      if (c < PCH) {
+        *reinterpret_cast<i32x4*>(lp + c * 16) = rp[0][u];
+        if constexpr (PL != 0) *reinterpret_cast<i32x4*>(lpl + c * 16) = rp[1][u];
+      }
     }
 #pragma unroll
     for (int u = 0; u < BU; ++u)
-      if (tid + NTHR * u < BCH) *reinterpret_cast<i32x4*>(lb + (tid + NTHR * u) * 16) = rb[u];
+      if (tid + NTHR * u < BCH) {
+        *reinterpret_cast<i32x4*>(lb + (tid + NTHR * u) * 16) = rb[0][u];
+        if constexpr (PL != 0) *reinterpret_cast<i32x4*>(lbl + (tid + NTHR * u) * 16) = rb[1][u];
+      }
   };
 
   // plain: the next frame's patch is fetched into registers under this frame's MFMAs.  pooled: no register prefetch
@@ -182,18 +214,30 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
     if (!POOL && dt + 1 < dt_hi) gload(dt + 1);  // in flight under this frame's MFMAs
 #pragma unroll
     for (int dh = 0; dh < 7; ++dh) {
-      bf16x8 bf[NT];
+      i32x4 bf[NT], bfl[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        bf[n] = *reinterpret_cast<const bf16x8*>(lb + (((dh * NT + n) * 4 + q) * 16 + l15) * 16);
-      const char* prow = lp + ((2 * w + dh) * PWP + l15 + q) * 16;  // plain: unit i = tile i of row w
+      for (int n = 0; n < NT; ++n) {
+        const int o = (((dh * NT + n) * 4 + q) * 16 + l15) * 16;
+        bf[n] = *reinterpret_cast<const i32x4*>(lb + o);
+        if constexpr (PL != 0) bfl[n] = *reinterpret_cast<const i32x4*>(lbl + o);
+      }
+      const int prow = ((2 * w + dh) * PWP + l15 + q) * 16;  // plain: unit i = tile i of row w
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
-        const bf16x8 af = POOL ? *reinterpret_cast<const bf16x8*>(lp + lane_off + ubase[i] + dh * (PWP * 16))
-                               : *reinterpret_cast<const bf16x8*>(prow + i * 256);
+        const int o = POOL ? lane_off + ubase[i] + dh * (PWP * 16) : prow + i * 256;
+        const i32x4 af = *reinterpret_cast<const i32x4*>(lp + o);
+        if constexpr (PL != 0) {
+          const i32x4 afl = *reinterpret_cast<const i32x4*>(lpl + o);
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[n], af, acc[i][n], 0, 0, 0);  // D[channel][position]
+          for (int n = 0; n < NT; ++n) {  // small terms first: wl*ah + wh*al + wh*ah
+            acc[i][n] = mfma16<PL>(bfl[n], af, acc[i][n]);
+            acc[i][n] = mfma16<PL>(bf[n], afl, acc[i][n]);
+            acc[i][n] = mfma16<PL>(bf[n], af, acc[i][n]);
+          }
+        } else {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[i][n] = mfma16<0>(bf[n], af, acc[i][n]);  // D[channel][position]
+        }
       }
     }
     __syncthreads();
@@ -206,13 +250,22 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
     b0 = *reinterpret_cast<const float4*>(a.bias + c0);
     b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
   }
-  auto packed = [&](int m) {
-    float v[8] = {acc[m][0][0] + b0.x, acc[m][0][1] + b0.y, acc[m][0][2] + b0.z, acc[m][0][3] + b0.w,
-                  acc[m][1][0] + b1.x, acc[m][1][1] + b1.y, acc[m][1][2] + b1.z, acc[m][1][3] + b1.w};
+  float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
+  if (PL != 0 && a.wscale && c0 < a.Cout) {
+    s0 = *reinterpret_cast<const float4*>(a.wscale + c0);
+    s1 = *reinterpret_cast<const float4*>(a.wscale + c0 + 4);
+  }
+  auto values = [&](int m, float* v) {
+    v[0] = acc[m][0][0] * s0.x + b0.x; v[1] = acc[m][0][1] * s0.y + b0.y; v[2] = acc[m][0][2] * s0.z + b0.z; v[3] = acc[m][0][3] * s0.w + b0.w;
+    v[4] = acc[m][1][0] * s1.x + b1.x; v[5] = acc[m][1][1] * s1.y + b1.y; v[6] = acc[m][1][2] * s1.z + b1.z; v[7] = acc[m][1][3] * s1.w + b1.w;
     if (a.relu) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     }
+  };
+  auto packed = [&](int m) {
+    float v[8];
+    values(m, v);
     uint4 pk;
     pk.x = avt::pack_bf16x2(v[0], v[1]);
     pk.y = avt::pack_bf16x2(v[2], v[3]);
@@ -224,8 +277,22 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
     if (c0 < a.Cout) {
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
-        uint16_t* orow = a.out + ((int64_t)((b * a.To + to) * a.Ho + ho0 + unit_row(i)) * WO) * a.Cout + c0;
-        if (w * TPW + i < R * MT) *reinterpret_cast<uint4*>(orow + (int64_t)(unit_mt(i) * 16 + l15) * a.Cout) = packed(i);
+        const int64_t o = ((int64_t)((b * a.To + to) * a.Ho + ho0 + unit_row(i)) * WO + unit_mt(i) * 16 + l15) * a.Cout + c0;
+        if (w * TPW + i < R * MT) {
+          if constexpr (PL != 0) {
+            float v[8];
+            values(i, v);
+            uint4 oh, ol;
+            avt::split2<PL == 2>(v[0], v[1], oh.x, ol.x);
+            avt::split2<PL == 2>(v[2], v[3], oh.y, ol.y);
+            avt::split2<PL == 2>(v[4], v[5], oh.z, ol.z);
+            avt::split2<PL == 2>(v[6], v[7], oh.w, ol.w);
+            *reinterpret_cast<uint4*>(a.out + o) = oh;
+            *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
+          } else {
+            *reinterpret_cast<uint4*>(a.out + o) = packed(i);
+          }
+        }
       }
     }
   } else {
@@ -265,12 +332,12 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : 3) void stem_kernel(St
   }
 }
 
-template <int MT, bool POOL>
+template <int MT, bool POOL, int PL = 0>
 int launch(const StemArgs& a, int batch, hipStream_t st, const char* what) {
   constexpr int R = POOL ? RBP + 1 : RB;
-  constexpr int patch = ((2 * R + 5) * (MT * 16 + 4) + BCH) * 16, tile = POOL ? R * MT * 16 * 64 : 0;
+  constexpr int patch = ((2 * R + 5) * (MT * 16 + 4) + BCH) * 16 * (PL ? 2 : 1), tile = POOL ? R * MT * 16 * 64 : 0;
   constexpr int lds_bytes = patch > tile ? patch : tile;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_kernel<MT, POOL>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_kernel<MT, POOL, PL>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, lds_bytes, hipGetErrorString(e));
@@ -284,7 +351,7 @@ int launch(const StemArgs& a, int batch, hipStream_t st, const char* what) {
   }();
   b.swz = swz;
   const dim3 grid((unsigned)(batch * a.To * (a.Ho / (POOL ? RBP : RB)) * b.ncg));
-  hipLaunchKernelGGL((stem_kernel<MT, POOL>), grid, dim3(POOL ? 512 : 256), lds_bytes, st, b);
+  hipLaunchKernelGGL((stem_kernel<MT, POOL, PL>), grid, dim3(POOL ? 512 : 256), lds_bytes, st, b);
   return avt::check_launch(what);
 }
 
@@ -313,6 +380,9 @@ int fill(StemArgs& a, const char* what, const void* in, const void* wt, const fl
   a.relu = relu;
   a.tgroup = 1;
   a.ldo = cout;
+  a.in_lo = a.wt_lo = nullptr;
+  a.out_lo = nullptr;
+  a.wscale = nullptr;
   AVT_REQUIRE(a.To > 0, "%s: no output frames", what);
   const int64_t in_b = (int64_t)batch * t * h * pw * 16, wt_b = (int64_t)cout * kt * KF * 2;
   AVT_REQUIRE(in_b < (1ll << 32) - 64 && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
@@ -351,4 +421,24 @@ extern "C" int avt_stem_conv_pool_bf16(const void* in, const void* wt, const flo
   hipStream_t s = static_cast<hipStream_t>(stream);
   return pw == 112 ? launch<7, true>(a, batch, s, "avt_stem_conv_pool_bf16")
                    : launch<2, true>(a, batch, s, "avt_stem_conv_pool_bf16");
+}
+
+extern "C" int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
+                                const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout, int kt,
+                                int st, int pt, int relu, int plane_dtype, void* stream) {
+  StemArgs a;
+  const int rc = fill(a, "avt_stem_conv_x3", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu);
+  if (rc) return rc;
+  AVT_REQUIRE(in_lo && wt_lo && out_lo && avt::aligned16(in_lo) && avt::aligned16(wt_lo) && avt::aligned16(out_lo) &&
+                  (!wscale || avt::aligned16(wscale)),
+              "avt_stem_conv_x3: every tensor needs both planes, 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_stem_conv_x3: bad plane_dtype");
+  a.in_lo = static_cast<const uint16_t*>(in_lo);
+  a.wt_lo = static_cast<const uint16_t*>(wt_lo);
+  a.out_lo = static_cast<uint16_t*>(out_lo);
+  a.wscale = wscale;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plane_dtype == AVT_X3_F16)
+    return pw == 112 ? launch<7, false, 2>(a, batch, s, "avt_stem_conv_x3") : launch<2, false, 2>(a, batch, s, "avt_stem_conv_x3");
+  return pw == 112 ? launch<7, false, 1>(a, batch, s, "avt_stem_conv_x3") : launch<2, false, 1>(a, batch, s, "avt_stem_conv_x3");
 }

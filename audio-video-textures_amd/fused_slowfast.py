@@ -335,13 +335,15 @@ def stem_conv(stem, device, tgroup=1, x3=None):
                                  (kt // 2, 3, 2), (0, 0, 1)), x3=x3)
         conv.tgroup, conv.frame_channels = g, c
         conv.alg_flops_per_row = g * 2.0 * (kt * kh * kw * 3) * c
-        conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1) if conv.cout % 32 == 0 and x3 is None else None
+        conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1) if conv.cout % 32 == 0 else None
+        conv.wt_lds_lo = stem_lds_image(conv.wt_lo, kt + g - 1) if conv.cout % 32 == 0 and x3 is not None else None
         return conv
     conv = FusedConv(None, None, True, device,
                      packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)), x3=x3)
     conv.tgroup, conv.frame_channels = 1, c
     conv.alg_flops_per_row = 2.0 * (kt * kh * kw * 3) * c
-    conv.wt_lds = stem_lds_image(conv.wt, kt) if conv.cout % 32 == 0 and x3 is None else None
+    conv.wt_lds = stem_lds_image(conv.wt, kt) if conv.cout % 32 == 0 else None
+    conv.wt_lds_lo = stem_lds_image(conv.wt_lo, kt) if conv.cout % 32 == 0 and x3 is not None else None
     return conv
 
 
@@ -757,7 +759,23 @@ class SlowFastMFMA(nn.Module):
         """Contract-grade stem: pixel-pair convolution on the plain split-plane kernel, then the plane-pair max-pool."""
         b, t, h, w, _ = clip.shape
         x = Act(clip.hi.view(b * t * h * (w // 2), 8), (b, t, h, w // 2), lo=clip.lo.view(b * t * h * (w // 2), 8))
-        y = conv(x)
+        if _STEM_LDS and conv.wt_lds_lo is not None and ops.stem_conv_supported(h, w // 2, conv.cout):
+            # production shape: the patch-resident stem kernel in its plane-pair form (no im2col gather)
+            od = conv.out_dims(x.dims)
+            m_out = od[0] * od[1] * od[2] * od[3]
+            y = new_act(m_out, conv.cout, od, self.dev, True)
+
+            def launch():
+                ops.stem_conv_x3(x.ptrs, conv.wt_lds, conv.wt_lds_lo, conv.bias, conv.wscale, y.ptrs, b, t, h, w // 2,
+                                 conv.cout, conv.kernel[0], conv.stride[0], conv.pad[0], self.x3, relu=True)
+
+            if PROFILER is None:
+                launch()
+            else:
+                PROFILER("stem_kernel<x3>", launch, m_out * conv.alg_flops_per_row,
+                         4.0 * (x.buf.numel() + m_out * conv.cout) + conv.wt.numel() * 4)
+        else:
+            y = conv(x)
         _, tg, h2, w2 = y.dims
         pd = (b, t, (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1)
         cf = conv.frame_channels

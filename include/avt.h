@@ -343,6 +343,11 @@ int avt_pw_x3_supported(int k, int n);
 int avt_pw_x3(const void* x_hi, const void* x_lo, int ldx, int k, const void* w_hi, const void* w_lo,
               const float* bias, const float* wscale, const void* res_hi, const void* res_lo, int ldr,
               void* y_hi, void* y_lo, int ldy, int n, int64_t m, int relu, int plane_dtype, void* stream);
+/* avt_stem_conv_bf16 in the same arithmetic (csrc/stem_conv.hip, patch-resident): in / wt / out as plane pairs, wt_* in the
+ * LDS image order of avt_stem_conv_bf16 (fused_slowfast.stem_lds_image of each plane), wscale [cout] or NULL. */
+int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
+                     const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
+                     int kt, int st, int pt, int relu, int plane_dtype, void* stream);
 /* avt_clip_pack_u8_ndhwc4 writing (hi, lo) planes: slow_* [n,8,hw,hw,4], fast_* [n,32,hw,hw,4]. */
 int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, int width,
                                const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw,

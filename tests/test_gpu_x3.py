@@ -152,6 +152,46 @@ def test_pw_x3_slices_and_agreement_with_general_tile(avt, dev, mode):
     assert (outs[0] - outs[1]).abs().max() < 2 * TOL[mode] * max(ref.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_stem_x3_patch_kernel_equals_general_tile(avt, dev, mode):
+    """Both stems + pools at the production clip size: the patch-resident plane-pair stem kernel (csrc/stem_conv.hip, PL > 0)
+    against the same layers on the general x3 tile, and against the fp32 module's stems."""
+    import avtex.fused_slowfast as fsf
+    from avtex import ops
+    from avtex.slowfast import SlowFast
+
+    pd = X3[mode]
+    torch.manual_seed(2)
+    m = SlowFast().eval()
+    with torch.no_grad():
+        for mod in m.s1.modules():
+            if isinstance(mod, nn.BatchNorm3d):
+                mod.weight.uniform_(0.6, 1.2); mod.bias.uniform_(-0.2, 0.2)
+                mod.running_mean.uniform_(-0.1, 0.1); mod.running_var.uniform_(0.8, 1.2)
+    enc = fsf.SlowFastMFMA(m, dev, precision=mode)
+    slow32, fast32 = torch.randn(1, 3, 8, 224, 224), torch.randn(1, 3, 32, 224, 224)
+    with torch.no_grad():
+        ref = m.s1([slow32, fast32])
+
+    def cl4(v):
+        f = torch.zeros((v.shape[0], v.shape[2], 224, 224, 4), dtype=torch.float32, device=dev)
+        f[..., :3] = v.to(dev).permute(0, 2, 3, 4, 1)
+        hi, lo = fsf.split_planes(f, pd)
+        return ops.SplitClip(hi, lo, pd)
+
+    outs = {}
+    for flag in (1, 0):
+        keep, fsf._STEM_LDS = fsf._STEM_LDS, flag
+        outs[flag] = [enc._stem_x3(c, clip)[0].float(pd).cpu() for c, clip in ((enc.stem_s, cl4(slow32)), (enc.stem_f, cl4(fast32)))]
+        fsf._STEM_LDS = keep
+        torch.cuda.synchronize()
+    for k in range(2):
+        want = ref[k].permute(0, 2, 3, 4, 1).reshape(-1, ref[k].shape[1])
+        scale = want.abs().max().item()
+        assert (outs[1][k] - want).abs().max().item() < 5 * TOL[mode] * scale  # vs torch's own fp32 conv
+        assert (outs[1][k] - outs[0][k]).abs().max().item() < 2 * TOL[mode] * scale
+
+
 def _calibrated_pair(dev, n, hw_src=128):
     from avtex import ops, synth
     from avtex.slowfast import SlowFast

@@ -59,8 +59,31 @@ def spy_pw(x_ptrs, ldx, k, w_hi, w_lo, bias, wscale, res_ptrs, ldr, y_ptrs, ldy,
     return orig_pw(x_ptrs, ldx, k, w_hi, w_lo, bias, wscale, res_ptrs, ldr, y_ptrs, ldy, n, m_, relu, plane_dtype)
 
 
+orig_stem = ops.stem_conv_x3
+
+
+def spy_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True):
+    shapes.append("stem (LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)" % (cout, kt, st, batch, t, h, pw))
+    return orig_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu)
+
+
+pool_recs = []
+orig_pool = ops.maxpool_hw3s2_x3
+
+
+def spy_pool(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1):
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    r = orig_pool(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup)
+    e.record()
+    pool_recs.append((a, e, "maxpool 3x3/2 x3 in(%d, %d, %d, %d)" % (bt, h, w, c), 4.0 * bt * c * (h * w + (h // 2) * (w // 2))))
+    return r
+
+
 ops.conv3d_igemm_x3 = spy
 ops.pw_x3 = spy_pw
+ops.stem_conv_x3 = spy_stem
+ops.maxpool_hw3s2_x3 = spy_pool
 fsf.PROFILER = hook
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -71,7 +94,7 @@ tot = e0.elapsed_time(e1)
 agg = collections.OrderedDict()
 for (a, e, fl, byt, sym), name in zip(recs, shapes):
     t = a.elapsed_time(e)
-    d = agg.setdefault(name + "  " + sym.split(",f16")[0].split(",bf16")[0].replace("conv_x3_kernel", "tile").replace("<f16>", "").replace("<bf16>", ""), [0, 0.0, 0.0, 0.0])
+    d = agg.setdefault(name + "  " + sym.split(",f16")[0].split(",bf16")[0].replace("conv_x3_kernel", "tile").replace("<f16>", "").replace("<bf16>", "").replace("<x3>", ""), [0, 0.0, 0.0, 0.0])
     d[0] += 1
     d[1] += t
     d[2] += fl
@@ -80,3 +103,6 @@ conv_ms = sum(v[1] for v in agg.values())
 print("batch %d forward %.2f ms; conv launches %.2f ms (%d launches); pools+head+glue %.2f ms" % (b, tot, conv_ms, len(recs), tot - conv_ms))
 for name, (n_, t, fl, byt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%7.3f ms x%d  %-74s %7.1f TF/s %7.0f GB/s" % (t, n_, name, fl / t / 1e9, byt / t / 1e6))
+for a, e, name, byt in pool_recs:
+    t = a.elapsed_time(e)
+    print("%7.3f ms     %-74s %7s      %7.0f GB/s" % (t, name, "", byt / t / 1e6))
