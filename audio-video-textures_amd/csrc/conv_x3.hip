@@ -4,8 +4,8 @@
 // this path is "similarity within 1e-3" = 1e-4 on a cosine: plain bf16 activations (2^-9 per element, every layer) are
 // two orders of magnitude away from that.  The f32-input MFMA runs at 1/16 of the bf16 rate, so this kernel keeps the
 // bf16 matrix pipe and splits every operand in two bf16 planes instead:
-//     x = hi + lo,  hi = bf16(x),  lo = bf16(x - hi)            (|x - hi - lo| <= 2^-18 |x|)
-//     sum_k a_k w_k  ~=  sum_k ( wh*ah + wh*al + wl*ah )         (the dropped wl*al term is <= 2^-18 |a w|)
+//     x = hi + lo,  hi = bf16(x),  lo = bf16(x - hi)            (|x - hi - lo| <= 2^-16 |x|; fp16 planes: 2^-22)
+//     sum_k a_k w_k  ~=  sum_k ( wh*ah + wh*al + wl*ah )         (the dropped wl*al term is <= 2^-16 |a w|; fp16: 2^-22)
 // three v_mfma_f32_32x32x16_bf16 per (n, m, k) sub-tile into ONE fp32 accumulator: 1/3 of the bf16 MFMA rate, 5x the
 // f32 MFMA rate, and ~1e-5 relative per product instead of 4e-3.
 //
@@ -14,7 +14,7 @@
 // conv_igemm.hip done twice (same tap table, same row masks, same SRSRC zero fill) — no conversion in the loop, and a
 // 3x3 consumer does not re-split its input nine times.  Bias, residual add (hi + lo of the residual planes, summed in
 // fp32), ReLU and the concat-slice write are fused in the epilogue like in the bf16 kernel; the tile is staged through
-// LDS in fp32 so the split happens on the final value (one rounding to 2^-18, not two).
+// LDS in fp32 so the split happens on the final value (one rounding to the pair, not two).
 //
 // Tiles (256 threads = 4 waves): <128,128,64> wide layers, <128,64,64> Cout <= 64, <128,32,32> Cout <= 32; BK = 64;
 // LDS per workgroup 2 x (BM + BN) x 144 B (two planes per operand) + the tap table: 82 / 63 / 54 KB.  Per K-step a wave

@@ -9,9 +9,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // fp32 pair -> packed (hi, lo) planes, both round-to-nearest-even; x - hi is exact in fp32.
-// F16 = false: bf16 planes (8 + 8 significant bits, |x - hi - lo| <= 2^-18 |x| at every magnitude).
-// F16 = true : fp16 planes (11 + 11 bits, <= 2^-23 |x| while lo stays a normal fp16, i.e. |x| >= 2^-3; below that the
-//              ABSOLUTE error is <= 2^-25) — values are clamped to the fp16 range first (an activation beyond 65504 would
+// F16 = false: bf16 planes (8 + 8 significant bits, |x - hi - lo| <= 2^-16 |x| at every magnitude; 2^-17 observed).
+// F16 = true : fp16 planes (11 + 11 bits, <= 2^-22 |x| while lo stays a normal fp16, i.e. |x| >= 2^-3; below that the
+//              ABSOLUTE error is <= 2^-24) — values are clamped to the fp16 range first (an activation beyond 65504 would
 //              otherwise become inf - inf).
 template <bool F16>
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {

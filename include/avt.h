@@ -318,8 +318,8 @@ int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const fl
  * The reference's encoders compute in fp32 (models/models.py:335, 399) and north_star asks for scores within 1e-3 of
  * them ON THE SAME FRAMES; bf16 activations are ~100x away from that (profiles/r02/precision_*.json).  In this mode every
  * activation / weight tensor is a PAIR of 16-bit planes of identical geometry, x = hi + lo:
- *   AVT_X3_BF16: bf16 planes, |x - hi - lo| <= 2^-18 |x| at every magnitude
- *   AVT_X3_F16 : fp16 planes, <= 2^-23 |x| for |x| >= 2^-3 (absolute 2^-25 below); values clamped to +-65504; weights
+ *   AVT_X3_BF16: bf16 planes, |x - hi - lo| <= 2^-16 |x| at every magnitude
+ *   AVT_X3_F16 : fp16 planes, <= 2^-22 |x| for |x| >= 2^-3 (absolute 2^-24 below); values clamped to +-65504; weights
  *                are stored pre-scaled by a power of two per output channel (wscale[n] undoes it on the accumulator)
  * and a product is three MFMA passes into one fp32 accumulator: wl*ah + wh*al + wh*ah (csrc/conv_x3.hip).
  * Arguments as avt_conv3d_igemm_rows_bf16, each tensor given as its two planes; res_hi/res_lo both NULL = no residual;

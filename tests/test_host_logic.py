@@ -156,3 +156,67 @@ def test_pack_wfrag_is_the_documented_fragment_order(avt):
             ch = cc * 32 + ks * 16 + (lane >> 5) * 8 + e
             want = wb[row, tap * cin + ch] if (row < cout and unit < nu and ch < cin) else torch.tensor(0.0, dtype=torch.bfloat16)
             assert f[tile, unit, ks, lane, e] == want, (cout, cin, taps, tile, unit, ks, lane, e)
+
+
+def test_split_planes_error_bounds(avt):
+    """The contract-grade number format (include/avt.h): x = hi + lo to 2^-16 |x| (bf16 planes) / 2^-22 |x| for |x| >= 2^-3 and
+    2^-24 absolute below (fp16 planes)."""
+    from avtex import ops
+    from avtex.fused_slowfast import split_planes
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(4096, generator=g) * 3, torch.randn(4096, generator=g) * 1e-3, torch.tensor([0.0, 1.0, -2.5, 60000.0])])
+    for pd, dt in ((ops.X3_BF16, torch.bfloat16), (ops.X3_F16, torch.float16)):
+        hi, lo = split_planes(x, pd)
+        back = hi.view(dt).float() + lo.view(dt).float()
+        err = (back.double() - x.double()).abs()
+        if pd == ops.X3_BF16:
+            assert (err <= 2.0 ** -16 * x.abs().double() + 1e-45).all()
+        else:
+            big = x.abs() >= 2.0 ** -3
+            assert (err[big] <= 2.0 ** -22 * x[big].abs().double()).all() and (err[~big] <= 2.0 ** -24).all()
+
+
+def test_pack_pw_planes_is_the_documented_fragment_order(avt):
+    """include/avt.h: fragment [nt][ks][lane][e] = W[32*(nt/2) + 8*(r/4) + 4*(nt%2) + r%4][32*ks + 8*(lane>>4) + e], r = lane & 15,
+    zero beyond K — for a raw 16-bit plane."""
+    from avtex.fused_slowfast import pack_pw_planes
+
+    n_out, k = 64, 80
+    w = torch.arange(n_out * k, dtype=torch.int16).view(n_out, k).view(torch.bfloat16)
+    f = pack_pw_planes(w).view(torch.int16)
+    assert f.shape == (n_out // 16, 3, 64, 8)
+    raw = w.view(torch.int16)
+    for nt, ks, lane, e in ((0, 0, 0, 0), (1, 2, 17, 3), (3, 1, 63, 7), (2, 2, 40, 5)):
+        r, q = lane & 15, lane >> 4
+        row, col = 32 * (nt // 2) + 8 * (r // 4) + 4 * (nt % 2) + r % 4, 32 * ks + 8 * q + e
+        assert int(f[nt, ks, lane, e]) == (int(raw[row, col]) if col < k else 0)
+
+
+def test_walk_from_survivors_consumes_numpy_like_validate(avt):
+    """agreement.walk_from_survivors (the rank-0 walk of the sharded validate): one rng.choice per step over the survivor
+    positions, first step appends W frames, later steps S (validate.py:570-615)."""
+    from avtex import agreement
+
+    n, W, S = 9, 6, 2
+    idx = np.tile(np.arange(3), (n, 1)).astype(np.int32)
+    seg = np.stack([np.array([(q + 1) % n, (q + 4) % n, (q + 6) % n]) for q in range(n)]).astype(np.int32)
+    cnt = np.array([3, 1, 2, 3, 3, 1, 2, 3, 3], np.int32)
+    frames, chosen = agreement.walk_from_survivors(idx, seg, cnt, n * S + W, W, S, 20, q_id=3, rng=np.random.RandomState(4))
+    rng, q, want = np.random.RandomState(4), 3, []
+    while len(want) < 20:
+        q = int(seg[q, rng.choice(idx[q, : cnt[q]])])
+        want.extend(range(q * S, q * S + W) if not want else range(q * S + W - S, q * S + W))
+    assert frames == want and len(chosen) == 1 + (len(frames) - W) // S
+
+
+def test_synth_inputs_are_deterministic_and_structured(avt):
+    from avtex import synth
+
+    a, b = synth.structured_video(3, 100, 16, 16), synth.structured_video(3, 100, 16, 16)
+    assert a.dtype == torch.uint8 and a.shape == (100, 16, 16, 3) and torch.equal(a, b)
+    d_near = (a[10].float() - a[11].float()).abs().mean()
+    d_far = (a[10].float() - a[80].float()).abs().mean()
+    assert d_near * 3 < d_far  # neighbouring frames similar, distant scenes not
+    m = synth.randomise_bn(torch.nn.Sequential(torch.nn.Conv3d(3, 4, 1), torch.nn.BatchNorm3d(4)), 1, 0.5)
+    assert float(m[1].weight.min()) >= 0.5 and float(m[1].running_var.min()) >= 0.8
