@@ -30,6 +30,18 @@
 #include "conv_args.h"
 #include "split_planes.h"
 
+#ifdef AVT_CONV_STAMP
+// diagnostic build only (`make stamp` -> libavt_hip_stamp.so, never the shipped library): the hooks live in tools/diag
+#define AVT_STAMP_FN avt_debug_stamps_x3
+namespace {
+#include "../../tools/diag/conv_stamp.h"
+}
+#else
+#define STAMP_BEGIN()
+#define STAMP(i)
+#define STAMP_END()
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -133,7 +145,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       f.wl[i] = *reinterpret_cast<const i32x4*>(lds + B_LO + o);
     }
   };
-  auto fmul = [&](const Frags& f) {
+  // The next slab's 2 (AU + BU) buffer loads are issued ONE AT A TIME between the MFMA triples of this slab: issued as a
+  // burst in front of the MFMAs they stall the wave for ~1800 cycles per K-step on the CU's vector-memory issue path
+  // (64 B/clk: 64 KB per workgroup and K-step; in-kernel stamps, profiles/r02/probe_stamps_x3_wide_v1.log: 31 % of a
+  // workgroup's time, MFMAs 38 %) — interleaved, that wait hides under the matrix pipe.
+  // (two pieces per triple: every load is out within the first half of the slab's MFMAs, so the last one has the second
+  // half to land before the stores need it — issued evenly, the wait for the late pieces was 24 % of a workgroup's time)
+  constexpr int NPIECE = 2 * (AU + BU), NGROUP = 4 * NT * MT, PPG = 2 * ((NPIECE + NGROUP - 1) / NGROUP);
+  auto fmul = [&](const Frags& f, int g0, bool more, auto&& piece) {
     // small terms first, the leading product last: D[n][m] += wl*ah + wh*al + wh*ah
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -142,25 +161,31 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
         acc[i][j] = mfma<F16>(f.wl[i], f.ah[j], acc[i][j]);
         acc[i][j] = mfma<F16>(f.wh[i], f.al[j], acc[i][j]);
         acc[i][j] = mfma<F16>(f.wh[i], f.ah[j], acc[i][j]);
+        if (more) {
+#pragma unroll
+          for (int e = 0; e < PPG; ++e) {
+            const int pc = (g0 + i * MT + j) * PPG + e;
+            if (pc < NPIECE) piece(pc);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
   };
-  auto compute = [&]() {
+  auto compute = [&](bool more, auto&& prep, auto&& piece) {
     // (sched_barrier: without it the machine scheduler sinks every read back to just before its first use)
     Frags f0, f1;
     fload(f0, 0);
     fload(f1, 1);
+    if (more) prep();  // the next slab's offsets: its table read joins the fragment reads, its VALU the first MFMAs
     __builtin_amdgcn_sched_barrier(0);
-    fmul(f0);
-    __builtin_amdgcn_sched_barrier(0);
+    fmul(f0, 0, more, piece);
     fload(f0, 2);
     __builtin_amdgcn_sched_barrier(0);
-    fmul(f1);
-    __builtin_amdgcn_sched_barrier(0);
+    fmul(f1, NT * MT, more, piece);
     fload(f1, 3);
     __builtin_amdgcn_sched_barrier(0);
-    fmul(f0);
-    __builtin_amdgcn_sched_barrier(0);
-    fmul(f1);
+    fmul(f0, 2 * NT * MT, more, piece);
+    fmul(f1, 3 * NT * MT, more, piece);
   };
 
   const __amdgpu_buffer_rsrc_t rih = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
@@ -172,25 +197,38 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   if (tab_lds)
     for (int i = tid; i < a.nk * 8; i += 256) ltab[i] = a.ktab[i];
   i32x4 rah[AU], ral[AU], rbh[BU], rbl[BU];
-  auto gload = [&](int kt) {
+  unsigned aoffs[AU], boffs[BU];
+  auto gprep = [&](int kt) {  // byte offsets of the slab's chunks (out of range = zero fill)
     const int2 e = tab_lds ? ltab[kt * 8 + c16] : a.ktab[kt * 8 + c16];
     const unsigned ebits = (unsigned)e.y;
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
       const unsigned sel = ((rowmask[u] & ebits) == ebits) ? 0xFFFFFFFFu : 0u;
-      const unsigned off = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
-      rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)off, 0, 0);
-      ral[u] = __builtin_amdgcn_raw_buffer_load_b128(ril, (int)off, 0, 0);
+      aoffs[u] = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
     }
     const unsigned ksel = ~(unsigned)(e.y >> 31);
     const unsigned kc2 = (unsigned)((kt * 8 + c16) * 16);
 #pragma unroll
     for (int u = 0; u < BU; ++u) {
       const unsigned sel = ksel & wsel[u];
-      const unsigned off = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
-      rbh[u] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)off, 0, 0);
-      rbl[u] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)off, 0, 0);
+      boffs[u] = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
     }
+  };
+  auto gpiece = [&](int p) {  // p (a constant after unrolling): piece 2u + plane of A, then of B
+    if (p < 2 * AU) {
+      const int u = p >> 1;
+      if (p & 1) ral[u] = __builtin_amdgcn_raw_buffer_load_b128(ril, (int)aoffs[u], 0, 0);
+      else rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)aoffs[u], 0, 0);
+    } else {
+      const int u = (p - 2 * AU) >> 1;
+      if (p & 1) rbl[u] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)boffs[u], 0, 0);
+      else rbh[u] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)boffs[u], 0, 0);
+    }
+  };
+  auto gload = [&](int kt) {
+    gprep(kt);
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) gpiece(p);
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -207,16 +245,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     }
   };
   __syncthreads();
+  STAMP_BEGIN();
   gload(0);
   lstore();
   __syncthreads();
+  STAMP(0);  // prologue
   for (int kt = 0; kt < a.nk; ++kt) {
-    if (kt + 1 < a.nk) gload(kt + 1);  // next slab's latency hides under this slab's 48 MFMAs per wave
-    compute();
+    const bool more = kt + 1 < a.nk;
+    STAMP(1);
+    compute(more, [&]() { gprep(kt + 1); }, gpiece);
+    STAMP(2);  // fragment reads + MFMAs + the next slab's loads, one per MFMA triple
     __syncthreads();
+    STAMP(3);  // barrier after compute
     if (kt + 1 < a.nk) {
       lstore();
+      STAMP(4);  // wait for the loads + ds_write
       __syncthreads();
+      STAMP(5);  // barrier after the stores
     }
   }
 
@@ -287,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
     }
   }
+  STAMP_END();
 }
 
 template <int BM, int BN, int WTM, bool F16>

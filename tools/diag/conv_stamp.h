@@ -31,7 +31,10 @@ __device__ unsigned long long g_stamp[10];  // [0..6] segments, [7] workgroups, 
     }                                                                        \
   } while (0)
 
-extern "C" int avt_debug_stamps(unsigned long long* out, int reset) {
+#ifndef AVT_STAMP_FN
+#define AVT_STAMP_FN avt_debug_stamps
+#endif
+extern "C" int AVT_STAMP_FN(unsigned long long* out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 10);
   if (reset) {
     unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -10,14 +10,16 @@ import sys, ctypes, subprocess
 sys.path.insert(0, ".")
 import torch, avtex
 from avtex import _lib
+import os
 lib = _lib.lib()
+stamps = lib.avt_debug_stamps_x3 if os.environ.get("PRECISION") else lib.avt_debug_stamps  # PRECISION=f16x3: the split-plane tile
 buf = (ctypes.c_ulonglong * 10)()
 sys.argv = ["x"] + sys.argv[1:]
 import runpy
-lib.avt_debug_stamps(buf, 1)
+stamps(buf, 1)
 runpy.run_path("tools/conv_layer_bench.py", run_name="__main__")
 torch.cuda.synchronize()
-lib.avt_debug_stamps(buf, 1)
+stamps(buf, 1)
 n = buf[7]
 names = ["prologue", "gload issue | XL: wait own DMA", "compute", "barrier1 | XL: barrier stage complete", "wait+ds_write | XL: DMA issue", "barrier2 | XL: barrier slot free", "epilogue"]
 tot = sum(buf[i] for i in range(7))
