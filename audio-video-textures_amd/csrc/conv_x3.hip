@@ -20,10 +20,11 @@
 // LDS per workgroup 2 x (BM + BN) x 144 B (two planes per operand) + the tap table: 82 / 63 / 54 KB.  Per K-step a wave
 // of the wide tile reads 8 fragments per 16-wide k-slice for 12 MFMAs (the bf16 tile: 4 for 4), so this form is much
 // closer to MFMA-bound than the bf16 one.  Roofline: MFMA at 1/3 of the bf16 peak (833 TFLOP/s algorithmic).
-// Measured and not kept (profiles/r02/probe_x3_wide_pipelined_tile_slower.log): a software-pipelined form of the wide
-// tile — 32-wide steps in two swizzled LDS buffers, ds_writes of step kt+1 under the MFMAs of step kt, one barrier per
-// step — was correct but 10 % SLOWER on every long-K layer (296 vs 328 TFLOP/s): twice the barriers and the fragment-read
-// latency at every step start cost more than the store phase it removed (the second workgroup of the CU already hides it).
+// Measured and not kept (profiles/r02/probe_x3_wide_pipelined_tile_slower.log, probe_stamps_x3_wide_pipelined.log): a
+// software-pipelined form of the wide tile — 32-wide steps in two swizzled LDS buffers, the loads of step kt+2 and the
+// ds_writes of step kt+1 interleaved with the MFMA triples of step kt, one barrier per step — was correct but 12 % SLOWER
+// on every long-K layer (293 vs 333 TFLOP/s), with the loads issued as a burst or interleaved alike: its MFMA phase
+// stretches to 4.4x the matrix time (16 fragment reads exposed at every 24-MFMA step, ds_writes in the MFMA stream).
 #include <stdlib.h>
 
 #include "avt_common.h"
