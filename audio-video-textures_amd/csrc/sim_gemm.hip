@@ -115,16 +115,18 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
   uint4 ra[NPL][4], rb[NPL][4];
   const int nk = (a.d + C::BK - 1) / C::BK;
 
-  auto gload = [&](int kt) {
+  // one staging load (piece p of the slab kt: plane, chunk, operand)
+  auto gpiece = [&](int kt, int p) {
     const int k0 = kt * C::BK;
+    const int op = p & 1, u = (p >> 1) & 3, pl = p >> 3;
+    const int c = tid + u * 256, r = c >> 3, c16 = c & 7;
+    if (op == 0) ra[pl][u] = load_chunk<C::ELEM, ALIGNED>(a.q[pl], row0 + r, a.nq, a.d, k0, c16);
+    else rb[pl][u] = load_chunk<C::ELEM, ALIGNED>(a.t[pl], col0 + r, a.nt, a.d, k0, c16);
+  };
+  constexpr int NPIECE = 8 * NPL;
+  auto gload = [&](int kt) {
 #pragma unroll
-    for (int p = 0; p < NPL; ++p)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = tid + u * 256, r = c >> 3, c16 = c & 7;
-        ra[p][u] = load_chunk<C::ELEM, ALIGNED>(a.q[p], row0 + r, a.nq, a.d, k0, c16);
-        rb[p][u] = load_chunk<C::ELEM, ALIGNED>(a.t[p], col0 + r, a.nt, a.d, k0, c16);
-      }
+    for (int p = 0; p < NPIECE; ++p) gpiece(kt, p);
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -141,7 +143,13 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
   const int arow = (wr * 64 + lr) * LSTR + lh * 16;
   const int brow = (wc * 64 + lr) * LSTR + lh * 16;
 
-  auto compute = [&]() {
+  // f32 mode: the next slab's staging loads are issued between the MFMA groups of this slab, not as a burst in front of
+  // them (a burst stalls the wave on the CU's vector-memory issue path — 31 % of a workgroup's time in the conv tiles'
+  // stamps, profiles/r02/probe_stamps_x3_wide_v1.log): +4.5 % (0.649 -> 0.677 of the f32 peak).  The bf16 modes keep the
+  // burst: interleaved, the plain bf16 mode measured 30 % slower (its 4 MFMAs per k-slice leave no room between them).
+  auto compute = [&](bool more, int ktn) {
+    int pc = 0;
+    if (MODE != AVT_SIM_F32 && more) gload(ktn);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {  // 4 sub-steps of 32 bytes of K per row
       if (MODE == AVT_SIM_F32) {
@@ -161,6 +169,11 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
               const float bv = s == 0 ? fb[n].x : s == 1 ? fb[n].y : s == 2 ? fb[n].z : fb[n].w;
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
             }
+        if (more) {  // 8 pieces over the first 4 of the 16 (ks, s) groups... two per k-slice keeps them in the first half
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ks < 2) gpiece(ktn, ks * 4 + e);
+        }
       } else {
         bf16x8 ah[2], bh[2], al[2], bl[2];
 #pragma unroll
@@ -185,14 +198,14 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
           }
       }
     }
+    (void)pc;
   };
 
   gload(0);
   lstore();
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(kt + 1);  // next slab's HBM/L2 latency hides under the MFMAs
-    compute();
+    compute(kt + 1 < nk, kt + 1);  // the next slab's loads ride between this slab's MFMA groups
     __syncthreads();
     if (kt + 1 < nk) {
       lstore();
