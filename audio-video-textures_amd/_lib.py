@@ -42,6 +42,9 @@ SIGNATURES = {
     "avt_bottleneck_first_supported": [C.c_int] * 3,
     "avt_bottleneck_first_bf16": [_vp] * 9 + [C.c_int] * 7 + [_vp],
     "avt_pairwise_l2_f32": [_vp, C.c_int, C.c_int64, _vp, _vp],
+    "avt_diag_filter_f32": [_vp, C.c_int, _vp, C.c_int, _vp, _vp],
+    "avt_q_learning_supported": [C.c_int],
+    "avt_q_learning_f32": [_vp, C.c_int, C.c_float, C.c_float, C.c_int, _vp, _vp, _vp],
     "avt_conv33_c64_supported": [C.c_int] * 3,
     "avt_conv33_c64_bf16": [_vp] * 4 + [C.c_int] * 6 + [_vp],
     "avt_pw_chain_supported": [C.c_int] * 5,

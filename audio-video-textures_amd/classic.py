@@ -47,6 +47,38 @@ def compute_D1_device(frames, sigma_factor, device="cuda"):
     return d1, p1, sigma
 
 
+def _p_from_d(d, sigma_factor):
+    """sigma, exp, one-row shift, row-normalise (computeD1.py:240-247; the same tail in computeD2.py and q_learning.py)."""
+    nz = torch.nonzero(d).size(0)
+    sigma = sigma_factor * (d.sum() / nz)
+    p = torch.exp(-d / sigma)
+    p = torch.cat((p[1:, :], p[-1, :].unsqueeze(0)), dim=0)
+    return p / p.sum(1, keepdim=True), sigma
+
+
+def compute_D2_device(d1, sigma_factor, filter_size=16):
+    """compute_D2 on the MI355X: the diagonal binomial filter as fs taps per output (csrc/classic.hip), not a dense
+    [fs, fs] conv2d over a diagonal kernel (computeD2.py:21-52)."""
+    from . import ops
+
+    w = torch.tensor((np.poly1d([0.5, 0.5]) ** (filter_size - 1)).coeffs, dtype=torch.float32, device=d1.device)
+    d2 = ops.diag_filter(d1.contiguous(), w)
+    p2, sigma = _p_from_d(d2, sigma_factor)
+    return d2, p2, sigma, torch.diag(w)
+
+
+def q_learning_device(d2, sigma_factor, p=0.7, alpha=0.997, thresholding=0.75, max_iter=1000):
+    """q_learning on the MI355X: every sweep inside ONE kernel launch with the matrix resident in LDS (csrc/classic.hip)."""
+    from . import ops
+
+    d3_new, _ = ops.q_learning((d2 ** p).contiguous(), alpha, 10e-3, max_iter)
+    p3, sigma = _p_from_d(d3_new, sigma_factor)
+    p3_new = p3.clone()
+    cut = p3_new.max(dim=1, keepdim=True)[0]
+    p3_new[p3_new < (cut - thresholding * cut)] = 0.0
+    return d3_new, p3, p3_new, sigma
+
+
 def compute_D2(d1, sigma_factor, filter_size=16, stride=1):
     w = torch.tensor(np.diag((np.poly1d([0.5, 0.5]) ** (filter_size - 1)).coeffs), dtype=torch.float32)
     d2 = F.conv2d(d1.view(1, 1, *d1.shape), w.view(1, 1, filter_size, filter_size), stride=stride)

@@ -83,6 +83,8 @@ def build_parser():
     a("--enc_batch", default=32, type=int, help="windows per encoder batch")
     a("--enc_impl", default="auto", choices=["auto", "mfma", "module"],
       help="SlowFast at -e: hand-written MFMA convolutions (auto/mfma) or the nn.Module on MIOpen (module)")
+    a("--dump_png", default=False, action="store_true",
+      help="also write the reference's per-frame PNG folder (validate.py:789-792); default: frames go to the encoder directly")
     a("--vcam", default=False, action="store_true", help="defined for validate.py:299; CAM dumps are out of scope")
     return parser
 

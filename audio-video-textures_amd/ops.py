@@ -470,6 +470,32 @@ def pairwise_l2(x):
     return out
 
 
+def diag_filter(d1, w):
+    """D2[i, j] = sum_k w[k] D1[i+k, j+k] (computeD2.py:21-52) on device matrices."""
+    _dev(d1, "d1", torch.float32)
+    _dev(w, "w", torch.float32)
+    n, fs = d1.shape[0], int(w.numel())
+    out = torch.empty((n - fs + 1, n - fs + 1), dtype=torch.float32, device=d1.device)
+    _lib.check(_lib.lib().avt_diag_filter_f32(_p(d1), int(n), _p(w), fs, _p(out), _stream()), "avt_diag_filter_f32")
+    return out
+
+
+def q_learning_supported(n):
+    return bool(_lib.lib().avt_q_learning_supported(int(n)))
+
+
+def q_learning(d3, alpha, tol=10e-3, max_iter=1000):
+    """The future-cost sweeps of q_learning.py:27-68 on d3 = D2**p (device, square, <= 200 rows) -> (D3_new, sweeps)."""
+    _dev(d3, "d3", torch.float32)
+    n = d3.shape[0]
+    assert d3.shape[1] == n
+    out = torch.empty_like(d3)
+    iters = torch.zeros(1, dtype=torch.int32, device=d3.device)
+    _lib.check(_lib.lib().avt_q_learning_f32(_p(d3), int(n), float(alpha), float(tol), int(max_iter), _p(out), _p(iters),
+                                             _stream()), "avt_q_learning_f32")
+    return out, iters
+
+
 # ---- audio front-end ------------------------------------------------------------------------
 def logmel(wave, window, melmat, hop, fft_len, log_offset):
     """wave [n] fp32/fp64, window [win] fp64, melmat [fft_len/2+1, n_mel] fp64 (device) -> log-mel [n_frames, n_mel]

@@ -74,3 +74,30 @@ def save_videos(frames_dir, outfile, fps, interpolation=False, audio_w=None, SF=
     cmd += ["-pix_fmt", "yuv420p", outfile]
     subprocess.call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return True
+
+
+def save_video_raw(frames_u8, outfile, fps, audio_file=""):
+    """Frame tensor -> mp4 WITHOUT the PNG round trip of the reference (validate.py:789-872 writes every frame as a PNG,
+    utils.py:43-189 lets ffmpeg read them back): uint8 [n, H, W, 3] RGB frames (host or device; gathered from the resident
+    video by index) are piped to ffmpeg's stdin as rawvideo.  Without an ffmpeg binary the frames are kept losslessly as
+    <outfile>.npz (video, fps) — the same container read_video() accepts — and False is returned."""
+    import numpy as np
+    import torch
+
+    v = torch.as_tensor(frames_u8)
+    if v.dtype != torch.uint8 or v.dim() != 4 or v.shape[3] != 3:
+        raise ValueError("save_video_raw expects uint8 [n, H, W, 3]")
+    arr = v.contiguous().cpu().numpy()
+    if shutil.which("ffmpeg") is None:
+        np.savez_compressed(os.path.splitext(outfile)[0] + ".npz", video=arr, fps=float(fps))
+        print("save_video_raw: ffmpeg not found; wrote {}.npz".format(os.path.splitext(outfile)[0]))
+        return False
+    n, h, w, _ = arr.shape
+    cmd = ["ffmpeg", "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", "{}x{}".format(w, h), "-framerate", str(fps), "-i", "-"]
+    if audio_file:
+        cmd += ["-i", audio_file, "-shortest"]
+    cmd += ["-pix_fmt", "yuv420p", outfile]
+    proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    proc.stdin.write(arr.tobytes())
+    proc.stdin.close()
+    return proc.wait() == 0

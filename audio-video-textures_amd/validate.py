@@ -28,7 +28,7 @@ import torch
 from . import texture
 from ._lib import AvtError
 from .audio_frontend import waveform_to_examples_device
-from .utils import AverageMeter, save_videos
+from .utils import AverageMeter, save_video_raw, save_videos
 from .vggish import VGGish
 
 
@@ -322,17 +322,21 @@ def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_
     try:
         from PIL import Image
     except ImportError:
-        print("PIL not installed; skipping the PNG dump")
-        return
+        Image = None
+        if getattr(args, "dump_png", False):
+            print("PIL not installed; skipping the PNG dump")
+            return
     results_folder = os.path.join(folder, "{}_model_{}_bs_{}_w_{}_stride_{}_temp_{}_th_{}_enca_{}_alpha_{}_intp_{}".format(
         args.logname, args.model_type, args.batch_size, args.window, args.stride, args.temp, args.threshold,
         args.enc_arch, args.alpha, False))
     os.makedirs(results_folder, exist_ok=True)
     new_video_id = len(os.listdir(results_folder)) + 1
     out_dir = os.path.join(results_folder, "video_{}_{}".format(video_name, new_video_id))
-    os.makedirs(out_dir)
-    for count, idx in enumerate(new_frames):
-        Image.fromarray(video[idx].numpy() if hasattr(video[idx], "numpy") else np.asarray(video[idx])).save(os.path.join(out_dir, "{:04d}.png".format(count + 1)))
+    dump_png = getattr(args, "dump_png", False)  # the reference's per-frame PNG folder, only on request
+    if dump_png:
+        os.makedirs(out_dir)
+        for count, idx in enumerate(new_frames):
+            Image.fromarray(video[idx].numpy() if hasattr(video[idx], "numpy") else np.asarray(video[idx])).save(os.path.join(out_dir, "{:04d}.png".format(count + 1)))
     audio_file = ""
     if driving_audio_name is not None and driving_audio_w is not None:
         from scipy.io import wavfile
@@ -340,4 +344,8 @@ def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_
         audio_file = os.path.join(results_folder, "audio_{}_{}.wav".format(video_name, new_video_id))
         wavfile.write(audio_file, int(sr or 16000), np.asarray(driving_audio_w[: len(new_frames) * apf], np.float32))
     print("Saving frames.")
-    save_videos(out_dir, out_dir + ".mp4", args.fps, audio_file=audio_file)
+    if dump_png:
+        save_videos(out_dir, out_dir + ".mp4", args.fps, audio_file=audio_file)
+    else:  # frame list -> one gather of the video tensor -> encoder, no PNG round trip
+        frames = torch.as_tensor(video)[torch.as_tensor(np.asarray(new_frames, dtype=np.int64))]
+        save_video_raw(frames, out_dir + ".mp4", args.fps, audio_file=audio_file)

@@ -377,6 +377,15 @@ int avt_clip_pack_gather_u8(const uint8_t* frames, int n_frames, int height, int
  * computeD1.py:47-96; BASELINE config 1): x [n, d] fp32 device rows (flattened frames), out [n, n] fp32.
  * fp64 accumulation in a fixed order, one sqrt, one rounding. */
 int avt_pairwise_l2_f32(const float* x, int n, int64_t d, float* out, void* stream);
+/* The next two steps of the same baseline on device matrices (csrc/classic.hip):
+ * avt_diag_filter_f32: D2[i, j] = sum_k w[k] * D1[i + k, j + k], out [(n-fs+1)^2] (computeD2.py:21-52: conv2d with a diagonal
+ *   [fs, fs] kernel, valid padding);
+ * avt_q_learning_f32: the future-cost iteration of q_learning.py:27-68 on d3 = D2^p [n, n] (n <= 200: one workgroup, matrix in
+ *   LDS): sweeps until mean((new - old)^2) <= tol or max_iter; out [n, n], *iters (device int, may be NULL) = sweeps run. */
+int avt_diag_filter_f32(const float* d1, int n, const float* w, int fs, float* out, void* stream);
+int avt_q_learning_supported(int n);
+int avt_q_learning_f32(const float* d3, int n, float alpha, float tol, int max_iter, float* out, int* iters,
+                       void* stream);
 
 /* Conv3d [1,3,3] 64 -> 64, stride 1, pad 1 (+ BN folded, optional ReLU) of the slow res2 blocks with the input
  * strip resident in LDS (csrc/conv33_c64.hip; same model, models/models.py:335, 399).  in [batch, t, h, w, 64],

@@ -251,3 +251,28 @@ def test_classic_pairwise_l2_matches_reference_fixture(avt, dev):
     # uint8 inputs: every squared difference and the whole sum are exact in fp64 -> identical up to the final rounding
     assert np.array_equal(d_gpu, d_ref)
     assert (np.diag(d_gpu) == 0).all() and np.array_equal(d_gpu, d_gpu.T)
+
+
+def test_classic_d2_and_q_learning_on_device(avt, dev):
+    """Config 1's remaining matrix steps on the GPU (csrc/classic.hip) vs the reference's outputs (fixture G8: computeD2 and
+    q_learning run from the imported reference) and vs the CPU restatement at the BASELINE size (200 frames, filter 16)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_classic.npz"))
+    d1 = torch.from_numpy(g["d1"]).to(dev)
+    d2, p2, s2, _ = avt.classic.compute_D2_device(d1, 0.1, filter_size=4)
+    np.testing.assert_allclose(d2.cpu().numpy(), g["d2"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(p2.cpu().numpy(), g["p2"], rtol=1e-4, atol=1e-7)
+    d3, p3, p3n, s3 = avt.classic.q_learning_device(torch.from_numpy(g["d2"]).to(dev), 0.1)
+    np.testing.assert_allclose(d3.cpu().numpy(), g["d3"], rtol=2e-6, atol=1e-4)  # (device pow differs from the CPU's in the last ulp)
+    np.testing.assert_allclose(p3.cpu().numpy(), g["p3"], rtol=1e-3, atol=1e-7)
+    assert np.array_equal(p3n.cpu().numpy() > 0, g["p3_thresholded"] > 0)
+    # BASELINE config 1 size: 200 frames 128x128x3 -> D1 200^2 -> D2 185^2 -> D3 185^2 (LDS-resident: 137 KB)
+    gen = torch.Generator().manual_seed(7)
+    frames = torch.randint(0, 256, (200, 32, 32, 3), generator=gen).float()
+    d1c, _, _ = avt.classic.compute_D1(frames, 0.1)
+    d2c, _, _, _ = avt.classic.compute_D2(d1c, 0.1, filter_size=16)
+    d3c, p3c, _, _ = avt.classic.q_learning(d2c, 0.1)
+    d2d, _, _, _ = avt.classic.compute_D2_device(d1c.to(dev), 0.1, filter_size=16)
+    np.testing.assert_allclose(d2d.cpu().numpy(), d2c.numpy(), rtol=1e-5, atol=1e-3)
+    d3d, p3d, _, _ = avt.classic.q_learning_device(d2c.to(dev), 0.1)
+    np.testing.assert_allclose(d3d.cpu().numpy(), d3c.numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(p3d.cpu().numpy(), p3c.numpy(), rtol=2e-3, atol=1e-7)

@@ -78,7 +78,9 @@ def test_classic_baseline_matches_reference(avt):
     d2, p2, s2, _ = avt.classic.compute_D2(torch.from_numpy(g["d1"]), 0.1, filter_size=4)
     np.testing.assert_allclose(d2.numpy(), g["d2"], rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(p2.numpy(), g["p2"], rtol=1e-4, atol=1e-7)
-    d3, p3, p3n, _ = avt.classic.q_learning(d2, 0.1)
+    d3, p3, p3n, s3 = avt.classic.q_learning(torch.from_numpy(g["d2"]), 0.1)  # pinned: the reference's own q_learning run
+    assert np.array_equal(d3.numpy(), g["d3"]) and np.array_equal(p3.numpy(), g["p3"])
+    assert np.array_equal(p3n.numpy(), g["p3_thresholded"]) and float(s3) == float(g["sigma3"])
     assert torch.isfinite(p3).all() and (p3n.sum(1) > 0).all()
     seq = avt.classic.random_walk(p3n.numpy(), 30, rng=np.random.RandomState(0))
     assert len(seq) == 30 and max(seq) < p3n.shape[0]
@@ -220,3 +222,22 @@ def test_synth_inputs_are_deterministic_and_structured(avt):
     assert d_near * 3 < d_far  # neighbouring frames similar, distant scenes not
     m = synth.randomise_bn(torch.nn.Sequential(torch.nn.Conv3d(3, 4, 1), torch.nn.BatchNorm3d(4)), 1, 0.5)
     assert float(m[1].weight.min()) >= 0.5 and float(m[1].running_var.min()) >= 0.8
+
+
+def test_save_video_raw_keeps_frames_without_ffmpeg(avt, tmp_path, monkeypatch):
+    """Output side (validate.py:789-872): the stitched frames go out by index gather, no PNG folder; without an ffmpeg binary
+    they are kept losslessly in the .npz container read_video() reads back."""
+    import shutil as _sh
+
+    from avtex.utils import save_video_raw
+    from avtex.validate import read_video
+
+    monkeypatch.setattr(_sh, "which", lambda name: None)
+    video = torch.randint(0, 256, (12, 8, 10, 3), dtype=torch.uint8)
+    frames = video[torch.tensor([3, 4, 5, 9, 10, 0])]
+    out = str(tmp_path / "clip.mp4")
+    assert save_video_raw(frames, out, 10) is False
+    back, fps = read_video(out)
+    assert fps == 10.0 and torch.equal(back, frames)
+    with pytest.raises(ValueError):
+        save_video_raw(frames.float(), out, 10)

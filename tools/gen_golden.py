@@ -415,9 +415,14 @@ def gen_g8():
     d1, p1, sigma1 = computeD1.compute_D1(frames, 0.1, feats="RGB", slow=True, batch_size=7)
     d1b, _, _ = computeD1.compute_D1(frames, 0.1, feats="RGB", slow=False)
     d2, p2, sigma2, filt = computeD2.compute_D2(d1, 0.1, filter_size=4)
+    import q_learning as ql  # (same stubbed third-party imports; prints its eps per sweep)
+
+    with contextlib.redirect_stdout(_io.StringIO()):
+        d3, p3, p3n, sigma3 = ql.q_learning(d2.clone(), 0.1)
     np.savez_compressed(os.path.join(OUT, "g8_classic.npz"), frames=frames.numpy(), d1=d1.numpy(), p1=p1.numpy(),
                         sigma1=np.array(float(sigma1)), d1_fast=d1b.numpy(), d2=d2.numpy(), p2=p2.numpy(),
-                        sigma2=np.array(float(sigma2)))
+                        sigma2=np.array(float(sigma2)), d3=d3.numpy(), p3=p3.numpy(), p3_thresholded=p3n.numpy(),
+                        sigma3=np.array(float(sigma3)))
     print("G8 done")
 
 
