@@ -465,15 +465,26 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = True  # MIOpen find mode, as the reference sets it (main.py:421)
+    # MIOpen find mode (the reference sets it, main.py:421) only where MIOpen is what is measured: the BatchNorm calibration and
+    # the fp32 reference tables of the precision block run a handful of untimed forwards, and an exhaustive solver search there
+    # costs tens of seconds of setup and runs every candidate kernel MIOpen has
+    torch.backends.cudnn.benchmark = args.encoder == "miopen" or args.mode == "train"
     ops.device_check()
     if args.mode == "train":
         return train_bench(args, rank, world, dev)
+    def note(msg):  # progress on stderr (stdout carries the one JSON line)
+        if rank == 0:
+            print("[bench] %s (%.0f s)" % (msg, time.perf_counter() - t_start), file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
     video, q_mod, t_mod = build_inputs(args, rank, dev)
+    note("inputs built; timing the %s leg" % args.precision)
     main_res = run_mode(args, args.precision, video, q_mod, t_mod, rank, world, dev)
+    note("contract-grade leg done")
     fast_res = None
     if not args.no_fast and args.precision != "bf16" and args.encoder == "mfma":
         fast_res = run_mode(args, "bf16", video, q_mod, t_mod, rank, world, dev)
+        note("fast leg done")
     if rank != 0:
         return
     N, D = args.windows, 2304
@@ -503,10 +514,13 @@ def main():
     if world == 1 and not args.no_precision_block and args.encoder == "mfma":
         modes = [args.precision] + (["bf16"] if args.precision != "bf16" else [])
         out["precision"] = precision_block(args, video, q_mod, t_mod, dev, modes)
+        note("precision block done")
     if world == 1 and not args.no_nxn_legs:
         out["nxn_legs"] = nxn_legs(dev)
+        note("NxN legs done")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(video.cpu(), q_mod, t_mod, 20, 4, N, D, 0.1, args)
+        note("CPU baseline done")
     print(json.dumps(out))
 
 
