@@ -80,7 +80,8 @@ def build_parser():
     a("--enc_dtype", default="fp32", choices=["fp32", "bf16", "bf16x3", "f16x3"],
       help="encoder arithmetic at -e: fp32 (default; on the MFMA kernels = the contract-grade split-plane mode f16x3), "
            "bf16 (fast path: 5x the throughput, scores off by up to 1e-1), or a split-plane mode by name")
-    a("--enc_batch", default=32, type=int, help="windows per encoder batch")
+    a("--enc_batch", default=64, type=int,
+      help="windows per encoder batch (64: whole rounds of the 256 CUs on the long-K layers; ~10 GB of activations at 224^2)")
     a("--enc_impl", default="auto", choices=["auto", "mfma", "module"],
       help="SlowFast at -e: hand-written MFMA convolutions (auto/mfma) or the nn.Module on MIOpen (module)")
     a("--dump_png", default=False, action="store_true",
