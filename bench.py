@@ -552,6 +552,10 @@ def attach_pmc_traffic(kern, args, precision):
         """sym: a device kernel symbol as bench names it; template tails are open ("conv_igemm_kernel<256,32,64" matches
         "...<256, 32, 64, true>"), and "pw_x3_kernel<f16>" means every pw_x3_kernel<K, NT, true>."""
         want_tail = None
+        if sym == "stem_kernel<x3>":  # the plane-pair form of the stem kernel: stem_kernel<MT, false, 1 | 2>
+            want_tail, sym = (",2>" if precision == "f16x3" else ",1>"), "stem_kernel<"
+        elif sym == "stem_kernel":    # the bf16 forms: stem_kernel<MT, POOL, 0>
+            want_tail, sym = ",0>", "stem_kernel<"
         if sym.startswith("pw_x3_kernel<"):
             want_tail, sym = ("true>" if "f16" in sym and "bf16" not in sym else "false>"), "pw_x3_kernel<"
         sym = sym.rstrip(">")
