@@ -57,6 +57,9 @@ SIGNATURES = {
     "avt_conv3d_ktab": [C.c_int] * 7 + [_vp, C.c_int],
     "avt_conv3d_igemm_bf16": [_vp] * 6 + [C.c_int] * 22 + [_vp],
     "avt_conv3d_igemm_rows_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp],
+    "avt_bn_train_fwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_float, C.c_float, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp],
+    "avt_bn_train_bwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp],
+    "avt_bn_train_ws_bytes": [C.c_int64, C.c_int],
     "avt_negative_sample_mt19937": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "avt_clip_pack_gather_u8": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                 C.c_int, _vp, _vp, C.c_int, _vp],
@@ -93,13 +96,16 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name in _RETURNS_I64 else C.c_int
         handle.avt_last_error.argtypes = []
         handle.avt_last_error.restype = C.c_char_p
         if handle.avt_abi_version() != 1:
             raise AvtError("libavt_hip.so ABI version %d, expected 1" % handle.avt_abi_version())
         _lib = handle
     return _lib
+
+
+_RETURNS_I64 = {"avt_bn_train_ws_bytes"}  # sizes; every other entry returns an AVT_* status
 
 
 def check(status, what):

@@ -1,0 +1,282 @@
+// bn_train — train-mode BatchNorm3d fused with what surrounds it in the SlowFast blocks, forward and backward, for
+// the contrastive TRAINING step (BASELINE config 5; contrastive_video_textures/train.py:114-141 runs the third-party
+// SlowFast in train mode: per-replica batch statistics, models/models.py:385-417):
+//     y = act( (x - mean_c) * invstd_c * gamma_c + beta_c  [+ r] )          act = ReLU or identity, r = the block's shortcut
+// In the steady-state step of the MIOpen path a third of the device time is NOT convolution (profiles/r02/
+// train_fp32_steady_state_kernels.log): MIOpenBatchNormFwdTrainSpatial 11.7 %, MIOpenBatchNormBwdSpatial 11.2 %, the
+// residual adds / ReLUs / their backward ~8 % as separate elementwise passes.  Here the normalise, the shortcut add and the
+// ReLU are ONE pass over the rows in each direction, next to one statistics pass: forward = read x twice (+ r once), write
+// y once; backward = read dy, y, x twice, write dx (+ dr) once.  HBM-bound; channels-last rows [M, C] (the physical layout
+// of a channels_last_3d tensor), C a power of two >= 8 (every BatchNorm of SlowFast-8x8-R50).
+// Statistics accumulate in fp64 with NO atomics (hipcc lowers atomicAdd(double) to a compare-and-swap loop, which under a
+// few thousand workgroups per address cost 6x the whole pass — measured, profiles/r02/train_fused_bn_atomics.log): per-thread
+// registers -> a halving tree in LDS -> one row of partials per workgroup -> a finalize launch where one wavefront per channel
+// sums the rows in a fixed order.  The result is bitwise reproducible run to run, and the mean / variance are the correctly
+// rounded ones.  The finalize launch also turns the sums into the per-channel coefficients the apply pass needs, so that
+// pass reads two floats per channel instead of redoing the fp64 arithmetic in every thread.
+// A thread walks the rows with a stride that is a multiple of the row's float4 chunks, so it always sees the SAME four
+// channels and keeps their partial sums / scale / shift in registers.
+#include "avt_common.h"
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kMaxBlocks = 1024;  // 4 workgroups per CU: enough 16-byte loads in flight for HBM, few enough rows of partials
+
+struct BnArgs {
+  const float* x;
+  const float* res;     // forward: shortcut added before the activation, or NULL
+  const float* dy;      // backward
+  const float* y;       // backward: the forward output (ReLU mask), or NULL when there was no ReLU
+  float* out;           // forward: y; backward: dx
+  float* dres;          // backward: gradient of the shortcut (= masked dy), or NULL
+  double* part;         // [blocks][nq * 8] per-workgroup partial sums (slot = quad-in-workgroup * 8 + {p0[4], p1[4]})
+  float* coef;          // [2C] forward: scale, shift; backward: mean(dz), mean(dz * xhat)
+  const float* gamma;
+  const float* beta;
+  const float* mean;    // backward: saved mean / invstd
+  const float* invstd;
+  float* save_mean;     // forward outputs
+  float* save_invstd;
+  float* running_mean;  // forward: updated in place when not NULL
+  float* running_var;
+  float* dgamma;        // backward outputs
+  float* dbeta;
+  int64_t M;            // rows
+  int C;
+  int relu;
+  float eps, momentum;
+  int64_t nchunk;       // M * C / 4
+  int64_t stride;       // total threads (a multiple of C / 4)
+  int blocks;
+  int nq;               // quads a workgroup sees: min(C / 4, kT)
+  int unit;             // workgroups per row when a row is wider than one (C / 4 > kT), else 1
+};
+
+// this thread's four channels (fixed for the whole walk)
+__device__ __forceinline__ int my_quad(const BnArgs& a) {
+  const int64_t i0 = (int64_t)blockIdx.x * kT + threadIdx.x;
+  return (int)(i0 % (a.C / 4));
+}
+
+// per-thread fp64 partials -> halving tree in LDS (threads t and t + w share their quad for every power of two w >= nq)
+// -> this workgroup's row of partials.  Fixed order: deterministic.
+__device__ __forceinline__ void block_reduce_store(const BnArgs& a, const double* p0, const double* p1) {
+  __shared__ double acc[8][kT];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    acc[e][threadIdx.x] = p0[e];
+    acc[4 + e][threadIdx.x] = p1[e];
+  }
+  __syncthreads();
+  for (int w = kT / 2; w >= a.nq; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k][threadIdx.x] += acc[k][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  double* row = a.part + (size_t)blockIdx.x * a.nq * 8;
+  for (int i = threadIdx.x; i < a.nq * 8; i += kT) row[i] = acc[i & 7][i >> 3];
+}
+
+// One wavefront per channel: sum that channel's two partials over the workgroups that saw it, in a fixed order.
+__device__ __forceinline__ void channel_sums(const BnArgs& a, int c, double& s0, double& s1) {
+  const int quad = c >> 2, e = c & 3, lane = threadIdx.x & 63;
+  const int slot = (quad % a.nq) * 8 + e;
+  const int first = a.unit > 1 ? quad / kT : 0;  // wide rows: workgroup b holds quads (b % unit) * kT ...
+  double t0 = 0.0, t1 = 0.0;
+  for (int b = first + lane * a.unit; b < a.blocks; b += 64 * a.unit) {
+    const double* row = a.part + (size_t)b * a.nq * 8;
+    t0 += row[slot];
+    t1 += row[slot + 4];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    t0 += __shfl_down(t0, off, 64);
+    t1 += __shfl_down(t1, off, 64);
+  }
+  s0 = t0;
+  s1 = t1;
+}
+
+__global__ __launch_bounds__(kT) void bn_fwd_stats_kernel(BnArgs a) {
+  double p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    p0[0] += v.x; p1[0] += (double)v.x * v.x;
+    p0[1] += v.y; p1[1] += (double)v.y * v.y;
+    p0[2] += v.z; p1[2] += (double)v.z * v.z;
+    p0[3] += v.w; p1[3] += (double)v.w * v.w;
+  }
+  block_reduce_store(a, p0, p1);
+}
+
+__global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // grid C / 4, a wavefront per channel
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double s0, s1;
+  channel_sums(a, c, s0, s1);
+  if ((threadIdx.x & 63) != 0) return;
+  const double mean = s0 / (double)a.M;
+  double var = s1 / (double)a.M - mean * mean;  // biased variance (normalisation)
+  var = var > 0.0 ? var : 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float sc = invstd * a.gamma[c];
+  a.coef[c] = sc;
+  a.coef[a.C + c] = a.beta[c] - (float)mean * sc;
+  a.save_mean[c] = (float)mean;
+  a.save_invstd[c] = invstd;
+  if (a.running_mean) {  // torch: running = (1 - m) * running + m * batch, running_var with the UNBIASED batch variance
+    const double unb = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
+    a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+    a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
+  const int quad = my_quad(a);
+  const float4 sc = reinterpret_cast<const float4*>(a.coef)[quad];
+  const float4 sh = reinterpret_cast<const float4*>(a.coef + a.C)[quad];
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (a.res) {
+      const float4 r = reinterpret_cast<const float4*>(a.res)[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (a.relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    reinterpret_cast<float4*>(a.out)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
+  const int quad = my_quad(a);
+  const float4 mu = reinterpret_cast<const float4*>(a.mean)[quad];
+  const float4 is = reinterpret_cast<const float4*>(a.invstd)[quad];
+  double p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
+    float4 g = reinterpret_cast<const float4*>(a.dy)[i];
+    if (a.y) {  // ReLU backward: the gradient passes where the forward output was positive
+      const float4 yv = reinterpret_cast<const float4*>(a.y)[i];
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    p0[0] += g.x; p1[0] += (double)g.x * ((v.x - mu.x) * is.x);
+    p0[1] += g.y; p1[1] += (double)g.y * ((v.y - mu.y) * is.y);
+    p0[2] += g.z; p1[2] += (double)g.z * ((v.z - mu.z) * is.z);
+    p0[3] += g.w; p1[3] += (double)g.w * ((v.w - mu.w) * is.w);
+  }
+  block_reduce_store(a, p0, p1);
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(BnArgs a) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double s0, s1;
+  channel_sums(a, c, s0, s1);
+  if ((threadIdx.x & 63) != 0) return;
+  a.coef[c] = (float)(s0 / (double)a.M);        // mean of dz
+  a.coef[a.C + c] = (float)(s1 / (double)a.M);  // mean of dz * xhat
+  a.dbeta[c] = (float)s0;
+  a.dgamma[c] = (float)s1;
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(BnArgs a) {
+  const int quad = my_quad(a);
+  const float4 mu = reinterpret_cast<const float4*>(a.mean)[quad];
+  const float4 is = reinterpret_cast<const float4*>(a.invstd)[quad];
+  const float4 gm = reinterpret_cast<const float4*>(a.gamma)[quad];
+  const float4 k0 = reinterpret_cast<const float4*>(a.coef)[quad];
+  const float4 k1 = reinterpret_cast<const float4*>(a.coef + a.C)[quad];
+  const float4 gs = make_float4(gm.x * is.x, gm.y * is.y, gm.z * is.z, gm.w * is.w);
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
+    float4 g = reinterpret_cast<const float4*>(a.dy)[i];
+    if (a.y) {
+      const float4 yv = reinterpret_cast<const float4*>(a.y)[i];
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    if (a.dres) reinterpret_cast<float4*>(a.dres)[i] = g;
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    float4 o;
+    o.x = gs.x * (g.x - k0.x - (v.x - mu.x) * is.x * k1.x);
+    o.y = gs.y * (g.y - k0.y - (v.y - mu.y) * is.y * k1.y);
+    o.z = gs.z * (g.z - k0.z - (v.z - mu.z) * is.z * k1.z);
+    o.w = gs.w * (g.w - k0.w - (v.w - mu.w) * is.w * k1.w);
+    reinterpret_cast<float4*>(a.out)[i] = o;
+  }
+}
+
+bool shape_ok(int64_t m, int c) { return m > 0 && c >= 8 && (c & (c - 1)) == 0 && c <= 4096; }
+
+void layout(BnArgs& a, int64_t m, int c) {
+  a.M = m;
+  a.C = c;
+  a.nchunk = m * (int64_t)(c / 4);
+  const int q = c / 4;
+  a.nq = q < kT ? q : kT;
+  a.unit = q > kT ? q / kT : 1;
+  int64_t blocks = (a.nchunk + kT - 1) / kT;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  blocks = ((blocks + a.unit - 1) / a.unit) * a.unit;  // whole rows per sweep, so a thread keeps its four channels
+  a.blocks = (int)blocks;
+  a.stride = blocks * kT;
+}
+
+size_t ws_bytes(const BnArgs& a) { return ((size_t)a.blocks * a.nq * 8) * sizeof(double) + (size_t)2 * a.C * sizeof(float); }
+
+int geometry(BnArgs& a, const char* who, int64_t m, int c, void* ws, size_t ws_size) {
+  AVT_REQUIRE(shape_ok(m, c), "%s: rows > 0 and a power-of-two channel count in 8..4096 (got %lld x %d)", who, (long long)m, c);
+  layout(a, m, c);
+  AVT_REQUIRE(a.stride % (c / 4) == 0, "%s: internal: stride %lld not a multiple of %d chunks", who, (long long)a.stride, c / 4);
+  AVT_REQUIRE(ws && avt::aligned16(ws) && ws_size >= ws_bytes(a), "%s: workspace of %zu bytes needed (avt_bn_train_ws_bytes), got %zu",
+              who, ws_bytes(a), ws_size);
+  a.part = static_cast<double*>(ws);
+  a.coef = reinterpret_cast<float*>(a.part + (size_t)a.blocks * a.nq * 8);
+  return AVT_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t avt_bn_train_ws_bytes(int64_t m, int c) {
+  if (!shape_ok(m, c)) return -1;
+  BnArgs a = {};
+  layout(a, m, c);
+  return (int64_t)ws_bytes(a);
+}
+
+extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
+                                float eps, float momentum, int relu, void* ws, int64_t ws_size, float* save_mean, float* save_invstd,
+                                float* running_mean, float* running_var, void* stream) {
+  AVT_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && (!running_mean == !running_var), "avt_bn_train_fwd: NULL pointer");
+  AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && (!res || avt::aligned16(res)), "avt_bn_train_fwd: rows must be 16-byte aligned");
+  BnArgs a = {};
+  const int rc = geometry(a, "avt_bn_train_fwd", m, c, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
+  if (rc) return rc;
+  a.x = x; a.res = res; a.out = y; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.relu = relu;
+  a.save_mean = save_mean; a.save_invstd = save_invstd; a.running_mean = running_mean; a.running_var = running_var;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);
+  hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
+  return avt::check_launch("avt_bn_train_fwd");
+}
+
+extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma, const float* save_mean,
+                                const float* save_invstd, void* ws, int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta,
+                                void* stream) {
+  AVT_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "avt_bn_train_bwd: NULL pointer");
+  AVT_REQUIRE(avt::aligned16(dy) && avt::aligned16(x) && avt::aligned16(dx) && (!y || avt::aligned16(y)) && (!dres || avt::aligned16(dres)) &&
+                  avt::aligned16(gamma) && avt::aligned16(save_mean) && avt::aligned16(save_invstd),
+              "avt_bn_train_bwd: rows and per-channel vectors must be 16-byte aligned");
+  BnArgs a = {};
+  const int rc = geometry(a, "avt_bn_train_bwd", m, c, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
+  if (rc) return rc;
+  a.dy = dy; a.y = y; a.x = x; a.gamma = gamma; a.mean = save_mean; a.invstd = save_invstd;
+  a.out = dx; a.dres = dres; a.dgamma = dgamma; a.dbeta = dbeta;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
+  return avt::check_launch("avt_bn_train_bwd");
+}

@@ -376,6 +376,13 @@ def train_bench(args, rank, world, dev):
     for _ in range(args.warmup):
         step()
     sync_all()
+    if args.train_profile and rank == 0:  # where a steady-state step goes, by device kernel (after MIOpen's solver search)
+        from torch.profiler import ProfilerActivity, profile
+
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=90), file=sys.stderr)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -452,6 +459,7 @@ def main():
                     help="synth: the synthesis hot path (headline); train: BASELINE config 5, contrastive training at size")
     ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="--mode train: encoder autocast dtype")
     ap.add_argument("--train-channels-last", action="store_true")
+    ap.add_argument("--train-profile", action="store_true", help="--mode train: print the top device kernels of one steady-state step")
     ap.add_argument("--precision-windows", type=int, default=128)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 4],
                     help="HIP streams for the q / t encoders (4 also splits each clip batch in halves)")

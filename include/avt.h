@@ -373,6 +373,22 @@ int avt_clip_pack_gather_u8(const uint8_t* frames, int n_frames, int height, int
                             const int32_t* win_start, int n_win, int win_len, int out_hw, float mean,
                             float std, int bgr, void* slow, void* fast, int out_dtype, void* stream);
 
+/* Train-mode BatchNorm3d fused with the shortcut add and the ReLU that follow it in the SlowFast blocks (csrc/bn_train.hip;
+ * the model the reference trains, train.py:114-141 / models/models.py:385-417), on channels-last fp32 rows [m, c] (c a power of
+ * two >= 8):   y = act((x - mean_c) * invstd_c * gamma_c + beta_c [+ res]),  batch statistics in fp64.
+ * Statistics are summed in fp64 in a fixed order (no atomics): results are bitwise reproducible.
+ * fwd: writes save_mean / save_invstd [c]; running_mean / running_var (both or neither) are updated with
+ *      momentum and the unbiased batch variance as torch.nn.BatchNorm3d does.
+ * bwd: y = the forward output when relu was applied (its sign is the ReLU mask) else NULL; dres (may be NULL) receives the
+ *      shortcut's gradient; dgamma / dbeta [c]. */
+int64_t avt_bn_train_ws_bytes(int64_t m, int c); /* workspace both calls need (16-byte aligned); -1 outside the domain */
+int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma,
+                     const float* beta, float eps, float momentum, int relu, void* ws, int64_t ws_size,
+                     float* save_mean, float* save_invstd, float* running_mean, float* running_var, void* stream);
+int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma,
+                     const float* save_mean, const float* save_invstd, void* ws, int64_t ws_size, float* dx,
+                     float* dres, float* dgamma, float* dbeta, void* stream);
+
 /* D1[i, j] = || x_i - x_j ||_2 of the classic video-texture baseline (baselines/classic_video_textures/
  * computeD1.py:47-96; BASELINE config 1): x [n, d] fp32 device rows (flattened frames), out [n, n] fp32.
  * fp64 accumulation in a fixed order, one sqrt, one rounding. */

@@ -1,0 +1,148 @@
+"""Fused train-mode BatchNorm3d (+ shortcut add + ReLU) forward / backward (csrc/bn_train.hip via avtex.train_ops) against
+torch.nn.BatchNorm3d + add + ReLU through autograd on the same inputs — the ops the reference's training step runs
+(contrastive_video_textures/train.py:114-141 with the SlowFast blocks of models/models.py:385-417 in train mode)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last_3d)
+
+
+@pytest.mark.parametrize("c,shape,res,relu", [
+    (64, (2, 4, 14, 14), False, True),     # stem-like
+    (8, (3, 8, 9, 7), False, True),        # the fast pathway's narrow layers, ragged rows
+    (256, (2, 2, 7, 7), True, True),       # block exit: BN + shortcut + ReLU
+    (256, (2, 2, 7, 7), False, False),     # projection shortcut: BN only
+    (2048, (2, 1, 4, 4), True, True),      # C/4 > one workgroup
+    (4096, (1, 1, 3, 3), False, True),
+    (32, (1, 1, 1, 5), True, False),       # fewer rows than threads
+    (64, (2, 8, 56, 56), True, True),      # more chunks than one sweep of the grid: every thread walks several rows
+    (8, (4, 32, 56, 56), False, True),
+    (2048, (4, 8, 7, 7), True, True),      # wide rows, several sweeps
+])
+def test_bn_act_matches_torch(c, shape, res, relu):
+    from avtex import train_ops
+    torch.manual_seed(c + shape[1])
+    dev = "cuda:0"
+    b, t, h, w = shape
+    x0 = _cl(torch.randn(b, c, t, h, w, device=dev) * 2.0 + 0.7)
+    r0 = _cl(torch.randn(b, c, t, h, w, device=dev)) if res else None
+    gy = _cl(torch.randn(b, c, t, h, w, device=dev))
+
+    def run(fused):
+        bn = nn.BatchNorm3d(c).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+            bn.running_mean.fill_(0.25)
+            bn.running_var.fill_(2.0)
+        bn.train()
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if res else None
+        if fused:
+            assert train_ops.fusable(x, bn, r)
+            y = train_ops.bn_act(x, bn, res=r, relu=relu)
+        else:
+            y = bn(x)
+            if res:
+                y = y + r
+            if relu:
+                y = F.relu(y)
+        y.backward(gy)
+        return (y.detach(), x.grad, None if r is None else r.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(),
+                bn.running_var.clone(), int(bn.num_batches_tracked))
+
+    a, e = run(True), run(False)
+    names = ["y", "dx", "dres", "dgamma", "dbeta", "running_mean", "running_var"]
+    for n, u, v in zip(names, a[:7], e[:7]):
+        if v is None:
+            assert u is None
+            continue
+        scale = float(v.abs().max()) + 1e-12
+        err = float((u - v).abs().max()) / scale
+        # fp32 ops against fp32 ops with fp64 statistics on our side: a few ulps of the largest value
+        assert err < 2e-5, (n, err)
+    assert a[7] == e[7] == 1
+
+
+def test_bn_act_falls_back_outside_its_domain():
+    from avtex import train_ops
+    dev = "cuda:0"
+    bn = nn.BatchNorm3d(24).to(dev).train()            # not a power of two
+    x = _cl(torch.randn(2, 24, 2, 5, 5, device=dev))
+    assert not train_ops.fusable(x, bn)
+    assert torch.equal(train_ops.bn_act(x, bn, relu=True), F.relu(nn.BatchNorm3d(24).to(dev).train()(x)))
+    bn = nn.BatchNorm3d(16).to(dev).train()
+    x = torch.randn(2, 16, 2, 5, 5, device=dev)       # NCDHW layout
+    assert not train_ops.fusable(x, bn)
+    bn.eval()
+    assert not train_ops.fusable(_cl(x), bn)           # eval mode: running statistics, the stock op
+
+
+def test_slowfast_train_step_is_as_close_to_fp64_as_the_stock_ops():
+    """One train-mode forward / backward of the SlowFast encoder with the fused passes, judged against the same step in
+    fp64.  The first form of this test asked for fused == stock fp32 within 2e-3 on every parameter's gradient and failed at
+    5.4e-2; tools/probe_bn_train.py (log: profiles/r02/probe_bn_train.log) showed that is this network's fp32 conditioning at
+    this size, not the kernels: against fp64 the stock NCDHW, stock channels-last and fused runs are 1.9e-2, 2.2e-2 and
+    1.9e-2 away over all gradients with the SAME parameters worst (3-5 %), while every fused call's forward output is within
+    2e-7 of fp64 on its own input.  So the claim tested is the one that can hold: the fused step is no further from the
+    fp64 gradients than the stock fp32 step is.  The running statistics went the same way: the second form compared them
+    with fp64 at rtol 1e-4 / atol 1e-6 and failed; the probe then showed the stock fp32 runs miss that too (worst error
+    relative to the tensor's largest entry 2.6e-5 NCDHW, 2.8e-5 channels-last, 2.4e-5 fused, same tensors worst), so they
+    are held to the stock step's distance as well.  Per layer, on the same input, the fused pass IS held to torch's numbers
+    directly (test_bn_act_matches_torch: 2e-5 on y, dx, dres, dgamma, dbeta and both running statistics)."""
+    import copy
+    from avtex import slowfast, train_ops
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    net = slowfast.SlowFast()
+    for m in net.modules():  # (the zero-initialised last BatchNorm of every block would hide its branch from the gradients)
+        if isinstance(m, nn.BatchNorm3d):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.uniform_(m.bias, -0.2, 0.2)
+    state = copy.deepcopy(net.state_dict())
+    clip = torch.randn(2, 3, 32, 64, 64)
+
+    def step(dtype, fused):
+        n = slowfast.SlowFast()
+        n.load_state_dict(state)
+        n = n.to(dev, dtype).to(memory_format=torch.channels_last_3d).train()
+        fast = _cl(clip.to(dev, dtype))
+        slow = _cl(clip.to(dev, dtype)[:, :, ::4])
+        old = train_ops._FUSED
+        train_ops._FUSED = 1 if fused else 0
+        try:
+            out = n([slow, fast])
+            loss = (out.double() ** 2).mean()
+            loss.backward()
+        finally:
+            train_ops._FUSED = old
+        return (float(loss.detach()), out.detach().double(), {k: p.grad.double() for k, p in n.named_parameters()},
+                {k: v.double() for k, v in n.state_dict().items() if "running" in k})
+
+    l64, o64, g64, r64 = step(torch.float64, False)
+    ls, os_, gs, rs = step(torch.float32, False)
+    lf, of, gf, rf = step(torch.float32, True)
+
+    def dist(g):
+        per = {k: float((g[k] - g64[k]).norm()) / (float(g64[k].norm()) + 1e-30) for k in g64}
+        num = sum(float((g[k] - g64[k]).norm()) ** 2 for k in g64)
+        den = sum(float(g64[k].norm()) ** 2 for k in g64)
+        return (num / den) ** 0.5, max(per.values())
+
+    all_s, worst_s = dist(gs)
+    all_f, worst_f = dist(gf)
+    assert abs(lf - l64) <= 1e-5 * abs(l64)
+    assert float((of - o64).abs().max()) <= 2.0 * float((os_ - o64).abs().max()) + 1e-6
+    assert all_f <= 1.5 * all_s + 1e-4, (all_f, all_s)          # measured 1.87e-2 against 2.23e-2
+    assert worst_f <= 2.0 * worst_s + 1e-3, (worst_f, worst_s)   # measured 5.1e-2 against 5.5e-2
+
+    def stat_dist(r):  # worst error of a running statistic, relative to that tensor's largest entry
+        return max(float((r[k] - r64[k]).abs().max()) / (float(r64[k].abs().max()) + 1e-30) for k in r64)
+
+    assert stat_dist(rf) <= 2.0 * stat_dist(rs) + 1e-6, (stat_dist(rf), stat_dist(rs))  # measured 2.4e-5 against 2.8e-5
