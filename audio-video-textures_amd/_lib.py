@@ -60,6 +60,11 @@ SIGNATURES = {
     "avt_bn_train_fwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_float, C.c_float, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp],
     "avt_bn_train_bwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp],
     "avt_bn_train_ws_bytes": [C.c_int64, C.c_int],
+    "avt_interp_pack_pair_u8": [_vp, _vp, C.c_int, C.c_int, _f32p, _vp, _vp, _vp, C.c_int, _vp],
+    "avt_avgpool2_x3": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp],
+    "avt_upsample2_bilinear_x3": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp],
+    "avt_interp_mid_input": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp],
+    "avt_interp_final_u8": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32p, _vp, C.c_int, _vp],
     "avt_negative_sample_mt19937": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "avt_clip_pack_gather_u8": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                 C.c_int, _vp, _vp, C.c_int, _vp],

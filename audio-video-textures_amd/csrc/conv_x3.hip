@@ -319,9 +319,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
           x[2 * e + 1] += r.y;
         }
       }
-      if (a.relu) {
+      if (a.relu == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+      } else if (a.relu == 2) {  // LeakyReLU(0.1): the SuperSloMo UNets (models/slowmo.py:69-71, 132-134, 195-207)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.1f * x[e]);
       }
       uint4 oh, ol;
       avt::split2<F16>(x[0], x[1], oh.x, ol.x);

@@ -162,6 +162,8 @@ class FusedConv:
             wt, bias, self.cin, self.kernel, self.stride, self.pad, self.crop = packed
             cout = wt.shape[0]
         self.cout, self.relu = cout, relu
+        if relu == 2 and x3 is None:
+            raise AvtError("FusedConv: LeakyReLU (relu=2) exists in the split-plane kernel only")
         if self.cin % 8:
             raise AvtError("FusedConv: input channels must be a multiple of 8 (got %d)" % self.cin)
         if cout % 8:  # pad the output channels with zero filters (the caller's buffer must be that wide)
@@ -182,7 +184,7 @@ class FusedConv:
             self.wt, self.wt_lo = hi.to(device), lo.to(device)
             # pointwise stride-1 layers: the streaming kernel (csrc/pw_x3.hip) with LDS-resident weight fragments
             self.pw = None
-            if (_PW_X3 and self.kernel == (1, 1, 1) and self.stride == (1, 1, 1) and self.pad == (0, 0, 0) and
+            if (_PW_X3 and relu != 2 and self.kernel == (1, 1, 1) and self.stride == (1, 1, 1) and self.pad == (0, 0, 0) and
                     not any(self.crop) and cout % 32 == 0 and ops.pw_x3_supported(self.cin, cout)):
                 self.pw = (pack_pw_planes(hi).to(device), pack_pw_planes(lo).to(device))
         else:

@@ -47,6 +47,8 @@ def build_parser():
     a("--new_video_length", "-nvl", default=30, type=int, help="Length of new video")
     a("--alpha", "-alpha", default=0.5, type=float, help="alpha for validation to control driving audio")
     a("--SF", "-SF", default=5, type=int, help="slomo factor N")
+    a("--slomo_ckpt", default="ckpt/SuperSloMo.ckpt", type=str,
+      help="SuperSloMo checkpoint (validate.py:183 hard-codes this path); 'random' = seeded weights; missing file = cuts")
     a("-long", "--long", dest="long", default=False, action="store_true", help="unused in the reference")
     a("-fb", "--frames_bar", dest="frames_bar", default=False, action="store_true", help="Visualize transitions.")
     a("--epochs", default=60, type=int, metavar="N", help="number of total epochs to run")

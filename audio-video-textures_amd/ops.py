@@ -316,7 +316,7 @@ def conv3d_igemm_x3(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, 
                                               C.c_void_p(rh) if rh else None, C.c_void_p(rl) if rl else None,
                                               C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]), _p(ktab), b, t, h, w,
                                               int(cin), int(cout), *kernel, *stride, *pad, *out_dims, int(ldi), int(ldo),
-                                              int(ldr), 1 if relu else 0, int(orr[0]), int(orr[1]), int(orr[2]),
+                                              int(ldr), int(relu), int(orr[0]), int(orr[1]), int(orr[2]),
                                               int(plane_dtype), _p(wscale), _stream()), "avt_conv3d_igemm_x3")
 
 
@@ -551,3 +551,48 @@ def infonce_bwd(q, t, logits, dlogits, inv_q, inv_t, temp):
                                           _p(inv_q), _p(inv_t), b, n, d, float(temp), _p(dq), _p(dt), _stream()),
                "avt_infonce_bwd")
     return dq, dt
+
+
+# ---------------------------------------------------------------- SuperSloMo interpolation passes (csrc/interp.hip)
+def _mean3(mean):
+    return (C.c_float * 3)(*[float(m) for m in mean])
+
+
+def interp_pack_pair(frame0, frame1, mean, img, x_ptrs, plane_dtype):
+    """Two uint8 [H,W,3] device frames -> img [2,H,W,4] fp32 (x / 255 - mean) and flowComp's input planes [H*W, 8]."""
+    _dev(frame0, "frame0", torch.uint8)
+    _dev(frame1, "frame1", torch.uint8)
+    _dev(img, "img", torch.float32)
+    h, w = frame0.shape[0], frame0.shape[1]
+    _lib.check(_lib.lib().avt_interp_pack_pair_u8(_p(frame0), _p(frame1), int(h), int(w), _mean3(mean), _p(img), C.c_void_p(x_ptrs[0]),
+                                                  C.c_void_p(x_ptrs[1]), int(plane_dtype), _stream()), "avt_interp_pack_pair_u8")
+
+
+def avgpool2_x3(x_ptrs, dims, c, ldi, y_ptrs, ldo, plane_dtype):
+    b, h, w = dims
+    _lib.check(_lib.lib().avt_avgpool2_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), int(b), int(h), int(w), int(c), int(ldi),
+                                          C.c_void_p(y_ptrs[0]), C.c_void_p(y_ptrs[1]), int(ldo), int(plane_dtype), _stream()),
+               "avt_avgpool2_x3")
+
+
+def upsample2_bilinear_x3(x_ptrs, dims, c, ldi, y_ptrs, ldo, plane_dtype):
+    b, h, w = dims
+    _lib.check(_lib.lib().avt_upsample2_bilinear_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), int(b), int(h), int(w), int(c),
+                                                    int(ldi), C.c_void_p(y_ptrs[0]), C.c_void_p(y_ptrs[1]), int(ldo), int(plane_dtype),
+                                                    _stream()), "avt_upsample2_bilinear_x3")
+
+
+def interp_mid_input(img, flow_ptrs, h, w, sf, x_ptrs, ft, plane_dtype):
+    _dev(img, "img", torch.float32)
+    _dev(ft, "ft", torch.float32)
+    _lib.check(_lib.lib().avt_interp_mid_input(_p(img), C.c_void_p(flow_ptrs[0]), C.c_void_p(flow_ptrs[1]), int(h), int(w), int(sf),
+                                               C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(ft), int(plane_dtype), _stream()),
+               "avt_interp_mid_input")
+
+
+def interp_final(img, ft, o_ptrs, h, w, sf, mean, out, plane_dtype):
+    _dev(img, "img", torch.float32)
+    _dev(ft, "ft", torch.float32)
+    _dev(out, "out", torch.uint8)
+    _lib.check(_lib.lib().avt_interp_final_u8(_p(img), _p(ft), C.c_void_p(o_ptrs[0]), C.c_void_p(o_ptrs[1]), int(h), int(w), int(sf),
+                                              _mean3(mean), _p(out), int(plane_dtype), _stream()), "avt_interp_final_u8")

@@ -25,7 +25,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import texture
+from . import slowmo, texture
 from ._lib import AvtError
 from .audio_frontend import waveform_to_examples_device
 from .utils import AverageMeter, save_video_raw, save_videos
@@ -146,8 +146,25 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         driving_audio_w, sr_da = driving_audio
         driving_audio_eg = waveform_to_examples_device(np.asarray(driving_audio_w), sr_da * sub, dev).unsqueeze(dim=1)
     print("Initializing interpolation model. ")
-    if getattr(args, "interpolation", False):
-        print("SuperSloMo interpolation at jumps is outside the hot-path scope; continuing without it (-nintp).")
+    intp_model, timeline = None, None
+    if getattr(args, "interpolation", False) and rank == 0:
+        # validate.py:181-185: interpolate([W, H], SF) + ckpt/SuperSloMo.ckpt.  The reference raises when the file is
+        # missing; here the jumps are then left as cuts (the Frames list does not depend on it).  `--slomo_ckpt random`
+        # runs the networks on seeded weights (benchmarks, tests).
+        ckpt = getattr(args, "slomo_ckpt", "ckpt/SuperSloMo.ckpt")
+        if ckpt == "random" or os.path.exists(ckpt):
+            intp_model = slowmo.Interpolator(int(video.shape[1]), int(video.shape[2]), int(args.SF), dev)
+            timeline = slowmo.IntpTimeline(int(args.SF))
+            if ckpt == "random":
+                g = torch.Generator().manual_seed(0)
+                for net_ in (intp_model.flow_comp, intp_model.arb_time):
+                    for p_ in net_.parameters():
+                        bound = (3.0 / p_[0].numel()) ** 0.5 if p_.dim() > 1 else 0.05
+                        p_.data.copy_((torch.rand(p_.shape, generator=g) * 2 - 1) * bound)
+            else:
+                intp_model.load_checkpoint(ckpt)
+        else:
+            print("SuperSloMo checkpoint {} not found; jumps are left as cuts (as with -nintp).".format(ckpt))
 
     # ---- ids (validate.py:188-257) --------------------------------------------------------------
     all_frame_ids = np.arange(n_in)
@@ -285,15 +302,28 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         accs.update(1.0 if (non_zero_count and choices[0] == 0 and bool(surv_p[0] == surv_p.max())) else 0.0, 1)
 
         # frame bookkeeping (validate.py:580-615)
+        intp_added = False
         if p_q_id == -1:
             diff_ids = all_frame_ids[q_id * S : q_id * S + W]
         else:
             if q_id != p_q_id + 1:
                 jump_count += 1
+                if intp_model is not None:  # validate.py:588-611: SF - 1 frames between the last frame shown and the next one
+                    frame0 = torch.as_tensor(video[new_frames[-1]]).to(dev)
+                    frame1 = torch.as_tensor(video[(q_id * S + (W - S)) * sub]).to(dev)
+                    int_frames = intp_model(frame0, frame1)
+                    print("Added {} intermediate frames.\n".format(len(int_frames)))
+                    timeline.jump(list(int_frames))
+                    intp_added = True
             diff_ids = all_frame_ids[q_id * S + (W - S) : q_id * S + W]
         new_frame_ids.extend(diff_ids)
+        count = 0
         for i in diff_ids:
-            new_frames.extend(range(i * sub, (i + 1) * sub))
+            for idx in range(i * sub, (i + 1) * sub):
+                new_frames.append(idx)
+                if timeline is not None:
+                    timeline.append(idx, first_after_jump=intp_added and count == 0)
+                count += 1
         iter_count += 1
         p_q_id = copy.deepcopy(q_id)
 
@@ -311,13 +341,34 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         print("Done logging Loss and Entropies.")
     print("Frames list: ", [int(i) for i in new_frame_ids])
     _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr)
+    if timeline is not None:
+        print("Saving Interpolated Video.\n")
+        assert len(timeline) == int((args.SF + 1) / 2) * len(new_frames)  # validate.py:812
+        _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr, timeline=timeline)
     return [int(i) for i in new_frame_ids]
 
 
-def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr):
-    """PNG dump + ffmpeg mux (validate.py:710-872).  Output side, off the hot path; skipped without a folder."""
+def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr, timeline=None):
+    """PNG dump + ffmpeg mux (validate.py:710-872).  Output side, off the hot path; skipped without a folder.
+    timeline = the interpolated sequence (validate.py:809-872): its own folder, (SF + 1) / 2 times the frame rate."""
     folder = getattr(args, "results_folder", None)
     if not folder:
+        return
+    if timeline is not None:
+        results_folder = os.path.join(folder, "{}_model_{}_bs_{}_w_{}_stride_{}_temp_{}_th_{}_enca_{}_intp_{}_alpha_{}_SF_{}".format(
+            args.logname, args.model_type, args.batch_size, args.window, args.stride, args.temp, args.threshold,
+            args.enc_arch, True, args.alpha, args.SF))
+        os.makedirs(results_folder, exist_ok=True)
+        new_video_id = len(os.listdir(results_folder)) + 1
+        out_dir = os.path.join(results_folder, "video_{}_{}".format(video_name, new_video_id))
+        audio_file = ""
+        if driving_audio_name is not None and driving_audio_w is not None:
+            from scipy.io import wavfile
+
+            audio_file = os.path.join(results_folder, "audio_{}_{}.wav".format(video_name, new_video_id))
+            wavfile.write(audio_file, int(sr or 16000), np.asarray(driving_audio_w[: len(new_frames) * apf], np.float32))
+        print("Saving frames.")
+        save_video_raw(timeline.frames(video), out_dir + ".mp4", ((args.SF + 1) / 2) * args.fps, audio_file=audio_file)
         return
     try:
         from PIL import Image

@@ -323,7 +323,7 @@ int avt_bottleneck_fused_bf16(const void* x, void* out, const void* wa, const fl
  *                are stored pre-scaled by a power of two per output channel (wscale[n] undoes it on the accumulator)
  * and a product is three MFMA passes into one fp32 accumulator: wl*ah + wh*al + wh*ah (csrc/conv_x3.hip).
  * Arguments as avt_conv3d_igemm_rows_bf16, each tensor given as its two planes; res_hi/res_lo both NULL = no residual;
- * wscale [cout] fp32 or NULL. */
+ * wscale [cout] fp32 or NULL.  * relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (the SuperSloMo UNets, models/slowmo.py:69-71; this entry only). */
 #define AVT_X3_BF16 0
 #define AVT_X3_F16  1
 int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
@@ -388,6 +388,29 @@ int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int 
 int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma,
                      const float* save_mean, const float* save_invstd, void* ws, int64_t ws_size, float* dx,
                      float* dres, float* dgamma, float* dbeta, void* stream);
+
+/* SuperSloMo interpolation at the jumps of the stitched video (contrastive_video_textures/interpolate.py:75-147, called from
+ * validate.py:588-611): the passes around the two UNets, whose convolutions are avt_conv3d_igemm_x3 with relu = 2
+ * (csrc/interp.hip).  Plane pairs as above (plane_dtype AVT_X3_*), NHWC rows; `mean3` is a HOST array of 3 floats.
+ * avt_interp_pack_pair_u8: frames [h, w, 3] uint8 RGB (device) -> img [2, h, w, 4] fp32 = x / 255 - mean (4th lane 0) and
+ *   flowComp's input planes [h*w, 8] = (I0 rgb, I1 rgb, 0, 0).
+ * avt_avgpool2_x3: F.avg_pool2d(x, 2): [batch, h, w, c] rows of stride ldi -> [batch, h/2, w/2, c] rows of stride ldo.
+ * avt_upsample2_bilinear_x3: F.interpolate(x, scale_factor=2, mode="bilinear") (align_corners False):
+ *   [batch, h, w, c] -> [batch, 2h, 2w, c]; ldo lets the result land in a channel slice of a concat buffer.
+ * avt_interp_mid_input: flow planes [h*w, 8] (flowComp's output: F_0_1, F_1_0, 4 pad) -> for t = i / sf, i = 1..sf-1:
+ *   ArbTimeFlowIntrp's input planes [(sf-1)*h*w, 24] (20 channels + 4 pad) and ft [(sf-1), h, w, 4] = (F_t_0, F_t_1).
+ * avt_interp_final_u8: o planes [(sf-1)*h*w, 8] (ArbTimeFlowIntrp's 5 outputs + pad) -> out [(sf-1), h, w, 3] uint8,
+ *   the frames ToPILImage would give (x * 255 truncated). */
+int avt_interp_pack_pair_u8(const uint8_t* frame0, const uint8_t* frame1, int height, int width, const float* mean3,
+                            float* img, void* x_hi, void* x_lo, int plane_dtype, void* stream);
+int avt_avgpool2_x3(const void* in_hi, const void* in_lo, int batch, int h, int w, int c, int ldi, void* out_hi,
+                    void* out_lo, int ldo, int plane_dtype, void* stream);
+int avt_upsample2_bilinear_x3(const void* in_hi, const void* in_lo, int batch, int h, int w, int c, int ldi,
+                              void* out_hi, void* out_lo, int ldo, int plane_dtype, void* stream);
+int avt_interp_mid_input(const float* img, const void* flow_hi, const void* flow_lo, int height, int width, int sf,
+                         void* x_hi, void* x_lo, float* ft, int plane_dtype, void* stream);
+int avt_interp_final_u8(const float* img, const float* ft, const void* o_hi, const void* o_lo, int height, int width,
+                        int sf, const float* mean3, uint8_t* out, int plane_dtype, void* stream);
 
 /* D1[i, j] = || x_i - x_j ||_2 of the classic video-texture baseline (baselines/classic_video_textures/
  * computeD1.py:47-96; BASELINE config 1): x [n, d] fp32 device rows (flattened frames), out [n, n] fp32.

@@ -241,3 +241,32 @@ def test_save_video_raw_keeps_frames_without_ffmpeg(avt, tmp_path, monkeypatch):
     assert fps == 10.0 and torch.equal(back, frames)
     with pytest.raises(ValueError):
         save_video_raw(frames.float(), out, 10)
+
+
+def test_interpolated_timeline_follows_the_reference_bookkeeping():
+    """validate.py:588-650: every source frame 1 + int((SF-1)/2) times; at a jump the last frame's copies are taken back,
+    SF - 1 interpolated frames go in and the first frame after the jump is shown once — so the reference's own check
+    (validate.py:812) len == int((SF+1)/2) * len(new_frames) holds for every odd SF."""
+    import torch
+    from avtex import slowmo
+    from avtex._lib import AvtError
+    video = torch.arange(40, dtype=torch.uint8).view(40, 1, 1, 1).expand(40, 2, 2, 3).contiguous()
+    for sf in (3, 5, 7):
+        tl = slowmo.IntpTimeline(sf)
+        shown = []
+        for idx in (4, 5, 6):
+            tl.append(idx)
+            shown.append(idx)
+        marks = [torch.full((2, 2, 3), 200 + k, dtype=torch.uint8) for k in range(sf - 1)]
+        tl.jump(marks)
+        for n, idx in enumerate((20, 21)):
+            tl.append(idx, first_after_jump=n == 0)
+            shown.append(idx)
+        assert len(tl) == int((sf + 1) / 2) * len(shown)
+        seq = tl.frames(video)[:, 0, 0, 0].tolist()
+        d = int((sf - 1) / 2)
+        expect = [4] * (1 + d) + [5] * (1 + d) + [6] + [200 + k for k in range(sf - 1)] + [20] + [21] * (1 + d)
+        assert seq == expect
+    for bad in (1, 2, 4):
+        with pytest.raises(AvtError):
+            slowmo.IntpTimeline(bad)

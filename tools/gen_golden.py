@@ -449,13 +449,65 @@ def gen_g9():
     print("G9 done", {k: v.tolist() for k, v in rec.items()})
 
 
+def gen_g10():
+    """G10 — SuperSloMo at a jump: the reference's own UNet / backWarp (models/slowmo.py) and interpolate.forward
+    (interpolate.py:93-147) on seeded weights (tests/interp_weights.py) and synthetic frame pairs.  torchvision is not
+    installed here, so the three transforms around the call are restated from its published behaviour (ToTensor: x / 255;
+    Normalize: (x - mean) / std; ToPILImage: x.mul(255).byte()); `interpolate.__init__` is bypassed because it places its
+    grid on `device=0` — the members it would create are built here with the reference's classes."""
+    from PIL import Image
+    import interpolate as ref_intp
+    from models import slowmo as ref_slowmo
+    from interp_weights import frame_pair, unet_state
+
+    mean = torch.tensor([0.429, 0.431, 0.397]).view(3, 1, 1)  # interpolate.py:51-52
+    out = {}
+    for name, (h, w, sf, seed) in {"a": (64, 96, 5, 3), "b": (32, 32, 3, 4), "c": (128, 128, 5, 5)}.items():
+        fc, at = unet_state(6, 4, 10 + seed, head_gain=20.0), unet_state(20, 5, 20 + seed, head_gain=5.0)
+        f0, f1 = frame_pair(seed, h, w)
+        m = ref_intp.interpolate.__new__(ref_intp.interpolate)
+        nn.Module.__init__(m)
+        m.flowComp = ref_slowmo.UNet(6, 4)
+        m.flowComp.load_state_dict(fc)
+        m.ArbTimeFlowIntrp = ref_slowmo.UNet(20, 5)
+        m.ArbTimeFlowIntrp.load_state_dict(at)
+        m.SF, m.origDim, m.dim = sf, [w, h], (w, h)
+        m.flowBackWarp = ref_slowmo.backWarp(w, h, device="cpu")
+        floats = []
+
+        def tp(x):  # revNormalize (mean -> -mean, std 1) + ToPILImage
+            y = (x - (-mean)) / torch.ones(3).view(3, 1, 1)
+            floats.append(y.clone())
+            return Image.fromarray(y.mul(255).byte().permute(1, 2, 0).contiguous().numpy())
+
+        def tt(f):  # ToTensor + Normalize
+            return (f.permute(2, 0, 1).float().div(255) - mean) / torch.ones(3).view(3, 1, 1)
+
+        frames = m.forward(tt(f0), tt(f1), tp)
+        assert len(frames) == sf - 1
+        with torch.no_grad():
+            flow = m.flowComp(torch.cat((tt(f0), tt(f1)), 0).unsqueeze(0))
+        out[name + "_dims"] = np.array([h, w, sf, seed], np.int64)
+        out[name + "_frame0"] = f0.numpy()
+        out[name + "_frame1"] = f1.numpy()
+        out[name + "_out"] = np.stack([np.array(fr) for fr in frames]).astype(np.uint8)
+        if h * w <= 64 * 96:
+            out[name + "_float"] = torch.stack(floats).numpy().astype(np.float32)   # [sf-1, 3, H, W] before * 255
+        out[name + "_flow"] = flow[0].numpy().astype(np.float32)                # flowComp's output [4, H, W]
+        out[name + "_wsum"] = np.array([sum(float(v.double().abs().sum()) for v in fc.values()),
+                                        sum(float(v.double().abs().sum()) for v in at.values())])
+        print("g10", name, "flow |mean| %.3f max %.3f" % (float(flow.abs().mean()), float(flow.abs().max())),
+              "out mean %.2f" % out[name + "_out"].mean())
+    np.savez_compressed(os.path.join(OUT, "g10_interp.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     import models  # noqa: F401  (reference)
     import utils as ref_utils
 
-    which = sys.argv[1:] or ["g1", "g3", "g5", "g6", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g3", "g5", "g6", "g8", "g9", "g10"]
     with torch.no_grad():
         if "g1" in which:
             gen_g1(ref_utils)
@@ -465,6 +517,8 @@ def main():
             gen_g5()
         if "g9" in which:
             gen_g9()
+        if "g10" in which:
+            gen_g10()
     if "g3" in which:
         gen_g3_g4(models)
     if "g8" in which:
