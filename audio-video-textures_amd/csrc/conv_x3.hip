@@ -25,6 +25,11 @@
 // ds_writes of step kt+1 interleaved with the MFMA triples of step kt, one barrier per step — was correct but 12 % SLOWER
 // on every long-K layer (293 vs 333 TFLOP/s), with the loads issued as a burst or interleaved alike: its MFMA phase
 // stretches to 4.4x the matrix time (16 fragment reads exposed at every 24-MFMA step, ds_writes in the MFMA stream).
+// Also measured and not kept (profiles/r02/probe_x3_paired_antiphase_tile_slower.log): two tiles per 512-thread workgroup,
+// the second group of four waves half a K-step behind the first so that every barrier is shared and one group is in its
+// MFMA phase while the other waits for loads / writes LDS (the two independent workgroups of a CU drift INTO phase).
+// Correct (42 parity tests) but 5-9 % slower on every long-K layer: one wave per SIMD cannot keep the matrix pipe full by
+// itself, so enforcing the alternation trades the free-running form's fine-grained sharing of the pipe for barrier bubbles.
 #include <stdlib.h>
 
 #include "avt_common.h"
