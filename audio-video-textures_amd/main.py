@@ -47,6 +47,8 @@ def build_parser():
     a("--new_video_length", "-nvl", default=30, type=int, help="Length of new video")
     a("--alpha", "-alpha", default=0.5, type=float, help="alpha for validation to control driving audio")
     a("--SF", "-SF", default=5, type=int, help="slomo factor N")
+    a("--train_layout", default="ndhwc", choices=["ndhwc", "ncdhw"],
+      help="memory layout of the encoders in training: ndhwc = channels_last_3d (+ fused BatchNorm passes), ncdhw = torch default")
     a("--slomo_ckpt", default="ckpt/SuperSloMo.ckpt", type=str,
       help="SuperSloMo checkpoint (validate.py:183 hard-codes this path); 'random' = seeded weights; missing file = cuts")
     a("-long", "--long", dest="long", default=False, action="store_true", help="unused in the reference")
@@ -145,6 +147,11 @@ def main(args, video_name, itr=0):
     if args.evaluate and args.enc_dtype == "bf16" and args.enc_impl == "module":
         for enc in (model.q_encoder, model.t_encoder):
             enc.to(torch.bfloat16).to(memory_format=torch.channels_last_3d)
+    if not args.evaluate and getattr(args, "train_layout", "ndhwc") == "ndhwc":
+        # training layout on the MI355X: channels-last convolution weights (MIOpen's fwd / dgrad / wgrad then run without
+        # layout transposes) and the fused train-mode BatchNorm + shortcut + ReLU passes of csrc/bn_train.hip, which work
+        # on channels-last rows (train_ops.bn_act; fp32 step 95 -> 130 clips/s).  Same arithmetic.
+        model = model.to(memory_format=torch.channels_last_3d)
     if world > 1 and not args.evaluate:  # weights resident per rank, gradients all-reduced over RCCL
         model = wrap_ddp(model, device, local)
     torch.backends.cudnn.benchmark = True

@@ -339,7 +339,8 @@ def train_bench(args, rank, world, dev):
     torch.manual_seed(0)
     model = avtex.ContrastivePredictionTemporal(SlowFast(), SlowFast(), None, 1, 128, temp=0.1, window=dargs.window,
                                                 stride=dargs.stride, enc_arch="slowfast", img_size=224).to(dev).train()
-    if args.train_channels_last:
+    channels_last = args.train_layout == "ndhwc" or args.train_channels_last
+    if channels_last:
         model = model.to(memory_format=torch.channels_last_3d)
     net = wrap_ddp(model, dev, dev.index) if world > 1 else model
     opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, weight_decay=1e-4)  # README.md:38 / main.py:440-446
@@ -357,7 +358,7 @@ def train_bench(args, rank, world, dev):
         idxs = rng.randint(0, len(ds), size=items)
         for k, i in enumerate(idxs):
             q, t, _, _ = bat.batch(torch.tensor([int(i)]))
-            if args.train_channels_last:
+            if channels_last:
                 q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
             sync = contextlib.nullcontext() if (world == 1 or k == items - 1) else net.no_sync()
             with sync:
@@ -403,7 +404,9 @@ def train_bench(args, rank, world, dev):
                                "through SlowFast-8x8-R50 q/t encoders (train-mode BatchNorm per item = per DataParallel "
                                "replica), HIP InfoNCE + CE, SGD; inputs sampled and packed on the device",
                    "items_per_rank": items, "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
-                   "encoder_backend": "MIOpen autograd (%s%s)" % (args.train_dtype, ", channels_last_3d" if args.train_channels_last else ""),
+                   "encoder_backend": "MIOpen convolutions through autograd (%s%s)" % (
+                       args.train_dtype, ", channels_last_3d" + (" + HIP bn_train (BatchNorm + shortcut + ReLU fwd/bwd)"
+                                                                 if args.train_dtype == "fp32" else "") if channels_last else ""),
                    "parallelism": "dp%d, gradient all-reduce once per step" % world},
         "training_steps_per_s": args.steps / total_s, "items_per_s": B * args.steps / total_s,
         "loss_first_last": [losses[0], losses[-1]],
@@ -458,7 +461,10 @@ def main():
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
                     help="synth: the synthesis hot path (headline); train: BASELINE config 5, contrastive training at size")
     ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="--mode train: encoder autocast dtype")
-    ap.add_argument("--train-channels-last", action="store_true")
+    ap.add_argument("--train-layout", choices=["ndhwc", "ncdhw"], default="ndhwc",
+                    help="--mode train: ndhwc = channels_last_3d weights + the fused BatchNorm passes (csrc/bn_train.hip), the "
+                         "product's default (main.py --train_layout); ncdhw = torch's default layout, stock BatchNorm")
+    ap.add_argument("--train-channels-last", action="store_true", help="(old spelling of --train-layout ndhwc)")
     ap.add_argument("--train-profile", action="store_true", help="--mode train: print the top device kernels of one steady-state step")
     ap.add_argument("--precision-windows", type=int, default=128)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 4],
