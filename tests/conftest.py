@@ -30,3 +30,14 @@ def dev():
     name = avtex.ops.device_check()  # raises loudly if the HIP library is missing / wrong arch
     assert name.startswith("gfx950")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _no_leaked_solver_search():
+    """main.main() turns torch.backends.cudnn.benchmark on (the reference does, main.py:422); left on, every later test
+    with a new convolution shape pays MIOpen's exhaustive solver search (one at-size training test: 5 minutes)."""
+    import torch
+
+    torch.backends.cudnn.benchmark = False
+    yield
+    torch.backends.cudnn.benchmark = False
