@@ -64,7 +64,11 @@ __device__ __forceinline__ f32x16 mfma(i32x4 w, i32x4 x, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 
-template <int BM, int BN, int WTM, bool F16>
+// IO32: the TRAINING form (train_ops.conv3d: forward and stride-1 dgrad of the SlowFast convolutions, train.py:114-141) —
+// activations are read as fp32 NDHWC rows and split into the two planes in registers on their way to the LDS (same number
+// of 16-byte loads as two planes; ~4 VALU operations per element next to 48 MFMAs per K-step), the result is written as
+// fp32: a drop-in for an fp32 convolution on channels-last tensors, no plane-pair tensors in the autograd graph.
+template <int BM, int BN, int WTM, bool F16, bool IO32 = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   constexpr int WAVES_M = BM / WTM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
       const unsigned sel = ((rowmask[u] & ebits) == ebits) ? 0xFFFFFFFFu : 0u;
-      aoffs[u] = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
+      aoffs[u] = (((unsigned)(rowoff[u] + e.x) * (IO32 ? 4u : 2u)) & sel) | (kOob & ~sel);
     }
     const unsigned ksel = ~(unsigned)(e.y >> 31);
     const unsigned kc2 = (unsigned)((kt * 8 + c16) * 16);
@@ -223,8 +227,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   auto gpiece = [&](int p) {  // p (a constant after unrolling): piece 2u + plane of A, then of B
     if (p < 2 * AU) {
       const int u = p >> 1;
-      if (p & 1) ral[u] = __builtin_amdgcn_raw_buffer_load_b128(ril, (int)aoffs[u], 0, 0);
-      else rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)aoffs[u], 0, 0);
+      if constexpr (IO32) {  // eight consecutive fp32 channels = two 16-byte loads of the SAME tensor
+        const unsigned o2 = aoffs[u] == kOob ? kOob : aoffs[u] + 16u;
+        if (p & 1) ral[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)o2, 0, 0);
+        else rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)aoffs[u], 0, 0);
+      } else {
+        if (p & 1) ral[u] = __builtin_amdgcn_raw_buffer_load_b128(ril, (int)aoffs[u], 0, 0);
+        else rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)aoffs[u], 0, 0);
+      }
     } else {
       const int u = (p - 2 * AU) >> 1;
       if (p & 1) rbl[u] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)boffs[u], 0, 0);
@@ -240,8 +250,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
       const int o = (r0 + 32 * u) * LSTR + c16 * 16;
-      *reinterpret_cast<i32x4*>(lds + o) = rah[u];
-      *reinterpret_cast<i32x4*>(lds + A_LO + o) = ral[u];
+      if constexpr (IO32) {
+        const float* fa = reinterpret_cast<const float*>(&rah[u]);
+        const float* fb = reinterpret_cast<const float*>(&ral[u]);
+        uint4 h, l;
+        avt::split2<F16>(fa[0], fa[1], h.x, l.x);
+        avt::split2<F16>(fa[2], fa[3], h.y, l.y);
+        avt::split2<F16>(fb[0], fb[1], h.z, l.z);
+        avt::split2<F16>(fb[2], fb[3], h.w, l.w);
+        *reinterpret_cast<uint4*>(lds + o) = h;
+        *reinterpret_cast<uint4*>(lds + A_LO + o) = l;
+      } else {
+        *reinterpret_cast<i32x4*>(lds + o) = rah[u];
+        *reinterpret_cast<i32x4*>(lds + A_LO + o) = ral[u];
+      }
     }
 #pragma unroll
     for (int u = 0; u < BU; ++u) {
@@ -331,20 +353,26 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.1f * x[e]);
       }
-      uint4 oh, ol;
-      avt::split2<F16>(x[0], x[1], oh.x, ol.x);
-      avt::split2<F16>(x[2], x[3], oh.y, ol.y);
-      avt::split2<F16>(x[4], x[5], oh.z, ol.z);
-      avt::split2<F16>(x[6], x[7], oh.w, ol.w);
       const int64_t o = (int64_t)out_row(a, m) * a.ldo + n;
-      *reinterpret_cast<uint4*>(a.out + o) = oh;
-      *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
+      if constexpr (IO32) {
+        float* of = reinterpret_cast<float*>(a.out) + o;
+        *reinterpret_cast<float4*>(of) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4*>(of + 4) = make_float4(x[4], x[5], x[6], x[7]);
+      } else {
+        uint4 oh, ol;
+        avt::split2<F16>(x[0], x[1], oh.x, ol.x);
+        avt::split2<F16>(x[2], x[3], oh.y, ol.y);
+        avt::split2<F16>(x[4], x[5], oh.z, ol.z);
+        avt::split2<F16>(x[6], x[7], oh.w, ol.w);
+        *reinterpret_cast<uint4*>(a.out + o) = oh;
+        *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
+      }
     }
   }
   STAMP_END();
 }
 
-template <int BM, int BN, int WTM, bool F16>
+template <int BM, int BN, int WTM, bool F16, bool IO32 = false>
 int launch_x3(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
@@ -356,13 +384,13 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
   int lds_bytes = 2 * (BM + BN) * LSTR + tab_bytes;
   constexpr int epi_bytes = BM * (BN * 4 + 16);
   if (lds_bytes < epi_bytes) lds_bytes = epi_bytes;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<BM, BN, WTM, F16>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<BM, BN, WTM, F16, IO32>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_max, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WTM, F16>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WTM, F16, IO32>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_x3");
 }
 
@@ -400,4 +428,34 @@ extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const v
   if (cout <= 32) return launch_x3<128, 32, 32, false>(a, s);
   if (cout <= 64) return launch_x3<128, 64, 64, false>(a, s);
   return launch_x3<128, 128, 64, false>(a, s);
+}
+
+// fp32 rows in, fp32 rows out, split-plane arithmetic in between (the IO32 form of the kernel): see include/avt.h
+extern "C" int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
+                                       const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
+                                       int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype, void* stream) {
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_conv3d_igemm_x3_f32: plane_dtype must be 0 (bf16) or 1 (fp16)");
+  AVT_REQUIRE(wt_lo && avt::aligned16(wt_lo) && (!wscale || avt::aligned16(wscale)), "avt_conv3d_igemm_x3_f32: weight planes / wscale NULL or unaligned");
+  AVT_REQUIRE((int64_t)batch * t * h * w * ldi < (1ll << 30) - 64, "avt_conv3d_igemm_x3_f32: input too large for 32-bit byte offsets");
+  ConvArgs a;
+  const int rc = conv_args_fill(a, "avt_conv3d_igemm_x3_f32", in, wt_hi, nullptr, nullptr, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw,
+                                st, sh, sw, pt, ph, pw, 0, 0, 0, ldi, ldo, 0, 0, 1, 0, 0);
+  if (rc != AVT_OK) return rc;
+  a.in_bytes *= 2u;  // fp32 elements
+  a.in_lo = nullptr;
+  a.wt_lo = static_cast<const uint16_t*>(wt_lo);
+  a.res_lo = nullptr;
+  a.out_lo = nullptr;
+  a.wscale = wscale;
+  a.wfrag = nullptr;
+  a.nup = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plane_dtype == AVT_X3_F16) {
+    if (cout <= 32) return launch_x3<128, 32, 32, true, true>(a, s);
+    if (cout <= 64) return launch_x3<128, 64, 64, true, true>(a, s);
+    return launch_x3<128, 128, 64, true, true>(a, s);
+  }
+  if (cout <= 32) return launch_x3<128, 32, 32, false, true>(a, s);
+  if (cout <= 64) return launch_x3<128, 64, 64, false, true>(a, s);
+  return launch_x3<128, 128, 64, false, true>(a, s);
 }

@@ -320,6 +320,19 @@ def conv3d_igemm_x3(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, 
                                               int(plane_dtype), _p(wscale), _stream()), "avt_conv3d_igemm_x3")
 
 
+def conv3d_igemm_x3_f32(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype):
+    """fp32 rows in / fp32 rows out on the split-plane kernel (training forward / stride-1 dgrad); see include/avt.h."""
+    b, t, h, w = dims
+    _dev(x, "x", torch.float32)
+    _dev(out, "out", torch.float32)
+    _dev(wt_hi, "wt_hi", torch.bfloat16)
+    _dev(wt_lo, "wt_lo", torch.bfloat16)
+    _lib.check(_lib.lib().avt_conv3d_igemm_x3_f32(_p(x), _p(wt_hi), _p(wt_lo), _p(wscale), _p(out), _p(ktab), int(b), int(t), int(h),
+                                                  int(w), int(cin), int(cout), *[int(k) for k in kernel], *[int(v) for v in stride],
+                                                  *[int(v) for v in pad], int(ldi), int(ldo), int(plane_dtype), _stream()),
+               "avt_conv3d_igemm_x3_f32")
+
+
 def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True):
     """stem_conv on plane pairs (contract-grade mode); wt_hi / wt_lo = fused_slowfast.stem_lds_image of each weight plane."""
     _dev(wt_hi, "wt_hi", torch.bfloat16)

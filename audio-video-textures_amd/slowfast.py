@@ -13,7 +13,7 @@ MI355X notes: convolutions go to MIOpen; run it in bf16 with channels_last_3d (`
 import torch
 import torch.nn as nn
 
-from .train_ops import bn_act
+from .train_ops import bn_act, conv3d
 
 ALPHA, BETA_INV, FUSION_RATIO, FUSION_KERNEL = 4, 8, 2, 7
 WIDTH = 64
@@ -32,7 +32,7 @@ class Stem(nn.Module):
         self.pool_layer = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
 
     def forward(self, x):
-        return self.pool_layer(bn_act(self.conv(x), self.bn, relu=True))  # (train mode on the GPU: one fused HIP pass)
+        return self.pool_layer(bn_act(conv3d(x, self.conv), self.bn, relu=True))  # (train mode on the GPU: one fused HIP pass)
 
 
 class VideoModelStem(nn.Module):
@@ -54,7 +54,7 @@ class FuseFastToSlow(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return [torch.cat([x[0], bn_act(self.conv_f2s(x[1]), self.bn, relu=True)], 1), x[1]]
+        return [torch.cat([x[0], bn_act(conv3d(x[1], self.conv_f2s), self.bn, relu=True)], 1), x[1]]
 
 
 class BottleneckTransform(nn.Module):
@@ -85,12 +85,12 @@ class ResBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        sc = bn_act(self.branch1(x), self.branch1_bn, relu=False) if hasattr(self, "branch1") else x
+        sc = bn_act(conv3d(x, self.branch1), self.branch1_bn, relu=False) if hasattr(self, "branch1") else x
         t = self.branch2
-        h = bn_act(t.a(x), t.a_bn, relu=True)
-        h = bn_act(t.b(h), t.b_bn, relu=True)
+        h = bn_act(conv3d(x, t.a), t.a_bn, relu=True)
+        h = bn_act(conv3d(h, t.b), t.b_bn, relu=True)
         # c's BatchNorm, the shortcut add and the block's ReLU: one pass in train mode (csrc/bn_train.hip), the stock ops else
-        return bn_act(t.c(h), t.c_bn, res=sc, relu=True)
+        return bn_act(conv3d(h, t.c), t.c_bn, res=sc, relu=True)
 
 
 class ResStage(nn.Module):

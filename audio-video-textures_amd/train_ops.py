@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from . import _lib
 
 _FUSED = int(os.environ.get("AVT_FUSED_BN", "1"))
+_CONV_X3 = int(os.environ.get("AVT_TRAIN_CONV_X3", "1"))
 
 
 def _p(t):
@@ -89,3 +90,118 @@ def bn_act(x, bn, res=None, relu=True):
             momentum = 1.0 / float(bn.num_batches_tracked)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Convolutions of the training step on the split-plane MFMA kernel (csrc/conv_x3.hip, IO32 form): the forward of every
+# Conv3d(bias=False) with channel counts in multiples of 8, and the input gradient of the stride-1 ones (a convolution of
+# dy with the flipped, transposed filter).  fp32 tensors in and out; 2^-22 (forward, fp16 planes) / 2^-16 (dgrad, bf16
+# planes: gradients need fp32's exponent range) per product instead of the fp32 MFMA's rate of 1/16 of the bf16 pipe.
+# The weight gradient stays MIOpen's (aten.convolution_backward, wgrad only); so do the strided dgrads.
+_TABS, _PLANES = {}, {}
+
+
+def _ktab(cin, kernel, h, w, ldi, device):
+    from . import ops
+    key = (cin, tuple(kernel), h, w, ldi, str(device))
+    tab = _TABS.get(key)
+    if tab is None:
+        tab = torch.from_numpy(ops.conv3d_ktab(cin, kernel, h, w, ldi)).to(device)
+        _TABS[key] = tab
+    return tab
+
+
+def _weight_planes(weight, transposed):
+    """(hi, lo, wscale) planes of a Conv3d weight in the kernel's [Cout, taps * Cin] order, cached until the optimizer
+    changes the tensor.  transposed: the dgrad filter W'[ci, co, flipped taps], as bf16 planes."""
+    from . import ops
+    from .fused_slowfast import split_planes
+    key = (weight.data_ptr(), bool(transposed))
+    hit = _PLANES.get(key)
+    if hit is not None and hit[0] == weight._version and hit[1] == tuple(weight.shape):
+        return hit[2]
+    with torch.no_grad():
+        w = weight.detach().float()
+        if w.shape[1] % 8:  # the stems' 3 input channels, padded with zero taps
+            w = torch.cat([w, w.new_zeros((w.shape[0], 8 - w.shape[1] % 8) + tuple(w.shape[2:]))], 1)
+        if transposed:
+            w = w.flip(2, 3, 4).transpose(0, 1)
+        wt = w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
+        if transposed:
+            hi, lo = split_planes(wt, ops.X3_BF16)
+            planes = (hi, lo, None)
+        else:  # fp16 planes: rows scaled by a power of two into [2^9, 2^10), undone on the accumulator (fused_slowfast.FusedConv)
+            mx = wt.abs().amax(dim=1).clamp_min(1e-30)
+            sc = torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
+            hi, lo = split_planes(wt * sc.view(-1, 1), ops.X3_F16)
+            planes = (hi, lo, (1.0 / sc).float().contiguous())
+    _PLANES[key] = (weight._version, tuple(weight.shape), planes)
+    return planes
+
+
+def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad):
+    """x [B, Cin, T, H, W] channels-last fp32 -> [B, Cout, To, Ho, Wo] channels-last fp32."""
+    from . import ops
+    b, _, t, h, w = x.shape
+    od = [(n + 2 * p - k) // s_ + 1 for n, p, k, s_ in zip((t, h, w), pad, kernel, stride)]
+    y = torch.empty((b, cout, od[0], od[1], od[2]), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+    ops.conv3d_igemm_x3_f32(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
+                            _ktab(cin, kernel, h, w, cin, x.device), (b, t, h, w), cin, cout, kernel, stride, pad, cin, cout, plane_dtype)
+    return y
+
+
+class _ConvX3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        from . import ops
+        cout, cin = weight.shape[0], weight.shape[1]
+        kernel = tuple(weight.shape[2:])
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (stride, padding, kernel, cin, cout)
+        xin = x
+        if cin % 8:  # stem: [B, 3, T, H, W] -> 8 channels-last channels, the last 5 zero (weights padded to match)
+            xin = torch.empty((x.shape[0], 8) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device, memory_format=torch.channels_last_3d)
+            xin[:, :cin] = x
+            xin[:, cin:] = 0
+        return _conv_x3_rows(xin, _weight_planes(weight, False), ops.X3_F16, xin.shape[1], cout, kernel, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        stride, padding, kernel, cin, cout = ctx.conf
+        dy = dy.contiguous(memory_format=torch.channels_last_3d)
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
+                                                     [False, True, False])[1]
+        if ctx.needs_input_grad[0]:
+            if cin % 8 == 0 and stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(padding, kernel)):
+                dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
+                                                         [True, False, False])[0]
+        return dx, dw, None, None
+
+
+def conv_fusable(x, conv):
+    """(in_channels == 3: the stems — the clip is zero-padded to 8 channels for the forward; it needs no input gradient.)"""
+    return (_CONV_X3 and conv.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and conv.bias is None and
+            conv.groups == 1 and tuple(conv.dilation) == (1, 1, 1) and conv.out_channels % 8 == 0 and
+            (conv.in_channels % 8 == 0 or (conv.in_channels == 3 and not x.requires_grad)) and
+            max(conv.kernel_size) <= 8 and conv.weight.dtype == torch.float32 and conv.padding_mode == "zeros" and
+            not isinstance(conv.padding, str) and x.numel() < (1 << 30) - 64 and
+            conv.weight.is_contiguous(memory_format=torch.channels_last_3d) and  # the model was put in the training layout
+            (max(conv.kernel_size) > 1 or x.is_contiguous(memory_format=torch.channels_last_3d)))  # (a 1x1x1 weight is both layouts)
+
+
+def conv3d(x, conv):
+    """conv(x) for a Conv3d module: the split-plane MFMA kernel in train mode on channels-last fp32 device tensors (forward
+    and stride-1 input gradient; weight gradient through MIOpen), the module itself otherwise."""
+    if not conv_fusable(x, conv):
+        return conv(x)
+    if conv.in_channels % 8 and not x.is_contiguous(memory_format=torch.channels_last_3d):
+        pass  # (the stem's padded copy is built channels-last from any layout)
+    else:
+        x = x.contiguous(memory_format=torch.channels_last_3d)  # no-op inside the network; a clip handed over as NCDHW is transposed once
+    return _ConvX3.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding))

@@ -389,6 +389,16 @@ int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m,
                      const float* save_mean, const float* save_invstd, void* ws, int64_t ws_size, float* dx,
                      float* dres, float* dgamma, float* dbeta, void* stream);
 
+/* The training form of avt_conv3d_igemm_x3 (csrc/conv_x3.hip, IO32): fp32 NDHWC rows in [batch*t*h*w, ldi], fp32 rows out
+ * [M, ldo], no bias / residual / activation — an fp32-grade Conv3d(bias=False) on channels-last tensors for the forward
+ * and the stride-1 input gradient of the SlowFast convolutions in train() (contrastive_video_textures/train.py:114-141;
+ * avtex/train_ops.py).  Activations are split into the two planes inside the kernel; wt_hi / wt_lo [cout, kt*kh*kw*cin]
+ * are the weight planes (plane_dtype AVT_X3_*; wscale as in avt_conv3d_igemm_x3, or NULL). */
+int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
+                            const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                            int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype,
+                            void* stream);
+
 /* SuperSloMo interpolation at the jumps of the stitched video (contrastive_video_textures/interpolate.py:75-147, called from
  * validate.py:588-611): the passes around the two UNets, whose convolutions are avt_conv3d_igemm_x3 with relu = 2
  * (csrc/interp.hip).  Plane pairs as above (plane_dtype AVT_X3_*), NHWC rows; `mean3` is a HOST array of 3 floats.

@@ -114,14 +114,14 @@ def test_slowfast_train_step_is_as_close_to_fp64_as_the_stock_ops():
         n = n.to(dev, dtype).to(memory_format=torch.channels_last_3d).train()
         fast = _cl(clip.to(dev, dtype))
         slow = _cl(clip.to(dev, dtype)[:, :, ::4])
-        old = train_ops._FUSED
-        train_ops._FUSED = 1 if fused else 0
+        old = (train_ops._FUSED, train_ops._CONV_X3)
+        train_ops._FUSED = train_ops._CONV_X3 = 1 if fused else 0
         try:
             out = n([slow, fast])
             loss = (out.double() ** 2).mean()
             loss.backward()
         finally:
-            train_ops._FUSED = old
+            train_ops._FUSED, train_ops._CONV_X3 = old
         return (float(loss.detach()), out.detach().double(), {k: p.grad.double() for k, p in n.named_parameters()},
                 {k: v.double() for k, v in n.state_dict().items() if "running" in k})
 

@@ -1,0 +1,95 @@
+"""The training convolutions on the split-plane MFMA kernel (avtex.train_ops.conv3d -> csrc/conv_x3.hip, IO32 form):
+forward and stride-1 input gradient against torch's fp32 Conv3d through autograd (what the reference's train() runs,
+contrastive_video_textures/train.py:114-141), weight gradient through MIOpen either way."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last_3d)
+
+
+@pytest.mark.parametrize("cin,cout,kernel,stride,pad,dims,gscale", [
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 14, 14), 1.0),
+    (8, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 9, 7), 1.0),         # narrow fast-pathway layer, ragged rows
+    (256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 7, 7), 1.0),
+    (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 7, 7), 1e-6),      # gradients far below fp16's range
+    (32, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 16, 6, 6), 1.0),       # lateral fusion: strided, dgrad stays MIOpen's
+    (64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 14, 14), 1.0),     # strided 3x3
+    (128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 8, 8), 1.0),
+])
+def test_conv_forward_and_gradients_match_fp32_autograd(cin, cout, kernel, stride, pad, dims, gscale):
+    from avtex import train_ops
+    torch.manual_seed(cin + cout)
+    b, t, h, w = dims
+    conv = nn.Conv3d(cin, cout, kernel, stride=stride, padding=pad, bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+    x0 = _cl(torch.randn(b, cin, t, h, w, device=DEV))
+    assert train_ops.conv_fusable(x0, conv)
+
+    def run(fused):
+        conv.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = train_ops.conv3d(x, conv) if fused else conv(x)
+        gy = _cl(torch.randn(y.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(7)) * gscale)
+        y.backward(gy)
+        return y.detach(), x.grad, conv.weight.grad.clone()
+
+    ya, dxa, dwa = run(True)
+    ye, dxe, dwe = run(False)
+    rel = lambda u, v: float((u - v).norm()) / (float(v.norm()) + 1e-30)
+    assert ya.shape == ye.shape
+    assert rel(ya, ye) < 2e-6, rel(ya, ye)      # fp16 planes: 2^-22 per product against fp32's own rounding
+    assert rel(dxa, dxe) < 2e-5, rel(dxa, dxe)  # bf16 planes (fp32's exponent range): 2^-16 per product, averaged over K
+    assert rel(dwa, dwe) < 1e-5, rel(dwa, dwe)  # MIOpen's wgrad both ways (atomics: not bitwise)
+
+
+def test_weight_planes_follow_the_optimizer():
+    from avtex import train_ops
+    conv = nn.Conv3d(16, 16, (1, 3, 3), padding=(0, 1, 1), bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+    x = _cl(torch.randn(1, 16, 2, 8, 8, device=DEV))
+    y0 = train_ops.conv3d(x, conv).detach()
+    with torch.no_grad():
+        conv.weight.mul_(2.0)  # in-place, as SGD updates
+    y1 = train_ops.conv3d(x, conv).detach()
+    assert torch.allclose(y1, 2 * y0, rtol=1e-6, atol=1e-6)
+
+
+def test_falls_back_outside_its_domain():
+    from avtex import train_ops
+    stem = nn.Conv3d(3, 64, (1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3), bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+    x = _cl(torch.randn(1, 3, 2, 32, 32, device=DEV))
+    assert not train_ops.conv_fusable(x.clone().requires_grad_(True), stem)   # 3 channels AND an input gradient wanted
+    conv = nn.Conv3d(16, 16, (1, 3, 3), bias=False).to(DEV).train()
+    assert not train_ops.conv_fusable(torch.randn(1, 16, 2, 8, 8, device=DEV), conv)   # model not in the training layout
+    conv = conv.to(memory_format=torch.channels_last_3d)
+    xn = torch.randn(1, 16, 2, 8, 8, device=DEV)                                       # an NCDHW input is transposed once
+    assert train_ops.conv_fusable(xn, conv) and torch.allclose(train_ops.conv3d(xn, conv), conv(xn), rtol=1e-5, atol=1e-5)
+    conv.eval()
+    assert not train_ops.conv_fusable(_cl(torch.randn(1, 16, 2, 8, 8, device=DEV)), conv)
+    xg = x.clone().requires_grad_(True)
+    assert torch.equal(train_ops.conv3d(xg, stem), stem(xg))
+
+
+@pytest.mark.parametrize("kt", [1, 5])
+def test_stem_runs_on_zero_padded_channels(kt):
+    """The stems (3 input channels, models/models.py:565-584's SlowFast): forward on the kernel over a clip padded to 8
+    channels, weight gradient through MIOpen on the original clip."""
+    from avtex import train_ops
+    torch.manual_seed(kt)
+    stem = nn.Conv3d(3, 64 if kt == 1 else 8, (kt, 7, 7), stride=(1, 2, 2), padding=(kt // 2, 3, 3), bias=False).to(DEV)
+    stem = stem.to(memory_format=torch.channels_last_3d).train()
+    x = torch.randn(2, 3, 4, 32, 32, device=DEV)  # NCDHW, as the batcher hands clips over
+    assert train_ops.conv_fusable(x, stem)
+    y = train_ops.conv3d(x, stem)
+    gy = _cl(torch.randn(y.shape, device=DEV))
+    y.backward(gy)
+    dwa = stem.weight.grad.clone()
+    stem.zero_grad(set_to_none=True)
+    ye = stem(x)
+    ye.backward(gy)
+    rel = lambda u, v: float((u - v).norm()) / float(v.norm())
+    assert rel(y.detach(), ye.detach()) < 2e-6 and rel(dwa, stem.weight.grad) < 1e-5

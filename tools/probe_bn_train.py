@@ -40,6 +40,7 @@ def main():
             fast = fast.contiguous(memory_format=torch.channels_last_3d)
             slow = slow.contiguous(memory_format=torch.channels_last_3d)
         train_ops._FUSED = 1 if fused else 0
+        train_ops._CONV_X3 = 1 if fused == 2 else 0
         out = n([slow, fast])
         loss = (out.double() ** 2).mean()
         loss.backward()
@@ -50,7 +51,8 @@ def main():
     l64, g64 = step(torch.float64, False, False)
     r64 = run[0]
     print("fp64 loss %.9f" % l64)
-    for name, cl, fused in (("fp32 stock NCDHW", False, False), ("fp32 stock channels-last", True, False), ("fp32 FUSED channels-last", True, True)):
+    for name, cl, fused in (("fp32 stock NCDHW", False, 0), ("fp32 stock channels-last", True, 0), ("fp32 FUSED BatchNorm channels-last", True, 1),
+                            ("fp32 FUSED BatchNorm + x3 convolutions", True, 2)):
         l, g = step(torch.float32, cl, fused)
         rows = []
         num = den = 0.0
@@ -97,7 +99,7 @@ def main():
         return y
 
     slowfast.bn_act = spy
-    step(torch.float32, True, True)
+    step(torch.float32, True, 2)
     slowfast.bn_act = real
     print("bn_act calls: %d, fused %d" % (len(calls), sum(c[2] for c in calls)))
     calls.sort(reverse=True)
