@@ -1,0 +1,339 @@
+// conv3d_wgrad_x3 — the WEIGHT gradient of the training convolutions on the split-plane MFMA arithmetic (the third piece
+// of the training step next to conv_x3's IO32 forward / input-gradient form; contrastive_video_textures/train.py:114-141
+// runs it through autograd -> MIOpen, whose fp32 bwd_weight kernels were 37 % of the step, profiles/r02/
+// train_fp32_default_kernels.log):
+//     dW[co][tap][ci] = sum over output positions m of  dY[m][co] * X[in(m, tap)][ci]
+// a GEMM whose REDUCTION runs over the rows of both operands ([positions, channels] fp32 NDHWC rows): both arrive
+// transposed for the matrix pipe.  Nothing is transposed on the way in: a 64-position slab of either operand is read with
+// coalesced 16-byte loads (32 lanes = 512 contiguous bytes of a row), split into bf16 hi / lo planes with the hardware
+// pair conversion (v_cvt_pk_bf16_f32: 3 VALU operations per element, already packed) and written to the LDS as it lies,
+// [position][channel], 256-byte rows with the chunk swizzle of the CDNA4 guide; the MFMA operands are then fetched with
+// gfx950's TRANSPOSING read, ds_read_b64_tr_b16 (a 4-position x 16-channel block per 16 lanes, delivered channel-major):
+// two of them make the 8 reduction values a lane owes for its channel row.  (The first version transposed on the way in —
+// a lane per position, one ds_write_b16 per element — and lost to MIOpen: its global loads touched 64 cache lines per
+// instruction; profiles/r02/train_wgrad_v1_uncoalesced.log.)  bf16 planes, not fp16: dY needs fp32's exponent range.
+// Per product: dyh*xh + dyh*xl + dyl*xh into one fp32 accumulator (2^-16), like conv_x3.
+// The x operand's axis is (tap, ci) FLATTENED (E = taps * Cin, dW is [co][E]): im2col rows that are never materialised — a
+// float4 of x is fetched from the row its tap points at (per-slab table of 64 positions x taps offsets, padding = -1) —
+// so an 8-channel 3x3 layer fills 72 of a tile's 128 rows and reads dY once, not 8 of 128 nine times over.
+// Work split: one workgroup = (chunk of slabs, 128 of the longer axis, BN of the shorter one); partial tiles are added into
+// dW with hardware fp32 atomics (dW is zeroed first; the order is not deterministic, as MIOpen's is not).  Strides,
+// padding and ragged edges live in the table; channel counts in multiples of 8; at most 28 taps (3x3x3, 7x1x1).
+#include <stdlib.h>
+
+#include "avt_common.h"
+#include "conv_args.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxTaps = 28;  // taps of one convolution the position table holds (3x3x3 = 27; the 7x1x1 lateral ones = 7)
+
+struct WgArgs {
+  const float* dy;  // [M, ldy]
+  const float* x;   // [B*T*H*W, ldx]
+  float* dw;        // [Cout][E], E = taps * Cin: the x operand's axis is (tap, ci) flattened — im2col rows, never materialised
+  int B, T, H, W, To, Ho, Wo, KT, KH, KW, st, sh, sw, pt, ph, pw;
+  int Cin, Cout, ldx, ldy, M, taps, E;
+  int r_tiles, s_tiles;  // tiles of the 128-wide / BN-wide operand axis
+  int nslab, slabs_per_chunk, nchunk;
+  FastDiv dWo, dHo, dTo, dKW, dKH, dCin;
+};
+
+__device__ __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kPlane = 64 * 256;  // one plane of one operand: [64 positions][128 channels x 2 B]
+
+// byte offset of 16-byte chunk `ch` (8 channels) of position row `row`: 256-byte rows, chunks XOR-swizzled so that the row
+// writes and the transposed reads are both conflict-free (cdna_hip_programming.md T10, image (b))
+__device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// four consecutive channels of one position -> 8 bytes of the hi plane + 8 bytes of the lo plane
+__device__ __forceinline__ void put4(char* lds, int hi_base, int off, float4 v) {
+  const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2));
+  const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.z, v.w}, bf16x2));
+  const float r0 = v.x - __builtin_bit_cast(float, h01 << 16), r1 = v.y - __builtin_bit_cast(float, h01 & 0xFFFF0000u);
+  const float r2 = v.z - __builtin_bit_cast(float, h23 << 16), r3 = v.w - __builtin_bit_cast(float, h23 & 0xFFFF0000u);
+  const uint32_t l01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+  const uint32_t l23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r2, r3}, bf16x2));
+  *reinterpret_cast<uint2*>(lds + hi_base + off) = make_uint2(h01, h23);
+  *reinterpret_cast<uint2*>(lds + hi_base + kPlane + off) = make_uint2(l01, l23);
+}
+
+// SWAP = false: the 128-wide axis is x's (tap, ci), the BN-wide one dy's co; true: the other way round (Cout > taps * Cin).
+template <int BN, bool SWAP>
+__global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
+  constexpr int BM = 128;
+  constexpr int WTM = BN == 32 ? 32 : 64;
+  constexpr int WAVES_M = BM / WTM, WAVES_N = 4 / WAVES_M, WN = BN / WAVES_N;
+  constexpr int NT = WN / 32, MT = WTM / 32;
+  constexpr int RQ = 8, SQ = BN / 16;  // float4 loads per thread and slab
+  constexpr int XQ = SWAP ? SQ : RQ;   // ... of which belong to the x operand
+  constexpr int XW = SWAP ? BN : BM;   // width of the x operand's tile
+  constexpr int R_HI = 0, S_HI = 2 * kPlane, YTAB = 4 * kPlane, XTAB = YTAB + 2 * 64 * 4;
+  static_assert(NT >= 1 && MT >= 1, "tile");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int* const ytab = reinterpret_cast<int*>(lds + YTAB);  // [2][64]: element offset of a position's dy row, -1 = none
+  int* const xtab = reinterpret_cast<int*>(lds + XTAB);  // [2][64][kMaxTaps]: ... of its x row under every tap, -1 = padding
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // work item: s-tile fastest (neighbours share the 128-wide operand's slabs), then r-tile, chunk
+  int b_ = blockIdx.x;
+  const int ts = b_ % a.s_tiles; b_ /= a.s_tiles;
+  const int tr = b_ % a.r_tiles;
+  const int chunk = b_ / a.r_tiles;
+  const int r0 = tr * BM, s0 = ts * BN;
+  const int slab0 = chunk * a.slabs_per_chunk;
+  const int slab1 = min(a.nslab, slab0 + a.slabs_per_chunk);
+  const int x0 = SWAP ? s0 : r0, y0 = SWAP ? r0 : s0;  // first (tap, ci) index / first co of this tile
+
+  // the x operand's loads: thread-constant (tap, ci) of each float4
+  int xtap[XQ], xci[XQ];
+#pragma unroll
+  for (int q = 0; q < XQ; ++q) {
+    const int idx = q * 256 + tid, e = x0 + 4 * (idx % (XW / 4));
+    xtap[q] = e < a.E ? (int)fastdiv((uint32_t)e, a.dCin) : -1;
+    xci[q] = e - xtap[q] * a.Cin;
+  }
+
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto decode = [&](int slab, int buf) {  // thread -> position tid & 63, taps (tid >> 6), + 4, + 8, ...
+    const int p = tid & 63, m = slab * 64 + p;
+    const bool ok = m < a.M;
+    const int q1 = (int)fastdiv((uint32_t)(ok ? m : 0), a.dWo), wo = (ok ? m : 0) - q1 * a.Wo;
+    const int q2 = (int)fastdiv((uint32_t)q1, a.dHo), ho = q1 - q2 * a.Ho;
+    const int bb = (int)fastdiv((uint32_t)q2, a.dTo), to = q2 - bb * a.To;
+    if (tid < 64) ytab[buf * 64 + p] = ok ? m * a.ldy : -1;
+    for (int tap = tid >> 6; tap < a.taps; tap += 4) {
+      const int t1 = (int)fastdiv((uint32_t)tap, a.dKW), dw_ = tap - t1 * a.KW;
+      const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
+      const int ti = to * a.st - a.pt + dt, hi = ho * a.sh - a.ph + dh, wi = wo * a.sw - a.pw + dw_;
+      const bool in = ok && (unsigned)ti < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      xtab[(buf * 64 + p) * kMaxTaps + tap] = in ? (((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx : -1;
+    }
+  };
+  float4 rq[RQ], sq[SQ];
+  auto gload = [&](int buf) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int idx = q * 256 + tid, p = idx >> 5;
+      if constexpr (SWAP) {
+        const int c = r0 + 4 * (idx & 31), row = ytab[buf * 64 + p];
+        rq[q] = (row >= 0 && c < a.Cout) ? *reinterpret_cast<const float4*>(a.dy + (int64_t)row + c) : z;
+      } else {
+        const int row = xtap[q] >= 0 ? xtab[(buf * 64 + p) * kMaxTaps + xtap[q]] : -1;
+        rq[q] = row >= 0 ? *reinterpret_cast<const float4*>(a.x + (int64_t)row + xci[q]) : z;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+      const int idx = q * 256 + tid, p = idx / (BN / 4);
+      if constexpr (SWAP) {
+        const int row = xtap[q] >= 0 ? xtab[(buf * 64 + p) * kMaxTaps + xtap[q]] : -1;
+        sq[q] = row >= 0 ? *reinterpret_cast<const float4*>(a.x + (int64_t)row + xci[q]) : z;
+      } else {
+        const int c = s0 + 4 * (idx % (BN / 4)), row = ytab[buf * 64 + p];
+        sq[q] = (row >= 0 && c < a.Cout) ? *reinterpret_cast<const float4*>(a.dy + (int64_t)row + c) : z;
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int idx = q * 256 + tid, p = idx >> 5, cq = idx & 31;
+      put4(lds, R_HI, swz(p, cq >> 1) + 8 * (cq & 1), rq[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+      const int idx = q * 256 + tid, p = idx / (BN / 4), cq = idx % (BN / 4);
+      put4(lds, S_HI, swz(p, cq >> 1) + 8 * (cq & 1), sq[q]);
+    }
+  };
+  // transposed-read addresses at k-slice 0 (T10: lane 4q + p of a 16-lane group supplies row q, channels 4p .. 4p + 3 of
+  // the block; groups 0 / 1 = channels 0-15 / 16-31 of the 32-row operand block, groups 2 / 3 the same for positions + 8).
+  // A k-slice is 16 positions = 4096 bytes further: + 16 rows leaves the swizzle's (row & 3) and (row >> 2) & 3 alone.
+  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  int raddr[MT][2], saddr[NT][2];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+      raddr[j][h2] = R_HI + swz(8 * (g >> 1) + 4 * h2 + tq, (wm * WTM + j * 32 + 16 * (g & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+      saddr[i][h2] = S_HI + swz(8 * (g >> 1) + 4 * h2 + tq, (wn * WN + i * 32 + 16 * (g & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+  auto frag = [&](int a0, int a1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0)));
+    const uint2 v = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1)));
+    return i32x4{(int)u.x, (int)u.y, (int)v.x, (int)v.y};
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      i32x4 rh[MT], rl[MT], sh_[NT], sl[NT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        rh[j] = frag(raddr[j][0] + 4096 * ks, raddr[j][1] + 4096 * ks);
+        rl[j] = frag(raddr[j][0] + kPlane + 4096 * ks, raddr[j][1] + kPlane + 4096 * ks);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        sh_[i] = frag(saddr[i][0] + 4096 * ks, saddr[i][1] + 4096 * ks);
+        sl[i] = frag(saddr[i][0] + kPlane + 4096 * ks, saddr[i][1] + kPlane + 4096 * ks);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          acc[i][j] = mfma(sl[i], rh[j], acc[i][j]);  // small terms first
+          acc[i][j] = mfma(sh_[i], rl[j], acc[i][j]);
+          acc[i][j] = mfma(sh_[i], rh[j], acc[i][j]);
+        }
+    }
+  };
+
+  if (slab0 < slab1) {
+    decode(slab0, slab0 & 1);
+    __syncthreads();
+    gload(slab0 & 1);
+  }
+  for (int s = slab0; s < slab1; ++s) {
+    if (s + 1 < slab1) decode(s + 1, (s + 1) & 1);
+    __syncthreads();  // the previous slab's fragments have been read; the next slab's table is written
+    lstore();
+    __syncthreads();
+    if (s + 1 < slab1) gload((s + 1) & 1);  // in flight under the MFMAs
+    compute();
+  }
+
+  // D layout: column (lane & 31) = index on the 128-wide axis, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = index on the other.
+  // dW is [co][e]: consecutive lanes must walk e for the atomics to coalesce.  Not swapped, they do.  Swapped, lanes walk co
+  // (rows 4 E bytes apart): the tile goes through the LDS first.
+  if constexpr (!SWAP) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int e = r0 + wm * WTM + j * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = s0 + wn * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.E + e, acc[i][j][r]);
+        }
+      }
+  } else {
+    constexpr int ES = BN + 1;  // floats per staged row (co), padded: a wave's 32 co rows hit 32 banks
+    float* const stage = reinterpret_cast<float*>(lds);
+    __syncthreads();  // the last slab's fragments have been read
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int col = wm * WTM + j * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[col * ES + wn * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[i][j][r];
+      }
+    __syncthreads();
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+      const int col = idx / BN, el = idx % BN;
+      const int co = r0 + col, e = s0 + el;
+      if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.E + e, stage[col * ES + el]);
+    }
+  }
+  (void)y0;
+}
+
+template <int BN, bool SWAP>
+int launch(WgArgs& a, int s_count, hipStream_t st) {
+  a.s_tiles = (s_count + BN - 1) / BN;
+  const int tiles = a.r_tiles * a.s_tiles;
+  // split over positions: enough workgroups to fill the chip (256 CUs x 2), but at least 16 slabs each — a workgroup's
+  // epilogue is 128 x BN atomics, and with 3 slabs apiece the pointwise layers spent their time there
+  // (profiles/r02/probe_wgrad_v2.log: 16 TFLOP/s on 256 -> 1024 channels)
+  int chunks = (1024 + tiles - 1) / tiles;
+  const int most = a.nslab / 16 > 1 ? a.nslab / 16 : 1;
+  if (chunks > most) chunks = most;
+  if (chunks < 1) chunks = 1;
+  a.slabs_per_chunk = (a.nslab + chunks - 1) / chunks;
+  a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
+  constexpr int lds_bytes = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTaps * 4;
+  static_assert(128 * (BN + 1) * 4 <= lds_bytes, "the swapped epilogue stages its tile over the operand planes (and tables)");
+  static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<BN, SWAP>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_conv3d_wgrad_x3_f32: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  const int64_t grid = (int64_t)tiles * a.nchunk;
+  AVT_REQUIRE(grid < (1ll << 31), "avt_conv3d_wgrad_x3_f32: grid too large");
+  hipLaunchKernelGGL((wgrad_x3_kernel<BN, SWAP>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
+  return avt::check_launch("avt_conv3d_wgrad_x3_f32");
+}
+
+template <bool SWAP>
+int dispatch(WgArgs& a, int r_count, int s_count, hipStream_t s) {
+  a.r_tiles = (r_count + 127) / 128;
+  if (s_count <= 32) return launch<32, SWAP>(a, s_count, s);
+  if (s_count <= 64) return launch<64, SWAP>(a, s_count, s);
+  return launch<128, SWAP>(a, s_count, s);
+}
+
+}  // namespace
+
+extern "C" int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
+                                       int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldx, int ldy,
+                                       void* stream) {
+  AVT_REQUIRE(dy && x && dw, "avt_conv3d_wgrad_x3_f32: NULL pointer");
+  AVT_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 8 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= cin && ldy >= cout,
+              "avt_conv3d_wgrad_x3_f32: channel counts in multiples of 8, row strides in multiples of 4 covering them");
+  AVT_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && kt * kh * kw <= kMaxTaps && st >= 1 && sh >= 1 && sw >= 1,
+              "avt_conv3d_wgrad_x3_f32: 1..%d kernel taps, strides >= 1", kMaxTaps);
+  AVT_REQUIRE(avt::aligned16(dy) && avt::aligned16(x) && avt::aligned16(dw), "avt_conv3d_wgrad_x3_f32: pointers must be 16-byte aligned");
+  WgArgs a = {};
+  a.dy = dy; a.x = x; a.dw = dw;
+  a.B = batch; a.T = t; a.H = h; a.W = w;
+  a.To = (t + 2 * pt - kt) / st + 1; a.Ho = (h + 2 * ph - kh) / sh + 1; a.Wo = (w + 2 * pw - kw) / sw + 1;
+  AVT_REQUIRE(batch > 0 && a.To > 0 && a.Ho > 0 && a.Wo > 0, "avt_conv3d_wgrad_x3_f32: empty output");
+  const int64_t M = (int64_t)batch * a.To * a.Ho * a.Wo;
+  AVT_REQUIRE(M < (1ll << 31) - 64 && M * ldy < (1ll << 31) && (int64_t)batch * t * h * w * ldx < (1ll << 31),
+              "avt_conv3d_wgrad_x3_f32: tensors too large for 32-bit element offsets");
+  a.KT = kt; a.KH = kh; a.KW = kw; a.st = st; a.sh = sh; a.sw = sw; a.pt = pt; a.ph = ph; a.pw = pw;
+  a.Cin = cin; a.Cout = cout; a.ldx = ldx; a.ldy = ldy; a.M = (int)M; a.taps = kt * kh * kw;
+  a.E = a.taps * cin;
+  a.dCin = make_fastdiv((uint32_t)cin);
+  a.nslab = (int)((M + 63) / 64);
+  a.dWo = make_fastdiv((uint32_t)a.Wo); a.dHo = make_fastdiv((uint32_t)a.Ho); a.dTo = make_fastdiv((uint32_t)a.To);
+  a.dKW = make_fastdiv((uint32_t)kw); a.dKH = make_fastdiv((uint32_t)kh);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cout * a.taps * cin, s) != hipSuccess) {
+    avt::set_error("avt_conv3d_wgrad_x3_f32: hipMemsetAsync failed");
+    return AVT_ERR_LAUNCH;
+  }
+  // the longer axis — x's (tap, ci) or dy's co — takes the 128-wide side of the tile
+  if (cout > a.E) return dispatch<true>(a, cout, a.E, s);
+  return dispatch<false>(a, a.E, cout, s);
+}

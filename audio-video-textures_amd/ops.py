@@ -333,6 +333,17 @@ def conv3d_igemm_x3_f32(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, ker
                "avt_conv3d_igemm_x3_f32")
 
 
+def conv3d_wgrad_x3_f32(dy, x, dw, dims, cin, cout, kernel, stride, pad, ldx, ldy):
+    """dw [cout, taps, cin] fp32 = weight gradient of the convolution (csrc/wgrad_x3.hip); dy / x fp32 NDHWC rows; dims = x's (B,T,H,W)."""
+    b, t, h, w = dims
+    _dev(dy, "dy", torch.float32)
+    _dev(x, "x", torch.float32)
+    _dev(dw, "dw", torch.float32)
+    _lib.check(_lib.lib().avt_conv3d_wgrad_x3_f32(_p(dy), _p(x), _p(dw), int(b), int(t), int(h), int(w), int(cin), int(cout),
+                                                  *[int(k) for k in kernel], *[int(v) for v in stride], *[int(v) for v in pad],
+                                                  int(ldx), int(ldy), _stream()), "avt_conv3d_wgrad_x3_f32")
+
+
 def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True):
     """stem_conv on plane pairs (contract-grade mode); wt_hi / wt_lo = fused_slowfast.stem_lds_image of each weight plane."""
     _dev(wt_hi, "wt_hi", torch.bfloat16)

@@ -14,6 +14,7 @@ from . import _lib
 
 _FUSED = int(os.environ.get("AVT_FUSED_BN", "1"))
 _CONV_X3 = int(os.environ.get("AVT_TRAIN_CONV_X3", "1"))
+_WGRAD_X3 = int(os.environ.get("AVT_TRAIN_WGRAD_X3", "1"))
 
 
 def _p(t):
@@ -97,7 +98,8 @@ def bn_act(x, bn, res=None, relu=True):
 # Conv3d(bias=False) with channel counts in multiples of 8, and the input gradient of the stride-1 ones (a convolution of
 # dy with the flipped, transposed filter).  fp32 tensors in and out; 2^-22 (forward, fp16 planes) / 2^-16 (dgrad, bf16
 # planes: gradients need fp32's exponent range) per product instead of the fp32 MFMA's rate of 1/16 of the bf16 pipe.
-# The weight gradient stays MIOpen's (aten.convolution_backward, wgrad only); so do the strided dgrads.
+# The weight gradient is csrc/wgrad_x3.hip (bf16 planes, transposing LDS stage, split over positions with fp32 atomics);
+# the strided dgrads and the stems' weight gradient stay MIOpen's (aten.convolution_backward).
 _TABS, _PLANES = {}, {}
 
 
@@ -173,8 +175,13 @@ class _ConvX3(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last_3d)
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
-                                                     [False, True, False])[1]
+            if _WGRAD_X3 and cin % 8 == 0 and weight.is_contiguous(memory_format=torch.channels_last_3d):
+                dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
+                ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1),
+                                        (x.shape[0], x.shape[2], x.shape[3], x.shape[4]), cin, cout, kernel, stride, padding, cin, cout)
+            else:  # the stems (3 input channels): MIOpen
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
+                                                         [False, True, False])[1]
         if ctx.needs_input_grad[0]:
             if cin % 8 == 0 and stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(padding, kernel)):
                 dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding)

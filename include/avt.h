@@ -399,6 +399,14 @@ int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_l
                             int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype,
                             void* stream);
 
+/* Weight gradient of the same convolution on the split-plane arithmetic (csrc/wgrad_x3.hip; bf16 planes, 2^-16 per
+ * product): dw[cout][kt*kh*kw][cin] (the memory of a channels_last_3d Conv3d weight) = sum over output positions of
+ * dy[m][co] * x[in(m, tap)][ci]; dy fp32 rows [batch*to*ho*wo, ldy], x fp32 rows [batch*t*h*w, ldx].  dw is zeroed by the
+ * call and accumulated with fp32 atomics (summation order not deterministic).  Any stride / padding. */
+int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
+                            int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldx, int ldy,
+                            void* stream);
+
 /* SuperSloMo interpolation at the jumps of the stitched video (contrastive_video_textures/interpolate.py:75-147, called from
  * validate.py:588-611): the passes around the two UNets, whose convolutions are avt_conv3d_igemm_x3 with relu = 2
  * (csrc/interp.hip).  Plane pairs as above (plane_dtype AVT_X3_*), NHWC rows; `mean3` is a HOST array of 3 floats.

@@ -44,7 +44,8 @@ def test_conv_forward_and_gradients_match_fp32_autograd(cin, cout, kernel, strid
     assert ya.shape == ye.shape
     assert rel(ya, ye) < 2e-6, rel(ya, ye)      # fp16 planes: 2^-22 per product against fp32's own rounding
     assert rel(dxa, dxe) < 2e-5, rel(dxa, dxe)  # bf16 planes (fp32's exponent range): 2^-16 per product, averaged over K
-    assert rel(dwa, dwe) < 1e-5, rel(dwa, dwe)  # MIOpen's wgrad both ways (atomics: not bitwise)
+    print("conv %s: fwd %.2e dx %.2e dw %.2e" % ((cin, cout, kernel, stride), rel(ya, ye), rel(dxa, dxe), rel(dwa, dwe)))
+    assert rel(dwa, dwe) < 1e-4, rel(dwa, dwe)  # csrc/wgrad_x3.hip: bf16 planes rounded half away, 2^-16 per product
 
 
 def test_weight_planes_follow_the_optimizer():
@@ -92,4 +93,27 @@ def test_stem_runs_on_zero_padded_channels(kt):
     ye = stem(x)
     ye.backward(gy)
     rel = lambda u, v: float((u - v).norm()) / float(v.norm())
-    assert rel(y.detach(), ye.detach()) < 2e-6 and rel(dwa, stem.weight.grad) < 1e-5
+    assert rel(y.detach(), ye.detach()) < 2e-6 and rel(dwa, stem.weight.grad) < 1e-5   # (the stems' wgrad is MIOpen's)
+
+
+@pytest.mark.parametrize("cin,cout,kernel,stride,pad,dims", [
+    (16, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 5, 7)),          # fewer positions than one slab
+    (24, 40, (3, 3, 3), (1, 2, 2), (1, 1, 1), (2, 3, 9, 11)),         # ragged everything, channel counts not powers of two
+    (136, 264, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 9, 9)),        # more than one tile on both sides, swapped operands
+    (264, 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 9, 9)),
+])
+def test_weight_gradient_kernel_edges(cin, cout, kernel, stride, pad, dims):
+    from avtex import ops
+    torch.manual_seed(cin)
+    b, t, h, w = dims
+    x = torch.randn(b, cin, t, h, w, device=DEV)
+    wgt = torch.randn(cout, cin, *kernel, device=DEV, requires_grad=True)
+    y = torch.nn.functional.conv3d(x, wgt, stride=stride, padding=pad)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dw = torch.empty((cout,) + tuple(kernel) + (cin,), device=DEV)
+    ops.conv3d_wgrad_x3_f32(gy.permute(0, 2, 3, 4, 1).contiguous(), x.permute(0, 2, 3, 4, 1).contiguous(), dw, (b, t, h, w), cin, cout,
+                            kernel, stride, pad, cin, cout)
+    exp = wgt.grad.permute(0, 2, 3, 4, 1)
+    err = float((dw - exp).norm()) / float(exp.norm())
+    assert err < 1e-4, err
