@@ -29,7 +29,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BM = 128, BN = 128;
+constexpr int BM = 128;
 constexpr int ROWB = 128;        // data bytes per row per K-step
 constexpr int LSTR = 144;        // LDS row stride in bytes (ROWB + 16 pad)
 constexpr int PLANE = 128 * LSTR;  // bytes of one operand plane in LDS
@@ -82,10 +82,20 @@ __device__ __forceinline__ uint4 load_chunk(const char* base, int64_t row, int64
   return v;
 }
 
-template <int MODE, bool ALIGNED>
+// TN = columns (target rows) per tile: 128, or 64 (AVT_SIM_F32_TN=64, f32 mode) — half the accumulators (96 + 32 registers
+// instead of 96 + 64) let a FOURTH workgroup share a CU, and 4096 x 4096 is then 2048 tiles over 1024 slots = two full
+// rounds instead of 1024 over 768 = one round and a third; an output element's k order, hence its bits, does not depend on
+// the tile shape.  Measured, f32 mode, fraction of the 157 TFLOP/s peak (128 | 64): N = 2048: 0.59 | 0.60, 4096: 0.69 | 0.66,
+// 16384: 0.82 | 0.79 — the narrower tile loses more per tile than the even rounds give back, so 128 stays the default; the
+// gap between 4096^2 and 16384^2 is the ramp and the tail of a 0.7 ms launch, not the K loop.
+template <int MODE, bool ALIGNED, int TN>
 __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
   using C = Cfg<MODE>;
   constexpr int NPL = C::NPL;
+  constexpr int NN = TN / 64;         // 32-column MFMA blocks per wave
+  constexpr int BU = TN / 32;         // B chunks per thread and plane
+  constexpr int BPLANE = TN * LSTR;   // bytes of one B plane
+  constexpr int BBASE = NPL * PLANE;  // B planes follow the A planes
   // LDS (dynamic, 2*NPL planes): [A planes][B planes], each 128 rows x 144 B
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -96,52 +106,62 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
   const int qd = a.nblk / 8, rm = a.nblk % 8, x = bid % 8;
   const int swz = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + bid / 8;
   const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
-  const int64_t row0 = (int64_t)tm * BM, col0 = (int64_t)tn * BN;
+  const int64_t row0 = (int64_t)tm * BM, col0 = (int64_t)tn * TN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int lr = lane & 31, lh = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NN];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NN; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
   // staging registers: per plane 4 chunks per thread (1024 chunks / 256 threads)
-  uint4 ra[NPL][4], rb[NPL][4];
+  uint4 ra[NPL][4], rb[NPL][BU];
   const int nk = (a.d + C::BK - 1) / C::BK;
 
   // one staging load (piece p of the slab kt: plane, chunk, operand)
+  constexpr int PPP = 4 + BU;  // pieces per plane: 4 chunks of A, BU of B
   auto gpiece = [&](int kt, int p) {
     const int k0 = kt * C::BK;
-    const int op = p & 1, u = (p >> 1) & 3, pl = p >> 3;
-    const int c = tid + u * 256, r = c >> 3, c16 = c & 7;
-    if (op == 0) ra[pl][u] = load_chunk<C::ELEM, ALIGNED>(a.q[pl], row0 + r, a.nq, a.d, k0, c16);
-    else rb[pl][u] = load_chunk<C::ELEM, ALIGNED>(a.t[pl], col0 + r, a.nt, a.d, k0, c16);
+    const int pl = p / PPP, r_ = p % PPP;
+    if (r_ < 4) {
+      const int c = tid + r_ * 256, r = c >> 3, c16 = c & 7;
+      ra[pl][r_] = load_chunk<C::ELEM, ALIGNED>(a.q[pl], row0 + r, a.nq, a.d, k0, c16);
+    } else {
+      const int u = r_ - 4, c = tid + u * 256, r = c >> 3, c16 = c & 7;
+      rb[pl][u] = load_chunk<C::ELEM, ALIGNED>(a.t[pl], col0 + r, a.nt, a.d, k0, c16);
+    }
   };
-  constexpr int NPIECE = 8 * NPL;
+  constexpr int NPIECE = PPP * NPL;
   auto gload = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) gpiece(kt, p);
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int p = 0; p < NPL; ++p)
+    for (int p = 0; p < NPL; ++p) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = tid + u * 256, r = c >> 3, c16 = c & 7;
         *reinterpret_cast<uint4*>(lds + p * PLANE + r * LSTR + c16 * 16) = ra[p][u];
-        *reinterpret_cast<uint4*>(lds + (NPL + p) * PLANE + r * LSTR + c16 * 16) = rb[p][u];
       }
+#pragma unroll
+      for (int u = 0; u < BU; ++u) {
+        const int c = tid + u * 256, r = c >> 3, c16 = c & 7;
+        *reinterpret_cast<uint4*>(lds + BBASE + p * BPLANE + r * LSTR + c16 * 16) = rb[p][u];
+      }
+    }
   };
 
   // this lane's fragment row addresses (bytes) inside a plane
   const int arow = (wr * 64 + lr) * LSTR + lh * 16;
-  const int brow = (wc * 64 + lr) * LSTR + lh * 16;
+  const int brow = (wc * (TN / 2) + lr) * LSTR + lh * 16;
 
   // f32 mode: the next slab's staging loads are issued between the MFMA groups of this slab, not as a burst in front of
   // them (a burst stalls the wave on the CU's vector-memory issue path — 31 % of a workgroup's time in the conv tiles'
@@ -153,42 +173,43 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {  // 4 sub-steps of 32 bytes of K per row
       if (MODE == AVT_SIM_F32) {
-        float4 fa[2], fb[2];
+        float4 fa[2], fb[NN];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          fa[m] = *reinterpret_cast<const float4*>(lds + arow + m * 32 * LSTR + ks * 32);
-          fb[m] = *reinterpret_cast<const float4*>(lds + PLANE + brow + m * 32 * LSTR + ks * 32);
-        }
+        for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const float4*>(lds + arow + m * 32 * LSTR + ks * 32);
+#pragma unroll
+        for (int n = 0; n < NN; ++n) fb[n] = *reinterpret_cast<const float4*>(lds + BBASE + brow + n * 32 * LSTR + ks * 32);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NN; ++n) {
               const float av = s == 0 ? fa[m].x : s == 1 ? fa[m].y : s == 2 ? fa[m].z : fa[m].w;
               const float bv = s == 0 ? fb[n].x : s == 1 ? fb[n].y : s == 2 ? fb[n].z : fb[n].w;
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
             }
-        if (more) {  // 8 pieces over the first 4 of the 16 (ks, s) groups... two per k-slice keeps them in the first half
+        if (more) {  // the slab's pieces over its first two k-slices: all out within the first half of the MFMAs
+          constexpr int HALF = (NPIECE + 1) / 2;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (ks < 2) gpiece(ktn, ks * 4 + e);
+          for (int e = 0; e < HALF; ++e)
+            if (ks < 2 && ks * HALF + e < NPIECE) gpiece(ktn, ks * HALF + e);
         }
       } else {
-        bf16x8 ah[2], bh[2], al[2], bl[2];
+        bf16x8 ah[2], bh[NN], al[2], bl[NN];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           ah[m] = *reinterpret_cast<const bf16x8*>(lds + arow + m * 32 * LSTR + ks * 32);
-          bh[m] = *reinterpret_cast<const bf16x8*>(lds + NPL * PLANE + brow + m * 32 * LSTR + ks * 32);
-          if (MODE == AVT_SIM_BF16X3) {
-            al[m] = *reinterpret_cast<const bf16x8*>(lds + PLANE + arow + m * 32 * LSTR + ks * 32);
-            bl[m] = *reinterpret_cast<const bf16x8*>(lds + (NPL + 1) * PLANE + brow + m * 32 * LSTR + ks * 32);
-          }
+          if (MODE == AVT_SIM_BF16X3) al[m] = *reinterpret_cast<const bf16x8*>(lds + PLANE + arow + m * 32 * LSTR + ks * 32);
+        }
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+          bh[n] = *reinterpret_cast<const bf16x8*>(lds + BBASE + brow + n * 32 * LSTR + ks * 32);
+          if (MODE == AVT_SIM_BF16X3) bl[n] = *reinterpret_cast<const bf16x8*>(lds + BBASE + BPLANE + brow + n * 32 * LSTR + ks * 32);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) {
+          for (int n = 0; n < NN; ++n) {
             if (MODE == AVT_SIM_BF16X3) {
               // small cross terms first, then the dominant hi*hi
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
@@ -217,8 +238,8 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int64_t col = col0 + wc * 64 + n * 32 + lr;
+    for (int n = 0; n < NN; ++n) {
+      const int64_t col = col0 + wc * (TN / 2) + n * 32 + lr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -227,11 +248,15 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
     }
 }
 
-template <int MODE>
-int launch(const Args& a, bool aligned, hipStream_t st) {
+template <int MODE, int TN>
+int launch(Args& a, bool aligned, hipStream_t st) {
+  const int64_t tiles_m = (a.nq + BM - 1) / BM, tiles_n = (a.nt + TN - 1) / TN;
+  AVT_REQUIRE(tiles_m * tiles_n < (1ll << 31), "avt_sim_gemm_nt: grid too large");
+  a.tiles_n = (int)tiles_n;
+  a.nblk = (int)(tiles_m * tiles_n);
   const dim3 grid((unsigned)a.nblk), block(256);
-  constexpr int lds_bytes = 2 * Cfg<MODE>::NPL * PLANE;
-  auto kern = aligned ? sim_gemm_kernel<MODE, true> : sim_gemm_kernel<MODE, false>;
+  constexpr int lds_bytes = Cfg<MODE>::NPL * (PLANE + TN * LSTR);
+  auto kern = aligned ? sim_gemm_kernel<MODE, true, TN> : sim_gemm_kernel<MODE, false, TN>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        lds_bytes);
@@ -269,17 +294,16 @@ extern "C" int avt_sim_gemm_nt(const void* q, const void* q_lo, const void* t, c
   a.temp = temp;
   a.out = out;
   a.ldo = ldo;
-  const int64_t tiles_m = (nq + BM - 1) / BM, tiles_n = (nt + BN - 1) / BN;
-  AVT_REQUIRE(tiles_m * tiles_n < (1ll << 31), "avt_sim_gemm_nt: grid too large");
-  a.tiles_n = (int)tiles_n;
-  a.nblk = (int)(tiles_m * tiles_n);
   const int epc = precision == AVT_SIM_F32 ? 4 : 8;
   bool aligned = (d % epc == 0) && avt::aligned16(q) && avt::aligned16(t);
   if (precision == AVT_SIM_BF16X3) aligned = aligned && avt::aligned16(q_lo) && avt::aligned16(t_lo);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (precision) {
-    case AVT_SIM_F32: return launch<AVT_SIM_F32>(a, aligned, st);
-    case AVT_SIM_BF16: return launch<AVT_SIM_BF16>(a, aligned, st);
-    default: return launch<AVT_SIM_BF16X3>(a, aligned, st);
+    case AVT_SIM_F32: {
+      static const int tn = avt::env_int_flag("AVT_SIM_F32_TN", 128);
+      return tn == 128 ? launch<AVT_SIM_F32, 128>(a, aligned, st) : launch<AVT_SIM_F32, 64>(a, aligned, st);
+    }
+    case AVT_SIM_BF16: return launch<AVT_SIM_BF16, 128>(a, aligned, st);
+    default: return launch<AVT_SIM_BF16X3, 128>(a, aligned, st);
   }
 }
