@@ -6,6 +6,7 @@ third of the step that is not convolution: MIOpenBatchNormFwdTrainSpatial, MIOpe
 add / ReLU / ReLU-backward passes (profiles/r02/train_fp32_steady_state_kernels.log)."""
 import ctypes as C
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -118,9 +119,10 @@ def _weight_planes(weight, transposed):
     changes the tensor.  transposed: the dgrad filter W'[ci, co, flipped taps], as bf16 planes."""
     from . import ops
     from .fused_slowfast import split_planes
-    key = (weight.data_ptr(), bool(transposed))
+    key = (id(weight), bool(transposed))
     hit = _PLANES.get(key)
-    if hit is not None and hit[0] == weight._version and hit[1] == tuple(weight.shape):
+    # (the entry remembers WHICH tensor it was made from: an id — like an address — can be reused after the first one died)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
         return hit[2]
     with torch.no_grad():
         w = weight.detach().float()
@@ -137,7 +139,10 @@ def _weight_planes(weight, transposed):
             sc = torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
             hi, lo = split_planes(wt * sc.view(-1, 1), ops.X3_F16)
             planes = (hi, lo, (1.0 / sc).float().contiguous())
-    _PLANES[key] = (weight._version, tuple(weight.shape), planes)
+    if len(_PLANES) > 4096:  # entries of models that are gone
+        for k in [k for k, v in _PLANES.items() if v[0]() is None]:
+            del _PLANES[k]
+    _PLANES[key] = (weakref.ref(weight), weight._version, planes)
     return planes
 
 

@@ -117,3 +117,22 @@ def test_weight_gradient_kernel_edges(cin, cout, kernel, stride, pad, dims):
     exp = wgt.grad.permute(0, 2, 3, 4, 1)
     err = float((dw - exp).norm()) / float(exp.norm())
     assert err < 1e-4, err
+
+
+def test_weight_plane_cache_is_per_tensor_not_per_address():
+    """Two models built one after the other can get the same addresses (and ids) for their weights: the cache must not hand
+    the second one the first one's planes."""
+    import gc
+
+    from avtex import train_ops
+    x = _cl(torch.randn(1, 16, 2, 8, 8, device=DEV))
+    outs = []
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        conv = nn.Conv3d(16, 16, (1, 3, 3), padding=(0, 1, 1), bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+        y = train_ops.conv3d(x, conv).detach()
+        assert torch.allclose(y, conv(x), rtol=1e-5, atol=1e-5)
+        outs.append(y)
+        del conv
+        gc.collect()
+    assert not torch.allclose(outs[0], outs[1])
