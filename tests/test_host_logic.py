@@ -270,3 +270,21 @@ def test_interpolated_timeline_follows_the_reference_bookkeeping():
     for bad in (1, 2, 4):
         with pytest.raises(AvtError):
             slowmo.IntpTimeline(bad)
+
+
+def test_training_passes_fall_back_to_torch_off_the_device():
+    """train_ops.bn_act / conv3d on CPU tensors (or in eval mode) are the stock torch ops — the fused HIP passes only take
+    channels-last fp32 device tensors in train mode — so the SlowFast module keeps working as a plain nn.Module."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from avtex import train_ops
+    torch.manual_seed(0)
+    bn = nn.BatchNorm3d(16).train()
+    x, r = torch.randn(2, 16, 2, 5, 5), torch.randn(2, 16, 2, 5, 5)
+    ref = nn.BatchNorm3d(16).train()
+    assert not train_ops.fusable(x, bn, r)
+    assert torch.equal(train_ops.bn_act(x, bn, res=r, relu=True), F.relu(ref(x) + r))
+    assert torch.equal(bn.running_mean, ref.running_mean) and int(bn.num_batches_tracked) == 1
+    conv = nn.Conv3d(16, 8, (1, 3, 3), padding=(0, 1, 1), bias=False).train()
+    assert not train_ops.conv_fusable(x, conv)
+    assert torch.equal(train_ops.conv3d(x, conv), conv(x))
