@@ -180,15 +180,18 @@ class _ConvX3(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last_3d)
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            if _WGRAD_X3 and cin % 8 == 0 and weight.is_contiguous(memory_format=torch.channels_last_3d):
+            taps = kernel[0] * kernel[1] * kernel[2]
+            if (_WGRAD_X3 and cin % 8 == 0 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64 and
+                    weight.is_contiguous(memory_format=torch.channels_last_3d)):
                 dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
                 ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1),
                                         (x.shape[0], x.shape[2], x.shape[3], x.shape[4]), cin, cout, kernel, stride, padding, cin, cout)
-            else:  # the stems (3 input channels): MIOpen
+            else:  # the stems (3 input channels, 49 / 245 taps): MIOpen
                 dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
                                                          [False, True, False])[1]
         if ctx.needs_input_grad[0]:
-            if cin % 8 == 0 and stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(padding, kernel)):
+            if (cin % 8 == 0 and stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(padding, kernel)) and
+                    dy.numel() < (1 << 30) - 64):
                 dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
@@ -208,8 +211,8 @@ def conv_fusable(x, conv):
 
 
 def conv3d(x, conv):
-    """conv(x) for a Conv3d module: the split-plane MFMA kernel in train mode on channels-last fp32 device tensors (forward
-    and stride-1 input gradient; weight gradient through MIOpen), the module itself otherwise."""
+    """conv(x) for a Conv3d module: the split-plane MFMA kernels in train mode on fp32 device tensors of a model in the
+    training layout (forward, stride-1 input gradient, weight gradient), the module itself otherwise."""
     if not conv_fusable(x, conv):
         return conv(x)
     if conv.in_channels % 8 and not x.is_contiguous(memory_format=torch.channels_last_3d):
