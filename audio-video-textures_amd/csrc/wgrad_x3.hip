@@ -40,6 +40,7 @@ struct WgArgs {
   int Cin, Cout, ldx, ldy, M, taps, E;
   int r_tiles, s_tiles;  // tiles of the 128-wide / BN-wide operand axis
   int nslab, slabs_per_chunk, nchunk;
+  int dbg;  // DIAGNOSTIC (AVT_WGRAD_DBG): 1 skip the LDS stage, 2 skip the MFMAs, 4 skip the global loads
   FastDiv dWo, dHo, dTo, dKW, dKH, dCin;
 };
 
@@ -89,8 +90,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int lr = lane & 31, lh = lane >> 5;
 
-  // work item: s-tile fastest (neighbours share the 128-wide operand's slabs), then r-tile, chunk
-  int b_ = blockIdx.x;
+  // work item: s-tile fastest (neighbours share the 128-wide operand's slabs), then r-tile, chunk — and neighbours in this
+  // list run on ONE XCD (blocks are dealt round-robin over the 8 XCDs, each with its own L2): all tiles of a chunk then
+  // meet their 64-position slabs of dY and X in that L2.  Dealt naively the kernel was bound by its global loads (phase-skip
+  // diagnostic, profiles/r02/probe_wgrad_phases.log: without them 2.1x faster, without the MFMAs 1.15x).
+  int b_ = avt::xcd_contiguous(blockIdx.x, gridDim.x);
   const int ts = b_ % a.s_tiles; b_ /= a.s_tiles;
   const int tr = b_ % a.r_tiles;
   const int chunk = b_ / a.r_tiles;
@@ -132,41 +136,68 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
     }
   };
   float4 rq[RQ], sq[SQ];
+  unsigned rmask = 0u, smask = 0u;  // which pieces are real (the others are zeroed when they are staged, not when they are loaded)
+  // Table reads first, all of them, then the 16-byte loads, all unconditional (an out-of-range piece reads the tensor's
+  // first bytes and is zeroed afterwards): written as `ok ? load : 0` per piece, every load sat behind its own LDS round trip
+  // and exec-mask branch, and the load phase was half of the kernel's time (profiles/r02/probe_wgrad_phases.log).
   auto gload = [&](int buf) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    int rrow[RQ], srow[SQ];
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
       const int idx = q * 256 + tid, p = idx >> 5;
-      if constexpr (SWAP) {
-        const int c = r0 + 4 * (idx & 31), row = ytab[buf * 64 + p];
-        rq[q] = (row >= 0 && c < a.Cout) ? *reinterpret_cast<const float4*>(a.dy + (int64_t)row + c) : z;
-      } else {
-        const int row = xtap[q] >= 0 ? xtab[(buf * 64 + p) * kMaxTaps + xtap[q]] : -1;
-        rq[q] = row >= 0 ? *reinterpret_cast<const float4*>(a.x + (int64_t)row + xci[q]) : z;
-      }
+      if constexpr (SWAP) rrow[q] = ytab[buf * 64 + p];
+      else rrow[q] = xtab[(buf * 64 + p) * kMaxTaps + (xtap[q] < 0 ? 0 : xtap[q])];
     }
 #pragma unroll
     for (int q = 0; q < SQ; ++q) {
       const int idx = q * 256 + tid, p = idx / (BN / 4);
+      if constexpr (SWAP) srow[q] = xtab[(buf * 64 + p) * kMaxTaps + (xtap[q] < 0 ? 0 : xtap[q])];
+      else srow[q] = ytab[buf * 64 + p];
+    }
+    rmask = smask = 0u;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int idx = q * 256 + tid;
+      int64_t off;
+      bool ok;
       if constexpr (SWAP) {
-        const int row = xtap[q] >= 0 ? xtab[(buf * 64 + p) * kMaxTaps + xtap[q]] : -1;
-        sq[q] = row >= 0 ? *reinterpret_cast<const float4*>(a.x + (int64_t)row + xci[q]) : z;
+        const int c = r0 + 4 * (idx & 31);
+        ok = rrow[q] >= 0 && c < a.Cout;
+        off = (int64_t)rrow[q] + c;
       } else {
-        const int c = s0 + 4 * (idx % (BN / 4)), row = ytab[buf * 64 + p];
-        sq[q] = (row >= 0 && c < a.Cout) ? *reinterpret_cast<const float4*>(a.dy + (int64_t)row + c) : z;
+        ok = rrow[q] >= 0 && xtap[q] >= 0;
+        off = (int64_t)rrow[q] + xci[q];
       }
+      rmask |= ok ? 1u << q : 0u;
+      rq[q] = *reinterpret_cast<const float4*>((SWAP ? a.dy : a.x) + (ok ? off : 0));
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+      const int idx = q * 256 + tid;
+      int64_t off;
+      bool ok;
+      if constexpr (SWAP) {
+        ok = srow[q] >= 0 && xtap[q] >= 0;
+        off = (int64_t)srow[q] + xci[q];
+      } else {
+        const int c = s0 + 4 * (idx % (BN / 4));
+        ok = srow[q] >= 0 && c < a.Cout;
+        off = (int64_t)srow[q] + c;
+      }
+      smask |= ok ? 1u << q : 0u;
+      sq[q] = *reinterpret_cast<const float4*>((SWAP ? a.x : a.dy) + (ok ? off : 0));
     }
   };
   auto lstore = [&]() {
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
       const int idx = q * 256 + tid, p = idx >> 5, cq = idx & 31;
-      put4(lds, R_HI, swz(p, cq >> 1) + 8 * (cq & 1), rq[q]);
+      put4(lds, R_HI, swz(p, cq >> 1) + 8 * (cq & 1), (rmask >> q) & 1u ? rq[q] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
 #pragma unroll
     for (int q = 0; q < SQ; ++q) {
       const int idx = q * 256 + tid, p = idx / (BN / 4), cq = idx % (BN / 4);
-      put4(lds, S_HI, swz(p, cq >> 1) + 8 * (cq & 1), sq[q]);
+      put4(lds, S_HI, swz(p, cq >> 1) + 8 * (cq & 1), (smask >> q) & 1u ? sq[q] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   };
   // transposed-read addresses at k-slice 0 (T10: lane 4q + p of a 16-lane group supplies row q, channels 4p .. 4p + 3 of
@@ -223,10 +254,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
   for (int s = slab0; s < slab1; ++s) {
     if (s + 1 < slab1) decode(s + 1, (s + 1) & 1);
     __syncthreads();  // the previous slab's fragments have been read; the next slab's table is written
-    lstore();
+    if (!(a.dbg & 1)) lstore();
     __syncthreads();
-    if (s + 1 < slab1) gload((s + 1) & 1);  // in flight under the MFMAs
-    compute();
+    if (s + 1 < slab1 && !(a.dbg & 4)) gload((s + 1) & 1);  // in flight under the MFMAs
+    if (!(a.dbg & 2)) compute();
   }
 
   // D layout: column (lane & 31) = index on the 128-wide axis, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = index on the other.
@@ -324,6 +355,7 @@ extern "C" int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* d
   a.KT = kt; a.KH = kh; a.KW = kw; a.st = st; a.sh = sh; a.sw = sw; a.pt = pt; a.ph = ph; a.pw = pw;
   a.Cin = cin; a.Cout = cout; a.ldx = ldx; a.ldy = ldy; a.M = (int)M; a.taps = kt * kh * kw;
   a.E = a.taps * cin;
+  a.dbg = avt::env_int_flag("AVT_WGRAD_DBG", 0);
   a.dCin = make_fastdiv((uint32_t)cin);
   a.nslab = (int)((M + 63) / 64);
   a.dWo = make_fastdiv((uint32_t)a.Wo); a.dHo = make_fastdiv((uint32_t)a.Ho); a.dTo = make_fastdiv((uint32_t)a.To);
