@@ -42,10 +42,19 @@
 namespace {
 #include "../../tools/diag/conv_stamp.h"
 }
+// phase-skip diagnostic of the same build (1 skip the LDS stage, 2 skip the MFMAs, 4 skip the global loads):
+// what the kernel's time really hangs on is what it gets faster without (tools/probe_conv_phases.sh)
+// — a COMPILE-TIME switch (-DAVT_DBG_CONST=n, one library per setting): read at run time, the branches around the MFMAs
+// alone cost 35 %.
+#ifndef AVT_DBG_CONST
+#define AVT_DBG_CONST 0
+#endif
+#define DBG_SKIP(bit) (((AVT_DBG_CONST) & (bit)) != 0)
 #else
 #define STAMP_BEGIN()
 #define STAMP(i)
 #define STAMP_END()
+#define DBG_SKIP(bit) false
 #endif
 
 namespace {
@@ -168,10 +177,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
-        acc[i][j] = mfma<F16>(f.wl[i], f.ah[j], acc[i][j]);
-        acc[i][j] = mfma<F16>(f.wh[i], f.al[j], acc[i][j]);
-        acc[i][j] = mfma<F16>(f.wh[i], f.ah[j], acc[i][j]);
-        if (more) {
+        if (!DBG_SKIP(2)) {
+          acc[i][j] = mfma<F16>(f.wl[i], f.ah[j], acc[i][j]);
+          acc[i][j] = mfma<F16>(f.wh[i], f.al[j], acc[i][j]);
+          acc[i][j] = mfma<F16>(f.wh[i], f.ah[j], acc[i][j]);
+        }
+        if (more && !DBG_SKIP(4)) {
 #pragma unroll
           for (int e = 0; e < PPG; ++e) {
             const int pc = (g0 + i * MT + j) * PPG + e;
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     __syncthreads();
     STAMP(3);  // barrier after compute
     if (kt + 1 < a.nk) {
-      lstore();
+      if (!DBG_SKIP(1)) lstore();
       STAMP(4);  // wait for the loads + ds_write
       __syncthreads();
       STAMP(5);  // barrier after the stores

@@ -7,6 +7,9 @@ __device__ unsigned long long g_stamp[10];  // [0..6] segments, [7] workgroups, 
   unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};            \
   unsigned long long last_ = __builtin_amdgcn_s_memtime();          \
   const unsigned long long t0_ = last_, r0_ = __builtin_amdgcn_s_memrealtime()
+#ifdef AVT_STAMP_OFF  // the phase-skip diagnostic (tools/probe_conv_phases.sh) wants the hooks' build without their cost
+#define STAMP(i) (void)seg_, (void)last_
+#else
 #define STAMP(i)                                                          \
   do {                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                    \
@@ -15,11 +18,15 @@ __device__ unsigned long long g_stamp[10];  // [0..6] segments, [7] workgroups, 
     seg_[i] += now_ - last_;                                              \
     last_ = now_;                                                         \
   } while (0)
+#endif
 #ifdef AVT_CONV_STAMP_FINE
 #define STAMP_FINE(i) STAMP(i)
 #else
 #define STAMP_FINE(i)
 #endif
+#ifdef AVT_STAMP_OFF
+#define STAMP_END() (void)t0_, (void)r0_
+#else
 #define STAMP_END()                                                          \
   do {                                                                       \
     STAMP(6); /* epilogue */                                                 \
@@ -30,6 +37,7 @@ __device__ unsigned long long g_stamp[10];  // [0..6] segments, [7] workgroups, 
       atomicAdd(&g_stamp[9], __builtin_amdgcn_s_memrealtime() - r0_);        \
     }                                                                        \
   } while (0)
+#endif
 
 #ifndef AVT_STAMP_FN
 #define AVT_STAMP_FN avt_debug_stamps
