@@ -24,6 +24,13 @@
 #include "avt_common.h"
 #include "conv_args.h"
 
+// phase-skip diagnostic (tools/probe_wgrad_phases.py against a library built with -DAVT_WGRAD_DBG_CONST=n: 1 skip the LDS
+// stage, 2 the MFMAs, 4 the global loads): compile-time, the shipped library carries no switch
+#ifndef AVT_WGRAD_DBG_CONST
+#define AVT_WGRAD_DBG_CONST 0
+#endif
+#define WG_SKIP(bit) (((AVT_WGRAD_DBG_CONST) & (bit)) != 0)
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,7 +47,6 @@ struct WgArgs {
   int Cin, Cout, ldx, ldy, M, taps, E;
   int r_tiles, s_tiles;  // tiles of the 128-wide / BN-wide operand axis
   int nslab, slabs_per_chunk, nchunk;
-  int dbg;  // DIAGNOSTIC (AVT_WGRAD_DBG): 1 skip the LDS stage, 2 skip the MFMAs, 4 skip the global loads
   FastDiv dWo, dHo, dTo, dKW, dKH, dCin;
 };
 
@@ -254,10 +260,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
   for (int s = slab0; s < slab1; ++s) {
     if (s + 1 < slab1) decode(s + 1, (s + 1) & 1);
     __syncthreads();  // the previous slab's fragments have been read; the next slab's table is written
-    if (!(a.dbg & 1)) lstore();
+    if (!WG_SKIP(1)) lstore();
     __syncthreads();
-    if (s + 1 < slab1 && !(a.dbg & 4)) gload((s + 1) & 1);  // in flight under the MFMAs
-    if (!(a.dbg & 2)) compute();
+    if (s + 1 < slab1 && !WG_SKIP(4)) gload((s + 1) & 1);  // in flight under the MFMAs
+    if (!WG_SKIP(2)) compute();
   }
 
   // D layout: column (lane & 31) = index on the 128-wide axis, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = index on the other.
@@ -355,7 +361,6 @@ extern "C" int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* d
   a.KT = kt; a.KH = kh; a.KW = kw; a.st = st; a.sh = sh; a.sw = sw; a.pt = pt; a.ph = ph; a.pw = pw;
   a.Cin = cin; a.Cout = cout; a.ldx = ldx; a.ldy = ldy; a.M = (int)M; a.taps = kt * kh * kw;
   a.E = a.taps * cin;
-  a.dbg = avt::env_int_flag("AVT_WGRAD_DBG", 0);
   a.dCin = make_fastdiv((uint32_t)cin);
   a.nslab = (int)((M + 63) / 64);
   a.dWo = make_fastdiv((uint32_t)a.Wo); a.dHo = make_fastdiv((uint32_t)a.Ho); a.dTo = make_fastdiv((uint32_t)a.To);

@@ -1,3 +1,5 @@
+"""Time of csrc/wgrad_x3.hip on four representative SlowFast layers (run it against libraries built with
+-DAVT_WGRAD_DBG_CONST=0/1/2/4 via AVT_HIP_LIB to see which phase the time hangs on; profiles/r02/probe_wgrad_phases.log)."""
 import sys, time, torch
 sys.path.insert(0, ".")
 from avtex import ops
