@@ -102,13 +102,22 @@ __device__ __forceinline__ void channel_sums(const BnArgs& a, int c, double& s0,
 
 __global__ __launch_bounds__(kT) void bn_fwd_stats_kernel(BnArgs a) {
   double p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
-    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+  // (two rows of the walk per trip: both loads are issued before either is summed — same order of additions, twice the bytes
+  //  in flight per thread)
+  auto add = [&](const float4 v) {
     p0[0] += v.x; p1[0] += (double)v.x * v.x;
     p0[1] += v.y; p1[1] += (double)v.y * v.y;
     p0[2] += v.z; p1[2] += (double)v.z * v.z;
     p0[3] += v.w; p1[3] += (double)v.w * v.w;
+  };
+  int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  for (; i + a.stride < a.nchunk; i += 2 * a.stride) {
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    const float4 u = reinterpret_cast<const float4*>(a.x)[i + a.stride];
+    add(v);
+    add(u);
   }
+  if (i < a.nchunk) add(reinterpret_cast<const float4*>(a.x)[i]);
   block_reduce_store(a, p0, p1);
 }
 
@@ -218,6 +227,11 @@ void layout(BnArgs& a, int64_t m, int c) {
   a.unit = q > kT ? q / kT : 1;
   int64_t blocks = (a.nchunk + kT - 1) / kT;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  // every workgroup leaves a row of 2 C doubles for the finalize pass: keep those rows a few per cent of the tensor itself
+  // (with 1024 of them a [23520, 1024] activation's partials were a third of its bytes: 3.4 TB/s backward instead of 5.2)
+  // — but not below two workgroups per CU, which the streaming itself needs
+  const int64_t cap = m / 64 + 1 > 512 ? m / 64 + 1 : 512;
+  if (blocks > cap) blocks = cap;
   blocks = ((blocks + a.unit - 1) / a.unit) * a.unit;  // whole rows per sweep, so a thread keeps its four channels
   a.blocks = (int)blocks;
   a.stride = blocks * kT;
