@@ -394,7 +394,8 @@ def train_bench(args, rank, world, dev):
     clips = B * (1 + 1 + negs)  # query + positive + negatives per item
     flops = 3.0 * 100.6e9 * clips  # forward + dgrad + wgrad of the convolutions
     value = clips * args.steps / total_s
-    peak = 157.3 if args.train_dtype == "fp32" else 2500.0
+    hand = channels_last and args.train_dtype == "fp32"  # the hand-written split-plane convolution passes ran (train_ops.py)
+    peak = (2500.0 / 3 if hand else 157.3) if args.train_dtype == "fp32" else 2500.0
     print(json.dumps({
         "metric": "contrastive training (train.py) InfoNCE negs=14 temp=0.1, batch of 8 items: encoder clips/s through forward+backward",
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -404,13 +405,15 @@ def train_bench(args, rank, world, dev):
                                "through SlowFast-8x8-R50 q/t encoders (train-mode BatchNorm per item = per DataParallel "
                                "replica), HIP InfoNCE + CE, SGD; inputs sampled and packed on the device",
                    "items_per_rank": items, "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
-                   "encoder_backend": "MIOpen convolutions through autograd (%s%s)" % (
-                       args.train_dtype, ", channels_last_3d" + (" + HIP bn_train (BatchNorm + shortcut + ReLU fwd/bwd)"
-                                                                 if args.train_dtype == "fp32" else "") if channels_last else ""),
+                   "encoder_backend": ("hand-written HIP through torch.autograd.Function (fp32, channels_last_3d): conv_x3 IO32 forward + "
+                                       "stride-1 dgrad, wgrad_x3, bn_train; MIOpen for the stems' wgrad and the strided dgrads") if hand
+                   else "MIOpen convolutions through autograd (%s%s)" % (args.train_dtype, ", channels_last_3d" if channels_last else ""),
                    "parallelism": "dp%d, gradient all-reduce once per step" % world},
         "training_steps_per_s": args.steps / total_s, "items_per_s": B * args.steps / total_s,
         "loss_first_last": [losses[0], losses[-1]],
-        "roofline": {"kernel": "MIOpen conv3d fwd/dgrad/wgrad (library)", "bound": "mfma", "achieved": flops * args.steps / total_s / 1e12,
+        "roofline": {"kernel": ("conv_x3_kernel<IO32> fwd / stride-1 dgrad + wgrad_x3_kernel (split-plane MFMA, 1/3 of the bf16 peak); "
+                                "whole step incl. BatchNorm passes, MIOpen stems' wgrad / strided dgrads, optimizer") if hand
+                               else "MIOpen conv3d fwd/dgrad/wgrad (library)", "bound": "mfma", "achieved": flops * args.steps / total_s / 1e12,
                      "peak": peak, "unit": "TFLOP/s", "frac": flops * args.steps / total_s / 1e12 / peak, "traffic": None}}))
 
 
