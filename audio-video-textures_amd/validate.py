@@ -340,15 +340,30 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
         tb_logger.flush()
         print("Done logging Loss and Entropies.")
     print("Frames list: ", [int(i) for i in new_frame_ids])
-    _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr)
+    _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr, n_input=n_in)
     if timeline is not None:
         print("Saving Interpolated Video.\n")
         assert len(timeline) == int((args.SF + 1) / 2) * len(new_frames)  # validate.py:812
-        _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr, timeline=timeline)
+        _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr, timeline=timeline, n_input=n_in)
     return [int(i) for i in new_frame_ids]
 
 
-def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr, timeline=None):
+def frames_bar(frames, src_ids, n_input):
+    """--frames_bar (validate.py:598-601, 634-638): rows [-25:-10] of every output frame become a black strip with a red
+    mark at the source frame's relative position, `frame_n = int(idx * W / len(input_frames))`, columns
+    [frame_n - 3 : frame_n + 3] — NumPy slicing as the reference writes it, so a mark whose start would be negative is not
+    drawn.  Interpolated frames (src id None) get the strip without a mark.  frames: uint8 [n, H, W, 3], edited in place."""
+    w = frames.shape[2]
+    for k, idx in enumerate(src_ids):
+        bar = torch.zeros((15, w, 3), dtype=torch.uint8, device=frames.device)
+        if idx is not None:
+            frame_n = int(idx * w / n_input)
+            bar[:, frame_n - 3 : frame_n + 3, 0] = 255
+        frames[k, -25:-10] = bar
+    return frames
+
+
+def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_audio_name, apf, sr, timeline=None, n_input=None):
     """PNG dump + ffmpeg mux (validate.py:710-872).  Output side, off the hot path; skipped without a folder.
     timeline = the interpolated sequence (validate.py:809-872): its own folder, (SF + 1) / 2 times the frame rate."""
     folder = getattr(args, "results_folder", None)
@@ -368,7 +383,10 @@ def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_
             audio_file = os.path.join(results_folder, "audio_{}_{}.wav".format(video_name, new_video_id))
             wavfile.write(audio_file, int(sr or 16000), np.asarray(driving_audio_w[: len(new_frames) * apf], np.float32))
         print("Saving frames.")
-        save_video_raw(timeline.frames(video), out_dir + ".mp4", ((args.SF + 1) / 2) * args.fps, audio_file=audio_file)
+        frames = timeline.frames(video)
+        if getattr(args, "frames_bar", False):
+            frames_bar(frames, [e if isinstance(e, int) else None for e in timeline.items], n_input or len(video))
+        save_video_raw(frames, out_dir + ".mp4", ((args.SF + 1) / 2) * args.fps, audio_file=audio_file)
         return
     try:
         from PIL import Image
@@ -399,4 +417,6 @@ def _write_result(args, video_name, video, new_frames, driving_audio_w, driving_
         save_videos(out_dir, out_dir + ".mp4", args.fps, audio_file=audio_file)
     else:  # frame list -> one gather of the video tensor -> encoder, no PNG round trip
         frames = torch.as_tensor(video)[torch.as_tensor(np.asarray(new_frames, dtype=np.int64))]
+        if getattr(args, "frames_bar", False):
+            frames_bar(frames, list(new_frames), n_input or len(video))
         save_video_raw(frames, out_dir + ".mp4", args.fps, audio_file=audio_file)

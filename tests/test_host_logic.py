@@ -288,3 +288,23 @@ def test_training_passes_fall_back_to_torch_off_the_device():
     conv = nn.Conv3d(16, 8, (1, 3, 3), padding=(0, 1, 1), bias=False).train()
     assert not train_ops.conv_fusable(x, conv)
     assert torch.equal(train_ops.conv3d(x, conv), conv(x))
+
+
+def test_frames_bar_matches_the_reference_slicing():
+    """validate.py:634-638 in NumPy, as the reference writes it, against validate.frames_bar."""
+    import importlib
+    V = importlib.import_module("avtex.validate")  # (the package re-exports the function under the module's name)
+    rng = np.random.RandomState(0)
+    video = rng.randint(0, 256, (50, 40, 64, 3)).astype(np.uint8)
+    ids = [0, 1, 2, 3, 25, 49, None]
+    got = torch.from_numpy(np.stack([video[i if i is not None else 0] for i in ids]).copy())
+    V.frames_bar(got, ids, 50)
+    for k, idx in enumerate(ids):
+        frame_arr = np.array(video[idx if idx is not None else 0])
+        bar = np.zeros((15, video.shape[-2], 3))
+        if idx is not None:
+            frame_n = int(idx * video.shape[-2] / 50)
+            bar[:, frame_n - 3 : frame_n + 3, :] = [255, 0, 0]
+        frame_arr[-25:-10, :, :] = bar
+        assert np.array_equal(got[k].numpy(), frame_arr), (k, idx)
+    assert got[0, -25:-10].sum() == 0 and got[4, -25:-10, :, 0].sum() == 15 * 6 * 255   # idx 0: start -3 -> nothing drawn
