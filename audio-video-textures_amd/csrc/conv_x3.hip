@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: residual planes requested first, tile staged in fp32, split on the final value
-  const bool has_res = a.res != nullptr;
+  const bool has_res = !IO32 && a.res != nullptr;  // (IO32: `res` is an fp32 tensor added in the store loop below)
   uint4 rrh[EU], rrl[EU];
   if (has_res) {
 #pragma unroll
@@ -366,6 +366,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       }
       const int64_t o = (int64_t)out_row(a, m) * a.ldo + n;
       if constexpr (IO32) {
+        if (a.res) {  // out = conv + add: a gradient that reaches the same tensor by another path, summed here instead of
+                      // in a separate pass (train_ops.conv3d_fork)
+          const float* rf = reinterpret_cast<const float*>(a.res) + (int64_t)m * a.ldr + n;
+          const float4 r0_ = *reinterpret_cast<const float4*>(rf), r1_ = *reinterpret_cast<const float4*>(rf + 4);
+          x[0] += r0_.x; x[1] += r0_.y; x[2] += r0_.z; x[3] += r0_.w;
+          x[4] += r1_.x; x[5] += r1_.y; x[6] += r1_.z; x[7] += r1_.w;
+        }
         float* of = reinterpret_cast<float*>(a.out) + o;
         *reinterpret_cast<float4*>(of) = make_float4(x[0], x[1], x[2], x[3]);
         *reinterpret_cast<float4*>(of + 4) = make_float4(x[4], x[5], x[6], x[7]);
@@ -442,15 +449,16 @@ extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const v
 }
 
 // fp32 rows in, fp32 rows out, split-plane arithmetic in between (the IO32 form of the kernel): see include/avt.h
-extern "C" int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
-                                       const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
-                                       int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype, void* stream) {
+extern "C" int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
+                                       float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                                       int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int lda, int plane_dtype,
+                                       void* stream) {
   AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_conv3d_igemm_x3_f32: plane_dtype must be 0 (bf16) or 1 (fp16)");
   AVT_REQUIRE(wt_lo && avt::aligned16(wt_lo) && (!wscale || avt::aligned16(wscale)), "avt_conv3d_igemm_x3_f32: weight planes / wscale NULL or unaligned");
   AVT_REQUIRE((int64_t)batch * t * h * w * ldi < (1ll << 30) - 64, "avt_conv3d_igemm_x3_f32: input too large for 32-bit byte offsets");
   ConvArgs a;
-  const int rc = conv_args_fill(a, "avt_conv3d_igemm_x3_f32", in, wt_hi, nullptr, nullptr, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw,
-                                st, sh, sw, pt, ph, pw, 0, 0, 0, ldi, ldo, 0, 0, 1, 0, 0);
+  const int rc = conv_args_fill(a, "avt_conv3d_igemm_x3_f32", in, wt_hi, nullptr, add, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw,
+                                st, sh, sw, pt, ph, pw, 0, 0, 0, ldi, ldo, add ? lda : 0, 0, 1, 0, 0);
   if (rc != AVT_OK) return rc;
   a.in_bytes *= 2u;  // fp32 elements
   a.in_lo = nullptr;

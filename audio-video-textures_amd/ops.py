@@ -320,17 +320,20 @@ def conv3d_igemm_x3(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, 
                                               int(plane_dtype), _p(wscale), _stream()), "avt_conv3d_igemm_x3")
 
 
-def conv3d_igemm_x3_f32(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype):
-    """fp32 rows in / fp32 rows out on the split-plane kernel (training forward / stride-1 dgrad); see include/avt.h."""
+def conv3d_igemm_x3_f32(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype, add=None):
+    """fp32 rows in / fp32 rows out on the split-plane kernel (training forward / stride-1 dgrad); add = fp32 rows [M, cout]
+    summed into the result; see include/avt.h."""
     b, t, h, w = dims
     _dev(x, "x", torch.float32)
     _dev(out, "out", torch.float32)
     _dev(wt_hi, "wt_hi", torch.bfloat16)
     _dev(wt_lo, "wt_lo", torch.bfloat16)
-    _lib.check(_lib.lib().avt_conv3d_igemm_x3_f32(_p(x), _p(wt_hi), _p(wt_lo), _p(wscale), _p(out), _p(ktab), int(b), int(t), int(h),
-                                                  int(w), int(cin), int(cout), *[int(k) for k in kernel], *[int(v) for v in stride],
-                                                  *[int(v) for v in pad], int(ldi), int(ldo), int(plane_dtype), _stream()),
-               "avt_conv3d_igemm_x3_f32")
+    if add is not None:
+        _dev(add, "add", torch.float32)
+    _lib.check(_lib.lib().avt_conv3d_igemm_x3_f32(_p(x), _p(wt_hi), _p(wt_lo), _p(wscale), _p(add), _p(out), _p(ktab), int(b), int(t),
+                                                  int(h), int(w), int(cin), int(cout), *[int(k) for k in kernel],
+                                                  *[int(v) for v in stride], *[int(v) for v in pad], int(ldi), int(ldo),
+                                                  int(cout), int(plane_dtype), _stream()), "avt_conv3d_igemm_x3_f32")
 
 
 def conv3d_wgrad_x3_f32(dy, x, dw, dims, cin, cout, kernel, stride, pad, ldx, ldy):

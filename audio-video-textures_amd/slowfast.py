@@ -13,7 +13,7 @@ MI355X notes: convolutions go to MIOpen; run it in bf16 with channels_last_3d (`
 import torch
 import torch.nn as nn
 
-from .train_ops import bn_act, conv3d
+from .train_ops import bn_act, conv3d, conv3d_fork
 
 ALPHA, BETA_INV, FUSION_RATIO, FUSION_KERNEL = 4, 8, 2, 7
 WIDTH = 64
@@ -85,9 +85,11 @@ class ResBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        sc = bn_act(conv3d(x, self.branch1), self.branch1_bn, relu=False) if hasattr(self, "branch1") else x
         t = self.branch2
-        h = bn_act(conv3d(x, t.a), t.a_bn, relu=True)
+        # (train mode on the GPU: the shortcut's gradient is summed into a's input gradient inside that kernel, train_ops)
+        h, xs = conv3d_fork(x, t.a)
+        sc = bn_act(conv3d(xs, self.branch1), self.branch1_bn, relu=False) if hasattr(self, "branch1") else xs
+        h = bn_act(h, t.a_bn, relu=True)
         h = bn_act(conv3d(h, t.b), t.b_bn, relu=True)
         # c's BatchNorm, the shortcut add and the block's ReLU: one pass in train mode (csrc/bn_train.hip), the stock ops else
         return bn_act(conv3d(h, t.c), t.c_bn, res=sc, relu=True)

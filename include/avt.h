@@ -393,11 +393,12 @@ int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m,
  * [M, ldo], no bias / residual / activation — an fp32-grade Conv3d(bias=False) on channels-last tensors for the forward
  * and the stride-1 input gradient of the SlowFast convolutions in train() (contrastive_video_textures/train.py:114-141;
  * avtex/train_ops.py).  Activations are split into the two planes inside the kernel; wt_hi / wt_lo [cout, kt*kh*kw*cin]
- * are the weight planes (plane_dtype AVT_X3_*; wscale as in avt_conv3d_igemm_x3, or NULL). */
-int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
-                            const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
-                            int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype,
-                            void* stream);
+ * are the weight planes (plane_dtype AVT_X3_*; wscale as in avt_conv3d_igemm_x3, or NULL).  add (may be NULL): fp32 rows
+ * [M, lda] summed into the result (out = conv + add) — a gradient reaching the same tensor by another path. */
+int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
+                            float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
+                            int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int lda,
+                            int plane_dtype, void* stream);
 
 /* Weight gradient of the same convolution on the split-plane arithmetic (csrc/wgrad_x3.hip; bf16 planes, 2^-16 per
  * product): dw[cout][kt*kh*kw][cin] (the memory of a channels_last_3d Conv3d weight) = sum over output positions of

@@ -136,3 +136,25 @@ def test_weight_plane_cache_is_per_tensor_not_per_address():
         del conv
         gc.collect()
     assert not torch.allclose(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("stride", [(1, 1, 1), (1, 2, 2)])
+def test_fork_sums_the_other_path_in_the_kernel(stride):
+    """conv3d_fork: the gradient that reaches x through the alias is added in the epilogue of the convolution's own
+    input-gradient kernel (stride 1) or after MIOpen's (strided) — either way dx = dgrad(dy) + d_alias."""
+    from avtex import train_ops
+    torch.manual_seed(5)
+    conv = nn.Conv3d(32, 64, (1, 3, 3), stride=stride, padding=(0, 1, 1), bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+    x0 = _cl(torch.randn(2, 32, 3, 10, 10, device=DEV))
+    x = x0.clone().requires_grad_(True)
+    y, xs = train_ops.conv3d_fork(x, conv)
+    gy, gx = _cl(torch.randn_like(y)), _cl(torch.randn_like(x0))
+    ((y * gy).sum() + (xs * gx).sum()).backward()
+    dwa = conv.weight.grad.clone()
+    conv.zero_grad(set_to_none=True)
+    xr = x0.clone().requires_grad_(True)
+    yr = conv(xr)
+    ((yr * gy).sum() + (xr * gx).sum()).backward()
+    rel = lambda u, v: float((u - v).norm()) / float(v.norm())
+    assert rel(y.detach(), yr.detach()) < 2e-6 and torch.equal(xs.detach(), x0)
+    assert rel(x.grad, xr.grad) < 2e-5 and rel(dwa, conv.weight.grad) < 1e-4
