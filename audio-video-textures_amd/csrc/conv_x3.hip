@@ -42,7 +42,7 @@
 namespace {
 #include "../../tools/diag/conv_stamp.h"
 }
-// phase-skip diagnostic of the same build (1 skip the LDS stage, 2 skip the MFMAs, 4 skip the global loads):
+// phase-skip diagnostic of the same build (1 skip the LDS stage, 2 skip the MFMAs, 4 skip the global loads, 8 skip the fragment reads):
 // what the kernel's time really hangs on is what it gets faster without (tools/probe_conv_phases.sh)
 // — a COMPILE-TIME switch (-DAVT_DBG_CONST=n, one library per setting): read at run time, the branches around the MFMAs
 // alone cost 35 %.
@@ -150,6 +150,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     i32x4 ah[MT], al[MT], wh[NT], wl[NT];
   };
   auto fload = [&](Frags& f, int ks) {
+    if (DBG_SKIP(8)) {  // diagnostic: MFMAs without their LDS fragment reads (operands that depend on ks, so nothing folds)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) f.ah[j] = f.al[j] = i32x4{ks, lane, j, 0x3c003c00};
+#pragma unroll
+      for (int i = 0; i < NT; ++i) f.wh[i] = f.wl[i] = i32x4{ks, lane, i, 0x3c003c00};
+      return;
+    }
     const int koff = ks * 32 + lh * 16;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
