@@ -256,6 +256,32 @@ def run_mode(args, precision, video, q_mod, t_mod, rank, world, dev):
     }
 
 
+def interpolation_leg(dev, sf=5, reps=10):
+    """SuperSloMo at a jump (avtex.slowmo, the reference's default output path, interpolate.py:93-147): device time per jump for
+    the SF - 1 frames between two frames, seeded weights, at the bench video's frame size and at the encoders' 224^2."""
+    from avtex import slowmo, synth
+
+    out = []
+    for hw in (128, 224):
+        it = slowmo.Interpolator(hw, hw, sf, dev)
+        g = torch.Generator().manual_seed(0)
+        for net in (it.flow_comp, it.arb_time):
+            for p in net.parameters():
+                bound = (3.0 / p[0].numel()) ** 0.5 if p.dim() > 1 else 0.05
+                p.data.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+        v = synth.structured_video(7, 2, hw, hw).to(dev)
+        for _ in range(3):
+            it(v[0], v[1])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fr = it(v[0], v[1])
+        b.record()
+        torch.cuda.synchronize()
+        out.append({"frame": "%dx%d" % (hw, hw), "sf": sf, "frames_per_jump": int(fr.shape[0]), "ms_per_jump": a.elapsed_time(b) / reps})
+    return out
+
+
 def nxn_legs(dev, reps=5):
     """The N x N transition build on its own, at the sizes SURVEY.md §8(d) lists, on seeded embeddings (Q = randn seed 0,
     T = the clustered variant Q.roll(-1) + 0.1 randn, so next-segment positives exist): l2norm x2 -> similarity -> select,
@@ -534,6 +560,7 @@ def main():
         note("precision block done")
     if world == 1 and not args.no_nxn_legs:
         out["nxn_legs"] = nxn_legs(dev)
+        out["interpolation"] = interpolation_leg(dev)
         note("NxN legs done")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(video.cpu(), q_mod, t_mod, 20, 4, N, D, 0.1, args)
