@@ -361,7 +361,8 @@ def train_bench(args, rank, world, dev):
     video = synth.structured_video(123 + rank, 1500, args.frame_hw, args.frame_hw)
     dargs = SimpleNamespace(vdata="/tmp", adata=None, n_negs=negs, img_size=224, enc_arch="slowfast", window=0, stride=0)
     torch.manual_seed(5)
-    ds = avtex.AudioVideoSegments(dargs, "synthetic", split="train", video=(video, fps))
+    with contextlib.redirect_stdout(sys.stderr):  # (the dataset prints its shapes, as the reference's does: keep stdout to the JSON line)
+        ds = avtex.AudioVideoSegments(dargs, "synthetic", split="train", video=(video, fps))
     torch.manual_seed(0)
     model = avtex.ContrastivePredictionTemporal(SlowFast(), SlowFast(), None, 1, 128, temp=0.1, window=dargs.window,
                                                 stride=dargs.stride, enc_arch="slowfast", img_size=224).to(dev).train()
