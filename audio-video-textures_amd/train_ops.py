@@ -224,9 +224,8 @@ class _ConvX3Fork(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dalias):
-        if dy is None:  # (the convolution's output was not used)
-            x, weight = ctx.saved_tensors
-            dy = torch.zeros_like(_ConvX3.forward(ctx, x, weight, ctx.conf[0], ctx.conf[1]))
+        if dy is None:  # (the convolution's output was not used: only the alias carries a gradient)
+            return (dalias if ctx.needs_input_grad[0] else None), None, None, None
         return _conv_backward(ctx, dy, dalias) + (None, None)
 
 
