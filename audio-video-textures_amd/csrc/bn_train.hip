@@ -40,6 +40,7 @@ struct BnArgs {
   float* save_invstd;
   float* running_mean;  // forward: updated in place when not NULL
   float* running_var;
+  long long* tracked;   // forward: nn.BatchNorm's num_batches_tracked, incremented here when not NULL (no launch of its own)
   float* dgamma;        // backward outputs
   float* dbeta;
   int64_t M;            // rows
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // gri
   double s0, s1;
   channel_sums(a, c, s0, s1);
   if ((threadIdx.x & 63) != 0) return;
+  if (a.tracked && c == 0) *a.tracked += 1;
   const double mean = s0 / (double)a.M;
   double var = s1 / (double)a.M - mean * mean;  // biased variance (normalisation)
   var = var > 0.0 ? var : 0.0;
@@ -261,7 +263,7 @@ extern "C" int64_t avt_bn_train_ws_bytes(int64_t m, int c) {
 
 extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
                                 float eps, float momentum, int relu, void* ws, int64_t ws_size, float* save_mean, float* save_invstd,
-                                float* running_mean, float* running_var, void* stream) {
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
   AVT_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && (!running_mean == !running_var), "avt_bn_train_fwd: NULL pointer");
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && (!res || avt::aligned16(res)), "avt_bn_train_fwd: rows must be 16-byte aligned");
   BnArgs a = {};
@@ -269,6 +271,7 @@ extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int6
   if (rc) return rc;
   a.x = x; a.res = res; a.out = y; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.relu = relu;
   a.save_mean = save_mean; a.save_invstd = save_invstd; a.running_mean = running_mean; a.running_var = running_var;
+  a.tracked = reinterpret_cast<long long*>(num_batches_tracked);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);

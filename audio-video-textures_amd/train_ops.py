@@ -50,7 +50,7 @@ def fusable(x, bn, res=None):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps, tracked=None):
         m, c = _rows(x)
         y = torch.empty_like(x)  # keeps the channels-last strides
         ws = _workspace(m, c, x.device)
@@ -58,7 +58,7 @@ class _BNAct(torch.autograd.Function):
         save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().avt_bn_train_fwd(_p(x), _p(res), _p(y), m, c, _p(weight), _p(bias), float(eps), float(momentum),
                                                1 if relu else 0, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
-                                               _p(running_mean), _p(running_var), _stream()), "avt_bn_train_fwd")
+                                               _p(running_mean), _p(running_var), _p(tracked), _stream()), "avt_bn_train_fwd")
         ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
         ctx.has_res = res is not None
         return y
@@ -75,7 +75,7 @@ class _BNAct(torch.autograd.Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().avt_bn_train_bwd(_p(dy), _p(y), _p(x), m, c, _p(weight), _p(save_mean), _p(save_invstd), _p(ws), ws.numel(),
                                                _p(dx), _p(dres), _p(dgamma), _p(dbeta), _stream()), "avt_bn_train_bwd")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
 def bn_act(x, bn, res=None, relu=True):
@@ -87,12 +87,14 @@ def bn_act(x, bn, res=None, relu=True):
             y = y + res
         return F.relu(y) if relu else y
     momentum = bn.momentum
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if momentum is None:  # cumulative moving average
-            momentum = 1.0 / float(bn.num_batches_tracked)
+    tracked = bn.num_batches_tracked if bn.track_running_stats else None
+    if tracked is not None and momentum is None:  # cumulative moving average: the factor needs the count on the host
+        tracked.add_(1)
+        momentum = 1.0 / float(tracked)
+        tracked = None
+    # (otherwise num_batches_tracked is incremented by the statistics kernel itself: a launch per BatchNorm and pass less)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps)
+    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps, tracked)
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -384,7 +384,8 @@ int avt_clip_pack_gather_u8(const uint8_t* frames, int n_frames, int height, int
 int64_t avt_bn_train_ws_bytes(int64_t m, int c); /* workspace both calls need (16-byte aligned); -1 outside the domain */
 int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma,
                      const float* beta, float eps, float momentum, int relu, void* ws, int64_t ws_size,
-                     float* save_mean, float* save_invstd, float* running_mean, float* running_var, void* stream);
+                     float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked /* incremented when not NULL */, void* stream);
 int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma,
                      const float* save_mean, const float* save_invstd, void* ws, int64_t ws_size, float* dx,
                      float* dres, float* dgamma, float* dbeta, void* stream);
