@@ -32,11 +32,17 @@ def _rows(x):
     return x.numel() // x.shape[1], x.shape[1]
 
 
+_WS_BYTES = {}
+
+
 def _workspace(m, c, device):
     """Scratch for the per-workgroup partial sums and the per-channel coefficients (sized by the library)."""
-    n = _lib.lib().avt_bn_train_ws_bytes(m, c)
-    if n < 0:
-        raise ValueError("bn_train: %d rows x %d channels is outside the kernel's domain" % (m, c))
+    n = _WS_BYTES.get((m, c))
+    if n is None:
+        n = _lib.lib().avt_bn_train_ws_bytes(m, c)
+        if n < 0:
+            raise ValueError("bn_train: %d rows x %d channels is outside the kernel's domain" % (m, c))
+        _WS_BYTES[(m, c)] = n
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
