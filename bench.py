@@ -703,3 +703,10 @@ def cpu_baseline(video, q_mod, t_mod, W, S, N, D, temp, args):
 
 if __name__ == "__main__":
     main()
+    # normal completion only (a rank that raised must exit at once so that the launcher can stop the others): all ranks meet
+    # once more, then RCCL is torn down the way torch asks
+    import torch.distributed as _dist
+
+    if _dist.is_available() and _dist.is_initialized():
+        _dist.barrier()
+        _dist.destroy_process_group()
