@@ -106,12 +106,14 @@ def lib():
             fn.restype = C.c_int64 if name in _RETURNS_I64 else C.c_int
         handle.avt_last_error.argtypes = []
         handle.avt_last_error.restype = C.c_char_p
-        if handle.avt_abi_version() != 1:
-            raise AvtError("libavt_hip.so ABI version %d, expected 1" % handle.avt_abi_version())
+        if handle.avt_abi_version() != ABI_VERSION:
+            raise AvtError("libavt_hip.so ABI version %d, expected %d: rebuild with `make -C %s`"
+                           % (handle.avt_abi_version(), ABI_VERSION, os.path.join(_HERE, "csrc")))
         _lib = handle
     return _lib
 
 
+ABI_VERSION = 2  # include/avt.h AVT_ABI_VERSION
 _RETURNS_I64 = {"avt_bn_train_ws_bytes"}  # sizes; every other entry returns an AVT_* status
 
 

@@ -146,11 +146,15 @@ __global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // gri
 
 __global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
   const int quad = my_quad(a);
+  // y = (x - mean) * (invstd * gamma) + beta, the subtraction FIRST as stock BatchNorm does it: the folded form
+  // x * sc + (beta - mean * sc) cancels two large terms when |mean| >> std (error ~ 2^-24 |mean| / std of the result)
   const float4 sc = reinterpret_cast<const float4*>(a.coef)[quad];
-  const float4 sh = reinterpret_cast<const float4*>(a.coef + a.C)[quad];
+  const float4 mu = reinterpret_cast<const float4*>(a.save_mean)[quad];
+  const float4 be = reinterpret_cast<const float4*>(a.beta)[quad];
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
     const float4 v = reinterpret_cast<const float4*>(a.x)[i];
-    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    float4 o = make_float4((v.x - mu.x) * sc.x + be.x, (v.y - mu.y) * sc.y + be.y, (v.z - mu.z) * sc.z + be.z,
+                           (v.w - mu.w) * sc.w + be.w);
     if (a.res) {
       const float4 r = reinterpret_cast<const float4*>(a.res)[i];
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -266,6 +270,7 @@ extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int6
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
   AVT_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && (!running_mean == !running_var), "avt_bn_train_fwd: NULL pointer");
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && (!res || avt::aligned16(res)), "avt_bn_train_fwd: rows must be 16-byte aligned");
+  AVT_REQUIRE(avt::aligned16(beta) && avt::aligned16(save_mean), "avt_bn_train_fwd: beta / save_mean must be 16-byte aligned");
   BnArgs a = {};
   const int rc = geometry(a, "avt_bn_train_fwd", m, c, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
   if (rc) return rc;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void clip_pack_gather_kernel(GArgs a) {
   const int slot = b % AVT_SLOTS;
   const int n = b / AVT_SLOTS;
   int f = a.win_start[n] + (slot < AVT_SLOW_T ? a.slow_idx[slot] : a.fast_idx[slot - AVT_SLOW_T]);
-  f = f < 0 ? 0 : (f > a.n_frames - 1 ? a.n_frames - 1 : f);  // a bad start cannot fault; the host wrapper validates ids
+  f = f < 0 ? 0 : (f > a.n_frames - 1 ? a.n_frames - 1 : f);  // a bad start cannot fault (range of the ids: checked once by dataset.DeviceSegmentBatcher)
   const int tid = threadIdx.x;
   const int ry = tid / a.cpr, cx = tid - ry * a.cpr;
   const int y = tile * a.rpb + ry;

@@ -11,15 +11,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // fp32 pair -> packed (hi, lo) planes, both round-to-nearest-even; x - hi is exact in fp32.
 // F16 = false: bf16 planes (8 + 8 significant bits, |x - hi - lo| <= 2^-16 |x| at every magnitude; 2^-17 observed).
 // F16 = true : fp16 planes (11 + 11 bits, <= 2^-22 |x| while lo stays a normal fp16, i.e. |x| >= 2^-3; below that the
-//              ABSOLUTE error is <= 2^-24) — values are clamped to the fp16 range first (an activation beyond 65504 would
-//              otherwise become inf - inf).
+//              ABSOLUTE error is <= 2^-24) — FINITE values are clamped to the fp16 range first (65504); a NaN stays a NaN
+//              and an infinity stays that infinity (hi = +-inf, lo = 0), so a poisoned or diverged activation still
+//              reaches the embedding / the loss instead of turning into a plausible finite number (fminf / fmaxf alone
+//              would map a NaN to -65504).
 template <bool F16>
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
   if constexpr (F16) {
-    const f32x2 v = {fminf(fmaxf(x0, -65504.0f), 65504.0f), fminf(fmaxf(x1, -65504.0f), 65504.0f)};
+    const bool fin0 = __builtin_fabsf(x0) <= 3.402823466e38f, fin1 = __builtin_fabsf(x1) <= 3.402823466e38f;  // false: inf, NaN
+    const f32x2 v = {fin0 ? fminf(fmaxf(x0, -65504.0f), 65504.0f) : x0, fin1 ? fminf(fmaxf(x1, -65504.0f), 65504.0f) : x1};
     const f16x2 h = __builtin_convertvector(v, f16x2);
     const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const f32x2 r = {v.x - hf.x, v.y - hf.y};
+    const f32x2 r = {fin0 ? v.x - hf.x : 0.0f, fin1 ? v.y - hf.y : 0.0f};
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
   } else {

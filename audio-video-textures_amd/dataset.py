@@ -151,9 +151,18 @@ class DeviceSegmentBatcher:
         self.frames = dataset.video_u8.to(self.dev).contiguous()
         self.audio_eg = dataset.audio_eg.to(self.dev) if dataset.audio_eg.dim() == 4 else None
         self.state = None
+        self._gauss = (0, 0.0)
+        # segment ids the sampler can produce are 0 .. len(ds) (positive = idx + 1, negatives from [0, len]); the gather kernel
+        # reads its starts on the device and CLAMPS frame ids (a bad id cannot fault, but would silently repeat edge frames),
+        # so the one check that every id is in range is made here, once
+        need = len(dataset) * dataset.stride + dataset.window
+        if need > self.frames.shape[0]:
+            raise ValueError("DeviceSegmentBatcher: segment %d needs frames up to %d, the video has %d"
+                             % (len(dataset), need, self.frames.shape[0]))
 
     def seed_from_numpy(self):
         st = np.random.get_state()
+        self._gauss = (int(st[3]), float(st[4]))  # a cached gaussian of the host stream survives the round trip
         words = np.concatenate([np.asarray(st[1], np.uint32), np.array([st[2]], np.uint32)])
         self.state = torch.from_numpy(words.view(np.int32).copy()).to(self.dev)
         return self
@@ -161,7 +170,7 @@ class DeviceSegmentBatcher:
     def sync_to_numpy(self):
         """Hands the advanced stream back to np.random (one D2H of 2.5 KB; only needed when host code draws next)."""
         words = self.state.cpu().numpy().view(np.uint32)
-        np.random.set_state(("MT19937", words[:624].copy(), int(words[624]), 0, 0.0))
+        np.random.set_state(("MT19937", words[:624].copy(), int(words[624]), self._gauss[0], self._gauss[1]))
 
     def sample(self, idx):
         """idx int64 [B] -> (positive ids [B], negative ids [B, n_negs]) on the device."""

@@ -49,6 +49,10 @@ def build_parser():
     a("--SF", "-SF", default=5, type=int, help="slomo factor N")
     a("--train_layout", default="ndhwc", choices=["ndhwc", "ncdhw"],
       help="memory layout of the encoders in training: ndhwc = channels_last_3d (+ fused BatchNorm passes), ncdhw = torch default")
+    a("--train_conv", default="x3", choices=["x3", "fp32"],
+      help="arithmetic of the training convolutions (with --train_layout ndhwc): x3 = split-plane MFMA kernels, fp32 "
+           "accumulation, forward 2^-22 / gradients 2^-16 per product (default; train_ops.py); fp32 = MIOpen's fp32 "
+           "convolutions, the reference's arithmetic (train.py:114-141)")
     a("--slomo_ckpt", default="ckpt/SuperSloMo.ckpt", type=str,
       help="SuperSloMo checkpoint (validate.py:183 hard-codes this path); 'random' = seeded weights; missing file = cuts")
     a("-long", "--long", dest="long", default=False, action="store_true", help="unused in the reference")
@@ -150,8 +154,16 @@ def main(args, video_name, itr=0):
     if not args.evaluate and getattr(args, "train_layout", "ndhwc") == "ndhwc":
         # training layout on the MI355X: channels-last convolution weights (MIOpen's fwd / dgrad / wgrad then run without
         # layout transposes) and the fused train-mode BatchNorm + shortcut + ReLU passes of csrc/bn_train.hip, which work
-        # on channels-last rows (train_ops.bn_act; fp32 step 95 -> 130 clips/s).  Same arithmetic.
+        # on channels-last rows (train_ops.bn_act; fp32 step 95 -> 130 clips/s).  The BatchNorm passes compute
+        # what stock fp32 BatchNorm computes (fp64 statistics); the CONVOLUTIONS' arithmetic is --train_conv's choice: x3 (the
+        # default) is split-plane MFMA, not bit-for-bit fp32 — printed so that a log says which one trained the model.
+        from . import train_ops
+
         model = model.to(memory_format=torch.channels_last_3d)
+        mode = train_ops.set_conv_mode(getattr(args, "train_conv", "x3"))
+        if rank == 0:
+            print("training convolutions: %s" % ("split-plane MFMA (x3: fp16 planes forward 2^-22, bf16 planes gradients 2^-16, "
+                                                  "fp32 accumulation)" if mode == "x3" else "MIOpen fp32"))
     if world > 1 and not args.evaluate:  # weights resident per rank, gradients all-reduced over RCCL
         model = wrap_ddp(model, device, local)
     torch.backends.cudnn.benchmark = True

@@ -6,6 +6,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import train_ops
 from ._lib import AvtError
 from .models import InfoNCECriterion
 from .utils import AverageMeter
@@ -41,6 +42,7 @@ def train(train_loader, model, optimizer, args, epoch, tb_logger=None):
         optimizer.zero_grad()
         loss.backward()
         optimizer.step()
+        train_ops.invalidate_weight_cache()  # (optimizers that update through .data do not bump Tensor._version)
 
         batch_time.update(time.time() - end)
         end = time.time()

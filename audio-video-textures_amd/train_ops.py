@@ -1,9 +1,21 @@
-"""Training-step fusion on the MI355X: train-mode BatchNorm3d + shortcut add + ReLU as one HIP pass in
-each direction (csrc/bn_train.hip), as a torch.autograd.Function the SlowFast modules call in train mode.
+"""Training-step kernels on the MI355X, as torch.autograd.Functions the SlowFast modules call in train mode
+when the model is in the training layout (channels_last_3d, main.py --train_layout ndhwc):
 
-The convolutions of the training step stay MIOpen's (forward / dgrad / wgrad through autograd); what this removes is the
-third of the step that is not convolution: MIOpenBatchNormFwdTrainSpatial, MIOpenBatchNormBwdSpatial and the separate
-add / ReLU / ReLU-backward passes (profiles/r02/train_fp32_steady_state_kernels.log)."""
+* `bn_act`: train-mode BatchNorm3d + shortcut add + ReLU as one HIP statistics pass + one apply pass in each direction
+  (csrc/bn_train.hip) instead of MIOpenBatchNormFwdTrainSpatial / BwdSpatial + separate add / ReLU passes;
+* `conv3d` / `conv3d_fork`: the convolutions' forward and stride-1 input gradient on the split-plane MFMA kernel
+  (csrc/conv_x3.hip, fp32 in / fp32 out) and their weight gradient on csrc/wgrad_x3.hip.  MIOpen keeps the strided input
+  gradients and the stems' weight gradient (aten.convolution_backward).
+
+ARITHMETIC (main.py --train_conv, set_conv_mode): "x3" (the default on the MI355X) computes every product from two 16-bit
+planes with fp32 accumulation — forward in fp16 planes (2^-22 per product), input and weight gradients in bf16 planes (2^-16
+per product, fp32's exponent range; fp32 atomics in the weight gradient, so its summation order is not fixed) — NOT bit-for-bit
+the reference's fp32 (train.py:114-141); "fp32" leaves every convolution to MIOpen's fp32 kernels (what the reference runs)
+and keeps only the fused BatchNorm passes.  tests/test_gpu_train_step.py bounds the loss / gradient deviation of "x3" from an
+fp64 step by the deviation of the stock fp32 step.
+Weight planes are cached per tensor and rebuilt when `weight._version` changes (optimizer.step(), load_state_dict, any
+in-place op on the parameter).  In-place updates through `.data` (EMA / momentum encoders, `p.data.clamp_()`) do NOT bump
+that counter: call `invalidate_weight_cache()` after them (train.train() does after every optimizer step)."""
 import ctypes as C
 import os
 import weakref
@@ -16,7 +28,33 @@ from . import _lib
 _FUSED = int(os.environ.get("AVT_FUSED_BN", "1"))
 _CONV_X3 = int(os.environ.get("AVT_TRAIN_CONV_X3", "1"))
 _WGRAD_X3 = int(os.environ.get("AVT_TRAIN_WGRAD_X3", "1"))
+_DGRAD_S_X3 = int(os.environ.get("AVT_TRAIN_DGRAD_STRIDED_X3", "1"))
+_STEM_WGRAD_X3 = int(os.environ.get("AVT_TRAIN_STEM_WGRAD_X3", "1"))
 _FORK = int(os.environ.get("AVT_TRAIN_FORK", "1"))
+
+
+def set_conv_mode(mode):
+    """"x3": convolutions of the training step on the split-plane MFMA kernels (see the module docstring for the precision);
+    "fp32": MIOpen's fp32 convolutions (the reference's arithmetic).  -> the mode now in force."""
+    global _CONV_X3, _WGRAD_X3
+    if mode not in ("x3", "fp32"):
+        raise ValueError("train_conv must be 'x3' or 'fp32', got %r" % (mode,))
+    _CONV_X3 = _WGRAD_X3 = 1 if mode == "x3" else 0
+    return mode
+
+
+def conv_mode():
+    return "x3" if _CONV_X3 else "fp32"
+
+
+def invalidate_weight_cache():
+    """Drop the cached weight planes (needed after in-place updates through `.data`, which `_version` does not see)."""
+    _PLANES.clear()
+
+
+# per-process launch counters of the hand-written training kernels (tests assert that the default path really runs them)
+CALLS = {"conv_fwd_x3": 0, "dgrad_x3": 0, "dgrad_strided_x3": 0, "wgrad_x3": 0, "wgrad_stem_x3": 0, "bn_fwd": 0, "bn_bwd": 0,
+         "miopen_dgrad": 0, "miopen_wgrad": 0}
 
 
 def _p(t):
@@ -62,6 +100,7 @@ class _BNAct(torch.autograd.Function):
         ws = _workspace(m, c, x.device)
         save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        CALLS["bn_fwd"] += 1
         _lib.check(_lib.lib().avt_bn_train_fwd(_p(x), _p(res), _p(y), m, c, _p(weight), _p(bias), float(eps), float(momentum),
                                                1 if relu else 0, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
                                                _p(running_mean), _p(running_var), _p(tracked), _stream()), "avt_bn_train_fwd")
@@ -79,6 +118,7 @@ class _BNAct(torch.autograd.Function):
         ws = _workspace(m, c, x.device)
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        CALLS["bn_bwd"] += 1
         _lib.check(_lib.lib().avt_bn_train_bwd(_p(dy), _p(y), _p(x), m, c, _p(weight), _p(save_mean), _p(save_invstd), _p(ws), ws.numel(),
                                                _p(dx), _p(dres), _p(dgamma), _p(dbeta), _stream()), "avt_bn_train_bwd")
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
@@ -180,6 +220,7 @@ class _ConvX3(torch.autograd.Function):
             xin = torch.empty((x.shape[0], 8) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device, memory_format=torch.channels_last_3d)
             xin[:, :cin] = x
             xin[:, cin:] = 0
+        CALLS["conv_fwd_x3"] += 1
         return _conv_x3_rows(xin, _weight_planes(weight, False), ops.X3_F16, xin.shape[1], cout, kernel, stride, padding)
 
     @staticmethod
@@ -191,33 +232,36 @@ def _conv_backward(ctx, dy, dalias):
     """(dx, dw) of the convolution; dalias = a gradient that reached the input by another path (conv3d_fork), summed into dx
     in the stride-1 kernel's epilogue instead of by a separate pass."""
     from . import ops
-    if True:
-        x, weight = ctx.saved_tensors
-        stride, padding, kernel, cin, cout = ctx.conf
-        dy = dy.contiguous(memory_format=torch.channels_last_3d)
-        dx = dw = None
-        if ctx.needs_input_grad[1]:
-            taps = kernel[0] * kernel[1] * kernel[2]
-            if (_WGRAD_X3 and cin % 8 == 0 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64 and
-                    weight.is_contiguous(memory_format=torch.channels_last_3d)):
-                dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
-                ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1),
-                                        (x.shape[0], x.shape[2], x.shape[3], x.shape[4]), cin, cout, kernel, stride, padding, cin, cout)
-            else:  # the stems (3 input channels, 49 / 245 taps): MIOpen
-                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
-                                                         [False, True, False])[1]
-        if ctx.needs_input_grad[0]:
+    x, weight = ctx.saved_tensors
+    stride, padding, kernel, cin, cout = ctx.conf
+    dy = dy.contiguous(memory_format=torch.channels_last_3d)
+    dx = dw = None
+    if ctx.needs_input_grad[1]:
+        taps = kernel[0] * kernel[1] * kernel[2]
+        if (_WGRAD_X3 and cin % 8 == 0 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64 and
+                weight.is_contiguous(memory_format=torch.channels_last_3d)):
+            dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
+            CALLS["wgrad_x3"] += 1
+            ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1),
+                                    (x.shape[0], x.shape[2], x.shape[3], x.shape[4]), cin, cout, kernel, stride, padding, cin, cout)
+        else:  # the stems (3 input channels, 49 / 245 taps): MIOpen
+            CALLS["miopen_wgrad"] += 1
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
+                                                     [False, True, False])[1]
+    if ctx.needs_input_grad[0]:
+        if dalias is not None:
+            dalias = dalias.contiguous(memory_format=torch.channels_last_3d)
+        if (cin % 8 == 0 and stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(padding, kernel)) and
+                dy.numel() < (1 << 30) - 64):
+            CALLS["dgrad_x3"] += 1
+            dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias)
+        else:
+            CALLS["miopen_dgrad"] += 1
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
+                                                     [True, False, False])[0]
             if dalias is not None:
-                dalias = dalias.contiguous(memory_format=torch.channels_last_3d)
-            if (cin % 8 == 0 and stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(padding, kernel)) and
-                    dy.numel() < (1 << 30) - 64):
-                dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias)
-            else:
-                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
-                                                         [True, False, False])[0]
-                if dalias is not None:
-                    dx = dx + dalias
-        return dx, dw
+                dx = dx + dalias
+    return dx, dw
 
 
 class _ConvX3Fork(torch.autograd.Function):

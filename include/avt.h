@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 1
+#define AVT_ABI_VERSION 2  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); round 3 adds entry points only */
 
 typedef enum {
   AVT_OK = 0,

@@ -9,6 +9,8 @@ import torch
 
 from oracle import ref_py
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -308,3 +310,72 @@ def test_frames_bar_matches_the_reference_slicing():
         frame_arr[-25:-10, :, :] = bar
         assert np.array_equal(got[k].numpy(), frame_arr), (k, idx)
     assert got[0, -25:-10].sum() == 0 and got[4, -25:-10, :, 0].sum() == 15 * 6 * 255   # idx 0: start -3 -> nothing drawn
+
+
+def _load_bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("avt_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_line_is_compact_and_round_trips():
+    """The driver's capture holds about 8 KB of stdout: the one JSON line must stay under bench.LINE_LIMIT (4096 bytes) with
+    every field of the contract in it, and must survive json.loads (round 2's 20 KB line came back with parsed = null)."""
+    import json
+
+    bench = _load_bench()
+    long_name = "conv_x3_kernel<128,128,64,f16>" + "x" * 40
+    out = {
+        "metric": bench.baseline_metric(), "value": 1234.56789123, "unit": "clip-windows/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+        "ms_per_step": 3318.123456789, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16x3",
+        "data": "synthetic",
+        "config": {"workload": "w" * 260, "windows_per_gpu": 4096, "windows_total": 32768, "embedding_dim": 2304,
+                   "encoder_precision": "f16x3 (contract grade, split-plane MFMA)", "sim_precision": "f32", "encoder_streams": 2,
+                   "parallelism": "windows sharded x8, all-gather(T_hat)"},
+        "roofline": {"kernel": long_name, "bound": "mfma", "achieved": 321.1343313029423, "peak": 833.3333333333334,
+                     "unit": "TFLOP/s", "frac": 0.38536119756353077, "traffic": 2128169230.0,
+                     "encoder_family_achieved": 202.33, "encoder_family_frac": 0.2428, "step_frac": 0.24},
+        "nxn_build_ms": 0.9123456, "survivors_per_row": 3332.123, "fast_mode_value": 2874.123, "fast_mode_ms_per_step": 1425.0,
+        "precision_max_abs_dscore": 2.288818359375e-05, "precision_windows": 128,
+        "frames_lists_identical": {"0.0": "3/3", "0.3": "3/3"}, "nxn_build_ms_seeded_th0": 0.91,
+        "cpu_baseline": {"value": 1.4544949820793884, "unit": "clip-windows/s", "cores": 16, "kind": "port", "sample": "s" * 200},
+        "train_clips_per_s": 174.123, "train_ms_per_step": 735.12,
+    }
+    line = bench.compact_line(out)
+    assert len(line.encode()) < bench.LINE_LIMIT <= 4096 and "\n" not in line
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back
+    assert back["roofline"]["frac"] == pytest.approx(0.385361, rel=1e-5) and back["config"]["workload"] == "w" * 260
+    assert set(back["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(back["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    with pytest.raises(RuntimeError):
+        bench.compact_line(dict(out, junk="j" * 4096))
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it starts N ranks as child processes (never an exec of a process that
+    has touched the GPU) with the rendezvous on 127.0.0.1 and the same arguments."""
+    import subprocess
+
+    bench = _load_bench()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
