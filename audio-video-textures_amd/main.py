@@ -88,6 +88,10 @@ def build_parser():
     a("--enc_dtype", default="fp32", choices=["fp32", "bf16", "bf16x3", "f16x3"],
       help="encoder arithmetic at -e: fp32 (default; on the MFMA kernels = the contract-grade split-plane mode f16x3), "
            "bf16 (fast path: 5x the throughput, scores off by up to 1e-1), or a split-plane mode by name")
+    a("--sim_precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+      help="similarity arithmetic of the SHARDED aligned build (world > 1): f32 = exact, bit-identical to one GPU (all-gathers "
+           "fp32 rows); bf16x3 = bf16 hi/lo planes through the MFMA bf16 pipe (all-gathers the planes, scores within 5e-6); "
+           "bf16 = one plane (outside the 1e-3 score contract)")
     a("--enc_batch", default=64, type=int,
       help="windows per encoder batch (64: whole rounds of the 256 CUs on the long-K layers; ~10 GB of activations at 224^2)")
     a("--enc_impl", default="auto", choices=["auto", "mfma", "module"],

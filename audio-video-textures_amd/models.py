@@ -247,12 +247,21 @@ class ModelBuilder3D(object):
             raise Exception("Architecture {} undefined: the reference's own ResNeXt/DenseNet factories reject the "
                             "arguments ModelBuilder3D passes (models.py:557-564)".format(arch))
         if pretrained:
-            # the reference reads Kinetics weights from absolute paths outside its repo (models.py:568-573);
-            # here they are optional and named by an environment variable
+            # the reference reads Kinetics weights from absolute paths outside its repo (models.py:568-573: the caffe2 pickle
+            # SLOWFAST_8x8_R50.pkl through PySlowFast); here the path is named by an environment variable, or found at the
+            # reference's own relative location, and both the caffe2 .pkl and a torch state dict are accepted
             path = os.environ.get("AVT_PRETRAINED_" + arch.upper())
+            if not path and "slowfast" in arch and os.path.isfile(os.path.join("pretrained", "SLOWFAST_8x8_R50.pkl")):
+                path = os.path.join("pretrained", "SLOWFAST_8x8_R50.pkl")
             if path and os.path.isfile(path):
-                sd = torch.load(path, map_location="cpu")
-                model.load_state_dict(sd.get("state_dict", sd), strict=False)
+                if "slowfast" in arch:
+                    from .checkpoint import load_kinetics_slowfast
+
+                    dropped = load_kinetics_slowfast(model, path, strict=True)
+                    print("ModelBuilder3D: {} loaded into SlowFast ({} blobs without a place dropped)".format(path, len(dropped)))
+                else:
+                    sd = torch.load(path, map_location="cpu")
+                    model.load_state_dict(sd.get("state_dict", sd), strict=False)
             else:
                 print("ModelBuilder3D: no pretrained weights for '{}' (set AVT_PRETRAINED_{}); random init".format(
                     arch, arch.upper()))

@@ -92,6 +92,11 @@ def _unwrap(model):
     return model.module if hasattr(model, "module") else model
 
 
+def eng_dim(net):
+    """Embedding width of the similarity: 2304 (m=1) or 2304 + 12288 (m=2, models.py:347-351)."""
+    return 2304 + (12288 if net.model_type == 2 else 0)
+
+
 def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=2, itr=0, video=None,
              audio=None, driving_audio=None):
     """Extra keyword inputs (all optional) let callers hand over decoded media instead of paths:
@@ -254,7 +259,14 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
             av = eng.audio_block(audio_eg, lo, hi) if net.model_type == 2 else None
             return qv, tv, av
 
-        surv = adist.sharded_survivors(encode_block, L, args.threshold, adist.HipCompute(net.temp, "f32"), rank, world,
+        # --sim_precision: f32 (default) = the exact fp32 similarity, bit-identical to the oracle and to world 1 — the exchange is
+        # N*D*4 B; bf16x3 all-gathers the bf16 hi/lo planes of T_hat instead (N*D*2 B each, north_star's figure per plane;
+        # scores within 5e-6 of f32, not used for bit-exact claims); bf16 = one plane (2e-3: outside the score contract)
+        sim_prec = getattr(args, "sim_precision", "f32")
+        if rank == 0:
+            print("Sharded N x N build over {} ranks, similarity {} ({} B exchanged per target row)".format(
+                world, sim_prec, {"f32": 4, "bf16x3": 4, "bf16": 2}[sim_prec] * eng_dim(net)))
+        surv = adist.sharded_survivors(encode_block, L, args.threshold, adist.HipCompute(net.temp, sim_prec), rank, world,
                                        want_sim=driving_audio_name is not None)
         if rank != 0:
             return None  # this rank's rows are with rank 0; the serial walk (validate.py:324, 572) is rank 0's

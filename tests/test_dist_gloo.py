@@ -152,3 +152,64 @@ def test_sharded_walk_world2_equals_world1(with_audio):
     assert np.array_equal(two["cnt"], one["cnt"]) and two["k"] == one["k"] == int(one["cnt"].max())
     assert np.array_equal(two["sim"], one["sim"])  # bit-identical rows whatever the shard boundary
     assert one["cnt"].min() < one["cnt"].max()  # ragged survivor lists: the agreed width really is a maximum
+
+
+class _OraclePlaneCompute(_OracleCompute):
+    """CPU stand-in for dist.HipCompute(temp, "bf16x3"): the planes that travel are the bf16 hi / lo bit patterns of the
+    normalised rows (typed bfloat16, as the product's planes are), the similarity is the oracle's three-product bf16 form."""
+
+    def l2norm(self, v, a=None):
+        from oracle import cref
+
+        _, hi, lo = cref.l2norm_rows(v.numpy(), None if a is None else a.numpy(), want_split=True)
+        return (torch.from_numpy(hi.view(np.int16)).view(torch.bfloat16), torch.from_numpy(lo.view(np.int16)).view(torch.bfloat16))
+
+    def sim(self, q, t):
+        from oracle import cref
+
+        u = lambda x: np.ascontiguousarray(x.contiguous().view(torch.int16).numpy()).view(np.uint16)
+        return torch.from_numpy(cref.sim_bf16(u(q[0]), u(q[1]), u(t[0]), u(t[1]), self.temp, True))
+
+
+def _walk_worker_planes(rank, world, port, n, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import avtex  # noqa: F401
+    from avtex import agreement, dist as adist
+
+    if world > 1:
+        adist.init_from_env(backend="gloo")
+    q, t, _ = _tables(n, 40, 24)
+    surv = adist.sharded_survivors(lambda lo, hi: (q[lo:hi].contiguous(), t[lo:hi].contiguous(), None), n, 0.3,
+                                   _OraclePlaneCompute(0.1), rank, world, want_sim=True)
+    if rank == 0:
+        frames, _ = agreement.walk_from_survivors(surv["idx"], surv["seg"], surv["cnt"], n * 2 + 6, 6, 2, 120, q_id=10,
+                                                  rng=np.random.RandomState(5))
+        ret["frames"], ret["sim"], ret["cnt"] = frames, surv["sim"], surv["cnt"]
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_sharded_walk_world4_equals_world1():
+    """Four ranks, ragged shards (51 = 13 + 13 + 13 + 12), audio columns: same frames list, same matrix bits as one rank."""
+    n = 51
+    mgr = mp.Manager()
+    one, four = mgr.dict(), mgr.dict()
+    _walk_worker(0, 1, 0, n, True, one)
+    mp.spawn(_walk_worker, args=(4, 29741, n, True, four), nprocs=4, join=True)
+    assert list(four["frames"]) == list(one["frames"]) and len(one["frames"]) >= 200
+    assert np.array_equal(four["cnt"], one["cnt"]) and np.array_equal(four["sim"], one["sim"])
+
+
+def test_sharded_plane_exchange_world2_equals_world1():
+    """--sim_precision bf16x3 on the sharded route (validate.py): the all-gather carries the two bf16 planes of T_hat
+    (N*D*2 B each, north_star's exchange) instead of fp32 rows; rows computed from gathered planes are bit-identical to
+    one rank's, so the frames list is too."""
+    n = 37
+    mgr = mp.Manager()
+    one, two = mgr.dict(), mgr.dict()
+    _walk_worker_planes(0, 1, 0, n, one)
+    mp.spawn(_walk_worker_planes, args=(2, 29751, n, two), nprocs=2, join=True)
+    assert np.array_equal(two["sim"], one["sim"]) and np.array_equal(two["cnt"], one["cnt"])
+    assert list(two["frames"]) == list(one["frames"])

@@ -379,3 +379,75 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+
+
+def _caffe2_names_of(key):
+    """TEST-side inverse, written from the caffe2 naming convention (not from checkpoint.py): a `SlowFast` state-dict key ->
+    the blob name the Kinetics model-zoo pickle uses for it."""
+    bn = {"weight": "s", "bias": "b", "running_mean": "rm", "running_var": "riv"}
+    parts = key.split(".")
+    if parts[0].endswith("_fuse"):  # s1_fuse.conv_f2s.weight / s3_fuse.bn.running_var
+        stage = int(parts[0][1])
+        last_block = {2: 2, 3: 3, 4: 5}  # the fusion hangs off the LAST fast block of stages 2-4 (depths 3, 4, 6)
+        pre = "t_pool1_subsample" if stage == 1 else "t_res%d_%d_branch2c_bn_subsample" % (stage, last_block[stage])
+        return pre + ("_w" if parts[1] == "conv_f2s" else "_bn_" + bn[parts[2]])
+    if parts[0] == "s1":  # s1.pathway1_stem.conv.weight
+        t = "t_" if parts[1].startswith("pathway1") else ""
+        return t + ("conv1_w" if parts[2] == "conv" else "res_conv1_bn_" + bn[parts[3]])
+    stage = int(parts[0][1])
+    t = "t_" if parts[1].startswith("pathway1") else ""
+    idx = int(parts[1].split("_res")[1])
+    pre = "%sres%d_%d_" % (t, stage, idx)
+    if parts[2] == "branch1":
+        return pre + "branch1_w"
+    if parts[2] == "branch1_bn":
+        return pre + "branch1_bn_" + bn[parts[3]]
+    name = parts[3]  # branch2.a.weight / branch2.b_bn.bias
+    return pre + ("branch2%s_w" % name if "_bn" not in name else "branch2%s_bn_%s" % (name[0], bn[parts[4]]))
+
+
+def test_kinetics_caffe2_checkpoint_loads_into_slowfast(tmp_path, monkeypatch):
+    """models.py:565-580: the reference's encoders start from the caffe2 pickle SLOWFAST_8x8_R50.pkl.  A synthetic blob dict
+    in the model zoo's naming covers EVERY parameter and running statistic of slowfast.SlowFast (+ the classifier, solver
+    momentum blobs and scalars a real file carries, which must be dropped); ModelBuilder3D loads it through
+    AVT_PRETRAINED_SLOWFAST and every tensor arrives in its place."""
+    import pickle
+
+    import avtex
+    from avtex import checkpoint
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(0)
+    src = SlowFast()
+    want = {k: v for k, v in src.state_dict().items() if not k.endswith("num_batches_tracked")}
+    rng = np.random.RandomState(0)
+    blobs, expect = {}, {}
+    for k, v in want.items():
+        name = _caffe2_names_of(k)
+        assert name not in blobs, (k, name)
+        blobs[name] = rng.standard_normal(tuple(v.shape)).astype(np.float32)
+        expect[k] = blobs[name]
+        if name.endswith("_w") or name.endswith("_s") or name.endswith("_b"):
+            blobs[name + "_momentum"] = np.zeros(tuple(v.shape), np.float32)
+    assert len(blobs) > 2 * len(want) * 0.5 and "t_res4_5_branch2c_bn_subsample_bn_riv" in blobs and "res5_2_branch2c_bn_s" in blobs
+    blobs.update({"pred_w": np.zeros((400, 2304), np.float32), "pred_b": np.zeros(400, np.float32),
+                  "lr": np.float32(0.1), "model_iter": np.float32(1.0)})
+    path = tmp_path / "SLOWFAST_8x8_R50.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({"blobs": blobs}, f, protocol=2)
+    # every model key is hit exactly once, nothing else maps anywhere
+    sd, dropped = checkpoint.convert_caffe2_slowfast(blobs)
+    assert set(sd) == set(want) and {"pred_w", "pred_b", "lr", "model_iter"} <= set(dropped)
+    assert all(d.endswith("_momentum") or d in ("pred_w", "pred_b", "lr", "model_iter") for d in dropped)
+    monkeypatch.setenv("AVT_PRETRAINED_SLOWFAST", str(path))
+    model, fc_dim = avtex.ModelBuilder3D.build_network("slowfast", 224, 20, pretrained=True)
+    assert fc_dim == 128
+    got = model.state_dict()
+    for k, v in expect.items():
+        assert np.array_equal(got[k].numpy(), v), k
+    # a file with a missing blob is rejected, not half-loaded
+    del blobs["t_res3_1_branch2b_w"]
+    with open(path, "wb") as f:
+        pickle.dump({"blobs": blobs}, f, protocol=2)
+    with pytest.raises(ValueError, match="missing"):
+        checkpoint.load_kinetics_slowfast(SlowFast(), str(path))
