@@ -1,0 +1,431 @@
+// bneck_x3 — one whole residual bottleneck of the SlowFast FAST pathway in a single kernel, in the contract-grade
+// split-plane arithmetic (conv_x3.hip: every tensor is two 16-bit planes x = hi + lo, a product is three MFMA passes
+// wl*xh + wh*xl + wh*xh into one fp32 accumulator):
+//     out = relu( c( relu( b( relu( a(x) ) ) ) ) + x )            identity blocks (C = 32 / 64 / 128, Cm = 8 / 16 / 32)
+//     out = relu( c( relu( b( relu( a(x) ) ) ) ) + s(x) )         res2's first block (x has 8 channels, s = 1x1x1 conv)
+//     a: Conv3d [3,1,1] C -> Cm,  b: Conv3d [1,3,3] Cm -> Cm,  c: Conv3d [1,1,1] Cm -> C,  BatchNorms folded
+// (blocks of the third-party SlowFast model the reference runs per clip window, contrastive_video_textures/models/models.py:
+// 335, 399).  The bf16 path's bottleneck_fused.hip keeps a 3-frame ring of the x strip in LDS; with two planes that ring is
+// 210 KB for the res2 strip and no longer fits.  Here the ring lives in REGISTERS: a wave owns the same 16-position tiles in
+// every stage of every frame, so
+//   * the three frame taps of a are the MFMA B operands as loaded (lane = position l & 15, k-group l >> 4 = 16 contiguous
+//     bytes of a row: pw_x3.hip's trick), kept for three frames in a register ring that rotates by renaming (the frame loop
+//     is unrolled by three); the load of frame t+2 is issued right after a's MFMAs of frame t have consumed frame t-1 and
+//     lands under the b and c stages, one whole frame-iteration ahead of its use;
+//   * c's residual is the ring's middle frame — the same registers, the same lane layout (c's output rows are permuted in
+//     the packing so a lane ends with 8 consecutive channels = one k-group of the operand);
+//   * LDS holds only the a-output and b-output strips (hi and lo planes; zero border columns for b's padding) and the
+//     weight fragments; HBM sees x once (+ a 2-row halo per strip, + 2 halo frames per frame chunk) and out once.
+// The first-block form keeps ONE operand per tile (k-group q = frame t-1+q, 8 channels each), rotated between lanes with
+// ds_bpermute when the next frame arrives; its shortcut conv reads the same operand (weights at k-group 1 = frame t).
+// HBM-bound by construction: ~900 MFMAs (16x16x32) per frame-strip against 129 KB of traffic on the res2 strip.
+// Output stores and x loads are raw buffer operations that are ALWAYS issued (out-of-range lanes carry an out-of-bounds
+// offset: loads return the zero padding, stores are dropped), so every wave's vmcnt sequence is the same whatever its tiles.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "avt_common.h"
+#include "split_planes.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFFFF0u;
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(i32x4 w, i32x4 x, f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+// one split-plane product, small terms first (conv_x3.hip's order)
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma3(i32x4 wh, i32x4 wl, i32x4 xh, i32x4 xl, f32x4 c) {
+  c = mfma16<F16>(wl, xh, c);
+  c = mfma16<F16>(wh, xl, c);
+  return mfma16<F16>(wh, xh, c);
+}
+
+struct BxArgs {
+  const uint16_t* xh;
+  const uint16_t* xl;
+  uint16_t* oh;
+  uint16_t* ol;
+  const i32x4* wf;    // [NF][2 planes][64 lanes]: a [3][KA][NTA] (first block: [NTA]), b [NB][NTA], c [C/16], shortcut [C/16]
+  const float* coef;  // [sa CMP | ba CMP | sb CMP | bb CMP | sc C | bc C]: power-of-two weight scales and biases
+  int T, H;
+  int strips, tchunks, TC;
+  int swz;
+  unsigned x_bytes, o_bytes;  // bytes of ONE plane
+};
+
+template <int C, int W, int HT, int CMP, int CIN, int NW, bool F16>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs a) {
+  constexpr bool FIRST = CIN == 8;
+  static_assert(FIRST || CIN == C, "identity blocks, or the 8-channel first block");
+  static_assert(!FIRST || CMP == 16, "first-block form: width <= 16");
+  constexpr int RX = HT + 2, AW = W + 2, APOS = RX * AW;
+  constexpr int AREC = CMP * 2, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
+  constexpr int KA = FIRST ? 1 : CIN / 32;
+  constexpr int NFA = (FIRST ? 1 : 3) * KA * NTA, NFB = NB * NTA, NTC = C / 16;
+  constexpr int NF = NFA + NFB + NTC + (FIRST ? NTC : 0);
+  constexpr int PB = HT * W, MTB = (PB + 15) / 16, MTH = (2 * W + 15) / 16;
+  // tile slots of a wave: CIT main tiles (wave w owns tiles w, w + NW, ...: the SAME positions in the a and the c stage), the
+  // halo tiles (strip rows 0 and HT + 1) in the slots the last round of main tiles leaves free, further ones in extra slots
+  constexpr int CIT = (MTB + NW - 1) / NW, REM = MTB - NW * (CIT - 1), FREE = NW - REM;
+  constexpr int AIT = CIT + (MTH > FREE ? (MTH - FREE + NW - 1) / NW : 0);
+  constexpr int ABYTES = APOS * AREC, BBYTES = MTB * 16 * AREC;
+  constexpr int NCOEF = 4 * CMP + 2 * C;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* wl = lds;                                             // [NF][2][1 KB]
+  float* cf = reinterpret_cast<float*>(lds + NF * 2048);      // [NCOEF]
+  char* aoh = lds + NF * 2048 + NCOEF * 4;                    // a-output strip, hi plane: [APOS][CMP]
+  char* aol = aoh + ABYTES;
+  char* boh = aol + ABYTES;                                   // b-output strip: [MTB * 16][CMP]
+  char* bol = boh + BBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  int bid = a.swz ? avt::xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tch = bid % a.tchunks;
+  bid /= a.tchunks;
+  const int strip = bid % a.strips, b = bid / a.strips;
+  const int h0 = strip * HT, t0 = tch * a.TC;
+  const int t1 = (t0 + a.TC < a.T) ? t0 + a.TC : a.T;
+
+  for (int f = wid; f < NF * 2; f += NW) *reinterpret_cast<i32x4*>(wl + f * 1024 + lane * 16) = a.wf[f * 64 + lane];
+  for (int i = tid; i < NCOEF; i += NW * 64) cf[i] = a.coef[i];
+  // both a strips start as zeros: border columns, rows outside the image and tile padding stay zero for the whole walk
+  for (int i = tid * 16; i < 2 * ABYTES; i += NW * 64 * 16) *reinterpret_cast<i32x4*>(aoh + i) = i32x4{0, 0, 0, 0};
+
+  const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)a.xh, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)a.xl, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t roh = __builtin_amdgcn_make_buffer_rsrc((void*)a.oh, 0, a.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rol = __builtin_amdgcn_make_buffer_rsrc((void*)a.ol, 0, a.o_bytes, 0x00020000);
+
+  // ---- geometry of this lane in every tile slot, computed once
+  unsigned poff[AIT];  // byte offset inside a frame (one plane) of this lane's chunk of k-step 0, or out of bounds
+  int a_st[AIT];       // a-strip byte offset of this lane's 4 channels of n-tile 0, or -1 (nothing to store)
+  unsigned a_used = 0;
+#pragma unroll
+  for (int it = 0; it < AIT; ++it) {
+    const int m = wid + NW * it;
+    const bool is_main = it < CIT && m < MTB;
+    int hidx = -1;
+    if (it == CIT - 1) hidx = is_main ? -1 : wid - REM;
+    if (it >= CIT) hidx = FREE + (it - CIT) * NW + wid;
+    const bool is_halo = !is_main && hidx >= 0 && hidx < MTH;
+    const int p = m * 16 + l15, hp = hidx * 16 + l15;
+    const bool valid = is_main ? p < PB : (is_halo && hp < 2 * W);
+    int srow, wcol;
+    if (is_main) {
+      const int pc = valid ? p : PB - 1;
+      const int r = pc / W;
+      srow = r + 1;
+      wcol = pc - r * W;
+    } else {
+      const int hc = valid ? hp : 0;
+      srow = hc < W ? 0 : HT + 1;
+      wcol = hc < W ? hc : hc - W;
+    }
+    const int hi = h0 - 1 + srow;
+    const bool rowin = valid && (unsigned)hi < (unsigned)a.H;
+    poff[it] = rowin ? (unsigned)(((hi * W + wcol) * CIN + (FIRST ? 0 : q * 8)) * 2) : kOob;
+    a_st[it] = rowin ? (srow * AW + wcol + 1) * AREC + q * 8 : -1;
+    a_used |= ((is_main || is_halo) ? 1u : 0u) << it;
+  }
+  a_used = __builtin_amdgcn_readfirstlane(a_used);
+  int tapoff[NB];  // b: byte offset of this lane's operand chunk of k-step j relative to tap (0, 0) of its position
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if constexpr (CMP == 16) {  // k-groups 0,1 = tap 2j, 2,3 = tap 2j+1 (tap 9 has zero weights: any finite data)
+      const int tap = (q >> 1) ? (2 * j + 1 < 9 ? 2 * j + 1 : 8) : 2 * j;
+      tapoff[j] = ((tap / 3) * AW + tap % 3) * AREC + (q & 1) * 16;
+    } else {
+      tapoff[j] = ((j / 3) * AW + j % 3) * AREC + q * 16;
+    }
+  }
+  const int cchunk = (CMP == 16 ? (q & 1) : q) * 16;  // c: this lane's k-group inside a b-strip record
+  int b_rd[CIT];
+  unsigned c_out[CIT];  // byte offset inside an output frame (one plane) of this lane's 8 channels of pair 0, or out of bounds
+#pragma unroll
+  for (int it = 0; it < CIT; ++it) {
+    const int m = wid + NW * it;
+    const int p = m * 16 + l15;
+    const int pc = (m < MTB && p < PB) ? p : PB - 1;
+    const int r = pc / W, w = pc - r * W;
+    b_rd[it] = (r * AW + w) * AREC;
+    c_out[it] = (m < MTB && p < PB && h0 + r < a.H) ? (unsigned)((((h0 + r) * W + w) * C + 8 * q) * 2) : kOob;
+  }
+  auto xo = [&](int it, int k, int tt) -> int {  // buffer offset of this lane's chunk of k-step k in frame tt
+    const bool tin = (unsigned)tt < (unsigned)a.T && tt <= t1;  // frames t0-1 .. t1 are all this chunk reads
+    const unsigned fbase = (unsigned)((b * a.T + tt) * a.H) * (unsigned)(W * CIN * 2);
+    return (int)((tin && poff[it] != kOob) ? fbase + poff[it] + (unsigned)(k * 64) : kOob);
+  };
+  auto WF = [&](int f, int plane, int lofs) { return *reinterpret_cast<const i32x4*>(wl + (f * 2 + plane) * 1024 + lofs); };
+
+  // ---- the register ring: xr[tile slot][ring slot][k-step][plane]; first block: op = this iteration's operand, nx = frame t+2
+  constexpr int RS = FIRST ? 2 : 3;
+  i32x4 xr[AIT][RS][KA][2];
+  auto load_frame = [&](auto slot_c, int tt) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int it = 0; it < AIT; ++it)
+#pragma unroll
+      for (int k = 0; k < KA; ++k) {
+        const int off = xo(it, k, tt);
+        xr[it][slot][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+        xr[it][slot][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
+      }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  if constexpr (FIRST) {
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {  // lane group q starts with frame t0 - 1 + q (group 3: zero weights, any frame)
+      const int off = xo(it, 0, t0 - 1 + (q < 3 ? q : 2));
+      xr[it][0][0][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+      xr[it][0][0][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
+    }
+  } else {
+    load_frame(I0{}, t0 - 1);
+    load_frame(I1{}, t0);
+    load_frame(I2{}, t0 + 1);
+  }
+  __syncthreads();  // weights, coefficients and the zeroed strips are in place
+
+  // one frame; R = rotation of the ring: slot R holds frame t-1, R+1 frame t, R+2 frame t+1
+  auto body = [&](auto rot_c, int t) __attribute__((always_inline)) {
+    constexpr int R = decltype(rot_c)::value;
+    constexpr int PV = R % 3, CU = (R + 1) % 3, NX = (R + 2) % 3;
+    if constexpr (FIRST) {
+      if (t > t0) {  // the operand moves one frame on: groups 0,1 take their right neighbour's chunk, group 2 the new frame
+#pragma unroll
+        for (int it = 0; it < AIT; ++it)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int up = __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) * 4, xr[it][0][0][pl][e]);
+              xr[it][0][0][pl][e] = q < 2 ? up : xr[it][1][0][pl][e];
+            }
+      }
+      load_frame(I1{}, t + 2);  // consumed by the rotation at the top of the next frame
+    }
+    // ---- [a] temporal conv, operands straight from the ring -> relu -> split -> a strips
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      if ((a_used >> it) & 1u) {  // wave-uniform
+        int lofs = lane * 16;  // opaque per tile: keeps the loop-invariant fragment reads from being hoisted into registers
+        asm volatile("" : "+v"(lofs));
+        f32x4 acc[NTA];
+#pragma unroll
+        for (int n = 0; n < NTA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (FIRST) {
+#pragma unroll
+          for (int n = 0; n < NTA; ++n)
+            acc[n] = mfma3<F16>(WF(n, 0, lofs), WF(n, 1, lofs), xr[it][0][0][0], xr[it][0][0][1], acc[n]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < KA; ++k)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+              constexpr int slots[3] = {PV, CU, NX};
+              const int s = slots[dt];
+#pragma unroll
+              for (int n = 0; n < NTA; ++n) {
+                const int f = (dt * KA + k) * NTA + n;
+                acc[n] = mfma3<F16>(WF(f, 0, lofs), WF(f, 1, lofs), xr[it][s][k][0], xr[it][s][k][1], acc[n]);
+              }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NTA; ++n) {
+          const float4 s = *reinterpret_cast<const float4*>(cf + 16 * n + 4 * q);
+          const float4 bb_ = *reinterpret_cast<const float4*>(cf + CMP + 16 * n + 4 * q);
+          uint2 h, l;
+          avt::split2<F16>(fmaxf(acc[n][0] * s.x + bb_.x, 0.f), fmaxf(acc[n][1] * s.y + bb_.y, 0.f), h.x, l.x);
+          avt::split2<F16>(fmaxf(acc[n][2] * s.z + bb_.z, 0.f), fmaxf(acc[n][3] * s.w + bb_.w, 0.f), h.y, l.y);
+          if (a_st[it] >= 0) {
+            *reinterpret_cast<uint2*>(aoh + a_st[it] + n * 32) = h;
+            *reinterpret_cast<uint2*>(aol + a_st[it] + n * 32) = l;
+          }
+        }
+      }
+    }
+    if constexpr (!FIRST) load_frame(std::integral_constant<int, PV>{}, t + 2);  // frame t-1 is consumed: its slot takes frame t+2
+    __syncthreads();  // a strips complete
+    // ---- [b] 3x3 spatial conv, operands straight from the a strips at tap-shifted addresses
+#pragma unroll
+    for (int it = 0; it < CIT; ++it) {
+      const int m = wid + NW * it;
+      if (m < MTB) {
+        int lofs = lane * 16;
+        asm volatile("" : "+v"(lofs));
+        f32x4 acc[NTA];
+#pragma unroll
+        for (int n = 0; n < NTA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const i32x4 fh = *reinterpret_cast<const i32x4*>(aoh + b_rd[it] + tapoff[j]);
+          const i32x4 fl = *reinterpret_cast<const i32x4*>(aol + b_rd[it] + tapoff[j]);
+#pragma unroll
+          for (int n = 0; n < NTA; ++n) {
+            const int f = NFA + j * NTA + n;
+            acc[n] = mfma3<F16>(WF(f, 0, lofs), WF(f, 1, lofs), fh, fl, acc[n]);
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NTA; ++n) {
+          const float4 s = *reinterpret_cast<const float4*>(cf + 2 * CMP + 16 * n + 4 * q);
+          const float4 bb_ = *reinterpret_cast<const float4*>(cf + 3 * CMP + 16 * n + 4 * q);
+          uint2 h, l;
+          avt::split2<F16>(fmaxf(acc[n][0] * s.x + bb_.x, 0.f), fmaxf(acc[n][1] * s.y + bb_.y, 0.f), h.x, l.x);
+          avt::split2<F16>(fmaxf(acc[n][2] * s.z + bb_.z, 0.f), fmaxf(acc[n][3] * s.w + bb_.w, 0.f), h.y, l.y);
+          const int o = (m * 16 + l15) * AREC + n * 32 + q * 8;
+          *reinterpret_cast<uint2*>(boh + o) = h;
+          *reinterpret_cast<uint2*>(bol + o) = l;
+        }
+      }
+    }
+    __syncthreads();  // b strips complete
+    // ---- [c] pointwise conv (+ shortcut conv) + bias + residual (the ring's frame t) -> relu -> split -> global
+    const unsigned obase = (unsigned)((b * a.T + t) * a.H) * (unsigned)(W * C * 2);
+#pragma unroll
+    for (int it = 0; it < CIT; ++it) {  // the same trip count in every wave: every store is issued, in or out of bounds
+      const int m = wid + NW * it;
+      const int pr = (m < MTB ? m : MTB - 1) * 16 + l15;
+      const i32x4 fh = *reinterpret_cast<const i32x4*>(boh + pr * AREC + cchunk);  // CMP = 16: k >= 16 has zero weights
+      const i32x4 fl = *reinterpret_cast<const i32x4*>(bol + pr * AREC + cchunk);
+      int lofs = lane * 16;
+      asm volatile("" : "+v"(lofs));
+#pragma unroll
+      for (int np = 0; np < NTC / 2; ++np) {
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        const int f0 = NFA + NFB + 2 * np;
+        c0 = mfma3<F16>(WF(f0, 0, lofs), WF(f0, 1, lofs), fh, fl, c0);
+        c1 = mfma3<F16>(WF(f0 + 1, 0, lofs), WF(f0 + 1, 1, lofs), fh, fl, c1);
+        if constexpr (FIRST) {  // shortcut = 1x1x1 conv of x(t) (k-group 1 of the operand) into the same tile; bc = bc + b_shortcut
+          const int s0 = NFA + NFB + NTC + 2 * np;
+          c0 = mfma3<F16>(WF(s0, 0, lofs), WF(s0, 1, lofs), xr[it][0][0][0], xr[it][0][0][1], c0);
+          c1 = mfma3<F16>(WF(s0 + 1, 0, lofs), WF(s0 + 1, 1, lofs), xr[it][0][0][0], xr[it][0][0][1], c1);
+        }
+        const float* sp = cf + 4 * CMP + 32 * np + 8 * q;
+        const float4 sa_ = *reinterpret_cast<const float4*>(sp), sb_ = *reinterpret_cast<const float4*>(sp + 4);
+        const float4 ba_ = *reinterpret_cast<const float4*>(sp + C), bb_ = *reinterpret_cast<const float4*>(sp + C + 4);
+        float v[8] = {c0[0] * sa_.x + ba_.x, c0[1] * sa_.y + ba_.y, c0[2] * sa_.z + ba_.z, c0[3] * sa_.w + ba_.w,
+                      c1[0] * sb_.x + bb_.x, c1[1] * sb_.y + bb_.y, c1[2] * sb_.z + bb_.z, c1[3] * sb_.w + bb_.w};
+        if constexpr (!FIRST) {
+          const i32x4 rh = xr[it][CU][np][0], rl = xr[it][CU][np][1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const avt::f32x2 r = avt::join2<F16>((uint32_t)rh[e], (uint32_t)rl[e]);
+            v[2 * e] += r.x;
+            v[2 * e + 1] += r.y;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        uint4 oh, ol;
+        avt::split2<F16>(v[0], v[1], oh.x, ol.x);
+        avt::split2<F16>(v[2], v[3], oh.y, ol.y);
+        avt::split2<F16>(v[4], v[5], oh.z, ol.z);
+        avt::split2<F16>(v[6], v[7], oh.w, ol.w);
+        const int off = (int)(c_out[it] != kOob ? obase + c_out[it] + (unsigned)(np * 64) : kOob);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, oh), roh, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ol), rol, off, 0, 0);
+      }
+    }
+  };
+
+  for (int t = t0; t < t1;) {
+    body(I0{}, t);
+    if (++t >= t1) break;
+    body(I1{}, t);
+    if (++t >= t1) break;
+    body(I2{}, t);
+    ++t;
+  }
+}
+
+template <int C, int W, int HT, int CMP, int CIN, int NW, bool F16>
+int launch(BxArgs& a, int batch, int h, hipStream_t st) {
+  constexpr bool FIRST = CIN == 8;
+  constexpr int KA = FIRST ? 1 : CIN / 32, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
+  constexpr int NF = (FIRST ? 1 : 3) * KA * NTA + NB * NTA + C / 16 + (FIRST ? C / 16 : 0);
+  constexpr int MTB = (HT * W + 15) / 16;
+  constexpr int lds_bytes = NF * 2048 + (4 * CMP + 2 * C) * 4 + 2 * ((HT + 2) * (W + 2) * CMP * 2) + 2 * (MTB * 16 * CMP * 2);
+  static_assert(lds_bytes <= 160 * 1024, "strips do not fit the LDS");
+  a.strips = (h + HT - 1) / HT;
+  static const int swz = avt::env_int_flag("AVT_XCD_SWZ", 1);
+  a.swz = swz;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_x3_kernel<C, W, HT, CMP, CIN, NW, F16>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_bneck_x3: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((bneck_x3_kernel<C, W, HT, CMP, CIN, NW, F16>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
+                     lds_bytes, st, a);
+  return avt::check_launch("avt_bneck_x3");
+}
+
+template <bool F16>
+int dispatch(BxArgs& a, int batch, int h, int w, int cin, int c, hipStream_t s) {
+  if (cin == 8) {
+    if (w == 56) return launch<32, 56, 8, 16, 8, 12, F16>(a, batch, h, s);
+    return launch<32, 12, 5, 16, 8, 4, F16>(a, batch, h, s);
+  }
+  if (c == 32 && w == 56) return launch<32, 56, 8, 16, 32, 12, F16>(a, batch, h, s);
+  if (c == 64 && w == 28) return launch<64, 28, 6, 16, 64, 8, F16>(a, batch, h, s);
+  if (c == 128 && w == 14) return launch<128, 14, 7, 32, 128, 9, F16>(a, batch, h, s);
+  if (c == 32 && w == 12) return launch<32, 12, 5, 16, 32, 4, F16>(a, batch, h, s);   // small shapes for the tests: ragged
+  if (c == 64 && w == 10) return launch<64, 10, 4, 16, 64, 4, F16>(a, batch, h, s);   // strips, partial tiles
+  return launch<128, 6, 3, 32, 128, 4, F16>(a, batch, h, s);
+}
+
+}  // namespace
+
+extern "C" int avt_bneck_x3_supported(int cin, int c, int w) {
+  if (cin == 8) return (c == 32 && (w == 56 || w == 12)) ? 1 : 0;
+  if (cin != c) return 0;
+  return ((c == 32 && (w == 56 || w == 12)) || (c == 64 && (w == 28 || w == 10)) || (c == 128 && (w == 14 || w == 6))) ? 1 : 0;
+}
+
+extern "C" int avt_bneck_x3(const void* x_hi, const void* x_lo, void* out_hi, void* out_lo, const void* wfrag, const float* coef,
+                            int batch, int t, int h, int w, int cin, int c, int tchunk, int plane_dtype, void* stream) {
+  AVT_REQUIRE(x_hi && x_lo && out_hi && out_lo && wfrag && coef, "avt_bneck_x3: NULL pointer");
+  AVT_REQUIRE(avt_bneck_x3_supported(cin, c, w),
+              "avt_bneck_x3: unsupported shape Cin=%d C=%d W=%d (fast-pathway blocks: 32x56, 64x28, 128x14, first block 8->32 x56)",
+              cin, c, w);
+  AVT_REQUIRE(batch > 0 && t > 0 && h > 0 && tchunk > 0, "avt_bneck_x3: bad sizes");
+  AVT_REQUIRE(x_hi != out_hi && x_lo != out_lo, "avt_bneck_x3: in-place is not supported (neighbouring strips read x)");
+  AVT_REQUIRE(avt::aligned16(x_hi) && avt::aligned16(x_lo) && avt::aligned16(out_hi) && avt::aligned16(out_lo) &&
+                  avt::aligned16(wfrag) && avt::aligned16(coef),
+              "avt_bneck_x3: pointers must be 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_bneck_x3: bad plane_dtype");
+  const int64_t xb = (int64_t)batch * t * h * w * cin * 2, ob = (int64_t)batch * t * h * w * c * 2;
+  AVT_REQUIRE(xb < (1ll << 32) - 64 && ob < (1ll << 32) - 64, "avt_bneck_x3: tensor too large for 32-bit offsets");
+  BxArgs a;
+  a.xh = static_cast<const uint16_t*>(x_hi);
+  a.xl = static_cast<const uint16_t*>(x_lo);
+  a.oh = static_cast<uint16_t*>(out_hi);
+  a.ol = static_cast<uint16_t*>(out_lo);
+  a.wf = static_cast<const i32x4*>(wfrag);
+  a.coef = coef;
+  a.T = t;
+  a.H = h;
+  a.TC = tchunk < t ? tchunk : t;
+  a.tchunks = (t + a.TC - 1) / a.TC;
+  a.x_bytes = (unsigned)xb;
+  a.o_bytes = (unsigned)ob;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return plane_dtype == AVT_X3_F16 ? dispatch<true>(a, batch, h, w, cin, c, s) : dispatch<false>(a, batch, h, w, cin, c, s);
+}

@@ -32,6 +32,8 @@ _XB = int(os.environ.get("AVT_CONV_XB", "1"))                # long-K layers: fr
 _FUSE_SCAT = int(os.environ.get("AVT_FUSE_SCAT", "1"))      # slow res3-5 first blocks: strided shortcut folded into c's GEMM
 _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "0"))   # frames walked per workgroup (2 halo frames each); 0 = by width:
 #                                                              16 at 56 columns (more workgroups), the whole clip (32) below
+_FUSE_BLOCK_X3 = int(os.environ.get("AVT_FUSE_BLOCK_X3", "1"))  # contract-grade mode: fast-pathway bottlenecks as one kernel
+_FUSE_TCHUNK_X3 = int(os.environ.get("AVT_FUSE_TCHUNK_X3", "0"))  # frames walked per workgroup; 0 = by width
 _PW_X3 = int(os.environ.get("AVT_PW_X3", "1"))               # contract-grade mode: pointwise layers on the streaming kernel
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 _STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "1"))  # max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both
@@ -367,11 +369,12 @@ def pack_pw_planes(plane):
     return wp[row, col].contiguous().view(torch.bfloat16)
 
 
-def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):
-    """BN-folded weights of a [3,1,1] -> [1,3,3] -> [1,1,1] bottleneck (wa [Cm,C,3,1,1], wb [Cm,Cm,1,3,3], wc [C,Cm,1,1,1])
-    -> the MFMA-fragment order of csrc/bottleneck_fused.hip (include/avt.h); the bottleneck width is zero-padded to
-    CMP = 16 (Cm <= 16; b's taps packed in pairs) or 32 (Cm = 32; one tap per MFMA k-step)."""
-    wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]  # packing is host work
+def _bottleneck_fragments(wa, wb, wc, wsc=None, sc_kgroup=0):
+    """fp32 weights of a [3,1,1] -> [1,3,3] -> [1,1,1] bottleneck (wa [Cm,Cin,3,1,1], wb [Cm,Cm,1,3,3], wc [C,Cm,1,1,1], optional
+    shortcut wsc [C,Cin,1,1,1]) -> fp32 tensors in the MFMA-fragment order of csrc/bottleneck_fused.hip / bneck_x3.hip
+    (include/avt.h): (wa_f, wb_f, wc_f, ws_f | None), the bottleneck width zero-padded to CMP = 16 (Cm <= 16; b's taps packed
+    in pairs) or 32 (Cm = 32; one tap per MFMA k-step).  sc_kgroup: k-group of the 8-channel first block's shortcut weights
+    (0: the operand is x(t) in every group; 1: the operand holds frames t-1, t, t+1 in groups 0, 1, 2 — bneck_x3)."""
     cm, c, cin = wa.shape[0], wc.shape[0], wa.shape[1]
     cmp_ = 16 if cm <= 16 else 32
     first = cin == 8  # res2's first block: 8 input channels, the three frame taps share one k-step (see include/avt.h)
@@ -413,20 +416,70 @@ def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):
     chan = (32 * (nt // 2) + 8 * (n >> 2).view(1, -1, 1) + 4 * (nt % 2) + (n & 3).view(1, -1, 1)).expand(c // 16, L, E)
     kk = (q.view(1, -1, 1) * 8 + e.view(1, 1, -1)).expand(c // 16, L, E)
     wc_f = wc_p[chan, kk]
+    if wsc is None:
+        return wa_f, wb_f, wc_f, None
+    # shortcut conv fragments [c/16][ks][64][8] in c's row order, k = 32*ks + 8*q + e over the input channels
+    ks = max(cin // 32, 1)
+    ws_p = torch.zeros((c, ks * 32))
+    ws_p[:, 8 * sc_kgroup : 8 * sc_kgroup + cin] = wsc[:, :, 0, 0, 0]
+    chan4 = chan.view(c // 16, 1, L, E).expand(c // 16, ks, L, E)
+    kk4 = (torch.arange(ks).view(1, -1, 1, 1) * 32 + kk.view(c // 16, 1, L, E)).expand(c // 16, ks, L, E)
+    return wa_f, wb_f, wc_f, ws_p[chan4, kk4]
+
+
+def pack_bottleneck(wa, ba, wb, bb, wc, bc, device, shortcut=None):
+    """BN-folded weights of a [3,1,1] -> [1,3,3] -> [1,1,1] bottleneck (wa [Cm,C,3,1,1], wb [Cm,Cm,1,3,3], wc [C,Cm,1,1,1])
+    -> the MFMA-fragment order of csrc/bottleneck_fused.hip (include/avt.h), bf16."""
+    wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]  # packing is host work
+    cmp_ = 16 if wa.shape[0] <= 16 else 32
+    wsc = bsc = None
+    if shortcut is not None:
+        wsc, bsc = [v.detach().float().cpu() for v in shortcut]  # [C, Cin, 1, 1, 1], [C]
+    wa_f, wb_f, wc_f, ws_f = _bottleneck_fragments(wa, wb, wc, wsc)
     padw = lambda v: torch.cat([v.float(), torch.zeros(cmp_ - v.numel())])
     dev = lambda v, dt: v.to(dt).contiguous().to(device)
     out = (dev(wa_f, torch.bfloat16), dev(padw(ba), torch.float32), dev(wb_f, torch.bfloat16), dev(padw(bb), torch.float32),
            dev(wc_f, torch.bfloat16))
     if shortcut is None:
         return out + (dev(bc.float(), torch.float32),)
-    # shortcut conv fragments [c/16][ks][64][8] in c's row order, k = 32*ks + 8*q + e over the input channels
-    wsc, bsc = [v.detach().float().cpu() for v in shortcut]  # [C, Cin, 1, 1, 1], [C]
-    ks = max(cin // 32, 1)
-    ws_p = torch.zeros((c, ks * 32))
-    ws_p[:, :cin] = wsc[:, :, 0, 0, 0]
-    chan4 = chan.view(c // 16, 1, L, E).expand(c // 16, ks, L, E)
-    kk4 = (torch.arange(ks).view(1, -1, 1, 1) * 32 + kk.view(c // 16, 1, L, E)).expand(c // 16, ks, L, E)
-    return out + (dev((bc + bsc).float(), torch.float32), dev(ws_p[chan4, kk4], torch.bfloat16))
+    return out + (dev((bc + bsc).float(), torch.float32), dev(ws_f, torch.bfloat16))
+
+
+def pack_bottleneck_x3(wa, ba, wb, bb, wc, bc, x3, device, shortcut=None):
+    """The same bottleneck for csrc/bneck_x3.hip (contract-grade split-plane arithmetic): -> (wfrag, coef).
+    wfrag [NF][2 planes][64][8] 16-bit (typed bfloat16): the fragments of a, b, c (and the 8-channel first block's shortcut
+    conv, weights at k-group 1 = frame t of the operand), each as its hi and its lo plane; coef fp32 [sa | ba | sb | bb |
+    sc | bc]: with fp16 planes every output channel's weights are scaled by a power of two into [2^9, 2^10) (low plane
+    normal, FusedConv's rule) and s* multiplies the accumulator back — exactly; c and its shortcut share one scale per
+    channel because they share the accumulator.  bf16 planes: scales 1."""
+    wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]
+    cm, c = wa.shape[0], wc.shape[0]
+    cmp_ = 16 if cm <= 16 else 32
+    wsc = bsc = None
+    if shortcut is not None:
+        wsc, bsc = [v.detach().float().cpu() for v in shortcut]
+
+    def scale_of(*ws):  # per output channel, over every weight that accumulates into it
+        if x3 != ops.X3_F16:
+            return torch.ones(ws[0].shape[0])
+        mx = torch.stack([w.reshape(w.shape[0], -1).abs().amax(dim=1) for w in ws]).amax(dim=0).clamp_min(1e-30)
+        return torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
+
+    sa, sb = scale_of(wa), scale_of(wb)
+    sc = scale_of(wc, wsc) if wsc is not None else scale_of(wc)
+    v5 = lambda s_: s_.view(-1, 1, 1, 1, 1)
+    wa_f, wb_f, wc_f, ws_f = _bottleneck_fragments(wa * v5(sa), wb * v5(sb), wc * v5(sc),
+                                                    None if wsc is None else wsc * v5(sc), sc_kgroup=1)
+    frags = [wa_f.reshape(-1, 64, 8), wb_f.reshape(-1, 64, 8), wc_f.reshape(-1, 64, 8)]
+    if ws_f is not None:
+        frags.append(ws_f.reshape(-1, 64, 8))
+    allf = torch.cat(frags, 0)
+    hi, lo = split_planes(allf, x3)
+    wfrag = torch.stack([hi, lo], 1).contiguous().to(device)  # [NF][2][64][8]
+    padw = lambda v, fill: torch.cat([v.float(), torch.full((cmp_ - v.numel(),), fill)])
+    coef = torch.cat([padw(1.0 / sa, 1.0), padw(ba, 0.0), padw(1.0 / sb, 1.0), padw(bb, 0.0), 1.0 / sc,
+                      bc if bsc is None else bc + bsc]).float().contiguous().to(device)
+    return wfrag, coef
 
 
 def pack_c33(wb, device):
@@ -644,8 +697,9 @@ class _Block:
 
 
 class _BlockX3:
-    """A residual block in the contract-grade mode: four plain split-plane convolutions (shortcut, a, b, c + residual);
-    none of the bf16 path's fused forms — this mode trades speed for fp32-grade arithmetic."""
+    """A residual block in the contract-grade mode.  Fast-pathway blocks with an identity shortcut (res2-4) and res2's
+    8-channel first block run as ONE kernel (csrc/bneck_x3.hip: the x3 counterpart of the bf16 path's bottleneck_fused);
+    every other block is four split-plane convolutions (shortcut, a, b, c + residual)."""
 
     def __init__(self, blk, device, x3):
         self.b1 = FusedConv(blk.branch1, blk.branch1_bn, False, device, x3=x3) if hasattr(blk, "branch1") else None
@@ -653,8 +707,35 @@ class _BlockX3:
         self.a = FusedConv(t.a, t.a_bn, True, device, x3=x3)
         self.b = FusedConv(t.b, t.b_bn, True, device, x3=x3)
         self.c = FusedConv(t.c, t.c_bn, True, device, x3=x3)  # ReLU after the residual add (fused)
+        self.x3, self.dev = x3, device
+        self.fused = None
+        shape_ok = (self.a.kernel == (3, 1, 1) and self.b.kernel == (1, 3, 3) and self.c.kernel == (1, 1, 1) and
+                    self.a.stride == (1, 1, 1) and self.b.stride == (1, 1, 1) and self.a.cout <= 32)
+        ident = self.b1 is None and self.c.cout == self.a.cin and self.c.cout in (32, 64, 128)
+        first8 = (self.b1 is not None and self.a.cin == 8 and self.c.cout == 32 and self.b1.kernel == (1, 1, 1) and
+                  self.b1.stride == (1, 1, 1))
+        if _FUSE_BLOCK_X3 and shape_ok and (ident or first8):
+            (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
+            self.fused = pack_bottleneck_x3(wa, ba, wb, bb, wc, bc, x3, device, shortcut=self.b1._folded if first8 else None)
 
     def __call__(self, x, out=None):
+        if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
+                ops.bneck_x3_supported(x.C, self.c.cout, x.dims[3])):
+            b, t, h, w = x.dims
+            y = new_act(b * t * h * w, self.c.cout, x.dims, self.dev, True)
+
+            def launch():
+                ops.bneck_x3(x.ptrs, y.ptrs, self.fused, b, t, h, w, x.C, self.c.cout, self.x3,
+                             tchunk=_FUSE_TCHUNK_X3 or (8 if w >= 28 else 16))  # measured: profiles/r03/probe_bneck_x3_tchunk.log
+
+            if PROFILER is None:
+                launch()
+            else:
+                m = b * t * h * w
+                fl = m * (self.a.alg_flops_per_row + self.b.alg_flops_per_row + self.c.alg_flops_per_row +
+                          (self.b1.alg_flops_per_row if self.b1 is not None else 0.0))
+                PROFILER("bneck_x3_kernel", launch, fl, 4.0 * m * (x.C + self.c.cout))
+            return y
         sc = self.b1(x) if self.b1 is not None else x
         return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)
 

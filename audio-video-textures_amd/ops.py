@@ -429,6 +429,21 @@ def bottleneck_fused(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk=8):
                                                     int(tchunk), _stream()), "avt_bottleneck_fused_bf16")
 
 
+def bneck_x3_supported(cin, c, w):
+    return bool(_lib.lib().avt_bneck_x3_supported(int(cin), int(c), int(w)))
+
+
+def bneck_x3(x_ptrs, out_ptrs, packed, batch, t, h, w, cin, c, plane_dtype, tchunk=16):
+    """One fast-pathway bottleneck (identity, or res2's 8-channel first block with its shortcut conv) on plane pairs in one
+    kernel (csrc/bneck_x3.hip); packed = fused_slowfast.pack_bottleneck_x3(...) = (wfrag, coef); raw plane addresses."""
+    wfrag, coef = packed
+    _dev(wfrag, "wfrag", torch.bfloat16)
+    _dev(coef, "coef", torch.float32)
+    _lib.check(_lib.lib().avt_bneck_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), C.c_void_p(out_ptrs[0]),
+                                       C.c_void_p(out_ptrs[1]), _p(wfrag), _p(coef), int(batch), int(t), int(h), int(w),
+                                       int(cin), int(c), int(tchunk), int(plane_dtype), _stream()), "avt_bneck_x3")
+
+
 def mean_positions(x_ptr, batch, p, c, ldi, out, col0=0):
     """Head average pool: bf16 rows [batch*p, ldi] (raw address) -> out[:, col0:col0+c] fp32 (device tensor [batch, D])."""
     _dev(out, "out", torch.float32)

@@ -333,6 +333,23 @@ int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi,
                         int to, int ho, int wo, int ldi, int ldo, int ldr, int relu,
                         int out_row_stride, int out_h, int out_w, int plane_dtype, const float* wscale,
                         void* stream);
+/* One bottleneck of the SlowFast FAST pathway in ONE kernel on plane pairs (csrc/bneck_x3.hip; the contract-grade form of
+ * avt_bottleneck_fused_bf16 / avt_bottleneck_first_bf16 above — same blocks of the third-party SlowFast model,
+ * models/models.py:335, 399):  out = relu(c(relu(b(relu(a(x))))) + x)  for cin == c (identity shortcut), or
+ * out = relu(c(..) + shortcut(x)) for cin == 8, c == 32 (res2's first block, 1x1x1 shortcut conv).
+ * x [batch, t, h, w, cin], out [batch, t, h, w, c] as hi / lo planes (NDHWC, distinct buffers); the a and b outputs stay in
+ * LDS, the three frame taps of a and c's residual live in a register ring (x crosses HBM once + a 2-row halo per strip).
+ * wfrag [NF][2 planes: hi, lo][64 lanes][8] 16-bit: the fragments of a ([3 dt][cin/32][NT]; first block: [NT], k-group q =
+ * frame tap), b ([5][1] tap pairs for CMP 16, [9][2] for CMP 32), c ([c/16], rows permuted as for
+ * avt_bottleneck_fused_bf16) and, for the first block, the shortcut ([c/16], weights at k-group 1 = frame t of the operand),
+ * in that order, each fragment's two planes adjacent.  coef fp32 [sa CMP | ba CMP | sb CMP | bb CMP | sc c | bc c]: the
+ * per-channel power-of-two factors that undo the fp16 planes' weight scaling (1 for bf16 planes) and the biases (bc includes
+ * the shortcut's).  tchunk = frames walked per workgroup.  Supported: (cin, c, w) = (32, 32, 56), (64, 64, 28),
+ * (128, 128, 14), (8, 32, 56) and small test shapes; anything else: the per-layer kernels. */
+int avt_bneck_x3_supported(int cin, int c, int w);
+int avt_bneck_x3(const void* x_hi, const void* x_lo, void* out_hi, void* out_lo, const void* wfrag, const float* coef,
+                 int batch, int t, int h, int w, int cin, int c, int tchunk, int plane_dtype, void* stream);
+
 /* Pointwise (1x1x1, stride 1) layers in the same arithmetic, streaming form (csrc/pw_x3.hip): a wave owns 16 rows from
  * load to store, weights are LDS-resident MFMA fragments of persistent workgroups.  y = act(W x + b [+ res]) on plane pairs;
  * x [m, ldx] (k valid channels), y / res [m, ldy / ldr] (n channels); w_hi / w_lo = fragments [n/16][ceil(k/32)][64 lanes][8]

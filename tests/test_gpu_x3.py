@@ -390,3 +390,72 @@ def test_validate_default_path_is_contract_grade(avt, dev, capsys):
 
     ref_frames, _, _ = ref_py.stitch_walk(row_fn, len(video), W, S, 64, q_id=10, rng=np.random.RandomState(7))
     assert frames == ref_frames
+
+
+def _fast_block(cin, c, cm, seed):
+    """A fast-pathway bottleneck as slowfast.ResBlock builds it ([3,1,1] -> [1,3,3] -> [1,1,1]), BatchNorms randomised."""
+    from avtex.slowfast import ResBlock
+
+    torch.manual_seed(seed)
+    blk = ResBlock(cin, c, cm, 3, 1).eval()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, nn.BatchNorm3d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+    return blk
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("cin,c,cm,dims,tchunk", [
+    (32, 32, 8, (2, 7, 13, 12), 4),      # res2 identity form, small: ragged strips (13 rows / 5), ragged frame chunks (7 / 4)
+    (64, 64, 16, (1, 5, 9, 10), 16),     # res3 form: partial tiles, two k-steps per frame tap
+    (128, 128, 32, (2, 4, 7, 6), 3),     # res4 form: 32-wide bottleneck (one tap per k-step)
+    (8, 32, 8, (2, 6, 11, 12), 4),       # res2's first block: 8 input channels, shortcut conv, lane-rotated operand
+    (32, 32, 8, (1, 8, 56, 56), 16),     # production shapes
+    (8, 32, 8, (1, 8, 56, 56), 16),
+    (64, 64, 16, (1, 6, 28, 28), 16),
+    (128, 128, 32, (1, 6, 14, 14), 32),
+])
+def test_bneck_x3_matches_fp64_and_the_per_layer_kernels(avt, dev, mode, cin, c, cm, dims, tchunk):
+    """csrc/bneck_x3.hip (a whole fast-pathway bottleneck in one kernel, register-resident frame ring) against the same block
+    in fp64 on PyTorch, and against the four per-layer split-plane launches it replaces."""
+    import avtex.fused_slowfast as fsf
+    from avtex import ops
+    from avtex.fused_slowfast import Act, _BlockX3, split_planes
+
+    pd = X3[mode]
+    blk = _fast_block(cin, c, cm, 17 * cin + c)
+    b, t, h, w = dims
+    m = b * t * h * w
+    torch.manual_seed(5)
+    x = torch.randn((m, cin)) * 1.5
+    hi, lo = split_planes(x, pd)
+    xq = (hi.view(torch.float16 if pd == 1 else torch.bfloat16).double() + lo.view(torch.float16 if pd == 1 else torch.bfloat16).double())
+    with torch.no_grad():
+        ref = blk.double()(xq.view(b, t, h, w, cin).permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1).reshape(m, c)
+    blk = blk.float()
+    assert ops.bneck_x3_supported(cin, c, w)
+    old = fsf._FUSE_TCHUNK_X3
+    fsf._FUSE_TCHUNK_X3 = tchunk
+    try:
+        fused = _BlockX3(blk, dev, pd)
+        assert fused.fused is not None
+        xa = Act(hi.to(dev), dims, lo=lo.to(dev))
+        y = fused(xa)
+        yf = y.float(pd).cpu().double()
+    finally:
+        fsf._FUSE_TCHUNK_X3 = old
+    fsf._FUSE_BLOCK_X3, keep = 0, fsf._FUSE_BLOCK_X3
+    try:
+        plain = _BlockX3(blk, dev, pd)
+        assert plain.fused is None
+        yp = plain(xa).float(pd).cpu().double()
+    finally:
+        fsf._FUSE_BLOCK_X3 = keep
+    scale = ref.abs().max().item()
+    err_f, err_p = (yf - ref).abs().max().item() / scale, (yp - ref).abs().max().item() / scale
+    print("bneck_x3 %s cin %d c %d dims %s: fused %.2e, per-layer %.2e of the output range from fp64" % (mode, cin, c, dims, err_f, err_p))
+    tol = 3 * TOL[mode]  # three layers deep
+    assert err_f < tol and err_p < tol, (err_f, err_p)
+    assert (yf - yp).abs().max().item() / scale < tol

@@ -80,6 +80,15 @@ def spy_pool(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1):
     return r
 
 
+orig_bn = ops.bneck_x3
+
+
+def spy_bn(x_ptrs, out_ptrs, packed, batch, t, h, w, cin, c, plane_dtype, tchunk=16):
+    shapes.append("fused bottleneck cin%d c%d in(%d, %d, %d, %d) tchunk %d" % (cin, c, batch, t, h, w, tchunk))
+    return orig_bn(x_ptrs, out_ptrs, packed, batch, t, h, w, cin, c, plane_dtype, tchunk)
+
+
+ops.bneck_x3 = spy_bn
 ops.conv3d_igemm_x3 = spy
 ops.pw_x3 = spy_pw
 ops.stem_conv_x3 = spy_stem
