@@ -2,7 +2,9 @@
 // split-plane arithmetic (conv_x3.hip: every tensor is two 16-bit planes x = hi + lo, a product is three MFMA passes
 // wl*xh + wh*xl + wh*xh into one fp32 accumulator):
 //     out = relu( c( relu( b( relu( a(x) ) ) ) ) + x )            identity blocks (C = 32 / 64 / 128, Cm = 8 / 16 / 32)
-//     out = relu( c( relu( b( relu( a(x) ) ) ) ) + s(x) )         res2's first block (x has 8 channels, s = 1x1x1 conv)
+//     out = relu( c( relu( b( relu( a(x) ) ) ) ) + s(x) )         res2's first block (x has 8 channels, s = 1x1x1 conv) and
+//                                                                 the STRIDED first blocks of res3 / res4 (Cin = C/2; b and s
+//                                                                 have spatial stride 2, out is [., h/2, w/2, C])
 //     a: Conv3d [3,1,1] C -> Cm,  b: Conv3d [1,3,3] Cm -> Cm,  c: Conv3d [1,1,1] Cm -> C,  BatchNorms folded
 // (blocks of the third-party SlowFast model the reference runs per clip window, contrastive_video_textures/models/models.py:
 // 335, 399).  The bf16 path's bottleneck_fused.hip keeps a 3-frame ring of the x strip in LDS; with two planes that ring is
@@ -18,6 +20,9 @@
 //     weight fragments; HBM sees x once (+ a 2-row halo per strip, + 2 halo frames per frame chunk) and out once.
 // The first-block form keeps ONE operand per tile (k-group q = frame t-1+q, 8 channels each), rotated between lanes with
 // ds_bpermute when the next frame arrives; its shortcut conv reads the same operand (weights at k-group 1 = frame t).
+// The strided form walks OUTPUT rows: a is computed on the 2*HT + 1 input rows the strip's outputs touch (every a tile is a
+// ring tile; no bottom halo), b reads the a strips at stride-2 tap addresses, and the shortcut's operand — x(t) at the even
+// positions, which no wave holds in c's tile order — is re-read from global memory (L2) at the top of the frame.
 // HBM-bound by construction: ~900 MFMAs (16x16x32) per frame-strip against 129 KB of traffic on the res2 strip.
 // Output stores and x loads are raw buffer operations that are ALWAYS issued (out-of-range lanes carry an out-of-bounds
 // offset: loads return the zero padding, stores are dropped), so every wave's vmcnt sequence is the same whatever its tiles.
@@ -64,21 +69,26 @@ struct BxArgs {
   unsigned x_bytes, o_bytes;  // bytes of ONE plane
 };
 
-template <int C, int W, int HT, int CMP, int CIN, int NW, bool F16>
+template <int C, int W, int HT, int CMP, int CIN, int ST, int NW, bool F16>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs a) {
   constexpr bool FIRST = CIN == 8;
-  static_assert(FIRST || CIN == C, "identity blocks, or the 8-channel first block");
+  constexpr bool STR = ST == 2;  // strided first block: shortcut conv over CIN = C/2 channels, output at half resolution
+  static_assert(ST == 1 || ST == 2, "spatial stride 1 or 2");
+  static_assert(STR ? (CIN * 2 == C && W % 2 == 0) : (FIRST || CIN == C), "identity blocks, the 8-channel first block, or a strided first block");
   static_assert(!FIRST || CMP == 16, "first-block form: width <= 16");
-  constexpr int RX = HT + 2, AW = W + 2, APOS = RX * AW;
+  constexpr int WO = W / ST;  // output row length
+  constexpr int RX = STR ? 2 * HT + 1 : HT + 2, AW = W + 2, APOS = RX * AW;
   constexpr int AREC = CMP * 2, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
   constexpr int KA = FIRST ? 1 : CIN / 32;
   constexpr int NFA = (FIRST ? 1 : 3) * KA * NTA, NFB = NB * NTA, NTC = C / 16;
-  constexpr int NF = NFA + NFB + NTC + (FIRST ? NTC : 0);
-  constexpr int PB = HT * W, MTB = (PB + 15) / 16, MTH = (2 * W + 15) / 16;
+  constexpr int KS = STR ? CIN / 32 : 1;  // k-steps of the shortcut conv
+  constexpr int NF = NFA + NFB + NTC + (FIRST || STR ? NTC * KS : 0);
+  constexpr int PB = HT * WO, MTB = (PB + 15) / 16, MTH = (2 * W + 15) / 16;
+  constexpr int PXS = RX * W, MTX = (PXS + 15) / 16;  // strided form: a tiles over the whole x strip
   // tile slots of a wave: CIT main tiles (wave w owns tiles w, w + NW, ...: the SAME positions in the a and the c stage), the
   // halo tiles (strip rows 0 and HT + 1) in the slots the last round of main tiles leaves free, further ones in extra slots
   constexpr int CIT = (MTB + NW - 1) / NW, REM = MTB - NW * (CIT - 1), FREE = NW - REM;
-  constexpr int AIT = CIT + (MTH > FREE ? (MTH - FREE + NW - 1) / NW : 0);
+  constexpr int AIT = STR ? (MTX + NW - 1) / NW : CIT + (MTH > FREE ? (MTH - FREE + NW - 1) / NW : 0);
   constexpr int ABYTES = APOS * AREC, BBYTES = MTB * 16 * AREC;
   constexpr int NCOEF = 4 * CMP + 2 * C;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -116,29 +126,40 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
 #pragma unroll
   for (int it = 0; it < AIT; ++it) {
     const int m = wid + NW * it;
-    const bool is_main = it < CIT && m < MTB;
-    int hidx = -1;
-    if (it == CIT - 1) hidx = is_main ? -1 : wid - REM;
-    if (it >= CIT) hidx = FREE + (it - CIT) * NW + wid;
-    const bool is_halo = !is_main && hidx >= 0 && hidx < MTH;
-    const int p = m * 16 + l15, hp = hidx * 16 + l15;
-    const bool valid = is_main ? p < PB : (is_halo && hp < 2 * W);
+    bool used, valid;
     int srow, wcol;
-    if (is_main) {
-      const int pc = valid ? p : PB - 1;
-      const int r = pc / W;
-      srow = r + 1;
-      wcol = pc - r * W;
+    if constexpr (STR) {
+      const int p = m * 16 + l15;
+      used = m < MTX;
+      valid = used && p < PXS;
+      const int pc = valid ? p : PXS - 1;
+      srow = pc / W;
+      wcol = pc - srow * W;
     } else {
-      const int hc = valid ? hp : 0;
-      srow = hc < W ? 0 : HT + 1;
-      wcol = hc < W ? hc : hc - W;
+      const bool is_main = it < CIT && m < MTB;
+      int hidx = -1;
+      if (it == CIT - 1) hidx = is_main ? -1 : wid - REM;
+      if (it >= CIT) hidx = FREE + (it - CIT) * NW + wid;
+      const bool is_halo = !is_main && hidx >= 0 && hidx < MTH;
+      const int p = m * 16 + l15, hp = hidx * 16 + l15;
+      valid = is_main ? p < PB : (is_halo && hp < 2 * W);
+      used = is_main || is_halo;
+      if (is_main) {
+        const int pc = valid ? p : PB - 1;
+        const int r = pc / W;
+        srow = r + 1;
+        wcol = pc - r * W;
+      } else {
+        const int hc = valid ? hp : 0;
+        srow = hc < W ? 0 : HT + 1;
+        wcol = hc < W ? hc : hc - W;
+      }
     }
-    const int hi = h0 - 1 + srow;
+    const int hi = ST * h0 - 1 + srow;
     const bool rowin = valid && (unsigned)hi < (unsigned)a.H;
     poff[it] = rowin ? (unsigned)(((hi * W + wcol) * CIN + (FIRST ? 0 : q * 8)) * 2) : kOob;
     a_st[it] = rowin ? (srow * AW + wcol + 1) * AREC + q * 8 : -1;
-    a_used |= ((is_main || is_halo) ? 1u : 0u) << it;
+    a_used |= (used ? 1u : 0u) << it;
   }
   a_used = __builtin_amdgcn_readfirstlane(a_used);
   int tapoff[NB];  // b: byte offset of this lane's operand chunk of k-step j relative to tap (0, 0) of its position
@@ -154,14 +175,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
   const int cchunk = (CMP == 16 ? (q & 1) : q) * 16;  // c: this lane's k-group inside a b-strip record
   int b_rd[CIT];
   unsigned c_out[CIT];  // byte offset inside an output frame (one plane) of this lane's 8 channels of pair 0, or out of bounds
+  unsigned s_off[STR ? CIT : 1];  // strided form: byte offset inside an x frame of the shortcut's operand chunk (k-step 0)
+  const int Ho = a.H / ST;
 #pragma unroll
   for (int it = 0; it < CIT; ++it) {
     const int m = wid + NW * it;
     const int p = m * 16 + l15;
-    const int pc = (m < MTB && p < PB) ? p : PB - 1;
-    const int r = pc / W, w = pc - r * W;
-    b_rd[it] = (r * AW + w) * AREC;
-    c_out[it] = (m < MTB && p < PB && h0 + r < a.H) ? (unsigned)((((h0 + r) * W + w) * C + 8 * q) * 2) : kOob;
+    const bool ok = m < MTB && p < PB;
+    const int pc = ok ? p : PB - 1;
+    const int r = pc / WO, w = pc - r * WO;
+    b_rd[it] = (ST * r * AW + ST * w) * AREC;  // tap (0, 0) of this output position in the a strips
+    c_out[it] = (ok && h0 + r < Ho) ? (unsigned)((((h0 + r) * WO + w) * C + 8 * q) * 2) : kOob;
+    if constexpr (STR) s_off[it] = (ok && h0 + r < Ho) ? (unsigned)(((ST * (h0 + r) * W + ST * w) * CIN + q * 8) * 2) : kOob;
   }
   auto xo = [&](int it, int k, int tt) -> int {  // buffer offset of this lane's chunk of k-step k in frame tt
     const bool tin = (unsigned)tt < (unsigned)a.T && tt <= t1;  // frames t0-1 .. t1 are all this chunk reads
@@ -184,6 +209,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
         xr[it][slot][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
       }
   };
+  i32x4 sx[STR ? CIT : 1][KS][2];  // strided form: the shortcut conv's operand, x(t) at the even positions
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
@@ -218,6 +244,17 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
             }
       }
       load_frame(I1{}, t + 2);  // consumed by the rotation at the top of the next frame
+    }
+    if constexpr (STR) {  // requested now, used in the c stage: an L2 read of rows this workgroup fetched a frame ago
+      const unsigned fb = (unsigned)((b * a.T + t) * a.H) * (unsigned)(W * CIN * 2);
+#pragma unroll
+      for (int it = 0; it < CIT; ++it)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const int off = (int)(s_off[it] != kOob ? fb + s_off[it] + (unsigned)(k * 64) : kOob);
+          sx[it][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+          sx[it][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
+        }
     }
     // ---- [a] temporal conv, operands straight from the ring -> relu -> split -> a strips
 #pragma unroll
@@ -297,7 +334,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
     }
     __syncthreads();  // b strips complete
     // ---- [c] pointwise conv (+ shortcut conv) + bias + residual (the ring's frame t) -> relu -> split -> global
-    const unsigned obase = (unsigned)((b * a.T + t) * a.H) * (unsigned)(W * C * 2);
+    const unsigned obase = (unsigned)((b * a.T + t) * Ho) * (unsigned)(WO * C * 2);
 #pragma unroll
     for (int it = 0; it < CIT; ++it) {  // the same trip count in every wave: every store is issued, in or out of bounds
       const int m = wid + NW * it;
@@ -317,12 +354,20 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           c0 = mfma3<F16>(WF(s0, 0, lofs), WF(s0, 1, lofs), xr[it][0][0][0], xr[it][0][0][1], c0);
           c1 = mfma3<F16>(WF(s0 + 1, 0, lofs), WF(s0 + 1, 1, lofs), xr[it][0][0][0], xr[it][0][0][1], c1);
         }
+        if constexpr (STR) {  // strided shortcut: KS k-steps over the input channels of x(t) at (2 ho, 2 wo)
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            const int s0 = NFA + NFB + NTC + (2 * np) * KS + k;
+            c0 = mfma3<F16>(WF(s0, 0, lofs), WF(s0, 1, lofs), sx[it][k][0], sx[it][k][1], c0);
+            c1 = mfma3<F16>(WF(s0 + KS, 0, lofs), WF(s0 + KS, 1, lofs), sx[it][k][0], sx[it][k][1], c1);
+          }
+        }
         const float* sp = cf + 4 * CMP + 32 * np + 8 * q;
         const float4 sa_ = *reinterpret_cast<const float4*>(sp), sb_ = *reinterpret_cast<const float4*>(sp + 4);
         const float4 ba_ = *reinterpret_cast<const float4*>(sp + C), bb_ = *reinterpret_cast<const float4*>(sp + C + 4);
         float v[8] = {c0[0] * sa_.x + ba_.x, c0[1] * sa_.y + ba_.y, c0[2] * sa_.z + ba_.z, c0[3] * sa_.w + ba_.w,
                       c1[0] * sb_.x + bb_.x, c1[1] * sb_.y + bb_.y, c1[2] * sb_.z + bb_.z, c1[3] * sb_.w + bb_.w};
-        if constexpr (!FIRST) {
+        if constexpr (!FIRST && !STR) {
           const i32x4 rh = xr[it][CU][np][0], rl = xr[it][CU][np][1];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -355,24 +400,24 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
   }
 }
 
-template <int C, int W, int HT, int CMP, int CIN, int NW, bool F16>
+template <int C, int W, int HT, int CMP, int CIN, int ST, int NW, bool F16>
 int launch(BxArgs& a, int batch, int h, hipStream_t st) {
-  constexpr bool FIRST = CIN == 8;
-  constexpr int KA = FIRST ? 1 : CIN / 32, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9;
-  constexpr int NF = (FIRST ? 1 : 3) * KA * NTA + NB * NTA + C / 16 + (FIRST ? C / 16 : 0);
-  constexpr int MTB = (HT * W + 15) / 16;
-  constexpr int lds_bytes = NF * 2048 + (4 * CMP + 2 * C) * 4 + 2 * ((HT + 2) * (W + 2) * CMP * 2) + 2 * (MTB * 16 * CMP * 2);
+  constexpr bool FIRST = CIN == 8, STR = ST == 2;
+  constexpr int KA = FIRST ? 1 : CIN / 32, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9, KS = STR ? CIN / 32 : 1;
+  constexpr int NF = (FIRST ? 1 : 3) * KA * NTA + NB * NTA + C / 16 + (FIRST || STR ? (C / 16) * KS : 0);
+  constexpr int MTB = (HT * (W / ST) + 15) / 16, RX = STR ? 2 * HT + 1 : HT + 2;
+  constexpr int lds_bytes = NF * 2048 + (4 * CMP + 2 * C) * 4 + 2 * (RX * (W + 2) * CMP * 2) + 2 * (MTB * 16 * CMP * 2);
   static_assert(lds_bytes <= 160 * 1024, "strips do not fit the LDS");
-  a.strips = (h + HT - 1) / HT;
+  a.strips = (h / ST + HT - 1) / HT;
   static const int swz = avt::env_int_flag("AVT_XCD_SWZ", 1);
   a.swz = swz;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_x3_kernel<C, W, HT, CMP, CIN, NW, F16>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_x3_kernel<C, W, HT, CMP, CIN, ST, NW, F16>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_bneck_x3: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((bneck_x3_kernel<C, W, HT, CMP, CIN, NW, F16>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
+  hipLaunchKernelGGL((bneck_x3_kernel<C, W, HT, CMP, CIN, ST, NW, F16>), dim3((unsigned)(batch * a.strips * a.tchunks)), dim3(NW * 64),
                      lds_bytes, st, a);
   return avt::check_launch("avt_bneck_x3");
 }
@@ -380,22 +425,28 @@ int launch(BxArgs& a, int batch, int h, hipStream_t st) {
 template <bool F16>
 int dispatch(BxArgs& a, int batch, int h, int w, int cin, int c, hipStream_t s) {
   if (cin == 8) {
-    if (w == 56) return launch<32, 56, 8, 16, 8, 12, F16>(a, batch, h, s);
-    return launch<32, 12, 5, 16, 8, 4, F16>(a, batch, h, s);
+    if (w == 56) return launch<32, 56, 8, 16, 8, 1, 12, F16>(a, batch, h, s);
+    return launch<32, 12, 5, 16, 8, 1, 4, F16>(a, batch, h, s);
   }
-  if (c == 32 && w == 56) return launch<32, 56, 8, 16, 32, 12, F16>(a, batch, h, s);
-  if (c == 64 && w == 28) return launch<64, 28, 6, 16, 64, 8, F16>(a, batch, h, s);
-  if (c == 128 && w == 14) return launch<128, 14, 7, 32, 128, 9, F16>(a, batch, h, s);
-  if (c == 32 && w == 12) return launch<32, 12, 5, 16, 32, 4, F16>(a, batch, h, s);   // small shapes for the tests: ragged
-  if (c == 64 && w == 10) return launch<64, 10, 4, 16, 64, 4, F16>(a, batch, h, s);   // strips, partial tiles
-  return launch<128, 6, 3, 32, 128, 4, F16>(a, batch, h, s);
+  if (cin != c) {  // strided first blocks (w = input width)
+    if (c == 64 && w == 56) return launch<64, 56, 4, 16, 32, 2, 12, F16>(a, batch, h, s);
+    if (c == 128 && w == 28) return launch<128, 28, 3, 32, 64, 2, 8, F16>(a, batch, h, s);
+    if (c == 64 && w == 12) return launch<64, 12, 3, 16, 32, 2, 4, F16>(a, batch, h, s);  // small shapes for the tests
+    return launch<128, 8, 2, 32, 64, 2, 4, F16>(a, batch, h, s);
+  }
+  if (c == 32 && w == 56) return launch<32, 56, 8, 16, 32, 1, 12, F16>(a, batch, h, s);
+  if (c == 64 && w == 28) return launch<64, 28, 6, 16, 64, 1, 8, F16>(a, batch, h, s);
+  if (c == 128 && w == 14) return launch<128, 14, 7, 32, 128, 1, 9, F16>(a, batch, h, s);
+  if (c == 32 && w == 12) return launch<32, 12, 5, 16, 32, 1, 4, F16>(a, batch, h, s);   // small shapes for the tests: ragged
+  if (c == 64 && w == 10) return launch<64, 10, 4, 16, 64, 1, 4, F16>(a, batch, h, s);   // strips, partial tiles
+  return launch<128, 6, 3, 32, 128, 1, 4, F16>(a, batch, h, s);
 }
 
 }  // namespace
 
 extern "C" int avt_bneck_x3_supported(int cin, int c, int w) {
   if (cin == 8) return (c == 32 && (w == 56 || w == 12)) ? 1 : 0;
-  if (cin != c) return 0;
+  if (cin != c) return ((cin == 32 && c == 64 && (w == 56 || w == 12)) || (cin == 64 && c == 128 && (w == 28 || w == 8))) ? 1 : 0;
   return ((c == 32 && (w == 56 || w == 12)) || (c == 64 && (w == 28 || w == 10)) || (c == 128 && (w == 14 || w == 6))) ? 1 : 0;
 }
 
@@ -403,7 +454,7 @@ extern "C" int avt_bneck_x3(const void* x_hi, const void* x_lo, void* out_hi, vo
                             int batch, int t, int h, int w, int cin, int c, int tchunk, int plane_dtype, void* stream) {
   AVT_REQUIRE(x_hi && x_lo && out_hi && out_lo && wfrag && coef, "avt_bneck_x3: NULL pointer");
   AVT_REQUIRE(avt_bneck_x3_supported(cin, c, w),
-              "avt_bneck_x3: unsupported shape Cin=%d C=%d W=%d (fast-pathway blocks: 32x56, 64x28, 128x14, first block 8->32 x56)",
+              "avt_bneck_x3: unsupported shape Cin=%d C=%d W=%d (fast-pathway blocks: 32x56, 64x28, 128x14; first blocks 8->32 x56, 32->64 x56, 64->128 x28)",
               cin, c, w);
   AVT_REQUIRE(batch > 0 && t > 0 && h > 0 && tchunk > 0, "avt_bneck_x3: bad sizes");
   AVT_REQUIRE(x_hi != out_hi && x_lo != out_lo, "avt_bneck_x3: in-place is not supported (neighbouring strips read x)");
@@ -411,7 +462,9 @@ extern "C" int avt_bneck_x3(const void* x_hi, const void* x_lo, void* out_hi, vo
                   avt::aligned16(wfrag) && avt::aligned16(coef),
               "avt_bneck_x3: pointers must be 16-byte aligned");
   AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_bneck_x3: bad plane_dtype");
-  const int64_t xb = (int64_t)batch * t * h * w * cin * 2, ob = (int64_t)batch * t * h * w * c * 2;
+  const int st = (cin != c && cin != 8) ? 2 : 1;
+  AVT_REQUIRE(st == 1 || h % 2 == 0, "avt_bneck_x3: the strided form needs an even input height");
+  const int64_t xb = (int64_t)batch * t * h * w * cin * 2, ob = (int64_t)batch * t * (h / st) * (w / st) * c * 2;
   AVT_REQUIRE(xb < (1ll << 32) - 64 && ob < (1ll << 32) - 64, "avt_bneck_x3: tensor too large for 32-bit offsets");
   BxArgs a;
   a.xh = static_cast<const uint16_t*>(x_hi);

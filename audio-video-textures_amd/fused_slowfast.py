@@ -469,7 +469,8 @@ def pack_bottleneck_x3(wa, ba, wb, bb, wc, bc, x3, device, shortcut=None):
     sc = scale_of(wc, wsc) if wsc is not None else scale_of(wc)
     v5 = lambda s_: s_.view(-1, 1, 1, 1, 1)
     wa_f, wb_f, wc_f, ws_f = _bottleneck_fragments(wa * v5(sa), wb * v5(sb), wc * v5(sc),
-                                                    None if wsc is None else wsc * v5(sc), sc_kgroup=1)
+                                                    None if wsc is None else wsc * v5(sc),
+                                                    sc_kgroup=1 if wa.shape[1] == 8 else 0)
     frags = [wa_f.reshape(-1, 64, 8), wb_f.reshape(-1, 64, 8), wc_f.reshape(-1, 64, 8)]
     if ws_f is not None:
         frags.append(ws_f.reshape(-1, 64, 8))
@@ -710,19 +711,26 @@ class _BlockX3:
         self.x3, self.dev = x3, device
         self.fused = None
         shape_ok = (self.a.kernel == (3, 1, 1) and self.b.kernel == (1, 3, 3) and self.c.kernel == (1, 1, 1) and
-                    self.a.stride == (1, 1, 1) and self.b.stride == (1, 1, 1) and self.a.cout <= 32)
-        ident = self.b1 is None and self.c.cout == self.a.cin and self.c.cout in (32, 64, 128)
-        first8 = (self.b1 is not None and self.a.cin == 8 and self.c.cout == 32 and self.b1.kernel == (1, 1, 1) and
+                    self.a.stride == (1, 1, 1) and self.a.cout <= 32)
+        s1 = self.b.stride == (1, 1, 1)
+        ident = s1 and self.b1 is None and self.c.cout == self.a.cin and self.c.cout in (32, 64, 128)
+        first8 = (s1 and self.b1 is not None and self.a.cin == 8 and self.c.cout == 32 and self.b1.kernel == (1, 1, 1) and
                   self.b1.stride == (1, 1, 1))
-        if _FUSE_BLOCK_X3 and shape_ok and (ident or first8):
+        strided = (self.b1 is not None and self.b.stride == (1, 2, 2) and self.b1.stride == (1, 2, 2) and
+                   self.b1.kernel == (1, 1, 1) and self.a.cin in (32, 64) and self.c.cout == 2 * self.a.cin)
+        self.st = 2 if strided else 1
+        if _FUSE_BLOCK_X3 and shape_ok and (ident or first8 or strided):
             (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
-            self.fused = pack_bottleneck_x3(wa, ba, wb, bb, wc, bc, x3, device, shortcut=self.b1._folded if first8 else None)
+            self.fused = pack_bottleneck_x3(wa, ba, wb, bb, wc, bc, x3, device,
+                                            shortcut=self.b1._folded if (first8 or strided) else None)
 
     def __call__(self, x, out=None):
         if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
-                ops.bneck_x3_supported(x.C, self.c.cout, x.dims[3])):
+                ops.bneck_x3_supported(x.C, self.c.cout, x.dims[3]) and x.dims[2] % self.st == 0):
             b, t, h, w = x.dims
-            y = new_act(b * t * h * w, self.c.cout, x.dims, self.dev, True)
+            od = (b, t, h // self.st, w // self.st)
+            mo = od[0] * od[1] * od[2] * od[3]
+            y = new_act(mo, self.c.cout, od, self.dev, True)
 
             def launch():
                 ops.bneck_x3(x.ptrs, y.ptrs, self.fused, b, t, h, w, x.C, self.c.cout, self.x3,
@@ -732,9 +740,9 @@ class _BlockX3:
                 launch()
             else:
                 m = b * t * h * w
-                fl = m * (self.a.alg_flops_per_row + self.b.alg_flops_per_row + self.c.alg_flops_per_row +
-                          (self.b1.alg_flops_per_row if self.b1 is not None else 0.0))
-                PROFILER("bneck_x3_kernel", launch, fl, 4.0 * m * (x.C + self.c.cout))
+                fl = m * self.a.alg_flops_per_row + mo * (self.b.alg_flops_per_row + self.c.alg_flops_per_row +
+                                                          (self.b1.alg_flops_per_row if self.b1 is not None else 0.0))
+                PROFILER("bneck_x3_kernel", launch, fl, 4.0 * (m * x.C + mo * self.c.cout))
             return y
         sc = self.b1(x) if self.b1 is not None else x
         return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)

@@ -392,12 +392,12 @@ def test_validate_default_path_is_contract_grade(avt, dev, capsys):
     assert frames == ref_frames
 
 
-def _fast_block(cin, c, cm, seed):
+def _fast_block(cin, c, cm, seed, stride=1):
     """A fast-pathway bottleneck as slowfast.ResBlock builds it ([3,1,1] -> [1,3,3] -> [1,1,1]), BatchNorms randomised."""
     from avtex.slowfast import ResBlock
 
     torch.manual_seed(seed)
-    blk = ResBlock(cin, c, cm, 3, 1).eval()
+    blk = ResBlock(cin, c, cm, 3, stride).eval()
     with torch.no_grad():
         for m in blk.modules():
             if isinstance(m, nn.BatchNorm3d):
@@ -416,6 +416,10 @@ def _fast_block(cin, c, cm, seed):
     (8, 32, 8, (1, 8, 56, 56), 16),
     (64, 64, 16, (1, 6, 28, 28), 16),
     (128, 128, 32, (1, 6, 14, 14), 32),
+    (32, 64, 16, (2, 5, 10, 12), 4),     # strided first block (res3's form), small: ragged strips (5 output rows / 3)
+    (64, 128, 32, (1, 4, 6, 8), 3),      # res4's form
+    (32, 64, 16, (1, 6, 56, 56), 8),     # ... at the production shapes
+    (64, 128, 32, (1, 6, 28, 28), 8),
 ])
 def test_bneck_x3_matches_fp64_and_the_per_layer_kernels(avt, dev, mode, cin, c, cm, dims, tchunk):
     """csrc/bneck_x3.hip (a whole fast-pathway bottleneck in one kernel, register-resident frame ring) against the same block
@@ -425,7 +429,8 @@ def test_bneck_x3_matches_fp64_and_the_per_layer_kernels(avt, dev, mode, cin, c,
     from avtex.fused_slowfast import Act, _BlockX3, split_planes
 
     pd = X3[mode]
-    blk = _fast_block(cin, c, cm, 17 * cin + c)
+    st = 2 if (cin != c and cin != 8) else 1
+    blk = _fast_block(cin, c, cm, 17 * cin + c, stride=st)
     b, t, h, w = dims
     m = b * t * h * w
     torch.manual_seed(5)
@@ -433,7 +438,7 @@ def test_bneck_x3_matches_fp64_and_the_per_layer_kernels(avt, dev, mode, cin, c,
     hi, lo = split_planes(x, pd)
     xq = (hi.view(torch.float16 if pd == 1 else torch.bfloat16).double() + lo.view(torch.float16 if pd == 1 else torch.bfloat16).double())
     with torch.no_grad():
-        ref = blk.double()(xq.view(b, t, h, w, cin).permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1).reshape(m, c)
+        ref = blk.double()(xq.view(b, t, h, w, cin).permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1).reshape(m // (st * st), c)
     blk = blk.float()
     assert ops.bneck_x3_supported(cin, c, w)
     old = fsf._FUSE_TCHUNK_X3
