@@ -397,6 +397,286 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   STAMP_END();
 }
 
+// ---- the XL tile: 256 x 256 outputs per workgroup, 8 waves, for the long-K layers with Cout % 256 == 0 ----------------------
+// What bounds the 128 x 128 tile on those layers is the operand traffic from L2 into the LDS, not the matrix pipe: the
+// phase-skip build (profiles/r02/probe_conv_x3_phases.log; 1024 -> 256 [3,1,1] at 64 clips) runs 349 us with the MFMAs
+// compiled out — 64 KB per workgroup and 64-wide K-step, 4.8 GB per launch at 13.8 TB/s — against 250-270 us of matrix time,
+// and the two do not hide under each other.  A 256 x 256 tile moves HALF the bytes per flop (the activation rows are not
+// fetched once per 128-wide column block, the weight rows not once per 128-row block), which puts the load pipeline (~175 us)
+// under the matrix time.  Structure: 32-wide K-steps, TWO LDS stages of 64 KB (rows of 64 bytes, unpadded, 16-byte chunks
+// XOR-swizzled by (row >> 2) & 3: conflict-free ds_read_b128 / ds_write_b128), ONE barrier per step — the next step's
+// buffer loads are issued one per MFMA triple, their ds_writes go to the other stage at the end of the step; 8 waves as
+// 2 (M) x 4 (N), 128 x 64 outputs per wave in 128 accumulator registers, 12 fragment reads per 24 MFMAs.  The fp32 epilogue
+// staging does not fit for 256 x 256 at once: four passes of one 64-column slab each (the waves of that column block write,
+// every thread splits and stores).
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
+  constexpr int BM = 256, BN = 256, NTHR = 512, KB = 32;  // K-step in elements
+  constexpr int MT = 4, NT = 2;                            // 32 x 32 sub-tiles of a wave's 128 x 64
+  constexpr int AU = BM / 128, BU = BN / 128;              // 16-byte chunks per thread, plane and K-step
+  constexpr int PL = BM * 64;                              // bytes of one operand plane in a stage (BM == BN)
+  constexpr int STG = 4 * PL;                              // A hi | A lo | B hi | B lo
+  constexpr int ESTR = 64 * 4 + 16;                        // epilogue staging row stride: one 64-column slab in fp32
+  static_assert(BM * ESTR <= 2 * STG, "epilogue staging fits the operand stages");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int swz = avt::xcd_contiguous(blockIdx.x, a.nblk);
+  const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int r0 = tid >> 2, c4 = tid & 3;
+
+  int rowoff[AU];
+  unsigned rowmask[AU];
+#pragma unroll
+  for (int u = 0; u < AU; ++u) {
+    const int m = m0 + r0 + 128 * u;
+    rowoff[u] = 0;
+    rowmask[u] = 0u;
+    if (m < a.M && a.pointwise) {
+      rowoff[u] = m * a.ldi;
+      rowmask[u] = 0x010101u;
+    } else if (m < a.M) {
+      const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
+      const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
+      const int b = (int)fastdiv((uint32_t)t2, a.dTo), to = t2 - b * a.To;
+      const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+      rowoff[u] = (((b * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.ldi;
+      unsigned mask = 0u;
+      for (int dt = 0; dt < a.KT; ++dt) mask |= ((unsigned)(ti0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
+      for (int dh = 0; dh < a.KH; ++dh) mask |= ((unsigned)(hi0 + dh) < (unsigned)a.H ? 1u : 0u) << (8 + dh);
+      for (int dw = 0; dw < a.KW; ++dw) mask |= ((unsigned)(wi0 + dw) < (unsigned)a.W ? 1u : 0u) << (16 + dw);
+      rowmask[u] = mask;
+    }
+  }
+  int wrow[BU];
+  unsigned wsel[BU];
+#pragma unroll
+  for (int u = 0; u < BU; ++u) {
+    const int n = n0 + r0 + 128 * u;
+    wrow[u] = n < a.Cout ? n * a.K : 0;
+    wsel[u] = n < a.Cout ? 0xFFFFFFFFu : 0u;
+  }
+
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rih = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ril = __builtin_amdgcn_make_buffer_rsrc((void*)a.in_lo, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt_lo, 0, a.wt_bytes, 0x00020000);
+  int2* ltab = reinterpret_cast<int2*>(lds + 2 * STG);
+  const bool tab_lds = a.nk <= kMaxTabSteps;  // uniform
+  if (tab_lds)
+    for (int i = tid; i < a.nk * 8; i += NTHR) ltab[i] = a.ktab[i];
+  const int nk32 = (a.K + KB - 1) / KB;  // the tap table has one entry per 8-channel chunk: 4 per 32-wide step
+
+  i32x4 rah[AU], ral[AU], rbh[BU], rbl[BU];
+  unsigned aoffs[AU], boffs[BU];
+  auto gprep = [&](int kt) {
+    const int2 e = tab_lds ? ltab[kt * 4 + c4] : a.ktab[kt * 4 + c4];
+    const unsigned ebits = (unsigned)e.y;
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const unsigned sel = ((rowmask[u] & ebits) == ebits) ? 0xFFFFFFFFu : 0u;
+      aoffs[u] = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
+    }
+    const unsigned ksel = ~(unsigned)(e.y >> 31);
+    const unsigned kc2 = (unsigned)((kt * 4 + c4) * 16);
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      const unsigned sel = ksel & wsel[u];
+      boffs[u] = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
+    }
+  };
+  constexpr int NPIECE = 2 * (AU + BU);  // 8 loads per thread and step
+  auto gpiece = [&](int p) {
+    if (p < 2 * AU) {
+      const int u = p >> 1;
+      if (p & 1) ral[u] = __builtin_amdgcn_raw_buffer_load_b128(ril, (int)aoffs[u], 0, 0);
+      else rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)aoffs[u], 0, 0);
+    } else {
+      const int u = (p - 2 * AU) >> 1;
+      if (p & 1) rbl[u] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)boffs[u], 0, 0);
+      else rbh[u] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)boffs[u], 0, 0);
+    }
+  };
+  // stage layout: row r, chunk c of a plane at r * 64 + ((c ^ ((r >> 2) & 3)) * 16)
+  const int wslot = (c4 ^ ((r0 >> 2) & 3)) * 16;  // (rows r0 and r0 + 128 share (r >> 2) & 3)
+  auto lstore = [&](char* st) {
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const int o = (r0 + 128 * u) * 64 + wslot;
+      *reinterpret_cast<i32x4*>(st + o) = rah[u];
+      *reinterpret_cast<i32x4*>(st + PL + o) = ral[u];
+    }
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      const int o = (r0 + 128 * u) * 64 + wslot;
+      *reinterpret_cast<i32x4*>(st + 2 * PL + o) = rbh[u];
+      *reinterpret_cast<i32x4*>(st + 3 * PL + o) = rbl[u];
+    }
+  };
+  const int fsw = (lr >> 2) & 3;  // the swizzle of this lane's fragment rows (tile bases are multiples of 32)
+  struct Frags {
+    i32x4 ah[MT], al[MT], wh[NT], wl[NT];
+  };
+  auto fload = [&](Frags& f, const char* st, int ks) {
+    const int slot = ((ks * 2 + lh) ^ fsw) * 16;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int o = (wm * 128 + j * 32 + lr) * 64 + slot;
+      f.ah[j] = *reinterpret_cast<const i32x4*>(st + o);
+      f.al[j] = *reinterpret_cast<const i32x4*>(st + PL + o);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int o = (wn * 64 + i * 32 + lr) * 64 + slot;
+      f.wh[i] = *reinterpret_cast<const i32x4*>(st + 2 * PL + o);
+      f.wl[i] = *reinterpret_cast<const i32x4*>(st + 3 * PL + o);
+    }
+  };
+  auto fmul = [&](const Frags& f, int g0, bool more) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        acc[i][j] = mfma<F16>(f.wl[i], f.ah[j], acc[i][j]);
+        acc[i][j] = mfma<F16>(f.wh[i], f.al[j], acc[i][j]);
+        acc[i][j] = mfma<F16>(f.wh[i], f.ah[j], acc[i][j]);
+        const int pc = g0 + i * MT + j;
+        if (more && pc < NPIECE) gpiece(pc);  // the next step's loads, one per MFMA triple of the first k-slice
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+
+  __syncthreads();
+  gprep(0);
+#pragma unroll
+  for (int p = 0; p < NPIECE; ++p) gpiece(p);
+  lstore(lds);
+  __syncthreads();
+  for (int kt = 0; kt < nk32; ++kt) {
+    const bool more = kt + 1 < nk32;
+    char* cur = lds + (kt & 1) * STG;
+    Frags f;
+    fload(f, cur, 0);
+    if (more) gprep(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fmul(f, 0, more);
+    fload(f, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fmul(f, NT * MT, more);
+    if (more) lstore(lds + ((kt + 1) & 1) * STG);  // the other stage: nobody reads it during this step
+    __syncthreads();
+  }
+
+  // ---- epilogue: one 64-column slab per pass, staged in fp32, split on the final value
+  constexpr int CPR = 8;                       // 8-channel chunks per slab row
+  constexpr int EU = (BM * CPR) / NTHR;        // 4 chunks per thread and pass
+  const bool has_res = a.res != nullptr;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    uint4 rrh[EU], rrl[EU];
+    if (has_res) {
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c = tid + NTHR * u;
+        const int m = m0 + c / CPR, n = n0 + pass * 64 + (c % CPR) * 8;
+        const bool ok = m < a.M && n < a.Cout;
+        rrh[u] = ok ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
+        rrl[u] = ok ? *reinterpret_cast<const uint4*>(a.res_lo + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    if (wn == pass) {
+      // D layout: column (lane & 31) = m, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = n
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = i * 32 + 8 * g + 4 * lh;  // column inside the slab
+          const int ng = n0 + pass * 64 + nl;
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (a.bias && ng < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + ng);
+          if (a.wscale && ng < a.Cout) sv = *reinterpret_cast<const float4*>(a.wscale + ng);
+#pragma unroll
+          for (int j = 0; j < MT; ++j) {
+            float4 v;
+            v.x = acc[i][j][4 * g + 0] * sv.x + bv.x;
+            v.y = acc[i][j][4 * g + 1] * sv.y + bv.y;
+            v.z = acc[i][j][4 * g + 2] * sv.z + bv.z;
+            v.w = acc[i][j][4 * g + 3] * sv.w + bv.w;
+            const int ml = wm * 128 + j * 32 + lr;
+            *reinterpret_cast<float4*>(lds + ml * ESTR + nl * 4) = v;
+          }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int c = tid + NTHR * u;
+      const int row = c / CPR, cc = c % CPR;
+      const int m = m0 + row, n = n0 + pass * 64 + cc * 8;
+      if (m < a.M && n < a.Cout) {
+        const float4 v0 = *reinterpret_cast<const float4*>(lds + row * ESTR + cc * 32);
+        const float4 v1 = *reinterpret_cast<const float4*>(lds + row * ESTR + cc * 32 + 16);
+        float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (has_res) {
+          const uint32_t* ph = reinterpret_cast<const uint32_t*>(&rrh[u]);
+          const uint32_t* pl = reinterpret_cast<const uint32_t*>(&rrl[u]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const avt::f32x2 r = avt::join2<F16>(ph[e], pl[e]);
+            x[2 * e] += r.x;
+            x[2 * e + 1] += r.y;
+          }
+        }
+        if (a.relu == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+        } else if (a.relu == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.1f * x[e]);
+        }
+        const int64_t o = (int64_t)out_row(a, m) * a.ldo + n;
+        uint4 oh, ol;
+        avt::split2<F16>(x[0], x[1], oh.x, ol.x);
+        avt::split2<F16>(x[2], x[3], oh.y, ol.y);
+        avt::split2<F16>(x[4], x[5], oh.z, ol.z);
+        avt::split2<F16>(x[6], x[7], oh.w, ol.w);
+        *reinterpret_cast<uint4*>(a.out + o) = oh;
+        *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <bool F16>
+int launch_x3_xl(ConvArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.Cout + 255) / 256;
+  a.nblk = tiles_m * a.tiles_n;
+  constexpr int lds_max = 2 * 4 * 256 * 64 + kMaxTabSteps * 64;
+  const int lds_bytes = 2 * 4 * 256 * 64 + (a.nk <= kMaxTabSteps ? a.nk : 0) * 64;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+  if (e != hipSuccess) {
+    avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_max, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((conv_x3_xl_kernel<F16>), dim3((unsigned)a.nblk), dim3(512), lds_bytes, st, a);
+  return avt::check_launch("avt_conv3d_igemm_x3");
+}
+
 template <int BM, int BN, int WTM, bool F16, bool IO32 = false>
 int launch_x3(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM;
@@ -420,6 +700,12 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// which tile avt_conv3d_igemm_x3 launches (bench.py names its roofline rows by it)
+extern "C" int avt_conv3d_igemm_x3_xl_picked(int cout, int k, int m) {
+  static const int min_k = avt::env_int_flag("AVT_CONV_X3_XL_MINK", 512);
+  return (cout % 256 == 0 && k >= min_k && m >= 256 * 64) ? 1 : 0;
+}
 
 extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
                                    const float* bias, const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
@@ -445,6 +731,10 @@ extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const v
   a.wfrag = nullptr;
   a.nup = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // long-K layers whose output channels fill 256-wide tiles: the XL tile (AVT_CONV_X3_XL=0: the 128 x 128 tile everywhere)
+  static const int xl = avt::env_int_flag("AVT_CONV_X3_XL", 1);
+  if (xl && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M))
+    return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true>(a, s) : launch_x3_xl<false>(a, s);
   if (plane_dtype == AVT_X3_F16) {
     if (cout <= 32) return launch_x3<128, 32, 32, true>(a, s);
     if (cout <= 64) return launch_x3<128, 64, 64, true>(a, s);

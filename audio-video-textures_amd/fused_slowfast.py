@@ -211,6 +211,8 @@ class FusedConv:
         if self.x3 is not None:
             if getattr(self, "pw", None) is not None:
                 return "pw_x3_kernel<%s>" % ("f16" if self.x3 == ops.X3_F16 else "bf16")
+            if ops.conv3d_igemm_x3_xl_picked(self.cout, self.wt.shape[1], m_out):
+                return "conv_x3_xl_kernel<%s>" % ("f16" if self.x3 == ops.X3_F16 else "bf16")
             tile = "128,32,32" if self.cout <= 32 else ("128,64,64" if self.cout <= 64 else "128,128,64")
             return "conv_x3_kernel<%s,%s>" % (tile, "f16" if self.x3 == ops.X3_F16 else "bf16")
         if self.wfrag is not None:

@@ -429,6 +429,10 @@ def bottleneck_fused(x_ptr, out_ptr, packed, batch, t, h, w, c, tchunk=8):
                                                     int(tchunk), _stream()), "avt_bottleneck_fused_bf16")
 
 
+def conv3d_igemm_x3_xl_picked(cout, k, m):
+    return bool(_lib.lib().avt_conv3d_igemm_x3_xl_picked(int(cout), int(k), int(m)))
+
+
 def bneck_x3_supported(cin, c, w):
     return bool(_lib.lib().avt_bneck_x3_supported(int(cin), int(c), int(w)))
 

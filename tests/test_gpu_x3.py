@@ -43,6 +43,10 @@ def _planes(x, pd, dev):
     (512, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 9, 9), False),      # K1S 16
     (32, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 6, 10), True),       # fast pathway (pixel-grouped): K1S 1
     (80, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 3, 7, 9), False),       # shortcut conv after the first fusion: K 80 -> 96
+    # the XL tile (256 x 256 per workgroup; Cout % 256 == 0, K >= 512, M >= 16384): ragged M, residual, taps, strides
+    (512, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 8, 46, 46), True),      # temporal taps, M = 16928 = 66.1 tiles
+    (64, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 4, 130, 130), False),    # strided 3x3, K = 576 (18 half-steps)
+    (520, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 8, 92, 92), True),      # strided pointwise, K = 520: a 32-step tail of 8
 ])
 def test_conv_x3_matches_fp32(avt, dev, mode, cin, cout, k, s, p, dims, with_res):
     from avtex.fused_slowfast import Act, FusedConv
