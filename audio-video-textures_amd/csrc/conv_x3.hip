@@ -405,7 +405,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 // fetched once per 128-wide column block, the weight rows not once per 128-row block), which puts the load pipeline (~175 us)
 // under the matrix time.  Structure: 32-wide K-steps, TWO LDS stages of 64 KB (rows of 64 bytes, unpadded, 16-byte chunks
 // XOR-swizzled by (row >> 2) & 3: conflict-free ds_read_b128 / ds_write_b128), ONE barrier per step — the next step's
-// buffer loads are issued one per MFMA triple, their ds_writes go to the other stage at the end of the step; 8 waves as
+// operands arrive by LDS-DMA (buffer_load ... lds, hardware zero fill, the swizzle applied on the source side), one piece
+// per MFMA triple, straight into the other stage — no staging registers, no ds_write phase, which leaves room for the
+// fragments of BOTH k-slices of a step in registers; 8 waves as
 // 2 (M) x 4 (N), 128 x 64 outputs per wave in 128 accumulator registers, 12 fragment reads per 24 MFMAs.  The fp32 epilogue
 // staging does not fit for 256 x 256 at once: four passes of one 64-column slab each (the waves of that column block write,
 // every thread splits and stores).
@@ -427,7 +429,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
   const int lr = lane & 31, lh = lane >> 5;
-  const int r0 = tid >> 2, c4 = tid & 3;
+  // LDS-DMA staging: a wave-instruction lands 1 KB = 16 rows x 64 B at consecutive LDS addresses (lane * 16), so a lane's
+  // slot inside its row is fixed (tid & 3) and the swizzle is applied on the SOURCE side: it fetches chunk slot ^ ((row >> 2) & 3)
+  const int r0 = tid >> 2, c4 = (tid & 3) ^ ((r0 >> 2) & 3);
 
   int rowoff[AU];
   unsigned rowmask[AU];
@@ -479,7 +483,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
     for (int i = tid; i < a.nk * 8; i += NTHR) ltab[i] = a.ktab[i];
   const int nk32 = (a.K + KB - 1) / KB;  // the tap table has one entry per 8-channel chunk: 4 per 32-wide step
 
-  i32x4 rah[AU], ral[AU], rbh[BU], rbl[BU];
   unsigned aoffs[AU], boffs[BU];
   auto gprep = [&](int kt) {
     const int2 e = tab_lds ? ltab[kt * 4 + c4] : a.ktab[kt * 4 + c4];
@@ -497,32 +500,20 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       boffs[u] = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
     }
   };
-  constexpr int NPIECE = 2 * (AU + BU);  // 8 loads per thread and step
-  auto gpiece = [&](int p) {
+  constexpr int NPIECE = 2 * (AU + BU);  // 8 LDS-DMA pieces per wave and step
+  // piece p of the step that lands in stage `st`: the hardware writes lane l's 16 bytes at (wave's 16-row block) + l * 16;
+  // out-of-range offsets (padding taps, rows / channels beyond the tensor) arrive as zeros
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int wrow0 = wid * 16 * 64;  // byte offset of this wave's 16-row block inside a plane
+  auto gpiece = [&](int p, char* st) {
     if (p < 2 * AU) {
       const int u = p >> 1;
-      if (p & 1) ral[u] = __builtin_amdgcn_raw_buffer_load_b128(ril, (int)aoffs[u], 0, 0);
-      else rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)aoffs[u], 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((p & 1) ? ril : rih, (lds_ptr)(st + (p & 1) * PL + wrow0 + u * 128 * 64), 16,
+                                               (int)aoffs[u], 0, 0, 0);
     } else {
       const int u = (p - 2 * AU) >> 1;
-      if (p & 1) rbl[u] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)boffs[u], 0, 0);
-      else rbh[u] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)boffs[u], 0, 0);
-    }
-  };
-  // stage layout: row r, chunk c of a plane at r * 64 + ((c ^ ((r >> 2) & 3)) * 16)
-  const int wslot = (c4 ^ ((r0 >> 2) & 3)) * 16;  // (rows r0 and r0 + 128 share (r >> 2) & 3)
-  auto lstore = [&](char* st) {
-#pragma unroll
-    for (int u = 0; u < AU; ++u) {
-      const int o = (r0 + 128 * u) * 64 + wslot;
-      *reinterpret_cast<i32x4*>(st + o) = rah[u];
-      *reinterpret_cast<i32x4*>(st + PL + o) = ral[u];
-    }
-#pragma unroll
-    for (int u = 0; u < BU; ++u) {
-      const int o = (r0 + 128 * u) * 64 + wslot;
-      *reinterpret_cast<i32x4*>(st + 2 * PL + o) = rbh[u];
-      *reinterpret_cast<i32x4*>(st + 3 * PL + o) = rbl[u];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((p & 1) ? rwl : rwh, (lds_ptr)(st + (2 + (p & 1)) * PL + wrow0 + u * 128 * 64), 16,
+                                               (int)boffs[u], 0, 0, 0);
     }
   };
   const int fsw = (lr >> 2) & 3;  // the swizzle of this lane's fragment rows (tile bases are multiples of 32)
@@ -544,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       f.wl[i] = *reinterpret_cast<const i32x4*>(st + 3 * PL + o);
     }
   };
-  auto fmul = [&](const Frags& f, int g0, bool more) {
+  auto fmul = [&](const Frags& f, int g0, bool more, char* nst) {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -553,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         acc[i][j] = mfma<F16>(f.wh[i], f.al[j], acc[i][j]);
         acc[i][j] = mfma<F16>(f.wh[i], f.ah[j], acc[i][j]);
         const int pc = g0 + i * MT + j;
-        if (more && pc < NPIECE) gpiece(pc);  // the next step's loads, one per MFMA triple of the first k-slice
+        if (more && pc < NPIECE) gpiece(pc, nst);  // the next step's DMA, one piece per MFMA triple of the first k-slice
         __builtin_amdgcn_sched_barrier(0);
       }
   };
@@ -561,21 +552,21 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   __syncthreads();
   gprep(0);
 #pragma unroll
-  for (int p = 0; p < NPIECE; ++p) gpiece(p);
-  lstore(lds);
+  for (int p = 0; p < NPIECE; ++p) gpiece(p, lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nk32; ++kt) {
     const bool more = kt + 1 < nk32;
     char* cur = lds + (kt & 1) * STG;
-    Frags f;
-    fload(f, cur, 0);
+    char* nst = lds + ((kt + 1) & 1) * STG;  // the other stage: nobody reads it during this step
+    Frags f0, f1;
+    fload(f0, cur, 0);
     if (more) gprep(kt + 1);
+    fload(f1, cur, 1);
     __builtin_amdgcn_sched_barrier(0);
-    fmul(f, 0, more);
-    fload(f, cur, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    fmul(f, NT * MT, more);
-    if (more) lstore(lds + ((kt + 1) & 1) * STG);  // the other stage: nobody reads it during this step
+    fmul(f0, 0, more, nst);
+    fmul(f1, NT * MT, false, nst);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed (the barrier does not wait for DMA)
     __syncthreads();
   }
 
