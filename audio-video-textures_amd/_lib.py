@@ -78,6 +78,7 @@ SIGNATURES = {
     "avt_clip_pack_u8_ndhwc4_x3": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                    C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp],
     "avt_maxpool_hw3s2_ndhwc_x3": [_vp] * 4 + [C.c_int] * 8 + [_vp],
+    "avt_maxpool_hw2s2_ndhwc_x3": [_vp] * 4 + [C.c_int] * 7 + [_vp],
     "avt_mean_positions_x3": [_vp, _vp] + [C.c_int] * 4 + [_vp, C.c_int, C.c_int, _vp],
     "avt_conv3d_igemm_x3_xl_picked": [C.c_int] * 3,
     "avt_bneck_x3_supported": [C.c_int] * 3,

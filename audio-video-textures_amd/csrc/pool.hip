@@ -157,7 +157,8 @@ extern "C" int avt_maxpool_hw2s2_ndhwc_bf16(const void* in, void* out, int bt, i
 // sums them in fp32 in the same fixed order as the bf16 kernel.
 namespace {
 
-template <bool F16>
+// KS = 3, PAD = 1: MaxPool3d((1,3,3),(1,2,2),(0,1,1)), the SlowFast stems;  KS = 2, PAD = 0: MaxPool2d(2, 2) floor mode, VGGish
+template <bool F16, int KS = 3, int PAD = 1>
 __global__ __launch_bounds__(256) void maxpool3_x3_kernel(const uint16_t* __restrict__ in_hi, const uint16_t* __restrict__ in_lo,
                                                            uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int bt,
                                                            int H, int W, int C, int ldi, int ldo, int Ho, int Wo, int tgroup) {
@@ -176,12 +177,12 @@ __global__ __launch_bounds__(256) void maxpool3_x3_kernel(const uint16_t* __rest
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      int hi = 2 * ho - 1 + dh;
+    for (int dh = 0; dh < KS; ++dh) {
+      int hi = 2 * ho - PAD + dh;
       hi = hi < 0 ? 0 : (hi > H - 1 ? H - 1 : hi);  // clamped taps duplicate a valid one: a max does not care
 #pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        int wi = 2 * wo - 1 + dw;
+      for (int dw = 0; dw < KS; ++dw) {
+        int wi = 2 * wo - PAD + dw;
         wi = wi < 0 ? 0 : (wi > W - 1 ? W - 1 : wi);
         const int64_t o = frame + (int64_t)(hi * W + wi) * ldi;
         const uint4 vh = *reinterpret_cast<const uint4*>(in_hi + o);
@@ -191,8 +192,9 @@ __global__ __launch_bounds__(256) void maxpool3_x3_kernel(const uint16_t* __rest
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const avt::f32x2 v = avt::join2<F16>(ph[e], pl[e]);
-          m[2 * e] = fmaxf(m[2 * e], v.x);
-          m[2 * e + 1] = fmaxf(m[2 * e + 1], v.y);
+          // (x > m ? x : m keeps a NaN of x; fmaxf would drop it — a poisoned activation must reach the embedding)
+          m[2 * e] = (v.x > m[2 * e] || v.x != v.x) ? v.x : m[2 * e];
+          m[2 * e + 1] = (v.y > m[2 * e + 1] || v.y != v.y) ? v.y : m[2 * e + 1];
         }
       }
     }
@@ -267,6 +269,29 @@ extern "C" int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, 
   else
     hipLaunchKernelGGL((maxpool3_x3_kernel<false>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, tgroup);
   return avt::check_launch("avt_maxpool_hw3s2_ndhwc_x3");
+}
+
+extern "C" int avt_maxpool_hw2s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h, int w,
+                                          int c, int ldi, int ldo, int plane_dtype, void* stream) {
+  AVT_REQUIRE(in_hi && in_lo && out_hi && out_lo, "avt_maxpool_hw2s2_ndhwc_x3: NULL pointer");
+  AVT_REQUIRE(bt > 0 && h >= 2 && w >= 2 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldi >= c && ldo >= c,
+              "avt_maxpool_hw2s2_ndhwc_x3: h, w >= 2; channels / leading dimensions must be multiples of 8");
+  AVT_REQUIRE(avt::aligned16(in_hi) && avt::aligned16(in_lo) && avt::aligned16(out_hi) && avt::aligned16(out_lo),
+              "avt_maxpool_hw2s2_ndhwc_x3: pointers must be 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_maxpool_hw2s2_ndhwc_x3: bad plane_dtype");
+  const int ho = h / 2, wo = w / 2;  // floor mode: an odd last row / column is dropped
+  const int64_t total = (int64_t)bt * ho * wo * (c / 8);
+  AVT_REQUIRE(total < (1ll << 31), "avt_maxpool_hw2s2_ndhwc_x3: more than 2^31 output chunks");
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+  auto ih = static_cast<const uint16_t*>(in_hi), il = static_cast<const uint16_t*>(in_lo);
+  auto oh = static_cast<uint16_t*>(out_hi), ol = static_cast<uint16_t*>(out_lo);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (plane_dtype == AVT_X3_F16)
+    hipLaunchKernelGGL((maxpool3_x3_kernel<true, 2, 0>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, 1);
+  else
+    hipLaunchKernelGGL((maxpool3_x3_kernel<false, 2, 0>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, 1);
+  return avt::check_launch("avt_maxpool_hw2s2_ndhwc_x3");
 }
 
 extern "C" int avt_mean_positions_x3(const void* in_hi, const void* in_lo, int batch, int p, int c, int ldi, float* out, int ldo,

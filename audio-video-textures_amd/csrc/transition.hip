@@ -181,12 +181,38 @@ __global__ __launch_bounds__(kThreads) void row_transition_kernel(TArgs a) {
 // Same arithmetic, same order of survivors; the row is read from HBM exactly once (coalesced: thread t owns
 // positions t, t+256, ...), every reduction is one shuffle tree + one LDS hop, and the ordered compaction needs a
 // single table of ITEMS x 4 ballot counts instead of one barrier round per 256 positions.
-template <int ITEMS>
-__global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
-  __shared__ BlockRed red;
-  __shared__ double red2[kThreads / 64];
-  __shared__ int cnt_tab[ITEMS * 4 + 1];
+// NTHR = 256: rows up to 4096 entries; NTHR = 1024 (16 waves): rows up to 16384 entries — config 4's N = 16384, where the
+// LDS-cached form below spent its time in 64 barrier rounds of compaction per row (0.4 TB/s).
+template <int ITEMS, int NTHR = kThreads>
+__global__ __launch_bounds__(NTHR) void row_transition_reg_kernel(TArgs a) {
+  constexpr int NWV = NTHR / 64;
+  __shared__ double red_d[NWV], red2[NWV];
+  __shared__ float red_f[NWV];
+  __shared__ int cnt_tab[ITEMS * NWV + 1];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // block reductions over NWV waves; fp64 partials are added in wave order, pairwise for NWV = 4 (the order the 256-thread
+  // form has always used)
+  auto bsum = [&](double v) {
+    v = avt::wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red_d[wid] = v;
+    __syncthreads();
+    if constexpr (NWV == 4) return (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWV; w += 2) t += red_d[w] + red_d[w + 1];
+    return t;
+  };
+  auto bmax = [&](float v) {
+    v = avt::wave_max(v);
+    __syncthreads();
+    if (lane == 0) red_f[wid] = v;
+    __syncthreads();
+    float t = red_f[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) t = fmaxf(t, red_f[w]);
+    return t;
+  };
   const float* x = a.sim + (int64_t)r * a.ld;
   const float* xa = a.sim_a ? a.sim_a + (int64_t)r * a.ld_a : nullptr;
   const bool perm = a.q_ids != nullptr;
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
   double s = 0.0, sa = 0.0;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    const int i = tid + k * kThreads;
+    const int i = tid + k * NTHR;
     v[k] = 0.0f;
     va[k] = 0.0f;
     if (i < L) {
@@ -220,24 +246,24 @@ __global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
       }
     }
   }
-  s = block_sum(s, red);
-  if (xa) sa = block_sum(sa, red);
+  s = bsum(s);
+  if (xa) sa = bsum(sa);
   const float sf = (float)s, saf = (float)sa;
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    const int i = tid + k * kThreads;
+    const int i = tid + k * NTHR;
     float p = __fdiv_rn(v[k], sf);
     if (xa) p = __fadd_rn(__fmul_rn(a.af, p), __fmul_rn(a.bf, __fdiv_rn(va[k], saf)));
     v[k] = p;
     if (i < L) mx = fmaxf(mx, p);
   }
-  mx = block_max(mx, red);
+  mx = bmax(mx);
   const float cut = __fsub_rn(mx, __fmul_rn(a.threshold, mx));
   double se = 0.0, s2 = 0.0;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    const int i = tid + k * kThreads;
+    const int i = tid + k * NTHR;
     if (i < L) {
       se += (double)__expf(v[k] - mx);  // CE is a reporting value: fast exp, fp64 sum
       if (!(v[k] < cut)) s2 += (double)v[k];
@@ -248,12 +274,21 @@ __global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
   s2 = avt::wave_sum(s2);
   __syncthreads();
   if (lane == 0) {
-    red.d[wid] = se;
+    red_d[wid] = se;
     red2[wid] = s2;
   }
   __syncthreads();
-  se = (red.d[0] + red.d[1]) + (red.d[2] + red.d[3]);
-  s2 = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+  if constexpr (NWV == 4) {
+    se = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    s2 = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+  } else {
+    se = s2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWV; w += 2) {
+      se += red_d[w] + red_d[w + 1];
+      s2 += red2[w] + red2[w + 1];
+    }
+  }
   const float s2f = (float)s2;
   const float p0 = __shfl(v[0], 0, 64);  // position 0 lives in thread 0 (wave 0); broadcast below through LDS
   // survivors: ballot per (round k, wave) -> exclusive offsets from one table
@@ -262,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
   double el = 0.0;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    const int i = tid + k * kThreads;
+    const int i = tid + k * NTHR;
     pn[k] = 0.0f;
     bool keep = false;
     if (i < L && !(v[k] < cut) && v[k] != 0.0f) {
@@ -271,35 +306,46 @@ __global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
     }
     bal[k] = __ballot(keep);
     el += keep ? (double)__logf(pn[k]) : 0.0;  // entropy is a reporting value: fast fp32 log, no divergent fp64 libm
-    if (lane == 0) cnt_tab[k * 4 + wid] = __popcll(bal[k]);
+    if (lane == 0) cnt_tab[k * NWV + wid] = __popcll(bal[k]);
   }
-  if (tid == 0) red.f[0] = p0;
+  __shared__ float s_p0;
+  if (tid == 0) s_p0 = p0;
   __syncthreads();  // counts (and p0) are in LDS
-  {                 // exclusive scan of the ITEMS*4 counts (<= 64 entries) by wave 0; barriers stay uniform
-    constexpr int n = ITEMS * 4;
-    int c = 0, incl = 0;
+  {                 // exclusive scan of the ITEMS * NWV counts (position order: round k, then wave) by wave 0; barriers stay uniform
+    constexpr int n = ITEMS * NWV, PER = (n + 63) / 64;  // PER consecutive entries per lane
+    int c[PER], incl = 0;
     if (wid == 0) {
-      c = lane < n ? cnt_tab[lane] : 0;
-      incl = c;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        c[e] = lane * PER + e < n ? cnt_tab[lane * PER + e] : 0;
+        incl += c[e];
+      }
+      const int mine = incl;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
       }
+      incl -= mine;  // exclusive over lanes
     }
     __syncthreads();
     if (wid == 0) {
-      if (lane < n) cnt_tab[lane] = incl - c;
-      if (lane == n - 1) cnt_tab[n] = incl;
+      int run = incl;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        if (lane * PER + e < n) cnt_tab[lane * PER + e] = run;
+        run += c[e];
+      }
+      if (lane == 63) cnt_tab[n] = run;
     }
     __syncthreads();
   }
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     if ((bal[k] >> lane) & 1ull) {
-      const int slot = cnt_tab[k * 4 + wid] + __popcll(bal[k] & ((1ull << lane) - 1ull));
+      const int slot = cnt_tab[k * NWV + wid] + __popcll(bal[k] & ((1ull << lane) - 1ull));
       if (slot < a.cap) {
-        const int i = tid + k * kThreads;
+        const int i = tid + k * NTHR;
         const int64_t o = (int64_t)r * a.cap + slot;
         if (a.surv_idx) a.surv_idx[o] = i;
         if (a.surv_seg) a.surv_seg[o] = col(i);
@@ -307,9 +353,9 @@ __global__ __launch_bounds__(kThreads) void row_transition_reg_kernel(TArgs a) {
       }
     }
   }
-  const int cnt = cnt_tab[ITEMS * 4];
-  const float p_first = red.f[0];
-  el = block_sum(el, red);
+  const int cnt = cnt_tab[ITEMS * NWV];
+  const float p_first = s_p0;
+  el = bsum(el);
   if (tid == 0) {
     if (a.surv_cnt) a.surv_cnt[r] = cnt;
     if (a.stats) {
@@ -383,6 +429,72 @@ __global__ __launch_bounds__(kThreads) void row_topk_kernel(KArgs a) {
   }
 }
 
+// Register-resident top-k: thread t holds positions t, t + NTHR, ... (the row is read from HBM once, coalesced); a round is a
+// per-thread scan of its ITEMS registers + one shuffle tree + one LDS hop, the winner's owner marks its register taken.
+// Same order as the LDS form: value descending, lowest column on ties; excluded / taken entries are NaN.
+template <int ITEMS, int NTHR>
+__global__ __launch_bounds__(NTHR) void row_topk_reg_kernel(KArgs a) {
+  constexpr int NWV = NTHR / 64;
+  __shared__ float s_v[NWV];
+  __shared__ int s_i[NWV];
+  __shared__ int s_win;
+  const int64_t r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* x = a.sim + r * a.ld;
+  const int self = a.self_col ? (int)a.self_col[r] : -1;
+  const int nt = (int)a.nt;
+  float v[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int j = tid + k * NTHR;
+    v[k] = (j < nt && j != self) ? x[j] : __builtin_nanf("");
+  }
+  for (int s = 0; s < a.k; ++s) {
+    float bv = -INFINITY;
+    int bi = -1;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {  // ascending j: the first maximum is kept -> lowest column on ties
+      const float u = v[k];
+      if (u == u && (bi < 0 || u > bv)) {
+        bv = u;
+        bi = tid + k * NTHR;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_v[wid] = bv;
+      s_i[wid] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = s_v[0];
+      int fi = s_i[0];
+      for (int w = 1; w < NWV; ++w)
+        if (s_i[w] >= 0 && (fi < 0 || s_v[w] > fv || (s_v[w] == fv && s_i[w] < fi))) {
+          fv = s_v[w];
+          fi = s_i[w];
+        }
+      a.top_idx[r * (int64_t)a.k + s] = fi;
+      a.top_val[r * (int64_t)a.k + s] = fi >= 0 ? fv : -INFINITY;
+      s_win = fi;
+    }
+    __syncthreads();
+    const int win = s_win;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+      if (tid + k * NTHR == win) v[k] = __builtin_nanf("");
+    // (the next round's first barrier orders the s_win read above before its rewrite)
+  }
+}
+
 }  // namespace
 
 extern "C" int avt_row_transition(const float* sim, int64_t nq, int64_t nt, int64_t ld, const int64_t* q_ids,
@@ -421,6 +533,10 @@ extern "C" int avt_row_transition(const float* sim, int64_t nq, int64_t nt, int6
     hipLaunchKernelGGL(row_transition_reg_kernel<8>, grid, block, 0, st, a);
   else if (nt <= 16 * kThreads)
     hipLaunchKernelGGL(row_transition_reg_kernel<16>, grid, block, 0, st, a);
+  else if (nt <= 8 * 1024)
+    hipLaunchKernelGGL((row_transition_reg_kernel<8, 1024>), grid, dim3(1024), 0, st, a);
+  else if (nt <= 16 * 1024)
+    hipLaunchKernelGGL((row_transition_reg_kernel<16, 1024>), grid, dim3(1024), 0, st, a);
   else if (nt <= kMaxLds)
     hipLaunchKernelGGL(row_transition_kernel<true>, grid, block, (size_t)nt * sizeof(float), st, a);
   else
@@ -439,6 +555,16 @@ extern "C" int avt_row_topk(const float* sim, int64_t nq, int64_t nt, int64_t ld
   }
   if (nq == 0) return AVT_OK;
   KArgs a{sim, self_col, nq, nt, ld, k, top_idx, top_val};
+  static const int reg_form = avt::env_int_flag("AVT_TOPK_REG", 1);  // 0: the LDS-resident form for every width
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  if (reg_form && nt <= 16 * 256) {
+    hipLaunchKernelGGL((row_topk_reg_kernel<16, 256>), dim3((unsigned)nq), dim3(256), 0, st_, a);
+    return avt::check_launch("avt_row_topk");
+  }
+  if (reg_form && nt <= 16 * 1024) {
+    hipLaunchKernelGGL((row_topk_reg_kernel<16, 1024>), dim3((unsigned)nq), dim3(1024), 0, st_, a);
+    return avt::check_launch("avt_row_topk");
+  }
   hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)nq), dim3(kThreads), (size_t)nt * sizeof(float),
                      static_cast<hipStream_t>(stream), a);
   return avt::check_launch("avt_row_topk");

@@ -9,22 +9,28 @@ The first layer has ONE input channel.  Eight adjacent mel bins (W axis) are rea
 chunk (fused_slowfast.group_weights_w): a block-Toeplitz [8*64, 8] x 3 x 3 filter over bin groups computes the same
 convolution with full chunks and full MFMA tiles (structured zeros instead of padding).
 
-Same contract as the module it wraps: forward([n,1,100,64]) -> [n, 12288] fp32; activations are bf16 (the fp32
-`vggish.VGGish` module stays the exact-parity path; validate.py picks this one together with the MFMA SlowFast).
+Same contract as the module it wraps: forward([n,1,100,64]) -> [n, 12288] fp32.  precision = "bf16": bf16 activations (the
+fast path); "f16x3" / "bf16x3": the contract-grade split-plane arithmetic of csrc/conv_x3.hip (every tensor two 16-bit planes,
+three MFMA passes per product, plane-pair 2x2 max-pool) — within 5e-5 of the fp32 module, so config 3's default path
+(validate.py, --enc_dtype fp32) has no MIOpen convolution left.
 """
 import torch
 import torch.nn as nn
 
 from . import ops
 from ._lib import AvtError
-from .fused_slowfast import Act, FusedConv, group_weights_w
+from .fused_slowfast import PRECISIONS, Act, FusedConv, group_weights_w, new_act, split_planes
 
 
 class VGGishMFMA(nn.Module):
     out_dim = 12288
 
-    def __init__(self, model, device):
+    def __init__(self, model, device, precision="bf16"):
         super().__init__()
+        if precision not in PRECISIONS:
+            raise AvtError("VGGishMFMA: precision must be one of %s" % sorted(PRECISIONS))
+        self.precision, self.x3 = precision, PRECISIONS[precision]
+        x3 = self.x3
         self.dev = torch.device(device)
         self._anchor = nn.Parameter(torch.zeros(1, dtype=torch.bfloat16, device=self.dev), requires_grad=False)
         self.layers = []  # (FusedConv, pool_after)
@@ -39,12 +45,12 @@ class VGGishMFMA(nn.Module):
             bias = m.bias.detach().float() if m.bias is not None else torch.zeros(w.shape[0])
             if w.shape[1] == 1:
                 wg, rg = group_weights_w(w, 8)
-                conv = FusedConv(None, None, True, self.dev, folded=(wg, bias.repeat(8), (1, 1, 1), (0, 1, rg)))
+                conv = FusedConv(None, None, True, self.dev, folded=(wg, bias.repeat(8), (1, 1, 1), (0, 1, rg)), x3=x3)
                 conv._folded = None  # already grouped
                 conv.alg_flops_per_row = 8 * 2.0 * 9 * w.shape[0]
                 conv.bins = 8
             else:
-                conv = FusedConv(None, None, True, self.dev, folded=(w, bias, (1, 1, 1), (0, 1, 1)))
+                conv = FusedConv(None, None, True, self.dev, folded=(w, bias, (1, 1, 1), (0, 1, 1)), x3=x3)
                 conv.bins = 1
             self.layers.append((conv, pool, w.shape[0]))
 
@@ -56,18 +62,24 @@ class VGGishMFMA(nn.Module):
         n, _, h, w = x.shape
         if w % 8:
             raise AvtError("VGGishMFMA: the number of mel bins must be a multiple of 8 (got %d)" % w)
-        buf = x.to(self.dev, torch.bfloat16).contiguous().view(n * h * (w // 8), 8)
-        act = Act(buf, (n, 1, h, w // 8))
+        if self.x3 is not None:
+            hi, lo = split_planes(x.to(self.dev, torch.float32).contiguous().view(n * h * (w // 8), 8), self.x3)
+            act = Act(hi, (n, 1, h, w // 8), lo=lo)
+        else:
+            act = Act(x.to(self.dev, torch.bfloat16).contiguous().view(n * h * (w // 8), 8), (n, 1, h, w // 8))
         for conv, pool, cout in self.layers:
             if conv.bins > 1:
                 y = conv(act)
-                act = Act(y.buf.view(-1, cout), (n, 1, h, w))
+                act = Act(y.buf.view(-1, cout), (n, 1, h, w), lo=None if y.lo is None else y.lo.view(-1, cout))
             else:
                 act = conv(act)
             if pool:
                 _, _, h, w = act.dims
-                out = torch.empty((n * (h // 2) * (w // 2), cout), dtype=torch.bfloat16, device=self.dev)
-                ops.maxpool_hw2s2(act.ptr, out.data_ptr(), n, h, w, cout, act.ld, cout)
+                out = new_act(n * (h // 2) * (w // 2), cout, (n, 1, h // 2, w // 2), self.dev, self.x3 is not None)
+                if self.x3 is not None:
+                    ops.maxpool_hw2s2_x3(act.ptrs, out.ptrs, n, h, w, cout, act.ld, cout, self.x3)
+                else:
+                    ops.maxpool_hw2s2(act.ptr, out.ptr, n, h, w, cout, act.ld, cout)
                 h, w = h // 2, w // 2
-                act = Act(out, (n, 1, h, w))
-        return act.buf.view(n, -1).float()
+                act = out
+        return act.float(self.x3).view(n, -1) if self.x3 is not None else act.buf.view(n, -1).float()

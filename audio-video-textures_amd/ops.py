@@ -379,6 +379,13 @@ def maxpool_hw3s2_x3(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgrou
                "avt_maxpool_hw3s2_ndhwc_x3")
 
 
+def maxpool_hw2s2_x3(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype):
+    """MaxPool2d(2, 2), floor mode, on plane pairs (NHWC rows): the contract-grade VGGish."""
+    _lib.check(_lib.lib().avt_maxpool_hw2s2_ndhwc_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), C.c_void_p(out_ptrs[0]),
+                                                     C.c_void_p(out_ptrs[1]), int(bt), int(h), int(w), int(c), int(ldi),
+                                                     int(ldo), int(plane_dtype), _stream()), "avt_maxpool_hw2s2_ndhwc_x3")
+
+
 def mean_positions_x3(x_ptrs, batch, p, c, ldi, out, col0, plane_dtype):
     _dev(out, "out", torch.float32)
     _lib.check(_lib.lib().avt_mean_positions_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), int(batch), int(p), int(c),

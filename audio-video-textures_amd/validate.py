@@ -219,15 +219,15 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
             print("Encoders: SlowFast on the MFMA kernels, precision {} ({})".format(
                 precision, "fast path, outside the 1e-3 score contract" if precision == "bf16" else "contract grade"))
             q_enc, t_enc = SlowFastMFMA(q_enc, dev, precision=precision), SlowFastMFMA(t_enc, dev, precision=precision)
-            if precision == "bf16":
-                # ... and so does VGGish (audio_models/vggish.py), for the model's audio branch and the driving branch;
-                # in the contract-grade modes VGGish stays the fp32 module (once per table, not on the critical path)
-                from .fused_vggish import VGGishMFMA
+            # ... and so does VGGish (audio_models/vggish.py), for the model's audio branch and the driving branch, in the SAME
+            # arithmetic as the video encoders: split planes in the contract-grade modes, bf16 in the fast mode
+            from .fused_vggish import VGGishMFMA
 
-                if isinstance(a_enc, VGGish):
-                    a_enc = VGGishMFMA(a_enc, dev)
-                if isinstance(da_model, VGGish):
-                    da_model = a_enc if da_model is getattr(net, "t_a_encoder", None) else VGGishMFMA(da_model, dev)
+            own = getattr(net, "t_a_encoder", None)
+            if isinstance(a_enc, VGGish):
+                a_enc = VGGishMFMA(a_enc, dev, precision=precision)
+            if isinstance(da_model, VGGish):
+                da_model = a_enc if (da_model is own and isinstance(a_enc, VGGishMFMA)) else VGGishMFMA(da_model, dev, precision=precision)
         elif impl == "mfma":
             raise AvtError("enc_impl=mfma needs SlowFast encoders (got {})".format(type(q_enc).__name__))
     eng = texture.TextureEngine(q_enc, t_enc, a_enc,

@@ -481,7 +481,7 @@ def main():
     ap.add_argument("--no-fast", action="store_true", help="skip the second timed leg (bf16 fast mode)")
     ap.add_argument("--encoder", default="mfma", choices=["mfma", "miopen"],
                     help="mfma: hand-written implicit-GEMM convolutions (fused_slowfast); miopen: stock nn.Module")
-    ap.add_argument("--enc-batch", type=int, default=128, help="clips per encoder launch")
+    ap.add_argument("--enc-batch", type=int, default=83, help="clips per encoder launch")
     ap.add_argument("--sim-precision", default="f32", choices=["f32", "bf16x3", "bf16"], help="similarity MFMA mode")
     ap.add_argument("--threshold", type=float, default=0.3)
     ap.add_argument("--frame-hw", type=int, default=128)

@@ -375,6 +375,10 @@ int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, 
                                const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw,
                                float mean, float std, int bgr, void* slow_hi, void* slow_lo,
                                void* fast_hi, void* fast_lo, int plane_dtype, void* stream);
+/* MaxPool2d(2, 2), floor mode, on plane pairs (NHWC rows): the contract-grade VGGish (audio_models/vggish.py:15-33; the
+ * plane-pair form of avt_maxpool_hw2s2_ndhwc_bf16).  The max is taken on hi + lo and split again: value-preserving. */
+int avt_maxpool_hw2s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h, int w, int c,
+                               int ldi, int ldo, int plane_dtype, void* stream);
 /* avt_maxpool_hw3s2_ndhwc_bf16 / avt_mean_positions_bf16 on plane pairs (max / sum of the fp32 values hi + lo). */
 int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h,
                                int w, int c, int ldi, int ldo, int tgroup, int plane_dtype, void* stream);

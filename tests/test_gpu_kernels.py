@@ -140,6 +140,34 @@ def test_transition_long_row_uncached(avt, dev):
     _check_transition(g, o, 256)
 
 
+@pytest.mark.parametrize("nt", [4097, 8192, 12000, 16384])
+@pytest.mark.parametrize("th", [0.0, 0.05])
+def test_transition_config4_width_rows(avt, dev, nt, th):
+    """Config 4's rows (N = 16384 windows; 2048 per rank x 16384): the 1024-thread register-resident select, bit-identical to
+    the oracle (survivors, their order, probabilities, row sum / max) at every width that takes it, with the reference's
+    [pos] + others target order (q_ids) and ragged last rounds."""
+    rng = np.random.default_rng(nt)
+    nq = 6
+    sim = (rng.random((nq, nt), dtype=np.float32) * 4 + 0.5).astype(np.float32)
+    sim[2, 100] = sim[2, nt - 1] = 9.0  # an exact tie for the maximum, first and last rounds
+    q_ids = np.array([0, 1, nt // 2, nt - 3, nt - 2, nt - 1], dtype=np.int64)
+    o = cref.row_transition(sim, q_ids=q_ids, n_seg=nt, threshold=th, cap=512)
+    g = avt.ops.row_transition(torch.from_numpy(sim).to(dev), q_ids=torch.from_numpy(q_ids).to(dev), threshold=th, cap=512)
+    _check_transition(g, o, 512)
+
+
+@pytest.mark.parametrize("nt", [3000, 4096, 5000, 16384])
+def test_topk_wide_rows(avt, dev, nt):
+    sim = _rand((12, nt), nt)
+    sim[3, 10] = sim[3, nt - 7] = 99.0  # tie -> lower column first
+    sim[4, :] = -np.inf                # nothing but -inf: still k distinct picks, lowest columns first
+    self_col = np.arange(12, dtype=np.int64) * (nt // 12)
+    oi, ov = cref.row_topk(sim, 8, self_col)
+    gi, gv = avt.ops.row_topk(torch.from_numpy(sim).to(dev), 8, torch.from_numpy(self_col).to(dev))
+    assert np.array_equal(gi.cpu().numpy(), oi)
+    assert np.array_equal(gv.cpu().numpy(), ov)
+
+
 def test_topk(avt, dev):
     sim = _rand((50, 3000), 21)
     sim[3, 10] = sim[3, 2000] = 99.0  # tie -> lower column first

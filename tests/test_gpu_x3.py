@@ -468,3 +468,70 @@ def test_bneck_x3_matches_fp64_and_the_per_layer_kernels(avt, dev, mode, cin, c,
     tol = 3 * TOL[mode]  # three layers deep
     assert err_f < tol and err_p < tol, (err_f, err_p)
     assert (yf - yp).abs().max().item() / scale < tol
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_vggish_x3_matches_fp32_module(avt, dev, mode):
+    """Contract-grade VGGish (audio_models/vggish.py:15-46 on csrc/conv_x3.hip + the plane-pair 2x2 max-pool) against the fp32
+    plugin module on MIOpen: [n, 12288] in the NHWC flatten order, relative error <= 5e-5 (fp16 planes) / 5e-4 (bf16
+    planes) — config 3's default path then has no MIOpen convolution."""
+    from avtex.fused_vggish import VGGishMFMA
+    from avtex.vggish import VGGish
+
+    torch.manual_seed(6)
+    m = VGGish().eval()
+    with torch.no_grad():
+        for mod in m.features:
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, nonlinearity="relu")
+                mod.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(5, 1, 100, 64) * 2 - 1  # log-mel range
+    y = VGGishMFMA(m, dev, precision=mode)(x).cpu()
+    with torch.no_grad():
+        ref64 = m.double()(x.double())
+        ref32 = m.float().to(dev)(x.to(dev)).cpu()
+    assert y.shape == (5, 12288) and torch.isfinite(y).all()
+    rel = ((y.double() - ref64).norm(dim=1) / ref64.norm(dim=1)).max().item()
+    rel32 = ((ref32.double() - ref64).norm(dim=1) / ref64.norm(dim=1)).max().item()
+    print("vggish %s vs fp64: rel %.3e (fp32 module on MIOpen vs fp64: %.3e)" % (mode, rel, rel32))
+    assert rel < (5e-4 if mode == "bf16x3" else 5e-5)
+
+
+def test_validate_m2_default_path_runs_vggish_on_the_split_plane_kernels(avt, dev, capsys, monkeypatch):
+    """Config 3 with the CLI defaults (--enc_dtype fp32 = f16x3): SlowFast x2 AND VGGish run on the contract-grade kernels —
+    the audio encoder validate() hands the engine is a VGGishMFMA in the same precision, not the MIOpen module."""
+    from types import SimpleNamespace
+
+    import avtex.texture as texture
+    from avtex.fused_vggish import VGGishMFMA
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(0)
+    model = avt.ContrastivePredictionTemporal(SlowFast(), SlowFast(), avt.VGGish(), 2, 128, temp=0.1, window=5, stride=2,
+                                              threshold=0.3, mini_batchsize=8, enc_arch="slowfast", img_size=64)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.uniform_(0.5, 1.0)
+    model = model.to(dev).eval()
+    seen = {}
+    real = texture.TextureEngine
+
+    def spy(q_enc, t_enc, a_enc, **kw):
+        seen["a"], seen["q"] = a_enc, q_enc
+        return real(q_enc, t_enc, a_enc, **kw)
+
+    monkeypatch.setattr(texture, "TextureEngine", spy)
+    rng = np.random.default_rng(3)
+    wave = (0.1 * rng.standard_normal(7 * 16000)).astype(np.float32)
+    g = torch.Generator().manual_seed(2)
+    video = torch.randint(0, 256, (70, 48, 48, 3), generator=g, dtype=torch.uint8)
+    args = SimpleNamespace(vdata=None, adata=None, dadata=None, subsample_rate=1, fps=10, stride=2, window=5,
+                           enc_arch="slowfast", img_size=64, model_type=2, mini_batchsize=8, threshold=0.3, alpha=0.5,
+                           temp=0.1, driving_audio=None, da_feats="VGG", interpolation=False, new_video_length=2,
+                           results_folder=None, logname="exp", batch_size=8, stitch_mode="aligned", ref_num_gpus=1,
+                           enc_batch=8, enc_impl="auto", enc_dtype="fp32")
+    np.random.seed(5)
+    frames = avt.validate(model, args, video_name="x", model_type=2, video=(video.numpy(), 10.0), audio=(wave, 16000))
+    assert len(frames) >= 10
+    assert isinstance(seen["a"], VGGishMFMA) and seen["a"].precision == "f16x3" and seen["q"].precision == "f16x3"
