@@ -288,8 +288,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           const float4 s = *reinterpret_cast<const float4*>(cf + 16 * n + 4 * q);
           const float4 bb_ = *reinterpret_cast<const float4*>(cf + CMP + 16 * n + 4 * q);
           uint2 h, l;
-          avt::split2<F16>(fmaxf(acc[n][0] * s.x + bb_.x, 0.f), fmaxf(acc[n][1] * s.y + bb_.y, 0.f), h.x, l.x);
-          avt::split2<F16>(fmaxf(acc[n][2] * s.z + bb_.z, 0.f), fmaxf(acc[n][3] * s.w + bb_.w, 0.f), h.y, l.y);
+          avt::split2<F16>(avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y), h.x, l.x);
+          avt::split2<F16>(avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w), h.y, l.y);
           if (a_st[it] >= 0) {
             *reinterpret_cast<uint2*>(aoh + a_st[it] + n * 32) = h;
             *reinterpret_cast<uint2*>(aol + a_st[it] + n * 32) = l;
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           const float4 s = *reinterpret_cast<const float4*>(cf + 2 * CMP + 16 * n + 4 * q);
           const float4 bb_ = *reinterpret_cast<const float4*>(cf + 3 * CMP + 16 * n + 4 * q);
           uint2 h, l;
-          avt::split2<F16>(fmaxf(acc[n][0] * s.x + bb_.x, 0.f), fmaxf(acc[n][1] * s.y + bb_.y, 0.f), h.x, l.x);
-          avt::split2<F16>(fmaxf(acc[n][2] * s.z + bb_.z, 0.f), fmaxf(acc[n][3] * s.w + bb_.w, 0.f), h.y, l.y);
+          avt::split2<F16>(avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y), h.x, l.x);
+          avt::split2<F16>(avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w), h.y, l.y);
           const int o = (m * 16 + l15) * AREC + n * 32 + q * 8;
           *reinterpret_cast<uint2*>(boh + o) = h;
           *reinterpret_cast<uint2*>(bol + o) = l;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        for (int i = 0; i < 8; ++i) v[i] = avt::relu_keep_nan(v[i]);
         uint4 oh, ol;
         avt::split2<F16>(v[0], v[1], oh.x, ol.x);
         avt::split2<F16>(v[2], v[3], oh.y, ol.y);

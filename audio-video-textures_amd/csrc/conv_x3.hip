@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       }
       if (a.relu == 1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+        for (int e = 0; e < 8; ++e) x[e] = avt::relu_keep_nan(x[e]);
       } else if (a.relu == 2) {  // LeakyReLU(0.1): the SuperSloMo UNets (models/slowmo.py:69-71, 132-134, 195-207)
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.1f * x[e]);
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         }
         if (a.relu == 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+          for (int e = 0; e < 8; ++e) x[e] = avt::relu_keep_nan(x[e]);
         } else if (a.relu == 2) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.1f * x[e]);

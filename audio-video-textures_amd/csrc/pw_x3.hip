@@ -151,7 +151,7 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_kernel(PxArgs a) {
       }
       if (a.relu) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        for (int i = 0; i < 8; ++i) v[i] = avt::relu_keep_nan(v[i]);
       }
       uint4 oh, ol;
       avt::split2<F16>(v[0], v[1], oh.x, ol.x);

@@ -30,6 +30,9 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
     lo = avt::pack_bf16x2(x0 - avt::bf16x2_lo(hi), x1 - avt::bf16x2_hi(hi));
   }
 }
+// ReLU that keeps a NaN a NaN, like torch.relu (fmaxf(NaN, 0) = 0 under IEEE maxNum would turn a poisoned activation into a
+// plausible zero; an infinity times a weight's low plane of either sign arrives here as a NaN too)
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.0f ? 0.0f : v; }
 // packed (hi, lo) planes -> the fp32 pair they stand for
 template <bool F16>
 __device__ __forceinline__ f32x2 join2(uint32_t hi, uint32_t lo) {

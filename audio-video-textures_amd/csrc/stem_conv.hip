@@ -260,7 +260,7 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
     v[4] = acc[m][1][0] * s1.x + b1.x; v[5] = acc[m][1][1] * s1.y + b1.y; v[6] = acc[m][1][2] * s1.z + b1.z; v[7] = acc[m][1][3] * s1.w + b1.w;
     if (a.relu) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+      for (int i = 0; i < 8; ++i) v[i] = PL ? avt::relu_keep_nan(v[i]) : fmaxf(v[i], 0.f);
     }
   };
   auto packed = [&](int m) {

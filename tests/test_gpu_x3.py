@@ -282,8 +282,10 @@ def test_contract_on_the_same_frames(avt, dev):
 @pytest.mark.parametrize("bad", [float("nan"), float("inf")])
 def test_x3_fp16_planes_propagate_nan_and_inf(avt, dev, bad):
     """A poisoned activation must reach the output: the fp16-plane split clamps FINITE values to 65504 but keeps a NaN a NaN
-    and an infinity an infinity (csrc/split_planes.h; fminf / fmaxf alone would turn a NaN into -65504).  Checked through
-    both contract-grade convolution kernels: the general tile (3x3) and the streaming pointwise kernel."""
+    and an infinity an infinity (csrc/split_planes.h; fminf / fmaxf alone would turn a NaN into -65504), and the kernels'
+    ReLU keeps a NaN like torch.relu does (fmaxf(NaN, 0) would return 0).  An infinite input comes out NON-FINITE (inf
+    times a weight's low plane of either sign is -inf or +inf: the accumulator may hold a NaN) — never a plausible number.
+    Checked through both contract-grade convolution kernels: the general tile (3x3) and the streaming pointwise kernel."""
     import torch.nn as nn
 
     from avtex import ops
@@ -304,14 +306,15 @@ def test_x3_fp16_planes_propagate_nan_and_inf(avt, dev, bad):
             assert torch.isnan(hi.view(torch.float16)[5, 7])
         y = fc(Act(hi.to(dev), dims, lo=lo.to(dev))).float(ops.X3_F16).cpu()
         # position 5 = (frame 0, row 0, col 5): its own output row is poisoned in every channel; far rows stay finite
-        assert (torch.isnan(y[5]).all() if bad != bad else torch.isinf(y[5]).all()), (k, y[5][:8])
+        assert (torch.isnan(y[5]).all() if bad != bad else (~torch.isfinite(y[5])).all()), (k, y[5][:8])
         assert torch.isfinite(y[m - 1]).all()
 
 
-@pytest.mark.parametrize("scale", [2.0 ** 14, 2.0 ** -16])
+@pytest.mark.parametrize("scale", [2.0 ** 12, 2.0 ** -16])
 def test_x3_fp16_planes_at_the_edges_of_their_range(avt, dev, scale):
     """Network-level range test of the fp16 planes: a residual block's worth of layers ([3,1,1] -> [1,3,3] -> [1,1,1] + residual)
-    with activations scaled to ~2^14 (a factor 4 under the fp16 clamp at 65504) and to ~2^-16 (below 2^-14 the planes go from
+    with activations scaled to ~2^12 (their 4.5-sigma tail and the layers' outputs stay a factor 2-3 under the fp16 clamp at
+    65504; at 2^14 the tails ARE clamped, and the test's first form measured exactly that) and to ~2^-16 (below 2^-14 the planes go from
     relative to ABSOLUTE precision, 2^-24 per element) against fp64 on the same weights.  Large: full 2^-22-grade relative
     accuracy.  Tiny: the error is bounded by the absolute floor — 2^-24 per input element times the layer's gain — and the
     test asserts that bound, i.e. documents where fp16 planes stop being fp32-grade (bf16 planes do not have this floor)."""
