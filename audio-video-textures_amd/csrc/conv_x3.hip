@@ -520,8 +520,17 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   struct Frags {
     i32x4 ah[MT], al[MT], wh[NT], wl[NT];
   };
+  // (reads are issued in the order the MFMAs first need them — wh0 wl0 ah0 al0, the other activation fragments, then the
+  //  second weight pair — so that the first triple of a step starts after three reads, not after all twelve: in-kernel
+  //  stamps put 16 % of a workgroup's time into the fragments' arrival at the top of each step)
   auto fload = [&](Frags& f, const char* st, int ks) {
     const int slot = ((ks * 2 + lh) ^ fsw) * 16;
+    auto rd_w = [&](int i) {
+      const int o = (wn * 64 + i * 32 + lr) * 64 + slot;
+      f.wh[i] = *reinterpret_cast<const i32x4*>(st + 2 * PL + o);
+      f.wl[i] = *reinterpret_cast<const i32x4*>(st + 3 * PL + o);
+    };
+    rd_w(0);
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
       const int o = (wm * 128 + j * 32 + lr) * 64 + slot;
@@ -529,11 +538,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       f.al[j] = *reinterpret_cast<const i32x4*>(st + PL + o);
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int o = (wn * 64 + i * 32 + lr) * 64 + slot;
-      f.wh[i] = *reinterpret_cast<const i32x4*>(st + 2 * PL + o);
-      f.wl[i] = *reinterpret_cast<const i32x4*>(st + 3 * PL + o);
-    }
+    for (int i = 1; i < NT; ++i) rd_w(i);
   };
   auto fmul = [&](const Frags& f, int g0, bool more, char* nst) {
 #pragma unroll
@@ -550,11 +555,13 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   };
 
   __syncthreads();
+  STAMP_BEGIN();
   gprep(0);
 #pragma unroll
   for (int p = 0; p < NPIECE; ++p) gpiece(p, lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  STAMP(0);  // prologue
   for (int kt = 0; kt < nk32; ++kt) {
     const bool more = kt + 1 < nk32;
     char* cur = lds + (kt & 1) * STG;
@@ -564,18 +571,56 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
     if (more) gprep(kt + 1);
     fload(f1, cur, 1);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef AVT_CONV_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (diagnostic build: the fragment reads' latency as its own segment)
+    STAMP(1);
+#endif
     fmul(f0, 0, more, nst);
     fmul(f1, NT * MT, false, nst);
+    STAMP(2);  // 48 MFMAs + the next step's 8 DMA pieces
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed (the barrier does not wait for DMA)
+    STAMP(3);  // wait for own DMA
     __syncthreads();
+    STAMP(4);  // barrier
   }
 
-  // ---- epilogue: one 64-column slab per pass, staged in fp32, split on the final value
+  // ---- epilogue: one 64-column slab per pass, staged in fp32 in one of TWO buffers (the operand stages + the table area are
+  // free now): the waves of column block p + 1 write their accumulators while every thread splits and stores slab p — one
+  // barrier per pass instead of two, and the stores of a slab run under the next slab's LDS writes
   constexpr int CPR = 8;                       // 8-channel chunks per slab row
   constexpr int EU = (BM * CPR) / NTHR;        // 4 chunks per thread and pass
+  constexpr int EBUF = BM * ESTR;
+  static_assert(2 * EBUF <= 2 * STG + kMaxTabSteps * 64, "two staging buffers fit the operand stages + the table area");
   const bool has_res = a.res != nullptr;
+  auto stage_slab = [&](int pass) {  // the two waves rows x this column block write their 128 x 64 accumulators
+    char* eb = lds + (pass & 1) * EBUF;
+    // D layout: column (lane & 31) = m, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = n
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = i * 32 + 8 * g + 4 * lh;  // column inside the slab
+        const int ng = n0 + pass * 64 + nl;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (a.bias && ng < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + ng);
+        if (a.wscale && ng < a.Cout) sv = *reinterpret_cast<const float4*>(a.wscale + ng);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          float4 v;
+          v.x = acc[i][j][4 * g + 0] * sv.x + bv.x;
+          v.y = acc[i][j][4 * g + 1] * sv.y + bv.y;
+          v.z = acc[i][j][4 * g + 2] * sv.z + bv.z;
+          v.w = acc[i][j][4 * g + 3] * sv.w + bv.w;
+          const int ml = wm * 128 + j * 32 + lr;
+          *reinterpret_cast<float4*>(eb + ml * ESTR + nl * 4) = v;
+        }
+      }
+  };
+  if (wn == 0) stage_slab(0);
+  __syncthreads();
 #pragma unroll 1
   for (int pass = 0; pass < 4; ++pass) {
+    const char* eb = lds + (pass & 1) * EBUF;
     uint4 rrh[EU], rrl[EU];
     if (has_res) {
 #pragma unroll
@@ -587,38 +632,15 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         rrl[u] = ok ? *reinterpret_cast<const uint4*>(a.res_lo + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
       }
     }
-    if (wn == pass) {
-      // D layout: column (lane & 31) = m, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = n
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = i * 32 + 8 * g + 4 * lh;  // column inside the slab
-          const int ng = n0 + pass * 64 + nl;
-          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
-          if (a.bias && ng < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + ng);
-          if (a.wscale && ng < a.Cout) sv = *reinterpret_cast<const float4*>(a.wscale + ng);
-#pragma unroll
-          for (int j = 0; j < MT; ++j) {
-            float4 v;
-            v.x = acc[i][j][4 * g + 0] * sv.x + bv.x;
-            v.y = acc[i][j][4 * g + 1] * sv.y + bv.y;
-            v.z = acc[i][j][4 * g + 2] * sv.z + bv.z;
-            v.w = acc[i][j][4 * g + 3] * sv.w + bv.w;
-            const int ml = wm * 128 + j * 32 + lr;
-            *reinterpret_cast<float4*>(lds + ml * ESTR + nl * 4) = v;
-          }
-        }
-    }
-    __syncthreads();
+    if (pass + 1 < 4 && wn == pass + 1) stage_slab(pass + 1);  // into the other buffer (its last readers passed the barrier below)
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       const int c = tid + NTHR * u;
       const int row = c / CPR, cc = c % CPR;
       const int m = m0 + row, n = n0 + pass * 64 + cc * 8;
       if (m < a.M && n < a.Cout) {
-        const float4 v0 = *reinterpret_cast<const float4*>(lds + row * ESTR + cc * 32);
-        const float4 v1 = *reinterpret_cast<const float4*>(lds + row * ESTR + cc * 32 + 16);
+        const float4 v0 = *reinterpret_cast<const float4*>(eb + row * ESTR + cc * 32);
+        const float4 v1 = *reinterpret_cast<const float4*>(eb + row * ESTR + cc * 32 + 16);
         float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (has_res) {
           const uint32_t* ph = reinterpret_cast<const uint32_t*>(&rrh[u]);
@@ -647,8 +669,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
       }
     }
-    __syncthreads();
+    __syncthreads();  // slab pass + 1 is staged; buffer pass & 1 is free for slab pass + 2
   }
+  STAMP_END();
 }
 
 template <bool F16>
@@ -657,7 +680,7 @@ int launch_x3_xl(ConvArgs& a, hipStream_t st) {
   a.tiles_n = (a.Cout + 255) / 256;
   a.nblk = tiles_m * a.tiles_n;
   constexpr int lds_max = 2 * 4 * 256 * 64 + kMaxTabSteps * 64;
-  const int lds_bytes = 2 * 4 * 256 * 64 + (a.nk <= kMaxTabSteps ? a.nk : 0) * 64;
+  const int lds_bytes = lds_max;  // (the epilogue's second staging buffer reaches into the table area)
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
@@ -694,7 +717,7 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
 
 // which tile avt_conv3d_igemm_x3 launches (bench.py names its roofline rows by it)
 extern "C" int avt_conv3d_igemm_x3_xl_picked(int cout, int k, int m) {
-  static const int min_k = avt::env_int_flag("AVT_CONV_X3_XL_MINK", 512);
+  static const int min_k = avt::env_int_flag("AVT_CONV_X3_XL_MINK", 256);
   return (cout % 256 == 0 && k >= min_k && m >= 256 * 64) ? 1 : 0;
 }
 

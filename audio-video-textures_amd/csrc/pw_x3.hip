@@ -216,6 +216,7 @@ int dispatch_k(PxArgs& a, int k1s, int nt1, hipStream_t st) {
     case 2: return dispatch_nt<2, F16>(a, nt1, st);
     case 3: return dispatch_nt<3, F16>(a, nt1, st);
     case 4: return dispatch_nt<4, F16>(a, nt1, st);
+    case 5: return dispatch_nt<5, F16>(a, nt1, st);
     case 8: return dispatch_nt<8, F16>(a, nt1, st);
     case 10: return dispatch_nt<10, F16>(a, nt1, st);
     case 16: return dispatch_nt<16, F16>(a, nt1, st);
@@ -228,7 +229,7 @@ int dispatch_k(PxArgs& a, int k1s, int nt1, hipStream_t st) {
 
 extern "C" int avt_pw_x3_supported(int k, int n) {
   const int k1s = (k + 31) / 32;
-  if (k % 8 || !(k1s == 1 || k1s == 2 || k1s == 3 || k1s == 4 || k1s == 8 || k1s == 10 || k1s == 16)) return 0;
+  if (k % 8 || !(k1s == 1 || k1s == 2 || k1s == 3 || k1s == 4 || k1s == 5 || k1s == 8 || k1s == 10 || k1s == 16)) return 0;
   const int nt1 = pick_nt1(k1s, n);
   if (!nt1) return 0;
   if ((nt1 == 16 && k1s > 4) || (nt1 == 8 && k1s > 8)) return 0;

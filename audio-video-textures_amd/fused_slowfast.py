@@ -725,6 +725,17 @@ class _BlockX3:
             (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
             self.fused = pack_bottleneck_x3(wa, ba, wb, bb, wc, bc, x3, device,
                                             shortcut=self.b1._folded if (first8 or strided) else None)
+        # first block of a stage with a stride-1 1x1x1 shortcut conv and a pointwise a (slow res2): c and the shortcut are ONE
+        # pointwise GEMM over K = [x | b-output] when b writes its output into spare columns behind x's channels — no shortcut
+        # launch, no shortcut tensor written and read back as the residual (self.extra = columns the caller leaves free)
+        self.ccat, self.extra = None, 0
+        if (_FUSE_KCAT and self.b1 is not None and self.fused is None and self.a.kernel == (1, 1, 1) and
+                self.c.kernel == (1, 1, 1) and self.b1.kernel == (1, 1, 1) and self.a.stride == (1, 1, 1) and
+                self.b.stride == (1, 1, 1) and self.b1.stride == (1, 1, 1) and self.c.stride == (1, 1, 1)):
+            (wsc, bsc), (wc, bc) = self.b1._folded, self.c._folded
+            self.ccat = FusedConv(None, None, True, device, folded=(torch.cat([wsc, wc], 1), bc + bsc, (1, 1, 1), (0, 0, 0)), x3=x3)
+            self.ccat.alg_flops_per_row = self.c.alg_flops_per_row + self.b1.alg_flops_per_row
+            self.extra = self.c.cin
 
     def __call__(self, x, out=None):
         if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
@@ -736,7 +747,7 @@ class _BlockX3:
 
             def launch():
                 ops.bneck_x3(x.ptrs, y.ptrs, self.fused, b, t, h, w, x.C, self.c.cout, self.x3,
-                             tchunk=_FUSE_TCHUNK_X3 or (8 if w >= 28 else 16))  # measured: profiles/r03/probe_bneck_x3_tchunk.log
+                             tchunk=_FUSE_TCHUNK_X3 or 8)  # measured: profiles/r03/probe_bneck_x3_tchunk.log
 
             if PROFILER is None:
                 launch()
@@ -746,6 +757,9 @@ class _BlockX3:
                                                           (self.b1.alg_flops_per_row if self.b1 is not None else 0.0))
                 PROFILER("bneck_x3_kernel", launch, fl, 4.0 * (m * x.C + mo * self.c.cout))
             return y
+        if self.ccat is not None and x.c0 == 0 and x.lo is not None and x.ld >= x.C + self.extra and x.C == self.a.cin:
+            self.b(self.a(x), out=Act(x.buf, x.dims, x.C, self.extra, lo=x.lo))  # b's output lands behind x in the same rows
+            return self.ccat(Act(x.buf, x.dims, 0, x.C + self.extra, lo=x.lo), out=out)
         sc = self.b1(x) if self.b1 is not None else x
         return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)
 
@@ -885,11 +899,12 @@ class SlowFastMFMA(nn.Module):
         cs, cf = self.stem_s.frame_channels, self.stem_f.frame_channels
         hs, ws = (slow.shape[2] // 2 - 1) // 2 + 1, (slow.shape[3] // 2 - 1) // 2 + 1
         ds = (b, slow.shape[1], hs, ws)
-        cat = new_act(ds[0] * ds[1] * ds[2] * ds[3], cs + 2 * cf, ds, self.dev, True)
+        extra = getattr(self.stages[0][0][0], "extra", 0)  # spare columns for the first slow block's K-concatenated c
+        cat = new_act(ds[0] * ds[1] * ds[2] * ds[3], cs + 2 * cf + extra, ds, self.dev, True)
         sl = lambda a, c0, c: Act(a.buf, a.dims, c0, c, lo=a.lo)
         self._stem_x3(self.stem_s, slow, out=sl(cat, 0, cs))
         self.fuse[0](f_act, out=sl(cat, cs, 2 * cf))
-        s_act = cat
+        s_act = sl(cat, 0, cs + 2 * cf)
         for k, (slow_blocks, fast_blocks) in enumerate(self.stages):
             for blk in fast_blocks:
                 f_act = blk(f_act)

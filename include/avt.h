@@ -335,7 +335,7 @@ int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi,
                         void* stream);
 /* HOST. 1 when avt_conv3d_igemm_x3 runs this layer (cout output channels, k = taps * cin, m output positions) on its XL
  * tile (256 x 256 outputs per workgroup, half the L2 -> LDS operand bytes per flop of the 128 x 128 tile): cout % 256 == 0,
- * k >= 512, m >= 16384.  Same arithmetic, same results to the last bit as the other tiles is NOT promised (fp32 accumulation
+ * k >= 256, m >= 16384.  Same arithmetic, same results to the last bit as the other tiles is NOT promised (fp32 accumulation
  * order over K differs in the 32-wide steps); both are held to the fp32 reference by the same tolerance. */
 int avt_conv3d_igemm_x3_xl_picked(int cout, int k, int m);
 /* One bottleneck of the SlowFast FAST pathway in ONE kernel on plane pairs (csrc/bneck_x3.hip; the contract-grade form of
