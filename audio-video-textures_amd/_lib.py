@@ -71,6 +71,7 @@ SIGNATURES = {
     "avt_clip_pack_gather_u8": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                 C.c_int, _vp, _vp, C.c_int, _vp],
     "avt_stem_conv_x3": [_vp] * 8 + [C.c_int] * 10 + [_vp],
+    "avt_stem_conv_pool_x3": [_vp] * 8 + [C.c_int] * 11 + [_vp],
     "avt_pw_x3_supported": [C.c_int] * 2,
     "avt_pw_x3": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int64,
                   C.c_int, C.c_int, _vp],

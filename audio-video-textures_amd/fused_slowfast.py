@@ -36,6 +36,10 @@ _FUSE_BLOCK_X3 = int(os.environ.get("AVT_FUSE_BLOCK_X3", "1"))  # contract-grade
 _FUSE_TCHUNK_X3 = int(os.environ.get("AVT_FUSE_TCHUNK_X3", "0"))  # frames walked per workgroup; 0 = by width
 _PW_X3 = int(os.environ.get("AVT_PW_X3", "1"))               # contract-grade mode: pointwise layers on the streaming kernel
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
+# contract-grade mode: max-pool fused into the stem kernel (1 = the slow stem, 2 = both).  OFF by default: measured 1.74 ms for the
+# pooled slow stem against 1.01 + 0.72 ms for stem + pool at 83 clips (profiles/r03/probe_stem_pool_x3.log) — the kernel is not
+# write-bound, and the fifth (recomputed) conv row + the fp32 tile's LDS round trip cost what the pool kernel did
+_STEM_POOL_X3 = int(os.environ.get("AVT_STEM_POOL_X3", "0"))
 _STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "1"))  # max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both
 #                                                         (the MFMA-bound fast stem loses 4 % to the recomputed ninth row)
 _KW1_CAP = int(os.environ.get("AVT_GROUP_KW1_CAP", "32"))  # measured: profiles/r01/probe_layers.log
@@ -866,7 +870,29 @@ class SlowFastMFMA(nn.Module):
         """Contract-grade stem: pixel-pair convolution on the plain split-plane kernel, then the plane-pair max-pool."""
         b, t, h, w, _ = clip.shape
         x = Act(clip.hi.view(b * t * h * (w // 2), 8), (b, t, h, w // 2), lo=clip.lo.view(b * t * h * (w // 2), 8))
-        if _STEM_LDS and conv.wt_lds_lo is not None and ops.stem_conv_supported(h, w // 2, conv.cout):
+        lds_path = _STEM_LDS and conv.wt_lds_lo is not None and ops.stem_conv_supported(h, w // 2, conv.cout)
+        kt = conv.kernel[0]
+        if lds_path and _STEM_POOL_X3 and (kt == 1 or _STEM_POOL_X3 > 1) and (h // 2) % 4 == 0:
+            # ... with the max-pool fused (the slow stem: one frame tap; the MFMA-bound fast stem would lose more to the
+            # recomputed fifth row than the separate pool costs): the conv output never reaches HBM
+            od = conv.out_dims(x.dims)
+            m_out = od[0] * od[1] * od[2] * od[3]
+            pd = (b, t, od[2] // 2, od[3] // 2)
+            cf = conv.frame_channels
+            if out is None:
+                out = new_act(pd[0] * pd[1] * pd[2] * pd[3], cf, pd, self.dev, True)
+
+            def launch():
+                ops.stem_conv_pool_x3(x.ptrs, conv.wt_lds, conv.wt_lds_lo, conv.bias, conv.wscale, out.ptrs, b, t, h, w // 2,
+                                      conv.cout, kt, conv.stride[0], conv.pad[0], conv.tgroup, out.ld, self.x3)
+
+            if PROFILER is None:
+                launch()
+            else:
+                PROFILER("stem_kernel<x3>", launch, m_out * conv.alg_flops_per_row,
+                         4.0 * (x.buf.numel() + pd[0] * pd[1] * pd[2] * pd[3] * cf) + conv.wt.numel() * 4)
+            return out, pd
+        if lds_path:
             # production shape: the patch-resident stem kernel in its plane-pair form (no im2col gather)
             od = conv.out_dims(x.dims)
             m_out = od[0] * od[1] * od[2] * od[3]
