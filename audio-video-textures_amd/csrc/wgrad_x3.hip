@@ -18,7 +18,10 @@
 // so an 8-channel 3x3 layer fills 72 of a tile's 128 rows and reads dY once, not 8 of 128 nine times over.
 // Work split: one workgroup = (chunk of slabs, 128 of the longer axis, BN of the shorter one); partial tiles are added into
 // dW with hardware fp32 atomics (dW is zeroed first; the order is not deterministic, as MIOpen's is not).  Strides,
-// padding and ragged edges live in the table; channel counts in multiples of 8; at most 28 taps (3x3x3, 7x1x1).
+// padding and ragged edges live in the table; input channels in multiples of 4 (a float4 per tap), output channels of 8; at most
+// 28 taps (3x3x3, 7x1x1) with two workgroups per CU, up to 49 ([1,7,7]: the SlowFast stems, whose 3 input channels travel as
+// 4 — the stems' weight gradient was the last MIOpen kernel of weight in the step, 77 ms of 730) with one; a frame-tap slice
+// of a longer filter (the fast stem's [5,7,7] = five [1,7,7] slices) is a sub-problem: explicit output extent, any pt, ldw.
 #include <stdlib.h>
 
 #include "avt_common.h"
@@ -37,7 +40,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMaxTaps = 28;  // taps of one convolution the position table holds (3x3x3 = 27; the 7x1x1 lateral ones = 7)
+constexpr int kMaxTaps = 28;   // taps the position table holds with two workgroups per CU (3x3x3 = 27; the 7x1x1 lateral ones = 7)
+constexpr int kMaxTapsBig = 49;  // ... with one workgroup per CU ([1,7,7]: the stems)
 
 struct WgArgs {
   const float* dy;  // [M, ldy]
@@ -45,6 +49,8 @@ struct WgArgs {
   float* dw;        // [Cout][E], E = taps * Cin: the x operand's axis is (tap, ci) flattened — im2col rows, never materialised
   int B, T, H, W, To, Ho, Wo, KT, KH, KW, st, sh, sw, pt, ph, pw;
   int Cin, Cout, ldx, ldy, M, taps, E;
+  int tapcap;  // taps the position table has room for (its row stride)
+  int ldw;     // row stride of dW (elements): E, or more when dW is a slice of a longer filter
   int r_tiles, s_tiles;  // tiles of the 128-wide / BN-wide operand axis
   int nslab, slabs_per_chunk, nchunk;
   FastDiv dWo, dHo, dTo, dKW, dKH, dCin;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
   static_assert(NT >= 1 && MT >= 1, "tile");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int* const ytab = reinterpret_cast<int*>(lds + YTAB);  // [2][64]: element offset of a position's dy row, -1 = none
-  int* const xtab = reinterpret_cast<int*>(lds + XTAB);  // [2][64][kMaxTaps]: ... of its x row under every tap, -1 = padding
+  int* const xtab = reinterpret_cast<int*>(lds + XTAB);  // [2][64][tapcap]: ... of its x row under every tap, -1 = padding
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
       const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
       const int ti = to * a.st - a.pt + dt, hi = ho * a.sh - a.ph + dh, wi = wo * a.sw - a.pw + dw_;
       const bool in = ok && (unsigned)ti < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      xtab[(buf * 64 + p) * kMaxTaps + tap] = in ? (((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx : -1;
+      xtab[(buf * 64 + p) * a.tapcap + tap] = in ? (((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx : -1;
     }
   };
   float4 rq[RQ], sq[SQ];
@@ -152,12 +158,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
     for (int q = 0; q < RQ; ++q) {
       const int idx = q * 256 + tid, p = idx >> 5;
       if constexpr (SWAP) rrow[q] = ytab[buf * 64 + p];
-      else rrow[q] = xtab[(buf * 64 + p) * kMaxTaps + (xtap[q] < 0 ? 0 : xtap[q])];
+      else rrow[q] = xtab[(buf * 64 + p) * a.tapcap + (xtap[q] < 0 ? 0 : xtap[q])];
     }
 #pragma unroll
     for (int q = 0; q < SQ; ++q) {
       const int idx = q * 256 + tid, p = idx / (BN / 4);
-      if constexpr (SWAP) srow[q] = xtab[(buf * 64 + p) * kMaxTaps + (xtap[q] < 0 ? 0 : xtap[q])];
+      if constexpr (SWAP) srow[q] = xtab[(buf * 64 + p) * a.tapcap + (xtap[q] < 0 ? 0 : xtap[q])];
       else srow[q] = ytab[buf * 64 + p];
     }
     rmask = smask = 0u;
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = s0 + wn * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.E + e, acc[i][j][r]);
+          if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.ldw + e, acc[i][j][r]);
         }
       }
   } else {
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
     for (int idx = tid; idx < BM * BN; idx += 256) {
       const int col = idx / BN, el = idx % BN;
       const int co = r0 + col, e = s0 + el;
-      if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.E + e, stage[col * ES + el]);
+      if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.ldw + e, stage[col * ES + el]);
     }
   }
   (void)y0;
@@ -316,13 +322,15 @@ int launch(WgArgs& a, int s_count, hipStream_t st) {
   if (chunks < 1) chunks = 1;
   a.slabs_per_chunk = (a.nslab + chunks - 1) / chunks;
   a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
-  constexpr int lds_bytes = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTaps * 4;
-  static_assert(128 * (BN + 1) * 4 <= lds_bytes, "the swapped epilogue stages its tile over the operand planes (and tables)");
-  static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
+  constexpr int lds_small = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTaps * 4;
+  constexpr int lds_big = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTapsBig * 4;
+  static_assert(128 * (BN + 1) * 4 <= lds_small, "the swapped epilogue stages its tile over the operand planes (and tables)");
+  static_assert(lds_small <= 80 * 1024, "two workgroups per CU");
+  const int lds_bytes = a.tapcap > kMaxTaps ? lds_big : lds_small;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<BN, SWAP>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
   if (e != hipSuccess) {
-    avt::set_error("avt_conv3d_wgrad_x3_f32: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    avt::set_error("avt_conv3d_wgrad_x3_f32: hipFuncSetAttribute(%d B LDS): %s", lds_big, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
   const int64_t grid = (int64_t)tiles * a.nchunk;
@@ -341,19 +349,23 @@ int dispatch(WgArgs& a, int r_count, int s_count, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
-                                       int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldx, int ldy,
-                                       void* stream) {
+// The general entry: explicit output extent (to, ho, wo; 0 = the symmetric-padding formula), any pt / ph / pw (a slice of a
+// longer filter is the same convolution with a shifted padding), dW rows ldw elements apart, zeroed here or by the caller.
+extern "C" int avt_conv3d_wgrad_x3_sub_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
+                                           int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo,
+                                           int ldx, int ldy, int ldw, int zero_dw, void* stream) {
   AVT_REQUIRE(dy && x && dw, "avt_conv3d_wgrad_x3_f32: NULL pointer");
-  AVT_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 8 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= cin && ldy >= cout,
-              "avt_conv3d_wgrad_x3_f32: channel counts in multiples of 8, row strides in multiples of 4 covering them");
-  AVT_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && kt * kh * kw <= kMaxTaps && st >= 1 && sh >= 1 && sw >= 1,
-              "avt_conv3d_wgrad_x3_f32: 1..%d kernel taps, strides >= 1", kMaxTaps);
+  AVT_REQUIRE(cin > 0 && cin % 4 == 0 && cout > 0 && cout % 8 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= cin && ldy >= cout,
+              "avt_conv3d_wgrad_x3_f32: input channels in multiples of 4, output channels of 8, row strides in multiples of 4 covering them");
+  AVT_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && kt * kh * kw <= kMaxTapsBig && st >= 1 && sh >= 1 && sw >= 1,
+              "avt_conv3d_wgrad_x3_f32: 1..%d kernel taps, strides >= 1", kMaxTapsBig);
   AVT_REQUIRE(avt::aligned16(dy) && avt::aligned16(x) && avt::aligned16(dw), "avt_conv3d_wgrad_x3_f32: pointers must be 16-byte aligned");
   WgArgs a = {};
   a.dy = dy; a.x = x; a.dw = dw;
   a.B = batch; a.T = t; a.H = h; a.W = w;
-  a.To = (t + 2 * pt - kt) / st + 1; a.Ho = (h + 2 * ph - kh) / sh + 1; a.Wo = (w + 2 * pw - kw) / sw + 1;
+  a.To = to > 0 ? to : (t + 2 * pt - kt) / st + 1;
+  a.Ho = ho > 0 ? ho : (h + 2 * ph - kh) / sh + 1;
+  a.Wo = wo > 0 ? wo : (w + 2 * pw - kw) / sw + 1;
   AVT_REQUIRE(batch > 0 && a.To > 0 && a.Ho > 0 && a.Wo > 0, "avt_conv3d_wgrad_x3_f32: empty output");
   const int64_t M = (int64_t)batch * a.To * a.Ho * a.Wo;
   AVT_REQUIRE(M < (1ll << 31) - 64 && M * ldy < (1ll << 31) && (int64_t)batch * t * h * w * ldx < (1ll << 31),
@@ -361,16 +373,31 @@ extern "C" int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* d
   a.KT = kt; a.KH = kh; a.KW = kw; a.st = st; a.sh = sh; a.sw = sw; a.pt = pt; a.ph = ph; a.pw = pw;
   a.Cin = cin; a.Cout = cout; a.ldx = ldx; a.ldy = ldy; a.M = (int)M; a.taps = kt * kh * kw;
   a.E = a.taps * cin;
+  a.tapcap = a.taps <= kMaxTaps ? kMaxTaps : kMaxTapsBig;
+  a.ldw = ldw > 0 ? ldw : a.E;
+  AVT_REQUIRE(a.ldw >= a.E, "avt_conv3d_wgrad_x3_f32: ldw (%d) < taps * cin (%d)", a.ldw, a.E);
   a.dCin = make_fastdiv((uint32_t)cin);
   a.nslab = (int)((M + 63) / 64);
   a.dWo = make_fastdiv((uint32_t)a.Wo); a.dHo = make_fastdiv((uint32_t)a.Ho); a.dTo = make_fastdiv((uint32_t)a.To);
   a.dKW = make_fastdiv((uint32_t)kw); a.dKH = make_fastdiv((uint32_t)kh);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cout * a.taps * cin, s) != hipSuccess) {
-    avt::set_error("avt_conv3d_wgrad_x3_f32: hipMemsetAsync failed");
-    return AVT_ERR_LAUNCH;
+  if (zero_dw) {
+    AVT_REQUIRE(a.ldw == a.E, "avt_conv3d_wgrad_x3_f32: a slice of a longer dW is zeroed by the caller (zero_dw = 0)");
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cout * a.E, s) != hipSuccess) {
+      avt::set_error("avt_conv3d_wgrad_x3_f32: hipMemsetAsync failed");
+      return AVT_ERR_LAUNCH;
+    }
   }
   // the longer axis — x's (tap, ci) or dy's co — takes the 128-wide side of the tile
   if (cout > a.E) return dispatch<true>(a, cout, a.E, s);
   return dispatch<false>(a, a.E, cout, s);
+}
+
+extern "C" int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
+                                       int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldx, int ldy,
+                                       void* stream) {
+  AVT_REQUIRE(cin % 8 == 0 && kt * kh * kw <= kMaxTaps, "avt_conv3d_wgrad_x3_f32: channel counts in multiples of 8, at most %d taps "
+              "(avt_conv3d_wgrad_x3_sub_f32 takes 4-channel inputs and [1,7,7] filters)", kMaxTaps);
+  return avt_conv3d_wgrad_x3_sub_f32(dy, x, dw, batch, t, h, w, cin, cout, kt, kh, kw, st, sh, sw, pt, ph, pw, 0, 0, 0, ldx, ldy, 0, 1,
+                                     stream);
 }

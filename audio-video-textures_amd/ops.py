@@ -347,6 +347,18 @@ def conv3d_wgrad_x3_f32(dy, x, dw, dims, cin, cout, kernel, stride, pad, ldx, ld
                                                   int(ldx), int(ldy), _stream()), "avt_conv3d_wgrad_x3_f32")
 
 
+def conv3d_wgrad_x3_sub_f32(dy, x, dw, dims, cin, cout, kernel, stride, pad, out_dims, ldx, ldy, ldw, zero_dw):
+    """The general weight-gradient entry (4-channel inputs, up to 49 taps, explicit output extent, any padding offset, dW a
+    column slice of a longer filter): the SlowFast stems; see include/avt.h.  dy / x / dw are device tensors (dw may be a view)."""
+    b, t, h, w = dims
+    _dev(dy, "dy", torch.float32)
+    _dev(x, "x", torch.float32)
+    _lib.check(_lib.lib().avt_conv3d_wgrad_x3_sub_f32(_p(dy), _p(x), C.c_void_p(dw.data_ptr()), int(b), int(t), int(h), int(w),
+                                                      int(cin), int(cout), *[int(k) for k in kernel], *[int(v) for v in stride],
+                                                      *[int(v) for v in pad], *[int(v) for v in out_dims], int(ldx), int(ldy),
+                                                      int(ldw), int(bool(zero_dw)), _stream()), "avt_conv3d_wgrad_x3_sub_f32")
+
+
 def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True):
     """stem_conv on plane pairs (contract-grade mode); wt_hi / wt_lo = fused_slowfast.stem_lds_image of each weight plane."""
     _dev(wt_hi, "wt_hi", torch.bfloat16)

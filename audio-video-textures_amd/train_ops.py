@@ -213,13 +213,14 @@ class _ConvX3(torch.autograd.Function):
         from . import ops
         cout, cin = weight.shape[0], weight.shape[1]
         kernel = tuple(weight.shape[2:])
-        ctx.save_for_backward(x, weight)
         ctx.conf = (stride, padding, kernel, cin, cout)
         xin = x
         if cin % 8:  # stem: [B, 3, T, H, W] -> 8 channels-last channels, the last 5 zero (weights padded to match)
             xin = torch.empty((x.shape[0], 8) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device, memory_format=torch.channels_last_3d)
             xin[:, :cin] = x
             xin[:, cin:] = 0
+        # (the stems keep the padded channels-last copy: their weight gradient reads it 4 channels at a time)
+        ctx.save_for_backward(xin if (cin % 8 and _STEM_WGRAD_X3) else x, weight)
         CALLS["conv_fwd_x3"] += 1
         return _conv_x3_rows(xin, _weight_planes(weight, False), ops.X3_F16, xin.shape[1], cout, kernel, stride, padding)
 
@@ -244,7 +245,23 @@ def _conv_backward(ctx, dy, dalias):
             CALLS["wgrad_x3"] += 1
             ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1),
                                     (x.shape[0], x.shape[2], x.shape[3], x.shape[4]), cin, cout, kernel, stride, padding, cin, cout)
-        else:  # the stems (3 input channels, 49 / 245 taps): MIOpen
+        elif (_WGRAD_X3 and _STEM_WGRAD_X3 and cin == 3 and x.shape[1] == 8 and kernel[1] * kernel[2] <= 49 and
+              max(x.numel(), dy.numel()) < (1 << 31) - 64):
+            # the stems: 3 input channels travel as 4 of the forward's 8-channel padded clip; a [kt,7,7] filter is kt slices of
+            # 49 taps, each a weight-gradient problem of its own with the temporal padding shifted by its frame tap
+            kt, kh, kw = kernel
+            acc = torch.zeros((cout, kt, kh * kw, 4), dtype=torch.float32, device=dy.device)
+            xr, dyr = x.permute(0, 2, 3, 4, 1), dy.permute(0, 2, 3, 4, 1)
+            dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
+            for dt in range(kt):
+                ops.conv3d_wgrad_x3_sub_f32(dyr, xr, acc[:, dt], dims, 4, cout, (1, kh, kw), stride, (padding[0] - dt, padding[1], padding[2]),
+                                            (dy.shape[2], dy.shape[3], dy.shape[4]), 8, cout, kt * kh * kw * 4, False)
+            CALLS["wgrad_stem_x3"] += 1
+            dw = torch.empty_like(weight)
+            dw.copy_(acc.view(cout, kt, kh, kw, 4)[..., :3].permute(0, 4, 1, 2, 3))
+        else:  # (stems when AVT_TRAIN_STEM_WGRAD_X3=0, filters of more than 28 taps): MIOpen
+            if x.shape[1] != weight.shape[1]:  # the padded copy was saved: MIOpen wants the 3-channel clip
+                x = x[:, : weight.shape[1]].contiguous(memory_format=torch.channels_last_3d)
             CALLS["miopen_wgrad"] += 1
             dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
                                                      [False, True, False])[1]

@@ -441,6 +441,14 @@ int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_l
 int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
                             int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldx, int ldy,
                             void* stream);
+/* The general form of avt_conv3d_wgrad_x3_f32: input channels in multiples of 4 (the SlowFast stems' 3 channels travel as 4:
+ * ldx may be wider than cin), up to 49 taps ([1,7,7]), an explicit output extent (to, ho, wo; 0 = the symmetric-padding
+ * formula) and any pt / ph / pw — so one frame-tap slice of a longer filter (the fast stem's [5,7,7] = five [1,7,7] slices,
+ * pt = pad - dt) is a call of its own writing into its columns of dW (rows ldw elements apart; 0 = taps * cin); zero_dw: dW
+ * is zeroed here (whole-filter calls) or was by the caller (slices).  Replaces the stems' MIOpen bwd_weight (train.py:139-141). */
+int avt_conv3d_wgrad_x3_sub_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
+                                int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo,
+                                int ldx, int ldy, int ldw, int zero_dw, void* stream);
 
 /* SuperSloMo interpolation at the jumps of the stitched video (contrastive_video_textures/interpolate.py:75-147, called from
  * validate.py:588-611): the passes around the two UNets, whose convolutions are avt_conv3d_igemm_x3 with relu = 2

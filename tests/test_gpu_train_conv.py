@@ -78,7 +78,8 @@ def test_falls_back_outside_its_domain():
 @pytest.mark.parametrize("kt", [1, 5])
 def test_stem_runs_on_zero_padded_channels(kt):
     """The stems (3 input channels, models/models.py:565-584's SlowFast): forward on the kernel over a clip padded to 8
-    channels, weight gradient through MIOpen on the original clip."""
+    channels; weight gradient on csrc/wgrad_x3.hip too — 4 of those channels per tap, the [kt,7,7] filter as kt slices of 49
+    taps — and, with AVT_TRAIN_STEM_WGRAD_X3 off, through MIOpen on the original clip."""
     from avtex import train_ops
     torch.manual_seed(kt)
     stem = nn.Conv3d(3, 64 if kt == 1 else 8, (kt, 7, 7), stride=(1, 2, 2), padding=(kt // 2, 3, 3), bias=False).to(DEV)
@@ -93,7 +94,18 @@ def test_stem_runs_on_zero_padded_channels(kt):
     ye = stem(x)
     ye.backward(gy)
     rel = lambda u, v: float((u - v).norm()) / float(v.norm())
-    assert rel(y.detach(), ye.detach()) < 2e-6 and rel(dwa, stem.weight.grad) < 1e-5   # (the stems' wgrad is MIOpen's)
+    # forward: fp16 planes (2^-22); weight gradient: bf16 planes (2^-16 per product, random signs: ~1e-5 of the norm)
+    assert rel(y.detach(), ye.detach()) < 2e-6 and rel(dwa, stem.weight.grad) < 1e-4, rel(dwa, stem.weight.grad)
+    before = train_ops.CALLS["wgrad_stem_x3"]
+    keep, train_ops._STEM_WGRAD_X3 = train_ops._STEM_WGRAD_X3, 0
+    try:  # the MIOpen route for the stems' weight gradient stays selectable
+        want = stem.weight.grad.clone()
+        stem.zero_grad(set_to_none=True)
+        y2 = train_ops.conv3d(x, stem)
+        y2.backward(gy)
+        assert rel(stem.weight.grad, want) < 1e-5 and train_ops.CALLS["wgrad_stem_x3"] == before
+    finally:
+        train_ops._STEM_WGRAD_X3 = keep
 
 
 @pytest.mark.parametrize("cin,cout,kernel,stride,pad,dims", [
