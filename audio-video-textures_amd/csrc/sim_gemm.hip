@@ -248,6 +248,126 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(Args a) {
     }
 }
 
+// ---- f32 mode, four workgroups per CU -------------------------------------------------------------------------------------
+// The 128 x 128 f32 tile above needs 160 registers (3 waves per SIMD): 4096 x 4096 is 1024 tiles over 768 resident slots =
+// one round and a third, and the launch pays two rounds (0.62-0.69 of the f32 peak against 0.82 at 16384^2, where the rounds
+// are many).  This form halves the K-step (64-byte rows: 16 staging registers instead of 32), fetches with buffer loads
+// (32-bit offsets; the hardware range check returns the zeros of rows beyond n and of the k tail: no 64-bit address
+// arithmetic, no bounds branches) and fits 128 registers: four workgroups per CU, 1024 slots, ONE round at 4096^2 and two at
+// config 4's 2048 x 16384 shard.  The k order of every output element — groups of 8 ascending, 0,4,1,5,2,6,3,7 inside a
+// group — is the one of the tile above, so the matrix stays bit-identical to the oracle.
+constexpr int LSTR2 = 80;             // 64 data bytes + 16 pad: ds_read_b128 of 16 consecutive rows touches 64 banks once
+constexpr int PLANE2 = 128 * LSTR2;
+constexpr unsigned kOobS = 0xFFFFFFF0u;
+
+__global__ __launch_bounds__(256, 4) void sim_f32_v2_kernel(Args a, unsigned q_bytes, unsigned t_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int bid = blockIdx.x;
+  const int qd = a.nblk / 8, rm = a.nblk % 8, x = bid % 8;
+  const int swz = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + bid / 8;
+  const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
+  const int row0 = tm * 128, col0 = tn * 128;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.q[0], 0, q_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)a.t[0], 0, t_bytes, 0x00020000);
+  // this thread's two chunks of each operand: rows r, r + 64 of the tile, 16-byte chunk c4 of the 64-byte row
+  const int r = tid >> 2, c4 = tid & 3;
+  unsigned qo[2], to_[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int64_t qr = (int64_t)row0 + r + 64 * u, tr = (int64_t)col0 + r + 64 * u;
+    qo[u] = qr < a.nq ? (unsigned)((qr * a.d + c4 * 4) * 4) : kOobS;
+    to_[u] = tr < a.nt ? (unsigned)((tr * a.d + c4 * 4) * 4) : kOobS;
+  }
+  const int kc = c4 * 4;  // first k of this thread's chunk inside a K-step
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 ra[2], rb[2];
+  auto gpiece = [&](int kt, int p) {
+    const int k0 = kt * 16;
+    const bool kin = k0 + kc < a.d;  // d % 4 == 0: the chunk is all in or all out
+    const int u = p & 1;
+    if (p < 2) ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int)((kin && qo[u] != kOobS) ? qo[u] + (unsigned)k0 * 4u : kOobS), 0, 0);
+    else rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rt, (int)((kin && to_[u] != kOobS) ? to_[u] + (unsigned)k0 * 4u : kOobS), 0, 0);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      *reinterpret_cast<i32x4*>(lds + (r + 64 * u) * LSTR2 + c4 * 16) = ra[u];
+      *reinterpret_cast<i32x4*>(lds + PLANE2 + (r + 64 * u) * LSTR2 + c4 * 16) = rb[u];
+    }
+  };
+  const int arow = (wr * 64 + lr) * LSTR2 + lh * 16;
+  const int brow = PLANE2 + (wc * 64 + lr) * LSTR2 + lh * 16;
+  const int nk = (a.d + 15) / 16;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) gpiece(0, p);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float4 fa[2], fb[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const float4*>(lds + arow + m * 32 * LSTR2 + ks * 32);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) fb[n] = *reinterpret_cast<const float4*>(lds + brow + n * 32 * LSTR2 + ks * 32);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const float av = s_ == 0 ? fa[m].x : s_ == 1 ? fa[m].y : s_ == 2 ? fa[m].z : fa[m].w;
+            const float bv = s_ == 0 ? fb[n].x : s_ == 1 ? fb[n].y : s_ == 2 ? fb[n].z : fb[n].w;
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
+          }
+      if (more && ks == 0) {  // the next slab's four loads ride behind the first k-slice's MFMAs
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gpiece(kt + 1, p);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int64_t col = (int64_t)col0 + wc * 64 + n * 32 + lr;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int64_t row = (int64_t)row0 + wr * 64 + m * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+        if (row < a.nq && col < a.nt) a.out[row * a.ldo + col] = __fdiv_rn(acc[m][n][rr], a.temp);
+      }
+    }
+}
+
+int launch_f32_v2(Args& a, hipStream_t st) {
+  const int64_t tiles_m = (a.nq + 127) / 128, tiles_n = (a.nt + 127) / 128;
+  AVT_REQUIRE(tiles_m * tiles_n < (1ll << 31), "avt_sim_gemm_nt: grid too large");
+  a.tiles_n = (int)tiles_n;
+  a.nblk = (int)(tiles_m * tiles_n);
+  hipLaunchKernelGGL(sim_f32_v2_kernel, dim3((unsigned)a.nblk), dim3(256), 2 * PLANE2, st, a, (unsigned)(a.nq * a.d * 4),
+                     (unsigned)(a.nt * a.d * 4));
+  return avt::check_launch("avt_sim_gemm_nt");
+}
+
 template <int MODE, int TN>
 int launch(Args& a, bool aligned, hipStream_t st) {
   const int64_t tiles_m = (a.nq + BM - 1) / BM, tiles_n = (a.nt + TN - 1) / TN;
@@ -300,6 +420,8 @@ extern "C" int avt_sim_gemm_nt(const void* q, const void* q_lo, const void* t, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (precision) {
     case AVT_SIM_F32: {
+      static const int v2 = avt::env_int_flag("AVT_SIM_F32_V2", 1);  // 0: the 3-workgroups-per-CU tile for every shape
+      if (v2 && aligned && nq * (int64_t)d * 4 < (1ll << 32) - 64 && nt * (int64_t)d * 4 < (1ll << 32) - 64) return launch_f32_v2(a, st);
       static const int tn = avt::env_int_flag("AVT_SIM_F32_TN", 128);
       return tn == 128 ? launch<AVT_SIM_F32, 128>(a, aligned, st) : launch<AVT_SIM_F32, 64>(a, aligned, st);
     }

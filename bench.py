@@ -383,6 +383,7 @@ def train_bench(args, rank, world, dev):
     def step():
         opt.zero_grad(set_to_none=True)
         idxs = rng.randint(0, len(ds), size=items)
+        step_loss = torch.zeros((), device=dev)
         for k, i in enumerate(idxs):
             q, t, _, _ = bat.batch(torch.tensor([int(i)]))
             if channels_last:
@@ -393,8 +394,9 @@ def train_bench(args, rank, world, dev):
                     out = net(q, t)
                 loss = crit(out.float(), torch.zeros(1, dtype=torch.long, device=dev)) / items
                 loss.backward()
-            losses.append(float(loss.detach()) * items)
+            step_loss += loss.detach()
         opt.step()
+        losses.append(float(step_loss))  # ONE host read per step, as the reference's loop has (train.py:118 loss.item() per batch)
 
     def sync_all():
         if torch.distributed.is_initialized():
