@@ -99,7 +99,9 @@ class TextureEngine:
         self._rows = {"q": None, "t": None}
         self._nrows = {"q": 0, "t": 0}
         self.encoded = 0  # windows pushed through an encoder (both encoders counted)
-        self.n_streams = 2
+        # q / t encoders on two HIP streams: +8-13 % for the bf16 path; the contract-grade kernels (one workgroup per CU on their
+        # XL / fused-block launches) fill the chip from one stream and measured 1.4 % slower with two
+        self.n_streams = 1 if getattr(q_enc, "x3", None) is not None else 2
         self._streams = None
         self._pending, self._inflight = [], []  # run_encoders(join=False): outputs / per-batch events not yet joined
 
