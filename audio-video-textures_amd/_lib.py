@@ -83,6 +83,8 @@ SIGNATURES = {
     "avt_maxpool_hw2s2_ndhwc_x3": [_vp] * 4 + [C.c_int] * 7 + [_vp],
     "avt_mean_positions_x3": [_vp, _vp] + [C.c_int] * 4 + [_vp, C.c_int, C.c_int, _vp],
     "avt_conv3d_igemm_x3_xl_picked": [C.c_int] * 3,
+    "avt_conv33_x3_supported": [C.c_int] * 2,
+    "avt_conv33_x3": [_vp] * 6 + [C.c_int] * 8 + [_vp],
     "avt_bneck_x3_supported": [C.c_int] * 3,
     "avt_bneck_x3": [_vp] * 6 + [C.c_int] * 8 + [_vp],
     "avt_conv3d_igemm_wfrag_supported": [C.c_int] * 5,

@@ -34,6 +34,7 @@ _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "0"))   # frames walked per
 #                                                              16 at 56 columns (more workgroups), the whole clip (32) below
 _FUSE_BLOCK_X3 = int(os.environ.get("AVT_FUSE_BLOCK_X3", "1"))  # contract-grade mode: fast-pathway bottlenecks as one kernel
 _FUSE_TCHUNK_X3 = int(os.environ.get("AVT_FUSE_TCHUNK_X3", "0"))  # frames walked per workgroup; 0 = by width
+_C33_X3 = int(os.environ.get("AVT_C33_X3", "1"))              # contract-grade mode: slow res2 b conv on the direct-operand kernel
 _PW_X3 = int(os.environ.get("AVT_PW_X3", "1"))               # contract-grade mode: pointwise layers on the streaming kernel
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
 # contract-grade mode: max-pool fused into the stem kernel (1 = the slow stem, 2 = both).  OFF by default: measured 1.74 ms for the
@@ -507,6 +508,35 @@ def pack_c33(wb, device):
     return wb9[row, ch, tap].to(torch.bfloat16).contiguous().to(device)
 
 
+def pack_c33_x3(wb, bias, x3, device):
+    """BN-folded [64,64,1,3,3] weights + bias -> csrc/conv33_x3.hip's (wfrag, coef) (include/avt.h): 32 x 32 x 16 MFMA fragments
+    of both planes, output rows permuted so that a lane of the accumulator ends with runs of 8 consecutive channels; fp16
+    planes: every output channel scaled by a power of two into [2^9, 2^10), undone by coef's scale."""
+    wb = wb.detach().float().cpu()
+    co, ci = wb.shape[0], wb.shape[1]
+    w9 = wb[:, :, 0].reshape(co, ci, 9)  # [out, in, tap]
+    if x3 == ops.X3_F16:
+        mx = w9.reshape(co, -1).abs().amax(dim=1).clamp_min(1e-30)
+        sc = torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
+    else:
+        sc = torch.ones(co)
+    w9 = w9 * sc.view(-1, 1, 1)
+    lane = torch.arange(64)
+    rho, kh = lane & 31, lane >> 5
+    h = (rho >> 2) & 1
+    r = (rho & 3) + 4 * (rho >> 3)
+    shape = (9, 4, 2, 64, 8)  # [tap][k-slice][n-tile][lane][e]
+    n = torch.arange(2).view(1, 1, -1, 1, 1)
+    ch = (32 * n + ((2 * (r >> 3) + h) * 8 + (r & 7)).view(1, 1, 1, -1, 1)).expand(shape)
+    kk = (torch.arange(4).view(1, -1, 1, 1, 1) * 16 + (kh * 8).view(1, 1, 1, -1, 1) + torch.arange(8).view(1, 1, 1, 1, -1)).expand(shape)
+    tap = torch.arange(9).view(-1, 1, 1, 1, 1).expand(shape)
+    frags = w9[ch, kk, tap]  # fp32 [9][4][2][64][8]
+    hi, lo = split_planes(frags, x3)
+    wfrag = torch.stack([hi, lo], 3).contiguous().to(device)  # [9][4][2][2 planes][64][8]
+    coef = torch.cat([1.0 / sc, bias.detach().float().cpu()]).float().contiguous().to(device)
+    return wfrag, coef
+
+
 def pack_pw(w, device):
     """BN-folded pointwise weights [N, K(,1,1,1)] -> csrc/pw_chain.hip's fragments [N/16][ceil(K/32)][64][8]: output
     rows permuted so a lane ends with 8 consecutive channels (include/avt.h), K zero-padded to whole 32-wide k-steps."""
@@ -732,6 +762,11 @@ class _BlockX3:
         # first block of a stage with a stride-1 1x1x1 shortcut conv and a pointwise a (slow res2): c and the shortcut are ONE
         # pointwise GEMM over K = [x | b-output] when b writes its output into spare columns behind x's channels — no shortcut
         # launch, no shortcut tensor written and read back as the residual (self.extra = columns the caller leaves free)
+        # slow res2: b ([1,3,3] 64 -> 64, stride 1) with the activations as direct MFMA operands (csrc/conv33_x3.hip)
+        self.c33 = None
+        if (_C33_X3 and self.fused is None and self.b.kernel == (1, 3, 3) and self.b.stride == (1, 1, 1) and
+                self.b._folded is not None and ops.conv33_x3_supported(self.b.cin, self.b.cout)):
+            self.c33 = pack_c33_x3(self.b._folded[0], self.b._folded[1], x3, device)
         self.ccat, self.extra = None, 0
         if (_FUSE_KCAT and self.b1 is not None and self.fused is None and self.a.kernel == (1, 1, 1) and
                 self.c.kernel == (1, 1, 1) and self.b1.kernel == (1, 1, 1) and self.a.stride == (1, 1, 1) and
@@ -762,10 +797,28 @@ class _BlockX3:
                 PROFILER("bneck_x3_kernel", launch, fl, 4.0 * (m * x.C + mo * self.c.cout))
             return y
         if self.ccat is not None and x.c0 == 0 and x.lo is not None and x.ld >= x.C + self.extra and x.C == self.a.cin:
-            self.b(self.a(x), out=Act(x.buf, x.dims, x.C, self.extra, lo=x.lo))  # b's output lands behind x in the same rows
+            self._b(self.a(x), out=Act(x.buf, x.dims, x.C, self.extra, lo=x.lo))  # b's output lands behind x in the same rows
             return self.ccat(Act(x.buf, x.dims, 0, x.C + self.extra, lo=x.lo), out=out)
         sc = self.b1(x) if self.b1 is not None else x
-        return self.c(self.b(self.a(x)), out=out, res=sc, relu=True)
+        return self.c(self._b(self.a(x)), out=out, res=sc, relu=True)
+
+    def _b(self, m, out=None):
+        """The block's b conv: the direct-operand kernel for 64 -> 64 [1,3,3], else the implicit GEMM."""
+        if self.c33 is None:
+            return self.b(m, out=out)
+        b, t, h, w = m.dims
+        if out is None:
+            out = new_act(b * t * h * w, self.b.cout, m.dims, self.dev, True)
+
+        def launch():
+            ops.conv33_x3(m.ptrs, self.c33, out.ptrs, b, t, h, w, m.ld, out.ld, self.x3, relu=True)
+
+        if PROFILER is None:
+            launch()
+        else:
+            rows = b * t * h * w
+            PROFILER("conv33_x3_kernel", launch, rows * self.b.alg_flops_per_row, 4.0 * rows * 2 * self.b.cout)
+        return out
 
 
 PRECISIONS = {"bf16": None, "bf16x3": ops.X3_BF16, "f16x3": ops.X3_F16}

@@ -462,6 +462,21 @@ def conv3d_igemm_x3_xl_picked(cout, k, m):
     return bool(_lib.lib().avt_conv3d_igemm_x3_xl_picked(int(cout), int(k), int(m)))
 
 
+def conv33_x3_supported(cin, cout):
+    return bool(_lib.lib().avt_conv33_x3_supported(int(cin), int(cout)))
+
+
+def conv33_x3(x_ptrs, packed, out_ptrs, batch, t, h, w, ldi, ldo, plane_dtype, relu=True):
+    """[1,3,3] 64 -> 64 stride-1 conv + BN + ReLU on plane pairs, activations as direct MFMA operands (csrc/conv33_x3.hip);
+    packed = fused_slowfast.pack_c33_x3(...) = (wfrag, coef)."""
+    wfrag, coef = packed
+    _dev(wfrag, "wfrag", torch.bfloat16)
+    _dev(coef, "coef", torch.float32)
+    _lib.check(_lib.lib().avt_conv33_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(wfrag), _p(coef), C.c_void_p(out_ptrs[0]),
+                                        C.c_void_p(out_ptrs[1]), int(batch), int(t), int(h), int(w), int(ldi), int(ldo),
+                                        int(bool(relu)), int(plane_dtype), _stream()), "avt_conv33_x3")
+
+
 def bneck_x3_supported(cin, c, w):
     return bool(_lib.lib().avt_bneck_x3_supported(int(cin), int(c), int(w)))
 

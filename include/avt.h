@@ -338,6 +338,18 @@ int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi,
  * k >= 256, m >= 16384.  Same arithmetic, same results to the last bit as the other tiles is NOT promised (fp32 accumulation
  * order over K differs in the 32-wide steps); both are held to the fp32 reference by the same tolerance. */
 int avt_conv3d_igemm_x3_xl_picked(int cout, int k, int m);
+/* The [1,3,3] 64 -> 64 stride-1 convolution (+ BN + ReLU) of the slow pathway's res2 bottlenecks on plane pairs
+ * (csrc/conv33_x3.hip; the contract-grade form of avt_conv33_c64_bf16): activations are MFMA operands as loaded from global
+ * memory (no LDS staging, zero padding by out-of-range buffer offsets), the weights live in LDS as fragments.
+ * x [batch*t*h*w, ldi], out [., ldo] plane pairs (channel slices of wider rows allowed).  wfrag [9 taps][4 k-slices of 16]
+ * [2 n-tiles][2 planes: hi, lo][64 lanes][8] 16-bit: lane l of a fragment holds W[channel(l & 31)][tap][16 k + 8 (l >> 5) + e]
+ * with channel(rho) = 32 n + (2 (r >> 3) + h) * 8 + (r & 7), h = (rho >> 2) & 1, r = (rho & 3) + 4 (rho >> 3) (so that a lane of
+ * the 32 x 32 accumulator ends with runs of 8 consecutive channels); coef fp32 [scale 64 | bias 64] by output channel (scale =
+ * the power of two that undoes the fp16 planes' weight scaling, 1 for bf16 planes). */
+int avt_conv33_x3_supported(int cin, int cout);
+int avt_conv33_x3(const void* x_hi, const void* x_lo, const void* wfrag, const float* coef, void* out_hi, void* out_lo,
+                  int batch, int t, int h, int w, int ldi, int ldo, int relu, int plane_dtype, void* stream);
+
 /* One bottleneck of the SlowFast FAST pathway in ONE kernel on plane pairs (csrc/bneck_x3.hip; the contract-grade form of
  * avt_bottleneck_fused_bf16 / avt_bottleneck_first_bf16 above — same blocks of the third-party SlowFast model,
  * models/models.py:335, 399):  out = relu(c(relu(b(relu(a(x))))) + x)  for cin == c (identity shortcut), or

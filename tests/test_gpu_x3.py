@@ -554,3 +554,46 @@ def test_validate_m2_default_path_runs_vggish_on_the_split_plane_kernels(avt, de
     frames = avt.validate(model, args, video_name="x", model_type=2, video=(video.numpy(), 10.0), audio=(wave, 16000))
     assert len(frames) >= 10
     assert isinstance(seen["a"], VGGishMFMA) and seen["a"].precision == "f16x3" and seen["q"].precision == "f16x3"
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("dims,ldi,ldo", [((2, 3, 9, 11), 64, 64), ((1, 2, 56, 56), 64, 144), ((1, 4, 7, 5), 80, 64)])
+def test_conv33_x3_direct_operand_kernel(avt, dev, mode, dims, ldi, ldo):
+    """csrc/conv33_x3.hip (slow res2's [1,3,3] 64 -> 64 + BN + ReLU, activations as MFMA operands straight from global memory,
+    zero padding by out-of-range offsets, persistent workgroups over 32-position tiles) against fp64 on PyTorch and the
+    general x3 tile: ragged tile counts, row / frame borders inside a tile, input and output as channel slices of wider rows."""
+    from avtex import ops
+    from avtex.fused_slowfast import Act, FusedConv, pack_c33_x3, split_planes
+
+    pd = X3[mode]
+    torch.manual_seed(dims[2] * 7 + ldi)
+    conv = nn.Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1), bias=False)
+    bn = nn.BatchNorm3d(64).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    b, t, h, w = dims
+    m = b * t * h * w
+    xw = torch.randn(m, ldi)
+    hi, lo = split_planes(xw, pd)
+    dt = torch.float16 if pd == 1 else torch.bfloat16
+    xq = (hi.view(dt).double() + lo.view(dt).double())[:, :64]
+    with torch.no_grad():
+        ref = F.relu(bn.double()(conv.double()(xq.view(b, t, h, w, 64).permute(0, 4, 1, 2, 3)))).permute(0, 2, 3, 4, 1).reshape(m, 64)
+    fc = FusedConv(conv.float(), bn.float(), True, dev, x3=pd)
+    packed = pack_c33_x3(fc._folded[0], fc._folded[1], pd, dev)
+    xa = Act(hi.to(dev), dims, 0, 64, lo=lo.to(dev))
+    ob = torch.full((m, ldo), 7.0)
+    oh, ol = split_planes(ob, pd)
+    out = Act(oh.to(dev), dims, ldo - 64, 64, lo=ol.to(dev))
+    ops.conv33_x3(xa.ptrs, packed, out.ptrs, b, t, h, w, ldi, ldo, pd, relu=True)
+    torch.cuda.synchronize()
+    got = out.float(pd).cpu().double()
+    gen = fc(xa).float(pd).cpu().double()
+    scale = ref.abs().max().item()
+    err, err_g = (got - ref).abs().max().item() / scale, (gen - ref).abs().max().item() / scale
+    print("conv33_x3 %s %s: direct %.2e, general tile %.2e of the output range from fp64" % (mode, dims, err, err_g))
+    assert err < TOL[mode] and err_g < TOL[mode]
+    if ldo > 64:  # the columns in front of the slice are untouched
+        whole = Act(out.buf, dims, 0, ldo, lo=out.lo).float(pd).cpu()
+        assert torch.equal(whole[:, : ldo - 64], torch.full((m, ldo - 64), 7.0))

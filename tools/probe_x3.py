@@ -96,6 +96,15 @@ def spy_sp(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, 
     return orig_sp(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, tgroup, ldo, plane_dtype)
 
 
+orig_c33 = ops.conv33_x3
+
+
+def spy_c33(x_ptrs, packed, out_ptrs, batch, t, h, w, ldi, ldo, plane_dtype, relu=True):
+    shapes.append("conv33 direct cin64 cout64 in(%d, %d, %d, %d) ldi %d ldo %d" % (batch, t, h, w, ldi, ldo))
+    return orig_c33(x_ptrs, packed, out_ptrs, batch, t, h, w, ldi, ldo, plane_dtype, relu)
+
+
+ops.conv33_x3 = spy_c33
 ops.stem_conv_pool_x3 = spy_sp
 ops.bneck_x3 = spy_bn
 ops.conv3d_igemm_x3 = spy
