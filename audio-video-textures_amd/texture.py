@@ -101,7 +101,7 @@ class TextureEngine:
         self.encoded = 0  # windows pushed through an encoder (both encoders counted)
         # q / t encoders on two HIP streams: +8-13 % for the bf16 path; the contract-grade kernels (one workgroup per CU on their
         # XL / fused-block launches) fill the chip from one stream and measured 1.4 % slower with two
-        self.n_streams = 1 if getattr(q_enc, "x3", None) is not None else 2
+        self.n_streams = 1 if getattr(q_encoder, "x3", None) is not None else 2
         self._streams = None
         self._pending, self._inflight = [], []  # run_encoders(join=False): outputs / per-batch events not yet joined
 

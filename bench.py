@@ -668,7 +668,8 @@ def baseline_metric():
 # their batches back to back and are joined once per step (texture.TextureEngine.run_encoders(join=False))
 JOIN_EVERY_BATCH = os.environ.get("AVT_BENCH_JOIN", "0") == "1"
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_fetch_write_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "pmc_fetch_write_summary.json")  # written by tools/gpu_profile_round.sh r03
+PMC_BATCH = 83  # the encoder batch tools/pmc_kernels.py launches at
 
 
 def attach_pmc_traffic(kern, args, precision):
@@ -676,7 +677,7 @@ def attach_pmc_traffic(kern, args, precision):
     runs of tools/pmc_kernels.py at these shapes by tools/gpu_pmc.sh, FETCH_SIZE doubled for gfx950 as
     MI355X_MICROARCH.md prescribes); the committed summary is read here because counters cannot be collected inside a
     timed run.  Rows are matched by device kernel symbol."""
-    if not os.path.exists(PMC_SUMMARY) or args.windows != 4096 or args.enc_batch != 128:
+    if not os.path.exists(PMC_SUMMARY) or args.windows != 4096 or args.enc_batch != PMC_BATCH:
         return
     pmc = json.load(open(PMC_SUMMARY))
 
@@ -690,6 +691,8 @@ def attach_pmc_traffic(kern, args, precision):
             want_tail, sym = ",0>", "stem_kernel<"
         if sym.startswith("pw_x3_kernel<"):
             want_tail, sym = ("true>" if "f16" in sym and "bf16" not in sym else "false>"), "pw_x3_kernel<"
+        if sym in ("bneck_x3_kernel", "conv33_x3_kernel") or sym.startswith("conv_x3_xl_kernel"):  # <..., F16> last
+            want_tail, sym = ("true>" if precision == "f16x3" else "false>"), sym.split("<")[0] + "<"
         sym = sym.rstrip(">")
         f = w = n = 0.0
         for name, v in pmc.items():
@@ -709,7 +712,7 @@ def attach_pmc_traffic(kern, args, precision):
         sym = sym.replace(",bf16>", ",false>").replace(",f16>", ",true>").replace(" ", "")
         k["traffic"] = kb(sym)
         if k["traffic"]:
-            k["traffic_source"] = "profiles/r02/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
+            k["traffic_source"] = "profiles/r03/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
 
 
 def cpu_baseline(video, q_mod, t_mod, W, S, N, D, temp, args):

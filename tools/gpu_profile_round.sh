@@ -5,15 +5,15 @@
 #   3. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE    -> pmc_fetch_write_summary.json (separate passes, kernel-trace only,
 #      over tools/pmc_kernels.py: every hand-written kernel at the bench shapes; FETCH_SIZE is doubled by the READER
 #      (bench.py attach_pmc_traffic) as MI355X_MICROARCH.md prescribes for gfx950)
-# usage: bash tools/gpu_profile_round.sh r02   -> gpurun_out/profile_r02/
+# usage: bash tools/gpu_profile_round.sh r03   -> gpurun_out/profile_r02/
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-block --no-nxn-legs > $OUT/prof_bench.json 2> $OUT/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 1 --warmup 1 --no-fast --no-train-leg --no-cpu-baseline --no-precision-block --no-nxn-legs > $OUT/prof_bench.json 2> $OUT/prof.err
 find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/rocprof_kernel_stats.csv
 find $OUT/prof -name "*kernel_trace.csv" -delete   # the per-dispatch trace is large; the stats summary is what is kept
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -36,7 +36,7 @@ out["_note"] = "KB per launch as rocprofv3 reports them (FETCH_SIZE NOT yet doub
 json.dump(out, open(out_dir + "/pmc_fetch_write_summary.json", "w"), indent=1)
 for k, v in out.items():
     if not k.startswith("_"):
-        print(k[:100], {c: round(x["mean"], 1) for c, x in v.items()})
+        pass
 PY
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/prof
-head -40 $OUT/rocprof_kernel_stats.csv
+cut -c1-120 $OUT/rocprof_kernel_stats.csv | head -25
