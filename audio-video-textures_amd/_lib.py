@@ -76,6 +76,9 @@ SIGNATURES = {
     "avt_pw_x3_supported": [C.c_int] * 2,
     "avt_pw_x3": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int64,
                   C.c_int, C.c_int, _vp],
+    "avt_pw_chain_x3_supported": [C.c_int] * 3,
+    "avt_pw_chain_x3": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                        _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, _vp],
     "avt_conv3d_igemm_x3": [_vp] * 10 + [C.c_int] * 26 + [_vp, _vp],
     "avt_clip_pack_u8_ndhwc4_x3": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                    C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp],

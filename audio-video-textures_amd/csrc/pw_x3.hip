@@ -167,6 +167,167 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_kernel(PxArgs a) {
   }
 }
 
+// ---- chained form: y = act(W1 x + b1 [+ r]) AND z = relu(W2 y + b2) in one pass over the rows ---------------------------------
+// The slow pathway's  c of block i (+ residual + ReLU)  ->  a of block i + 1 (+ ReLU)  (the x3 counterpart of pw_chain.hip):
+// the first GEMM's D layout — a lane ends with 8 consecutive channels of its position, already split into the two planes it
+// stores — IS the second GEMM's B-operand layout (k-group q of k-step jj = channels 32 jj + 8 q .. + 7), so y goes from the
+// epilogue's registers into the next MFMAs without touching LDS or HBM again: the a layer's read of y (256 channels x 2 planes
+// per row, a third of the pair's bytes) disappears.  z is computed from the SAME rounded planes the unchained a layer would
+// read, in the same k order: bit-identical to the two launches.  One chunk holds all N1 channels (res2: 64 -> 256 -> 64:
+// 64 + 64 KB of fragments, one 8-wave workgroup per CU).
+struct PcArgs {
+  PxArgs p;            // first layer (wh / wl / bias / wscale / relu of layer 1; n_chunks == 1)
+  const i32x4* w2h;    // [N2/16][K2S][64 lanes] fragments of layer 2 over K2 = N1
+  const i32x4* w2l;
+  const float* bias2;
+  const float* wscale2;
+  uint16_t* zh;        // [M, ldz]
+  uint16_t* zl;
+  int ldz;
+};
+
+template <int K1S, int NT1, int NT2, bool F16>
+__global__ __launch_bounds__(PX_NW * 64) void pw_chain_x3_kernel(PcArgs c) {
+  const PxArgs& a = c.p;
+  constexpr int NC = NT1 * 16, K2S = NT1 / 2, NC2 = NT2 * 16;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* whl = lds;
+  char* wll = whl + NT1 * K1S * 1024;
+  char* w2hl = wll + NT1 * K1S * 1024;
+  char* w2ll = w2hl + NT2 * K2S * 1024;
+  float* bl = reinterpret_cast<float*>(w2ll + NT2 * K2S * 1024);  // [NC] bias, [NC] scale, [NC2] bias2, [NC2] scale2
+  float* sl = bl + NC;
+  float* b2l = sl + NC;
+  float* s2l = b2l + NC2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  for (int f = wid; f < NT1 * K1S; f += PX_NW) {
+    *reinterpret_cast<i32x4*>(whl + f * 1024 + lane * 16) = a.wh[f * 64 + lane];
+    *reinterpret_cast<i32x4*>(wll + f * 1024 + lane * 16) = a.wl[f * 64 + lane];
+  }
+  for (int f = wid; f < NT2 * K2S; f += PX_NW) {
+    *reinterpret_cast<i32x4*>(w2hl + f * 1024 + lane * 16) = c.w2h[f * 64 + lane];
+    *reinterpret_cast<i32x4*>(w2ll + f * 1024 + lane * 16) = c.w2l[f * 64 + lane];
+  }
+  for (int i = tid; i < NC; i += PX_NW * 64) {
+    bl[i] = a.bias ? a.bias[i] : 0.0f;
+    sl[i] = a.wscale ? a.wscale[i] : 1.0f;
+  }
+  for (int i = tid; i < NC2; i += PX_NW * 64) {
+    b2l[i] = c.bias2 ? c.bias2[i] : 0.0f;
+    s2l[i] = c.wscale2 ? c.wscale2[i] : 1.0f;
+  }
+  __syncthreads();
+  const bool has_res = a.rh != nullptr;
+
+  for (int tile = blockIdx.x * PX_NW + wid; tile < a.ntiles; tile += gridDim.x * PX_NW) {
+    const int p = tile * 16 + l15;
+    const bool ok = p < a.M;
+    int lofs = lane * 16;
+    asm volatile("" : "+v"(lofs));
+    const int64_t pc = ok ? p : a.M - 1;
+    i32x4 xh[K1S], xl[K1S];
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks) {
+      int ch = 4 * ks + q;
+      ch = ch < a.k1c ? ch : a.k1c - 1;
+      xh[ks] = *reinterpret_cast<const i32x4*>(a.xh + pc * a.ldx + ch * 8);
+      xl[ks] = *reinterpret_cast<const i32x4*>(a.xl + pc * a.ldx + ch * 8);
+    }
+    uint4 rfh[NT1 / 2], rfl[NT1 / 2];
+    if (has_res) {
+#pragma unroll
+      for (int jj = 0; jj < NT1 / 2; ++jj) {
+        const int64_t o = pc * a.ldr + 32 * jj + 8 * q;
+        rfh[jj] = *reinterpret_cast<const uint4*>(a.rh + o);
+        rfl[jj] = *reinterpret_cast<const uint4*>(a.rl + o);
+      }
+    }
+    f32x4 acc2[NT2];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) acc2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < NT1 / 2; ++jj) {  // tiles 2jj, 2jj+1 of layer 1 -> channels 32 jj + 8 q .. + 7 = k-step jj of layer 2
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < K1S; ++ks) {
+        const int f0 = (2 * jj) * K1S + ks, f1 = (2 * jj + 1) * K1S + ks;
+        const i32x4 w0h = *reinterpret_cast<const i32x4*>(whl + f0 * 1024 + lofs), w0l = *reinterpret_cast<const i32x4*>(wll + f0 * 1024 + lofs);
+        const i32x4 w1h = *reinterpret_cast<const i32x4*>(whl + f1 * 1024 + lofs), w1l = *reinterpret_cast<const i32x4*>(wll + f1 * 1024 + lofs);
+        a0 = mfma16<F16>(w0l, xh[ks], a0);
+        a0 = mfma16<F16>(w0h, xl[ks], a0);
+        a0 = mfma16<F16>(w0h, xh[ks], a0);
+        a1 = mfma16<F16>(w1l, xh[ks], a1);
+        a1 = mfma16<F16>(w1h, xl[ks], a1);
+        a1 = mfma16<F16>(w1h, xh[ks], a1);
+      }
+      const int cl = 32 * jj + 8 * q;
+      const float4 ba = *reinterpret_cast<const float4*>(bl + cl), bb = *reinterpret_cast<const float4*>(bl + cl + 4);
+      const float4 sa = *reinterpret_cast<const float4*>(sl + cl), sb = *reinterpret_cast<const float4*>(sl + cl + 4);
+      float v[8] = {a0[0] * sa.x + ba.x, a0[1] * sa.y + ba.y, a0[2] * sa.z + ba.z, a0[3] * sa.w + ba.w,
+                    a1[0] * sb.x + bb.x, a1[1] * sb.y + bb.y, a1[2] * sb.z + bb.z, a1[3] * sb.w + bb.w};
+      if (has_res) {
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(&rfh[jj]);
+        const uint32_t* pl = reinterpret_cast<const uint32_t*>(&rfl[jj]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const avt::f32x2 r = avt::join2<F16>(ph[e], pl[e]);
+          v[2 * e] += r.x;
+          v[2 * e + 1] += r.y;
+        }
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = avt::relu_keep_nan(v[i]);
+      }
+      uint4 oh, ol;
+      avt::split2<F16>(v[0], v[1], oh.x, ol.x);
+      avt::split2<F16>(v[2], v[3], oh.y, ol.y);
+      avt::split2<F16>(v[4], v[5], oh.z, ol.z);
+      avt::split2<F16>(v[6], v[7], oh.w, ol.w);
+      if (ok) {
+        const int64_t o = pc * a.ldy + cl;
+        *reinterpret_cast<uint4*>(a.yh + o) = oh;
+        *reinterpret_cast<uint4*>(a.yl + o) = ol;
+      }
+      // layer 2, k-step jj: the planes just stored are the operand
+      const i32x4 yh = __builtin_bit_cast(i32x4, oh), yl = __builtin_bit_cast(i32x4, ol);
+#pragma unroll
+      for (int n = 0; n < NT2; ++n) {
+        const int f = n * K2S + jj;
+        const i32x4 wh = *reinterpret_cast<const i32x4*>(w2hl + f * 1024 + lofs), wl = *reinterpret_cast<const i32x4*>(w2ll + f * 1024 + lofs);
+        acc2[n] = mfma16<F16>(wl, yh, acc2[n]);
+        acc2[n] = mfma16<F16>(wh, yl, acc2[n]);
+        acc2[n] = mfma16<F16>(wh, yh, acc2[n]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < NT2 / 2; ++jj) {
+      const int cl = 32 * jj + 8 * q;
+      const float4 ba = *reinterpret_cast<const float4*>(b2l + cl), bb = *reinterpret_cast<const float4*>(b2l + cl + 4);
+      const float4 sa = *reinterpret_cast<const float4*>(s2l + cl), sb = *reinterpret_cast<const float4*>(s2l + cl + 4);
+      float v[8] = {acc2[2 * jj][0] * sa.x + ba.x,     acc2[2 * jj][1] * sa.y + ba.y,
+                    acc2[2 * jj][2] * sa.z + ba.z,     acc2[2 * jj][3] * sa.w + ba.w,
+                    acc2[2 * jj + 1][0] * sb.x + bb.x, acc2[2 * jj + 1][1] * sb.y + bb.y,
+                    acc2[2 * jj + 1][2] * sb.z + bb.z, acc2[2 * jj + 1][3] * sb.w + bb.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = avt::relu_keep_nan(v[i]);
+      uint4 oh, ol;
+      avt::split2<F16>(v[0], v[1], oh.x, ol.x);
+      avt::split2<F16>(v[2], v[3], oh.y, ol.y);
+      avt::split2<F16>(v[4], v[5], oh.z, ol.z);
+      avt::split2<F16>(v[6], v[7], oh.w, ol.w);
+      if (ok) {
+        const int64_t o = pc * c.ldz + cl;
+        *reinterpret_cast<uint4*>(c.zh + o) = oh;
+        *reinterpret_cast<uint4*>(c.zl + o) = ol;
+      }
+    }
+  }
+}
+
 // tiles per workgroup chunk for (K1S, N): the widest of 16 / 8 / 4 / 2 that divides N/16 and keeps both planes' fragments
 // within 128 KB of LDS; 0 = unsupported
 int pick_nt1(int k1s, int n) {
@@ -270,4 +431,71 @@ extern "C" int avt_pw_x3(const void* x_hi, const void* x_lo, int ldx, int k, con
   a.n_chunks = n / (16 * nt1);
   hipStream_t st = static_cast<hipStream_t>(stream);
   return plane_dtype == AVT_X3_F16 ? dispatch_k<true>(a, k1s, nt1, st) : dispatch_k<false>(a, k1s, nt1, st);
+}
+
+// (k1, n1, n2) of the chained form: the slow res2 pair 64 -> 256 (+ residual) -> 64
+extern "C" int avt_pw_chain_x3_supported(int k1, int n1, int n2) { return (k1 == 64 && n1 == 256 && n2 == 64) ? 1 : 0; }
+
+extern "C" int avt_pw_chain_x3(const void* x_hi, const void* x_lo, int ldx, int k1, const void* w1_hi, const void* w1_lo, const float* bias1,
+                               const float* wscale1, const void* res_hi, const void* res_lo, int ldr, void* y_hi, void* y_lo, int ldy,
+                               int n1, int relu1, const void* w2_hi, const void* w2_lo, const float* bias2, const float* wscale2,
+                               void* z_hi, void* z_lo, int ldz, int n2, int64_t m, int plane_dtype, void* stream) {
+  AVT_REQUIRE(x_hi && x_lo && w1_hi && w1_lo && y_hi && y_lo && w2_hi && w2_lo && z_hi && z_lo && (!res_hi == !res_lo),
+              "avt_pw_chain_x3: NULL pointer / half a plane pair");
+  AVT_REQUIRE(avt_pw_chain_x3_supported(k1, n1, n2), "avt_pw_chain_x3: unsupported pair K1=%d N1=%d N2=%d (64 -> 256 -> 64)", k1, n1, n2);
+  AVT_REQUIRE(m > 0 && m < (1ll << 31) - 16 && ldx >= k1 && ldy >= n1 && ldz >= n2 && ldx % 8 == 0 && ldy % 8 == 0 && ldz % 8 == 0 &&
+                  (!res_hi || (ldr >= n1 && ldr % 8 == 0)),
+              "avt_pw_chain_x3: bad sizes / leading dimensions");
+  AVT_REQUIRE(avt::aligned16(x_hi) && avt::aligned16(x_lo) && avt::aligned16(w1_hi) && avt::aligned16(w1_lo) && avt::aligned16(y_hi) &&
+                  avt::aligned16(y_lo) && avt::aligned16(w2_hi) && avt::aligned16(w2_lo) && avt::aligned16(z_hi) && avt::aligned16(z_lo) &&
+                  (!res_hi || (avt::aligned16(res_hi) && avt::aligned16(res_lo))) && (!bias1 || avt::aligned16(bias1)) &&
+                  (!wscale1 || avt::aligned16(wscale1)) && (!bias2 || avt::aligned16(bias2)) && (!wscale2 || avt::aligned16(wscale2)),
+              "avt_pw_chain_x3: pointers must be 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_pw_chain_x3: bad plane_dtype");
+  PcArgs c;
+  PxArgs& a = c.p;
+  a.xh = static_cast<const uint16_t*>(x_hi);
+  a.xl = static_cast<const uint16_t*>(x_lo);
+  a.rh = static_cast<const uint16_t*>(res_hi);
+  a.rl = static_cast<const uint16_t*>(res_lo);
+  a.yh = static_cast<uint16_t*>(y_hi);
+  a.yl = static_cast<uint16_t*>(y_lo);
+  a.wh = static_cast<const i32x4*>(w1_hi);
+  a.wl = static_cast<const i32x4*>(w1_lo);
+  a.bias = bias1;
+  a.wscale = wscale1;
+  a.M = (int)m;
+  a.ldx = ldx;
+  a.ldr = ldr;
+  a.ldy = ldy;
+  a.k1c = k1 / 8;
+  a.ntiles = (int)((m + 15) / 16);
+  a.relu = relu1;
+  a.n_chunks = 1;
+  a.n_rg = 0;
+  c.w2h = static_cast<const i32x4*>(w2_hi);
+  c.w2l = static_cast<const i32x4*>(w2_lo);
+  c.bias2 = bias2;
+  c.wscale2 = wscale2;
+  c.zh = static_cast<uint16_t*>(z_hi);
+  c.zl = static_cast<uint16_t*>(z_lo);
+  c.ldz = ldz;
+  constexpr int K1S = 2, NT1 = 16, NT2 = 4;
+  constexpr int lds_bytes = 2 * NT1 * K1S * 1024 + 2 * NT2 * (NT1 / 2) * 1024 + (2 * NT1 * 16 + 2 * NT2 * 16) * 4;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_chain_x3_kernel<K1S, NT1, NT2, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  static const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_chain_x3_kernel<K1S, NT1, NT2, false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    avt::set_error("avt_pw_chain_x3: hipFuncSetAttribute(%d B LDS) failed", lds_bytes);
+    return AVT_ERR_LAUNCH;
+  }
+  int grid = (a.ntiles + PX_NW - 1) / PX_NW;
+  if (grid > 256) grid = 256;  // persistent: one workgroup per CU (129 KB of fragments)
+  if (plane_dtype == AVT_X3_F16)
+    hipLaunchKernelGGL((pw_chain_x3_kernel<K1S, NT1, NT2, true>), dim3((unsigned)grid), dim3(PX_NW * 64), lds_bytes, st, c);
+  else
+    hipLaunchKernelGGL((pw_chain_x3_kernel<K1S, NT1, NT2, false>), dim3((unsigned)grid), dim3(PX_NW * 64), lds_bytes, st, c);
+  return avt::check_launch("avt_pw_chain_x3");
 }

@@ -34,6 +34,7 @@ _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "0"))   # frames walked per
 #                                                              16 at 56 columns (more workgroups), the whole clip (32) below
 _FUSE_BLOCK_X3 = int(os.environ.get("AVT_FUSE_BLOCK_X3", "1"))  # contract-grade mode: fast-pathway bottlenecks as one kernel
 _FUSE_TCHUNK_X3 = int(os.environ.get("AVT_FUSE_TCHUNK_X3", "0"))  # frames walked per workgroup; 0 = by width
+_CHAIN_X3 = int(os.environ.get("AVT_PW_CHAIN_X3", "1"))        # contract-grade mode: slow res2 c (+ residual) -> next a in one pass
 _C33_X3 = int(os.environ.get("AVT_C33_X3", "1"))              # contract-grade mode: slow res2 b conv on the direct-operand kernel
 _PW_X3 = int(os.environ.get("AVT_PW_X3", "1"))               # contract-grade mode: pointwise layers on the streaming kernel
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
@@ -776,7 +777,36 @@ class _BlockX3:
             self.ccat.alg_flops_per_row = self.c.alg_flops_per_row + self.b1.alg_flops_per_row
             self.extra = self.c.cin
 
-    def __call__(self, x, out=None):
+    def can_chain(self, nxt):
+        """True when this block's c (+ residual + ReLU) and the next block's a (+ ReLU) run as ONE pointwise pass
+        (csrc/pw_x3.hip, the chained form): both pointwise on the streaming kernel, identity shortcut here."""
+        return (_CHAIN_X3 and nxt is not None and self.b1 is None and self.fused is None and nxt.fused is None and
+                getattr(self.c, "pw", None) is not None and getattr(nxt.a, "pw", None) is not None and nxt.ccat is None and
+                nxt.a.cin == self.c.cout and ops.pw_chain_x3_supported(self.c.cin, self.c.cout, nxt.a.cout))
+
+    def __call__(self, x, out=None, chain=None, a_pre=None):
+        """chain = the next block (can_chain(...) holds): returns (y, a-output of the next block); a_pre = this block's a-output
+        when the previous block's chained pass has already produced it."""
+        if chain is not None or a_pre is not None:
+            m = self._b(a_pre if a_pre is not None else self.a(x))
+            sc = self.b1(x) if self.b1 is not None else x
+            if chain is None:
+                return self.c(m, out=out, res=sc, relu=True)
+            rows = m.dims[0] * m.dims[1] * m.dims[2] * m.dims[3]
+            y = out if out is not None else new_act(rows, self.c.cout, m.dims, self.dev, True)
+            z = new_act(rows, chain.a.cout, m.dims, self.dev, True)
+
+            def launch():
+                ops.pw_chain_x3(m.ptrs, m.ld, self.c.cin, self.c.pw, self.c.bias, self.c.wscale, sc.ptrs, sc.ld, y.ptrs, y.ld,
+                                self.c.cout, True, chain.a.pw, chain.a.bias, chain.a.wscale, z.ptrs, z.ld, chain.a.cout, rows,
+                                self.x3)
+
+            if PROFILER is None:
+                launch()
+            else:
+                PROFILER("pw_chain_x3_kernel", launch, rows * (self.c.alg_flops_per_row + chain.a.alg_flops_per_row),
+                         4.0 * rows * (self.c.cin + 2 * self.c.cout + chain.a.cout))
+            return y, z
         if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
                 ops.bneck_x3_supported(x.C, self.c.cout, x.dims[3]) and x.dims[2] % self.st == 0):
             b, t, h, w = x.dims
@@ -988,16 +1018,22 @@ class SlowFastMFMA(nn.Module):
             for blk in fast_blocks:
                 f_act = blk(f_act)
             last = k == len(self.stages) - 1
+            pre = None  # the a-output of the coming slow block, when the previous block's chained pass produced it
             for i, blk in enumerate(slow_blocks):
+                nxt = slow_blocks[i + 1] if i + 1 < len(slow_blocks) else None
+                if blk.can_chain(nxt):
+                    s_act, pre = blk(s_act, chain=nxt, a_pre=pre)
+                    continue
+                a_pre, pre = pre, None
                 if i == len(slow_blocks) - 1 and not last:  # straight into the next fusion's concat buffer
                     od = blk.b.out_dims(blk.a.out_dims(s_act.dims))
                     cs, cf = blk.c.cout, f_act.C
                     cat = new_act(od[0] * od[1] * od[2] * od[3], cs + 2 * cf, od, self.dev, True)
-                    blk(s_act, out=sl(cat, 0, cs))
+                    blk(s_act, out=sl(cat, 0, cs), a_pre=a_pre)
                     self.fuse[k + 1](f_act, out=sl(cat, cs, 2 * cf))
                     s_act = cat
                 else:
-                    s_act = blk(s_act)
+                    s_act = blk(s_act, a_pre=a_pre)
         emb = torch.empty((b, s_act.C + f_act.C), dtype=torch.float32, device=self.dev)
         ops.mean_positions_x3(s_act.ptrs, b, s_act.buf.shape[0] // b, s_act.C, s_act.ld, emb, 0, self.x3)
         ops.mean_positions_x3(f_act.ptrs, b, f_act.buf.shape[0] // b, f_act.C, f_act.ld, emb, s_act.C, self.x3)

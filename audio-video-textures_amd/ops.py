@@ -394,6 +394,23 @@ def pw_x3(x_ptrs, ldx, k, w_hi, w_lo, bias, wscale, res_ptrs, ldr, y_ptrs, ldy, 
                                     1 if relu else 0, int(plane_dtype), _stream()), "avt_pw_x3")
 
 
+def pw_chain_x3_supported(k1, n1, n2):
+    return bool(_lib.lib().avt_pw_chain_x3_supported(int(k1), int(n1), int(n2)))
+
+
+def pw_chain_x3(x_ptrs, ldx, k1, w1, bias1, wscale1, res_ptrs, ldr, y_ptrs, ldy, n1, relu1, w2, bias2, wscale2, z_ptrs, ldz, n2, m,
+                plane_dtype):
+    """y = act(W1 x + b1 [+ res]), z = relu(W2 y + b2) in one pass on plane pairs (csrc/pw_x3.hip); w1 / w2 = (hi, lo) fragment
+    planes (fused_slowfast.pack_pw_planes)."""
+    rh, rl = res_ptrs if res_ptrs is not None else (0, 0)
+    _lib.check(_lib.lib().avt_pw_chain_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), int(ldx), int(k1), _p(w1[0]), _p(w1[1]),
+                                          _p(bias1), _p(wscale1), C.c_void_p(rh) if rh else None, C.c_void_p(rl) if rl else None,
+                                          int(ldr), C.c_void_p(y_ptrs[0]), C.c_void_p(y_ptrs[1]), int(ldy), int(n1),
+                                          1 if relu1 else 0, _p(w2[0]), _p(w2[1]), _p(bias2), _p(wscale2), C.c_void_p(z_ptrs[0]),
+                                          C.c_void_p(z_ptrs[1]), int(ldz), int(n2), int(m), int(plane_dtype), _stream()),
+               "avt_pw_chain_x3")
+
+
 def maxpool_hw3s2_x3(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1):
     _lib.check(_lib.lib().avt_maxpool_hw3s2_ndhwc_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), C.c_void_p(out_ptrs[0]),
                                                      C.c_void_p(out_ptrs[1]), int(bt), int(h), int(w), int(c), int(ldi),

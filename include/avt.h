@@ -377,6 +377,16 @@ int avt_pw_x3_supported(int k, int n);
 int avt_pw_x3(const void* x_hi, const void* x_lo, int ldx, int k, const void* w_hi, const void* w_lo,
               const float* bias, const float* wscale, const void* res_hi, const void* res_lo, int ldr,
               void* y_hi, void* y_lo, int ldy, int n, int64_t m, int relu, int plane_dtype, void* stream);
+/* Two pointwise layers of consecutive slow-pathway bottlenecks in ONE pass over the rows, on plane pairs (csrc/pw_x3.hip; the
+ * contract-grade form of avt_pw_chain_bf16):  y = act(W1 x + b1 [+ res]) (block i's expanding conv + residual + ReLU) and
+ * z = relu(W2 y + b2) (block i + 1's reducing conv).  The first GEMM's result, already split into the planes it stores, is the
+ * second GEMM's operand in registers: y is written once and never read back.  z is bit-identical to avt_pw_x3 applied to the
+ * stored y.  w1 / w2 as for avt_pw_x3 (fragments over K1 and over K2 = n1).  Supported: (k1, n1, n2) = (64, 256, 64). */
+int avt_pw_chain_x3_supported(int k1, int n1, int n2);
+int avt_pw_chain_x3(const void* x_hi, const void* x_lo, int ldx, int k1, const void* w1_hi, const void* w1_lo, const float* bias1,
+                    const float* wscale1, const void* res_hi, const void* res_lo, int ldr, void* y_hi, void* y_lo, int ldy,
+                    int n1, int relu1, const void* w2_hi, const void* w2_lo, const float* bias2, const float* wscale2,
+                    void* z_hi, void* z_lo, int ldz, int n2, int64_t m, int plane_dtype, void* stream);
 /* avt_stem_conv_bf16 in the same arithmetic (csrc/stem_conv.hip, patch-resident): in / wt / out as plane pairs, wt_* in the
  * LDS image order of avt_stem_conv_bf16 (fused_slowfast.stem_lds_image of each plane), wscale [cout] or NULL. */
 int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,

@@ -597,3 +597,52 @@ def test_conv33_x3_direct_operand_kernel(avt, dev, mode, dims, ldi, ldo):
     if ldo > 64:  # the columns in front of the slice are untouched
         whole = Act(out.buf, dims, 0, ldo, lo=out.lo).float(pd).cpu()
         assert torch.equal(whole[:, : ldo - 64], torch.full((m, ldo - 64), 7.0))
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_pw_chain_x3_is_bit_identical_to_the_two_launches(avt, dev, mode):
+    """csrc/pw_x3.hip's chained form (slow res2: c of block i + residual + ReLU -> a of block i + 1 in one pass, y handed over in
+    registers) against the two pointwise launches it replaces: the same rounded planes feed the second GEMM in the same k
+    order, so y AND z are bit-identical; and the whole encoder's embedding does not change by a bit."""
+    import avtex.fused_slowfast as fsf
+    from avtex import ops
+    from avtex.fused_slowfast import Act, FusedConv, new_act, split_planes
+
+    pd = X3[mode]
+    torch.manual_seed(9)
+    c = nn.Conv3d(64, 256, 1, bias=False)
+    a2 = nn.Conv3d(256, 64, 1, bias=False)
+    bnc, bna = nn.BatchNorm3d(256).eval(), nn.BatchNorm3d(64).eval()
+    with torch.no_grad():
+        for bn in (bnc, bna):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+            bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    fc, fa = FusedConv(c, bnc, True, dev, x3=pd), FusedConv(a2, bna, True, dev, x3=pd)
+    assert fc.pw is not None and fa.pw is not None and ops.pw_chain_x3_supported(64, 256, 64)
+    dims = (2, 3, 9, 11)  # 594 rows: a ragged last 16-row tile
+    m = dims[0] * dims[1] * dims[2] * dims[3]
+    xh, xl = _planes(torch.randn(m, 64), pd, dev)
+    rh, rl = _planes(torch.randn(m, 256), pd, dev)
+    x, res = Act(xh, dims, lo=xl), Act(rh, dims, lo=rl)
+    y_ref = fc(x, res=res, relu=True)
+    z_ref = fa(y_ref)
+    y, z = new_act(m, 256, dims, dev, True), new_act(m, 64, dims, dev, True)
+    ops.pw_chain_x3(x.ptrs, x.ld, 64, fc.pw, fc.bias, fc.wscale, res.ptrs, res.ld, y.ptrs, y.ld, 256, True, fa.pw, fa.bias, fa.wscale,
+                    z.ptrs, z.ld, 64, m, pd)
+    torch.cuda.synchronize()
+    for got, want in ((y, y_ref), (z, z_ref)):
+        assert torch.equal(got.buf, want.buf) and torch.equal(got.lo, want.lo)
+    # the encoder with and without the chained pass
+    from avtex.slowfast import SlowFast
+    torch.manual_seed(1)
+    net = SlowFast().eval()
+    sx = ops.SplitClip(*split_planes(torch.randn(1, 8, 224, 224, 4, device=dev), pd), pd)
+    fx = ops.SplitClip(*split_planes(torch.randn(1, 32, 224, 224, 4, device=dev), pd), pd)
+    outs = []
+    for flag in (1, 0):
+        keep, fsf._CHAIN_X3 = fsf._CHAIN_X3, flag
+        try:
+            outs.append(fsf.SlowFastMFMA(net, dev, precision=mode).forward_ndhwc4(sx, fx).clone())
+        finally:
+            fsf._CHAIN_X3 = keep
+    assert torch.equal(outs[0], outs[1])

@@ -104,6 +104,15 @@ def spy_c33(x_ptrs, packed, out_ptrs, batch, t, h, w, ldi, ldo, plane_dtype, rel
     return orig_c33(x_ptrs, packed, out_ptrs, batch, t, h, w, ldi, ldo, plane_dtype, relu)
 
 
+orig_pc = ops.pw_chain_x3
+
+
+def spy_pc(x_ptrs, ldx, k1, w1, bias1, wscale1, res_ptrs, ldr, y_ptrs, ldy, n1, relu1, w2, bias2, wscale2, z_ptrs, ldz, n2, m_, plane_dtype):
+    shapes.append("pointwise chain cin%d -> %d (+res) -> %d rows %d" % (k1, n1, n2, m_))
+    return orig_pc(x_ptrs, ldx, k1, w1, bias1, wscale1, res_ptrs, ldr, y_ptrs, ldy, n1, relu1, w2, bias2, wscale2, z_ptrs, ldz, n2, m_, plane_dtype)
+
+
+ops.pw_chain_x3 = spy_pc
 ops.conv33_x3 = spy_c33
 ops.stem_conv_pool_x3 = spy_sp
 ops.bneck_x3 = spy_bn
