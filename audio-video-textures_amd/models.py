@@ -108,6 +108,18 @@ class InfoNCECriterion(nn.Module):
         return self._Fn.apply(logits.float(), labels)
 
 
+_TRAIN_STREAMS = int(os.environ.get("AVT_TRAIN_STREAMS", "1"))
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 class ContrastivePredictionTemporal(nn.Module):
     def __init__(self, q_image_enc_model, t_image_enc_model, audio_enc_model, model_type, fc_dim, temp=0.1,
                  window=20, stride=2, threshold=0.20, mini_batchsize=20, dropout=0.5, enc_arch="resnet",
@@ -164,7 +176,18 @@ class ContrastivePredictionTemporal(nn.Module):
             H, W = q_f.shape[3], q_f.shape[4]
             batch_size = q_f.shape[0]
             q_f = q_f.permute(0, 2, 1, 3, 4).contiguous().view(-1, C, self.window, H, W)
-        q_v = self._run_enc(self.q_encoder, q_f).view(batch_size, -1)
+        # Training on the device: the query encoder (ONE clip per item: launches of a few workgroups each) runs on a side
+        # stream next to the target encoder's 15 clips — the two are independent until the logits, and autograd replays each
+        # backward node on its forward's stream, so the backward passes overlap the same way (AVT_TRAIN_STREAMS=0: one stream)
+        q_side = None
+        if self.training and _TRAIN_STREAMS and slowfast and q_f[0].is_cuda and self.model_type != 2:
+            cur = torch.cuda.current_stream(q_f[0].device)
+            q_side = _side_stream(q_f[0].device)
+            q_side.wait_stream(cur)
+            with torch.cuda.stream(q_side):
+                q_v = self._run_enc(self.q_encoder, q_f).view(batch_size, -1)
+        else:
+            q_v = self._run_enc(self.q_encoder, q_f).view(batch_size, -1)
 
         q_a = t_a = None
         if self.model_type == 2:
@@ -189,6 +212,9 @@ class ContrastivePredictionTemporal(nn.Module):
             t_f = [t_f[0].reshape(-1, C, SLOW_T, t_f[0].shape[-2], t_f[0].shape[-1]),
                    t_f[1].reshape(-1, C, FAST_T, t_f[1].shape[-2], t_f[1].shape[-1])]
         t_v = self._run_enc(self.t_encoder, t_f).view(batch_size, t_len, -1)
+        if q_side is not None:
+            cur.wait_stream(q_side)
+            q_v.record_stream(cur)  # (allocated on the side stream, consumed and freed from this one)
         if self.model_type == 2:
             t_a = self._run_enc(self.t_a_encoder, t_audio_eg.contiguous().view(-1, A_c, A_w, A_h)).view(
                 batch_size, t_len, -1)

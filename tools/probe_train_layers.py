@@ -1,0 +1,125 @@
+"""Per-layer device time of ONE item of config 5's step (1 query + 15 targets at 224^2, both encoders, forward + backward):
+every hand-written launch of train_ops is timed with events around the call (a synchronisation per call: the sum is the
+device time of the launches, not the step's wall time).  python tools/probe_train_layers.py [items]"""
+import collections
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import avtex as avt  # noqa: E402
+from avtex import _lib, ops, synth, train_ops  # noqa: E402
+from avtex.dataset import DeviceSegmentBatcher  # noqa: E402
+from avtex.slowfast import SlowFast  # noqa: E402
+
+ROWS = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])  # key -> [calls, ms, flops, bytes]
+ON = [False]
+
+
+def timed(key, fn, flops, nbytes):
+    if not ON[0]:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    e1.synchronize()
+    row = ROWS[key]
+    row[0] += 1
+    row[1] += e0.elapsed_time(e1)
+    row[2] += flops
+    row[3] += nbytes
+    return r
+
+
+_fwd, _wg, _wgs = ops.conv3d_igemm_x3_f32, ops.conv3d_wgrad_x3_f32, ops.conv3d_wgrad_x3_sub_f32
+
+
+def fwd(x, wh, wl, ws, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype, add=None):
+    mo = out.numel() // cout
+    taps = kernel[0] * kernel[1] * kernel[2]
+    what = "fwd  " if plane_dtype == ops.X3_F16 else "dgrad"
+    key = "%s cin%-4d cout%-4d k%s s%s in%s%s" % (what, cin, cout, tuple(kernel), tuple(stride), tuple(dims), " +add" if add is not None else "")
+    return timed(key, lambda: _fwd(x, wh, wl, ws, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype, add=add),
+                 2.0 * mo * taps * cin * cout, 4.0 * (x.numel() + out.numel() * (2 if add is not None else 1)))
+
+
+def wg(dy, x, dw, dims, cin, cout, kernel, stride, pad, ldx, ldy):
+    mo = dy.numel() // cout
+    taps = kernel[0] * kernel[1] * kernel[2]
+    key = "wgrad cin%-4d cout%-4d k%s s%s in%s" % (cin, cout, tuple(kernel), tuple(stride), tuple(dims))
+    return timed(key, lambda: _wg(dy, x, dw, dims, cin, cout, kernel, stride, pad, ldx, ldy), 2.0 * mo * taps * cin * cout,
+                 4.0 * (x.numel() + dy.numel()))
+
+
+def wgs(dy, x, dw, dims, cin, cout, kernel, stride, pad, out_dims, ldx, ldy, ldw, zero_dw):
+    mo = dy.numel() // cout
+    taps = kernel[0] * kernel[1] * kernel[2]
+    key = "wgrad-slice cin%-4d cout%-4d k%s s%s in%s" % (cin, cout, tuple(kernel), tuple(stride), tuple(dims))
+    return timed(key, lambda: _wgs(dy, x, dw, dims, cin, cout, kernel, stride, pad, out_dims, ldx, ldy, ldw, zero_dw),
+                 2.0 * mo * taps * cin * cout, 4.0 * (x.numel() // 2 + dy.numel()))
+
+
+ops.conv3d_igemm_x3_f32, ops.conv3d_wgrad_x3_f32, ops.conv3d_wgrad_x3_sub_f32 = fwd, wg, wgs
+
+_bn_apply = train_ops._BNAct.apply
+_bf, _bb = train_ops._BNAct.forward, train_ops._BNAct.backward
+
+
+def bn_fwd(ctx, x, *a, **k):
+    m, c = train_ops._rows(x)
+    res = a[4]
+    return timed("bn_fwd  c%-4d rows %d%s" % (c, m, " +res" if res is not None else ""), lambda: _bf(ctx, x, *a, **k), 0.0,
+                 4.0 * x.numel() * (3 + (1 if res is not None else 0)))
+
+
+def bn_bwd(ctx, dy):
+    m, c = dy.numel() // dy.shape[1], dy.shape[1]
+    return timed("bn_bwd  c%-4d rows %d%s" % (c, m, " +res" if ctx.has_res else ""), lambda: _bb(ctx, dy), 0.0,
+                 4.0 * dy.numel() * (6 + (1 if ctx.has_res else 0)))
+
+
+train_ops._BNAct.forward, train_ops._BNAct.backward = staticmethod(bn_fwd), staticmethod(bn_bwd)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    args = SimpleNamespace(vdata="/tmp", adata=None, n_negs=14, img_size=224, enc_arch="slowfast", window=0, stride=0)
+    torch.manual_seed(5)
+    ds = avt.AudioVideoSegments(args, "x", split="train", video=(synth.structured_video(3, 600, 64, 64), 30.0))
+    torch.manual_seed(0)
+    m = avt.ContrastivePredictionTemporal(SlowFast(), SlowFast(), None, 1, 128, temp=0.1, window=ds.window, stride=ds.stride,
+                                          enc_arch="slowfast", img_size=224)
+    synth.randomise_bn(m, 4, 0.0)
+    m = m.to(dev).train().to(memory_format=torch.channels_last_3d)
+    np.random.seed(3)
+    bat = DeviceSegmentBatcher(ds, dev).seed_from_numpy()
+    q, t, _, _ = bat.batch(torch.tensor([20]))
+    label = torch.zeros(1, dtype=torch.long, device=dev)
+    crit = avt.InfoNCECriterion()
+    for it in range(3):
+        ON[0] = it == 2
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        loss = crit(m(q, t), label)
+        loss.backward()
+        e1.record()
+        torch.cuda.synchronize()
+        print("item %d: %.1f ms%s" % (it, e0.elapsed_time(e1), " (timed per launch: serialised)" if ON[0] else ""))
+        m.zero_grad(set_to_none=True)
+    tot = sum(r[1] for r in ROWS.values())
+    print("hand-written launches: %.1f ms in %d launches" % (tot, sum(r[0] for r in ROWS.values())))
+    cat = collections.defaultdict(float)
+    for k, r in ROWS.items():
+        cat[k.split()[0]] += r[1]
+    print("  by kind: " + ", ".join("%s %.1f ms" % kv for kv in sorted(cat.items(), key=lambda kv: -kv[1])))
+    for k, r in sorted(ROWS.items(), key=lambda kv: -kv[1][1])[:70]:
+        print("  %7.3f ms x%-2d %-84s %6.1f TF/s %6.0f GB/s" % (r[1], r[0], k, r[2] / r[1] * 1e-9, r[3] / r[1] * 1e-6))
+
+
+if __name__ == "__main__":
+    main()
