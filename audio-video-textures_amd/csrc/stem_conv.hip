@@ -65,6 +65,9 @@ struct StemArgs {
   const uint16_t* wt_lo;
   uint16_t* out_lo;
   const float* wscale;
+  // training forward (avt_stem_conv_x3_f32): `out` is an fp32 NDHWC tensor [B, To * tgroup, Ho, Wo, Cout / tgroup] — the
+  // time-grouped channels go back to their frames on the way out
+  int out_f32;
 };
 
 constexpr int RB = 4;   // conv rows a workgroup owns in the plain form (pooled: RBP = 8, plus one recomputed row above them)
@@ -285,6 +288,14 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
           if constexpr (PL != 0) {
             float v[8];
             values(i, v);
+            if (a.out_f32) {  // uniform
+              const int cf = a.Cout / a.tgroup, j = c0 / cf, cin_f = c0 - j * cf;
+              const int64_t of = ((int64_t)(((b * a.To + to) * a.tgroup + j) * a.Ho + ho0 + unit_row(i)) * WO + unit_mt(i) * 16 + l15) * cf + cin_f;
+              float* d = reinterpret_cast<float*>(a.out) + of;
+              *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+              continue;
+            }
             uint4 oh, ol;
             avt::split2<PL == 2>(v[0], v[1], oh.x, ol.x);
             avt::split2<PL == 2>(v[2], v[3], oh.y, ol.y);
@@ -434,6 +445,7 @@ int fill(StemArgs& a, const char* what, const void* in, const void* wt, const fl
   a.in_lo = a.wt_lo = nullptr;
   a.out_lo = nullptr;
   a.wscale = nullptr;
+  a.out_f32 = 0;
   AVT_REQUIRE(a.To > 0, "%s: no output frames", what);
   const int64_t in_b = (int64_t)batch * t * h * pw * 16, wt_b = (int64_t)cout * kt * KF * 2;
   AVT_REQUIRE(in_b < (1ll << 32) - 64 && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
@@ -492,6 +504,30 @@ extern "C" int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void
   if (plane_dtype == AVT_X3_F16)
     return pw == 112 ? launch<7, false, 2>(a, batch, s, "avt_stem_conv_x3") : launch<2, false, 2>(a, batch, s, "avt_stem_conv_x3");
   return pw == 112 ? launch<7, false, 1>(a, batch, s, "avt_stem_conv_x3") : launch<2, false, 1>(a, batch, s, "avt_stem_conv_x3");
+}
+
+// the training forward (train_ops._StemX3): fp32 NDHWC out, no bias, no ReLU (BatchNorm follows in train mode); see include/avt.h
+extern "C" int avt_stem_conv_x3_f32(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* wscale,
+                                    float* out, int batch, int t, int h, int pw, int cout, int kt, int st, int pt, int tgroup,
+                                    int plane_dtype, void* stream) {
+  StemArgs a;
+  const int rc = fill(a, "avt_stem_conv_x3_f32", in_hi, wt_hi, nullptr, out, batch, t, h, pw, cout, kt, st, pt, 0);
+  if (rc) return rc;
+  AVT_REQUIRE(in_lo && wt_lo && avt::aligned16(in_lo) && avt::aligned16(wt_lo) && (!wscale || avt::aligned16(wscale)),
+              "avt_stem_conv_x3_f32: every operand needs both planes, 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_stem_conv_x3_f32: bad plane_dtype");
+  AVT_REQUIRE(tgroup >= 1 && cout % tgroup == 0 && (cout / tgroup) % 8 == 0,
+              "avt_stem_conv_x3_f32: tgroup must split the channels into multiples of 8");
+  a.in_lo = static_cast<const uint16_t*>(in_lo);
+  a.wt_lo = static_cast<const uint16_t*>(wt_lo);
+  a.out_lo = nullptr;
+  a.wscale = wscale;
+  a.tgroup = tgroup;
+  a.out_f32 = 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plane_dtype == AVT_X3_F16)
+    return pw == 112 ? launch<7, false, 2>(a, batch, s, "avt_stem_conv_x3_f32") : launch<2, false, 2>(a, batch, s, "avt_stem_conv_x3_f32");
+  return pw == 112 ? launch<7, false, 1>(a, batch, s, "avt_stem_conv_x3_f32") : launch<2, false, 1>(a, batch, s, "avt_stem_conv_x3_f32");
 }
 
 extern "C" int avt_stem_conv_pool_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,

@@ -16,12 +16,12 @@ _PREC = {"bf16": SIM_BF16, "bf16x3": SIM_BF16X3, "f32": SIM_F32}
 FAST_T, SLOW_T, SLOTS = 32, 8, 40
 
 
-def _dev(t, name, dtype=None):
+def _dev(t, name, dtype=None, contiguous=True):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.AvtError("%s must be a device (HIP) tensor; the hot path has no CPU fallback" % name)
     if dtype is not None and t.dtype != dtype:
         raise _lib.AvtError("%s must be %s, got %s" % (name, dtype, t.dtype))
-    if not t.is_contiguous():
+    if contiguous and not t.is_contiguous():
         raise _lib.AvtError("%s must be contiguous" % name)
     return t
 
@@ -367,6 +367,45 @@ def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, 
                                            _p(wscale), C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]), int(batch), int(t),
                                            int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(bool(relu)),
                                            int(plane_dtype), _stream()), "avt_stem_conv_x3")
+
+
+def clip_planes_f32(x, plane_dtype):
+    """[B, 3, T, H, W] fp32 device tensor (any strides) -> (hi, lo) planes [B, T, H, W, 4] typed bfloat16 (raw bits), the 4th
+    channel zero: what the patch-resident stem kernels read as pixel pairs [B, T, H, W/2, 8]."""
+    _dev(x, "x", torch.float32, contiguous=False)
+    if x.dim() != 5 or x.shape[1] != 3:
+        raise _lib.AvtError("clip_planes_f32: expected [B, 3, T, H, W], got %s" % (tuple(x.shape),))
+    b, _, t, h, w = x.shape
+    hi = torch.empty((b, t, h, w, 4), dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty_like(hi)
+    sb, sc, st, sh, sw = x.stride()
+    _lib.check(_lib.lib().avt_clip_planes_f32(_p(x), b, t, h, w, sb, sc, st, sh, sw, _p(hi), _p(lo), int(plane_dtype), _stream()),
+               "avt_clip_planes_f32")
+    return hi, lo
+
+
+def stem_conv_x3_f32(x_hi, x_lo, wt_hi, wt_lo, wscale, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype):
+    """The stems' training forward: stem_conv_x3 with fp32 NDHWC output [batch, to*tgroup, h/2, pw, cout/tgroup], no bias / ReLU."""
+    _dev(wt_hi, "wt_hi", torch.bfloat16)
+    _dev(wt_lo, "wt_lo", torch.bfloat16)
+    _dev(out, "out", torch.float32, contiguous=False)
+    _lib.check(_lib.lib().avt_stem_conv_x3_f32(_p(x_hi), _p(x_lo), _p(wt_hi), _p(wt_lo), _p(wscale), _p(out), int(batch), int(t),
+                                               int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(tgroup),
+                                               int(plane_dtype), _stream()), "avt_stem_conv_x3_f32")
+
+
+def stem_wgrad_x3_supported(h, pw, cout, kt):
+    return bool(_lib.lib().avt_stem_wgrad_x3_supported(int(h), int(pw), int(cout), int(kt)))
+
+
+def stem_wgrad_x3(x_hi, x_lo, dy, batch, t, h, pw, cout, kt, pt):
+    """The stems' weight gradient in the pixel-pair form -> dw [cout, kt, 7, 4, 8] fp32 (see include/avt.h); x_* = bf16 planes
+    of clip_planes_f32, dy = fp32 NDHWC rows [batch, to, h/2, pw, cout] (dense)."""
+    _dev(dy, "dy", torch.float32, contiguous=False)
+    dw = torch.zeros((cout, kt, 7, 4, 8), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().avt_stem_wgrad_x3(_p(x_hi), _p(x_lo), _p(dy), _p(dw), int(batch), int(t), int(h), int(pw), int(cout),
+                                            int(kt), int(pt), _stream()), "avt_stem_wgrad_x3")
+    return dw
 
 
 def stem_conv_pool_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, tgroup, ldo, plane_dtype):

@@ -4,8 +4,9 @@ when the model is in the training layout (channels_last_3d, main.py --train_layo
 * `bn_act`: train-mode BatchNorm3d + shortcut add + ReLU as one HIP statistics pass + one apply pass in each direction
   (csrc/bn_train.hip) instead of MIOpenBatchNormFwdTrainSpatial / BwdSpatial + separate add / ReLU passes;
 * `conv3d` / `conv3d_fork`: the convolutions' forward and stride-1 input gradient on the split-plane MFMA kernel
-  (csrc/conv_x3.hip, fp32 in / fp32 out) and their weight gradient on csrc/wgrad_x3.hip.  MIOpen keeps the strided input
-  gradients and the stems' weight gradient (aten.convolution_backward).
+  (csrc/conv_x3.hip, fp32 in / fp32 out) and their weight gradient on csrc/wgrad_x3.hip; the two stems ([kt,7,7] on the
+  3-channel clip) on the patch-resident kernels (csrc/stem_conv.hip forward with fp32 output, csrc/stem_train.hip weight
+  gradient, both in the pixel-pair form).  MIOpen keeps the strided input gradients (aten.convolution_backward).
 
 ARITHMETIC (main.py --train_conv, set_conv_mode): "x3" (the default on the MI355X) computes every product from two 16-bit
 planes with fp32 accumulation — forward in fp16 planes (2^-22 per product), input and weight gradients in bf16 planes (2^-16
@@ -30,6 +31,7 @@ _CONV_X3 = int(os.environ.get("AVT_TRAIN_CONV_X3", "1"))
 _WGRAD_X3 = int(os.environ.get("AVT_TRAIN_WGRAD_X3", "1"))
 _DGRAD_S_X3 = int(os.environ.get("AVT_TRAIN_DGRAD_STRIDED_X3", "1"))
 _STEM_WGRAD_X3 = int(os.environ.get("AVT_TRAIN_STEM_WGRAD_X3", "1"))
+_STEM_PATCH = int(os.environ.get("AVT_TRAIN_STEM_PATCH", "1"))  # the stems on the patch-resident kernels (0: conv_x3 + wgrad slices)
 _FORK = int(os.environ.get("AVT_TRAIN_FORK", "1"))
 
 
@@ -50,11 +52,12 @@ def conv_mode():
 def invalidate_weight_cache():
     """Drop the cached weight planes (needed after in-place updates through `.data`, which `_version` does not see)."""
     _PLANES.clear()
+    _STEM_IMAGES.clear()
 
 
 # per-process launch counters of the hand-written training kernels (tests assert that the default path really runs them)
 CALLS = {"conv_fwd_x3": 0, "dgrad_x3": 0, "dgrad_strided_x3": 0, "wgrad_x3": 0, "wgrad_stem_x3": 0, "bn_fwd": 0, "bn_bwd": 0,
-         "miopen_dgrad": 0, "miopen_wgrad": 0}
+         "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0}
 
 
 def _p(t):
@@ -298,6 +301,99 @@ class _ConvX3Fork(torch.autograd.Function):
         return _conv_backward(ctx, dy, dalias) + (None, None)
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# The stems: Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) on the raw clip.  As an implicit GEMM over 8 padded
+# channels the fast stem's forward ran 4.7 ms and its weight gradient (five [1,7,7] slices of wgrad_x3) 9.5 ms of a 95 ms item
+# (profiles/r03/train_layers_before_stem.log): both gather every pixel once per tap.  The patch-resident kernels stage the
+# input rows once: the forward is the inference stem kernel (pixel-pair form, time-grouped for the 8-channel fast stem, fp16
+# planes) writing fp32, the weight gradient csrc/stem_train.hip (bf16 planes).  The clip is re-split into planes in each
+# direction (a 12-byte read and a 16-byte write per pixel) instead of kept: the saved tensor is the caller's clip itself.
+_STEM_IMAGES = {}
+
+
+def _stem_tgroup(cout, t):
+    """Output frames computed together as channels of one MFMA tile (fused_slowfast.stem_conv): 32 / cout, or None."""
+    if cout % 32 == 0:
+        return 1
+    g = 32 // cout if 32 % cout == 0 else 0
+    return g if g > 1 and t % g == 0 else None
+
+
+def stem_patch_ok(x, conv):
+    from . import ops
+    if not (_STEM_PATCH and conv.in_channels == 3 and x.dim() == 5 and x.shape[1] == 3):
+        return False
+    kt = conv.kernel_size[0]
+    _, _, t, h, w = x.shape
+    return (tuple(conv.kernel_size[1:]) == (7, 7) and tuple(conv.stride) == (1, 2, 2) and tuple(conv.padding) == (kt // 2, 3, 3) and
+            w % 2 == 0 and _stem_tgroup(conv.out_channels, t) is not None and
+            bool(_lib.lib().avt_stem_conv_supported(h, w // 2, conv.out_channels * _stem_tgroup(conv.out_channels, t))) and
+            ops.stem_wgrad_x3_supported(h, w // 2, conv.out_channels, kt) and x.numel() // 3 * 16 < (1 << 32) - 64)
+
+
+def _stem_weight_image(weight, g):
+    """(hi, lo, wscale) of a stem weight [C, 3, kt, 7, 7] in the LDS image order of csrc/stem_conv.hip: pixel-pair taps
+    (column tap k -> pair tap (k + 1) // 2, pixel (k + 1) % 2; the first is a structural zero), g output frames as g * C
+    channels over kt + g - 1 frame taps, fp16 planes of rows scaled into [2^9, 2^10).  Cached until the tensor changes."""
+    from . import ops
+    from .fused_slowfast import split_planes, stem_lds_image
+    key = (id(weight), g)
+    hit = _STEM_IMAGES.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    with torch.no_grad():
+        w = weight.detach().float()
+        c, _, kt = w.shape[0], w.shape[1], w.shape[2]
+        w8 = w.new_zeros((c, kt, 7, 8, 4))
+        w8[:, :, :, 1:, :3] = w.permute(0, 2, 3, 4, 1)
+        wg = w.new_zeros((g, c, kt + g - 1, 7, 8, 4))
+        for j in range(g):
+            wg[j, :, j : j + kt] = w8
+        wt = wg.reshape(g * c, -1)
+        mx = wt.abs().amax(dim=1).clamp_min(1e-30)
+        sc = torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
+        hi, lo = split_planes(wt * sc.view(-1, 1), ops.X3_F16)
+        img = (stem_lds_image(hi, kt + g - 1), stem_lds_image(lo, kt + g - 1), (1.0 / sc).float().contiguous())
+    if len(_STEM_IMAGES) > 64:
+        for k in [k for k, v in _STEM_IMAGES.items() if v[0]() is None]:
+            del _STEM_IMAGES[k]
+    _STEM_IMAGES[key] = (weakref.ref(weight), weight._version, img)
+    return img
+
+
+class _StemX3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        from . import ops
+        b, _, t, h, w = x.shape
+        c, kt = weight.shape[0], weight.shape[2]
+        g = _stem_tgroup(c, t)
+        xh, xl = ops.clip_planes_f32(x, ops.X3_F16)
+        wh, wl, wscale = _stem_weight_image(weight, g)
+        y = torch.empty((b, c, t, h // 2, w // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+        CALLS["conv_fwd_x3"] += 1
+        CALLS["stem_fwd_patch"] += 1
+        ops.stem_conv_x3_f32(xh, xl, wh, wl, wscale, y, b, t, h, w // 2, g * c, kt + g - 1, g, kt // 2, g, ops.X3_F16)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None
+        b, _, t, h, w = x.shape
+        c, kt = weight.shape[0], weight.shape[2]
+        dy = dy.contiguous(memory_format=torch.channels_last_3d)
+        xh, xl = ops.clip_planes_f32(x, ops.X3_BF16)
+        CALLS["wgrad_stem_patch"] += 1
+        dwp = ops.stem_wgrad_x3(xh, xl, dy, b, t, h, w // 2, c, kt, kt // 2)  # [c, kt, 7, 4 pair taps, 2 pixels x 4 channels]
+        dw = torch.empty_like(weight)
+        dw.copy_(dwp.view(c, kt, 7, 8, 4)[:, :, :, 1:, :3].permute(0, 4, 1, 2, 3))  # column tap k = 2 * pair + pixel - 1
+        return None, dw
+
+
 def conv_fusable(x, conv):
     """(in_channels == 3: the stems — the clip is zero-padded to 8 channels for the forward; it needs no input gradient.)"""
     return (_CONV_X3 and conv.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and conv.bias is None and
@@ -325,6 +421,8 @@ def conv3d(x, conv):
     training layout (forward, stride-1 input gradient, weight gradient), the module itself otherwise."""
     if not conv_fusable(x, conv):
         return conv(x)
+    if conv.in_channels == 3 and stem_patch_ok(x, conv):
+        return _StemX3.apply(x, conv.weight)
     if conv.in_channels % 8 and not x.is_contiguous(memory_format=torch.channels_last_3d):
         pass  # (the stem's padded copy is built channels-last from any layout)
     else:

@@ -472,6 +472,26 @@ int avt_conv3d_wgrad_x3_sub_f32(const float* dy, const float* x, float* dw, int 
                                 int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo,
                                 int ldx, int ldy, int ldw, int zero_dw, void* stream);
 
+/* The SlowFast stems in the TRAINING step, patch-resident like the inference stem (csrc/stem_conv.hip, csrc/stem_train.hip;
+ * the reference trains them through autograd -> MIOpen, train.py:114-141):
+ * avt_clip_planes_f32: the clip, a [batch, 3, t, h, w] fp32 view with element strides (sb, sc, st, sh, sw), -> the two
+ *   16-bit planes [batch, t, h, w, 4] (4th channel 0; read as pixel pairs [.., w/2, 8] by the stem kernels).
+ * avt_stem_conv_x3_f32: avt_stem_conv_x3 without bias / ReLU and with fp32 output [batch, to*tgroup, h/2, pw, cout/tgroup]
+ *   (NDHWC rows; the time-grouped fast stem's channels go back to their frames): the forward of the training step.
+ * avt_stem_wgrad_x3: the weight gradient of Conv3d(3, cout, [kt,7,7], stride [1,2,2], pad [pt,3,3]) in the pixel-pair form:
+ *   dw[cout][kt][7][4 pair taps][8 = pixel-in-pair * 4 + channel] fp32, ZEROED BY THE CALLER, accumulated with fp32 atomics;
+ *   pair tap dp, pixel p = column tap 2 dp + p - 1 (dp = p = 0 is the structural zero of the pair form: ignore it);
+ *   x_* = bf16 planes of avt_clip_planes_f32, dy fp32 [batch, to, h/2, pw, cout].  Split-plane bf16 arithmetic, 2^-16 per
+ *   product.  avt_stem_wgrad_x3_supported: (h/2) % 4 == 0, 8 <= pw <= 128, kt 1 or 5, cout 8 or a multiple of 16. */
+int avt_clip_planes_f32(const float* in, int batch, int t, int h, int w, int64_t sb, int64_t sc, int64_t st, int64_t sh,
+                        int64_t sw, void* out_hi, void* out_lo, int plane_dtype, void* stream);
+int avt_stem_conv_x3_f32(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* wscale,
+                         float* out, int batch, int t, int h, int pw, int cout, int kt, int st, int pt, int tgroup,
+                         int plane_dtype, void* stream);
+int avt_stem_wgrad_x3_supported(int h, int pw, int cout, int kt);
+int avt_stem_wgrad_x3(const void* x_hi, const void* x_lo, const float* dy, float* dw, int batch, int t, int h, int pw,
+                      int cout, int kt, int pt, void* stream);
+
 /* SuperSloMo interpolation at the jumps of the stitched video (contrastive_video_textures/interpolate.py:75-147, called from
  * validate.py:588-611): the passes around the two UNets, whose convolutions are avt_conv3d_igemm_x3 with relu = 2
  * (csrc/interp.hip).  Plane pairs as above (plane_dtype AVT_X3_*), NHWC rows; `mean3` is a HOST array of 3 floats.

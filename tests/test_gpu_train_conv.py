@@ -108,6 +108,90 @@ def test_stem_runs_on_zero_padded_channels(kt):
         train_ops._STEM_WGRAD_X3 = keep
 
 
+@pytest.mark.parametrize("layout", ["ncdhw", "ndhwc", "view"])
+@pytest.mark.parametrize("plane", ["f16", "bf16"])
+def test_clip_planes_split_the_clip(layout, plane):
+    """avt_clip_planes_f32: [B,3,T,H,W] fp32 of any strides -> hi / lo planes [B,T,H,W,4], value = hi + lo, 4th channel 0."""
+    from avtex import ops
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 3, 10, 12, device=DEV) * 2.0
+    if layout == "ndhwc":
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+    elif layout == "view":  # a strided window of a larger tensor (the batcher's target stack sliced per clip)
+        x = torch.randn(2, 3, 5, 12, 16, device=DEV)[:, :, 1:4, 1:11, 2:14]
+    dt = ops.X3_F16 if plane == "f16" else ops.X3_BF16
+    hi, lo = ops.clip_planes_f32(x, dt)
+    raw = torch.float16 if plane == "f16" else torch.bfloat16
+    got = hi.view(raw).float() + lo.view(raw).float()
+    want = torch.cat([x.permute(0, 2, 3, 4, 1), torch.zeros_like(x[:, :1]).permute(0, 2, 3, 4, 1)], -1)
+    tol = 2.0 ** -21 if plane == "f16" else 2.0 ** -15
+    assert got.shape == want.shape and float((got - want).abs().max()) <= tol * float(want.abs().max())
+    assert float(got[..., 3].abs().max()) == 0.0
+    hi_want = want.to(raw)
+    assert torch.equal(hi.view(raw), hi_want)  # the high plane is the rounded value itself
+
+
+@pytest.mark.parametrize("kt,cout,dims", [
+    (5, 8, (2, 8, 64, 64)),     # fast stem: 4 output frames per MFMA tile (time-grouped), 32 pixel pairs per row
+    (1, 64, (2, 4, 64, 64)),    # slow stem
+    (5, 8, (1, 8, 224, 224)),   # production rows: 112 pairs
+    (1, 64, (1, 2, 224, 224)),
+    (5, 8, (1, 4, 64, 64)),     # 4 frames: every frame tap meets the clip's ends
+])
+def test_stems_run_on_the_patch_kernels(kt, cout, dims):
+    """The stems of the training step on the patch-resident kernels (csrc/stem_conv.hip with fp32 output, csrc/stem_train.hip):
+    forward and weight gradient against fp64 autograd, next to what stock fp32 gives."""
+    from avtex import train_ops
+    torch.manual_seed(kt + dims[1])
+    b, t, h, w = dims
+    stem = nn.Conv3d(3, cout, (kt, 7, 7), stride=(1, 2, 2), padding=(kt // 2, 3, 3), bias=False).to(DEV)
+    stem = stem.to(memory_format=torch.channels_last_3d).train()
+    x = torch.randn(b, 3, t, h, w, device=DEV)
+    assert train_ops.conv_fusable(x, stem) and train_ops.stem_patch_ok(x, stem)
+    before = dict(train_ops.CALLS)
+    y = train_ops.conv3d(x, stem)
+    assert y.is_contiguous(memory_format=torch.channels_last_3d)
+    gy = _cl(torch.randn(y.shape, device=DEV))
+    y.backward(gy)
+    ran = {k: train_ops.CALLS[k] - before[k] for k in before}
+    assert ran["stem_fwd_patch"] == 1 and ran["wgrad_stem_patch"] == 1 and ran["wgrad_stem_x3"] == 0 and ran["miopen_wgrad"] == 0, ran
+    dwa = stem.weight.grad.clone()
+    stem64 = nn.Conv3d(3, cout, (kt, 7, 7), stride=(1, 2, 2), padding=(kt // 2, 3, 3), bias=False).to(DEV).double()
+    stem64.weight.data.copy_(stem.weight.detach().double())
+    y64 = stem64(x.double())
+    y64.backward(gy.double())
+    stem.zero_grad(set_to_none=True)
+    y32 = stem(x)
+    y32.backward(gy)
+    rel = lambda u, v: float((u.double() - v).norm()) / float(v.norm())
+    e_y, e_y32 = rel(y.detach(), y64.detach()), rel(y32.detach(), y64.detach())
+    e_w, e_w32 = rel(dwa, stem64.weight.grad), rel(stem.weight.grad, stem64.weight.grad)
+    print("stem kt=%d cout=%d %s: forward %.2e (stock fp32 %.2e), weight gradient %.2e (stock fp32 %.2e)" % (kt, cout, dims, e_y, e_y32, e_w, e_w32))
+    # forward: fp16 planes (2^-22 per product); weight gradient: bf16 planes (2^-16 per product, random signs)
+    assert e_y < 2e-6 and e_w < 1e-4, (e_y, e_w)
+    assert float((dwa.double() - stem64.weight.grad).abs().max()) < 2e-4 * float(stem64.weight.grad.abs().max())
+
+
+def test_stem_patch_path_follows_the_optimizer_and_can_be_switched_off():
+    from avtex import train_ops
+    torch.manual_seed(9)
+    stem = nn.Conv3d(3, 8, (5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+    x = torch.randn(1, 3, 8, 64, 64, device=DEV)
+    y0 = train_ops.conv3d(x, stem).detach().clone()
+    with torch.no_grad():
+        stem.weight.mul_(2.0)  # an in-place update (optimizer.step()): the cached LDS image must be rebuilt
+    y1 = train_ops.conv3d(x, stem).detach()
+    assert float((y1 - 2.0 * y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+    keep, train_ops._STEM_PATCH = train_ops._STEM_PATCH, 0
+    try:
+        before = train_ops.CALLS["stem_fwd_patch"]
+        y2 = train_ops.conv3d(x, stem).detach()
+        assert train_ops.CALLS["stem_fwd_patch"] == before
+        assert float((y2 - y1).abs().max()) <= 1e-5 * float(y1.abs().max())
+    finally:
+        train_ops._STEM_PATCH = keep
+
+
 @pytest.mark.parametrize("cin,cout,kernel,stride,pad,dims", [
     (16, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 5, 7)),          # fewer positions than one slab
     (24, 40, (3, 3, 3), (1, 2, 2), (1, 1, 1), (2, 3, 9, 11)),         # ragged everything, channel counts not powers of two

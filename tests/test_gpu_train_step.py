@@ -70,9 +70,11 @@ def test_config5_default_step_at_size_runs_the_hand_written_kernels(avt, dev):
     n_conv = sum(1 for mod in list(base.q_encoder.modules()) + list(base.t_encoder.modules()) if isinstance(mod, torch.nn.Conv3d))
     assert ran["conv_fwd_x3"] == n_conv, (ran, n_conv)  # 110 per encoder
     assert ran["conv_fwd_x3"] >= 2 * 100 and ran["bn_fwd"] >= 2 * 100 and ran["bn_bwd"] == ran["bn_fwd"], ran
-    assert ran["wgrad_x3"] + ran["wgrad_stem_x3"] + ran["miopen_wgrad"] == ran["conv_fwd_x3"], (ran, n_conv)
+    assert ran["wgrad_x3"] + ran["wgrad_stem_x3"] + ran["wgrad_stem_patch"] + ran["miopen_wgrad"] == ran["conv_fwd_x3"], (ran, n_conv)
     assert ran["wgrad_x3"] >= 2 * 100 and ran["dgrad_x3"] >= 2 * 80, ran
-    assert ran["miopen_wgrad"] == 0 and ran["wgrad_stem_x3"] == 4 and ran["miopen_dgrad"] + ran["dgrad_strided_x3"] == 2 * 16, ran  # the stems' wgrad; 16 strided input gradients per encoder
+    # the four stems on the patch-resident kernels (forward and weight gradient); 16 strided input gradients per encoder
+    assert ran["miopen_wgrad"] == 0 and ran["stem_fwd_patch"] == 4 and ran["wgrad_stem_patch"] == 4 and ran["wgrad_stem_x3"] == 0, ran
+    assert ran["miopen_dgrad"] + ran["dgrad_strided_x3"] == 2 * 16, ran
 
     out_s, loss_s, g_s = run(torch.float32, False)
     out_64, loss_64, g_64 = run(torch.float64, False)

@@ -64,6 +64,27 @@ def wgs(dy, x, dw, dims, cin, cout, kernel, stride, pad, out_dims, ldx, ldy, ldw
 
 
 ops.conv3d_igemm_x3_f32, ops.conv3d_wgrad_x3_f32, ops.conv3d_wgrad_x3_sub_f32 = fwd, wg, wgs
+_sf, _sw, _cp = ops.stem_conv_x3_f32, ops.stem_wgrad_x3, ops.clip_planes_f32
+
+
+def stem_fwd(xh, xl, wh, wl, ws, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype):
+    c = cout // tgroup
+    key = "fwd   stem (patch) cout%-3d kt%d in%s" % (c, kt - tgroup + 1, (batch, t, h, 2 * pw))
+    return timed(key, lambda: _sf(xh, xl, wh, wl, ws, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype),
+                 2.0 * out.numel() * (kt - tgroup + 1) * 49 * 3, 4.0 * out.numel() + 4.0 * xh.numel())
+
+
+def stem_wg(xh, xl, dy, batch, t, h, pw, cout, kt, pt):
+    key = "wgrad stem (patch) cout%-3d kt%d in%s" % (cout, kt, (batch, t, h, 2 * pw))
+    return timed(key, lambda: _sw(xh, xl, dy, batch, t, h, pw, cout, kt, pt), 2.0 * dy.numel() * kt * 49 * 3,
+                 4.0 * dy.numel() + 4.0 * xh.numel())
+
+
+def clip_planes(x, plane_dtype):
+    return timed("planes clip -> pixel-pair planes %s" % (tuple(x.shape),), lambda: _cp(x, plane_dtype), 0.0, 12.0 * x.numel() / 3 + 16.0 * x.numel() / 3)
+
+
+ops.stem_conv_x3_f32, ops.stem_wgrad_x3, ops.clip_planes_f32 = stem_fwd, stem_wg, clip_planes
 
 _bn_apply = train_ops._BNAct.apply
 _bf, _bb = train_ops._BNAct.forward, train_ops._BNAct.backward
