@@ -6,7 +6,9 @@
 // train_fp32_steady_state_kernels.log): MIOpenBatchNormFwdTrainSpatial 11.7 %, MIOpenBatchNormBwdSpatial 11.2 %, the
 // residual adds / ReLUs / their backward ~8 % as separate elementwise passes.  Here the normalise, the shortcut add and the
 // ReLU are ONE pass over the rows in each direction, next to one statistics pass: forward = read x twice (+ r once), write
-// y once; backward = read dy, y, x twice, write dx (+ dr) once.  HBM-bound; channels-last rows [M, C] (the physical layout
+// y once; backward = read dy, x (and y when there was a shortcut) twice, write dx (+ dr) once — without a shortcut the ReLU mask
+// is RECOMPUTED from x with the forward's own expression (same operations in the same order, -ffp-contract=off: the same bits),
+// which takes the forward output out of both backward passes (a third of their bytes).  HBM-bound; channels-last rows [M, C] (the physical layout
 // of a channels_last_3d tensor), C a power of two >= 8 (every BatchNorm of SlowFast-8x8-R50).
 // Statistics accumulate in fp64 with NO atomics (hipcc lowers atomicAdd(double) to a compare-and-swap loop, which under a
 // few thousand workgroups per address cost 6x the whole pass — measured, profiles/r02/train_fused_bn_atomics.log): per-thread
@@ -170,14 +172,23 @@ __global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
   const int quad = my_quad(a);
   const float4 mu = reinterpret_cast<const float4*>(a.mean)[quad];
   const float4 is = reinterpret_cast<const float4*>(a.invstd)[quad];
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), be = sc;
+  if (!a.y && a.relu) {  // the forward's scale = invstd * gamma (bn_fwd_finalize_kernel) and shift
+    const float4 gm = reinterpret_cast<const float4*>(a.gamma)[quad];
+    sc = make_float4(is.x * gm.x, is.y * gm.y, is.z * gm.z, is.w * gm.w);
+    be = reinterpret_cast<const float4*>(a.beta)[quad];
+  }
   double p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
     float4 g = reinterpret_cast<const float4*>(a.dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
     if (a.y) {  // ReLU backward: the gradient passes where the forward output was positive
       const float4 yv = reinterpret_cast<const float4*>(a.y)[i];
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    } else if (a.relu) {  // ... recomputed: bn_fwd_apply_kernel's expression, no shortcut
+      g.x = (v.x - mu.x) * sc.x + be.x > 0.f ? g.x : 0.f; g.y = (v.y - mu.y) * sc.y + be.y > 0.f ? g.y : 0.f;
+      g.z = (v.z - mu.z) * sc.z + be.z > 0.f ? g.z : 0.f; g.w = (v.w - mu.w) * sc.w + be.w > 0.f ? g.w : 0.f;
     }
-    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
     p0[0] += g.x; p1[0] += (double)g.x * ((v.x - mu.x) * is.x);
     p0[1] += g.y; p1[1] += (double)g.y * ((v.y - mu.y) * is.y);
     p0[2] += g.z; p1[2] += (double)g.z * ((v.z - mu.z) * is.z);
@@ -205,14 +216,20 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(BnArgs a) {
   const float4 k0 = reinterpret_cast<const float4*>(a.coef)[quad];
   const float4 k1 = reinterpret_cast<const float4*>(a.coef + a.C)[quad];
   const float4 gs = make_float4(gm.x * is.x, gm.y * is.y, gm.z * is.z, gm.w * is.w);
+  const float4 sc = make_float4(is.x * gm.x, is.y * gm.y, is.z * gm.z, is.w * gm.w);  // the forward's scale (same product)
+  float4 be = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!a.y && a.relu) be = reinterpret_cast<const float4*>(a.beta)[quad];
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
     float4 g = reinterpret_cast<const float4*>(a.dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
     if (a.y) {
       const float4 yv = reinterpret_cast<const float4*>(a.y)[i];
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    } else if (a.relu) {
+      g.x = (v.x - mu.x) * sc.x + be.x > 0.f ? g.x : 0.f; g.y = (v.y - mu.y) * sc.y + be.y > 0.f ? g.y : 0.f;
+      g.z = (v.z - mu.z) * sc.z + be.z > 0.f ? g.z : 0.f; g.w = (v.w - mu.w) * sc.w + be.w > 0.f ? g.w : 0.f;
     }
     if (a.dres) reinterpret_cast<float4*>(a.dres)[i] = g;
-    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
     float4 o;
     o.x = gs.x * (g.x - k0.x - (v.x - mu.x) * is.x * k1.x);
     o.y = gs.y * (g.y - k0.y - (v.y - mu.y) * is.y * k1.y);
@@ -284,17 +301,20 @@ extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int6
   return avt::check_launch("avt_bn_train_fwd");
 }
 
-extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma, const float* save_mean,
-                                const float* save_invstd, void* ws, int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta,
-                                void* stream) {
+extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma, const float* beta,
+                                const float* save_mean, const float* save_invstd, int relu, void* ws, int64_t ws_size, float* dx,
+                                float* dres, float* dgamma, float* dbeta, void* stream) {
   AVT_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "avt_bn_train_bwd: NULL pointer");
+  AVT_REQUIRE(!relu || y || (beta && avt::aligned16(beta) && !dres),
+              "avt_bn_train_bwd: a ReLU needs the forward output y, or (no shortcut) beta to recompute its mask from x");
   AVT_REQUIRE(avt::aligned16(dy) && avt::aligned16(x) && avt::aligned16(dx) && (!y || avt::aligned16(y)) && (!dres || avt::aligned16(dres)) &&
                   avt::aligned16(gamma) && avt::aligned16(save_mean) && avt::aligned16(save_invstd),
               "avt_bn_train_bwd: rows and per-channel vectors must be 16-byte aligned");
   BnArgs a = {};
   const int rc = geometry(a, "avt_bn_train_bwd", m, c, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
   if (rc) return rc;
-  a.dy = dy; a.y = y; a.x = x; a.gamma = gamma; a.mean = save_mean; a.invstd = save_invstd;
+  a.dy = dy; a.y = relu ? y : nullptr; a.x = x; a.gamma = gamma; a.beta = beta; a.mean = save_mean; a.invstd = save_invstd;
+  a.relu = relu;
   a.out = dx; a.dres = dres; a.dgamma = dgamma; a.dbeta = dbeta;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(a.blocks), dim3(kT), 0, st, a);

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 2  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); round 3 adds entry points only */
+#define AVT_ABI_VERSION 3  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_bwd takes beta and relu (round 3) */
 
 typedef enum {
   AVT_OK = 0,
@@ -434,16 +434,17 @@ int avt_clip_pack_gather_u8(const uint8_t* frames, int n_frames, int height, int
  * Statistics are summed in fp64 in a fixed order (no atomics): results are bitwise reproducible.
  * fwd: writes save_mean / save_invstd [c]; running_mean / running_var (both or neither) are updated with
  *      momentum and the unbiased batch variance as torch.nn.BatchNorm3d does.
- * bwd: y = the forward output when relu was applied (its sign is the ReLU mask) else NULL; dres (may be NULL) receives the
- *      shortcut's gradient; dgamma / dbeta [c]. */
+ * bwd: relu = whether the forward applied one; its mask is the sign of y (the forward output) or, with y NULL — allowed when
+ *      the forward had no shortcut — recomputed from x with the forward's own expression (needs beta; a third fewer bytes);
+ *      dres (may be NULL) receives the shortcut's gradient; dgamma / dbeta [c]. */
 int64_t avt_bn_train_ws_bytes(int64_t m, int c); /* workspace both calls need (16-byte aligned); -1 outside the domain */
 int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma,
                      const float* beta, float eps, float momentum, int relu, void* ws, int64_t ws_size,
                      float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked /* incremented when not NULL */, void* stream);
 int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma,
-                     const float* save_mean, const float* save_invstd, void* ws, int64_t ws_size, float* dx,
-                     float* dres, float* dgamma, float* dbeta, void* stream);
+                     const float* beta, const float* save_mean, const float* save_invstd, int relu, void* ws,
+                     int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta, void* stream);
 
 /* The training form of avt_conv3d_igemm_x3 (csrc/conv_x3.hip, IO32): fp32 NDHWC rows in [batch*t*h*w, ldi], fp32 rows out
  * [M, ldo], no bias / residual / activation — an fp32-grade Conv3d(bias=False) on channels-last tensors for the forward
