@@ -215,8 +215,26 @@ def wrap_ddp(model, device, local):
         enc = getattr(net, name, None)
         if isinstance(enc, VGGish) and hasattr(enc, "fc"):
             enc.fc.requires_grad_(False)
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=[local] if device.type == "cuda" else None,
-                                                     find_unused_parameters=True)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local] if device.type == "cuda" else None,
+                                                    find_unused_parameters=True)
+    if device.type == "cuda":
+        ddp.register_comm_hook(None, _allreduce_after_every_stream)
+    return ddp
+
+
+def _allreduce_after_every_stream(_state, bucket):
+    """DDP's default all-reduce (mean over ranks), started only after EVERY stream of the training forward has produced its
+    part of the bucket: the query encoder runs on a side stream (models.ContrastivePredictionTemporal.forward) and autograd
+    replays its backward there, while the reducer orders the collective after the stream of the LAST gradient only."""
+    import torch.distributed as dist
+    from . import models
+    buf = bucket.buffer()
+    cur = torch.cuda.current_stream(buf.device)
+    for s in models.training_side_streams(buf.device) + [torch.cuda.default_stream(buf.device)]:
+        if s != cur:
+            cur.wait_stream(s)
+    buf.div_(dist.get_world_size())
+    return dist.all_reduce(buf, async_op=True).get_future().then(lambda f: f.value()[0])
 
 
 def save_checkpoint(state, is_best, filename):

@@ -120,6 +120,12 @@ def _side_stream(device):
     return s
 
 
+def training_side_streams(device):
+    """The side streams training forwards have used on `device` (main.wrap_ddp's gradient hook waits for them: a bucket can
+    hold gradients written on the query encoder's stream and on the step's own)."""
+    return [s for k, s in _SIDE_STREAMS.items() if k[1] == (device.index if device.index is not None else torch.cuda.current_device())]
+
+
 class ContrastivePredictionTemporal(nn.Module):
     def __init__(self, q_image_enc_model, t_image_enc_model, audio_enc_model, model_type, fc_dim, temp=0.1,
                  window=20, stride=2, threshold=0.20, mini_batchsize=20, dropout=0.5, enc_arch="resnet",

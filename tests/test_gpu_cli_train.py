@@ -165,3 +165,49 @@ print("DDP_OK", float(loss))
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DDP_OK" in r.stdout, r.stderr[-3000:]
+
+
+def test_ddp_gradients_with_the_query_encoder_on_its_side_stream(avt, dev):
+    """Training under DistributedDataParallel with the query encoder on a side stream (models.ContrastivePredictionTemporal.
+    forward): main.wrap_ddp's hook starts a bucket's all-reduce after BOTH streams — the gradients equal the single-stream,
+    unwrapped step's."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import copy, os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import avtex
+from avtex import models
+from tiny_encoders import TinySlowFast, seeded
+from avtex import dist as adist
+rank, world, local = adist.init_from_env()
+dev = torch.device("cuda", local)
+base = avtex.ContrastivePredictionTemporal(seeded(TinySlowFast, 1), seeded(TinySlowFast, 2), None, 1, 128, temp=0.1, window=5,
+                                           stride=2, enc_arch="slowfast", img_size=32).to(dev).train()
+g = torch.Generator().manual_seed(0)
+qf = [torch.randn(2, 3, 8, 32, 32, generator=g).to(dev), torch.randn(2, 3, 32, 32, 32, generator=g).to(dev)]
+tf = [torch.randn(2, 4, 3, 8, 32, 32, generator=g).to(dev), torch.randn(2, 4, 3, 32, 32, 32, generator=g).to(dev)]
+crit = avtex.InfoNCECriterion()
+lab = torch.zeros(2, dtype=torch.long, device=dev)
+def grads(net, streams):
+    models._TRAIN_STREAMS = streams
+    for _ in range(3):  # (several steps: the side stream and the bucket hooks are exercised while earlier work is in flight)
+        net.zero_grad(set_to_none=True)
+        crit(net(qf, tf), lab).backward()
+    torch.cuda.synchronize()
+    mod = net.module if hasattr(net, "module") else net
+    return {k: p.grad.detach().clone() for k, p in mod.named_parameters() if p.grad is not None}
+want = grads(copy.deepcopy(base), 0)
+from avtex.main import wrap_ddp
+got = grads(wrap_ddp(copy.deepcopy(base), dev, local), 1)
+assert models.training_side_streams(dev), "the side stream was not used"
+assert set(got) == set(want)
+worst = max(float((got[k] - want[k]).abs().max()) / (float(want[k].abs().max()) + 1e-30) for k in want)
+assert worst < 1e-4, worst
+print("DDP_STREAMS_OK", worst)
+''' % (root, root)
+    env = dict(os.environ, AVT_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP_STREAMS_OK" in r.stdout, r.stderr[-3000:]
