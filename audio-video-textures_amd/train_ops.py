@@ -150,6 +150,108 @@ def bn_act(x, bn, res=None, relu=True):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+# Gradient accumulation over micro-batches (one optimizer step = several forward/backward passes: config 5's batch of 8 items
+# on fewer than 8 GPUs, each item with its own BatchNorm statistics as a DataParallel replica has, main.py:420).  Left to
+# autograd, every parameter's gradient is added into .grad by its own 5-microsecond launch per pass (640 per item) and every
+# weight-gradient kernel is preceded by its own memset: 39 ms of a 540 ms step in launches that move no data to speak of
+# (profiles/r03/train_step_kernels_before_accumulator.log).  Here a pass's gradients are taken from .grad with ONE
+# multi-tensor add, and the weight-gradient kernels write into slices of one arena zeroed by ONE memset per pass.
+_ARENA = None
+
+
+class _GradArena:
+    def __init__(self):
+        self.buf, self.used, self.want = {}, {}, {}
+
+    def reset(self):
+        """Start of a pass: zero what the last pass used; grow to what it asked for."""
+        for dev in list(self.buf) + [d for d in self.want if d not in self.buf]:
+            want = self.want.get(dev, 0)
+            if dev not in self.buf or self.buf[dev].numel() < want:
+                self.buf[dev] = torch.zeros(int(want * 1.05) + 1024, dtype=torch.float32, device=dev)
+            elif self.used.get(dev, 0):
+                self.buf[dev][: self.used[dev]].zero_()
+            self.used[dev], self.want[dev] = 0, 0
+
+    def take(self, n, device):
+        n4 = (n + 3) // 4 * 4  # 16-byte aligned slices
+        self.want[device] = self.want.get(device, 0) + n4
+        buf, off = self.buf.get(device), self.used.get(device, 0)
+        if buf is None or off + n4 > buf.numel():
+            return None  # (first pass, or a pass larger than the last: the caller allocates and zeroes its own)
+        self.used[device] = off + n4
+        return buf[off : off + n]
+
+
+class MicroBatchGradients:
+    """Sums the gradients of several forward/backward passes into the parameters' .grad with one multi-tensor add per pass.
+
+        acc = MicroBatchGradients(model.parameters())
+        acc.begin(len(items))                # instead of optimizer.zero_grad()
+        for k, item in enumerate(items):
+            if k == len(items) - 1: acc.before_last_backward()   # (needed under DistributedDataParallel: its all-reduce
+            loss(item).backward()                                #  must see the sum — the last pass accumulates in .grad)
+            if k < len(items) - 1: acc.after_backward()
+        acc.finish(); optimizer.step()
+
+    Same sum as autograd's own accumulation (fp32 adds in the same order per parameter)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.acc = None
+        self.seen = False
+        self.arena = _GradArena()
+
+    def begin(self, passes):
+        """passes: forward/backward passes of this optimizer step (1: nothing to accumulate, the arena stays off)."""
+        global _ARENA
+        for p in self.params:
+            p.grad = None
+        live = [a for a in (self.acc or []) if a is not None]
+        if live:
+            torch._foreach_zero_(live)
+        self.seen = False
+        _ARENA = self.arena if passes > 1 else None
+        if passes > 1:
+            self.arena.reset()
+
+    def after_backward(self):
+        if self.acc is None:
+            self.acc = [None] * len(self.params)
+        src, dst = [], []
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            if self.acc[i] is None:  # own storage (a gradient may be a slice of the arena, which the next pass zeroes)
+                self.acc[i] = torch.zeros_like(p.grad)
+            dst.append(self.acc[i])
+            src.append(p.grad)
+            p.grad = None
+        if src:
+            torch._foreach_add_(dst, src)
+        self.seen = True
+        self.arena.reset()
+
+    def before_last_backward(self):
+        """Hand the sum so far to autograd: the next backward accumulates into it (and DDP all-reduces the total)."""
+        if self.seen:
+            for p, a in zip(self.params, self.acc):
+                if a is not None:
+                    p.grad = a
+
+    def finish(self):
+        global _ARENA
+        _ARENA = None
+        # the gradients the last pass produced as arena slices live on in .grad only where autograd accumulated into the
+        # accumulator's own tensors; a parameter first seen in the last pass keeps an arena slice: give it its own storage
+        if self.acc is None:
+            self.acc = [None] * len(self.params)
+        for i, p in enumerate(self.params):
+            if p.grad is not None and self.acc[i] is None:
+                p.grad = p.grad.clone()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 # Convolutions of the training step on the split-plane MFMA kernel (csrc/conv_x3.hip, IO32 form): the forward of every
 # Conv3d(bias=False) with channel counts in multiples of 8, and the input gradient of the stride-1 ones (a convolution of
 # dy with the flipped, transposed filter).  fp32 tensors in and out; 2^-22 (forward, fp16 planes) / 2^-16 (dgrad, bf16
@@ -247,10 +349,17 @@ def _conv_backward(ctx, dy, dalias):
         taps = kernel[0] * kernel[1] * kernel[2]
         if (_WGRAD_X3 and cin % 8 == 0 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64 and
                 weight.is_contiguous(memory_format=torch.channels_last_3d)):
-            dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
             CALLS["wgrad_x3"] += 1
-            ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1),
-                                    (x.shape[0], x.shape[2], x.shape[3], x.shape[4]), cin, cout, kernel, stride, padding, cin, cout)
+            dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
+            flat = _ARENA.take(weight.numel(), weight.device) if _ARENA is not None else None
+            if flat is not None:  # a zeroed slice of the micro-batch's gradient arena: no memset launch per convolution
+                dw = flat.view(cout, kernel[0], kernel[1], kernel[2], cin).permute(0, 4, 1, 2, 3)
+                ops.conv3d_wgrad_x3_sub_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), flat, dims, cin, cout, kernel, stride,
+                                            padding, (0, 0, 0), cin, cout, taps * cin, False)
+            else:
+                dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
+                ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1), dims, cin, cout,
+                                        kernel, stride, padding, cin, cout)
         elif (_WGRAD_X3 and _STEM_WGRAD_X3 and cin == 3 and x.shape[1] == 8 and kernel[1] * kernel[2] <= 49 and
               max(x.numel(), dy.numel()) < (1 << 31) - 64):
             # the stems: 3 input channels travel as 4 of the forward's 8-channel padded clip; a [kt,7,7] filter is kt slices of

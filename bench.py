@@ -381,21 +381,34 @@ def train_bench(args, rank, world, dev):
     amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if args.train_dtype == "bf16" else contextlib.nullcontext
     losses = []
 
+    from avtex import train_ops
+    grads = train_ops.MicroBatchGradients(model.parameters()) if args.grad_accumulator else None
+
     def step():
-        opt.zero_grad(set_to_none=True)
+        if grads is not None:
+            grads.begin(items)
+        else:
+            opt.zero_grad(set_to_none=True)
         idxs = rng.randint(0, len(ds), size=items)
         step_loss = torch.zeros((), device=dev)
         for k, i in enumerate(idxs):
             q, t, _, _ = bat.batch(torch.tensor([int(i)]))
             if channels_last:
                 q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
-            sync = contextlib.nullcontext() if (world == 1 or k == items - 1) else net.no_sync()
+            last = k == items - 1
+            sync = contextlib.nullcontext() if (world == 1 or last) else net.no_sync()
             with sync:
                 with amp():
                     out = net(q, t)
                 loss = crit(out.float(), torch.zeros(1, dtype=torch.long, device=dev)) / items
+                if grads is not None and last:
+                    grads.before_last_backward()
                 loss.backward()
+                if grads is not None and not last:
+                    grads.after_backward()
             step_loss += loss.detach()
+        if grads is not None:
+            grads.finish()
         opt.step()
         losses.append(float(step_loss))  # ONE host read per step, as the reference's loop has (train.py:118 loss.item() per batch)
 
@@ -499,6 +512,8 @@ def main():
                     help="--mode train: ndhwc = channels_last_3d weights + the fused BatchNorm passes (csrc/bn_train.hip), the "
                          "product's default (main.py --train_layout); ncdhw = torch's default layout, stock BatchNorm")
     ap.add_argument("--train-channels-last", action="store_true", help="(old spelling of --train-layout ndhwc)")
+    ap.add_argument("--no-grad-accumulator", dest="grad_accumulator", action="store_false",
+                    help="--mode train: leave the per-item gradient sums to autograd (one add launch per parameter and item)")
     ap.add_argument("--train-profile", action="store_true", help="--mode train: print the top device kernels of one steady-state step")
     ap.add_argument("--precision-windows", type=int, default=128)
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 4],

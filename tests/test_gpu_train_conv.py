@@ -281,3 +281,55 @@ def test_training_convolution_at_full_size_scales():
     assert torch.equal(dx4, 4 * dx1)
     assert float((y4 - 4 * y1).norm()) <= 1e-6 * float((4 * y1).norm())
     assert float((dw4 - 16 * dw1).norm()) <= 1e-5 * float((16 * dw1).norm())
+
+
+@pytest.mark.parametrize("passes", [1, 3])
+def test_micro_batch_gradients_equal_autograd_accumulation(passes):
+    """train_ops.MicroBatchGradients (one multi-tensor add per pass, weight gradients written into slices of one zeroed
+    arena) gives the sums autograd's own .grad accumulation gives, step after step (the arena is re-zeroed, not re-used dirty)."""
+    from avtex import train_ops
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = nn.Conv3d(8, 16, (1, 3, 3), padding=(0, 1, 1), bias=False)
+            self.b1 = nn.BatchNorm3d(16)
+            self.c2 = nn.Conv3d(16, 8, (3, 1, 1), padding=(1, 0, 0), bias=False)
+            self.unused = nn.Linear(4, 4)
+
+        def forward(self, x):
+            return train_ops.conv3d(train_ops.bn_act(train_ops.conv3d(x, self.c1), self.b1), self.c2)
+
+    torch.manual_seed(passes)
+    net = Net().to(DEV).to(memory_format=torch.channels_last_3d).train()
+    xs = [_cl(torch.randn(2, 8, 4, 12, 12, device=DEV)) for _ in range(passes)]
+
+    def run(accumulate):
+        out = []
+        acc = train_ops.MicroBatchGradients(net.parameters()) if accumulate else None
+        for step in range(3):  # the second and third steps meet a used arena / used accumulators
+            if acc is not None:
+                acc.begin(passes)
+            else:
+                net.zero_grad(set_to_none=True)
+            for k, x in enumerate(xs):
+                last = k == passes - 1
+                if acc is not None and last:
+                    acc.before_last_backward()
+                (net(x * (1.0 + step)).square().mean()).backward()
+                if acc is not None and not last:
+                    acc.after_backward()
+            if acc is not None:
+                acc.finish()
+            torch.cuda.synchronize()
+            out.append({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+        return out
+
+    before = train_ops.CALLS["wgrad_x3"]
+    want, got = run(False), run(True)
+    assert train_ops.CALLS["wgrad_x3"] - before == 2 * 3 * passes * 2
+    assert train_ops._ARENA is None  # switched off again after finish()
+    for w, g in zip(want, got):
+        assert set(w) == set(g) and "unused.weight" not in g
+        for k in w:
+            assert float((w[k] - g[k]).abs().max()) <= 2e-5 * float(w[k].abs().max()) + 1e-12, k
