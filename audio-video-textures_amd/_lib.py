@@ -84,6 +84,7 @@ SIGNATURES = {
     "avt_pw_chain_x3": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
                         _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, _vp],
     "avt_conv3d_igemm_x3": [_vp] * 10 + [C.c_int] * 26 + [_vp, _vp],
+    "avt_conv3d_igemm_x3_wblk": [_vp] * 10 + [C.c_int] * 26 + [_vp, _vp],
     "avt_clip_pack_u8_ndhwc4_x3": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                    C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp],
     "avt_maxpool_hw3s2_ndhwc_x3": [_vp] * 4 + [C.c_int] * 8 + [_vp],

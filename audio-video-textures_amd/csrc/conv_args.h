@@ -56,6 +56,7 @@ struct ConvArgs {
   int pointwise;                // 1x1x1 / stride 1 / pad 0: rows need no decode
   const uint16_t* wfrag;        // XB kernel: weights in MFMA-fragment order [Cout/32][nup][2][64][8] (walk order of K), or NULL
   int nup;                      // ... units per 32-row tile in that array (>= units walked + 3)
+  int wblk;                     // x3 XL tile: weight planes in K-blocked order [K / 32][Cout][32] (avt_conv3d_igemm_x3_wblk)
   unsigned wf_bytes;
   int ors, oH, oW;              // output row remap: position (f, ho, wo) -> row (f * oH + ors * ho) * oW + ors * wo (ors = 1: none)
   // split-bf16 ("x3") kernels: the low-order planes, same geometry as in / wt / res / out (conv_x3.hip)

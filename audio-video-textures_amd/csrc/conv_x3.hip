@@ -516,6 +516,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
     for (int u = 0; u < BU; ++u) {
       const unsigned sel = ksel & wsel[u];
       boffs[u] = (((unsigned)wrow[u] * 2u + kc2) & sel) | (kOob & ~sel);
+      // K-blocked weight planes [K / 32][Cout][32]: the 16 rows of a wave-instruction are 1 KB of consecutive bytes (8 whole
+      // cache lines) instead of 16 half lines 2 K bytes apart — measured +5 % on the long-K layers (profiles/r03/probe_xl_traffic.log)
+      if (a.wblk) boffs[u] = (((unsigned)(kt * a.Cout + n0 + r0 + 128 * u) * 64u + (unsigned)c4 * 16u) & sel) | (kOob & ~sel);
     }
 #ifdef AVT_XL_TRAFFIC_EXPERIMENT  // TIMING ONLY (results are garbage): what full-cache-line operand fetches would buy
     if constexpr (V >= 3) {
@@ -870,12 +873,12 @@ extern "C" int avt_conv3d_igemm_x3_xl_picked(int cout, int k, int m) {
   return (cout % 256 == 0 && k >= min_k && k <= kMaxTabSteps * 64 && m >= 256 * 64) ? 1 : 0;
 }
 
-extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
-                                   const float* bias, const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
-                                   const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
-                                   int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi,
-                                   int ldo, int ldr, int relu, int out_row_stride, int out_h, int out_w, int plane_dtype,
-                                   const float* wscale, void* stream) {
+static int igemm_x3_impl(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
+                         const float* bias, const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
+                         const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                         int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi,
+                         int ldo, int ldr, int relu, int out_row_stride, int out_h, int out_w, int plane_dtype,
+                         const float* wscale, void* stream, int wblk) {
   AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_conv3d_igemm_x3: plane_dtype must be 0 (bf16) or 1 (fp16)");
   AVT_REQUIRE(!wscale || avt::aligned16(wscale), "avt_conv3d_igemm_x3: wscale must be 16-byte aligned");
   AVT_REQUIRE(in_lo && wt_lo && out_lo && (!res_hi == !res_lo), "avt_conv3d_igemm_x3: every tensor needs both planes");
@@ -893,9 +896,12 @@ extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const v
   a.wscale = wscale;
   a.wfrag = nullptr;
   a.nup = 0;
+  a.wblk = wblk;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // long-K layers whose output channels fill 256-wide tiles: the XL tile (AVT_CONV_X3_XL=0: the 128 x 128 tile everywhere)
   static const int xl = avt::env_int_flag("AVT_CONV_X3_XL", 1);
+  AVT_REQUIRE(!wblk || (xl && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M) && a.K % 32 == 0),
+              "avt_conv3d_igemm_x3_wblk: K-blocked weights are the 256 x 256 tile's (avt_conv3d_igemm_x3_xl_picked, K %% 32 == 0)");
   if (xl && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M)) {
     static const int xlv = avt::env_int_flag("AVT_CONV_X3_XL_V", 1);  // 0: the un-rotated K loop (A/B runs)
     if (xlv == 0) return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, 0>(a, s) : launch_x3_xl<false, 0>(a, s);
@@ -914,6 +920,30 @@ extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const v
   if (cout <= 32) return launch_x3<128, 32, 32, false>(a, s);
   if (cout <= 64) return launch_x3<128, 64, 64, false>(a, s);
   return launch_x3<128, 128, 64, false>(a, s);
+}
+
+extern "C" int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
+                                   const float* bias, const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
+                                   const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                                   int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi,
+                                   int ldo, int ldr, int relu, int out_row_stride, int out_h, int out_w, int plane_dtype,
+                                   const float* wscale, void* stream) {
+  return igemm_x3_impl(in_hi, in_lo, wt_hi, wt_lo, bias, res_hi, res_lo, out_hi, out_lo, ktab, batch, t, h, w, cin, cout, kt, kh, kw,
+                       st, sh, sw, pt, ph, pw, to, ho, wo, ldi, ldo, ldr, relu, out_row_stride, out_h, out_w, plane_dtype, wscale,
+                       stream, 0);
+}
+
+// the same convolution with the weight planes in K-blocked order [K / 32][cout][32] (see include/avt.h): only where
+// avt_conv3d_igemm_x3_xl_picked(cout, K, M) holds and K % 32 == 0
+extern "C" int avt_conv3d_igemm_x3_wblk(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
+                                        const float* bias, const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
+                                        const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                                        int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi,
+                                        int ldo, int ldr, int relu, int out_row_stride, int out_h, int out_w, int plane_dtype,
+                                        const float* wscale, void* stream) {
+  return igemm_x3_impl(in_hi, in_lo, wt_hi, wt_lo, bias, res_hi, res_lo, out_hi, out_lo, ktab, batch, t, h, w, cin, cout, kt, kh, kw,
+                       st, sh, sw, pt, ph, pw, to, ho, wo, ldi, ldo, ldr, relu, out_row_stride, out_h, out_w, plane_dtype, wscale,
+                       stream, 1);
 }
 
 // fp32 rows in, fp32 rows out, split-plane arithmetic in between (the IO32 form of the kernel): see include/avt.h
@@ -936,6 +966,7 @@ extern "C" int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const
   a.wscale = wscale;
   a.wfrag = nullptr;
   a.nup = 0;
+  a.wblk = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (plane_dtype == AVT_X3_F16) {
     if (cout <= 32) return launch_x3<128, 32, 32, true, true>(a, s);

@@ -35,6 +35,7 @@ _FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "0"))   # frames walked per
 _FUSE_BLOCK_X3 = int(os.environ.get("AVT_FUSE_BLOCK_X3", "1"))  # contract-grade mode: fast-pathway bottlenecks as one kernel
 _FUSE_TCHUNK_X3 = int(os.environ.get("AVT_FUSE_TCHUNK_X3", "0"))  # frames walked per workgroup; 0 = by width
 _CHAIN_X3 = int(os.environ.get("AVT_PW_CHAIN_X3", "1"))        # contract-grade mode: slow res2 c (+ residual) -> next a in one pass
+_WBLK_X3 = int(os.environ.get("AVT_WBLK_X3", "1"))            # contract-grade mode: K-blocked weight planes for the 256 x 256 tile
 _C33_X3 = int(os.environ.get("AVT_C33_X3", "1"))              # contract-grade mode: slow res2 b conv on the direct-operand kernel
 _PW_X3 = int(os.environ.get("AVT_PW_X3", "1"))               # contract-grade mode: pointwise layers on the streaming kernel
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
@@ -176,7 +177,7 @@ class FusedConv:
             raise AvtError("FusedConv: input channels must be a multiple of 8 (got %d)" % self.cin)
         if cout % 8:  # pad the output channels with zero filters (the caller's buffer must be that wide)
             raise AvtError("FusedConv: output channels must be a multiple of 8 (got %d)" % cout)
-        self.wfrag = self.wt_lo = self.wscale = None
+        self.wfrag = self.wt_lo = self.wscale = self.wblk = None
         taps = self.kernel[0] * self.kernel[1] * self.kernel[2]
         if x3 is not None:
             wf = wt.detach().float()
@@ -190,6 +191,12 @@ class FusedConv:
                 self.wscale = (1.0 / sc).float().contiguous().to(device)
             hi, lo = split_planes(wf, x3)
             self.wt, self.wt_lo = hi.to(device), lo.to(device)
+            # layers the 256 x 256 tile can run: the planes once more in K-blocked order [K / 32, Cout, 32] (a wave's 16 weight
+            # rows per staging instruction are 8 whole cache lines instead of 16 half lines; avt_conv3d_igemm_x3_wblk)
+            k_all = hi.shape[1]
+            if _WBLK_X3 and cout % 256 == 0 and k_all % 32 == 0 and ops.conv3d_igemm_x3_xl_picked(cout, k_all, 1 << 20):
+                blk = lambda p: p.view(cout, k_all // 32, 32).permute(1, 0, 2).contiguous().to(device)
+                self.wblk = (blk(hi), blk(lo))
             # pointwise stride-1 layers: the streaming kernel (csrc/pw_x3.hip) with LDS-resident weight fragments
             self.pw = None
             if (_PW_X3 and relu != 2 and self.kernel == (1, 1, 1) and self.stride == (1, 1, 1) and self.pad == (0, 0, 0) and
@@ -283,10 +290,14 @@ class FusedConv:
             out = new_act(m, self.cout, od, self.dev, self.x3 is not None)
 
         def launch_x3():
-            ops.conv3d_igemm_x3(x.ptrs, self.wt, self.wt_lo, self.bias, res.ptrs if res is not None else None, out.ptrs, tab,
+            m_rows = od[0] * od[1] * od[2] * od[3]
+            blocked = self.wblk is not None and ops.conv3d_igemm_x3_xl_picked(self.cout, self.wt.shape[1], m_rows)
+            wh, wl = self.wblk if blocked else (self.wt, self.wt_lo)
+            ops.conv3d_igemm_x3(x.ptrs, wh, wl, self.bias, res.ptrs if res is not None else None, out.ptrs, tab,
                                 x.dims, self.cin, self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld,
                                 res.ld if res is not None else 0, self.relu if relu is None else relu, self.x3,
-                                wscale=self.wscale, out_dims=od[1:] if any(self.crop) else (0, 0, 0), out_rows=out_rows)
+                                wscale=self.wscale, out_dims=od[1:] if any(self.crop) else (0, 0, 0), out_rows=out_rows,
+                                wblk=blocked)
 
         def launch_pw():
             m_rows = x.dims[0] * x.dims[1] * x.dims[2] * x.dims[3]

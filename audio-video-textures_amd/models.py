@@ -112,8 +112,10 @@ _TRAIN_STREAMS = int(os.environ.get("AVT_TRAIN_STREAMS", "1"))
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device):
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+def _side_stream(device, cur):
+    """The side stream that belongs to stream `cur` of `device` (a training loop that runs its items on several streams gets
+    one per stream: the query encoders of two items in flight do not queue behind each other)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
     s = _SIDE_STREAMS.get(key)
     if s is None:
         s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -188,7 +190,7 @@ class ContrastivePredictionTemporal(nn.Module):
         q_side = None
         if self.training and _TRAIN_STREAMS and slowfast and q_f[0].is_cuda and self.model_type != 2:
             cur = torch.cuda.current_stream(q_f[0].device)
-            q_side = _side_stream(q_f[0].device)
+            q_side = _side_stream(q_f[0].device, cur)
             q_side.wait_stream(cur)
             with torch.cuda.stream(q_side):
                 q_v = self._run_enc(self.q_encoder, q_f).view(batch_size, -1)

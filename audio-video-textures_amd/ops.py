@@ -304,20 +304,22 @@ def conv3d_igemm(x_ptr, wt, bias, res_ptr, out_ptr, ktab, dims, cin, cout, kerne
 
 
 def conv3d_igemm_x3(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo,
-                    ldr, relu, plane_dtype, wscale=None, out_dims=(0, 0, 0), out_rows=None):
+                    ldr, relu, plane_dtype, wscale=None, out_dims=(0, 0, 0), out_rows=None, wblk=False):
     """Contract-grade (split-plane) convolution: x_ptrs / res_ptrs / out_ptrs = (hi, lo) device addresses of the two
-    16-bit planes (res_ptrs None = no residual); wt_hi / wt_lo bf16-typed [Cout, K] planes; see include/avt.h."""
+    16-bit planes (res_ptrs None = no residual); wt_hi / wt_lo bf16-typed [Cout, K] planes — wblk: in K-blocked order
+    [K / 32, Cout, 32] (avt_conv3d_igemm_x3_wblk: layers the XL tile runs); see include/avt.h."""
     b, t, h, w = dims
     _dev(wt_hi, "wt_hi", torch.bfloat16)
     _dev(wt_lo, "wt_lo", torch.bfloat16)
     orr = out_rows if out_rows is not None else (1, 0, 0)
     rh, rl = res_ptrs if res_ptrs is not None else (0, 0)
-    _lib.check(_lib.lib().avt_conv3d_igemm_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(wt_hi), _p(wt_lo), _p(bias),
+    fn = _lib.lib().avt_conv3d_igemm_x3_wblk if wblk else _lib.lib().avt_conv3d_igemm_x3
+    _lib.check(fn(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(wt_hi), _p(wt_lo), _p(bias),
                                               C.c_void_p(rh) if rh else None, C.c_void_p(rl) if rl else None,
                                               C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]), _p(ktab), b, t, h, w,
                                               int(cin), int(cout), *kernel, *stride, *pad, *out_dims, int(ldi), int(ldo),
                                               int(ldr), int(relu), int(orr[0]), int(orr[1]), int(orr[2]),
-                                              int(plane_dtype), _p(wscale), _stream()), "avt_conv3d_igemm_x3")
+                                              int(plane_dtype), _p(wscale), _stream()), "avt_conv3d_igemm_x3_wblk" if wblk else "avt_conv3d_igemm_x3")
 
 
 def conv3d_igemm_x3_f32(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype, add=None):

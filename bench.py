@@ -384,6 +384,11 @@ def train_bench(args, rank, world, dev):
     from avtex import train_ops
     grads = train_ops.MicroBatchGradients(model.parameters()) if args.grad_accumulator else None
 
+    # --item-streams 2: consecutive items alternate between two streams; the forward of item k + 1 is ordered after the forward
+    # of item k (BatchNorm running statistics, the batcher's generator, the weight-plane caches) and its backward after the
+    # backward of item k (gradient sums), so what overlaps is forward(k + 1) with backward(k)
+    istreams = [torch.cuda.Stream(device=dev) for _ in range(args.item_streams)] if args.item_streams > 1 else None
+
     def step():
         if grads is not None:
             grads.begin(items)
@@ -391,22 +396,38 @@ def train_bench(args, rank, world, dev):
             opt.zero_grad(set_to_none=True)
         idxs = rng.randint(0, len(ds), size=items)
         step_loss = torch.zeros((), device=dev)
+        main = torch.cuda.current_stream(dev)
+        f_done, prev = None, None
         for k, i in enumerate(idxs):
-            q, t, _, _ = bat.batch(torch.tensor([int(i)]))
-            if channels_last:
-                q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
             last = k == items - 1
-            sync = contextlib.nullcontext() if (world == 1 or last) else net.no_sync()
-            with sync:
-                with amp():
-                    out = net(q, t)
-                loss = crit(out.float(), torch.zeros(1, dtype=torch.long, device=dev)) / items
-                if grads is not None and last:
-                    grads.before_last_backward()
-                loss.backward()
-                if grads is not None and not last:
-                    grads.after_backward()
-            step_loss += loss.detach()
+            s = istreams[k % len(istreams)] if istreams else main
+            if istreams:
+                s.wait_stream(main)
+            with torch.cuda.stream(s):
+                if f_done is not None:
+                    s.wait_event(f_done)
+                q, t, _, _ = bat.batch(torch.tensor([int(i)]))
+                if channels_last:
+                    q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
+                sync = contextlib.nullcontext() if (world == 1 or last) else net.no_sync()
+                with sync:
+                    with amp():
+                        out = net(q, t)
+                    loss = crit(out.float(), torch.zeros(1, dtype=torch.long, device=dev)) / items
+                    if istreams:
+                        f_done = torch.cuda.Event()
+                        f_done.record(s)
+                        if prev is not None and prev is not s:
+                            s.wait_stream(prev)
+                    if grads is not None and last:
+                        grads.before_last_backward()
+                    loss.backward()
+                    if grads is not None and not last:
+                        grads.after_backward()
+                step_loss += loss.detach()
+            prev = s
+        if istreams:
+            main.wait_stream(prev)
         if grads is not None:
             grads.finish()
         opt.step()
@@ -512,6 +533,8 @@ def main():
                     help="--mode train: ndhwc = channels_last_3d weights + the fused BatchNorm passes (csrc/bn_train.hip), the "
                          "product's default (main.py --train_layout); ncdhw = torch's default layout, stock BatchNorm")
     ap.add_argument("--train-channels-last", action="store_true", help="(old spelling of --train-layout ndhwc)")
+    ap.add_argument("--item-streams", type=int, default=1,
+                    help="--mode train: streams the items of a step alternate between (2: forward of item k+1 under backward of item k)")
     ap.add_argument("--no-grad-accumulator", dest="grad_accumulator", action="store_false",
                     help="--mode train: leave the per-item gradient sums to autograd (one add launch per parameter and item)")
     ap.add_argument("--train-profile", action="store_true", help="--mode train: print the top device kernels of one steady-state step")

@@ -338,6 +338,16 @@ int avt_conv3d_igemm_x3(const void* in_hi, const void* in_lo, const void* wt_hi,
  * k >= 256, m >= 16384.  Same arithmetic, same results to the last bit as the other tiles is NOT promised (fp32 accumulation
  * order over K differs in the 32-wide steps); both are held to the fp32 reference by the same tolerance. */
 int avt_conv3d_igemm_x3_xl_picked(int cout, int k, int m);
+/* avt_conv3d_igemm_x3 for a layer its XL tile runs (avt_conv3d_igemm_x3_xl_picked(cout, k, m) == 1 and k % 32 == 0; an error
+ * otherwise), with the weight planes in K-BLOCKED order wt[k / 32][cout][32] (element (n, kk) of the [cout, K] matrix at
+ * ((kk / 32) * cout + n) * 32 + kk % 32): the 16 weight rows a wave stages per instruction are then 1 KB of consecutive bytes
+ * (8 whole cache lines) instead of 16 half lines.  Same arithmetic and results as avt_conv3d_igemm_x3. */
+int avt_conv3d_igemm_x3_wblk(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
+                             const float* bias, const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
+                             const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                             int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi,
+                             int ldo, int ldr, int relu, int out_row_stride, int out_h, int out_w, int plane_dtype,
+                             const float* wscale, void* stream);
 /* The [1,3,3] 64 -> 64 stride-1 convolution (+ BN + ReLU) of the slow pathway's res2 bottlenecks on plane pairs
  * (csrc/conv33_x3.hip; the contract-grade form of avt_conv33_c64_bf16): activations are MFMA operands as loaded from global
  * memory (no LDS staging, zero padding by out-of-range buffer offsets), the weights live in LDS as fragments.

@@ -37,10 +37,10 @@ orig = ops.conv3d_igemm_x3
 
 
 def spy(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr, relu,
-        plane_dtype, wscale=None, out_dims=(0, 0, 0), out_rows=None):
-    shapes.append("cin%d cout%d k%s s%s in%s%s" % (cin, cout, kernel, stride, tuple(dims), " +res" if res_ptrs else ""))
+        plane_dtype, wscale=None, out_dims=(0, 0, 0), out_rows=None, wblk=False):
+    shapes.append("cin%d cout%d k%s s%s in%s%s%s" % (cin, cout, kernel, stride, tuple(dims), " +res" if res_ptrs else "", " wblk" if wblk else ""))
     return orig(x_ptrs, wt_hi, wt_lo, bias, res_ptrs, out_ptrs, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, ldr,
-                relu, plane_dtype, wscale, out_dims, out_rows)
+                relu, plane_dtype, wscale, out_dims, out_rows, wblk)
 
 
 def hook(name, launch, flops, nbytes):
