@@ -68,6 +68,11 @@ struct StemArgs {
   // training forward (avt_stem_conv_x3_f32): `out` is an fp32 NDHWC tensor [B, To * tgroup, Ho, Wo, Cout / tgroup] — the
   // time-grouped channels go back to their frames on the way out
   int out_f32;
+  // frame-major tiles of the time-grouped form (non-pooled split-plane entries): tile n of a 32-channel group holds output
+  // frames 2n, 2n + 1 (8 channels each), so it meets frame taps 2n .. 2n + kt0 only (kt0 = the convolution's own frame taps)
+  // and the other (tap, tile) pairs — structural zeros of the block-Toeplitz weights, 4 of 16 for [5,7,7] — are skipped.
+  // 0 = the classic image (a lane's two accumulators are 8 consecutive channels)
+  int fm_kt0;
 };
 
 constexpr int RB = 4;   // conv rows a workgroup owns in the plain form (pooled: RBP = 8, plus one recomputed row above them)
@@ -218,6 +223,9 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
     lstore();
     __syncthreads();
     if (!POOL && dt + 1 < dt_hi) gload(dt + 1);  // in flight under this frame's MFMAs
+    bool act[NT];  // uniform
+#pragma unroll
+    for (int n = 0; n < NT; ++n) act[n] = POOL || PL == 0 || !a.fm_kt0 || (dt >= 2 * n && dt <= 2 * n + a.fm_kt0);
 #pragma unroll
     for (int dh = 0; dh < 7; ++dh) {
       i32x4 bf[NT], bfl[NT];
@@ -236,6 +244,7 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
           const i32x4 afl = *reinterpret_cast<const i32x4*>(lpl + o);
 #pragma unroll
           for (int n = 0; n < NT; ++n) {  // small terms first: wl*ah + wh*al + wh*ah
+            if (!act[n]) continue;
             acc[i][n] = mfma16<PL>(bfl[n], af, acc[i][n]);
             acc[i][n] = mfma16<PL>(bf[n], afl, acc[i][n]);
             acc[i][n] = mfma16<PL>(bf[n], af, acc[i][n]);
@@ -279,6 +288,40 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
     pk.w = avt::pack_bf16x2(v[6], v[7]);
     return pk;
   };
+  if constexpr (!POOL && PL != 0) {
+    if (a.fm_kt0) {  // uniform.  Frame-major tiles: this lane's rows 4q .. 4q + 3 of tile n are channels n_base + 16n + 4q ..
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int c = n_base + 16 * n + 4 * q;
+        if (c >= a.Cout) continue;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + c);
+        if (a.wscale) sv = *reinterpret_cast<const float4*>(a.wscale + c);
+        const int cf = a.Cout / a.tgroup, j = c / cf, cin_f = c - j * cf;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          if (w * TPW + i >= R * MT) continue;
+          float v[4] = {acc[i][n][0] * sv.x + bv.x, acc[i][n][1] * sv.y + bv.y, acc[i][n][2] * sv.z + bv.z, acc[i][n][3] * sv.w + bv.w};
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = avt::relu_keep_nan(v[e]);
+          }
+          const int64_t pos = (int64_t)((b * a.To + to) * a.Ho + ho0 + unit_row(i)) * WO + unit_mt(i) * 16 + l15;
+          if (a.out_f32) {
+            const int64_t of = ((int64_t)(((b * a.To + to) * a.tgroup + j) * a.Ho + ho0 + unit_row(i)) * WO + unit_mt(i) * 16 + l15) * cf + cin_f;
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + of) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 oh, ol;
+            avt::split2<PL == 2>(v[0], v[1], oh.x, ol.x);
+            avt::split2<PL == 2>(v[2], v[3], oh.y, ol.y);
+            *reinterpret_cast<uint2*>(a.out + pos * a.Cout + c) = oh;
+            *reinterpret_cast<uint2*>(a.out_lo + pos * a.Cout + c) = ol;
+          }
+        }
+      }
+      return;
+    }
+  }
   if constexpr (!POOL) {
     if (c0 < a.Cout) {
 #pragma unroll
@@ -446,6 +489,7 @@ int fill(StemArgs& a, const char* what, const void* in, const void* wt, const fl
   a.out_lo = nullptr;
   a.wscale = nullptr;
   a.out_f32 = 0;
+  a.fm_kt0 = 0;
   AVT_REQUIRE(a.To > 0, "%s: no output frames", what);
   const int64_t in_b = (int64_t)batch * t * h * pw * 16, wt_b = (int64_t)cout * kt * KF * 2;
   AVT_REQUIRE(in_b < (1ll << 32) - 64 && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
@@ -486,11 +530,23 @@ extern "C" int avt_stem_conv_pool_bf16(const void* in, const void* wt, const flo
                    : launch<2, true>(a, batch, s, "avt_stem_conv_pool_bf16");
 }
 
+// frames_per_tile (the time-grouped form, st = frames per 32-channel group > 1): 0 = the classic weight image; 2 = the
+// frame-major image (a 16-channel tile = 2 output frames of 8 channels) whose structurally-zero (frame tap, tile) pairs are skipped
+static int fm_arg(StemArgs& a, const char* what, int frames_per_tile, int cout, int kt, int st) {
+  AVT_REQUIRE(frames_per_tile == 0 || (frames_per_tile == 2 && st == 4 && cout == 32 && kt > st - 1),
+              "%s: frames_per_tile is 0, or 2 for the 4-frame x 8-channel time-grouped form (st 4, cout 32)", what);
+  a.fm_kt0 = frames_per_tile ? kt - st + 1 : 0;
+  a.tgroup = frames_per_tile ? st : a.tgroup;
+  return AVT_OK;
+}
+
 extern "C" int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
                                 const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout, int kt,
-                                int st, int pt, int relu, int plane_dtype, void* stream) {
+                                int st, int pt, int relu, int plane_dtype, int frames_per_tile, void* stream) {
   StemArgs a;
-  const int rc = fill(a, "avt_stem_conv_x3", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu);
+  int rc = fill(a, "avt_stem_conv_x3", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu);
+  if (rc) return rc;
+  rc = fm_arg(a, "avt_stem_conv_x3", frames_per_tile, cout, kt, st);
   if (rc) return rc;
   AVT_REQUIRE(in_lo && wt_lo && out_lo && avt::aligned16(in_lo) && avt::aligned16(wt_lo) && avt::aligned16(out_lo) &&
                   (!wscale || avt::aligned16(wscale)),
@@ -509,10 +565,13 @@ extern "C" int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void
 // the training forward (train_ops._StemX3): fp32 NDHWC out, no bias, no ReLU (BatchNorm follows in train mode); see include/avt.h
 extern "C" int avt_stem_conv_x3_f32(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* wscale,
                                     float* out, int batch, int t, int h, int pw, int cout, int kt, int st, int pt, int tgroup,
-                                    int plane_dtype, void* stream) {
+                                    int plane_dtype, int frames_per_tile, void* stream) {
   StemArgs a;
-  const int rc = fill(a, "avt_stem_conv_x3_f32", in_hi, wt_hi, nullptr, out, batch, t, h, pw, cout, kt, st, pt, 0);
+  int rc = fill(a, "avt_stem_conv_x3_f32", in_hi, wt_hi, nullptr, out, batch, t, h, pw, cout, kt, st, pt, 0);
   if (rc) return rc;
+  rc = fm_arg(a, "avt_stem_conv_x3_f32", frames_per_tile, cout, kt, st);
+  if (rc) return rc;
+  AVT_REQUIRE(!frames_per_tile || tgroup == st, "avt_stem_conv_x3_f32: the frame-major form has tgroup == st");
   AVT_REQUIRE(in_lo && wt_lo && avt::aligned16(in_lo) && avt::aligned16(wt_lo) && (!wscale || avt::aligned16(wscale)),
               "avt_stem_conv_x3_f32: every operand needs both planes, 16-byte aligned");
   AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_stem_conv_x3_f32: bad plane_dtype");

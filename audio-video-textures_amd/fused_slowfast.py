@@ -36,6 +36,7 @@ _FUSE_BLOCK_X3 = int(os.environ.get("AVT_FUSE_BLOCK_X3", "1"))  # contract-grade
 _FUSE_TCHUNK_X3 = int(os.environ.get("AVT_FUSE_TCHUNK_X3", "0"))  # frames walked per workgroup; 0 = by width
 _CHAIN_X3 = int(os.environ.get("AVT_PW_CHAIN_X3", "1"))        # contract-grade mode: slow res2 c (+ residual) -> next a in one pass
 _WBLK_X3 = int(os.environ.get("AVT_WBLK_X3", "1"))            # contract-grade mode: K-blocked weight planes for the 256 x 256 tile
+_STEM_FM_X3 = int(os.environ.get("AVT_STEM_FM_X3", "1"))      # contract-grade mode: frame-major tiles in the time-grouped fast stem
 _C33_X3 = int(os.environ.get("AVT_C33_X3", "1"))              # contract-grade mode: slow res2 b conv on the direct-operand kernel
 _PW_X3 = int(os.environ.get("AVT_PW_X3", "1"))               # contract-grade mode: pointwise layers on the streaming kernel
 _STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
@@ -324,10 +325,15 @@ class FusedConv:
         return out
 
 
-def stem_lds_image(wt, kt):
+def stem_lds_image(wt, kt, frame_major=False):
     """Packed stem weights [Cout, kt*7*4*8] -> the LDS image order of csrc/stem_conv.hip (include/avt.h):
-    [Cout/32, kt, 7 dh, 2 tiles, 4 dp, 16 rows, 8], channel = 32*group + 8*(row//4) + 4*tile + row%4."""
+    [Cout/32, kt, 7 dh, 2 tiles, 4 dp, 16 rows, 8], channel = 32*group + 8*(row//4) + 4*tile + row%4 — or, frame_major (the
+    time-grouped fast stem in the split-plane kernels), channel = 32*group + 16*tile + row: a tile is two output FRAMES and
+    the kernel skips the frame taps a tile never meets."""
     cout = wt.shape[0]
+    if frame_major:
+        w = wt.reshape(cout // 32, 2, 4, 4, kt, 7, 4, 8)  # [G, tile, q, i, dt, dh, dp, 8]
+        return w.permute(0, 4, 5, 1, 6, 2, 3, 7).contiguous().reshape(cout // 32, -1)
     w = wt.reshape(cout // 32, 4, 2, 4, kt, 7, 4, 8)  # [G, q, tile, i, dt, dh, dp, 8]
     return w.permute(0, 4, 5, 2, 6, 1, 3, 7).contiguous().reshape(cout // 32, -1)
 
@@ -358,12 +364,17 @@ def stem_conv(stem, device, tgroup=1, x3=None):
                                  (kt // 2, 3, 2), (0, 0, 1)), x3=x3)
         conv.tgroup, conv.frame_channels = g, c
         conv.alg_flops_per_row = g * 2.0 * (kt * kh * kw * 3) * c
-        conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1) if conv.cout % 32 == 0 else None
-        conv.wt_lds_lo = stem_lds_image(conv.wt_lo, kt + g - 1) if conv.cout % 32 == 0 and x3 is not None else None
+        # split-plane kernels: frame-major tiles (4 frames x 8 channels only), whose structurally-zero frame taps are skipped
+        conv.frames_per_tile = 2 if (_STEM_FM_X3 and x3 is not None and g == 4 and c == 8) else 0
+        fm = conv.frames_per_tile > 0
+        conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1, fm) if conv.cout % 32 == 0 else None
+        conv.wt_lds_lo = stem_lds_image(conv.wt_lo, kt + g - 1, fm) if conv.cout % 32 == 0 and x3 is not None else None
+        if fm:  # the pooled kernel (off by default) reads the classic image
+            conv.wt_lds_pool = (stem_lds_image(conv.wt, kt + g - 1), stem_lds_image(conv.wt_lo, kt + g - 1))
         return conv
     conv = FusedConv(None, None, True, device,
                      packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)), x3=x3)
-    conv.tgroup, conv.frame_channels = 1, c
+    conv.tgroup, conv.frame_channels, conv.frames_per_tile = 1, c, 0
     conv.alg_flops_per_row = 2.0 * (kt * kh * kw * 3) * c
     conv.wt_lds = stem_lds_image(conv.wt, kt) if conv.cout % 32 == 0 else None
     conv.wt_lds_lo = stem_lds_image(conv.wt_lo, kt) if conv.cout % 32 == 0 and x3 is not None else None
@@ -976,8 +987,10 @@ class SlowFastMFMA(nn.Module):
             if out is None:
                 out = new_act(pd[0] * pd[1] * pd[2] * pd[3], cf, pd, self.dev, True)
 
+            wlp = getattr(conv, "wt_lds_pool", None) or (conv.wt_lds, conv.wt_lds_lo)
+
             def launch():
-                ops.stem_conv_pool_x3(x.ptrs, conv.wt_lds, conv.wt_lds_lo, conv.bias, conv.wscale, out.ptrs, b, t, h, w // 2,
+                ops.stem_conv_pool_x3(x.ptrs, wlp[0], wlp[1], conv.bias, conv.wscale, out.ptrs, b, t, h, w // 2,
                                       conv.cout, kt, conv.stride[0], conv.pad[0], conv.tgroup, out.ld, self.x3)
 
             if PROFILER is None:
@@ -994,7 +1007,8 @@ class SlowFastMFMA(nn.Module):
 
             def launch():
                 ops.stem_conv_x3(x.ptrs, conv.wt_lds, conv.wt_lds_lo, conv.bias, conv.wscale, y.ptrs, b, t, h, w // 2,
-                                 conv.cout, conv.kernel[0], conv.stride[0], conv.pad[0], self.x3, relu=True)
+                                 conv.cout, conv.kernel[0], conv.stride[0], conv.pad[0], self.x3, relu=True,
+                                 frames_per_tile=conv.frames_per_tile)
 
             if PROFILER is None:
                 launch()

@@ -361,14 +361,16 @@ def conv3d_wgrad_x3_sub_f32(dy, x, dw, dims, cin, cout, kernel, stride, pad, out
                                                       int(ldw), int(bool(zero_dw)), _stream()), "avt_conv3d_wgrad_x3_sub_f32")
 
 
-def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True):
-    """stem_conv on plane pairs (contract-grade mode); wt_hi / wt_lo = fused_slowfast.stem_lds_image of each weight plane."""
+def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True,
+                 frames_per_tile=0):
+    """stem_conv on plane pairs (contract-grade mode); wt_hi / wt_lo = fused_slowfast.stem_lds_image of each weight plane
+    (frames_per_tile = 2: its frame-major form for the 4-frame x 8-channel time-grouped stem)."""
     _dev(wt_hi, "wt_hi", torch.bfloat16)
     _dev(wt_lo, "wt_lo", torch.bfloat16)
     _lib.check(_lib.lib().avt_stem_conv_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(wt_hi), _p(wt_lo), _p(bias),
                                            _p(wscale), C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]), int(batch), int(t),
                                            int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(bool(relu)),
-                                           int(plane_dtype), _stream()), "avt_stem_conv_x3")
+                                           int(plane_dtype), int(frames_per_tile), _stream()), "avt_stem_conv_x3")
 
 
 def clip_planes_f32(x, plane_dtype):
@@ -386,14 +388,14 @@ def clip_planes_f32(x, plane_dtype):
     return hi, lo
 
 
-def stem_conv_x3_f32(x_hi, x_lo, wt_hi, wt_lo, wscale, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype):
+def stem_conv_x3_f32(x_hi, x_lo, wt_hi, wt_lo, wscale, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype, frames_per_tile=0):
     """The stems' training forward: stem_conv_x3 with fp32 NDHWC output [batch, to*tgroup, h/2, pw, cout/tgroup], no bias / ReLU."""
     _dev(wt_hi, "wt_hi", torch.bfloat16)
     _dev(wt_lo, "wt_lo", torch.bfloat16)
     _dev(out, "out", torch.float32, contiguous=False)
     _lib.check(_lib.lib().avt_stem_conv_x3_f32(_p(x_hi), _p(x_lo), _p(wt_hi), _p(wt_lo), _p(wscale), _p(out), int(batch), int(t),
                                                int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(tgroup),
-                                               int(plane_dtype), _stream()), "avt_stem_conv_x3_f32")
+                                               int(plane_dtype), int(frames_per_tile), _stream()), "avt_stem_conv_x3_f32")
 
 
 def stem_wgrad_x3_supported(h, pw, cout, kt):

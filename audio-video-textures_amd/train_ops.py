@@ -465,7 +465,8 @@ def _stem_weight_image(weight, g):
         mx = wt.abs().amax(dim=1).clamp_min(1e-30)
         sc = torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
         hi, lo = split_planes(wt * sc.view(-1, 1), ops.X3_F16)
-        img = (stem_lds_image(hi, kt + g - 1), stem_lds_image(lo, kt + g - 1), (1.0 / sc).float().contiguous())
+        fm = g == 4 and c == 8  # frame-major tiles: the kernel skips the frame taps a tile never meets
+        img = (stem_lds_image(hi, kt + g - 1, fm), stem_lds_image(lo, kt + g - 1, fm), (1.0 / sc).float().contiguous(), 2 if fm else 0)
     if len(_STEM_IMAGES) > 64:
         for k in [k for k, v in _STEM_IMAGES.items() if v[0]() is None]:
             del _STEM_IMAGES[k]
@@ -481,11 +482,11 @@ class _StemX3(torch.autograd.Function):
         c, kt = weight.shape[0], weight.shape[2]
         g = _stem_tgroup(c, t)
         xh, xl = ops.clip_planes_f32(x, ops.X3_F16)
-        wh, wl, wscale = _stem_weight_image(weight, g)
+        wh, wl, wscale, fpt = _stem_weight_image(weight, g)
         y = torch.empty((b, c, t, h // 2, w // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
         CALLS["conv_fwd_x3"] += 1
         CALLS["stem_fwd_patch"] += 1
-        ops.stem_conv_x3_f32(xh, xl, wh, wl, wscale, y, b, t, h, w // 2, g * c, kt + g - 1, g, kt // 2, g, ops.X3_F16)
+        ops.stem_conv_x3_f32(xh, xl, wh, wl, wscale, y, b, t, h, w // 2, g * c, kt + g - 1, g, kt // 2, g, ops.X3_F16, frames_per_tile=fpt)
         ctx.save_for_backward(x, weight)
         return y
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 3  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_bwd takes beta and relu (round 3) */
+#define AVT_ABI_VERSION 3  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_bwd takes beta and relu, avt_stem_conv_x3 takes frames_per_tile (round 3) */
 
 typedef enum {
   AVT_OK = 0,
@@ -399,9 +399,13 @@ int avt_pw_chain_x3(const void* x_hi, const void* x_lo, int ldx, int k1, const v
                     void* z_hi, void* z_lo, int ldz, int n2, int64_t m, int plane_dtype, void* stream);
 /* avt_stem_conv_bf16 in the same arithmetic (csrc/stem_conv.hip, patch-resident): in / wt / out as plane pairs, wt_* in the
  * LDS image order of avt_stem_conv_bf16 (fused_slowfast.stem_lds_image of each plane), wscale [cout] or NULL. */
+/* frames_per_tile (round 3, ABI 3): 0 = that image; 2 = its FRAME-MAJOR form for the time-grouped fast stem (st = 4 output
+ * frames x 8 channels = cout 32 over kt = 5 + 3 frame taps): channel 16*tile + row, i.e. a 16-channel MFMA tile holds two output
+ * frames and meets frame taps 2*tile .. 2*tile + 5 only — the other (tap, tile) pairs are structural zeros of the block-Toeplitz
+ * weights and are skipped (4 of 16).  Same results. */
 int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
                      const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
-                     int kt, int st, int pt, int relu, int plane_dtype, void* stream);
+                     int kt, int st, int pt, int relu, int plane_dtype, int frames_per_tile, void* stream);
 /* avt_stem_conv_x3 with MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused (the plane-pair form of avt_stem_conv_pool_bf16): the
  * conv + BN + ReLU output stays on chip as an fp32 tile, the pooled tensor [batch, To*tgroup, h/4, pw/2, cout/tgroup] is
  * written as hi / lo planes with row stride ldo (a channel slice of a wider buffer is allowed).  A workgroup owns 4 conv
@@ -498,7 +502,7 @@ int avt_clip_planes_f32(const float* in, int batch, int t, int h, int w, int64_t
                         int64_t sw, void* out_hi, void* out_lo, int plane_dtype, void* stream);
 int avt_stem_conv_x3_f32(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* wscale,
                          float* out, int batch, int t, int h, int pw, int cout, int kt, int st, int pt, int tgroup,
-                         int plane_dtype, void* stream);
+                         int plane_dtype, int frames_per_tile /* as avt_stem_conv_x3 */, void* stream);
 int avt_stem_wgrad_x3_supported(int h, int pw, int cout, int kt);
 int avt_stem_wgrad_x3(const void* x_hi, const void* x_lo, const float* dy, float* dw, int batch, int t, int h, int pw,
                       int cout, int kt, int pt, void* stream);

@@ -67,10 +67,10 @@ ops.conv3d_igemm_x3_f32, ops.conv3d_wgrad_x3_f32, ops.conv3d_wgrad_x3_sub_f32 = 
 _sf, _sw, _cp = ops.stem_conv_x3_f32, ops.stem_wgrad_x3, ops.clip_planes_f32
 
 
-def stem_fwd(xh, xl, wh, wl, ws, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype):
+def stem_fwd(xh, xl, wh, wl, ws, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype, frames_per_tile=0):
     c = cout // tgroup
     key = "fwd   stem (patch) cout%-3d kt%d in%s" % (c, kt - tgroup + 1, (batch, t, h, 2 * pw))
-    return timed(key, lambda: _sf(xh, xl, wh, wl, ws, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype),
+    return timed(key, lambda: _sf(xh, xl, wh, wl, ws, out, batch, t, h, pw, cout, kt, st, pt, tgroup, plane_dtype, frames_per_tile),
                  2.0 * out.numel() * (kt - tgroup + 1) * 49 * 3, 4.0 * out.numel() + 4.0 * xh.numel())
 
 

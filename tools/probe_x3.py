@@ -62,9 +62,9 @@ def spy_pw(x_ptrs, ldx, k, w_hi, w_lo, bias, wscale, res_ptrs, ldr, y_ptrs, ldy,
 orig_stem = ops.stem_conv_x3
 
 
-def spy_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True):
-    shapes.append("stem (LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)" % (cout, kt, st, batch, t, h, pw))
-    return orig_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu)
+def spy_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True, frames_per_tile=0):
+    shapes.append("stem (LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)%s" % (cout, kt, st, batch, t, h, pw, " frame-major" if frames_per_tile else ""))
+    return orig_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu, frames_per_tile)
 
 
 pool_recs = []
