@@ -213,3 +213,48 @@ def test_sharded_plane_exchange_world2_equals_world1():
     mp.spawn(_walk_worker_planes, args=(2, 29751, n, two), nprocs=2, join=True)
     assert np.array_equal(two["sim"], one["sim"]) and np.array_equal(two["cnt"], one["cnt"])
     assert list(two["frames"]) == list(one["frames"])
+
+
+def _accum_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from avtex import dist as adist, train_ops
+
+    adist.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    xs = torch.randn(world, 3, 4, 6, generator=torch.Generator().manual_seed(1))  # [rank][micro-batch][rows][features]
+    acc = train_ops.MicroBatchGradients(net.parameters())
+    for step in range(2):  # the second step meets used accumulators
+        acc.begin(3)
+        for k in range(3):
+            last = k == 2
+            ctx = ddp.no_sync() if not last else __import__("contextlib").nullcontext()
+            with ctx:
+                loss = ddp(xs[rank, k] * (1.0 + step)).square().sum()
+                if last:
+                    acc.before_last_backward()
+                loss.backward()
+                if not last:
+                    acc.after_backward()
+        acc.finish()
+    if rank == 0:
+        ret["grads"] = [p.grad.clone() for p in net.parameters()]
+    dist.destroy_process_group()
+
+
+def test_micro_batch_gradients_under_ddp_world2():
+    """train_ops.MicroBatchGradients with DistributedDataParallel (gloo, 2 ranks, 3 passes per rank and step): the all-reduce of
+    the last pass sees the sum of all passes — the gradients are the mean over ranks of each rank's summed passes."""
+    ret = mp.Manager().dict()
+    mp.spawn(_accum_worker, args=(2, 29761, ret), nprocs=2, join=True)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    xs = torch.randn(2, 3, 4, 6, generator=torch.Generator().manual_seed(1))
+    for r in range(2):
+        for k in range(3):
+            (net(xs[r, k] * 2.0).square().sum() / 2).backward()  # step 1's scale; mean over the 2 ranks
+    for got, p in zip(ret["grads"], net.parameters()):
+        assert torch.allclose(got, p.grad, rtol=1e-5, atol=1e-6), (got, p.grad)
