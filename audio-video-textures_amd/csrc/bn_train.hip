@@ -18,6 +18,10 @@
 // pass reads two floats per channel instead of redoing the fp64 arithmetic in every thread.
 // A thread walks the rows with a stride that is a multiple of the row's float4 chunks, so it always sees the SAME four
 // channels and keeps their partial sums / scale / shift in registers.
+// GROUPS (round 3): the rows are `groups` equal, consecutive slabs, each with its OWN batch statistics — the items of a batch as
+// the reference's DataParallel replicas see them (per-replica BatchNorm, main.py:420) in ONE launch over the whole batch:
+// blockIdx.y walks the groups in the streaming passes, a finalize wavefront walks them in order for its channel (so the running
+// statistics receive the groups' updates in item order, as a loop over the items would apply them).
 #include "avt_common.h"
 
 namespace {
@@ -45,7 +49,8 @@ struct BnArgs {
   long long* tracked;   // forward: nn.BatchNorm's num_batches_tracked, incremented here when not NULL (no launch of its own)
   float* dgamma;        // backward outputs
   float* dbeta;
-  int64_t M;            // rows
+  int64_t M;            // rows PER GROUP
+  int groups;           // slabs of M rows with statistics of their own (1: plain BatchNorm)
   int C;
   int relu;
   float eps, momentum;
@@ -84,13 +89,13 @@ __device__ __forceinline__ void block_reduce_store(const BnArgs& a, const double
 }
 
 // One wavefront per channel: sum that channel's two partials over the workgroups that saw it, in a fixed order.
-__device__ __forceinline__ void channel_sums(const BnArgs& a, int c, double& s0, double& s1) {
+__device__ __forceinline__ void channel_sums(const BnArgs& a, int g, int c, double& s0, double& s1) {
   const int quad = c >> 2, e = c & 3, lane = threadIdx.x & 63;
   const int slot = (quad % a.nq) * 8 + e;
   const int first = a.unit > 1 ? quad / kT : 0;  // wide rows: workgroup b holds quads (b % unit) * kT ...
   double t0 = 0.0, t1 = 0.0;
   for (int b = first + lane * a.unit; b < a.blocks; b += 64 * a.unit) {
-    const double* row = a.part + (size_t)b * a.nq * 8;
+    const double* row = a.part + ((size_t)g * a.blocks + b) * a.nq * 8;
     t0 += row[slot];
     t1 += row[slot + 4];
   }
@@ -103,7 +108,12 @@ __device__ __forceinline__ void channel_sums(const BnArgs& a, int c, double& s0,
   s1 = t1;
 }
 
+// this workgroup's group: its slab of the activation (in float4 chunks) and its rows of partials
+__device__ __forceinline__ int64_t slab(const BnArgs& a) { return (int64_t)blockIdx.y * a.nchunk; }
+
 __global__ __launch_bounds__(kT) void bn_fwd_stats_kernel(BnArgs a) {
+  a.x += 4 * slab(a);
+  a.part += (size_t)blockIdx.y * a.blocks * a.nq * 8;
   double p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
   // (two rows of the walk per trip: both loads are issued before either is summed — same order of additions, twice the bytes
   //  in flight per thread)
@@ -126,28 +136,36 @@ __global__ __launch_bounds__(kT) void bn_fwd_stats_kernel(BnArgs a) {
 
 __global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // grid C / 4, a wavefront per channel
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  double s0, s1;
-  channel_sums(a, c, s0, s1);
-  if ((threadIdx.x & 63) != 0) return;
-  if (a.tracked && c == 0) *a.tracked += 1;
-  const double mean = s0 / (double)a.M;
-  double var = s1 / (double)a.M - mean * mean;  // biased variance (normalisation)
-  var = var > 0.0 ? var : 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
-  const float sc = invstd * a.gamma[c];
-  a.coef[c] = sc;
-  a.coef[a.C + c] = a.beta[c] - (float)mean * sc;
-  a.save_mean[c] = (float)mean;
-  a.save_invstd[c] = invstd;
-  if (a.running_mean) {  // torch: running = (1 - m) * running + m * batch, running_var with the UNBIASED batch variance
-    const double unb = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
-    a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-    a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+  for (int g = 0; g < a.groups; ++g) {  // in item order: the running statistics take the groups' updates one after the other
+    double s0, s1;
+    channel_sums(a, g, c, s0, s1);
+    if ((threadIdx.x & 63) != 0) continue;
+    if (a.tracked && c == 0) *a.tracked += 1;
+    const double mean = s0 / (double)a.M;
+    double var = s1 / (double)a.M - mean * mean;  // biased variance (normalisation)
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float sc = invstd * a.gamma[c];
+    float* coef = a.coef + (size_t)g * 2 * a.C;
+    coef[c] = sc;
+    coef[a.C + c] = a.beta[c] - (float)mean * sc;
+    a.save_mean[(size_t)g * a.C + c] = (float)mean;
+    a.save_invstd[(size_t)g * a.C + c] = invstd;
+    if (a.running_mean) {  // torch: running = (1 - m) * running + m * batch, running_var with the UNBIASED batch variance
+      const double unb = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
+      a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+      a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+    }
   }
 }
 
 __global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
   const int quad = my_quad(a);
+  a.x += 4 * slab(a);
+  a.out += 4 * slab(a);
+  if (a.res) a.res += 4 * slab(a);
+  a.coef += (size_t)blockIdx.y * 2 * a.C;
+  a.save_mean += (size_t)blockIdx.y * a.C;
   // y = (x - mean) * (invstd * gamma) + beta, the subtraction FIRST as stock BatchNorm does it: the folded form
   // x * sc + (beta - mean * sc) cancels two large terms when |mean| >> std (error ~ 2^-24 |mean| / std of the result)
   const float4 sc = reinterpret_cast<const float4*>(a.coef)[quad];
@@ -170,6 +188,12 @@ __global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
 
 __global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
   const int quad = my_quad(a);
+  a.dy += 4 * slab(a);
+  a.x += 4 * slab(a);
+  if (a.y) a.y += 4 * slab(a);
+  a.mean += (size_t)blockIdx.y * a.C;
+  a.invstd += (size_t)blockIdx.y * a.C;
+  a.part += (size_t)blockIdx.y * a.blocks * a.nq * 8;
   const float4 mu = reinterpret_cast<const float4*>(a.mean)[quad];
   const float4 is = reinterpret_cast<const float4*>(a.invstd)[quad];
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), be = sc;
@@ -199,17 +223,32 @@ __global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
 
 __global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(BnArgs a) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  double s0, s1;
-  channel_sums(a, c, s0, s1);
+  double g0 = 0.0, g1 = 0.0;  // dbeta / dgamma: over ALL groups (the parameters are shared), summed in group order
+  for (int g = 0; g < a.groups; ++g) {
+    double s0, s1;
+    channel_sums(a, g, c, s0, s1);
+    if ((threadIdx.x & 63) != 0) continue;
+    float* coef = a.coef + (size_t)g * 2 * a.C;
+    coef[c] = (float)(s0 / (double)a.M);        // mean of dz within the group
+    coef[a.C + c] = (float)(s1 / (double)a.M);  // mean of dz * xhat
+    g0 += s0;
+    g1 += s1;
+  }
   if ((threadIdx.x & 63) != 0) return;
-  a.coef[c] = (float)(s0 / (double)a.M);        // mean of dz
-  a.coef[a.C + c] = (float)(s1 / (double)a.M);  // mean of dz * xhat
-  a.dbeta[c] = (float)s0;
-  a.dgamma[c] = (float)s1;
+  a.dbeta[c] = (float)g0;
+  a.dgamma[c] = (float)g1;
 }
 
 __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(BnArgs a) {
   const int quad = my_quad(a);
+  a.dy += 4 * slab(a);
+  a.x += 4 * slab(a);
+  a.out += 4 * slab(a);
+  if (a.y) a.y += 4 * slab(a);
+  if (a.dres) a.dres += 4 * slab(a);
+  a.mean += (size_t)blockIdx.y * a.C;
+  a.invstd += (size_t)blockIdx.y * a.C;
+  a.coef += (size_t)blockIdx.y * 2 * a.C;
   const float4 mu = reinterpret_cast<const float4*>(a.mean)[quad];
   const float4 is = reinterpret_cast<const float4*>(a.invstd)[quad];
   const float4 gm = reinterpret_cast<const float4*>(a.gamma)[quad];
@@ -260,50 +299,55 @@ void layout(BnArgs& a, int64_t m, int c) {
   a.stride = blocks * kT;
 }
 
-size_t ws_bytes(const BnArgs& a) { return ((size_t)a.blocks * a.nq * 8) * sizeof(double) + (size_t)2 * a.C * sizeof(float); }
+size_t ws_bytes(const BnArgs& a) {
+  return (size_t)a.groups * (((size_t)a.blocks * a.nq * 8) * sizeof(double) + (size_t)2 * a.C * sizeof(float));
+}
 
-int geometry(BnArgs& a, const char* who, int64_t m, int c, void* ws, size_t ws_size) {
+int geometry(BnArgs& a, const char* who, int64_t m, int c, int groups, void* ws, size_t ws_size) {
   AVT_REQUIRE(shape_ok(m, c), "%s: rows > 0 and a power-of-two channel count in 8..4096 (got %lld x %d)", who, (long long)m, c);
-  layout(a, m, c);
+  AVT_REQUIRE(groups >= 1 && groups <= 65535 && m % groups == 0, "%s: %lld rows do not split into %d groups", who, (long long)m, groups);
+  a.groups = groups;
+  layout(a, m / groups, c);
   AVT_REQUIRE(a.stride % (c / 4) == 0, "%s: internal: stride %lld not a multiple of %d chunks", who, (long long)a.stride, c / 4);
   AVT_REQUIRE(ws && avt::aligned16(ws) && ws_size >= ws_bytes(a), "%s: workspace of %zu bytes needed (avt_bn_train_ws_bytes), got %zu",
               who, ws_bytes(a), ws_size);
   a.part = static_cast<double*>(ws);
-  a.coef = reinterpret_cast<float*>(a.part + (size_t)a.blocks * a.nq * 8);
+  a.coef = reinterpret_cast<float*>(a.part + (size_t)a.groups * a.blocks * a.nq * 8);
   return AVT_OK;
 }
 
 }  // namespace
 
-extern "C" int64_t avt_bn_train_ws_bytes(int64_t m, int c) {
-  if (!shape_ok(m, c)) return -1;
+extern "C" int64_t avt_bn_train_ws_bytes(int64_t m, int c, int groups) {
+  if (!shape_ok(m, c) || groups < 1 || m % groups) return -1;
   BnArgs a = {};
-  layout(a, m, c);
+  a.groups = groups;
+  layout(a, m / groups, c);
   return (int64_t)ws_bytes(a);
 }
 
 extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
-                                float eps, float momentum, int relu, void* ws, int64_t ws_size, float* save_mean, float* save_invstd,
-                                float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
+                                float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,
+                                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
   AVT_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && (!running_mean == !running_var), "avt_bn_train_fwd: NULL pointer");
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && (!res || avt::aligned16(res)), "avt_bn_train_fwd: rows must be 16-byte aligned");
   AVT_REQUIRE(avt::aligned16(beta) && avt::aligned16(save_mean), "avt_bn_train_fwd: beta / save_mean must be 16-byte aligned");
   BnArgs a = {};
-  const int rc = geometry(a, "avt_bn_train_fwd", m, c, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
+  const int rc = geometry(a, "avt_bn_train_fwd", m, c, groups, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
   if (rc) return rc;
   a.x = x; a.res = res; a.out = y; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.relu = relu;
   a.save_mean = save_mean; a.save_invstd = save_invstd; a.running_mean = running_mean; a.running_var = running_var;
   a.tracked = reinterpret_cast<long long*>(num_batches_tracked);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
+  hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);
-  hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
+  hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
   return avt::check_launch("avt_bn_train_fwd");
 }
 
 extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma, const float* beta,
-                                const float* save_mean, const float* save_invstd, int relu, void* ws, int64_t ws_size, float* dx,
-                                float* dres, float* dgamma, float* dbeta, void* stream) {
+                                const float* save_mean, const float* save_invstd, int relu, int groups, void* ws, int64_t ws_size,
+                                float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
   AVT_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "avt_bn_train_bwd: NULL pointer");
   AVT_REQUIRE(!relu || y || (beta && avt::aligned16(beta) && !dres),
               "avt_bn_train_bwd: a ReLU needs the forward output y, or (no shortcut) beta to recompute its mask from x");
@@ -311,14 +355,14 @@ extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x,
                   avt::aligned16(gamma) && avt::aligned16(save_mean) && avt::aligned16(save_invstd),
               "avt_bn_train_bwd: rows and per-channel vectors must be 16-byte aligned");
   BnArgs a = {};
-  const int rc = geometry(a, "avt_bn_train_bwd", m, c, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
+  const int rc = geometry(a, "avt_bn_train_bwd", m, c, groups, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
   if (rc) return rc;
   a.dy = dy; a.y = relu ? y : nullptr; a.x = x; a.gamma = gamma; a.beta = beta; a.mean = save_mean; a.invstd = save_invstd;
   a.relu = relu;
   a.out = dx; a.dres = dres; a.dgamma = dgamma; a.dbeta = dbeta;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(a.blocks), dim3(kT), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
   return avt::check_launch("avt_bn_train_bwd");
 }

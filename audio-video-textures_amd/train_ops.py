@@ -76,15 +76,37 @@ def _rows(x):
 _WS_BYTES = {}
 
 
-def _workspace(m, c, device):
+def _workspace(m, c, groups, device):
     """Scratch for the per-workgroup partial sums and the per-channel coefficients (sized by the library)."""
-    n = _WS_BYTES.get((m, c))
+    n = _WS_BYTES.get((m, c, groups))
     if n is None:
-        n = _lib.lib().avt_bn_train_ws_bytes(m, c)
+        n = _lib.lib().avt_bn_train_ws_bytes(m, c, groups)
         if n < 0:
-            raise ValueError("bn_train: %d rows x %d channels is outside the kernel's domain" % (m, c))
-        _WS_BYTES[(m, c)] = n
+            raise ValueError("bn_train: %d rows x %d channels in %d groups is outside the kernel's domain" % (m, c, groups))
+        _WS_BYTES[(m, c, groups)] = n
     return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+# Per-replica BatchNorm in one launch: inside `with bn_replicas(n):` every fused BatchNorm treats its batch as n equal groups of
+# consecutive samples, each normalised with its own statistics — the n items of a batch as the reference's DataParallel replicas
+# see them (main.py:420: one item per GPU at batch 8 on 8 GPUs) — so that a rank's items go through the encoders as ONE batch
+# (convolutions over 8 x 16 clips instead of 8 launches over 16: the deep layers have 8 x the tiles) with unchanged arithmetic.
+_BN_GROUPS = 1
+
+
+class bn_replicas:
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        global _BN_GROUPS
+        self.keep, _BN_GROUPS = _BN_GROUPS, self.n
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_GROUPS
+        _BN_GROUPS = self.keep
+        return False
 
 
 def fusable(x, bn, res=None):
@@ -97,20 +119,21 @@ def fusable(x, bn, res=None):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps, tracked=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps, tracked=None, groups=1):
         m, c = _rows(x)
         y = torch.empty_like(x)  # keeps the channels-last strides
-        ws = _workspace(m, c, x.device)
-        save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
-        save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = _workspace(m, c, groups, x.device)
+        save_mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         CALLS["bn_fwd"] += 1
         _lib.check(_lib.lib().avt_bn_train_fwd(_p(x), _p(res), _p(y), m, c, _p(weight), _p(bias), float(eps), float(momentum),
-                                               1 if relu else 0, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
+                                               1 if relu else 0, groups, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
                                                _p(running_mean), _p(running_var), _p(tracked), _stream()), "avt_bn_train_fwd")
         # (ReLU without a shortcut: the backward recomputes the mask from x — the output is not read again, nor kept alive here)
         ctx.save_for_backward(x, y if (relu and res is not None) else None, weight, bias, save_mean, save_invstd)
         ctx.has_res = res is not None
         ctx.relu = bool(relu)
+        ctx.groups = groups
         return y
 
     @staticmethod
@@ -120,33 +143,42 @@ class _BNAct(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last_3d)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
-        ws = _workspace(m, c, x.device)
+        ws = _workspace(m, c, ctx.groups, x.device)
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
         CALLS["bn_bwd"] += 1
         _lib.check(_lib.lib().avt_bn_train_bwd(_p(dy), _p(y), _p(x), m, c, _p(weight), _p(bias), _p(save_mean), _p(save_invstd),
-                                               1 if ctx.relu else 0, _p(ws), ws.numel(), _p(dx), _p(dres), _p(dgamma), _p(dbeta),
-                                               _stream()), "avt_bn_train_bwd")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+                                               1 if ctx.relu else 0, ctx.groups, _p(ws), ws.numel(), _p(dx), _p(dres), _p(dgamma),
+                                               _p(dbeta), _stream()), "avt_bn_train_bwd")
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
 def bn_act(x, bn, res=None, relu=True):
     """act(bn(x) [+ res]) for a BatchNorm3d module `bn`: the fused HIP pass in train mode on channels-last fp32 device tensors,
-    the stock torch ops otherwise (eval mode, other layouts / dtypes, CPU) — same result, same running-statistics update."""
+    the stock torch ops otherwise (eval mode, other layouts / dtypes, CPU) — same result, same running-statistics update.
+    Inside `bn_replicas(n)` the batch is n groups with statistics of their own (the stock path: a loop over the groups)."""
+    groups = _BN_GROUPS if (bn.training and _BN_GROUPS > 1) else 1
+    if groups > 1 and x.shape[0] % groups:
+        raise ValueError("bn_replicas(%d): a batch of %d samples does not split into the replicas" % (groups, x.shape[0]))
     if not fusable(x, bn, res):
-        y = bn(x)
+        if groups > 1:  # per-replica statistics on the stock ops: one BatchNorm call per group, in order
+            y = torch.cat([bn(xg) for xg in x.chunk(groups, 0)], 0)
+        else:
+            y = bn(x)
         if res is not None:
             y = y + res
         return F.relu(y) if relu else y
     momentum = bn.momentum
     tracked = bn.num_batches_tracked if bn.track_running_stats else None
     if tracked is not None and momentum is None:  # cumulative moving average: the factor needs the count on the host
+        if groups > 1:
+            raise ValueError("bn_replicas: BatchNorm with momentum=None (cumulative average) is not supported in groups")
         tracked.add_(1)
         momentum = 1.0 / float(tracked)
         tracked = None
     # (otherwise num_batches_tracked is incremented by the statistics kernel itself: a launch per BatchNorm and pass less)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps, tracked)
+    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps, tracked, groups)
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -389,31 +389,38 @@ def train_bench(args, rank, world, dev):
     # backward of item k (gradient sums), so what overlaps is forward(k + 1) with backward(k)
     istreams = [torch.cuda.Stream(device=dev) for _ in range(args.item_streams)] if args.item_streams > 1 else None
 
+    # items per forward/backward pass: all of the rank's items as ONE batch (each item a BatchNorm group of its own:
+    # train_ops.bn_replicas = per-replica statistics, what DataParallel gives the reference), or fewer per pass when memory is short
+    per_pass = min(items, args.train_pass_items) if args.train_pass_items > 0 else items
+    passes = -(-items // per_pass)
+
     def step():
         if grads is not None:
-            grads.begin(items)
+            grads.begin(passes)
         else:
             opt.zero_grad(set_to_none=True)
         idxs = rng.randint(0, len(ds), size=items)
         step_loss = torch.zeros((), device=dev)
         main = torch.cuda.current_stream(dev)
         f_done, prev = None, None
-        for k, i in enumerate(idxs):
-            last = k == items - 1
+        for k in range(passes):
+            ids = [int(i) for i in idxs[k * per_pass : (k + 1) * per_pass]]
+            last = k == passes - 1
             s = istreams[k % len(istreams)] if istreams else main
             if istreams:
                 s.wait_stream(main)
             with torch.cuda.stream(s):
                 if f_done is not None:
                     s.wait_event(f_done)
-                q, t, _, _ = bat.batch(torch.tensor([int(i)]))
+                q, t, _, _ = bat.batch(torch.tensor(ids))
                 if channels_last:
                     q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
                 sync = contextlib.nullcontext() if (world == 1 or last) else net.no_sync()
                 with sync:
-                    with amp():
+                    with amp(), train_ops.bn_replicas(len(ids)):
                         out = net(q, t)
-                    loss = crit(out.float(), torch.zeros(1, dtype=torch.long, device=dev)) / items
+                    # (the criterion averages over the pass's items; the step's loss is the mean over all of the rank's items)
+                    loss = crit(out.float(), torch.zeros(len(ids), dtype=torch.long, device=dev)) * (len(ids) / items)
                     if istreams:
                         f_done = torch.cuda.Event()
                         f_done.record(s)
@@ -468,13 +475,14 @@ def train_bench(args, rank, world, dev):
         "config": {"workload": "BASELINE config 5: batch 8 x (1 query + 1 positive + 14 negatives) = 128 clips/step at 224^2 "
                                "through SlowFast-8x8-R50 q/t encoders (train-mode BatchNorm per item = per DataParallel "
                                "replica), HIP InfoNCE + CE, SGD; inputs sampled and packed on the device",
-                   "items_per_rank": items, "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
+                   "items_per_rank": items, "items_per_pass": per_pass, "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
                    "encoder_backend": ("hand-written HIP through torch.autograd.Function (fp32, channels_last_3d): conv_x3 IO32 forward + "
                                        "stride-1 dgrad, wgrad_x3, patch-resident stems (forward + weight gradient), bn_train; query encoder on a side stream; "
                                        "MIOpen for the strided dgrads") if hand
                    else "MIOpen convolutions through autograd (%s%s)" % (args.train_dtype, ", channels_last_3d" if channels_last else ""),
                    "parallelism": "dp%d, gradient all-reduce once per step" % world},
         "training_steps_per_s": args.steps / total_s, "items_per_s": B * args.steps / total_s,
+        "max_memory_allocated_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         "loss_first_last": [losses[0], losses[-1]],
         "roofline": {"kernel": ("conv_x3_kernel<IO32> fwd / stride-1 dgrad + wgrad_x3_kernel (split-plane MFMA, 1/3 of the bf16 peak); "
                                 "whole step incl. BatchNorm passes, the stems, MIOpen strided dgrads, optimizer") if hand
@@ -534,6 +542,9 @@ def main():
                     help="--mode train: ndhwc = channels_last_3d weights + the fused BatchNorm passes (csrc/bn_train.hip), the "
                          "product's default (main.py --train_layout); ncdhw = torch's default layout, stock BatchNorm")
     ap.add_argument("--train-channels-last", action="store_true", help="(old spelling of --train-layout ndhwc)")
+    ap.add_argument("--train-pass-items", type=int, default=0,
+                    help="--mode train: items per forward/backward pass (0 = all of the rank's items as one batch with per-item "
+                         "BatchNorm groups; 1 = one pass per item, round 2's loop)")
     ap.add_argument("--item-streams", type=int, default=1,
                     help="--mode train: streams the items of a step alternate between (2: forward of item k+1 under backward of item k)")
     ap.add_argument("--no-grad-accumulator", dest="grad_accumulator", action="store_false",

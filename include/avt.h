@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 3  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_bwd takes beta and relu, avt_stem_conv_x3 takes frames_per_tile (round 3) */
+#define AVT_ABI_VERSION 3  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3) */
 
 typedef enum {
   AVT_OK = 0,
@@ -451,13 +451,16 @@ int avt_clip_pack_gather_u8(const uint8_t* frames, int n_frames, int height, int
  * bwd: relu = whether the forward applied one; its mask is the sign of y (the forward output) or, with y NULL — allowed when
  *      the forward had no shortcut — recomputed from x with the forward's own expression (needs beta; a third fewer bytes);
  *      dres (may be NULL) receives the shortcut's gradient; dgamma / dbeta [c]. */
-int64_t avt_bn_train_ws_bytes(int64_t m, int c); /* workspace both calls need (16-byte aligned); -1 outside the domain */
+int64_t avt_bn_train_ws_bytes(int64_t m, int c, int groups); /* workspace both calls need (16-byte aligned); -1 outside the domain */
+/* groups (round 3, ABI 3): the m rows are `groups` equal consecutive slabs, each normalised with its OWN batch statistics — the
+ * items of a batch as DataParallel replicas see them (main.py:420) in one launch; save_mean / save_invstd are [groups, c], the
+ * running statistics take the groups' updates in order, dgamma / dbeta sum over all groups.  1 = plain BatchNorm. */
 int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma,
-                     const float* beta, float eps, float momentum, int relu, void* ws, int64_t ws_size,
+                     const float* beta, float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size,
                      float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                     int64_t* num_batches_tracked /* incremented when not NULL */, void* stream);
+                     int64_t* num_batches_tracked /* incremented (by groups) when not NULL */, void* stream);
 int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma,
-                     const float* beta, const float* save_mean, const float* save_invstd, int relu, void* ws,
+                     const float* beta, const float* save_mean, const float* save_invstd, int relu, int groups, void* ws,
                      int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta, void* stream);
 
 /* The training form of avt_conv3d_igemm_x3 (csrc/conv_x3.hip, IO32): fp32 NDHWC rows in [batch*t*h*w, ldi], fp32 rows out

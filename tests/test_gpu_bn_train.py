@@ -146,3 +146,49 @@ def test_slowfast_train_step_is_as_close_to_fp64_as_the_stock_ops():
         return max(float((r[k] - r64[k]).abs().max()) / (float(r64[k].abs().max()) + 1e-30) for k in r64)
 
     assert stat_dist(rf) <= 2.0 * stat_dist(rs) + 1e-6, (stat_dist(rf), stat_dist(rs))  # measured 2.4e-5 against 2.8e-5
+
+
+@pytest.mark.parametrize("c,dims,groups,res,relu", [
+    (64, (8, 2, 6, 6), 4, True, True),
+    (32, (6, 3, 5, 7), 3, False, True),
+    (256, (8, 1, 4, 4), 8, False, False),
+    (2048, (4, 1, 2, 2), 2, True, True),   # a row wider than one workgroup
+])
+def test_replica_groups_equal_a_loop_over_the_groups(c, dims, groups, res, relu):
+    """train_ops.bn_replicas(n): ONE launch over the batch with n groups of statistics == n launches over the groups, in order
+    (the reference's per-replica BatchNorm under DataParallel, main.py:420): outputs, input gradients and running statistics
+    bit for bit, dgamma / dbeta to fp32 rounding (summed over the groups in fp64 here, in fp32 by autograd there)."""
+    from avtex import train_ops
+    torch.manual_seed(c + groups)
+    b, t, h, w = dims
+    x = (torch.randn(b, c, t, h, w, device="cuda:0") * 2 + 0.5).contiguous(memory_format=torch.channels_last_3d)
+    r = torch.randn_like(x).contiguous(memory_format=torch.channels_last_3d) if res else None
+    gy = torch.randn_like(x).contiguous(memory_format=torch.channels_last_3d)
+
+    def make():
+        bn = torch.nn.BatchNorm3d(c).to("cuda:0").train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        return bn
+
+    bn1, bn2 = make(), make()
+    bn2.load_state_dict(bn1.state_dict())
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    r1 = r.clone().requires_grad_(True) if res else None
+    r2 = r.clone().requires_grad_(True) if res else None
+    with train_ops.bn_replicas(groups):
+        y1 = train_ops.bn_act(x1, bn1, res=r1, relu=relu)
+    y1.backward(gy)
+    ys = []
+    for g in range(groups):
+        sl = slice(g * b // groups, (g + 1) * b // groups)
+        ys.append(train_ops.bn_act(x2[sl], bn2, res=None if r2 is None else r2[sl], relu=relu))
+    y2 = torch.cat(ys, 0)
+    y2.backward(gy)
+    assert torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad)
+    if res:
+        assert torch.equal(r1.grad, r2.grad)
+    assert torch.equal(bn1.running_mean, bn2.running_mean) and torch.equal(bn1.running_var, bn2.running_var)
+    assert int(bn1.num_batches_tracked) == int(bn2.num_batches_tracked) == groups
+    for p1, p2 in ((bn1.weight.grad, bn2.weight.grad), (bn1.bias.grad, bn2.bias.grad)):
+        assert float((p1 - p2).abs().max()) <= 2e-6 * float(p2.abs().max()) + 1e-7

@@ -118,3 +118,51 @@ def test_train_conv_switch_selects_miopen_fp32(avt, dev):
     assert (num / den) ** 0.5 < 5e-2  # same step, two arithmetics (this network's fp32 conditioning)
     with pytest.raises(ValueError):
         train_ops.set_conv_mode("bf16")
+
+
+def test_items_as_one_batch_equal_the_loop_over_items(avt, dev):
+    """Config 5's items as ONE batch with per-item BatchNorm groups (train_ops.bn_replicas; what bench.py --mode train runs)
+    against one forward/backward per item (round 2's loop = one DataParallel replica each): same logits, same summed gradients
+    up to fp32 summation order, same running statistics."""
+    from avtex import synth, train_ops
+    from avtex.dataset import DeviceSegmentBatcher
+    from avtex.slowfast import SlowFast
+
+    args = SimpleNamespace(vdata="/tmp", adata=None, n_negs=3, img_size=64, enc_arch="slowfast", window=0, stride=0)
+    torch.manual_seed(5)
+    ds = avt.AudioVideoSegments(args, "x", split="train", video=(synth.structured_video(3, 400, 48, 48), 30.0))
+    torch.manual_seed(0)
+    base = avt.ContrastivePredictionTemporal(SlowFast(), SlowFast(), None, 1, 128, temp=0.1, window=ds.window,
+                                             stride=ds.stride, enc_arch="slowfast", img_size=64)
+    synth.randomise_bn(base, 4, 0.0)
+    base = base.to(dev).train().to(memory_format=torch.channels_last_3d)
+    np.random.seed(3)
+    bat = DeviceSegmentBatcher(ds, dev).seed_from_numpy()
+    q, t, _, _ = bat.batch(torch.tensor([20, 31, 7]))
+    crit = avt.InfoNCECriterion()
+
+    def grads_of(m):
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    m1 = copy.deepcopy(base)
+    with train_ops.bn_replicas(3):
+        out1 = m1(q, t)
+    crit(out1, torch.zeros(3, dtype=torch.long, device=dev)).backward()
+    m2 = copy.deepcopy(base)
+    outs = []
+    for i in range(3):
+        o = m2([v[i : i + 1] for v in q], [v[i : i + 1] for v in t])
+        (crit(o, torch.zeros(1, dtype=torch.long, device=dev)) / 3).backward()
+        outs.append(o.detach())
+    torch.cuda.synchronize()
+    out2 = torch.cat(outs, 0)
+    assert float((out1.detach() - out2).abs().max()) < 2e-4 * float(out2.abs().max())
+    g1, g2 = grads_of(m1), grads_of(m2)
+    assert set(g1) == set(g2)
+    num = sum(float((g1[k] - g2[k]).norm()) ** 2 for k in g2) ** 0.5
+    den = sum(float(g2[k].norm()) ** 2 for k in g2) ** 0.5
+    print("batched vs per-item: logits %.2e, gradients %.2e of the norm" % (float((out1.detach() - out2).abs().max()), num / den))
+    assert num / den < 1e-3
+    b1 = dict(m1.named_buffers()); b2 = dict(m2.named_buffers())
+    worst = max(float((b1[k].float() - b2[k].float()).abs().max()) / (float(b2[k].float().abs().max()) + 1e-12) for k in b2)
+    assert worst < 1e-5, worst
