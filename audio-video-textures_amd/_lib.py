@@ -58,8 +58,9 @@ SIGNATURES = {
     "avt_conv3d_igemm_bf16": [_vp] * 6 + [C.c_int] * 22 + [_vp],
     "avt_conv3d_igemm_rows_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp],
     "avt_bn_train_fwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_float, C.c_float, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, _vp,
-                         _vp, _vp, _vp],
-    "avt_bn_train_bwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp],
+                         _vp, _vp, _vp, _vp],
+    "avt_bn_train_bwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
+                         _vp],
     "avt_bn_train_ws_bytes": [C.c_int64, C.c_int, C.c_int],
     "avt_conv3d_igemm_x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 19 + [_vp],
     "avt_conv3d_wgrad_x3_f32": [_vp, _vp, _vp] + [C.c_int] * 17 + [_vp],

@@ -34,6 +34,8 @@ struct BnArgs {
   const float* res;     // forward: shortcut added before the activation, or NULL
   const float* dy;      // backward
   const float* y;       // backward: the forward output (ReLU mask), or NULL when there was no ReLU
+  uint8_t* mask;        // the ReLU mask as 4 bits per float4 chunk (one byte per chunk): written by the forward's apply pass when
+                        // not NULL, read by the backward's passes INSTEAD of y (a sixteenth of its bytes)
   float* out;           // forward: y; backward: dx
   float* dres;          // backward: gradient of the shortcut (= masked dy), or NULL
   double* part;         // [blocks][nq * 8] per-workgroup partial sums (slot = quad-in-workgroup * 8 + {p0[4], p1[4]})
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
   if (a.res) a.res += 4 * slab(a);
   a.coef += (size_t)blockIdx.y * 2 * a.C;
   a.save_mean += (size_t)blockIdx.y * a.C;
+  if (a.mask) a.mask += slab(a);
   // y = (x - mean) * (invstd * gamma) + beta, the subtraction FIRST as stock BatchNorm does it: the folded form
   // x * sc + (beta - mean * sc) cancels two large terms when |mean| >> std (error ~ 2^-24 |mean| / std of the result)
   const float4 sc = reinterpret_cast<const float4*>(a.coef)[quad];
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     if (a.relu) {
+      if (a.mask) a.mask[i] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
     reinterpret_cast<float4*>(a.out)[i] = o;
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
   a.dy += 4 * slab(a);
   a.x += 4 * slab(a);
   if (a.y) a.y += 4 * slab(a);
+  if (a.mask) a.mask += slab(a);
   a.mean += (size_t)blockIdx.y * a.C;
   a.invstd += (size_t)blockIdx.y * a.C;
   a.part += (size_t)blockIdx.y * a.blocks * a.nq * 8;
@@ -206,7 +211,10 @@ __global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
     float4 g = reinterpret_cast<const float4*>(a.dy)[i];
     const float4 v = reinterpret_cast<const float4*>(a.x)[i];
-    if (a.y) {  // ReLU backward: the gradient passes where the forward output was positive
+    if (a.mask) {  // ReLU backward: the gradient passes where the forward output was positive — from the saved bits,
+      const unsigned mk = a.mask[i];
+      g.x = (mk & 1u) ? g.x : 0.f; g.y = (mk & 2u) ? g.y : 0.f; g.z = (mk & 4u) ? g.z : 0.f; g.w = (mk & 8u) ? g.w : 0.f;
+    } else if (a.y) {  // ... from the output itself,
       const float4 yv = reinterpret_cast<const float4*>(a.y)[i];
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     } else if (a.relu) {  // ... recomputed: bn_fwd_apply_kernel's expression, no shortcut
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(BnArgs a) {
   a.x += 4 * slab(a);
   a.out += 4 * slab(a);
   if (a.y) a.y += 4 * slab(a);
+  if (a.mask) a.mask += slab(a);
   if (a.dres) a.dres += 4 * slab(a);
   a.mean += (size_t)blockIdx.y * a.C;
   a.invstd += (size_t)blockIdx.y * a.C;
@@ -261,7 +270,10 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(BnArgs a) {
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
     float4 g = reinterpret_cast<const float4*>(a.dy)[i];
     const float4 v = reinterpret_cast<const float4*>(a.x)[i];
-    if (a.y) {
+    if (a.mask) {
+      const unsigned mk = a.mask[i];
+      g.x = (mk & 1u) ? g.x : 0.f; g.y = (mk & 2u) ? g.y : 0.f; g.z = (mk & 4u) ? g.z : 0.f; g.w = (mk & 8u) ? g.w : 0.f;
+    } else if (a.y) {
       const float4 yv = reinterpret_cast<const float4*>(a.y)[i];
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     } else if (a.relu) {
@@ -328,7 +340,8 @@ extern "C" int64_t avt_bn_train_ws_bytes(int64_t m, int c, int groups) {
 
 extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
                                 float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,
-                                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
+                                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                void* relu_mask, void* stream) {
   AVT_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && (!running_mean == !running_var), "avt_bn_train_fwd: NULL pointer");
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && (!res || avt::aligned16(res)), "avt_bn_train_fwd: rows must be 16-byte aligned");
   AVT_REQUIRE(avt::aligned16(beta) && avt::aligned16(save_mean), "avt_bn_train_fwd: beta / save_mean must be 16-byte aligned");
@@ -338,6 +351,7 @@ extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int6
   a.x = x; a.res = res; a.out = y; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.relu = relu;
   a.save_mean = save_mean; a.save_invstd = save_invstd; a.running_mean = running_mean; a.running_var = running_var;
   a.tracked = reinterpret_cast<long long*>(num_batches_tracked);
+  a.mask = relu ? static_cast<uint8_t*>(relu_mask) : nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);
@@ -346,11 +360,11 @@ extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int6
 }
 
 extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma, const float* beta,
-                                const float* save_mean, const float* save_invstd, int relu, int groups, void* ws, int64_t ws_size,
-                                float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
+                                const float* save_mean, const float* save_invstd, int relu, int groups, const void* relu_mask, void* ws,
+                                int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
   AVT_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "avt_bn_train_bwd: NULL pointer");
-  AVT_REQUIRE(!relu || y || (beta && avt::aligned16(beta) && !dres),
-              "avt_bn_train_bwd: a ReLU needs the forward output y, or (no shortcut) beta to recompute its mask from x");
+  AVT_REQUIRE(!relu || y || relu_mask || (beta && avt::aligned16(beta) && !dres),
+              "avt_bn_train_bwd: a ReLU needs the forward's mask, its output y, or (no shortcut) beta to recompute the mask from x");
   AVT_REQUIRE(avt::aligned16(dy) && avt::aligned16(x) && avt::aligned16(dx) && (!y || avt::aligned16(y)) && (!dres || avt::aligned16(dres)) &&
                   avt::aligned16(gamma) && avt::aligned16(save_mean) && avt::aligned16(save_invstd),
               "avt_bn_train_bwd: rows and per-channel vectors must be 16-byte aligned");
@@ -359,6 +373,7 @@ extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x,
   if (rc) return rc;
   a.dy = dy; a.y = relu ? y : nullptr; a.x = x; a.gamma = gamma; a.beta = beta; a.mean = save_mean; a.invstd = save_invstd;
   a.relu = relu;
+  a.mask = relu ? const_cast<uint8_t*>(static_cast<const uint8_t*>(relu_mask)) : nullptr;
   a.out = dx; a.dres = dres; a.dgamma = dgamma; a.dbeta = dbeta;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);

@@ -126,11 +126,13 @@ class _BNAct(torch.autograd.Function):
         save_mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         CALLS["bn_fwd"] += 1
+        # ReLU with a shortcut: the mask leaves the apply pass as 4 bits per float4 chunk and is what the backward reads;
+        # without a shortcut the backward recomputes it from x.  Either way the output is not read again, nor kept alive here
+        mask = torch.empty(m * c // 4, dtype=torch.uint8, device=x.device) if (relu and res is not None) else None
         _lib.check(_lib.lib().avt_bn_train_fwd(_p(x), _p(res), _p(y), m, c, _p(weight), _p(bias), float(eps), float(momentum),
                                                1 if relu else 0, groups, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
-                                               _p(running_mean), _p(running_var), _p(tracked), _stream()), "avt_bn_train_fwd")
-        # (ReLU without a shortcut: the backward recomputes the mask from x — the output is not read again, nor kept alive here)
-        ctx.save_for_backward(x, y if (relu and res is not None) else None, weight, bias, save_mean, save_invstd)
+                                               _p(running_mean), _p(running_var), _p(tracked), _p(mask), _stream()), "avt_bn_train_fwd")
+        ctx.save_for_backward(x, mask, weight, bias, save_mean, save_invstd)
         ctx.has_res = res is not None
         ctx.relu = bool(relu)
         ctx.groups = groups
@@ -138,7 +140,7 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        x, mask, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         m, c = _rows(x)
         dy = dy.contiguous(memory_format=torch.channels_last_3d)
         dx = torch.empty_like(x)
@@ -147,9 +149,9 @@ class _BNAct(torch.autograd.Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
         CALLS["bn_bwd"] += 1
-        _lib.check(_lib.lib().avt_bn_train_bwd(_p(dy), _p(y), _p(x), m, c, _p(weight), _p(bias), _p(save_mean), _p(save_invstd),
-                                               1 if ctx.relu else 0, ctx.groups, _p(ws), ws.numel(), _p(dx), _p(dres), _p(dgamma),
-                                               _p(dbeta), _stream()), "avt_bn_train_bwd")
+        _lib.check(_lib.lib().avt_bn_train_bwd(_p(dy), None, _p(x), m, c, _p(weight), _p(bias), _p(save_mean), _p(save_invstd),
+                                               1 if ctx.relu else 0, ctx.groups, _p(mask), _p(ws), ws.numel(), _p(dx), _p(dres),
+                                               _p(dgamma), _p(dbeta), _stream()), "avt_bn_train_bwd")
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 

@@ -455,13 +455,17 @@ int64_t avt_bn_train_ws_bytes(int64_t m, int c, int groups); /* workspace both c
 /* groups (round 3, ABI 3): the m rows are `groups` equal consecutive slabs, each normalised with its OWN batch statistics — the
  * items of a batch as DataParallel replicas see them (main.py:420) in one launch; save_mean / save_invstd are [groups, c], the
  * running statistics take the groups' updates in order, dgamma / dbeta sum over all groups.  1 = plain BatchNorm. */
+/* relu_mask (round 3; may be NULL): m * c / 4 bytes, 4 bits per float4 chunk of the rows — the forward writes where its output
+ * is positive, the backward reads it INSTEAD of y (with a shortcut the mask cannot be recomputed from x: a sixteenth of y's bytes
+ * in each of the backward's two passes). */
 int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma,
                      const float* beta, float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size,
                      float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                     int64_t* num_batches_tracked /* incremented (by groups) when not NULL */, void* stream);
+                     int64_t* num_batches_tracked /* incremented (by groups) when not NULL */, void* relu_mask, void* stream);
 int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma,
-                     const float* beta, const float* save_mean, const float* save_invstd, int relu, int groups, void* ws,
-                     int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta, void* stream);
+                     const float* beta, const float* save_mean, const float* save_invstd, int relu, int groups,
+                     const void* relu_mask, void* ws, int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta,
+                     void* stream);
 
 /* The training form of avt_conv3d_igemm_x3 (csrc/conv_x3.hip, IO32): fp32 NDHWC rows in [batch*t*h*w, ldi], fp32 rows out
  * [M, ldo], no bias / residual / activation — an fp32-grade Conv3d(bias=False) on channels-last tensors for the forward

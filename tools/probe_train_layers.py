@@ -118,19 +118,21 @@ def main():
     m = m.to(dev).train().to(memory_format=torch.channels_last_3d)
     np.random.seed(3)
     bat = DeviceSegmentBatcher(ds, dev).seed_from_numpy()
-    q, t, _, _ = bat.batch(torch.tensor([20]))
-    label = torch.zeros(1, dtype=torch.long, device=dev)
+    items = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # items in the pass (each a BatchNorm group of its own)
+    q, t, _, _ = bat.batch(torch.tensor([20 + 7 * i for i in range(items)]))
+    label = torch.zeros(items, dtype=torch.long, device=dev)
     crit = avt.InfoNCECriterion()
     for it in range(3):
         ON[0] = it == 2
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        loss = crit(m(q, t), label)
+        with train_ops.bn_replicas(items):
+            loss = crit(m(q, t), label)
         loss.backward()
         e1.record()
         torch.cuda.synchronize()
-        print("item %d: %.1f ms%s" % (it, e0.elapsed_time(e1), " (timed per launch: serialised)" if ON[0] else ""))
+        print("pass %d (%d items): %.1f ms%s" % (it, items, e0.elapsed_time(e1), " (timed per launch: serialised)" if ON[0] else ""))
         m.zero_grad(set_to_none=True)
     tot = sum(r[1] for r in ROWS.values())
     print("hand-written launches: %.1f ms in %d launches" % (tot, sum(r[0] for r in ROWS.values())))
