@@ -90,24 +90,37 @@ __device__ __forceinline__ void block_reduce_store(const BnArgs& a, const double
   for (int i = threadIdx.x; i < a.nq * 8; i += kT) row[i] = acc[i & 7][i >> 3];
 }
 
-// One wavefront per channel: sum that channel's two partials over the workgroups that saw it, in a fixed order.
-__device__ __forceinline__ void channel_sums(const BnArgs& a, int g, int c, double& s0, double& s1) {
+// One wavefront per channel: sum that channel's two partials over the workgroups that saw it, in a fixed order — for up to
+// kGroupBatch groups AT ONCE (a lane keeps one pair of sums per group and walks the groups' rows of partials together: with
+// 8 groups walked one after the other the finalize launches were 64 us each, 25 ms of a 415 ms step).  Valid in lane 0.
+constexpr int kGroupBatch = 8;
+__device__ __forceinline__ void channel_sums(const BnArgs& a, int g0, int ng, int c, double* s0, double* s1) {
   const int quad = c >> 2, e = c & 3, lane = threadIdx.x & 63;
   const int slot = (quad % a.nq) * 8 + e;
   const int first = a.unit > 1 ? quad / kT : 0;  // wide rows: workgroup b holds quads (b % unit) * kT ...
-  double t0 = 0.0, t1 = 0.0;
+  double t0[kGroupBatch], t1[kGroupBatch];
+#pragma unroll
+  for (int j = 0; j < kGroupBatch; ++j) t0[j] = t1[j] = 0.0;
+  const size_t gstride = (size_t)a.blocks * a.nq * 8;
   for (int b = first + lane * a.unit; b < a.blocks; b += 64 * a.unit) {
-    const double* row = a.part + ((size_t)g * a.blocks + b) * a.nq * 8;
-    t0 += row[slot];
-    t1 += row[slot + 4];
+    const double* row = a.part + ((size_t)g0 * a.blocks + b) * a.nq * 8 + slot;
+#pragma unroll
+    for (int j = 0; j < kGroupBatch; ++j)
+      if (j < ng) {  // uniform
+        t0[j] += row[j * gstride];
+        t1[j] += row[j * gstride + 4];
+      }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    t0 += __shfl_down(t0, off, 64);
-    t1 += __shfl_down(t1, off, 64);
+  for (int j = 0; j < kGroupBatch; ++j) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      t0[j] += __shfl_down(t0[j], off, 64);
+      t1[j] += __shfl_down(t1[j], off, 64);
+    }
+    s0[j] = t0[j];
+    s1[j] = t1[j];
   }
-  s0 = t0;
-  s1 = t1;
 }
 
 // this workgroup's group: its slab of the activation (in float4 chunks) and its rows of partials
@@ -138,25 +151,29 @@ __global__ __launch_bounds__(kT) void bn_fwd_stats_kernel(BnArgs a) {
 
 __global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // grid C / 4, a wavefront per channel
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  for (int g = 0; g < a.groups; ++g) {  // in item order: the running statistics take the groups' updates one after the other
-    double s0, s1;
-    channel_sums(a, g, c, s0, s1);
+  for (int g0 = 0; g0 < a.groups; g0 += kGroupBatch) {
+    const int ng = a.groups - g0 < kGroupBatch ? a.groups - g0 : kGroupBatch;
+    double s0[kGroupBatch], s1[kGroupBatch];
+    channel_sums(a, g0, ng, c, s0, s1);
     if ((threadIdx.x & 63) != 0) continue;
-    if (a.tracked && c == 0) *a.tracked += 1;
-    const double mean = s0 / (double)a.M;
-    double var = s1 / (double)a.M - mean * mean;  // biased variance (normalisation)
-    var = var > 0.0 ? var : 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
-    const float sc = invstd * a.gamma[c];
-    float* coef = a.coef + (size_t)g * 2 * a.C;
-    coef[c] = sc;
-    coef[a.C + c] = a.beta[c] - (float)mean * sc;
-    a.save_mean[(size_t)g * a.C + c] = (float)mean;
-    a.save_invstd[(size_t)g * a.C + c] = invstd;
-    if (a.running_mean) {  // torch: running = (1 - m) * running + m * batch, running_var with the UNBIASED batch variance
-      const double unb = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
-      a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-      a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+    for (int j = 0; j < ng; ++j) {  // in item order: the running statistics take the groups' updates one after the other
+      const int g = g0 + j;
+      if (a.tracked && c == 0) *a.tracked += 1;
+      const double mean = s0[j] / (double)a.M;
+      double var = s1[j] / (double)a.M - mean * mean;  // biased variance (normalisation)
+      var = var > 0.0 ? var : 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+      const float sc = invstd * a.gamma[c];
+      float* coef = a.coef + (size_t)g * 2 * a.C;
+      coef[c] = sc;
+      coef[a.C + c] = a.beta[c] - (float)mean * sc;
+      a.save_mean[(size_t)g * a.C + c] = (float)mean;
+      a.save_invstd[(size_t)g * a.C + c] = invstd;
+      if (a.running_mean) {  // torch: running = (1 - m) * running + m * batch, running_var with the UNBIASED batch variance
+        const double unb = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
+        a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+        a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+      }
     }
   }
 }
@@ -231,20 +248,23 @@ __global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
 
 __global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(BnArgs a) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  double g0 = 0.0, g1 = 0.0;  // dbeta / dgamma: over ALL groups (the parameters are shared), summed in group order
-  for (int g = 0; g < a.groups; ++g) {
-    double s0, s1;
-    channel_sums(a, g, c, s0, s1);
+  double g0s = 0.0, g1s = 0.0;  // dbeta / dgamma: over ALL groups (the parameters are shared), summed in group order
+  for (int g0 = 0; g0 < a.groups; g0 += kGroupBatch) {
+    const int ng = a.groups - g0 < kGroupBatch ? a.groups - g0 : kGroupBatch;
+    double s0[kGroupBatch], s1[kGroupBatch];
+    channel_sums(a, g0, ng, c, s0, s1);
     if ((threadIdx.x & 63) != 0) continue;
-    float* coef = a.coef + (size_t)g * 2 * a.C;
-    coef[c] = (float)(s0 / (double)a.M);        // mean of dz within the group
-    coef[a.C + c] = (float)(s1 / (double)a.M);  // mean of dz * xhat
-    g0 += s0;
-    g1 += s1;
+    for (int j = 0; j < ng; ++j) {
+      float* coef = a.coef + (size_t)(g0 + j) * 2 * a.C;
+      coef[c] = (float)(s0[j] / (double)a.M);        // mean of dz within the group
+      coef[a.C + c] = (float)(s1[j] / (double)a.M);  // mean of dz * xhat
+      g0s += s0[j];
+      g1s += s1[j];
+    }
   }
   if ((threadIdx.x & 63) != 0) return;
-  a.dbeta[c] = (float)g0;
-  a.dgamma[c] = (float)g1;
+  a.dbeta[c] = (float)g0s;
+  a.dgamma[c] = (float)g1s;
 }
 
 __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(BnArgs a) {
@@ -300,11 +320,15 @@ void layout(BnArgs& a, int64_t m, int c) {
   a.nq = q < kT ? q : kT;
   a.unit = q > kT ? q / kT : 1;
   int64_t blocks = (a.nchunk + kT - 1) / kT;
-  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  // (with groups the grid is blocks x groups: the same 1024-2048 workgroups in all, so that the finalize pass — one wavefront
+  //  per channel over every row of partials — does not grow with the number of groups)
+  const int64_t most = a.groups > 1 ? (2 * kMaxBlocks / a.groups > 128 ? 2 * kMaxBlocks / a.groups : 128) : kMaxBlocks;
+  if (blocks > most) blocks = most;
   // every workgroup leaves a row of 2 C doubles for the finalize pass: keep those rows a few per cent of the tensor itself
   // (with 1024 of them a [23520, 1024] activation's partials were a third of its bytes: 3.4 TB/s backward instead of 5.2)
   // — but not below two workgroups per CU, which the streaming itself needs
-  const int64_t cap = m / 64 + 1 > 512 ? m / 64 + 1 : 512;
+  const int64_t floor_ = a.groups > 1 ? 128 : 512;
+  const int64_t cap = m / 64 + 1 > floor_ ? m / 64 + 1 : floor_;
   if (blocks > cap) blocks = cap;
   blocks = ((blocks + a.unit - 1) / a.unit) * a.unit;  // whole rows per sweep, so a thread keeps its four channels
   a.blocks = (int)blocks;
