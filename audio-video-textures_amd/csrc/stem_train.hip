@@ -226,6 +226,91 @@ __global__ __launch_bounds__(NTHR, 2) void stem_wgrad_kernel(SwArgs a) {
   }
 }
 
+// ---- the stems' MaxPool3d((1,3,3),(1,2,2),(0,1,1)) in the training step ---------------------------------------------------------
+// fp32 NDHWC rows.  Forward: the max of the window and WHICH tap held it (4 bits per element, first maximum in row-major tap
+// order, as torch's kernel picks it; a NaN wins, as there).  Backward as a GATHER: an input position sums the dy of the (at most
+// four) windows that cover it and whose recorded tap is this position — no atomics, fixed order.  Both passes HBM-bound: the
+// forward reads x once (neighbouring windows' re-reads meet in L1 / L2), the backward writes dx once.
+struct MpArgs {
+  const float* x;
+  float* y;
+  uint8_t* tap;  // [bt, Ho, Wo, C / 2]: two 4-bit taps per byte
+  const float* dy;
+  float* dx;
+  int bt, H, W, C, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void maxpool_train_fwd_kernel(MpArgs a) {
+  const unsigned cpr = (unsigned)a.C >> 2;  // float4 chunks per row
+  const unsigned total = (unsigned)a.bt * a.Ho * a.Wo * cpr;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned p = i / cpr;
+    const unsigned cc = i - p * cpr;
+    const unsigned q = p / (unsigned)a.Wo;
+    const int wo = (int)(p - q * a.Wo);
+    const unsigned b = q / (unsigned)a.Ho;
+    const int ho = (int)(q - b * a.Ho);
+    const float* frame = a.x + (int64_t)b * a.H * a.W * a.C + cc * 4;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned t[4] = {0u, 0u, 0u, 0u};
+    bool first = true;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hi = 2 * ho - 1 + dh;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wi = 2 * wo - 1 + dw;
+        if ((unsigned)hi >= (unsigned)a.H || (unsigned)wi >= (unsigned)a.W) continue;  // padding: never the maximum
+        const float4 v = *reinterpret_cast<const float4*>(frame + (int64_t)(hi * a.W + wi) * a.C);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (first || x[e] > m[e] || x[e] != x[e]) {  // strictly greater: the FIRST maximum keeps the gradient; a NaN takes it
+            m[e] = x[e];
+            t[e] = (unsigned)(dh * 3 + dw);
+          }
+        first = false;
+      }
+    }
+    *reinterpret_cast<float4*>(a.y + (int64_t)p * a.C + cc * 4) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<uint16_t*>(a.tap + ((int64_t)p * a.C + cc * 4) / 2) = (uint16_t)(t[0] | (t[1] << 4) | (t[2] << 8) | (t[3] << 12));
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_train_bwd_kernel(MpArgs a) {
+  const unsigned cpr = (unsigned)a.C >> 2;
+  const unsigned total = (unsigned)a.bt * a.H * a.W * cpr;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned p = i / cpr;
+    const unsigned cc = i - p * cpr;
+    const unsigned q = p / (unsigned)a.W;
+    const int w = (int)(p - q * a.W);
+    const unsigned b = q / (unsigned)a.H;
+    const int h = (int)(q - b * a.H);
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    // windows (ho, wo) with 2 ho - 1 + dh == h: ho = (h + 1 - dh) / 2 for the dh of h + 1's parity
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hh = h + 1 - dh;
+      if (hh < 0 || (hh & 1) || (hh >> 1) >= a.Ho) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int ww = w + 1 - dw;
+        if (ww < 0 || (ww & 1) || (ww >> 1) >= a.Wo) continue;
+        const int64_t o = ((int64_t)(b * a.Ho + (hh >> 1)) * a.Wo + (ww >> 1)) * a.C + cc * 4;
+        const unsigned t = *reinterpret_cast<const uint16_t*>(a.tap + o / 2);
+        const float4 d = *reinterpret_cast<const float4*>(a.dy + o);
+        const unsigned me = (unsigned)(dh * 3 + dw);
+        g[0] += ((t & 15u) == me) ? d.x : 0.f;
+        g[1] += (((t >> 4) & 15u) == me) ? d.y : 0.f;
+        g[2] += (((t >> 8) & 15u) == me) ? d.z : 0.f;
+        g[3] += ((t >> 12) == me) ? d.w : 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(a.dx + (int64_t)p * a.C + cc * 4) = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+
 template <int KT, int CO>
 int launch_wgrad(SwArgs& a, hipStream_t st) {
   constexpr int FP = CO == 8 ? 2 : 1, NP = (KT + FP - 1) / FP;
@@ -300,4 +385,35 @@ extern "C" int avt_stem_wgrad_x3(const void* x_hi, const void* x_lo, const float
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (kt == 5) return cout == 8 ? launch_wgrad<5, 8>(a, s) : launch_wgrad<5, 16>(a, s);
   return cout == 8 ? launch_wgrad<1, 8>(a, s) : launch_wgrad<1, 16>(a, s);
+}
+
+// MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the training step on fp32 NDHWC rows (see include/avt.h)
+extern "C" int avt_maxpool_train_fwd(const float* x, float* y, void* tap, int bt, int h, int w, int c, void* stream) {
+  AVT_REQUIRE(x && y && tap && bt > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "avt_maxpool_train_fwd: NULL pointer / bad sizes (c %% 4 == 0)");
+  AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && avt::aligned16(tap), "avt_maxpool_train_fwd: pointers must be 16-byte aligned");
+  MpArgs a = {};
+  a.x = x; a.y = y; a.tap = static_cast<uint8_t*>(tap);
+  a.bt = bt; a.H = h; a.W = w; a.C = c;
+  a.Ho = (h - 1) / 2 + 1; a.Wo = (w - 1) / 2 + 1;
+  const int64_t total = (int64_t)bt * a.Ho * a.Wo * (c / 4);
+  AVT_REQUIRE((int64_t)bt * h * w * (c / 4) < (1ll << 32), "avt_maxpool_train_fwd: more than 2^32 chunks");
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(maxpool_train_fwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return avt::check_launch("avt_maxpool_train_fwd");
+}
+
+extern "C" int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx, int bt, int h, int w, int c, void* stream) {
+  AVT_REQUIRE(dy && dx && tap && bt > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "avt_maxpool_train_bwd: NULL pointer / bad sizes (c %% 4 == 0)");
+  AVT_REQUIRE(avt::aligned16(dy) && avt::aligned16(dx) && avt::aligned16(tap), "avt_maxpool_train_bwd: pointers must be 16-byte aligned");
+  MpArgs a = {};
+  a.dy = dy; a.dx = dx; a.tap = const_cast<uint8_t*>(static_cast<const uint8_t*>(tap));
+  a.bt = bt; a.H = h; a.W = w; a.C = c;
+  a.Ho = (h - 1) / 2 + 1; a.Wo = (w - 1) / 2 + 1;
+  const int64_t total = (int64_t)bt * h * w * (c / 4);
+  AVT_REQUIRE(total < (1ll << 32), "avt_maxpool_train_bwd: more than 2^32 chunks");
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(maxpool_train_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return avt::check_launch("avt_maxpool_train_bwd");
 }

@@ -13,7 +13,7 @@ MI355X notes: convolutions go to MIOpen; run it in bf16 with channels_last_3d (`
 import torch
 import torch.nn as nn
 
-from .train_ops import bn_act, conv3d, conv3d_fork
+from .train_ops import bn_act, conv3d, conv3d_fork, max_pool_hw
 
 ALPHA, BETA_INV, FUSION_RATIO, FUSION_KERNEL = 4, 8, 2, 7
 WIDTH = 64
@@ -32,7 +32,7 @@ class Stem(nn.Module):
         self.pool_layer = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
 
     def forward(self, x):
-        return self.pool_layer(bn_act(conv3d(x, self.conv), self.bn, relu=True))  # (train mode on the GPU: one fused HIP pass)
+        return max_pool_hw(bn_act(conv3d(x, self.conv), self.bn, relu=True), self.pool_layer)  # (train mode on the GPU: fused HIP passes)
 
 
 class VideoModelStem(nn.Module):

@@ -57,7 +57,7 @@ def invalidate_weight_cache():
 
 # per-process launch counters of the hand-written training kernels (tests assert that the default path really runs them)
 CALLS = {"conv_fwd_x3": 0, "dgrad_x3": 0, "dgrad_strided_x3": 0, "wgrad_x3": 0, "wgrad_stem_x3": 0, "bn_fwd": 0, "bn_bwd": 0,
-         "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0}
+         "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0, "maxpool_hip": 0}
 
 
 def _p(t):
@@ -539,6 +539,43 @@ class _StemX3(torch.autograd.Function):
         dw = torch.empty_like(weight)
         dw.copy_(dwp.view(c, kt, 7, 8, 4)[:, :, :, 1:, :3].permute(0, 4, 1, 2, 3))  # column tap k = 2 * pair + pixel - 1
         return None, dw
+
+
+class _MaxPoolHW(torch.autograd.Function):
+    """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on channels-last fp32 (csrc/stem_train.hip): the forward records which tap held each
+    maximum (4 bits per element), the backward gathers the gradient from it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        b, c, t, h, w = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((b, c, t, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+        tap = torch.empty(y.numel() // 2, dtype=torch.uint8, device=x.device)
+        CALLS["maxpool_hip"] += 1
+        _lib.check(_lib.lib().avt_maxpool_train_fwd(_p(x), _p(y), _p(tap), b * t, h, w, c, _stream()), "avt_maxpool_train_fwd")
+        ctx.save_for_backward(tap)
+        ctx.dims = (b, c, t, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tap,) = ctx.saved_tensors
+        b, c, t, h, w = ctx.dims
+        dy = dy.contiguous(memory_format=torch.channels_last_3d)
+        dx = torch.empty((b, c, t, h, w), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last_3d)
+        _lib.check(_lib.lib().avt_maxpool_train_bwd(_p(dy), _p(tap), _p(dx), b * t, h, w, c, _stream()), "avt_maxpool_train_bwd")
+        return dx
+
+
+def max_pool_hw(x, pool):
+    """pool(x) for the stems' nn.MaxPool3d((1,3,3),(1,2,2),(0,1,1)): the HIP pair above on channels-last fp32 device tensors
+    that carry a gradient in train mode, the module itself otherwise."""
+    if (_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.requires_grad and x.shape[1] % 4 == 0 and
+            x.is_contiguous(memory_format=torch.channels_last_3d) and tuple(pool.kernel_size) == (1, 3, 3) and
+            tuple(pool.stride) == (1, 2, 2) and tuple(pool.padding) == (0, 1, 1) and not pool.ceil_mode and
+            pool.dilation in (1, (1, 1, 1)) and x.numel() // 4 < (1 << 32)):
+        return _MaxPoolHW.apply(x)
+    return pool(x)
 
 
 def conv_fusable(x, conv):

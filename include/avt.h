@@ -514,6 +514,13 @@ int avt_stem_wgrad_x3_supported(int h, int pw, int cout, int kt);
 int avt_stem_wgrad_x3(const void* x_hi, const void* x_lo, const float* dy, float* dw, int batch, int t, int h, int pw,
                       int cout, int kt, int pt, void* stream);
 
+/* MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the stems in the training step on fp32 NDHWC rows [bt, h, w, c] (csrc/stem_train.hip;
+ * the reference: the third-party SlowFast stem under autograd, train.py:114-141).  fwd: y [bt, ho, wo, c] and `tap`
+ * (bt*ho*wo*c/2 bytes: 4 bits per element = which of the 9 taps held the maximum; the first one on ties, a NaN wins — torch's
+ * rule).  bwd: dx = the gradient routed to those taps, as a gather (no atomics, fixed order).  c % 4 == 0. */
+int avt_maxpool_train_fwd(const float* x, float* y, void* tap, int bt, int h, int w, int c, void* stream);
+int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx, int bt, int h, int w, int c, void* stream);
+
 /* SuperSloMo interpolation at the jumps of the stitched video (contrastive_video_textures/interpolate.py:75-147, called from
  * validate.py:588-611): the passes around the two UNets, whose convolutions are avt_conv3d_igemm_x3 with relu = 2
  * (csrc/interp.hip).  Plane pairs as above (plane_dtype AVT_X3_*), NHWC rows; `mean3` is a HOST array of 3 floats.

@@ -333,3 +333,27 @@ def test_micro_batch_gradients_equal_autograd_accumulation(passes):
         assert set(w) == set(g) and "unused.weight" not in g
         for k in w:
             assert float((w[k] - g[k]).abs().max()) <= 2e-5 * float(w[k].abs().max()) + 1e-12, k
+
+
+@pytest.mark.parametrize("dims,c", [((2, 3, 12, 12), 8), ((1, 2, 11, 9), 64), ((2, 1, 112, 112), 16)])
+def test_stem_max_pool_forward_and_gradient_equal_torch(dims, c):
+    """train_ops.max_pool_hw (csrc/stem_train.hip) against nn.MaxPool3d((1,3,3),(1,2,2),(0,1,1)) through autograd: values bit for
+    bit, the gradient routed to the same (first) maximum — with ties in the input (a ReLU output has many zeros)."""
+    from avtex import train_ops
+    torch.manual_seed(dims[2])
+    b, t, h, w = dims
+    x0 = torch.relu(torch.randn(b, c, t, h, w, device=DEV)).contiguous(memory_format=torch.channels_last_3d)  # zeros: ties
+    pool = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+    xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    before = train_ops.CALLS["maxpool_hip"]
+    ya = train_ops.max_pool_hw(xa, pool)
+    assert train_ops.CALLS["maxpool_hip"] == before + 1
+    yb = pool(xb)
+    gy = _cl(torch.randn_like(yb))
+    ya.backward(gy)
+    yb.backward(gy)
+    assert torch.equal(ya, yb) and ya.is_contiguous(memory_format=torch.channels_last_3d)
+    # (an input position can be the maximum of up to four windows: torch adds them with atomics in any order, the gather here
+    #  in a fixed one — equal up to fp32 rounding of that sum; a different tie rule would move whole gradients instead)
+    assert float((xa.grad - xb.grad).abs().max()) <= 4e-7 * float(xb.grad.abs().max())
+    assert train_ops.max_pool_hw(x0, pool).shape == yb.shape and train_ops.CALLS["maxpool_hip"] == before + 1  # no gradient: the module
