@@ -74,7 +74,7 @@ struct ConvArgs {
 // laid out over a `ors`x finer grid — a stride-2 [1,3,3] conv writing behind the channels of ITS OWN input's rows, so
 // that the block's c conv and strided shortcut conv become one GEMM over K = [x | b-output] (fused_slowfast._Block).
 __device__ __forceinline__ int out_row(const ConvArgs& a, int m) {
-  if (a.ors == 1) return m;
+  if (a.oH == 0) return m;
   const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
   const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
   return (t2 * a.oH + ho * a.ors) * a.oW + wo * a.ors;
@@ -110,8 +110,12 @@ inline int conv_args_fill(ConvArgs& a, const char* who, const void* in, const vo
   a.To = to > 0 ? to : fto;
   a.Ho = ho > 0 ? ho : fho;
   a.Wo = wo > 0 ? wo : fwo;
-  AVT_REQUIRE(a.To > 0 && a.Ho > 0 && a.Wo > 0 && batch > 0 && a.To <= fto && a.Ho <= fho && a.Wo <= fwo,
-              "%s: bad output extent %dx%dx%d (max %dx%dx%d)", who, a.To, a.Ho, a.Wo, fto, fho, fwo);
+  // (an explicit extent may also reach past the formula's by up to k - 1 positions: padding on the far side only — every tap is
+  //  bounds-checked against the input by the kernels; avt_conv3d_igemm_x3_f32_ex)
+  AVT_REQUIRE(a.To > 0 && a.Ho > 0 && a.Wo > 0 && batch > 0 && a.To <= fto + (kt - 1) / st && a.Ho <= fho + (kh - 1) / sh &&
+                  a.Wo <= fwo + (kw - 1) / sw,
+              "%s: bad output extent %dx%dx%d (max %dx%dx%d)", who, a.To, a.Ho, a.Wo, fto + (kt - 1) / st, fho + (kh - 1) / sh,
+              fwo + (kw - 1) / sw);
   a.Cout = cout;
   a.K = kt * kh * kw * cin;
   a.KT = kt;
@@ -140,15 +144,18 @@ inline int conv_args_fill(ConvArgs& a, const char* who, const void* in, const vo
   a.dWo = make_fastdiv((uint32_t)a.Wo);
   a.dHo = make_fastdiv((uint32_t)a.Ho);
   a.dTo = make_fastdiv((uint32_t)a.To);
-  AVT_REQUIRE(out_row_stride >= 1 && (out_row_stride == 1 || (!res && out_h >= out_row_stride * (a.Ho - 1) + 1 &&
-                                                               out_w >= out_row_stride * (a.Wo - 1) + 1)),
+  // (out_row_stride 1 with an out_h x out_w grid: the frame's rows land at the top-left of a larger frame — one temporal class
+  //  of a strided transposed convolution, train_ops._dgrad_strided)
+  const bool remap = out_row_stride > 1 || (out_h > 0 && out_w > 0);
+  AVT_REQUIRE(out_row_stride >= 1 && (!remap || (!res && out_h >= out_row_stride * (a.Ho - 1) + 1 &&
+                                                 out_w >= out_row_stride * (a.Wo - 1) + 1)),
               "%s: the remapped rows need an out_h x out_w grid that holds %d x (%d x %d), no residual", who,
               out_row_stride, a.Ho, a.Wo);
-  AVT_REQUIRE(out_row_stride == 1 || (int64_t)batch * a.To * out_h * out_w < (1ll << 31),
+  AVT_REQUIRE(!remap || (int64_t)batch * a.To * out_h * out_w < (1ll << 31),
               "%s: output buffer too large for 32-bit rows", who);
   a.ors = out_row_stride;
-  a.oH = out_h;
-  a.oW = out_w;
+  a.oH = remap ? out_h : 0;
+  a.oW = remap ? out_w : 0;
   return AVT_OK;
 }
 

@@ -947,16 +947,16 @@ extern "C" int avt_conv3d_igemm_x3_wblk(const void* in_hi, const void* in_lo, co
 }
 
 // fp32 rows in, fp32 rows out, split-plane arithmetic in between (the IO32 form of the kernel): see include/avt.h
-extern "C" int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
-                                       float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
-                                       int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int lda, int plane_dtype,
-                                       void* stream) {
+static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
+                             float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                             int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi, int ldo, int lda,
+                             int out_row_stride, int out_h, int out_w, int plane_dtype, void* stream) {
   AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_conv3d_igemm_x3_f32: plane_dtype must be 0 (bf16) or 1 (fp16)");
   AVT_REQUIRE(wt_lo && avt::aligned16(wt_lo) && (!wscale || avt::aligned16(wscale)), "avt_conv3d_igemm_x3_f32: weight planes / wscale NULL or unaligned");
   AVT_REQUIRE((int64_t)batch * t * h * w * ldi < (1ll << 30) - 64, "avt_conv3d_igemm_x3_f32: input too large for 32-bit byte offsets");
   ConvArgs a;
   const int rc = conv_args_fill(a, "avt_conv3d_igemm_x3_f32", in, wt_hi, nullptr, add, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw,
-                                st, sh, sw, pt, ph, pw, 0, 0, 0, ldi, ldo, add ? lda : 0, 0, 1, 0, 0);
+                                st, sh, sw, pt, ph, pw, to, ho, wo, ldi, ldo, add ? lda : 0, 0, out_row_stride, out_h, out_w);
   if (rc != AVT_OK) return rc;
   a.in_bytes *= 2u;  // fp32 elements
   a.in_lo = nullptr;
@@ -976,4 +976,22 @@ extern "C" int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const
   if (cout <= 32) return launch_x3<128, 32, 32, false, true>(a, s);
   if (cout <= 64) return launch_x3<128, 64, 64, false, true>(a, s);
   return launch_x3<128, 128, 64, false, true>(a, s);
+}
+
+extern "C" int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
+                                       float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
+                                       int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int lda, int plane_dtype,
+                                       void* stream) {
+  return igemm_x3_f32_impl(in, wt_hi, wt_lo, wscale, add, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw, st, sh, sw, pt, ph, pw, 0, 0, 0,
+                           ldi, ldo, lda, 1, 0, 0, plane_dtype, stream);
+}
+
+// ... with an explicit output extent (any padding on the far side) and the output-row remap of avt_conv3d_igemm_x3: one class of
+// a strided transposed convolution (train_ops._dgrad_strided); no `add` operand
+extern "C" int avt_conv3d_igemm_x3_f32_ex(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
+                                          const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
+                                          int pt, int ph, int pw, int to, int ho, int wo, int ldi, int ldo, int out_row_stride, int out_h,
+                                          int out_w, int plane_dtype, void* stream) {
+  return igemm_x3_f32_impl(in, wt_hi, wt_lo, wscale, nullptr, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw, 1, 1, 1, pt, ph, pw, to, ho,
+                           wo, ldi, ldo, 0, out_row_stride, out_h, out_w, plane_dtype, stream);
 }

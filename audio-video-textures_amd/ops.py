@@ -338,6 +338,21 @@ def conv3d_igemm_x3_f32(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, ker
                                                   int(cout), int(plane_dtype), _stream()), "avt_conv3d_igemm_x3_f32")
 
 
+def conv3d_igemm_x3_f32_ex(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, kernel, pad, out_dims, ldi, ldo, plane_dtype,
+                           out_rows=(1, 0, 0)):
+    """conv3d_igemm_x3_f32 at stride 1 with an explicit output extent and the output-row remap (out_rows = (stride, grid h, grid w));
+    `out` is the first element the class writes (a view into the full gradient); see include/avt.h."""
+    b, t, h, w = dims
+    _dev(x, "x", torch.float32)
+    _dev(wt_hi, "wt_hi", torch.bfloat16)
+    _dev(wt_lo, "wt_lo", torch.bfloat16)
+    _lib.check(_lib.lib().avt_conv3d_igemm_x3_f32_ex(_p(x), _p(wt_hi), _p(wt_lo), _p(wscale), C.c_void_p(out.data_ptr()), _p(ktab), int(b),
+                                                     int(t), int(h), int(w), int(cin), int(cout), *[int(k) for k in kernel],
+                                                     *[int(v) for v in pad], *[int(v) for v in out_dims], int(ldi), int(ldo),
+                                                     int(out_rows[0]), int(out_rows[1]), int(out_rows[2]), int(plane_dtype), _stream()),
+               "avt_conv3d_igemm_x3_f32_ex")
+
+
 def conv3d_wgrad_x3_f32(dy, x, dw, dims, cin, cout, kernel, stride, pad, ldx, ldy):
     """dw [cout, taps, cin] fp32 = weight gradient of the convolution (csrc/wgrad_x3.hip); dy / x fp32 NDHWC rows; dims = x's (B,T,H,W)."""
     b, t, h, w = dims

@@ -6,7 +6,8 @@ when the model is in the training layout (channels_last_3d, main.py --train_layo
 * `conv3d` / `conv3d_fork`: the convolutions' forward and stride-1 input gradient on the split-plane MFMA kernel
   (csrc/conv_x3.hip, fp32 in / fp32 out) and their weight gradient on csrc/wgrad_x3.hip; the two stems ([kt,7,7] on the
   3-channel clip) on the patch-resident kernels (csrc/stem_conv.hip forward with fp32 output, csrc/stem_train.hip weight
-  gradient, both in the pixel-pair form).  MIOpen keeps the strided input gradients (aten.convolution_backward).
+  gradient, both in the pixel-pair form); the strided layers' input gradients as one stride-1 convolution of dY per residue
+  class of the input position (`_dgrad_strided`).  No MIOpen convolution is left in the step.
 
 ARITHMETIC (main.py --train_conv, set_conv_mode): "x3" (the default on the MI355X) computes every product from two 16-bit
 planes with fp32 accumulation — forward in fp16 planes (2^-22 per product), input and weight gradients in bf16 planes (2^-16
@@ -422,12 +423,90 @@ def _conv_backward(ctx, dy, dalias):
             CALLS["dgrad_x3"] += 1
             dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias)
         else:
-            CALLS["miopen_dgrad"] += 1
-            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
-                                                     [True, False, False])[0]
+            dx = _dgrad_strided(dy, weight, stride, padding, kernel, tuple(x.shape)) if (_DGRAD_S_X3 and cin % 8 == 0) else None
+            if dx is not None:
+                CALLS["dgrad_strided_x3"] += 1
+            else:
+                CALLS["miopen_dgrad"] += 1
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
+                                                         [True, False, False])[0]
             if dalias is not None:
                 dx = dx + dalias
     return dx, dw
+
+
+def _stride_classes(k, s, p, x, y):
+    """One dimension of a strided convolution's input gradient: for every residue r of the input index mod s, the taps that
+    reach it (descending, so that the offsets into dY ascend), the padding in front of dY and the number of input positions
+    -> [(r, taps, pad_before, count)]; None when a class would need dY shifted the other way (not a SlowFast shape)."""
+    out = []
+    for r in range(s):
+        taps = list(range((r + p) % s, k, s))
+        offs = [(r + p - d) // s for d in taps]  # descending with d ascending
+        if offs and min(offs) > 0:
+            return None
+        out.append((r, taps[::-1], -min(offs) if offs else 0, max(0, -(-(x - r) // s))))
+    return out
+
+
+def _dgrad_strided(dy, weight, stride, padding, kernel, xshape):
+    """Input gradient of a STRIDED convolution as convolutions of dY, one per residue class of the input position modulo the
+    stride (a transposed convolution decomposed so that no zero is multiplied): class r gathers the taps d = (r + p) mod s,
+    + s, ... and writes the positions s i + r through the kernel's output-row remap.  SlowFast's three kinds: [1,3,3] stride
+    (1,2,2) (4 classes of 1, 2, 2, 4 taps), 1x1x1 stride (1,2,2) (one class; the other positions are zeros), [7,1,1] stride
+    (4,1,1) (4 temporal classes of 1, 2, 2, 2 taps).  -> dx, or None outside that domain (the caller falls back to MIOpen)."""
+    from . import ops
+    from .fused_slowfast import split_planes
+    b, cin, t, h, w = xshape
+    cout = weight.shape[0]
+    st, sh, sw = stride
+    if not ((st == 1 and sh == sw and sh > 1) or (sh == 1 and sw == 1 and st > 1)) or cin % 8 or cout % 8:
+        return None
+    if (st > 1 and t % st) or (sh > 1 and (h % sh or w % sw)) or dy.numel() >= (1 << 30) - 64:
+        return None
+    to, ho, wo = dy.shape[2], dy.shape[3], dy.shape[4]
+    if st > 1 and to * st != t:
+        return None
+    key = (id(weight), "strided", tuple(stride), tuple(padding))
+    hit = _PLANES.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        classes = hit[2]
+    else:
+        per_dim = [_stride_classes(k, s_, p, x, y) for k, s_, p, x, y in zip(kernel, stride, padding, (t, h, w), (to, ho, wo))]
+        if any(c is None for c in per_dim):
+            return None
+        classes = []
+        with torch.no_grad():
+            wf = weight.detach().float()  # [cout, cin, kt, kh, kw]
+            for rt, dt, pbt, nt in per_dim[0]:
+                for rh, dh, pbh, nh in per_dim[1]:
+                    for rw, dw, pbw, nw in per_dim[2]:
+                        if not (dt and dh and dw):
+                            classes.append(((rt, rh, rw), None))
+                            continue
+                        sub = wf[:, :, dt][:, :, :, dh][:, :, :, :, dw]                  # [cout, cin, |dt|, |dh|, |dw|]
+                        wt = sub.transpose(0, 1).permute(0, 2, 3, 4, 1).reshape(cin, -1)   # rows ci, K = (taps, co)
+                        hi, lo = split_planes(wt, ops.X3_BF16)
+                        classes.append(((rt, rh, rw), (hi, lo, (len(dt), len(dh), len(dw)), (pbt, pbh, pbw), (nt, nh, nw))))
+        _PLANES[key] = (weakref.ref(weight), weight._version, classes)
+    dx = torch.empty((b, cin, t, h, w), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last_3d)
+    if any(c[1] is None for c in classes):  # classes no tap reaches (a 1x1x1 filter at stride 2: three of four) are zeros
+        dx.zero_()
+    rows = dx.permute(0, 2, 3, 4, 1).reshape(-1, cin)  # (a view: channels-last memory)
+    dyr = dy.permute(0, 2, 3, 4, 1)
+    for (rt, rh, rw), c in classes:
+        if c is None:
+            continue
+        hi, lo, kern, pad_b, n = c
+        if n[0] * n[1] * n[2] == 0:
+            continue
+        if st > 1:   # temporal classes: frame i_t of class rt is frame st * i_t + rt: a grid of st * h rows per group of st frames
+            out_rows, first = (1, st * h, w), rt * h * w
+        else:        # spatial classes: position (i_h, i_w) of class (rh, rw) is (sh * i_h + rh, sw * i_w + rw)
+            out_rows, first = (sh, h, w), rh * w + rw
+        ops.conv3d_igemm_x3_f32_ex(dyr, hi, lo, None, rows[first:], _ktab(cout, kern, ho, wo, cout, dy.device), (b, to, ho, wo), cout,
+                                   cin, kern, pad_b, n, cout, cin, ops.X3_BF16, out_rows=out_rows)
+    return dx
 
 
 class _ConvX3Fork(torch.autograd.Function):

@@ -477,6 +477,15 @@ int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_l
                             float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
                             int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int lda,
                             int plane_dtype, void* stream);
+/* avt_conv3d_igemm_x3_f32 (stride 1) with an explicit output extent to x ho x wo (positions past the symmetric-padding formula's
+ * far edge are not allowed, fewer are: padding after = whatever the extent needs) and the output-row remap of avt_conv3d_igemm_x3
+ * (position (f, ho, wo) -> row (f * out_h + out_row_stride * ho) * out_w + out_row_stride * wo; out_h = out_w = 0: none).  One
+ * residue class of a STRIDED convolution's input gradient is such a convolution of dY (train_ops._dgrad_strided: the strided
+ * [1,3,3], 1x1x1 and [7,1,1] layers of SlowFast, train.py:139-141 — the last kernels MIOpen ran in the training step). */
+int avt_conv3d_igemm_x3_f32_ex(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
+                               const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
+                               int pt, int ph, int pw, int to, int ho, int wo, int ldi, int ldo, int out_row_stride, int out_h,
+                               int out_w, int plane_dtype, void* stream);
 
 /* Weight gradient of the same convolution on the split-plane arithmetic (csrc/wgrad_x3.hip; bf16 planes, 2^-16 per
  * product): dw[cout][kt*kh*kw][cin] (the memory of a channels_last_3d Conv3d weight) = sum over output positions of

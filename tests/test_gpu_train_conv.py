@@ -18,8 +18,10 @@ def _cl(t):
     (8, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 9, 7), 1.0),         # narrow fast-pathway layer, ragged rows
     (256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 7, 7), 1.0),
     (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 7, 7), 1e-6),      # gradients far below fp16's range
-    (32, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 16, 6, 6), 1.0),       # lateral fusion: strided, dgrad stays MIOpen's
-    (64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 14, 14), 1.0),     # strided 3x3
+    (32, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 16, 6, 6), 1.0),       # lateral fusion: temporal stride 4, dgrad = 4 classes
+    (64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 14, 14), 1.0),     # strided 3x3: dgrad = 4 classes of 1 / 2 / 2 / 4 taps
+    (64, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 3, 14, 10), 1.0),     # strided shortcut: one class, the rest zeros
+    (8, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 4, 28, 28), 1e-6),      # fast-pathway widths, tiny gradients
     (128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 8, 8), 1.0),
 ])
 def test_conv_forward_and_gradients_match_fp32_autograd(cin, cout, kernel, stride, pad, dims, gscale):
@@ -38,7 +40,10 @@ def test_conv_forward_and_gradients_match_fp32_autograd(cin, cout, kernel, strid
         y.backward(gy)
         return y.detach(), x.grad, conv.weight.grad.clone()
 
+    before = dict(train_ops.CALLS)
     ya, dxa, dwa = run(True)
+    assert train_ops.CALLS["miopen_dgrad"] == before["miopen_dgrad"]  # every input gradient on the HIP kernels, strided ones too
+    assert train_ops.CALLS["dgrad_x3"] + train_ops.CALLS["dgrad_strided_x3"] == before["dgrad_x3"] + before["dgrad_strided_x3"] + 1
     ye, dxe, dwe = run(False)
     rel = lambda u, v: float((u - v).norm()) / (float(v.norm()) + 1e-30)
     assert ya.shape == ye.shape
