@@ -741,7 +741,9 @@ def attach_pmc_traffic(kern, args, precision):
             want_tail, sym = ",0>", "stem_kernel<"
         if sym.startswith("pw_x3_kernel<"):
             want_tail, sym = ("true>" if "f16" in sym and "bf16" not in sym else "false>"), "pw_x3_kernel<"
-        if sym in ("bneck_x3_kernel", "conv33_x3_kernel") or sym.startswith("conv_x3_xl_kernel"):  # <..., F16> last
+        if sym.startswith("conv_x3_xl_kernel"):  # conv_x3_xl_kernel<F16, loop variant>
+            sym = "conv_x3_xl_kernel<%s," % ("true" if precision == "f16x3" else "false")
+        elif sym in ("bneck_x3_kernel", "conv33_x3_kernel"):  # <..., F16> last
             want_tail, sym = ("true>" if precision == "f16x3" else "false>"), sym.split("<")[0] + "<"
         sym = sym.rstrip(">")
         f = w = n = 0.0
@@ -756,7 +758,7 @@ def attach_pmc_traffic(kern, args, precision):
 
     table = {"clip_pack": "clip_pack_nhwc4_kernel<%d>" % {"bf16": 0, "bf16x3": 1, "f16x3": 2}[precision],
              "l2norm_rows": "l2norm_vec4", "row_transition": "row_transition_reg_kernel",
-             "sim_gemm_nt": {"f32": "sim_gemm_kernel<2", "bf16x3": "sim_gemm_kernel<1", "bf16": "sim_gemm_kernel<0"}[args.sim_precision]}
+             "sim_gemm_nt": {"f32": "sim_f32_v2_kernel", "bf16x3": "sim_gemm_kernel<1", "bf16": "sim_gemm_kernel<0"}[args.sim_precision]}
     for k in kern:
         sym = table.get(k["kernel"], k["kernel"])
         sym = sym.replace(",bf16>", ",false>").replace(",f16>", ",true>").replace(" ", "")

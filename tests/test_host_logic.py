@@ -451,3 +451,19 @@ def test_kinetics_caffe2_checkpoint_loads_into_slowfast(tmp_path, monkeypatch):
         pickle.dump({"blobs": blobs}, f, protocol=2)
     with pytest.raises(ValueError, match="missing"):
         checkpoint.load_kinetics_slowfast(SlowFast(), str(path))
+
+
+def test_committed_pmc_summary_resolves_the_headline_kernels_traffic():
+    """bench.py's roofline.traffic comes from the committed rocprofv3 PMC summary, matched by device kernel symbol: a renamed
+    template parameter list must not silently turn it into null (it did once: conv_x3_xl_kernel<true> -> <true, 1>)."""
+    import types
+
+    import bench
+    if not os.path.exists(bench.PMC_SUMMARY):
+        pytest.skip("no committed PMC summary")
+    args = types.SimpleNamespace(windows=4096, enc_batch=bench.PMC_BATCH, sim_precision="f32")
+    kern = [{"kernel": k} for k in ("conv_x3_xl_kernel<f16>", "pw_x3_kernel<f16>", "stem_kernel<x3>", "bneck_x3_kernel",
+                                    "conv33_x3_kernel", "sim_gemm_nt", "row_transition", "clip_pack", "l2norm_rows")]
+    bench.attach_pmc_traffic(kern, args, "f16x3")
+    missing = [k["kernel"] for k in kern if not k.get("traffic")]
+    assert not missing, missing
