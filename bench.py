@@ -391,10 +391,11 @@ def train_bench(args, rank, world, dev):
 
     # items per forward/backward pass: all of the rank's items as ONE batch (each item a BatchNorm group of its own:
     # train_ops.bn_replicas = per-replica statistics, what DataParallel gives the reference), or fewer per pass when memory is short
-    per_pass = min(items, args.train_pass_items) if args.train_pass_items > 0 else items
-    passes = -(-items // per_pass)
+    plan = {"per_pass": min(items, args.train_pass_items) if args.train_pass_items > 0 else items}
+    plan["passes"] = -(-items // plan["per_pass"])
 
     def step():
+        per_pass, passes = plan["per_pass"], plan["passes"]
         if grads is not None:
             grads.begin(passes)
         else:
@@ -445,8 +446,19 @@ def train_bench(args, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for w in range(max(args.warmup, 1)):
+        try:
+            step()
+            torch.cuda.synchronize()
+        except torch.cuda.OutOfMemoryError:  # (135 GB for 8 items at once: halve the pass until it fits beside whatever else is resident)
+            if plan["per_pass"] == 1 or world > 1:
+                raise
+            model.zero_grad(set_to_none=True)
+            torch.cuda.empty_cache()
+            plan["per_pass"] = max(1, plan["per_pass"] // 2)
+            plan["passes"] = -(-items // plan["per_pass"])
+            print("[bench] out of memory: %d items per pass" % plan["per_pass"], file=sys.stderr, flush=True)
+            step()
     sync_all()
     if args.train_profile and rank == 0:  # where a steady-state step goes, by device kernel (after MIOpen's solver search)
         from torch.profiler import ProfilerActivity, profile
@@ -475,7 +487,7 @@ def train_bench(args, rank, world, dev):
         "config": {"workload": "BASELINE config 5: batch 8 x (1 query + 1 positive + 14 negatives) = 128 clips/step at 224^2 "
                                "through SlowFast-8x8-R50 q/t encoders (train-mode BatchNorm per item = per DataParallel "
                                "replica), HIP InfoNCE + CE, SGD; inputs sampled and packed on the device",
-                   "items_per_rank": items, "items_per_pass": per_pass, "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
+                   "items_per_rank": items, "items_per_pass": plan["per_pass"], "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
                    "encoder_backend": ("hand-written HIP through torch.autograd.Function (fp32, channels_last_3d): conv_x3 IO32 forward + "
                                        "stride-1 dgrad, wgrad_x3, patch-resident stems (forward + weight gradient), bn_train; query encoder on a side stream; "
                                        "MIOpen for the strided dgrads") if hand
