@@ -420,7 +420,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 // 2 (M) x 4 (N), 128 x 64 outputs per wave in 128 accumulator registers, 12 fragment reads per 24 MFMAs.  The fp32 epilogue
 // staging does not fit for 256 x 256 at once: four passes of one 64-column slab each (the waves of that column block write,
 // every thread splits and stores).
-template <bool F16, int V = 1>
+// IO32 (the training form, avt_conv3d_igemm_x3_f32 on the long-K layers now that a rank's items are one batch): the activations
+// are fp32 rows — they cannot go to the LDS by DMA, so each thread fetches its two 8-channel chunks of the NEXT step into
+// registers (four 16-byte loads) under this step's MFMAs and splits them into the two planes on the way to the LDS after them;
+// the weight planes still arrive by LDS-DMA; ONE fragment set instead of two pays for the staging registers; fp32 epilogue
+// with the `add` operand.
+template <bool F16, int V = 1, bool IO32 = false>
 __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   constexpr int BM = 256, BN = 256, NTHR = 512, KB = 32;  // K-step in elements
   constexpr int MT = 4, NT = 2;                            // 32 x 32 sub-tiles of a wave's 128 x 64
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
       const unsigned sel = ((rowmask[u] & ebits) == ebits) ? 0xFFFFFFFFu : 0u;
-      aoffs[u] = (((unsigned)(rowoff[u] + e.x) * 2u) & sel) | (kOob & ~sel);
+      aoffs[u] = (((unsigned)(rowoff[u] + e.x) * (IO32 ? 4u : 2u)) & sel) | (kOob & ~sel);
     }
     const unsigned ksel = ~(unsigned)(e.y >> 31);
     const unsigned kc2 = (unsigned)((kt * 4 + c4) * 16);
@@ -552,6 +557,35 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
                                                (int)boffs[u], 0, 0, 0);
     }
   };
+  // IO32: this thread's two 8-channel chunks of the step (fp32: two 16-byte loads each) -> planes -> the slot the DMA would fill
+  i32x4 ra[IO32 ? AU : 1][2];
+  auto aload = [&]() {
+    if constexpr (IO32) {
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const unsigned o2 = aoffs[u] == kOob ? kOob : aoffs[u] + 16u;
+        ra[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)aoffs[u], 0, 0);
+        ra[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rih, (int)o2, 0, 0);
+      }
+    }
+  };
+  auto astore = [&](char* st) {
+    if constexpr (IO32) {
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const float* fa = reinterpret_cast<const float*>(&ra[u][0]);
+        const float* fb = reinterpret_cast<const float*>(&ra[u][1]);
+        uint4 h, l;
+        avt::split2<F16>(fa[0], fa[1], h.x, l.x);
+        avt::split2<F16>(fa[2], fa[3], h.y, l.y);
+        avt::split2<F16>(fb[0], fb[1], h.z, l.z);
+        avt::split2<F16>(fb[2], fb[3], h.w, l.w);
+        const int o = (r0 + 128 * u) * 64 + (tid & 3) * 16;
+        *reinterpret_cast<uint4*>(st + o) = h;
+        *reinterpret_cast<uint4*>(st + PL + o) = l;
+      }
+    }
+  };
   const int fsw = (lr >> 2) & 3;  // the swizzle of this lane's fragment rows (tile bases are multiples of 32)
   struct Frags {
     i32x4 ah[MT], al[MT], wh[NT], wl[NT];
@@ -584,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         acc[i][j] = mfma<F16>(f.wl[i], f.ah[j], acc[i][j]);
         acc[i][j] = mfma<F16>(f.wh[i], f.al[j], acc[i][j]);
         acc[i][j] = mfma<F16>(f.wh[i], f.ah[j], acc[i][j]);
-        const int pc = g0 + i * MT + j;
+        const int pc = g0 + i * MT + j + (IO32 ? 2 * AU : 0);  // (IO32: the weight pieces only)
         if (more && pc < NPIECE) gpiece(pc, nst);  // the next step's DMA, one piece per MFMA triple of the first k-slice
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -631,12 +665,42 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   __syncthreads();
   STAMP_BEGIN();
   gprep(0);
+  if constexpr (IO32) {
+    aload();
 #pragma unroll
-  for (int p = 0; p < NPIECE; ++p) gpiece(p, lds);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int p = 2 * AU; p < NPIECE; ++p) gpiece(p, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    astore(lds);
+  } else {
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) gpiece(p, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
   STAMP(0);  // prologue
-  if constexpr (V == 2) {
+  if constexpr (IO32) {
+    for (int kt = 0; kt < nk32; ++kt) {
+      const bool more = kt + 1 < nk32;
+      char* cur = lds + (kt & 1) * STG;
+      char* nst = lds + ((kt + 1) & 1) * STG;
+      int2 e = make_int2(0, 0);
+      if (more) e = gtab(kt + 1);
+      Frags f;
+      fload(f, cur, 0);
+      if (more) {
+        gcalc(kt + 1, e);
+        aload();  // in flight under this step's MFMAs
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fmul(f, 0, more, nst);
+      fload(f, cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      fmul(f, NPIECE, false, nst);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (more) astore(nst);
+      __syncthreads();
+    }
+  } else if constexpr (V == 2) {
     for (int kt = 0; kt < nk32; ++kt) {
       const bool more = kt + 1 < nk32;
       char* cur = lds + (kt & 1) * STG;
@@ -721,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   constexpr int EU = (BM * CPR) / NTHR;        // 4 chunks per thread and pass
   constexpr int EBUF = BM * ESTR;
   static_assert(2 * EBUF <= 2 * STG + kMaxTabSteps * 64, "two staging buffers fit the operand stages + the table area");
-  const bool has_res = a.res != nullptr;
+  const bool has_res = !IO32 && a.res != nullptr;  // (IO32: `res` is an fp32 tensor added in the store loop)
   auto stage_slab = [&](int pass) {  // the two waves rows x this column block write their 128 x 64 accumulators
     char* eb = lds + (pass & 1) * EBUF;
     if constexpr (V == 2) {
@@ -812,13 +876,25 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
           for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.1f * x[e]);
         }
         const int64_t o = (int64_t)out_row(a, m) * a.ldo + n;
-        uint4 oh, ol;
-        avt::split2<F16>(x[0], x[1], oh.x, ol.x);
-        avt::split2<F16>(x[2], x[3], oh.y, ol.y);
-        avt::split2<F16>(x[4], x[5], oh.z, ol.z);
-        avt::split2<F16>(x[6], x[7], oh.w, ol.w);
-        *reinterpret_cast<uint4*>(a.out + o) = oh;
-        *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
+        if constexpr (IO32) {
+          if (a.res) {  // out = conv + add (train_ops.conv3d_fork): fp32 rows
+            const float* rf = reinterpret_cast<const float*>(a.res) + (int64_t)m * a.ldr + n;
+            const float4 q0 = *reinterpret_cast<const float4*>(rf), q1 = *reinterpret_cast<const float4*>(rf + 4);
+            x[0] += q0.x; x[1] += q0.y; x[2] += q0.z; x[3] += q0.w;
+            x[4] += q1.x; x[5] += q1.y; x[6] += q1.z; x[7] += q1.w;
+          }
+          float* of = reinterpret_cast<float*>(a.out) + o;
+          *reinterpret_cast<float4*>(of) = make_float4(x[0], x[1], x[2], x[3]);
+          *reinterpret_cast<float4*>(of + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        } else {
+          uint4 oh, ol;
+          avt::split2<F16>(x[0], x[1], oh.x, ol.x);
+          avt::split2<F16>(x[2], x[3], oh.y, ol.y);
+          avt::split2<F16>(x[4], x[5], oh.z, ol.z);
+          avt::split2<F16>(x[6], x[7], oh.w, ol.w);
+          *reinterpret_cast<uint4*>(a.out + o) = oh;
+          *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
+        }
       }
     }
     __syncthreads();  // slab pass + 1 is staged; buffer pass & 1 is free for slab pass + 2
@@ -826,20 +902,20 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   STAMP_END();
 }
 
-template <bool F16, int V = 1>
+template <bool F16, int V = 1, bool IO32 = false>
 int launch_x3_xl(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.Cout + 255) / 256;
   a.nblk = tiles_m * a.tiles_n;
   constexpr int lds_max = 2 * 4 * 256 * 64 + kMaxTabSteps * 64;
   const int lds_bytes = lds_max;  // (the epilogue's second staging buffer reaches into the table area)
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16, V>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16, V, IO32>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_max, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((conv_x3_xl_kernel<F16, V>), dim3((unsigned)a.nblk), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_x3_xl_kernel<F16, V, IO32>), dim3((unsigned)a.nblk), dim3(512), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_x3");
 }
 
@@ -968,6 +1044,10 @@ static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_
   a.nup = 0;
   a.wblk = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // long-K layers at a batch that fills 256 x 256 tiles (a rank's items as one batch): the XL tile's IO32 form
+  static const int xl32 = avt::env_int_flag("AVT_CONV_X3_XL_IO32", 1);
+  if (xl32 && a.K % 32 == 0 && a.oH == 0 && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M) && a.M >= 256 * 256)
+    return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, 0, true>(a, s) : launch_x3_xl<false, 0, true>(a, s);
   if (plane_dtype == AVT_X3_F16) {
     if (cout <= 32) return launch_x3<128, 32, 32, true, true>(a, s);
     if (cout <= 64) return launch_x3<128, 64, 64, true, true>(a, s);

@@ -23,6 +23,9 @@ def _cl(t):
     (64, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 3, 14, 10), 1.0),     # strided shortcut: one class, the rest zeros
     (8, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 4, 28, 28), 1e-6),      # fast-pathway widths, tiny gradients
     (128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 8, 8), 1.0),
+    (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (24, 8, 20, 20), 1.0),   # 76 800 positions: the 256 x 256 tile's IO32 form (fwd + dgrad)
+    (512, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (41, 8, 15, 15), 1e-6),  # ragged last tile (73 800 rows), long K, tiny gradients
+    (256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (24, 8, 20, 20), 1.0),  # pointwise rows, 4 column tiles; dgrad has K = 1024
 ])
 def test_conv_forward_and_gradients_match_fp32_autograd(cin, cout, kernel, stride, pad, dims, gscale):
     from avtex import train_ops
