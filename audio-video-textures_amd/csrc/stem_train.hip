@@ -311,6 +311,75 @@ __global__ __launch_bounds__(256) void maxpool_train_bwd_kernel(MpArgs a) {
   }
 }
 
+// ---- weight planes of the training convolutions ------------------------------------------------------------------------------
+// The optimizer changes every weight every step, so every step re-splits them into the planes conv_x3 reads.  As torch ops that
+// was ~35 tiny launches per convolution (abs / amax / log2 / floor / pow / mul / casts / flip / permute-copies): 7 600 launches
+// and 42 ms of a 415 ms step once a rank's items had become one pass (profiles/r03/rocprof_train_kernel_stats_before_planes.csv).
+// Two kernels instead: the forward's planes straight from the channels-last weight (its memory IS [cout][taps][cin]), and the
+// input gradient's transposed, tap-selected planes W'[ci][tap a][co] = W[co][taps[a]][ci] through a 32 x 32 LDS transpose.
+template <bool F16>
+__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ w, int K, uint16_t* __restrict__ hi,
+                                                            uint16_t* __restrict__ lo, float* __restrict__ wscale) {
+  __shared__ float red[256];
+  const float* row = w + (int64_t)blockIdx.x * K;
+  float sc = 1.0f;
+  if (wscale) {  // fp16 planes: the row scaled by a power of two into [2^9, 2^10) (undone on the accumulator: wscale = 1 / scale)
+    float mx = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(row[k]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+      __syncthreads();
+    }
+    mx = fmaxf(red[0], 1e-30f);
+    int e;
+    (void)frexpf(mx, &e);  // mx = m * 2^e, m in [0.5, 1): floor(log2(mx)) = e - 1
+    sc = ldexpf(1.0f, 10 - e);
+    if (threadIdx.x == 0) wscale[blockIdx.x] = ldexpf(1.0f, e - 10);
+  }
+  for (int k = 2 * threadIdx.x; k < K; k += 512) {
+    uint32_t h, l;
+    avt::split2<F16>(row[k] * sc, row[k + 1] * sc, h, l);
+    *reinterpret_cast<uint32_t*>(hi + (int64_t)blockIdx.x * K + k) = h;
+    *reinterpret_cast<uint32_t*>(lo + (int64_t)blockIdx.x * K + k) = l;
+  }
+}
+
+struct WtArgs {
+  const float* w;  // [cout][taps][cin]
+  uint16_t* hi;    // [cin][nsel][cout]
+  uint16_t* lo;
+  int cout, taps, cin, nsel;
+  int sel[32];     // source tap of output tap a
+};
+
+__global__ __launch_bounds__(256) void weight_planes_t_kernel(WtArgs a) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int src = a.sel[tap];
+#pragma unroll
+  for (int j = ty; j < 32; j += 8) {
+    const int co = co0 + j, ci = ci0 + tx;
+    tile[j][tx] = (co < a.cout && ci < a.cin) ? a.w[((int64_t)co * a.taps + src) * a.cin + ci] : 0.0f;
+  }
+  __syncthreads();
+  // out row ci0 + i, columns co0 .. co0 + 31 as 16 pairs: thread (pair p = tx & 15, row i = ty + 8 * (tx >> 4) + 16 * h)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int i = ty + 8 * (tx >> 4) + 16 * h, p = tx & 15;
+    const int ci = ci0 + i, co = co0 + 2 * p;
+    if (ci < a.cin && co < a.cout) {
+      uint32_t hh, ll;
+      avt::split2<false>(tile[2 * p][i], tile[2 * p + 1][i], hh, ll);
+      const int64_t o = ((int64_t)ci * a.nsel + tap) * a.cout + co;
+      *reinterpret_cast<uint32_t*>(a.hi + o) = hh;
+      *reinterpret_cast<uint32_t*>(a.lo + o) = ll;
+    }
+  }
+}
+
 template <int KT, int CO>
 int launch_wgrad(SwArgs& a, hipStream_t st) {
   constexpr int FP = CO == 8 ? 2 : 1, NP = (KT + FP - 1) / FP;
@@ -416,4 +485,32 @@ extern "C" int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx
   hipLaunchKernelGGL(maxpool_train_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return avt::check_launch("avt_maxpool_train_bwd");
+}
+
+// Weight planes of a training convolution (see include/avt.h)
+extern "C" int avt_weight_planes_f32(const float* w, int cout, int k, void* hi, void* lo, float* wscale, int plane_dtype, void* stream) {
+  AVT_REQUIRE(w && hi && lo && cout > 0 && k > 0 && k % 2 == 0, "avt_weight_planes_f32: NULL pointer / bad sizes (k even)");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_weight_planes_f32: bad plane_dtype");
+  AVT_REQUIRE((plane_dtype == AVT_X3_F16) == (wscale != nullptr), "avt_weight_planes_f32: fp16 planes are row-scaled (wscale), bf16 planes are not");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto h = static_cast<uint16_t*>(hi), l = static_cast<uint16_t*>(lo);
+  if (plane_dtype == AVT_X3_F16) hipLaunchKernelGGL(weight_planes_kernel<true>, dim3((unsigned)cout), dim3(256), 0, s, w, k, h, l, wscale);
+  else hipLaunchKernelGGL(weight_planes_kernel<false>, dim3((unsigned)cout), dim3(256), 0, s, w, k, h, l, wscale);
+  return avt::check_launch("avt_weight_planes_f32");
+}
+
+extern "C" int avt_weight_planes_t_f32(const float* w, int cout, int taps, int cin, const int32_t* sel, int nsel, void* hi, void* lo,
+                                       void* stream) {
+  AVT_REQUIRE(w && hi && lo && sel && cout > 0 && cout % 2 == 0 && cin > 0 && taps > 0 && nsel > 0 && nsel <= 32,
+              "avt_weight_planes_t_f32: NULL pointer / bad sizes (cout even, 1..32 selected taps)");
+  WtArgs a;
+  a.w = w; a.hi = static_cast<uint16_t*>(hi); a.lo = static_cast<uint16_t*>(lo);
+  a.cout = cout; a.taps = taps; a.cin = cin; a.nsel = nsel;
+  for (int i = 0; i < nsel; ++i) {
+    AVT_REQUIRE(sel[i] >= 0 && sel[i] < taps, "avt_weight_planes_t_f32: tap %d outside the filter", sel[i]);
+    a.sel[i] = sel[i];
+  }
+  const dim3 grid((unsigned)((cin + 31) / 32), (unsigned)((cout + 31) / 32), (unsigned)nsel);
+  hipLaunchKernelGGL(weight_planes_t_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return avt::check_launch("avt_weight_planes_t_f32");
 }

@@ -353,6 +353,32 @@ def conv3d_igemm_x3_f32_ex(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, 
                "avt_conv3d_igemm_x3_f32_ex")
 
 
+def weight_planes_f32(w2d, plane_dtype):
+    """[cout, k] fp32 rows (a channels-last Conv3d weight viewed as rows) -> (hi, lo, wscale): fp16 planes row-scaled into
+    [2^9, 2^10) with wscale = 1 / scale, or unscaled bf16 planes with wscale None (csrc/stem_train.hip)."""
+    _dev(w2d, "w", torch.float32)
+    cout, k = w2d.shape
+    hi = torch.empty((cout, k), dtype=torch.bfloat16, device=w2d.device)
+    lo = torch.empty_like(hi)
+    ws = torch.empty(cout, dtype=torch.float32, device=w2d.device) if plane_dtype == X3_F16 else None
+    _lib.check(_lib.lib().avt_weight_planes_f32(_p(w2d), int(cout), int(k), _p(hi), _p(lo), _p(ws), int(plane_dtype), _stream()),
+               "avt_weight_planes_f32")
+    return hi, lo, ws
+
+
+def weight_planes_t_f32(w3d, sel):
+    """[cout, taps, cin] fp32 -> (hi, lo) bf16 planes [cin, len(sel) * cout] with out[ci][a][co] = w[co][sel[a]][ci]: the input
+    gradient's filter (sel = all taps reversed) or one residue class of a strided layer's (csrc/stem_train.hip)."""
+    _dev(w3d, "w", torch.float32)
+    cout, taps, cin = w3d.shape
+    hi = torch.empty((cin, len(sel) * cout), dtype=torch.bfloat16, device=w3d.device)
+    lo = torch.empty_like(hi)
+    arr = (C.c_int32 * len(sel))(*[int(v) for v in sel])
+    _lib.check(_lib.lib().avt_weight_planes_t_f32(_p(w3d), int(cout), int(taps), int(cin), arr, len(sel), _p(hi), _p(lo), _stream()),
+               "avt_weight_planes_t_f32")
+    return hi, lo
+
+
 def conv3d_wgrad_x3_f32(dy, x, dw, dims, cin, cout, kernel, stride, pad, ldx, ldy):
     """dw [cout, taps, cin] fp32 = weight gradient of the convolution (csrc/wgrad_x3.hip); dy / x fp32 NDHWC rows; dims = x's (B,T,H,W)."""
     b, t, h, w = dims

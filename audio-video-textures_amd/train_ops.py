@@ -32,6 +32,7 @@ _CONV_X3 = int(os.environ.get("AVT_TRAIN_CONV_X3", "1"))
 _WGRAD_X3 = int(os.environ.get("AVT_TRAIN_WGRAD_X3", "1"))
 _DGRAD_S_X3 = int(os.environ.get("AVT_TRAIN_DGRAD_STRIDED_X3", "1"))
 _STEM_WGRAD_X3 = int(os.environ.get("AVT_TRAIN_STEM_WGRAD_X3", "1"))
+_PLANES_HIP = int(os.environ.get("AVT_TRAIN_PLANES_HIP", "1"))  # weight planes by csrc/stem_train.hip's two kernels (0: torch ops)
 _STEM_PATCH = int(os.environ.get("AVT_TRAIN_STEM_PATCH", "1"))  # the stems on the patch-resident kernels (0: conv_x3 + wgrad slices)
 _FORK = int(os.environ.get("AVT_TRAIN_FORK", "1"))
 
@@ -276,7 +277,9 @@ class MicroBatchGradients:
 
     def finish(self):
         global _ARENA
-        _ARENA = None
+        arena_on, _ARENA = _ARENA is not None, None
+        if not arena_on:  # (a single pass: every gradient owns its storage)
+            return
         # the gradients the last pass produced as arena slices live on in .grad only where autograd accumulated into the
         # accumulator's own tensors; a parameter first seen in the last pass keeps an arena slice: give it its own storage
         if self.acc is None:
@@ -317,20 +320,33 @@ def _weight_planes(weight, transposed):
     if hit is not None and hit[0]() is weight and hit[1] == weight._version:
         return hit[2]
     with torch.no_grad():
-        w = weight.detach().float()
-        if w.shape[1] % 8:  # the stems' 3 input channels, padded with zero taps
-            w = torch.cat([w, w.new_zeros((w.shape[0], 8 - w.shape[1] % 8) + tuple(w.shape[2:]))], 1)
-        if transposed:
-            w = w.flip(2, 3, 4).transpose(0, 1)
-        wt = w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
-        if transposed:
-            hi, lo = split_planes(wt, ops.X3_BF16)
-            planes = (hi, lo, None)
-        else:  # fp16 planes: rows scaled by a power of two into [2^9, 2^10), undone on the accumulator (fused_slowfast.FusedConv)
-            mx = wt.abs().amax(dim=1).clamp_min(1e-30)
-            sc = torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
-            hi, lo = split_planes(wt * sc.view(-1, 1), ops.X3_F16)
-            planes = (hi, lo, (1.0 / sc).float().contiguous())
+        w = weight.detach()
+        fast = (_PLANES_HIP and w.dtype == torch.float32 and w.dim() == 5 and w.shape[1] % 8 == 0 and w.shape[0] % 2 == 0 and
+                w.is_contiguous(memory_format=torch.channels_last_3d) and w.shape[2] * w.shape[3] * w.shape[4] <= 32)
+        if fast:  # two launches per convolution and step instead of ~35 torch ops (the memory of a channels-last weight is
+            #       already [cout][taps][cin], the kernels' K order)
+            cout, cin = w.shape[0], w.shape[1]
+            taps = w.shape[2] * w.shape[3] * w.shape[4]
+            rows = w.permute(0, 2, 3, 4, 1).reshape(cout, taps * cin)  # a view
+            if transposed:
+                planes = ops.weight_planes_t_f32(rows.view(cout, taps, cin), list(range(taps - 1, -1, -1))) + (None,)
+            else:
+                planes = ops.weight_planes_f32(rows, ops.X3_F16)
+        else:
+            w = w.float()
+            if w.shape[1] % 8:  # the stems' 3 input channels, padded with zero taps
+                w = torch.cat([w, w.new_zeros((w.shape[0], 8 - w.shape[1] % 8) + tuple(w.shape[2:]))], 1)
+            if transposed:
+                w = w.flip(2, 3, 4).transpose(0, 1)
+            wt = w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
+            if transposed:
+                hi, lo = split_planes(wt, ops.X3_BF16)
+                planes = (hi, lo, None)
+            else:  # fp16 planes: rows scaled by a power of two into [2^9, 2^10), undone on the accumulator (fused_slowfast.FusedConv)
+                mx = wt.abs().amax(dim=1).clamp_min(1e-30)
+                sc = torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
+                hi, lo = split_planes(wt * sc.view(-1, 1), ops.X3_F16)
+                planes = (hi, lo, (1.0 / sc).float().contiguous())
     if len(_PLANES) > 4096:  # entries of models that are gone
         for k in [k for k, v in _PLANES.items() if v[0]() is None]:
             del _PLANES[k]
@@ -477,16 +493,24 @@ def _dgrad_strided(dy, weight, stride, padding, kernel, xshape):
             return None
         classes = []
         with torch.no_grad():
-            wf = weight.detach().float()  # [cout, cin, kt, kh, kw]
+            wd = weight.detach()
+            fast = (_PLANES_HIP and wd.dtype == torch.float32 and wd.is_contiguous(memory_format=torch.channels_last_3d) and
+                    cout % 2 == 0)
+            wf = None if fast else wd.float()  # [cout, cin, kt, kh, kw]
+            w3 = wd.permute(0, 2, 3, 4, 1).reshape(cout, kernel[0] * kernel[1] * kernel[2], cin) if fast else None  # a view
             for rt, dt, pbt, nt in per_dim[0]:
                 for rh, dh, pbh, nh in per_dim[1]:
                     for rw, dw, pbw, nw in per_dim[2]:
                         if not (dt and dh and dw):
                             classes.append(((rt, rh, rw), None))
                             continue
-                        sub = wf[:, :, dt][:, :, :, dh][:, :, :, :, dw]                  # [cout, cin, |dt|, |dh|, |dw|]
-                        wt = sub.transpose(0, 1).permute(0, 2, 3, 4, 1).reshape(cin, -1)   # rows ci, K = (taps, co)
-                        hi, lo = split_planes(wt, ops.X3_BF16)
+                        if fast:  # one launch: the class's taps (row-major over its (dt, dh, dw) lists) gathered and transposed
+                            sel = [(a * kernel[1] + b_) * kernel[2] + c_ for a in dt for b_ in dh for c_ in dw]
+                            hi, lo = ops.weight_planes_t_f32(w3, sel)
+                        else:
+                            sub = wf[:, :, dt][:, :, :, dh][:, :, :, :, dw]                  # [cout, cin, |dt|, |dh|, |dw|]
+                            wt = sub.transpose(0, 1).permute(0, 2, 3, 4, 1).reshape(cin, -1)   # rows ci, K = (taps, co)
+                            hi, lo = split_planes(wt, ops.X3_BF16)
                         classes.append(((rt, rh, rw), (hi, lo, (len(dt), len(dh), len(dw)), (pbt, pbh, pbw), (nt, nh, nw))))
         _PLANES[key] = (weakref.ref(weight), weight._version, classes)
     dx = torch.empty((b, cin, t, h, w), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last_3d)

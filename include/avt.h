@@ -523,6 +523,17 @@ int avt_stem_wgrad_x3_supported(int h, int pw, int cout, int kt);
 int avt_stem_wgrad_x3(const void* x_hi, const void* x_lo, const float* dy, float* dw, int batch, int t, int h, int pw,
                       int cout, int kt, int pt, void* stream);
 
+/* The planes conv_x3 reads, from a training convolution's fp32 weight (re-made after every optimizer step; csrc/stem_train.hip).
+ * avt_weight_planes_f32: w [cout][k] fp32 (a channels-last Conv3d weight: k = taps * cin) -> hi / lo [cout][k]; fp16 planes
+ *   (plane_dtype 1) are scaled per row by a power of two into [2^9, 2^10) and wscale [cout] receives 1 / scale; bf16 planes
+ *   (plane_dtype 0) are unscaled and wscale must be NULL.
+ * avt_weight_planes_t_f32: the input gradient's filter: hi / lo [cin][nsel][cout] bf16 planes with
+ *   out[ci][a][co] = w[co][sel[a]][ci] (sel = HOST array of nsel <= 32 source taps: all taps reversed for a stride-1 layer,
+ *   one residue class's taps for a strided one, train_ops._dgrad_strided). */
+int avt_weight_planes_f32(const float* w, int cout, int k, void* hi, void* lo, float* wscale, int plane_dtype, void* stream);
+int avt_weight_planes_t_f32(const float* w, int cout, int taps, int cin, const int32_t* sel, int nsel, void* hi, void* lo,
+                            void* stream);
+
 /* MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the stems in the training step on fp32 NDHWC rows [bt, h, w, c] (csrc/stem_train.hip;
  * the reference: the third-party SlowFast stem under autograd, train.py:114-141).  fwd: y [bt, ho, wo, c] and `tap`
  * (bt*ho*wo*c/2 bytes: 4 bits per element = which of the 9 taps held the maximum; the first one on ties, a NaN wins — torch's
