@@ -242,14 +242,19 @@ def test_weight_plane_cache_is_per_tensor_not_per_address():
     assert not torch.allclose(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("stride", [(1, 1, 1), (1, 2, 2)])
-def test_fork_sums_the_other_path_in_the_kernel(stride):
+@pytest.mark.parametrize("stride,cin,cout,kernel,pad,dims", [
+    ((1, 1, 1), 32, 64, (1, 3, 3), (0, 1, 1), (2, 3, 10, 10)),
+    ((1, 2, 2), 32, 64, (1, 3, 3), (0, 1, 1), (2, 3, 10, 10)),
+    ((1, 1, 1), 256, 64, (3, 1, 1), (1, 0, 0), (24, 8, 20, 20)),   # 76 800 positions, dgrad 64 -> 256 over K = 192: the 128-wide tile
+    ((1, 1, 1), 256, 256, (3, 1, 1), (1, 0, 0), (24, 8, 20, 20)),  # dgrad 256 -> 256 over K = 768: the 256 x 256 tile's IO32 form + add
+])
+def test_fork_sums_the_other_path_in_the_kernel(stride, cin, cout, kernel, pad, dims):
     """conv3d_fork: the gradient that reaches x through the alias is added in the epilogue of the convolution's own
-    input-gradient kernel (stride 1) or after MIOpen's (strided) — either way dx = dgrad(dy) + d_alias."""
+    input-gradient kernel (stride 1, both tiles) or after the strided classes — either way dx = dgrad(dy) + d_alias."""
     from avtex import train_ops
     torch.manual_seed(5)
-    conv = nn.Conv3d(32, 64, (1, 3, 3), stride=stride, padding=(0, 1, 1), bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
-    x0 = _cl(torch.randn(2, 32, 3, 10, 10, device=DEV))
+    conv = nn.Conv3d(cin, cout, kernel, stride=stride, padding=pad, bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+    x0 = _cl(torch.randn(dims[0], cin, *dims[1:], device=DEV))
     x = x0.clone().requires_grad_(True)
     y, xs = train_ops.conv3d_fork(x, conv)
     gy, gx = _cl(torch.randn_like(y)), _cl(torch.randn_like(x0))
