@@ -49,6 +49,10 @@ def build_parser():
     a("--SF", "-SF", default=5, type=int, help="slomo factor N")
     a("--train_layout", default="ndhwc", choices=["ndhwc", "ncdhw"],
       help="memory layout of the encoders in training: ndhwc = channels_last_3d (+ fused BatchNorm passes), ncdhw = torch default")
+    a("--bn_replicas", default=1, type=int,
+      help="train(): normalise the rank's batch as this many equal groups of items, each with its own BatchNorm statistics — "
+           "what the reference's DataParallel gives every GPU's share of the batch (main.py:420); 1 = over the rank's whole "
+           "batch; -1 = one group per item (batch 8 on 8 GPUs in the reference)")
     a("--train_conv", default="x3", choices=["x3", "fp32"],
       help="arithmetic of the training convolutions (with --train_layout ndhwc): x3 = split-plane MFMA kernels, fp32 "
            "accumulation, forward 2^-22 / gradients 2^-16 per product (default; train_ops.py); fp32 = MIOpen's fp32 "

@@ -33,8 +33,11 @@ def train(train_loader, model, optimizer, args, epoch, tb_logger=None):
         q_audio_eg, t_audio_eg = q_audio_eg.cuda(), t_audio_eg.cuda()
         data_time.update(time.time() - end)
 
-        output = model(q_frames, t_frames, q_audio_eg=q_audio_eg, t_audio_eg=t_audio_eg)  # train.py:114-116
         batch_size = (q_frames[0] if isinstance(q_frames, list) else q_frames).shape[0]
+        groups = getattr(args, "bn_replicas", 1)
+        groups = batch_size if groups < 0 else groups
+        with train_ops.bn_replicas(groups if groups > 1 and batch_size % groups == 0 else 1):
+            output = model(q_frames, t_frames, q_audio_eg=q_audio_eg, t_audio_eg=t_audio_eg)  # train.py:114-116
         labels = torch.zeros(batch_size, dtype=torch.long, device=output.device)  # positives at column 0
         loss = criterion(output, labels).mean()
         losses.update(loss.item(), batch_size)

@@ -36,3 +36,16 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
 rows = sorted(prof.key_averages(), key=lambda e: -e.count)
 for e in rows[:40]:
     print("%-60s count %5d  cpu %8.1f us  cuda %8.1f us" % (e.key[:60], e.count, e.self_cpu_time_total, e.self_device_time_total))
+# who launches the small device copies / fills: the innermost torch op around each hipMemcpyAsync / hipMemsetAsync
+import collections
+par = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("hipMemcpyAsync", "hipMemcpyWithStream", "hipMemsetAsync") or "Memcpy" in ev.name:
+        p_ = ev.cpu_parent
+        chain = []
+        while p_ is not None and len(chain) < 3:
+            chain.append(p_.name[:40])
+            p_ = p_.cpu_parent
+        par[(ev.name[:24], " < ".join(chain))] += 1
+for k, v in par.most_common(15):
+    print(v, k)
