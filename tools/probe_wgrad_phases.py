@@ -4,10 +4,11 @@ import sys, time, torch
 sys.path.insert(0, ".")
 from avtex import ops
 dev = "cuda:0"
-for (cin, cout, k, s, p, xs) in [(1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (15, 1024, 8, 14, 14)),
-                                 (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (15, 256, 8, 14, 14)),
-                                 (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (15, 64, 8, 56, 56)),
-                                 (256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (15, 256, 8, 14, 14))]:
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 15  # clips per launch (120 = a rank's items as one batch)
+for (cin, cout, k, s, p, xs) in [(1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (BATCH, 1024, 8, 14, 14)),
+                                 (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (BATCH, 256, 8, 14, 14)),
+                                 (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (BATCH, 64, 8, 56, 56)),
+                                 (256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (BATCH, 256, 8, 14, 14))]:
     x = torch.randn(xs, device=dev).contiguous(memory_format=torch.channels_last_3d)
     w = torch.randn(cout, cin, *k, device=dev).contiguous(memory_format=torch.channels_last_3d)
     y = torch.nn.functional.conv3d(x, w, stride=s, padding=p)
