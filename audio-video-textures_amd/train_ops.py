@@ -295,7 +295,7 @@ class MicroBatchGradients:
 # dy with the flipped, transposed filter).  fp32 tensors in and out; 2^-22 (forward, fp16 planes) / 2^-16 (dgrad, bf16
 # planes: gradients need fp32's exponent range) per product instead of the fp32 MFMA's rate of 1/16 of the bf16 pipe.
 # The weight gradient is csrc/wgrad_x3.hip (bf16 planes, transposing LDS stage, split over positions with fp32 atomics);
-# the strided dgrads and the stems' weight gradient stay MIOpen's (aten.convolution_backward).
+# the strided layers' input gradients are `_dgrad_strided` below; the stems have kernels of their own (`_StemX3`).
 _TABS, _PLANES = {}, {}
 
 

@@ -490,14 +490,14 @@ def train_bench(args, rank, world, dev):
                    "items_per_rank": items, "items_per_pass": plan["per_pass"], "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
                    "encoder_backend": ("hand-written HIP through torch.autograd.Function (fp32, channels_last_3d): conv_x3 IO32 forward + "
                                        "stride-1 dgrad, wgrad_x3, patch-resident stems (forward + weight gradient), bn_train; query encoder on a side stream; "
-                                       "MIOpen for the strided dgrads") if hand
+                                       "strided input gradients as residue-class convolutions, HIP max-pool; the rank's items as one batch of per-item BatchNorm groups") if hand
                    else "MIOpen convolutions through autograd (%s%s)" % (args.train_dtype, ", channels_last_3d" if channels_last else ""),
                    "parallelism": "dp%d, gradient all-reduce once per step" % world},
         "training_steps_per_s": args.steps / total_s, "items_per_s": B * args.steps / total_s,
         "max_memory_allocated_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         "loss_first_last": [losses[0], losses[-1]],
         "roofline": {"kernel": ("conv_x3_kernel<IO32> fwd / stride-1 dgrad + wgrad_x3_kernel (split-plane MFMA, 1/3 of the bf16 peak); "
-                                "whole step incl. BatchNorm passes, the stems, MIOpen strided dgrads, optimizer") if hand
+                                "whole step incl. BatchNorm passes, the stems, optimizer") if hand
                                else "MIOpen conv3d fwd/dgrad/wgrad (library)", "bound": "mfma", "achieved": flops * args.steps / total_s / 1e12,
                      "peak": peak, "unit": "TFLOP/s", "frac": flops * args.steps / total_s / 1e12 / peak, "traffic": None}}
 
