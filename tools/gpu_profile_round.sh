@@ -32,7 +32,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 agg[row["Kernel_Name"][:120]].append(float(row["Counter_Value"]))
     for k, v in agg.items():
         out.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "total": sum(v)}
-out["_note"] = "KB per launch as rocprofv3 reports them (FETCH_SIZE NOT yet doubled); tools/pmc_kernels.py shapes: N=4096, D=2304, 128-clip encoder forwards"
+out["_note"] = "KB per launch as rocprofv3 reports them (FETCH_SIZE NOT yet doubled); tools/pmc_kernels.py shapes: N=4096, D=2304, encoder forwards at bench.py's default --enc-batch"
 json.dump(out, open(out_dir + "/pmc_fetch_write_summary.json", "w"), indent=1)
 for k, v in out.items():
     if not k.startswith("_"):

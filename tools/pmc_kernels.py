@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import avtex
 from avtex import ops
 dev = torch.device("cuda:0")
-N, D, W, S, B = 4096, 2304, 20, 4, 83  # B = bench.py's --enc-batch default
+N, D, W, S, B = 4096, 2304, 20, 4, 166  # B = bench.py's --enc-batch default
 g = torch.Generator().manual_seed(123)
 video = torch.randint(0, 256, (B * S + W, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
 starts = np.arange(B, dtype=np.int64) * S
