@@ -16,6 +16,7 @@ def test_bench_under_torchrun_one_rank_rccl(dev):
     env = dict(os.environ, AVT_FORCE_PG="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--windows", "128",
+           "--enc-batch", "64",  # (two batches: the bf16 leg's two encoder streams have something to overlap)
            "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-precision-block", "--no-nxn-legs", "--no-train-leg"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
