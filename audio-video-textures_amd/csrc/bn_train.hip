@@ -178,9 +178,12 @@ __global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // gri
     double s0[kGroupBatch], s1[kGroupBatch];
     channel_sums(a, g0, ng, c, s0, s1);
     if ((threadIdx.x & 63) != 0) continue;
-    for (int j = 0; j < ng; ++j) {  // in item order: the running statistics take the groups' updates one after the other
+    for (int j = 0; j < ng; ++j) {
       const int g = g0 + j;
-      if (a.tracked && c == 0) *a.tracked += 1;
+      // running statistics / num_batches_tracked: GROUP 0's update only.  The groups stand for the reference's DataParallel
+      // replicas (main.py:420), and DataParallel keeps the buffer updates of the replica on device 0 alone (the other replicas'
+      // buffers are broadcast copies that are dropped after the forward): one momentum step and +1 tracked per forward
+      if (a.tracked && c == 0 && g == 0) *a.tracked += 1;
       const double mean = s0[j] / (double)a.M;
       double var = s1[j] / (double)a.M - mean * mean;  // biased variance (normalisation)
       var = var > 0.0 ? var : 0.0;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // gri
       coef[a.C + c] = a.beta[c] - (float)mean * sc;
       a.save_mean[(size_t)g * a.C + c] = (float)mean;
       a.save_invstd[(size_t)g * a.C + c] = invstd;
-      if (a.running_mean) {  // torch: running = (1 - m) * running + m * batch, running_var with the UNBIASED batch variance
+      if (a.running_mean && g == 0) {  // torch: running = (1 - m) * running + m * batch, running_var with the UNBIASED batch variance
         const double unb = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
         a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
         a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;

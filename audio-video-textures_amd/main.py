@@ -51,8 +51,9 @@ def build_parser():
       help="memory layout of the encoders in training: ndhwc = channels_last_3d (+ fused BatchNorm passes), ncdhw = torch default")
     a("--bn_replicas", default=1, type=int,
       help="train(): normalise the rank's batch as this many equal groups of items, each with its own BatchNorm statistics — "
-           "what the reference's DataParallel gives every GPU's share of the batch (main.py:420); 1 = over the rank's whole "
-           "batch; -1 = one group per item (batch 8 on 8 GPUs in the reference)")
+           "what the reference's DataParallel gives every GPU's share of the batch (main.py:420), running statistics from "
+           "the first group only as DataParallel keeps replica 0's buffers; 1 = over the rank's whole batch; -1 = one group "
+           "per item (batch 8 on 8 GPUs in the reference)")
     a("--train_conv", default="x3", choices=["x3", "fp32"],
       help="arithmetic of the training convolutions (with --train_layout ndhwc): x3 = split-plane MFMA kernels, fp32 "
            "accumulation, forward 2^-22 / gradients 2^-16 per product (default; train_ops.py); fp32 = MIOpen's fp32 "
@@ -97,7 +98,7 @@ def build_parser():
            "fp32 rows); bf16x3 = bf16 hi/lo planes through the MFMA bf16 pipe (all-gathers the planes, scores within 5e-6); "
            "bf16 = one plane (outside the 1e-3 score contract)")
     a("--enc_batch", default=166, type=int,
-      help="windows per encoder batch (83 k: whole rounds of the 256 x 256 tile on the 256 CUs; 166 measured +2 % over 83; "
+      help="windows per encoder batch (83 k: whole rounds of the 256 x 256 tile on the 256 CUs; 166 measured +2 %% over 83; "
            "~25 GB of activations at 224^2)")
     a("--enc_impl", default="auto", choices=["auto", "mfma", "module"],
       help="SlowFast at -e: hand-written MFMA convolutions (auto/mfma) or the nn.Module on MIOpen (module)")

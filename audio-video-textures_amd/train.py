@@ -36,7 +36,13 @@ def train(train_loader, model, optimizer, args, epoch, tb_logger=None):
         batch_size = (q_frames[0] if isinstance(q_frames, list) else q_frames).shape[0]
         groups = getattr(args, "bn_replicas", 1)
         groups = batch_size if groups < 0 else groups
-        with train_ops.bn_replicas(groups if groups > 1 and batch_size % groups == 0 else 1):
+        if groups > 1 and batch_size % groups:  # (a short last batch: say so instead of changing the BatchNorm semantics silently)
+            if not getattr(train, "_warned_groups", False):
+                print("train(): --bn_replicas %d does not divide a batch of %d items: that batch is normalised as ONE group "
+                      "(use a batch size the replicas divide, or drop_last)" % (groups, batch_size))
+                train._warned_groups = True
+            groups = 1
+        with train_ops.bn_replicas(groups):
             output = model(q_frames, t_frames, q_audio_eg=q_audio_eg, t_audio_eg=t_audio_eg)  # train.py:114-116
         labels = torch.zeros(batch_size, dtype=torch.long, device=output.device)  # positives at column 0
         loss = criterion(output, labels).mean()

@@ -93,6 +93,9 @@ def _workspace(m, c, groups, device):
 # consecutive samples, each normalised with its own statistics — the n items of a batch as the reference's DataParallel replicas
 # see them (main.py:420: one item per GPU at batch 8 on 8 GPUs) — so that a rank's items go through the encoders as ONE batch
 # (convolutions over 8 x 16 clips instead of 8 launches over 16: the deep layers have 8 x the tiles) with unchanged arithmetic.
+# Running statistics and num_batches_tracked take GROUP 0's update only: DataParallel keeps the buffer updates of the replica on
+# device 0 and drops the other replicas' (their buffers are per-forward broadcast copies), so a checkpoint trained here carries the
+# eval-mode statistics the reference's would (one momentum step per forward, from item 0).
 _BN_GROUPS = 1
 
 
@@ -165,8 +168,10 @@ def bn_act(x, bn, res=None, relu=True):
     if groups > 1 and x.shape[0] % groups:
         raise ValueError("bn_replicas(%d): a batch of %d samples does not split into the replicas" % (groups, x.shape[0]))
     if not fusable(x, bn, res):
-        if groups > 1:  # per-replica statistics on the stock ops: one BatchNorm call per group, in order
-            y = torch.cat([bn(xg) for xg in x.chunk(groups, 0)], 0)
+        if groups > 1:  # per-replica statistics on the stock ops: one BatchNorm call per group; running statistics from group 0
+            # only (DataParallel keeps the buffer updates of the replica on device 0 alone, reference main.py:420)
+            xs = x.chunk(groups, 0)
+            y = torch.cat([bn(xs[0])] + [F.batch_norm(xg, None, None, bn.weight, bn.bias, True, 0.0, bn.eps) for xg in xs[1:]], 0)
         else:
             y = bn(x)
         if res is not None:

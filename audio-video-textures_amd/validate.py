@@ -236,6 +236,7 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
                                 enc_batch=getattr(args, "enc_batch", 166),
                                 enc_arch=getattr(args, "enc_arch", "slowfast"))
     assert eng.set_video(input_video) == L
+    validate.last_engine = eng  # (handle for tests / probes: the resident tables of the last run)
     need_audio = net.model_type == 2 or driving_audio_name is not None
     if need_audio and audio_eg.dim() != 4:
         raise AvtError("model_type 2 / driving audio need real source audio (-adata); the reference crashes "

@@ -22,10 +22,17 @@ class _AliasLoader(importlib.abc.Loader):
         self.real = real
 
     def create_module(self, spec):
-        return importlib.import_module(self.real)  # the one module object, under its real name
+        mod = importlib.import_module(self.real)  # the one module object, under its real name
+        self.spec = getattr(mod, "__spec__", None)
+        return mod
 
     def exec_module(self, module):
-        pass  # already executed by the import above
+        # already executed by the import above; importlib's module_from_spec has just overwritten the module's __spec__ (and
+        # __loader__) with the alias's no-op ones — put the real ones back so that importlib.reload() and anything that relies on
+        # __spec__.name == __name__ keep working
+        if self.spec is not None:
+            module.__spec__ = self.spec
+            module.__loader__ = self.spec.loader
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder):

@@ -1,0 +1,200 @@
+"""End-to-end `validate()` AT SIZE on the MI355X: BASELINE configs 2 and 3 on ~2k windows of a structured
+128^2 video with the real SlowFast-8x8-R50 encoders in the default (contract-grade f16x3) arithmetic, aligned mode — the frames
+list against the CPU oracle's normalise / similarity / select / walk over the SAME embedding tables (reference:
+validate.py:324-685, the m=2 blend :524-527); and, on boxes with two or more GPUs, the same runs over real RCCL
+(reference: DataParallel, main.py:420)."""
+import os
+import subprocess
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref, ref_py
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, S, FPS, L = 20, 4, 30.0, 2048
+
+
+def _encoders(dev, video):
+    from avtex import ops, synth
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(0)
+    q_mod = synth.randomise_bn(SlowFast().eval(), 10, 2.0, 0.1).to(dev)
+    t_mod = synth.perturbed_copy(q_mod, 11, 0.05)
+    cal = np.linspace(0, L - 1, 8).astype(np.int64) * S
+    slow, fast = ops.clip_pack(video.to(dev), cal, W, out_hw=224, dtype=torch.float32)
+    synth.calibrate_bn(q_mod, slow, fast)
+    synth.calibrate_bn(t_mod, slow, fast)
+    return q_mod.eval(), t_mod.eval()
+
+
+def _args(model_type, threshold, nvl=10):
+    return SimpleNamespace(vdata=None, adata=None, dadata=None, subsample_rate=1, fps=FPS, stride=S, window=W, enc_arch="slowfast",
+                           img_size=224, model_type=model_type, mini_batchsize=100, threshold=threshold, alpha=0.5, temp=0.1,
+                           driving_audio=None, da_feats="VGG", interpolation=False, new_video_length=nvl, results_folder=None,
+                           logname="exp", batch_size=8, stitch_mode="aligned", enc_batch=166, enc_impl="auto", enc_dtype="fp32")
+
+
+def _clamp_rows(a, n):
+    return a[np.minimum(np.arange(n), a.shape[0] - 1)]
+
+
+def test_config2_validate_at_size_equals_the_oracle_walk(avt, dev, capsys):
+    """BASELINE config 2: contrastive synthesis (-e) of one ~2k-window video, SlowFast encoders, w=20 stride=4, one MI355X."""
+    from avtex import synth
+    from avtex.validate import validate
+
+    video = synth.structured_video(11, L * S + W + 1, 128, 128, variety=1)
+    q_mod, t_mod = _encoders(dev, video)
+    model = avt.ContrastivePredictionTemporal(q_mod, t_mod, None, 1, 128, 0.1, W, S, 0.3, mini_batchsize=100,
+                                              enc_arch="slowfast", img_size=224).to(dev).eval()
+    args = _args(1, 0.3)
+    np.random.seed(7)
+    frames = validate(model, args, video_name="synthetic", model_type=1, video=(video, FPS))
+    out = capsys.readouterr().out
+    assert "precision f16x3 (contract grade)" in out and "Windows encoded: %d " % (2 * L) in out
+    eng = validate.last_engine
+    assert eng.N == L and tuple(eng.Qv.shape) == (L, 2304)
+    qn, _, _ = cref.l2norm_rows(eng.Qv.cpu().numpy(), want_split=False)
+    tn, _, _ = cref.l2norm_rows(eng.Tv.cpu().numpy(), want_split=False)
+    sim = cref.sim_f32(qn, tn, 0.1)
+    assert np.array_equal(eng.sim.cpu().numpy(), sim)  # the whole 2048^2 matrix, bit for bit
+    kept = []
+
+    def row_fn(q):
+        o = cref.row_transition(sim[q : q + 1], q_ids=np.array([q]), n_seg=L, threshold=0.3, cap=L)
+        kept.append(int(o["cnt"][0]))
+        return o["idx"][0, : o["cnt"][0]], ref_py.target_segment_ids(q, L)
+
+    ref_frames, steps, jumps = ref_py.stitch_walk(row_fn, len(video), W, S, int(np.ceil(FPS)) * 10, q_id=10, rng=np.random.RandomState(7))
+    assert frames == ref_frames and len(frames) >= 300
+    assert 1 <= np.mean(kept) < 0.5 * L, np.mean(kept)  # rows are neither degenerate nor all-surviving
+    print("config 2 at size: %d steps, %d jumps, %.1f survivors per visited row" % (len(steps), jumps, np.mean(kept)))
+
+
+def test_config3_validate_m2_driving_audio_at_size_equals_the_oracle_walk(avt, dev, capsys):
+    """BASELINE config 3: audio-conditioned synthesis (m=2): SlowFast + VGGish, D = 2304 + 12288 = 14592 jointly normalised,
+    driving audio blended at alpha = 0.5, th 0.0 (argmax) — every stitch step against the oracle on the same tables."""
+    from avtex import synth
+    from avtex.validate import audio_start_segment, validate
+
+    video = synth.structured_video(12, L * S + W + 1, 128, 128, variety=1)
+    q_mod, t_mod = _encoders(dev, video)
+    torch.manual_seed(3)
+    vgg = avt.VGGish()
+    model = avt.ContrastivePredictionTemporal(q_mod, t_mod, vgg, 2, 128, 0.1, W, S, 0.0, mini_batchsize=100,
+                                              enc_arch="slowfast", img_size=224).to(dev).eval()
+    rng = np.random.default_rng(5)
+    n_in = len(video)
+    wave = (0.1 * rng.standard_normal(int(n_in / FPS * 16000) + 16000)).astype(np.float32)
+    wave_da = (0.1 * rng.standard_normal(12 * 16000)).astype(np.float32)
+    args = _args(2, 0.0)
+    np.random.seed(9)
+    frames = validate(model, args, video_name="synthetic", model_type=2, video=(video, FPS), audio=(wave, 16000),
+                      driving_audio=(wave_da, 16000))
+    capsys.readouterr()
+    eng = validate.last_engine
+    assert tuple(eng.A.shape)[1] == 12288 and eng.Ad is not None
+    a = _clamp_rows(eng.A.cpu().numpy(), L)
+    qn, _, _ = cref.l2norm_rows(eng.Qv.cpu().numpy(), a, want_split=False)
+    tn, _, _ = cref.l2norm_rows(eng.Tv.cpu().numpy(), a, want_split=False)
+    assert qn.shape == (L, 14592)
+    sim = cref.sim_f32(qn, tn, 0.1)
+    assert np.array_equal(eng.sim.cpu().numpy(), sim)
+    dn, _, _ = cref.l2norm_rows(eng.Ad.cpu().numpy(), want_split=False)
+    an, _, _ = cref.l2norm_rows(_clamp_rows(eng.A_da.cpu().numpy(), L), want_split=False)
+    sim_a = cref.sim_f32(dn, an, 0.1)
+    step = [1]  # validate()'s iter_count starts at 1 (validate.py:257) and indexes the driving example of the step
+
+    def row_fn(q):
+        o = cref.row_transition(sim[q : q + 1], q_ids=np.array([q]), n_seg=L, sim_a=sim_a[step[0] : step[0] + 1], alpha=0.5,
+                                threshold=0.0, cap=L)
+        step[0] += 1
+        return o["idx"][0, : o["cnt"][0]], ref_py.target_segment_ids(q, L)
+
+    # start segment: validate.py:223-240 on the log-mel examples (host logic of the product, pinned by fixture G5 sf_da)
+    from avtex.audio_frontend import waveform_to_examples
+
+    apf = int(np.floor(16000 / FPS))
+    aeg = torch.from_numpy(waveform_to_examples(wave[: n_in * apf], 16000)).float()[:L]
+    deg = torch.from_numpy(waveform_to_examples(wave_da, 16000)).float()
+    q0 = audio_start_segment(aeg, deg[0])
+    ref_frames, steps, _ = ref_py.stitch_walk(row_fn, n_in, W, S, int(np.ceil(FPS)) * 10, q_id=q0, rng=np.random.RandomState(9))
+    assert frames == ref_frames and len(frames) >= 300
+
+
+def _run(cmd, env_extra=None, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **(env_extra or {}))
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+needs_two = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (real RCCL over xGMI)")
+
+
+@needs_two
+def test_bench_self_launch_two_ranks_over_rccl(dev):
+    """`python bench.py --gpus 2` with NO launcher: bench starts its own ranks (a child process of torch.distributed.run),
+    shards 2 x 256 windows, all-gathers T_hat over RCCL and prints one line that says so itself."""
+    import json
+
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--windows", "256", "--steps", "1", "--warmup", "1", "--enc-batch", "64",
+              "--no-fast", "--no-train-leg", "--no-cpu-baseline", "--no-nxn-legs", "--no-precision-block"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["windows_total"] == 512
+    assert line["allgather_ms"] is not None and line["allgather_ms"] > 0 and line["value"] > 0
+
+
+_WORLD_SCRIPT = r"""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+import avtex as avt
+from avtex import dist as adist, synth
+from avtex.validate import validate
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from test_gpu_e2e import _args, _encoders, W, S, FPS
+rank, world, local = adist.init_from_env()
+dev = torch.device("cuda", local)
+torch.cuda.set_device(dev)
+n = 256
+video = synth.structured_video(11, n * S + W + 1, 128, 128, variety=1)
+import test_gpu_e2e
+test_gpu_e2e.L = n
+q_mod, t_mod = _encoders(dev, video)
+model = avt.ContrastivePredictionTemporal(q_mod, t_mod, None, 1, 128, 0.1, W, S, 0.3, mini_batchsize=100, enc_arch="slowfast",
+                                          img_size=224).to(dev).eval()
+args = _args(1, 0.3, nvl=5)
+args.enc_batch = 64
+np.random.seed(7)
+frames = validate(model, args, video_name="synthetic", model_type=1, video=(video, FPS))
+if rank == 0:
+    print("FRAMES " + json.dumps(frames))
+if torch.distributed.is_initialized():
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+"""
+
+
+@needs_two
+def test_validate_world2_over_rccl_equals_world1(dev, tmp_path):
+    """validate() sharded over two GPUs (index blocks -> RCCL all-gather of T_hat -> row blocks -> survivors to rank 0) walks
+    the same frames list as one GPU."""
+    import json
+
+    script = tmp_path / "world.py"
+    script.write_text(_WORLD_SCRIPT % {"root": ROOT})
+
+    def frames_of(r):
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("FRAMES ")][-1][7:])
+
+    one = frames_of(_run([sys.executable, str(script)]))
+    two = frames_of(_run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29533", str(script)]))
+    assert one == two and len(one) >= 150

@@ -357,6 +357,24 @@ def test_bench_line_is_compact_and_round_trips():
         bench.compact_line(dict(out, junk="j" * 4096))
 
 
+def test_cli_and_bench_usage_text_renders(avt):
+    """argparse expands help strings with `help % params`: a bare '%' in one of them makes --help (and format_help) raise
+    TypeError (both parsers had one).  Every help string of the product CLI and of bench.py must render."""
+    p = avt.main.build_parser() if hasattr(avt, "main") else __import__("avtex.main", fromlist=["x"]).build_parser()
+    assert "--enc_batch" in p.format_help()
+    text = _load_bench().build_parser().format_help()
+    assert "--enc-batch" in text and "--config" in text
+
+
+def test_bench_config4_is_one_flag(monkeypatch):
+    """`bench.py --config 4` = BASELINE.json's config 4 on one rank: 2048 windows per GPU and the top-k (k = 8) leg."""
+    bench = _load_bench()
+    a = bench.build_parser().parse_args(["--config", "4", "--gpus", "8", "--sim-precision", "bf16x3"])
+    assert a.config == 4 and a.gpus == 8 and a.sim_precision == "bf16x3"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "args.windows = 2048" in src and "args.topk = args.topk or 8" in src
+
+
 def test_bench_self_launch_command(monkeypatch):
     """`python bench.py --gpus N` with no launcher around it starts N ranks as child processes (never an exec of a process that
     has touched the GPU) with the rendezvous on 127.0.0.1 and the same arguments."""
