@@ -75,7 +75,6 @@ SIGNATURES = {
     "avt_clip_pack_gather_u8": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                 C.c_int, _vp, _vp, C.c_int, _vp],
     "avt_stem_conv_x3": [_vp] * 8 + [C.c_int] * 11 + [_vp],
-    "avt_stem_conv_pool_x3": [_vp] * 8 + [C.c_int] * 11 + [_vp],
     "avt_clip_planes_f32": [_vp] + [C.c_int] * 4 + [C.c_int64] * 5 + [_vp, _vp, C.c_int, _vp],
     "avt_stem_conv_x3_f32": [_vp] * 6 + [C.c_int] * 11 + [_vp],
     "avt_weight_planes_f32": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp],
@@ -136,7 +135,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 3  # include/avt.h AVT_ABI_VERSION
+ABI_VERSION = 4  # include/avt.h AVT_ABI_VERSION
 _RETURNS_I64 = {"avt_bn_train_ws_bytes"}  # sizes; every other entry returns an AVT_* status
 
 

@@ -28,26 +28,15 @@ namespace {
 
 constexpr int kT = 256;
 
-// streamed once: non-temporal loads in every pass and non-temporal stores of the backward's outputs (AVT_BN_NT, compile-time):
-// +2.4 % on the training step (profiles/r03/train_bn_nt_ab.log)
-#ifndef AVT_BN_NT
-#define AVT_BN_NT 1
-#endif
+// streamed once: non-temporal loads in every pass and non-temporal stores of the backward's outputs: +2.4 % on the training
+// step (profiles/r03/train_bn_nt_ab.log)
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ldg4(const float* p, int64_t i) {
-#if AVT_BN_NT
   const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p) + i);
   return make_float4(v.x, v.y, v.z, v.w);
-#else
-  return reinterpret_cast<const float4*>(p)[i];
-#endif
 }
 __device__ __forceinline__ void stg4(float* p, int64_t i, float4 v) {
-#if AVT_BN_NT
   __builtin_nontemporal_store(f32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4n*>(p) + i);
-#else
-  reinterpret_cast<float4*>(p)[i] = v;
-#endif
 }
 constexpr int kMaxBlocks = 1024;  // 4 workgroups per CU: enough 16-byte loads in flight for HBM, few enough rows of partials
 

@@ -409,8 +409,7 @@ int launch(BxArgs& a, int batch, int h, hipStream_t st) {
   constexpr int lds_bytes = NF * 2048 + (4 * CMP + 2 * C) * 4 + 2 * (RX * (W + 2) * CMP * 2) + 2 * (MTB * 16 * CMP * 2);
   static_assert(lds_bytes <= 160 * 1024, "strips do not fit the LDS");
   a.strips = (h / ST + HT - 1) / HT;
-  static const int swz = avt::env_int_flag("AVT_XCD_SWZ", 1);
-  a.swz = swz;
+  a.swz = 1;  // XCD-contiguous work order
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_x3_kernel<C, W, HT, CMP, CIN, ST, NW, F16>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
@@ -426,9 +425,7 @@ template <bool F16>
 int dispatch(BxArgs& a, int batch, int h, int w, int cin, int c, hipStream_t s) {
   if (cin == 8) {
     // (x has 8 channels: halo rows are cheap, so 4-row strips — 57 KB of LDS, two workgroups per CU — cost nothing in bytes)
-    static const int alt = avt::env_int_flag("AVT_BNECK_FIRST8_HT4", 1);
-    if (w == 56 && alt) return launch<32, 56, 4, 16, 8, 1, 8, F16>(a, batch, h, s);
-    if (w == 56) return launch<32, 56, 8, 16, 8, 1, 12, F16>(a, batch, h, s);
+    if (w == 56) return launch<32, 56, 4, 16, 8, 1, 8, F16>(a, batch, h, s);
     return launch<32, 12, 5, 16, 8, 1, 4, F16>(a, batch, h, s);
   }
   if (cin != c) {  // strided first blocks (w = input width)
@@ -438,10 +435,7 @@ int dispatch(BxArgs& a, int batch, int h, int w, int cin, int c, hipStream_t s) 
     return launch<128, 8, 2, 32, 64, 2, 4, F16>(a, batch, h, s);
   }
   if (c == 32 && w == 56) return launch<32, 56, 8, 16, 32, 1, 12, F16>(a, batch, h, s);
-  if (c == 64 && w == 28) {
-    static const int nw16 = avt::env_int_flag("AVT_BNECK_RES3_NW16", 1);
-    return nw16 ? launch<64, 28, 6, 16, 64, 1, 16, F16>(a, batch, h, s) : launch<64, 28, 6, 16, 64, 1, 8, F16>(a, batch, h, s);
-  }
+  if (c == 64 && w == 28) return launch<64, 28, 6, 16, 64, 1, 16, F16>(a, batch, h, s);
   if (c == 128 && w == 14) return launch<128, 14, 7, 32, 128, 1, 9, F16>(a, batch, h, s);
   if (c == 32 && w == 12) return launch<32, 12, 5, 16, 32, 1, 4, F16>(a, batch, h, s);   // small shapes for the tests: ragged
   if (c == 64 && w == 10) return launch<64, 10, 4, 16, 64, 1, 4, F16>(a, batch, h, s);   // strips, partial tiles

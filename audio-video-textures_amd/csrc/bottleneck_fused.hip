@@ -45,7 +45,7 @@ struct BArgs {
   const float* bc;  // [C]
   int T, H;
   int strips, tchunks, TC;
-  int swz;  // XCD-contiguous work order (AVT_XCD_SWZ, default 1)
+  int swz;  // XCD-contiguous work order (always on since round 2)
   unsigned x_bytes;
 };
 
@@ -351,8 +351,7 @@ int launch(BArgs& a, int batch, int h, hipStream_t st) {
   constexpr int lds_bytes = 3 * NDMA * 1024 + (RX * AW + 32) * CMP * 2 + MTB * 16 * CMP * 2 + wfrags * 1024;
   static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
   a.strips = (h / ST + HT - 1) / HT;
-  static const int swz = avt::env_int_flag("AVT_XCD_SWZ", 1);
-  a.swz = swz;
+  a.swz = 1;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<C, W, HT, CMP, CIN, ST, NW>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
@@ -398,12 +397,8 @@ static int run_bottleneck(const char* what, const void* x, void* out, const void
   a.x_bytes = (unsigned)xb;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // 16 waves (4 per SIMD, <= 128 VGPRs) hide the stages' latencies better than 8 (+10 % on the C = 32 form) where the
-  // kernel fits them without spilling (C <= 64); AVT_BN_NW=8 selects the 8-wave builds
-  static const int nw = []() {
-    const char* e = getenv("AVT_BN_NW");
-    return e ? atoi(e) : 16;
-  }();
-#define AVT_BN_LAUNCH(...) (nw == 16 ? launch<__VA_ARGS__, 16>(a, batch, h, s) : launch<__VA_ARGS__, 8>(a, batch, h, s))
+  // kernel fits them without spilling (C <= 64)
+#define AVT_BN_LAUNCH(...) launch<__VA_ARGS__, 16>(a, batch, h, s)
   if (cin == 8) {
     if (w == 56) return AVT_BN_LAUNCH(32, 56, 8, 16, 8, 1);
     return launch<32, 12, 5, 16, 8>(a, batch, h, s);

@@ -28,7 +28,7 @@ struct C33Args {
   const i32x4* wb;      // [NFB][64 lanes]
   const float* bias;    // [64]
   int T, H, strips, ldo, relu;
-  int swz;  // XCD-contiguous work order (AVT_XCD_SWZ, default 1)
+  int swz;  // XCD-contiguous work order (always on)
   unsigned in_bytes;
 };
 
@@ -159,7 +159,7 @@ int launch(C33Args& a, int batch, int h, hipStream_t st) {
   constexpr int lds_bytes = NFB * 1024 + 2 * (((HT + 2) * (W + 1) + 1) * 128);
   static_assert(lds_bytes <= 160 * 1024, "strip does not fit the LDS");
   a.strips = (h + HT - 1) / HT;
-  static const int swz = avt::env_int_flag("AVT_XCD_SWZ", 1);
+  constexpr int swz = 1;  // XCD-contiguous work order
   a.swz = swz;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c33_kernel<W, HT>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

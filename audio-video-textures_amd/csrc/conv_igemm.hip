@@ -23,8 +23,6 @@
 //
 // Tiles (256 threads = 4 waves, v_mfma_f32_32x32x16_bf16, fp32 accumulate), <BM, BN, WTM = wave-tile rows>:
 //   <128,128, 64>: 2x2 waves, wave tile  64(m) x 64(n)   — wide layers
-//   <256,128,128>: 2x2 waves, wave tile 128(m) x 64(n)   — wide layers with many rows (AVT_CONV_BIG): 6 LDS fragment
-//                  reads per 8 MFMAs instead of 8 and half the ds_write bytes per MFMA (the K loop is LDS-bound)
 //   <256, 64, 64>: 4x1 waves, wave tile  64(m) x 64(n)   — Cout = 64
 //   <256, 32, 64>: 4x1 waves, wave tile  64(m) x 32(n)   — few output channels
 // LDS rows are padded to 144 B (conflict-free ds_read_b128, see sim_gemm.hip).  Roofline: MFMA for the wide
@@ -874,23 +872,15 @@ int launch_xb(ConvArgs& a, hipStream_t st) {
   a.dKW = make_fastdiv((uint32_t)a.KW);
   a.dNT = make_fastdiv((uint32_t)(a.KT * a.KH * a.KW));
   a.tapinner = 1;
-  static const int issue_a = []() {
-    const char* e = getenv("AVT_XB_ISSUE_A");
-    return e ? atoi(e) : 1;  // +1-5 % per layer (profiles/r01/probe_ab_chain.log)
-  }();
+  // (conv_xb_kernel<true>: the activation DMA issued in the fragment-read phase, +1-5 % per layer, profiles/r01/probe_ab_chain.log)
   constexpr int lds_bytes = 128 * (256 * 2 + 16) > 4 * 256 * 64 ? 128 * (256 * 2 + 16) : 4 * 256 * 64;
-  static const hipError_t e = issue_a ? hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<true>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
-                                     : hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<false>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_igemm_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  if (issue_a)
-    hipLaunchKernelGGL((conv_xb_kernel<true>), dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
-  else
-    hipLaunchKernelGGL((conv_xb_kernel<false>), dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_xb_kernel<true>), dim3((unsigned)a.nblk), dim3(XT), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_bf16");
 }
 
@@ -904,11 +894,7 @@ int launch_xl(ConvArgs& a, hipStream_t st) {
   a.dKHW = make_fastdiv((uint32_t)(a.KH * a.KW));
   a.dKW = make_fastdiv((uint32_t)a.KW);
   a.dNT = make_fastdiv((uint32_t)(a.KT * a.KH * a.KW));
-  static const int tapinner = []() {
-    const char* e = getenv("AVT_XL_TAPINNER");
-    return e ? atoi(e) : 1;
-  }();
-  a.tapinner = (tapinner && a.KT * a.KH * a.KW > 1) ? 1 : 0;
+  a.tapinner = a.KT * a.KH * a.KW > 1 ? 1 : 0;  // taps innermost: a chunk's per-tap re-reads meet in L2 (+3-5 %, round 1)
   constexpr int lds_bytes = XRING * (XBM + XBN) * 64;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<XBM, XBN, WM>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -963,10 +949,7 @@ extern "C" int avt_conv3d_igemm_rows_bf16(const void* in, const void* wt, const 
 
 extern "C" int avt_conv3d_igemm_wfrag_supported(int cin, int cout, int kt, int kh, int kw) {
   const int taps = kt * kh * kw;
-  static const int min_nk = []() {  // shortest K loop (64-wide steps) the XB tile is used for
-    const char* e = getenv("AVT_CONV_XB_NK");
-    return e ? atoi(e) : 16;
-  }();
+  constexpr int min_nk = 16;  // shortest K loop (64-wide steps) the XB tile is used for
   return (cout >= 256 && (taps * cin + 63) / 64 >= min_nk && cin % 32 == 0) ? 1 : 0;
 }
 
@@ -992,42 +975,11 @@ extern "C" int avt_conv3d_igemm_wfrag_bf16(const void* in, const void* wt, const
     a.wf_bytes = (unsigned)wfb;
     return launch_xb(a, s);
   }
-  // GEMM-like layers: the 256x256 LDS-DMA tile.  AVT_CONV_XL = minimum number of its tiles (0 = never),
-  // AVT_CONV_XL_NK = minimum number of 64-wide K-steps.  A unit of 32 K must not straddle two taps: one tap, or
-  // Cin % 32 == 0.
-  static const int xl = []() {
-    const char* e = getenv("AVT_CONV_XL");
-    return e ? atoi(e) : 1;
-  }();
-  static const int xl_nk = []() {
-    const char* e = getenv("AVT_CONV_XL_NK");
-    return e ? atoi(e) : 16;  // shorter K loops (the 1x1x1 + residual layers) are faster on the 128x128 tile
-  }();
-  if (xl > 0 && cout >= 256 && a.nk >= xl_nk && (cin % 32 == 0 || kt * kh * kw == 1) &&
-      (int64_t)((a.M + 255) / 256) * ((cout + 255) / 256) >= xl)
-    return launch_xl<256, 256, 2>(a, s);
-  // ... and its 64x64-per-wave forms for the 64- / 128-channel layers (AVT_CONV_XLS: bit 0 = <512,64>, bit 1 = <256,128>)
-  static const int xls = []() {
-    const char* e = getenv("AVT_CONV_XLS");
-    return e ? atoi(e) : 0;
-  }();
-  static const int xls_tiles = []() {  // minimum tile count (tests set 1)
-    const char* e = getenv("AVT_CONV_XLS_TILES");
-    return e ? atoi(e) : 256;
-  }();
-  if (xl > 0 && (cin % 32 == 0 || kt * kh * kw == 1)) {
-    if ((xls & 1) && cout == 64 && a.nk >= 8 && (a.M + 511) / 512 >= xls_tiles) return launch_xl<512, 64, 8>(a, s);
-    if ((xls & 2) && cout > 64 && cout <= 128 && a.nk >= 16 && (a.M + 255) / 256 >= xls_tiles)
-      return launch_xl<256, 128, 4>(a, s);
-  }
+  // GEMM-like layers: the 256x256 LDS-DMA tile for K loops of 16 or more 64-wide steps (shorter ones — the 1x1x1 + residual
+  // layers — are faster on the 128x128 tile).  A unit of 32 K must not straddle two taps: one tap, or Cin % 32 == 0.
+  if (cout >= 256 && a.nk >= 16 && (cin % 32 == 0 || kt * kh * kw == 1)) return launch_xl<256, 256, 2>(a, s);
   if (cout <= 32) return launch<256, 32, 64>(a, s);
   if (cout <= 64) return launch<256, 64, 64>(a, s);
-  // wide layers: the 256x128 tile (128x64 per wave) when there are enough tiles of it to fill the chip
-  // (2 workgroups per CU x 256 CUs).  AVT_CONV_BIG = minimum tile count, 0 = never.
-  static const int big = []() {
-    const char* e = getenv("AVT_CONV_BIG");
-    return e ? atoi(e) : 0;  // off: measured 7 % slower end to end (profiles/r01/probe_big_ab.log), 2 waves/SIMD hide less of the gather
-  }();
-  if (big > 0 && (int64_t)((a.M + 255) / 256) * ((cout + 127) / 128) >= big) return launch<256, 128, 128>(a, s);
+  // (a 256x128 tile, 128x64 per wave, measured 7 % slower end to end: 2 waves/SIMD hide less of the gather, profiles/r01/probe_big_ab.log)
   return launch<128, 128, 64>(a, s);
 }

@@ -73,15 +73,6 @@ __device__ __forceinline__ f32x16 mfma(i32x4 w, i32x4 x, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <bool F16>
-__device__ __forceinline__ f32x4v mfma16(i32x4 w, i32x4 x, f32x4v c) {
-  if constexpr (F16)
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
-}
-
 // IO32: the TRAINING form (train_ops.conv3d: forward and stride-1 dgrad of the SlowFast convolutions, train.py:114-141) —
 // activations are read as fp32 NDHWC rows and split into the two planes in registers on their way to the LDS (same number
 // of 16-byte loads as two planes; ~4 VALU operations per element next to 48 MFMAs per K-step), the result is written as
@@ -427,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 // registers (four 16-byte loads) under this step's MFMAs and splits them into the two planes on the way to the LDS after them;
 // the weight planes still arrive by LDS-DMA; ONE fragment set instead of two pays for the staging registers; fp32 epilogue
 // with the `add` operand.
-template <bool F16, int V = 1, bool IO32 = false>
+template <bool F16, bool IO32 = false>
 __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   constexpr int BM = 256, BN = 256, NTHR = 512, KB = 32;  // K-step in elements
   constexpr int MT = 4, NT = 2;                            // 32 x 32 sub-tiles of a wave's 128 x 64
@@ -488,16 +479,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
     for (int j = 0; j < MT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  // V == 2: the same 128 x 64 outputs per wave as 4 x 8 tiles of v_mfma_f32_16x16x32 (one instruction covers the whole 32-wide
-  // K-step of a 16 x 16 tile: the same 24 fragment reads and the same matrix cycles per step; MI355X_MICROARCH.md "DVFS
-  // give-back" (7): the chip can hold a higher clock on this shape)
-  constexpr int NT16 = 4, MT16 = 8;
-  f32x4v acc16[NT16][MT16];
-#pragma unroll
-  for (int i = 0; i < NT16; ++i)
-#pragma unroll
-    for (int j = 0; j < MT16; ++j) acc16[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
   const __amdgpu_buffer_rsrc_t rih = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ril = __builtin_amdgcn_make_buffer_rsrc((void*)a.in_lo, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
@@ -527,20 +508,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       // cache lines) instead of 16 half lines 2 K bytes apart — measured +5 % on the long-K layers (profiles/r03/probe_xl_traffic.log)
       if (a.wblk) boffs[u] = (((unsigned)(kt * a.Cout + n0 + r0 + 128 * u) * 64u + (unsigned)c4 * 16u) & sel) | (kOob & ~sel);
     }
-#ifdef AVT_XL_TRAFFIC_EXPERIMENT  // TIMING ONLY (results are garbage): what full-cache-line operand fetches would buy
-    if constexpr (V >= 3) {
-#pragma unroll
-      for (int u = 0; u < BU; ++u)  // weights as [K / 32][Cout][32]: a wave-instruction reads 1 KB contiguous
-        boffs[u] = ((unsigned)(kt * a.Cout + n0 + r0 + 128 * u) * 64u + (unsigned)(tid & 3) * 16u) % (unsigned)a.wt_bytes & ~15u;
-    }
-    if constexpr (V == 4) {
-#pragma unroll
-      for (int u = 0; u < AU; ++u) {  // activations: 8 rows x 128 B per wave-instruction instead of 16 rows x 64 B
-        const unsigned row = (unsigned)(m0 + (r0 >> 1) + 128 * u) % (unsigned)a.M;
-        aoffs[u] = (row * (unsigned)a.ldi * 2u + (unsigned)((kt >> 1) * 128 + (tid & 7) * 16) % (unsigned)(a.ldi * 2)) & ~15u;
-      }
-    }
-#endif
   };
   auto gprep = [&](int kt) { gcalc(kt, gtab(kt)); };
   constexpr int NPIECE = 2 * (AU + BU);  // 8 LDS-DMA pieces per wave and step
@@ -626,44 +593,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       }
   };
 
-  const int r16 = lane & 15, kq = lane >> 4;
-  struct Frags16 {
-    i32x4 ah[MT16], al[MT16], wh[NT16], wl[NT16];
-  };
-  auto fload16 = [&](Frags16& f, const char* st) {  // lane: row (lane & 15) of the tile, k-chunk (lane >> 4) of the step
-    const int slot = (kq ^ ((r16 >> 2) & 3)) * 16;
-    auto rd_w = [&](int i) {
-      const int o = (wn * 64 + i * 16 + r16) * 64 + slot;
-      f.wh[i] = *reinterpret_cast<const i32x4*>(st + 2 * PL + o);
-      f.wl[i] = *reinterpret_cast<const i32x4*>(st + 3 * PL + o);
-    };
-    rd_w(0);
-#pragma unroll
-    for (int j = 0; j < MT16; ++j) {
-      const int o = (wm * 128 + j * 16 + r16) * 64 + slot;
-      f.ah[j] = *reinterpret_cast<const i32x4*>(st + o);
-      f.al[j] = *reinterpret_cast<const i32x4*>(st + PL + o);
-    }
-#pragma unroll
-    for (int i = 1; i < NT16; ++i) rd_w(i);
-  };
-  auto fmul16 = [&](const Frags16& f, bool more, char* nst) {
-#pragma unroll
-    for (int i = 0; i < NT16; ++i)
-#pragma unroll
-      for (int j = 0; j < MT16; j += 2) {  // two accumulators interleaved: no back-to-back dependent MFMAs
-        acc16[i][j] = mfma16<F16>(f.wl[i], f.ah[j], acc16[i][j]);
-        acc16[i][j + 1] = mfma16<F16>(f.wl[i], f.ah[j + 1], acc16[i][j + 1]);
-        acc16[i][j] = mfma16<F16>(f.wh[i], f.al[j], acc16[i][j]);
-        acc16[i][j + 1] = mfma16<F16>(f.wh[i], f.al[j + 1], acc16[i][j + 1]);
-        acc16[i][j] = mfma16<F16>(f.wh[i], f.ah[j], acc16[i][j]);
-        acc16[i][j + 1] = mfma16<F16>(f.wh[i], f.ah[j + 1], acc16[i][j + 1]);
-        const int pc = i * (MT16 / 2) + j / 2;
-        if (more && pc < NPIECE) gpiece(pc, nst);  // the next step's DMA, one piece per six MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-      }
-  };
-
   __syncthreads();
   STAMP_BEGIN();
   gprep(0);
@@ -701,46 +630,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (more) astore(nst);
       __syncthreads();
-    }
-  } else if constexpr (V == 2) {
-    for (int kt = 0; kt < nk32; ++kt) {
-      const bool more = kt + 1 < nk32;
-      char* cur = lds + (kt & 1) * STG;
-      char* nst = lds + ((kt + 1) & 1) * STG;
-      int2 e = make_int2(0, 0);
-      if (more) e = gtab(kt + 1);
-      Frags16 f;
-      fload16(f, cur);
-      if (more) gcalc(kt + 1, e);
-      __builtin_amdgcn_sched_barrier(0);
-      fmul16(f, more, nst);
-      STAMP(2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      STAMP(3);
-      __syncthreads();
-      STAMP(4);
-    }
-  } else if constexpr (V == 0 || V >= 3) {
-    for (int kt = 0; kt < nk32; ++kt) {
-      const bool more = kt + 1 < nk32;
-      char* cur = lds + (kt & 1) * STG;
-      char* nst = lds + ((kt + 1) & 1) * STG;  // the other stage: nobody reads it during this step
-      Frags f0, f1;
-      fload(f0, cur, 0);
-      if (more) gprep(kt + 1);
-      fload(f1, cur, 1);
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef AVT_CONV_STAMP
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (diagnostic build: the fragment reads' latency as its own segment)
-      STAMP(1);
-#endif
-      fmul(f0, 0, more, nst);
-      fmul(f1, NT * MT, false, nst);
-      STAMP(2);  // 48 MFMAs + the next step's 8 DMA pieces
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed (the barrier does not wait for DMA)
-      STAMP(3);  // wait for own DMA
-      __syncthreads();
-      STAMP(4);  // barrier
     }
   } else {
     // The loop rotated by one k-slice: what follows a barrier is the reads of the new stage's FIRST slice and then the MFMAs
@@ -790,28 +679,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   const bool has_res = !IO32 && a.res != nullptr;  // (IO32: `res` is an fp32 tensor added in the store loop)
   auto stage_slab = [&](int pass) {  // the two waves rows x this column block write their 128 x 64 accumulators
     char* eb = lds + (pass & 1) * EBUF;
-    if constexpr (V == 2) {
-      // D layout of the 16 x 16 tile: column (lane & 15) = m, rows 4 * (lane >> 4) + reg = n
-#pragma unroll
-      for (int i = 0; i < NT16; ++i) {
-        const int nl = i * 16 + 4 * kq;
-        const int ng = n0 + pass * 64 + nl;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (a.bias && ng < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + ng);
-        if (a.wscale && ng < a.Cout) sv = *reinterpret_cast<const float4*>(a.wscale + ng);
-#pragma unroll
-        for (int j = 0; j < MT16; ++j) {
-          float4 v;
-          v.x = acc16[i][j][0] * sv.x + bv.x;
-          v.y = acc16[i][j][1] * sv.y + bv.y;
-          v.z = acc16[i][j][2] * sv.z + bv.z;
-          v.w = acc16[i][j][3] * sv.w + bv.w;
-          const int ml = wm * 128 + j * 16 + r16;
-          *reinterpret_cast<float4*>(eb + ml * ESTR + nl * 4) = v;
-        }
-      }
-      return;
-    }
     // D layout: column (lane & 31) = m, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = n
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -905,20 +772,20 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   STAMP_END();
 }
 
-template <bool F16, int V = 1, bool IO32 = false>
+template <bool F16, bool IO32 = false>
 int launch_x3_xl(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.Cout + 255) / 256;
   a.nblk = tiles_m * a.tiles_n;
   constexpr int lds_max = 2 * 4 * 256 * 64 + kMaxTabSteps * 64;
   const int lds_bytes = lds_max;  // (the epilogue's second staging buffer reaches into the table area)
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16, V, IO32>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16, IO32>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_max, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((conv_x3_xl_kernel<F16, V, IO32>), dim3((unsigned)a.nblk), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_x3_xl_kernel<F16, IO32>), dim3((unsigned)a.nblk), dim3(512), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_x3");
 }
 
@@ -948,8 +815,7 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
 
 // which tile avt_conv3d_igemm_x3 launches (bench.py names its roofline rows by it)
 extern "C" int avt_conv3d_igemm_x3_xl_picked(int cout, int k, int m) {
-  static const int min_k = avt::env_int_flag("AVT_CONV_X3_XL_MINK", 256);
-  return (cout % 256 == 0 && k >= min_k && k <= kMaxTabSteps * 64 && m >= 256 * 64) ? 1 : 0;
+  return (cout % 256 == 0 && k >= 256 && k <= kMaxTabSteps * 64 && m >= 256 * 64) ? 1 : 0;
 }
 
 static int igemm_x3_impl(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo,
@@ -977,20 +843,11 @@ static int igemm_x3_impl(const void* in_hi, const void* in_lo, const void* wt_hi
   a.nup = 0;
   a.wblk = wblk;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // long-K layers whose output channels fill 256-wide tiles: the XL tile (AVT_CONV_X3_XL=0: the 128 x 128 tile everywhere)
-  static const int xl = avt::env_int_flag("AVT_CONV_X3_XL", 1);
-  AVT_REQUIRE(!wblk || (xl && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M) && a.K % 32 == 0),
+  // long-K layers whose output channels fill 256-wide tiles: the XL tile
+  AVT_REQUIRE(!wblk || (avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M) && a.K % 32 == 0),
               "avt_conv3d_igemm_x3_wblk: K-blocked weights are the 256 x 256 tile's (avt_conv3d_igemm_x3_xl_picked, K %% 32 == 0)");
-  if (xl && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M)) {
-    static const int xlv = avt::env_int_flag("AVT_CONV_X3_XL_V", 1);  // 0: the un-rotated K loop (A/B runs)
-    if (xlv == 0) return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, 0>(a, s) : launch_x3_xl<false, 0>(a, s);
-    if (xlv == 2) return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, 2>(a, s) : launch_x3_xl<false, 2>(a, s);
-#ifdef AVT_XL_TRAFFIC_EXPERIMENT
-    if (xlv == 3) return launch_x3_xl<true, 3>(a, s);
-    if (xlv == 4) return launch_x3_xl<true, 4>(a, s);
-#endif
-    return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, 1>(a, s) : launch_x3_xl<false, 1>(a, s);
-  }
+  if (avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M))
+    return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true>(a, s) : launch_x3_xl<false>(a, s);
   if (plane_dtype == AVT_X3_F16) {
     if (cout <= 32) return launch_x3<128, 32, 32, true>(a, s);
     if (cout <= 64) return launch_x3<128, 64, 64, true>(a, s);
@@ -1048,9 +905,8 @@ static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_
   a.wblk = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // long-K layers at a batch that fills 256 x 256 tiles (a rank's items as one batch): the XL tile's IO32 form
-  static const int xl32 = avt::env_int_flag("AVT_CONV_X3_XL_IO32", 1);
-  if (xl32 && a.K % 32 == 0 && a.oH == 0 && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M) && a.M >= 256 * 256)
-    return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, 0, true>(a, s) : launch_x3_xl<false, 0, true>(a, s);
+  if (a.K % 32 == 0 && a.oH == 0 && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M) && a.M >= 256 * 256)
+    return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, true>(a, s) : launch_x3_xl<false, true>(a, s);
   if (plane_dtype == AVT_X3_F16) {
     if (cout <= 32) return launch_x3<128, 32, 32, true, true>(a, s);
     if (cout <= 64) return launch_x3<128, 64, 64, true, true>(a, s);

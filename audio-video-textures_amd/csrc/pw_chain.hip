@@ -293,11 +293,6 @@ __global__ __launch_bounds__(NW * 64) void pw_chain_wide_kernel(PwArgs a) {
   }
 }
 
-int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return s ? atoi(s) : dflt;
-}
-
 template <int K1S, int N1, int N2, bool HAS_RES, bool W1_LDS, int NW, int K2X = 0>
 int launch(PwArgs& a, hipStream_t st) {
   constexpr int lds_bytes = (N2 / 16) * (N1 / 32 + K2X) * 1024 + (W1_LDS ? (N1 / 16) * K1S * 1024 : 0) + (N1 + N2) * 4;
@@ -308,7 +303,7 @@ int launch(PwArgs& a, hipStream_t st) {
     avt::set_error("avt_pw_chain_bf16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  static const int per_cu = env_int("AVT_PWC_WGS", (160 * 1024) / lds_bytes >= 2 ? 2 : 1);
+  constexpr int per_cu = (160 * 1024) / lds_bytes >= 2 ? 2 : 1;
   int grid = 256 * per_cu;
   const int need = (a.ntiles + NW - 1) / NW;
   if (grid > need) grid = need;
@@ -376,7 +371,5 @@ extern "C" int avt_pw_chain_bf16(const void* x1, int ldx, int k1, const void* w1
   if (k1 == 64 && x2) return launch<2, 256, 128, true, true, 12, 2>(a, s);  // 112 KB of weights
   if (k1 == 64) return launch<2, 256, 64, true, true, 6>(a, s);    // 146 VGPRs: 3 waves/SIMD = two 6-wave workgroups per CU
   if (k1 == 144) return launch<5, 256, 64, false, true, 12>(a, s);  // 112 KB of weights: one 12-wave workgroup per CU
-  static const int wide = env_int("AVT_PWC_WIDE", 1);
-  if (wide) return launch_wide(a, s);
-  return launch<4, 512, 128, true, false, 8>(a, s);
+  return launch_wide(a, s);  // res3: 128 -> 512 -> 128
 }

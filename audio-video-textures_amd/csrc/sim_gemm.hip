@@ -420,10 +420,8 @@ extern "C" int avt_sim_gemm_nt(const void* q, const void* q_lo, const void* t, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (precision) {
     case AVT_SIM_F32: {
-      static const int v2 = avt::env_int_flag("AVT_SIM_F32_V2", 1);  // 0: the 3-workgroups-per-CU tile for every shape
-      if (v2 && aligned && nq * (int64_t)d * 4 < (1ll << 32) - 64 && nt * (int64_t)d * 4 < (1ll << 32) - 64) return launch_f32_v2(a, st);
-      static const int tn = avt::env_int_flag("AVT_SIM_F32_TN", 128);
-      return tn == 128 ? launch<AVT_SIM_F32, 128>(a, aligned, st) : launch<AVT_SIM_F32, 64>(a, aligned, st);
+      if (aligned && nq * (int64_t)d * 4 < (1ll << 32) - 64 && nt * (int64_t)d * 4 < (1ll << 32) - 64) return launch_f32_v2(a, st);
+      return launch<AVT_SIM_F32, 128>(a, aligned, st);  // (unaligned / very large operands: the round-2 tile)
     }
     case AVT_SIM_BF16: return launch<AVT_SIM_BF16, 128>(a, aligned, st);
     default: return launch<AVT_SIM_BF16X3, 128>(a, aligned, st);

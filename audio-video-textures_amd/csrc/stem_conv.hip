@@ -59,7 +59,7 @@ struct StemArgs {
   // fused max-pool (POOL): out is the pooled tensor [B, To*tgroup, Ho/2, Wo/2, .] with row stride ldo (elements)
   int tgroup, ldo;
   int ncg;  // 32-channel groups
-  int swz;  // XCD-aware work order (AVT_STEM_SWZ, default 1)
+  int swz;  // XCD-aware work order (always on)
   // split-plane form (PL > 0): the low-order planes, same geometry, and the fp16 planes' per-channel weight scale
   const uint16_t* in_lo;
   const uint16_t* wt_lo;
@@ -93,9 +93,7 @@ __device__ __forceinline__ uint32_t max2(uint32_t x, uint32_t y) {  // packed bf
 // Work split: the R x MT (conv row, 16-position tile) units are dealt out evenly to the waves (plain: 4 rows x 7 tiles
 // on 4 waves = one row each; pooled: 9 x 7 = 63 units on 8 waves) — the kernel is MFMA-bound, and one wave per row
 // with 5 or 9 rows leaves one SIMD with twice the work of the others (measured 2.4x slower than stem + pool).
-// pooled split-plane form: 4 conv rows owned (+ 1 recomputed) instead of 8 — both planes of the patch and the fp32 conv tile
-// then fit in 77 KB, so two workgroups still share a CU and hide each other's patch fetch (8 owned rows need 129 KB)
-constexpr int RBPX = 4;
+constexpr int RBPX = 4;  // (split-plane instantiations never pool; kept for the shared index arithmetic)
 template <int MT, bool POOL, int PL = 0>
 __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void stem_kernel(StemArgs a) {
   constexpr int OWNP = PL ? RBPX : RBP;
@@ -387,52 +385,7 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
       *reinterpret_cast<uint4*>(a.out + pos * a.ldo + cin_f) = mx;
     }
   } else {
-    // split-plane form: the conv tile [R rows][WO][32 channels] in fp32 (over the patch), the max taken on the values, the
-    // pooled value split ONCE (equal to stem -> planes -> maxpool_hw3s2_ndhwc_x3, whose max of hi + lo is value-preserving)
-    __syncthreads();  // every wave is past its last read of the patch (the bf16 form's tile is smaller than the weights' offset)
-    constexpr int TROW = WO * 128;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-      float v[8];
-      values(i, v);
-      float* d = reinterpret_cast<float*>(lds + unit_row(i) * TROW + (unit_mt(i) * 16 + l15) * 128 + q * 32);
-      *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    }
-    __syncthreads();
-    constexpr int WP = WO / 2;
-    const int Hp = a.Ho / 2;
-    const int cf = a.Cout / a.tgroup;
-    for (int i = tid; i < (OWN / 2) * WP * 4; i += NTHR) {
-      const int cc = i & 3, pw_ = (i >> 2) % WP, pl = (i >> 2) / WP;
-      const int ch = n_base + cc * 8;
-      if (ch >= a.Cout) continue;
-      float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // ReLU output >= 0: the pool's padding can be 0
-#pragma unroll
-      for (int dh = 0; dh < 3; ++dh) {
-        const int tr = 2 * pl + dh;
-        if (ho0 + tr < 0) continue;
-#pragma unroll
-        for (int dw = 0; dw < 3; ++dw) {
-          const int wc = 2 * pw_ - 1 + dw;
-          if (wc < 0) continue;
-          const float* sp = reinterpret_cast<const float*>(lds + tr * TROW + wc * 128 + cc * 32);
-          const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
-          const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) m[e] = (x[e] > m[e] || x[e] != x[e]) ? x[e] : m[e];  // (keeps a NaN)
-        }
-      }
-      uint4 oh, ol;
-      avt::split2<PL == 2>(m[0], m[1], oh.x, ol.x);
-      avt::split2<PL == 2>(m[2], m[3], oh.y, ol.y);
-      avt::split2<PL == 2>(m[4], m[5], oh.z, ol.z);
-      avt::split2<PL == 2>(m[6], m[7], oh.w, ol.w);
-      const int j = ch / cf, cin_f = ch - j * cf;
-      const int64_t pos = ((int64_t)((b * a.To + to) * a.tgroup + j) * Hp + (OWN / 2) * hg + pl) * WP + pw_;
-      *reinterpret_cast<uint4*>(a.out + pos * a.ldo + cin_f) = oh;
-      *reinterpret_cast<uint4*>(a.out_lo + pos * a.ldo + cin_f) = ol;
-    }
+    static_assert(PL == 0 || !POOL, "the pooled form exists in bf16 only (the split-plane one measured slower than stem + pool)");
   }
 }
 
@@ -450,11 +403,7 @@ int launch(const StemArgs& a, int batch, hipStream_t st, const char* what) {
   }
   StemArgs b = a;
   b.ncg = (a.Cout + NT * 16 - 1) / (NT * 16);
-  static const int swz = []() {
-    const char* e = getenv("AVT_STEM_SWZ");
-    return e ? atoi(e) : 1;
-  }();
-  b.swz = swz;
+  b.swz = 1;
   const dim3 grid((unsigned)(batch * a.To * (a.Ho / (POOL ? OWNP : RB)) * b.ncg));
   hipLaunchKernelGGL((stem_kernel<MT, POOL, PL>), grid, dim3(POOL ? 512 : 256), lds_bytes, st, b);
   return avt::check_launch(what);
@@ -589,27 +538,3 @@ extern "C" int avt_stem_conv_x3_f32(const void* in_hi, const void* in_lo, const 
   return pw == 112 ? launch<7, false, 1>(a, batch, s, "avt_stem_conv_x3_f32") : launch<2, false, 1>(a, batch, s, "avt_stem_conv_x3_f32");
 }
 
-extern "C" int avt_stem_conv_pool_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
-                                     const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
-                                     int kt, int st, int pt, int tgroup, int ldo, int plane_dtype, void* stream) {
-  StemArgs a;
-  const int rc = fill(a, "avt_stem_conv_pool_x3", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, 1);
-  if (rc) return rc;
-  AVT_REQUIRE(in_lo && wt_lo && out_lo && avt::aligned16(in_lo) && avt::aligned16(wt_lo) && avt::aligned16(out_lo) &&
-                  (!wscale || avt::aligned16(wscale)),
-              "avt_stem_conv_pool_x3: every tensor needs both planes, 16-byte aligned");
-  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_stem_conv_pool_x3: bad plane_dtype");
-  AVT_REQUIRE(tgroup >= 1 && cout % tgroup == 0 && (cout / tgroup) % 8 == 0 && ldo % 8 == 0 && ldo >= cout / tgroup,
-              "avt_stem_conv_pool_x3: tgroup must split the channels into multiples of 8; ldo >= channels per frame");
-  AVT_REQUIRE((h / 2) % RBPX == 0, "avt_stem_conv_pool_x3: conv rows (%d) must be a multiple of %d", h / 2, RBPX);
-  a.in_lo = static_cast<const uint16_t*>(in_lo);
-  a.wt_lo = static_cast<const uint16_t*>(wt_lo);
-  a.out_lo = static_cast<uint16_t*>(out_lo);
-  a.wscale = wscale;
-  a.tgroup = tgroup;
-  a.ldo = ldo;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (plane_dtype == AVT_X3_F16)
-    return pw == 112 ? launch<7, true, 2>(a, batch, s, "avt_stem_conv_pool_x3") : launch<2, true, 2>(a, batch, s, "avt_stem_conv_pool_x3");
-  return pw == 112 ? launch<7, true, 1>(a, batch, s, "avt_stem_conv_pool_x3") : launch<2, true, 1>(a, batch, s, "avt_stem_conv_pool_x3");
-}

@@ -391,7 +391,7 @@ int launch_wgrad(SwArgs& a, hipStream_t st) {
     return AVT_ERR_LAUNCH;
   }
   const int slices = (a.Cout + 15) / 16;
-  static const int wgs = avt::env_int_flag("AVT_STEM_WGRAD_WGS", 256);  // persistent workgroups (one per CU: up to 150 KB of LDS)
+  constexpr int wgs = 256;  // persistent workgroups (one per CU: up to 150 KB of LDS)
   int gx = wgs / slices;
   if (gx < 1) gx = 1;
   if (gx > a.nunit) gx = a.nunit;

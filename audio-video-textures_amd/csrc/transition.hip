@@ -555,13 +555,12 @@ extern "C" int avt_row_topk(const float* sim, int64_t nq, int64_t nt, int64_t ld
   }
   if (nq == 0) return AVT_OK;
   KArgs a{sim, self_col, nq, nt, ld, k, top_idx, top_val};
-  static const int reg_form = avt::env_int_flag("AVT_TOPK_REG", 1);  // 0: the LDS-resident form for every width
   hipStream_t st_ = static_cast<hipStream_t>(stream);
-  if (reg_form && nt <= 16 * 256) {
+  if (nt <= 16 * 256) {  // register-resident forms up to 16384-wide rows, the LDS-resident form beyond
     hipLaunchKernelGGL((row_topk_reg_kernel<16, 256>), dim3((unsigned)nq), dim3(256), 0, st_, a);
     return avt::check_launch("avt_row_topk");
   }
-  if (reg_form && nt <= 16 * 1024) {
+  if (nt <= 16 * 1024) {
     hipLaunchKernelGGL((row_topk_reg_kernel<16, 1024>), dim3((unsigned)nq), dim3(1024), 0, st_, a);
     return avt::check_launch("avt_row_topk");
   }

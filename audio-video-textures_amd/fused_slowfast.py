@@ -21,32 +21,29 @@ from . import ops
 from ._lib import AvtError
 
 
-import os
-
-_FUSE_BLOCK = int(os.environ.get("AVT_FUSE_BLOCK", "1"))    # fast-pathway identity bottlenecks as one kernel
-_C33 = int(os.environ.get("AVT_C33", "1"))                  # slow res2 b conv on the strip-resident kernel
-_CHAIN = int(os.environ.get("AVT_PW_CHAIN", "1"))            # slow res2 / res3: c (+ residual) of block i and a of block i+1 in one pass
-_CHAIN_MAXN = int(os.environ.get("AVT_PW_CHAIN_MAXN", "512"))  # widest c to chain
-_FUSE_KCAT = int(os.environ.get("AVT_FUSE_KCAT", "1"))      # slow res2 first block: shortcut folded into c's GEMM
-_XB = int(os.environ.get("AVT_CONV_XB", "1"))                # long-K layers: fragment-order weights that bypass the LDS (XB tile)
-_FUSE_SCAT = int(os.environ.get("AVT_FUSE_SCAT", "1"))      # slow res3-5 first blocks: strided shortcut folded into c's GEMM
-_FUSE_TCHUNK = int(os.environ.get("AVT_FUSE_TCHUNK", "0"))   # frames walked per workgroup (2 halo frames each); 0 = by width:
-#                                                              16 at 56 columns (more workgroups), the whole clip (32) below
-_FUSE_BLOCK_X3 = int(os.environ.get("AVT_FUSE_BLOCK_X3", "1"))  # contract-grade mode: fast-pathway bottlenecks as one kernel
-_FUSE_TCHUNK_X3 = int(os.environ.get("AVT_FUSE_TCHUNK_X3", "0"))  # frames walked per workgroup; 0 = by width
-_CHAIN_X3 = int(os.environ.get("AVT_PW_CHAIN_X3", "1"))        # contract-grade mode: slow res2 c (+ residual) -> next a in one pass
-_WBLK_X3 = int(os.environ.get("AVT_WBLK_X3", "1"))            # contract-grade mode: K-blocked weight planes for the 256 x 256 tile
-_STEM_FM_X3 = int(os.environ.get("AVT_STEM_FM_X3", "1"))      # contract-grade mode: frame-major tiles in the time-grouped fast stem
-_C33_X3 = int(os.environ.get("AVT_C33_X3", "1"))              # contract-grade mode: slow res2 b conv on the direct-operand kernel
-_PW_X3 = int(os.environ.get("AVT_PW_X3", "1"))               # contract-grade mode: pointwise layers on the streaming kernel
-_STEM_LDS = int(os.environ.get("AVT_STEM_LDS", "1"))
-# contract-grade mode: max-pool fused into the stem kernel (1 = the slow stem, 2 = both).  OFF by default: measured 1.74 ms for the
-# pooled slow stem against 1.01 + 0.72 ms for stem + pool at 83 clips (profiles/r03/probe_stem_pool_x3.log) — the kernel is not
-# write-bound, and the fifth (recomputed) conv row + the fp32 tile's LDS round trip cost what the pool kernel did
-_STEM_POOL_X3 = int(os.environ.get("AVT_STEM_POOL_X3", "0"))
-_STEM_POOL = int(os.environ.get("AVT_STEM_POOL", "1"))  # max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both
-#                                                         (the MFMA-bound fast stem loses 4 % to the recomputed ninth row)
-_KW1_CAP = int(os.environ.get("AVT_GROUP_KW1_CAP", "32"))  # measured: profiles/r01/probe_layers.log
+# Which layers run on their fused / specialised kernels.  Plain module constants (no environment switches since round 4): every
+# one of them names the shipped path; tests and probes set some of them to 0 to get the per-layer general-tile path, which is
+# also the fallback for shapes a specialised kernel does not cover.
+_FUSE_BLOCK = 1      # bf16: fast-pathway bottlenecks as one kernel (csrc/bottleneck_fused.hip)
+_C33 = 1             # bf16: slow res2 b conv on the strip-resident kernel (csrc/conv33_c64.hip)
+_CHAIN = 1           # bf16: slow res2 / res3: c (+ residual) of block i and a of block i + 1 in one pass (csrc/pw_chain.hip)
+_CHAIN_MAXN = 512    # widest c to chain
+_FUSE_KCAT = 1       # slow res2 first block: shortcut folded into c's GEMM (K = [x | b-output])
+_XB = 1              # bf16: long-K layers with fragment-order weights that bypass the LDS (XB tile)
+_FUSE_SCAT = 1       # bf16: slow res3-5 first blocks: strided shortcut folded into c's GEMM
+_FUSE_TCHUNK = 0     # bf16 fused blocks: frames walked per workgroup (2 halo frames each); 0 = by width: 16 at 56 columns, else 32
+_FUSE_BLOCK_X3 = 1   # contract grade: fast-pathway bottlenecks as one kernel (csrc/bneck_x3.hip)
+_FUSE_TCHUNK_X3 = 0  # contract grade: frames walked per workgroup; 0 = by width (11 at 14 columns, else 8)
+_CHAIN_X3 = 1        # contract grade: slow res2 c (+ residual) -> next a in one pass (pw_chain_x3_kernel)
+_WBLK_X3 = 1         # contract grade: K-blocked weight planes for the 256 x 256 tile
+_STEM_FM_X3 = 1      # contract grade: frame-major tiles in the time-grouped fast stem
+_C33_X3 = 1          # contract grade: slow res2 b conv on the direct-operand kernel (csrc/conv33_x3.hip)
+_PW_X3 = 1           # contract grade: pointwise layers on the streaming kernel (csrc/pw_x3.hip)
+_STEM_LDS = 1        # both: the stems on the patch-resident kernel (csrc/stem_conv.hip)
+_STEM_POOL = 1       # bf16: max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both (the MFMA-bound fast
+#                      stem loses 4 % to the recomputed ninth row).  The split-plane pooled stem was built in round 3, measured
+#                      slower than stem + pool (1.74 ms against 1.01 + 0.72 ms, profiles/r03/probe_stem_pool_x3.log) and removed
+_KW1_CAP = 32        # pixel grouping of temporal-tap layers stops at this output width (profiles/r01/probe_layers.log)
 
 # Optional launch observer for bench.py: PROFILER(name, launch_fn, flops, bytes) must call launch_fn().
 PROFILER = None
@@ -369,8 +366,6 @@ def stem_conv(stem, device, tgroup=1, x3=None):
         fm = conv.frames_per_tile > 0
         conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1, fm) if conv.cout % 32 == 0 else None
         conv.wt_lds_lo = stem_lds_image(conv.wt_lo, kt + g - 1, fm) if conv.cout % 32 == 0 and x3 is not None else None
-        if fm:  # the pooled kernel (off by default) reads the classic image
-            conv.wt_lds_pool = (stem_lds_image(conv.wt, kt + g - 1), stem_lds_image(conv.wt_lo, kt + g - 1))
         return conv
     conv = FusedConv(None, None, True, device,
                      packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)), x3=x3)
@@ -838,7 +833,9 @@ class _BlockX3:
 
             def launch():
                 ops.bneck_x3(x.ptrs, y.ptrs, self.fused, b, t, h, w, x.C, self.c.cout, self.x3,
-                             tchunk=_FUSE_TCHUNK_X3 or 8)  # measured: profiles/r03/probe_bneck_x3_tchunk.log
+                             tchunk=_FUSE_TCHUNK_X3 or (11 if w == 14 else 8))  # measured: profiles/r03/probe_bneck_x3_tchunk.log;
+                # 14-wide stage (round 4): 11 frames per workgroup = 3 chunks per clip: 996 workgroups = 3.9 rounds of the 256 CUs at
+                # 166 clips (4 chunks: 5.2 rounds) and 2 halo frames per 11 instead of per 8 (profiles/r04/probe_bneck_early_load_ab.log)
 
             if PROFILER is None:
                 launch()
@@ -977,28 +974,6 @@ class SlowFastMFMA(nn.Module):
         x = Act(clip.hi.view(b * t * h * (w // 2), 8), (b, t, h, w // 2), lo=clip.lo.view(b * t * h * (w // 2), 8))
         lds_path = _STEM_LDS and conv.wt_lds_lo is not None and ops.stem_conv_supported(h, w // 2, conv.cout)
         kt = conv.kernel[0]
-        if lds_path and _STEM_POOL_X3 and (kt == 1 or _STEM_POOL_X3 > 1) and (h // 2) % 4 == 0:
-            # ... with the max-pool fused (the slow stem: one frame tap; the MFMA-bound fast stem would lose more to the
-            # recomputed fifth row than the separate pool costs): the conv output never reaches HBM
-            od = conv.out_dims(x.dims)
-            m_out = od[0] * od[1] * od[2] * od[3]
-            pd = (b, t, od[2] // 2, od[3] // 2)
-            cf = conv.frame_channels
-            if out is None:
-                out = new_act(pd[0] * pd[1] * pd[2] * pd[3], cf, pd, self.dev, True)
-
-            wlp = getattr(conv, "wt_lds_pool", None) or (conv.wt_lds, conv.wt_lds_lo)
-
-            def launch():
-                ops.stem_conv_pool_x3(x.ptrs, wlp[0], wlp[1], conv.bias, conv.wscale, out.ptrs, b, t, h, w // 2,
-                                      conv.cout, kt, conv.stride[0], conv.pad[0], conv.tgroup, out.ld, self.x3)
-
-            if PROFILER is None:
-                launch()
-            else:
-                PROFILER("stem_kernel<x3>", launch, m_out * conv.alg_flops_per_row,
-                         4.0 * (x.buf.numel() + pd[0] * pd[1] * pd[2] * pd[3] * cf) + conv.wt.numel() * 4)
-            return out, pd
         if lds_path:
             # production shape: the patch-resident stem kernel in its plane-pair form (no im2col gather)
             od = conv.out_dims(x.dims)

@@ -108,7 +108,7 @@ class InfoNCECriterion(nn.Module):
         return self._Fn.apply(logits.float(), labels)
 
 
-_TRAIN_STREAMS = int(os.environ.get("AVT_TRAIN_STREAMS", "1"))
+_TRAIN_STREAMS = 1  # the query encoder on a side stream next to the target encoder (tests set 0 for the single-stream step)
 _SIDE_STREAMS = {}
 
 

@@ -453,16 +453,6 @@ def stem_wgrad_x3(x_hi, x_lo, dy, batch, t, h, pw, cout, kt, pt):
     return dw
 
 
-def stem_conv_pool_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, tgroup, ldo, plane_dtype):
-    """stem_conv_x3 with the stem max-pool fused (the conv output stays on chip); out = pooled planes, row stride ldo."""
-    _dev(wt_hi, "wt_hi", torch.bfloat16)
-    _dev(wt_lo, "wt_lo", torch.bfloat16)
-    _lib.check(_lib.lib().avt_stem_conv_pool_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(wt_hi), _p(wt_lo), _p(bias),
-                                                _p(wscale), C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]), int(batch), int(t),
-                                                int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(tgroup), int(ldo),
-                                                int(plane_dtype), _stream()), "avt_stem_conv_pool_x3")
-
-
 def pw_x3_supported(k, n):
     return bool(_lib.lib().avt_pw_x3_supported(int(k), int(n)))
 

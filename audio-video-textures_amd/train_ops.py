@@ -19,7 +19,6 @@ Weight planes are cached per tensor and rebuilt when `weight._version` changes (
 in-place op on the parameter).  In-place updates through `.data` (EMA / momentum encoders, `p.data.clamp_()`) do NOT bump
 that counter: call `invalidate_weight_cache()` after them (train.train() does after every optimizer step)."""
 import ctypes as C
-import os
 import weakref
 
 import torch
@@ -27,14 +26,16 @@ import torch.nn.functional as F
 
 from . import _lib
 
-_FUSED = int(os.environ.get("AVT_FUSED_BN", "1"))
-_CONV_X3 = int(os.environ.get("AVT_TRAIN_CONV_X3", "1"))
-_WGRAD_X3 = int(os.environ.get("AVT_TRAIN_WGRAD_X3", "1"))
-_DGRAD_S_X3 = int(os.environ.get("AVT_TRAIN_DGRAD_STRIDED_X3", "1"))
-_STEM_WGRAD_X3 = int(os.environ.get("AVT_TRAIN_STEM_WGRAD_X3", "1"))
-_PLANES_HIP = int(os.environ.get("AVT_TRAIN_PLANES_HIP", "1"))  # weight planes by csrc/stem_train.hip's two kernels (0: torch ops)
-_STEM_PATCH = int(os.environ.get("AVT_TRAIN_STEM_PATCH", "1"))  # the stems on the patch-resident kernels (0: conv_x3 + wgrad slices)
-_FORK = int(os.environ.get("AVT_TRAIN_FORK", "1"))
+# Which passes of the training step run on the hand-written kernels.  Module constants (no environment switches since round 4);
+# `set_conv_mode` (main.py --train_conv) is the user-facing switch, tests set some of these to 0 for the stock-op reference path.
+_FUSED = 1          # train-mode BatchNorm (+ shortcut + ReLU) on csrc/bn_train.hip
+_CONV_X3 = 1        # convolution forward / stride-1 input gradient on conv_x3 (fp32 I/O)
+_WGRAD_X3 = 1       # weight gradient on csrc/wgrad_x3.hip
+_DGRAD_S_X3 = 1     # strided input gradients as residue-class convolutions on conv_x3 (0: MIOpen's bwd_data)
+_STEM_WGRAD_X3 = 1  # the stems' weight gradient on the hand-written kernels
+_PLANES_HIP = 1     # weight planes by csrc/stem_train.hip's two kernels (0: torch ops)
+_STEM_PATCH = 1     # the stems on the patch-resident kernels (0: conv_x3 + wgrad slices)
+_FORK = 1           # the shortcut's gradient summed in the a-convolution's input-gradient epilogue
 
 
 def set_conv_mode(mode):

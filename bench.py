@@ -780,9 +780,8 @@ def baseline_metric():
         return "clip-windows/sec encoded + N×N transition build, N=4096; HBM GB/s achieved"
 
 
-# AVT_BENCH_JOIN=1: rendezvous the two encoder streams after every batch (the earlier behaviour); default: the streams run
-# their batches back to back and are joined once per step (texture.TextureEngine.run_encoders(join=False))
-JOIN_EVERY_BATCH = os.environ.get("AVT_BENCH_JOIN", "0") == "1"
+# the encoder streams run their batches back to back and are joined once per step (texture.TextureEngine.run_encoders(join=False))
+JOIN_EVERY_BATCH = False
 
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "pmc_fetch_write_summary.json")  # written by tools/gpu_profile_round.sh r03
 PMC_BATCH = 166  # the encoder batch tools/pmc_kernels.py launches at

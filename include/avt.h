@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 3  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3) */
+#define AVT_ABI_VERSION 4  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed (round 4) */
 
 typedef enum {
   AVT_OK = 0,
@@ -406,13 +406,6 @@ int avt_pw_chain_x3(const void* x_hi, const void* x_lo, int ldx, int k1, const v
 int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
                      const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
                      int kt, int st, int pt, int relu, int plane_dtype, int frames_per_tile, void* stream);
-/* avt_stem_conv_x3 with MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused (the plane-pair form of avt_stem_conv_pool_bf16): the
- * conv + BN + ReLU output stays on chip as an fp32 tile, the pooled tensor [batch, To*tgroup, h/4, pw/2, cout/tgroup] is
- * written as hi / lo planes with row stride ldo (a channel slice of a wider buffer is allowed).  A workgroup owns 4 conv
- * rows (+ 1 recomputed): needs (h/2) % 4 == 0.  Equal to avt_stem_conv_x3 -> avt_maxpool_hw3s2_ndhwc_x3. */
-int avt_stem_conv_pool_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
-                          const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
-                          int kt, int st, int pt, int tgroup, int ldo, int plane_dtype, void* stream);
 /* avt_clip_pack_u8_ndhwc4 writing (hi, lo) planes: slow_* [n,8,hw,hw,4], fast_* [n,32,hw,hw,4]. */
 int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, int width,
                                const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw,

@@ -481,7 +481,7 @@ def test_pw_chain_matches_two_launches_and_torch(avt, dev, k1, n1, n2, has_res, 
 
 
 def test_chained_pointwise_passes_are_used_and_agree_with_unchained(avt, dev, monkeypatch):
-    """The slow pathway's chained passes (csrc/pw_chain.hip) against the same runner with AVT_PW_CHAIN off: six passes
+    """The slow pathway's chained passes (csrc/pw_chain.hip) against the same runner with fused_slowfast._CHAIN off: six passes
     per forward (res2: first block, identity block, the res2 -> res3 boundary; res3: three), embeddings agree to bf16
     rounding (the chained pass adds the residual before its one rounding, the implicit GEMM after its first)."""
     import avtex.fused_slowfast as fsf

@@ -87,7 +87,7 @@ def test_falls_back_outside_its_domain():
 def test_stem_runs_on_zero_padded_channels(kt):
     """The stems (3 input channels, models/models.py:565-584's SlowFast): forward on the kernel over a clip padded to 8
     channels; weight gradient on csrc/wgrad_x3.hip too — 4 of those channels per tap, the [kt,7,7] filter as kt slices of 49
-    taps — and, with AVT_TRAIN_STEM_WGRAD_X3 off, through MIOpen on the original clip."""
+    taps — and, with train_ops._STEM_WGRAD_X3 off, through MIOpen on the original clip."""
     from avtex import train_ops
     torch.manual_seed(kt)
     stem = nn.Conv3d(3, 64 if kt == 1 else 8, (kt, 7, 7), stride=(1, 2, 2), padding=(kt // 2, 3, 3), bias=False).to(DEV)

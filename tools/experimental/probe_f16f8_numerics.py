@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""NUMERICS-ONLY experiment: would a two-unit product — fp16 hi x hi on the fp16 pipe plus BOTH cross terms
+(wh * xl + wl * xh) as ONE fp8 (e4m3) K-concatenated MFMA pass at twice the fp16 rate — hold the contract?  No kernel is built:
+every Conv3d of the fp32 SlowFast nn.Module is replaced by an emulation of the candidate arithmetic out of fp32 convolutions on
+ROUNDED operands (the rounding is what the hardware would see; the accumulation is fp32 either way), and the resulting tables
+go through the same gate as tests/test_gpu_x3.py::test_contract_on_the_same_frames (agreement.compare_tables against the plain
+fp32 module on the same frames: max |dscore| < 1e-3, identical survivors on every row at th 0.0 and 0.3, 3/3 frames lists).
+The same emulation of f16x3 and bf16x3 (known: 2.4e-5 / 2.0e-4) calibrates it.
+usage: probe_f16f8_numerics.py [windows=256] [inputs=r04|r03]"""
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+import avtex  # noqa: E402
+from avtex import agreement, ops, synth  # noqa: E402
+from avtex.slowfast import SlowFast  # noqa: E402
+from avtex.texture import TextureEngine  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+inputs = sys.argv[2] if len(sys.argv) > 2 else "r04"
+dev = torch.device("cuda:0")
+W, S = 20, 4
+torch.backends.cudnn.benchmark = False
+
+if inputs == "r04":
+    video = synth.structured_video(5, n * S + W, 128, 128, variety=1)
+    torch.manual_seed(0)
+    q_mod = synth.randomise_bn(SlowFast().eval(), 10, 2.0, 0.1).to(dev)
+    t_mod = synth.perturbed_copy(q_mod, 11, 0.05)
+else:
+    video = synth.structured_video(5, n * S + W, 128, 128)
+    torch.manual_seed(0)
+    q_mod = synth.randomise_bn(SlowFast().eval(), 10, 0.5).to(dev)
+    torch.manual_seed(1)
+    t_mod = synth.randomise_bn(SlowFast().eval(), 11, 0.5).to(dev)
+cal = np.linspace(0, n - 1, 8).astype(np.int64) * S
+slow, fast = ops.clip_pack(video.to(dev), cal, W, out_hw=224, dtype=torch.float32)
+synth.calibrate_bn(q_mod, slow, fast)
+synth.calibrate_bn(t_mod, slow, fast)
+del slow, fast
+q_mod, t_mod = q_mod.eval(), t_mod.eval()
+
+MODE = [None]
+
+
+def rnd(x, dt):
+    return x.to(dt).float()
+
+
+def fp8(x, scale_pow2):
+    """e4m3 (OCP fn) with ONE power-of-two scale for the tensor (pessimistic against MX's per-32-block scales): saturating."""
+    y = (x * scale_pow2).clamp(-448.0, 448.0)
+    return y.to(torch.float8_e4m3fn).float() / scale_pow2
+
+
+def pow2_scale_for(x, top=256.0):
+    """largest power of two s with max|x| * s <= top (top < 448: headroom like a block scale chosen from the block maximum)"""
+    m = float(x.abs().max())
+    if m == 0.0 or not np.isfinite(m):
+        return 1.0
+    return 2.0 ** np.floor(np.log2(top / m))
+
+
+def emulated_conv(self, x, w, b):
+    mode = MODE[0]
+    if mode is None:
+        return F.conv3d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
+    conv = lambda a, ww: F.conv3d(a, ww, None, self.stride, self.padding, self.dilation, self.groups)
+    plane = torch.bfloat16 if mode == "bf16x3" else torch.float16
+    # weights: per-output-channel power-of-two prescale into [2^9, 2^10) (the product's fp16 planes; harmless for bf16)
+    amax = w.abs().flatten(1).amax(1).clamp_min(1e-30)
+    s = torch.exp2(9.0 - torch.floor(torch.log2(amax))).view(-1, 1, 1, 1, 1)
+    ws = w * s
+    wh = rnd(ws, plane)
+    wl = rnd(ws - wh, plane)
+    xh = rnd(x.clamp(-65504.0, 65504.0) if plane == torch.float16 else x, plane)
+    xl = rnd(x - xh, plane)
+    y = conv(xh, wh)
+    if mode in ("f16x3", "bf16x3"):
+        y = y + conv(xl, wh) + conv(xh, wl)
+    elif mode == "f16f8":  # both cross terms on 8-bit operands: wh8 * xl8 + wl8 * xh8
+        y = y + conv(fp8(xl, pow2_scale_for(xl)), fp8(wh, pow2_scale_for(wh))) + conv(fp8(xh, pow2_scale_for(xh)), fp8(wl, pow2_scale_for(wl)))
+    elif mode == "f16f8w":  # only the weight-side low plane in 8 bits (wl8 * xh fp16 would still be an fp16 pass: reference point)
+        y = y + conv(xl, wh) + conv(xh, fp8(wl, pow2_scale_for(wl)))
+    elif mode == "f16x2":   # no cross terms at all
+        pass
+    y = y / s.view(1, -1, 1, 1, 1)
+    return y if b is None else y + b.view(1, -1, 1, 1, 1)
+
+
+nn.Conv3d._conv_forward = emulated_conv
+
+
+def tables(mode):
+    MODE[0] = mode
+    eng = TextureEngine(q_mod, t_mod, None, window=W, stride=S, temp=0.1, img_size=224, model_type=1, device=dev, enc_batch=8,
+                        enc_arch="slowfast")
+    eng.set_video(video)
+    qv, tv = eng.build_tables()
+    torch.cuda.synchronize()
+    MODE[0] = None
+    return qv.clone(), tv.clone()
+
+
+q32, t32 = tables(None)
+print("inputs %s, %d windows; reference = fp32 nn.Module (MIOpen)" % (inputs, n), flush=True)
+for mode in ("f16x3", "bf16x3", "f16f8", "f16f8w", "f16x2"):
+    qv, tv = tables(mode)
+    r = agreement.compare_tables(qv, tv, q32, t32, 0.1, W, S)
+    th = r["thresholds"]
+    print("%-7s rel emb err %.2e  max|dscore| %.2e  survivors identical th0.0 %.4f th0.3 %.4f  frames lists %s / %s  (mean survivors th0.3 %.1f)" % (
+        mode, max(r["rel_embedding_err_q"], r["rel_embedding_err_t"]), r["max_abs_dscore"], th["0.0"]["rows_identical_survivors"],
+        th["0.3"]["rows_identical_survivors"], th["0.0"]["frames_lists_identical"], th["0.3"]["frames_lists_identical"],
+        th["0.3"]["mean_survivors"]), flush=True)

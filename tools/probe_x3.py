@@ -88,14 +88,6 @@ def spy_bn(x_ptrs, out_ptrs, packed, batch, t, h, w, cin, c, plane_dtype, tchunk
     return orig_bn(x_ptrs, out_ptrs, packed, batch, t, h, w, cin, c, plane_dtype, tchunk)
 
 
-orig_sp = ops.stem_conv_pool_x3
-
-
-def spy_sp(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, tgroup, ldo, plane_dtype):
-    shapes.append("stem + pool (LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)" % (cout, kt, st, batch, t, h, pw))
-    return orig_sp(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, tgroup, ldo, plane_dtype)
-
-
 orig_c33 = ops.conv33_x3
 
 
@@ -114,7 +106,6 @@ def spy_pc(x_ptrs, ldx, k1, w1, bias1, wscale1, res_ptrs, ldr, y_ptrs, ldy, n1, 
 
 ops.pw_chain_x3 = spy_pc
 ops.conv33_x3 = spy_c33
-ops.stem_conv_pool_x3 = spy_sp
 ops.bneck_x3 = spy_bn
 ops.conv3d_igemm_x3 = spy
 ops.pw_x3 = spy_pw
