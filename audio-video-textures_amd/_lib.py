@@ -74,7 +74,7 @@ SIGNATURES = {
     "avt_negative_sample_mt19937": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "avt_clip_pack_gather_u8": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                 C.c_int, _vp, _vp, C.c_int, _vp],
-    "avt_stem_conv_x3": [_vp] * 8 + [C.c_int] * 11 + [_vp],
+    "avt_stem_conv_x3": [_vp] * 8 + [C.c_int] * 11 + [_vp, C.c_int, _vp],
     "avt_clip_planes_f32": [_vp] + [C.c_int] * 4 + [C.c_int64] * 5 + [_vp, _vp, C.c_int, _vp],
     "avt_stem_conv_x3_f32": [_vp] * 6 + [C.c_int] * 11 + [_vp],
     "avt_weight_planes_f32": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp],
@@ -93,7 +93,7 @@ SIGNATURES = {
     "avt_conv3d_igemm_x3_wblk": [_vp] * 10 + [C.c_int] * 26 + [_vp, _vp],
     "avt_clip_pack_u8_ndhwc4_x3": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                    C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp],
-    "avt_maxpool_hw3s2_ndhwc_x3": [_vp] * 4 + [C.c_int] * 8 + [_vp],
+    "avt_maxpool_hw3s2_ndhwc_x3": [_vp] * 4 + [C.c_int] * 8 + [_vp, _vp],
     "avt_maxpool_hw2s2_ndhwc_x3": [_vp] * 4 + [C.c_int] * 7 + [_vp],
     "avt_mean_positions_x3": [_vp, _vp] + [C.c_int] * 4 + [_vp, C.c_int, C.c_int, _vp],
     "avt_conv3d_igemm_x3_xl_picked": [C.c_int] * 3,

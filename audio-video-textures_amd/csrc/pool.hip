@@ -161,7 +161,10 @@ namespace {
 template <bool F16, int KS = 3, int PAD = 1>
 __global__ __launch_bounds__(256) void maxpool3_x3_kernel(const uint16_t* __restrict__ in_hi, const uint16_t* __restrict__ in_lo,
                                                            uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int bt,
-                                                           int H, int W, int C, int ldi, int ldo, int Ho, int Wo, int tgroup) {
+                                                           int H, int W, int C, int ldi, int ldo, int Ho, int Wo, int tgroup,
+                                                           const int32_t* __restrict__ fidx = nullptr) {
+  // fidx (round 4): output frame b pools INPUT frame fidx[b] — the slow stem runs once per distinct source frame and the pool
+  // hands every (window, slot) its frame (overlapping windows share about half of their slow-pathway frames)
   const unsigned cpr = (unsigned)C >> 3;
   const unsigned cg = (unsigned)(C / tgroup);
   const unsigned total = (unsigned)bt * Ho * Wo * cpr;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void maxpool3_x3_kernel(const uint16_t* __rest
     const int wo = (int)(p - q * Wo);
     const unsigned b = q / (unsigned)Ho;
     const int ho = (int)(q - b * Ho);
-    const int64_t frame = (int64_t)b * H * W * ldi + cc * 8;
+    const int64_t frame = (int64_t)(fidx ? (unsigned)fidx[b] : b) * H * W * ldi + cc * 8;
     float m[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
@@ -247,8 +250,10 @@ __global__ __launch_bounds__(256) void mean_positions_x3_kernel(const uint16_t* 
 }  // namespace
 
 extern "C" int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h,
-                                          int w, int c, int ldi, int ldo, int tgroup, int plane_dtype, void* stream) {
+                                          int w, int c, int ldi, int ldo, int tgroup, int plane_dtype, const int32_t* frame_idx,
+                                          void* stream) {
   AVT_REQUIRE(in_hi && in_lo && out_hi && out_lo, "avt_maxpool_hw3s2_ndhwc_x3: NULL pointer");
+  AVT_REQUIRE(!frame_idx || tgroup == 1, "avt_maxpool_hw3s2_ndhwc_x3: frame_idx goes with tgroup == 1");
   AVT_REQUIRE(bt > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldi >= c,
               "avt_maxpool_hw3s2_ndhwc_x3: channels / leading dimensions must be multiples of 8");
   AVT_REQUIRE(avt::aligned16(in_hi) && avt::aligned16(in_lo) && avt::aligned16(out_hi) && avt::aligned16(out_lo),
@@ -265,9 +270,9 @@ extern "C" int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, 
   auto oh = static_cast<uint16_t*>(out_hi), ol = static_cast<uint16_t*>(out_lo);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (plane_dtype == AVT_X3_F16)
-    hipLaunchKernelGGL((maxpool3_x3_kernel<true>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, tgroup);
+    hipLaunchKernelGGL((maxpool3_x3_kernel<true>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, tgroup, frame_idx);
   else
-    hipLaunchKernelGGL((maxpool3_x3_kernel<false>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, tgroup);
+    hipLaunchKernelGGL((maxpool3_x3_kernel<false>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, tgroup, frame_idx);
   return avt::check_launch("avt_maxpool_hw3s2_ndhwc_x3");
 }
 
@@ -288,9 +293,9 @@ extern "C" int avt_maxpool_hw2s2_ndhwc_x3(const void* in_hi, const void* in_lo, 
   auto oh = static_cast<uint16_t*>(out_hi), ol = static_cast<uint16_t*>(out_lo);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (plane_dtype == AVT_X3_F16)
-    hipLaunchKernelGGL((maxpool3_x3_kernel<true, 2, 0>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, 1);
+    hipLaunchKernelGGL((maxpool3_x3_kernel<true, 2, 0>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, 1, nullptr);
   else
-    hipLaunchKernelGGL((maxpool3_x3_kernel<false, 2, 0>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, 1);
+    hipLaunchKernelGGL((maxpool3_x3_kernel<false, 2, 0>), dim3(grid), dim3(256), 0, st, ih, il, oh, ol, bt, h, w, c, ldi, ldo, ho, wo, 1, nullptr);
   return avt::check_launch("avt_maxpool_hw2s2_ndhwc_x3");
 }
 

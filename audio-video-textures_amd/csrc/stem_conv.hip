@@ -68,6 +68,10 @@ struct StemArgs {
   // training forward (avt_stem_conv_x3_f32): `out` is an fp32 NDHWC tensor [B, To * tgroup, Ho, Wo, Cout / tgroup] — the
   // time-grouped channels go back to their frames on the way out
   int out_f32;
+  // frame table (avt_stem_conv_x3 with frame_idx): `in` holds n_table distinct frames [n_table, H, PW, 8] and input frame t of clip b
+  // is table frame fidx[b * T + t] — clip windows that overlap (W / S of their frames each) and the fast pathway's repeated
+  // frames are then packed ONCE instead of once per (window, slot).  nullptr = the dense clip tensor [B, T, H, PW, 8]
+  const int32_t* fidx;
   // frame-major tiles of the time-grouped form (non-pooled split-plane entries): tile n of a 32-channel group holds output
   // frames 2n, 2n + 1 (8 channels each), so it meets frame taps 2n .. 2n + kt0 only (kt0 = the convolution's own frame taps)
   // and the other (tap, tile) pairs — structural zeros of the block-Toeplitz weights, 4 of 16 for [5,7,7] — are skipped.
@@ -179,7 +183,8 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
   constexpr int NPL = PL ? 2 : 1;
   i32x4 rp[NPL][PU], rb[NPL][BU];
   auto gload = [&](int dt) {
-    const unsigned fbase = (unsigned)(((b * a.T + t0 + dt) * a.H) * a.PW) * 16u;
+    const int fr = b * a.T + t0 + dt;
+    const unsigned fbase = (unsigned)(((a.fidx ? a.fidx[fr] : fr) * a.H) * a.PW) * 16u;
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
       const unsigned off = poff[u] == kOob ? kOob : fbase + poff[u];
@@ -439,6 +444,7 @@ int fill(StemArgs& a, const char* what, const void* in, const void* wt, const fl
   a.wscale = nullptr;
   a.out_f32 = 0;
   a.fm_kt0 = 0;
+  a.fidx = nullptr;
   AVT_REQUIRE(a.To > 0, "%s: no output frames", what);
   const int64_t in_b = (int64_t)batch * t * h * pw * 16, wt_b = (int64_t)cout * kt * KF * 2;
   AVT_REQUIRE(in_b < (1ll << 32) - 64 && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
@@ -491,10 +497,18 @@ static int fm_arg(StemArgs& a, const char* what, int frames_per_tile, int cout, 
 
 extern "C" int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
                                 const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout, int kt,
-                                int st, int pt, int relu, int plane_dtype, int frames_per_tile, void* stream) {
+                                int st, int pt, int relu, int plane_dtype, int frames_per_tile, const int32_t* frame_idx,
+                                int n_table_frames, void* stream) {
   StemArgs a;
   int rc = fill(a, "avt_stem_conv_x3", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu);
   if (rc) return rc;
+  if (frame_idx) {  // the input is a table of distinct frames (entries of frame_idx must lie in [0, n_table_frames): the
+    // buffer descriptor's range check turns an index beyond it into zeros, never into a fault)
+    AVT_REQUIRE(n_table_frames > 0 && (int64_t)n_table_frames * h * pw * 16 < (1ll << 32) - 64,
+                "avt_stem_conv_x3: frame table of %d frames is empty or too large for 32-bit offsets", n_table_frames);
+    a.fidx = frame_idx;
+    a.in_bytes = (unsigned)((int64_t)n_table_frames * h * pw * 16);
+  }
   rc = fm_arg(a, "avt_stem_conv_x3", frames_per_tile, cout, kt, st);
   if (rc) return rc;
   AVT_REQUIRE(in_lo && wt_lo && out_lo && avt::aligned16(in_lo) && avt::aligned16(wt_lo) && avt::aligned16(out_lo) &&

@@ -971,9 +971,19 @@ class SlowFastMFMA(nn.Module):
     def _stem_x3(self, conv, clip, out=None):
         """Contract-grade stem: pixel-pair convolution on the plain split-plane kernel, then the plane-pair max-pool."""
         b, t, h, w, _ = clip.shape
-        x = Act(clip.hi.view(b * t * h * (w // 2), 8), (b, t, h, w // 2), lo=clip.lo.view(b * t * h * (w // 2), 8))
         lds_path = _STEM_LDS and conv.wt_lds_lo is not None and ops.stem_conv_supported(h, w // 2, conv.cout)
+        table = isinstance(clip, ops.FrameClip)
+        if table and not lds_path:  # (shapes the patch-resident kernel does not cover: gather the clips the table stands for)
+            clip, table = clip.dense(), False
+        # a frame table [F, h, w, 4] read through clip.idx (round 4), or the dense clips [b, t, h, w, 4]
+        nf = clip.table_frames if table else b * t
         kt = conv.kernel[0]
+        # a stem without temporal taps (the slow pathway's [1,7,7]) is a per-frame function: on a frame table it runs ONCE per
+        # distinct frame and the pool hands every (window, slot) its frame (overlapping windows share about half of them)
+        per_frame = table and kt == 1 and conv.tgroup == 1 and conv.stride[0] == 1
+        sb, st_ = (nf, 1) if per_frame else (b, t)
+        x = Act(clip.hi.view(nf * h * (w // 2), 8), (sb, st_, h, w // 2), lo=clip.lo.view(nf * h * (w // 2), 8))
+        pool_idx = clip.idx.reshape(-1) if per_frame else None
         if lds_path:
             # production shape: the patch-resident stem kernel in its plane-pair form (no im2col gather)
             od = conv.out_dims(x.dims)
@@ -981,9 +991,10 @@ class SlowFastMFMA(nn.Module):
             y = new_act(m_out, conv.cout, od, self.dev, True)
 
             def launch():
-                ops.stem_conv_x3(x.ptrs, conv.wt_lds, conv.wt_lds_lo, conv.bias, conv.wscale, y.ptrs, b, t, h, w // 2,
+                ops.stem_conv_x3(x.ptrs, conv.wt_lds, conv.wt_lds_lo, conv.bias, conv.wscale, y.ptrs, sb, st_, h, w // 2,
                                  conv.cout, conv.kernel[0], conv.stride[0], conv.pad[0], self.x3, relu=True,
-                                 frames_per_tile=conv.frames_per_tile)
+                                 frames_per_tile=conv.frames_per_tile, frame_idx=clip.idx if (table and not per_frame) else None,
+                                 table_frames=nf if (table and not per_frame) else 0)
 
             if PROFILER is None:
                 launch()
@@ -997,7 +1008,10 @@ class SlowFastMFMA(nn.Module):
         cf = conv.frame_channels
         if out is None:
             out = new_act(pd[0] * pd[1] * pd[2] * pd[3], cf, pd, self.dev, True)
-        ops.maxpool_hw3s2_x3(y.ptrs, out.ptrs, b * tg, h2, w2, conv.cout, y.ld, out.ld, self.x3, tgroup=conv.tgroup)
+        if per_frame:
+            ops.maxpool_hw3s2_x3(y.ptrs, out.ptrs, b * t, h2, w2, conv.cout, y.ld, out.ld, self.x3, frame_idx=pool_idx)
+        else:
+            ops.maxpool_hw3s2_x3(y.ptrs, out.ptrs, b * tg, h2, w2, conv.cout, y.ld, out.ld, self.x3, tgroup=conv.tgroup)
         return out, pd
 
     @torch.no_grad()

@@ -84,6 +84,41 @@ class SplitClip:
         return self.hi.view(dt).float() + self.lo.view(dt).float()
 
 
+class FrameClip:
+    """A batch of clips as a TABLE of distinct packed frames plus an index (round 4): planes hi / lo [F, hw, hw, 4] (F distinct
+    source frames, resized / normalised once each) and idx [n, T] int32 — clip i's frame t is table frame idx[i, t].  Overlapping
+    windows (W / S of their frames each) and the fast pathway's repeated frames share table rows: 0.55 GB instead of 5.3 GB per
+    166 windows at W = 20, S = 4.  Quacks like SplitClip ([n, T, hw, hw, 4]); the patch-resident stem kernel reads it through the
+    index (avt_stem_conv_x3 frame_idx), anything else asks for .dense()."""
+
+    def __init__(self, hi, lo, idx, plane_dtype):
+        self.hi, self.lo, self.idx, self.plane_dtype = hi, lo, idx, plane_dtype
+
+    @property
+    def shape(self):
+        return (self.idx.shape[0], self.idx.shape[1]) + tuple(self.hi.shape[1:])
+
+    @property
+    def table_frames(self):
+        return int(self.hi.shape[0])
+
+    def chunk(self, parts):
+        return [FrameClip(self.hi, self.lo, i.contiguous(), self.plane_dtype) for i in self.idx.chunk(parts)]
+
+    def record_stream(self, st):
+        for t_ in (self.hi, self.lo, self.idx):
+            t_.record_stream(st)
+
+    def dense(self):
+        """-> the SplitClip [n, T, hw, hw, 4] this table stands for (a gather: shapes the table kernels do not cover)."""
+        flat = self.idx.reshape(-1).long()
+        shp = self.shape
+        return SplitClip(self.hi.index_select(0, flat).view(shp), self.lo.index_select(0, flat).view(shp), self.plane_dtype)
+
+    def float(self):
+        return self.dense().float()
+
+
 X3_BF16, X3_F16 = 0, 1
 _X3 = {"bf16x3": X3_BF16, "f16x3": X3_F16}
 
@@ -127,6 +162,36 @@ def clip_pack(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0.225, b
                                            float(mean), float(std), 1 if bgr else 0, _p(slow), _p(fast),
                                            1 if dtype == torch.bfloat16 else 0, _stream()), "avt_clip_pack_u8")
     return slow, fast
+
+
+def clip_pack_frames(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0.225, bgr=True, planes="f16x3"):
+    """clip_pack for the contract-grade encoder as a frame TABLE: every frame of frames_u8 [F,H,W,3] is resized / normalised /
+    split ONCE into planes [F, hw, hw, 4] (the ndhwc4 kernel with one destination per frame), and the windows' temporal
+    sampling (linspace(0, W-1, 32).long() and its 8-subsample) becomes two index arrays -> (slow FrameClip [n,8,..], fast
+    FrameClip [n,32,..]) sharing the table."""
+    _dev(frames_u8, "frames_u8", torch.uint8)
+    assert frames_u8.dim() == 4 and frames_u8.shape[3] == 3
+    n_frames, h, w, _ = frames_u8.shape
+    win_start = np.ascontiguousarray(win_start, np.int64)
+    if win_start.size and (win_start.min() < 0 or win_start.max() + win_len > n_frames):
+        raise _lib.AvtError("clip_pack_frames: a window leaves the %d frames" % n_frames)
+    pd = _X3[planes]
+    dev = frames_u8.device
+    f = np.arange(n_frames, dtype=np.int32)
+    off = np.arange(n_frames + 1, dtype=np.int32)            # one destination per frame ...
+    slot = (f // SLOW_T) * SLOTS + f % SLOW_T               # ... slot f of a "slow" tensor [ceil(F/8), 8, hw, hw, 4] = table row f
+    n_grp = -(-n_frames // SLOW_T)
+    hi = torch.empty((n_grp * SLOW_T, out_hw, out_hw, 4), dtype=torch.bfloat16, device=dev)
+    lo = torch.empty_like(hi)
+    d_off, d_slot = torch.from_numpy(off).to(dev, non_blocking=True), torch.from_numpy(slot.astype(np.int32)).to(dev, non_blocking=True)
+    _lib.check(_lib.lib().avt_clip_pack_u8_ndhwc4_x3(_p(frames_u8), n_frames, h, w, _p(d_off), _p(d_slot), n_grp, int(out_hw),
+                                                     float(mean), float(std), 1 if bgr else 0, _p(hi), _p(lo), _p(hi), _p(lo), pd,
+                                                     _stream()), "avt_clip_pack_u8_ndhwc4_x3")
+    fast_off, slow_off = clip_sample_table(win_len)
+    idx_f = torch.from_numpy((win_start[:, None] + fast_off[None, :]).astype(np.int32)).to(dev, non_blocking=True)
+    idx_s = torch.from_numpy((win_start[:, None] + slow_off[None, :]).astype(np.int32)).to(dev, non_blocking=True)
+    hi, lo = hi[:n_frames], lo[:n_frames]
+    return FrameClip(hi, lo, idx_s, pd), FrameClip(hi, lo, idx_f, pd)
 
 
 def clip_pack_gather(frames_u8, win_start_dev, win_len, out_hw=224, mean=0.45, std=0.225, bgr=True, dtype=torch.float32):
@@ -403,15 +468,21 @@ def conv3d_wgrad_x3_sub_f32(dy, x, dw, dims, cin, cout, kernel, stride, pad, out
 
 
 def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True,
-                 frames_per_tile=0):
+                 frames_per_tile=0, frame_idx=None, table_frames=0):
     """stem_conv on plane pairs (contract-grade mode); wt_hi / wt_lo = fused_slowfast.stem_lds_image of each weight plane
-    (frames_per_tile = 2: its frame-major form for the 4-frame x 8-channel time-grouped stem)."""
+    (frames_per_tile = 2: its frame-major form for the 4-frame x 8-channel time-grouped stem).  frame_idx (int32 [batch * t],
+    device): x_ptrs is a table of `table_frames` distinct frames and clip b's frame t is table frame frame_idx[b * t_total + t]."""
     _dev(wt_hi, "wt_hi", torch.bfloat16)
     _dev(wt_lo, "wt_lo", torch.bfloat16)
+    if frame_idx is not None:
+        _dev(frame_idx, "frame_idx", torch.int32)
+        if frame_idx.numel() != batch * t:
+            raise _lib.AvtError("stem_conv_x3: frame_idx has %d entries, expected batch * t = %d" % (frame_idx.numel(), batch * t))
     _lib.check(_lib.lib().avt_stem_conv_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(wt_hi), _p(wt_lo), _p(bias),
                                            _p(wscale), C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]), int(batch), int(t),
                                            int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(bool(relu)),
-                                           int(plane_dtype), int(frames_per_tile), _stream()), "avt_stem_conv_x3")
+                                           int(plane_dtype), int(frames_per_tile), _p(frame_idx), int(table_frames), _stream()),
+               "avt_stem_conv_x3")
 
 
 def clip_planes_f32(x, plane_dtype):
@@ -485,10 +556,15 @@ def pw_chain_x3(x_ptrs, ldx, k1, w1, bias1, wscale1, res_ptrs, ldr, y_ptrs, ldy,
                "avt_pw_chain_x3")
 
 
-def maxpool_hw3s2_x3(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1):
+def maxpool_hw3s2_x3(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1, frame_idx=None):
+    """frame_idx (int32 [bt], device): output frame b pools input frame frame_idx[b] (a table of distinct frames)."""
+    if frame_idx is not None:
+        _dev(frame_idx, "frame_idx", torch.int32)
+        if frame_idx.numel() != bt:
+            raise _lib.AvtError("maxpool_hw3s2_x3: frame_idx has %d entries, expected %d" % (frame_idx.numel(), bt))
     _lib.check(_lib.lib().avt_maxpool_hw3s2_ndhwc_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), C.c_void_p(out_ptrs[0]),
                                                      C.c_void_p(out_ptrs[1]), int(bt), int(h), int(w), int(c), int(ldi),
-                                                     int(ldo), int(tgroup), int(plane_dtype), _stream()),
+                                                     int(ldo), int(tgroup), int(plane_dtype), _p(frame_idx), _stream()),
                "avt_maxpool_hw3s2_ndhwc_x3")
 
 

@@ -8,7 +8,10 @@ SLOWFAST_8x8_R50 with PySlowFast's module names, so a con
 checkpoint (`q_encoder.s1.pathway0_stem.conv.weight`, ...) loads by key.  PARITY UNPINNED: no
 reference test or weight file pins its arithmetic.
 
-MI355X notes: convolutions go to MIOpen; run it in bf16 with channels_last_3d (`prepare_encoder`).
+MI355X notes: this nn.Module is the weight container and the plugin surface.  At `-e` its weights run on the hand-written MFMA
+convolutions (fused_slowfast.SlowFastMFMA: BatchNorm folded, split-plane fp16 arithmetic by default); in train mode its
+convolutions / BatchNorms / pools run on the hand-written passes of train_ops (channels_last_3d).  Only `--enc_impl module`
+and `--train_conv fp32` send it to MIOpen.
 """
 import torch
 import torch.nn as nn

@@ -25,6 +25,10 @@ import torch
 from . import ops
 from ._lib import AvtError
 
+# contract-grade encoders: pack every distinct frame once and hand the stems a frame table + index (ops.FrameClip) instead of
+# dense per-window clips (round 4; tests set False to compare the two forms: same embeddings bit for bit)
+FRAME_TABLE = True
+
 
 def num_segments(n_frames, window, stride):
     return math.floor((n_frames - window) / stride)  # validate.py:189
@@ -164,6 +168,10 @@ class TextureEngine:
     # ---- packing + encoding ----------------------------------------------------------
     def _pack(self, frames, starts):
         lo, hi = int(starts.min()), int(starts.max()) + self.W
+        if self.planes is not None and self.layout == "ndhwc4" and FRAME_TABLE:
+            # contract-grade encoders: every distinct frame packed once, the windows' sampling as an index (ops.FrameClip)
+            return ops.clip_pack_frames(frames[lo:hi], starts - lo, self.W, out_hw=self.hw, mean=self.mean, std=self.std,
+                                        bgr=True, planes=self.planes)
         return ops.clip_pack(frames[lo:hi], starts - lo, self.W, out_hw=self.hw, mean=self.mean, std=self.std,
                              bgr=True, dtype=self.pack_dtype, layout=self.layout, planes=self.planes)
 

@@ -111,6 +111,7 @@ def run_mode(args, precision, video, q_mod, t_mod, rank, world, dev):
     """K timed steps of the hot path with the encoders in `precision` -> result dict (rank 0) / None."""
     from avtex import dist as adist, ops
     import avtex.fused_slowfast as fsf
+    import avtex.texture as texture_mod
     from avtex.texture import TextureEngine
 
     W, S, N, D, temp = 20, 4, args.windows, 2304, 0.1
@@ -142,12 +143,19 @@ def run_mode(args, precision, video, q_mod, t_mod, rank, world, dev):
             for i in range(0, N, args.enc_batch):
                 st = starts[i : i + args.enc_batch]
                 lo, hi = int(st.min()), int(st.max()) + W
-                off, slot = ops.clip_pack_plan(st - lo, W, hi - lo)
-                plan = (torch.from_numpy(off).to(dev, non_blocking=True), torch.from_numpy(slot).to(dev, non_blocking=True))
-                slow, fast = timer.run("clip_pack", lambda: ops.clip_pack(eng.frames[lo:hi], st - lo, W, out_hw=224,
-                                                                           dtype=eng.pack_dtype, plan=plan,
-                                                                           layout=eng.layout, planes=eng.planes))
-                if timer.on and len(pack_bytes) < 4096:
+                if eng.planes is not None and eng.layout == "ndhwc4" and texture_mod.FRAME_TABLE:
+                    # contract-grade leg: every distinct frame packed once (ops.FrameClip: a frame table + the windows' index)
+                    slow, fast = timer.run("clip_pack", lambda: ops.clip_pack_frames(eng.frames[lo:hi], st - lo, W, out_hw=224,
+                                                                                      planes=eng.planes))
+                    if timer.on and len(pack_bytes) < 4096:
+                        pack_bytes.append((hi - lo) * (args.frame_hw * args.frame_hw * 3 + 224 * 224 * 4 * esz))
+                else:
+                    off, slot = ops.clip_pack_plan(st - lo, W, hi - lo)
+                    plan = (torch.from_numpy(off).to(dev, non_blocking=True), torch.from_numpy(slot).to(dev, non_blocking=True))
+                    slow, fast = timer.run("clip_pack", lambda: ops.clip_pack(eng.frames[lo:hi], st - lo, W, out_hw=224,
+                                                                               dtype=eng.pack_dtype, plan=plan,
+                                                                               layout=eng.layout, planes=eng.planes))
+                if timer.on and len(pack_bytes) < 4096 and not isinstance(slow, ops.FrameClip):
                     n_el = int(np.prod(slow.shape)) + int(np.prod(fast.shape))
                     pack_bytes.append((hi - lo) * args.frame_hw * args.frame_hw * 3 +
                                       n_el * (esz if eng.layout == "ndhwc4" else slow.element_size()))
@@ -372,7 +380,8 @@ def train_bench(args, rank, world, dev):
     accumulate over the rank's items (DDP no_sync) and are all-reduced once per step over RCCL.  Input path on the device:
     resident uint8 video, MT19937 negative sampling, gather packing (dataset.DeviceSegmentBatcher); fused HIP
     normalise->bmm->/temp forward/backward + HIP softmax-CE (models._InfoNCELogits, InfoNCECriterion); encoder
-    forward/backward = MIOpen autograd (see DESIGN.md for why the BN-folded MFMA kernels do not apply in train mode)."""
+    forward/backward = the hand-written passes of train_ops (split-plane MFMA convolutions forward / input gradient / weight
+    gradient with fp32 I/O, train-mode BatchNorm, max-pool) — MIOpen autograd only with --train-layout ncdhw."""
     import contextlib
     from types import SimpleNamespace
 
@@ -508,7 +517,9 @@ def train_bench(args, rank, world, dev):
         "metric": "contrastive training (train.py) InfoNCE negs=14 temp=0.1, batch of 8 items: encoder clips/s through forward+backward",
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": total_s / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.train_dtype, "data": "synthetic",
+        # the arithmetic of the convolutions, not a precision claim: fp32 tensors in and out, products from 16-bit planes
+        "dtype": ("x3 (f16 fwd / bf16 grad planes, fp32 I/O)" if (channels_last and args.train_dtype == "fp32") else args.train_dtype),
+        "data": "synthetic",
         "config": {"workload": "BASELINE config 5: batch 8 x (1 query + 1 positive + 14 negatives) = 128 clips/step at 224^2 "
                                "through SlowFast-8x8-R50 q/t encoders (train-mode BatchNorm per item = per DataParallel "
                                "replica), HIP InfoNCE + CE, SGD; inputs sampled and packed on the device",

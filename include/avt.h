@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 4  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed (round 4) */
+#define AVT_ABI_VERSION 4  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index (round 4) */
 
 typedef enum {
   AVT_OK = 0,
@@ -403,9 +403,15 @@ int avt_pw_chain_x3(const void* x_hi, const void* x_lo, int ldx, int k1, const v
  * frames x 8 channels = cout 32 over kt = 5 + 3 frame taps): channel 16*tile + row, i.e. a 16-channel MFMA tile holds two output
  * frames and meets frame taps 2*tile .. 2*tile + 5 only — the other (tap, tile) pairs are structural zeros of the block-Toeplitz
  * weights and are skipped (4 of 16).  Same results. */
+/* frame_idx (round 4, ABI 4): NULL = `in_*` is the dense clip tensor [batch, t, h, pw, 8].  Otherwise `in_*` is a TABLE of
+ * n_table_frames distinct frames [n_table_frames, h, pw, 8] and input frame t of clip b is table frame frame_idx[b * t_total + t]
+ * (int32, device): overlapping clip windows (W / S of their frames each; reference validate.py:188-195) and the fast pathway's
+ * repeated frames (linspace(0, W-1, 32).long() with W < 32) are packed once per distinct frame instead of once per
+ * (window, slot) — 0.55 GB instead of 5.3 GB per 166 windows at W = 20, S = 4.  Same results. */
 int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
                      const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
-                     int kt, int st, int pt, int relu, int plane_dtype, int frames_per_tile, void* stream);
+                     int kt, int st, int pt, int relu, int plane_dtype, int frames_per_tile, const int32_t* frame_idx,
+                     int n_table_frames, void* stream);
 /* avt_clip_pack_u8_ndhwc4 writing (hi, lo) planes: slow_* [n,8,hw,hw,4], fast_* [n,32,hw,hw,4]. */
 int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, int width,
                                const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw,
@@ -415,9 +421,12 @@ int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, 
  * plane-pair form of avt_maxpool_hw2s2_ndhwc_bf16).  The max is taken on hi + lo and split again: value-preserving. */
 int avt_maxpool_hw2s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h, int w, int c,
                                int ldi, int ldo, int plane_dtype, void* stream);
-/* avt_maxpool_hw3s2_ndhwc_bf16 / avt_mean_positions_bf16 on plane pairs (max / sum of the fp32 values hi + lo). */
+/* avt_maxpool_hw3s2_ndhwc_bf16 / avt_mean_positions_bf16 on plane pairs (max / sum of the fp32 values hi + lo).
+ * frame_idx (round 4, ABI 4; tgroup == 1): NULL, or int32 [bt] on the device: output frame b pools INPUT frame frame_idx[b] —
+ * the slow stem ([1,7,7]: no temporal taps) runs once per distinct source frame and the pool hands every (window, slot) its frame. */
 int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h,
-                               int w, int c, int ldi, int ldo, int tgroup, int plane_dtype, void* stream);
+                               int w, int c, int ldi, int ldo, int tgroup, int plane_dtype, const int32_t* frame_idx,
+                               void* stream);
 int avt_mean_positions_x3(const void* in_hi, const void* in_lo, int batch, int p, int c, int ldi,
                           float* out, int ldo, int plane_dtype, void* stream);
 

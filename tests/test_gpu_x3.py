@@ -637,3 +637,41 @@ def test_pw_chain_x3_is_bit_identical_to_the_two_launches(avt, dev, mode):
         finally:
             fsf._CHAIN_X3 = keep
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_frame_table_equals_dense_clips(avt, dev, mode):
+    """ops.clip_pack_frames (every distinct frame packed once + the windows' sampling index, read by the stem kernel through
+    avt_stem_conv_x3's frame_idx) against dense per-window clips (ops.clip_pack): the table's rows equal the dense clips' frames
+    bit for bit, and the encoder's embeddings are identical — W = 20, S = 4 windows (the fast pathway repeats frames, windows
+    overlap by 16 of 20), ragged window starts, and the explicit-gather fallback for a shape the table kernel does not cover."""
+    import avtex.fused_slowfast as fsf
+    import avtex.texture as texture
+    from avtex import ops, synth
+    from avtex.slowfast import SlowFast
+
+    W, S, n = 20, 4, 7
+    video = synth.structured_video(3, 80, 48, 56).to(dev)
+    starts = np.array([0, 4, 8, 12, 21, 33, 60], dtype=np.int64)
+    slow_d, fast_d = ops.clip_pack(video, starts, W, out_hw=224, layout="ndhwc4", planes=mode)
+    slow_t, fast_t = ops.clip_pack_frames(video, starts, W, out_hw=224, planes=mode)
+    assert slow_t.shape == tuple(slow_d.shape) and fast_t.shape == tuple(fast_d.shape) and slow_t.table_frames == 80
+    for dense, tab in ((slow_d, slow_t), (fast_d, fast_t)):
+        g = tab.dense()
+        assert torch.equal(g.hi, dense.hi) and torch.equal(g.lo, dense.lo)
+    torch.manual_seed(0)
+    enc = fsf.SlowFastMFMA(synth.randomise_bn(SlowFast().eval(), 3, 0.5), dev, precision=mode)
+    e_dense = enc.forward_ndhwc4(slow_d, fast_d)
+    e_table = enc.forward_ndhwc4(slow_t, fast_t)
+    assert torch.equal(e_dense, e_table)
+    # ... and through the engine (texture.FRAME_TABLE on / off), batches of 3 windows
+    from avtex.texture import TextureEngine
+
+    outs = []
+    for flag in (True, False):
+        keep, texture.FRAME_TABLE = texture.FRAME_TABLE, flag
+        eng = TextureEngine(enc, enc, None, window=W, stride=S, temp=0.1, img_size=224, model_type=1, device=dev, enc_batch=3)
+        eng.set_video(video)
+        outs.append(eng.embed_windows([enc], starts=starts)[0].clone())
+        texture.FRAME_TABLE = keep
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], e_dense)

@@ -19,8 +19,13 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = fsf.SlowFastMFMA(SlowFast(), dev, precision=mode)
 pd = fsf.PRECISIONS[mode]
-mk = lambda t_: ops.SplitClip(*fsf.split_planes(torch.randn(b, t_, 224, 224, 4, device=dev), pd), pd)
-slow, fast = mk(8), mk(32)
+if len(sys.argv) > 3 and sys.argv[3] == "table":  # the product's input form: every distinct frame packed once + the windows' index
+    vid = torch.randint(0, 256, (b * 4 + 20, 128, 128, 3), dtype=torch.uint8, device=dev)
+    import numpy as np
+    slow, fast = ops.clip_pack_frames(vid, np.arange(b, dtype=np.int64) * 4, 20, out_hw=224, planes=mode)
+else:
+    mk = lambda t_: ops.SplitClip(*fsf.split_planes(torch.randn(b, t_, 224, 224, 4, device=dev), pd), pd)
+    slow, fast = mk(8), mk(32)
 for _ in range(2):
     y = m.forward_ndhwc4(slow, fast)
 torch.cuda.synchronize()
@@ -62,19 +67,22 @@ def spy_pw(x_ptrs, ldx, k, w_hi, w_lo, bias, wscale, res_ptrs, ldr, y_ptrs, ldy,
 orig_stem = ops.stem_conv_x3
 
 
-def spy_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True, frames_per_tile=0):
-    shapes.append("stem (LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)%s" % (cout, kt, st, batch, t, h, pw, " frame-major" if frames_per_tile else ""))
-    return orig_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu, frames_per_tile)
+def spy_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu=True, frames_per_tile=0,
+             frame_idx=None, table_frames=0):
+    shapes.append("stem (LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d)%s%s" % (cout, kt, st, batch, t, h, pw, " frame-major" if frames_per_tile else "",
+                                                                               " via a table of %d frames" % table_frames if frame_idx is not None else ""))
+    return orig_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, relu, frames_per_tile,
+                     frame_idx, table_frames)
 
 
 pool_recs = []
 orig_pool = ops.maxpool_hw3s2_x3
 
 
-def spy_pool(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1):
+def spy_pool(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup=1, frame_idx=None):
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    r = orig_pool(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup)
+    r = orig_pool(x_ptrs, out_ptrs, bt, h, w, c, ldi, ldo, plane_dtype, tgroup, frame_idx)
     e.record()
     pool_recs.append((a, e, "maxpool 3x3/2 x3 in(%d, %d, %d, %d)" % (bt, h, w, c), 4.0 * bt * c * (h * w + (h // 2) * (w // 2))))
     return r
