@@ -72,6 +72,14 @@ struct StemArgs {
   // is table frame fidx[b * T + t] — clip windows that overlap (W / S of their frames each) and the fast pathway's repeated
   // frames are then packed ONCE instead of once per (window, slot).  nullptr = the dense clip tensor [B, T, H, PW, 8]
   const int32_t* fidx;
+  // merged frame taps (avt_stem_conv_x3_merged): the fast pathway samples 32 slots from a W-frame window with
+  // linspace(0, W-1, 32).long() — for W = 20 only 5 of the 8 slots an output-frame group meets are DISTINCT source frames.
+  // Conv is linear in the weights, so the taps that read one source frame are summed on the host: group `to` walks ktm merged
+  // taps, tap j reads table frame mtab[(b * To + to) * ktm + j] (-1 = no further tap) with the weight slab (to * ktm + j) of the
+  // image, and bit n of mact[to * ktm + j] says whether tile n's rows of that slab are non-zero.  nullptr = one tap per slot.
+  const int32_t* mtab;
+  const int32_t* mact;
+  int ktm;
   // frame-major tiles of the time-grouped form (non-pooled split-plane entries): tile n of a 32-channel group holds output
   // frames 2n, 2n + 1 (8 channels each), so it meets frame taps 2n .. 2n + kt0 only (kt0 = the convolution's own frame taps)
   // and the other (tap, tile) pairs — structural zeros of the block-Toeplitz weights, 4 of 16 for [5,7,7] — are skipped.
@@ -155,7 +163,8 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
   // weights arrive in the LDS image order [group of 32 channels][frame tap][7 dh][NT][4 dp][16 rows] x 16 B (host-side
   // repack, see include/avt.h): staging them is a linear copy — coalesced global reads, conflict-free ds_write_b128.
   // Row 4q'+i of tile nt holds channel 8q' + 4nt + i of the group, so a lane's two accumulators are 8 consecutive channels.
-  const unsigned gbase = (unsigned)(cgi * a.KT) * (unsigned)(BCH * 16);
+  const unsigned gbase = a.mtab ? (unsigned)((cgi * a.To + to) * a.ktm) * (unsigned)(BCH * 16) : (unsigned)(cgi * a.KT) * (unsigned)(BCH * 16);
+  const int32_t* mrow = a.mtab ? a.mtab + (int64_t)(b * a.To + to) * a.ktm : nullptr;
 
   f32x4 acc[TPW][NT];
   const int lane_off = (l15 + q) * 16;
@@ -177,14 +186,19 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
 
   // frame taps that fall inside the clip
   const int t0 = to * a.st - a.pt;
-  const int dt_lo = t0 < 0 ? -t0 : 0;
-  const int dt_hi = (a.T - t0) < a.KT ? (a.T - t0) : a.KT;
+  int dt_lo = t0 < 0 ? -t0 : 0;
+  int dt_hi = (a.T - t0) < a.KT ? (a.T - t0) : a.KT;
+  if (mrow) {  // merged taps: 0 .. the first -1 (uniform)
+    dt_lo = 0;
+    dt_hi = 0;
+    while (dt_hi < a.ktm && mrow[dt_hi] >= 0) ++dt_hi;
+  }
 
   constexpr int NPL = PL ? 2 : 1;
   i32x4 rp[NPL][PU], rb[NPL][BU];
   auto gload = [&](int dt) {
     const int fr = b * a.T + t0 + dt;
-    const unsigned fbase = (unsigned)(((a.fidx ? a.fidx[fr] : fr) * a.H) * a.PW) * 16u;
+    const unsigned fbase = (unsigned)(((mrow ? mrow[dt] : (a.fidx ? a.fidx[fr] : fr)) * a.H) * a.PW) * 16u;
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
       const unsigned off = poff[u] == kOob ? kOob : fbase + poff[u];
@@ -228,7 +242,8 @@ __global__ __launch_bounds__(POOL ? 512 : 256, POOL ? 4 : (PL ? 2 : 3)) void ste
     if (!POOL && dt + 1 < dt_hi) gload(dt + 1);  // in flight under this frame's MFMAs
     bool act[NT];  // uniform
 #pragma unroll
-    for (int n = 0; n < NT; ++n) act[n] = POOL || PL == 0 || !a.fm_kt0 || (dt >= 2 * n && dt <= 2 * n + a.fm_kt0);
+    for (int n = 0; n < NT; ++n)
+      act[n] = mrow ? ((a.mact[to * a.ktm + dt] >> n) & 1) != 0 : (POOL || PL == 0 || !a.fm_kt0 || (dt >= 2 * n && dt <= 2 * n + a.fm_kt0));
 #pragma unroll
     for (int dh = 0; dh < 7; ++dh) {
       i32x4 bf[NT], bfl[NT];
@@ -445,6 +460,8 @@ int fill(StemArgs& a, const char* what, const void* in, const void* wt, const fl
   a.out_f32 = 0;
   a.fm_kt0 = 0;
   a.fidx = nullptr;
+  a.mtab = a.mact = nullptr;
+  a.ktm = 0;
   AVT_REQUIRE(a.To > 0, "%s: no output frames", what);
   const int64_t in_b = (int64_t)batch * t * h * pw * 16, wt_b = (int64_t)cout * kt * KF * 2;
   AVT_REQUIRE(in_b < (1ll << 32) - 64 && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
@@ -523,6 +540,38 @@ extern "C" int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void
   if (plane_dtype == AVT_X3_F16)
     return pw == 112 ? launch<7, false, 2>(a, batch, s, "avt_stem_conv_x3") : launch<2, false, 2>(a, batch, s, "avt_stem_conv_x3");
   return pw == 112 ? launch<7, false, 1>(a, batch, s, "avt_stem_conv_x3") : launch<2, false, 1>(a, batch, s, "avt_stem_conv_x3");
+}
+
+// the time-grouped fast stem over a frame table with the taps of one source frame merged (see StemArgs::mtab, include/avt.h)
+extern "C" int avt_stem_conv_x3_merged(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
+                                       const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
+                                       int kt, int st, int pt, int relu, int plane_dtype, const int32_t* tap_frames,
+                                       const int32_t* tap_tiles, int ktm, int n_table_frames, void* stream) {
+  StemArgs a;
+  int rc = fill(a, "avt_stem_conv_x3_merged", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu);
+  if (rc) return rc;
+  rc = fm_arg(a, "avt_stem_conv_x3_merged", 2, cout, kt, st);  // the frame-major 4-frame x 8-channel form only
+  if (rc) return rc;
+  AVT_REQUIRE(tap_frames && tap_tiles && ktm > 0 && ktm <= kt, "avt_stem_conv_x3_merged: tap tables / 0 < ktm <= kt");
+  AVT_REQUIRE(n_table_frames > 0 && (int64_t)n_table_frames * h * pw * 16 < (1ll << 32) - 64,
+              "avt_stem_conv_x3_merged: frame table of %d frames is empty or too large for 32-bit offsets", n_table_frames);
+  AVT_REQUIRE(in_lo && wt_lo && out_lo && avt::aligned16(in_lo) && avt::aligned16(wt_lo) && avt::aligned16(out_lo) &&
+                  (!wscale || avt::aligned16(wscale)),
+              "avt_stem_conv_x3_merged: every tensor needs both planes, 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_stem_conv_x3_merged: bad plane_dtype");
+  a.in_bytes = (unsigned)((int64_t)n_table_frames * h * pw * 16);
+  a.wt_bytes = (unsigned)((int64_t)cout * a.To * ktm * KF * 2);  // the merged image: [cout / 32][To * ktm] slabs
+  a.mtab = tap_frames;
+  a.mact = tap_tiles;
+  a.ktm = ktm;
+  a.in_lo = static_cast<const uint16_t*>(in_lo);
+  a.wt_lo = static_cast<const uint16_t*>(wt_lo);
+  a.out_lo = static_cast<uint16_t*>(out_lo);
+  a.wscale = wscale;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plane_dtype == AVT_X3_F16)
+    return pw == 112 ? launch<7, false, 2>(a, batch, s, "avt_stem_conv_x3_merged") : launch<2, false, 2>(a, batch, s, "avt_stem_conv_x3_merged");
+  return pw == 112 ? launch<7, false, 1>(a, batch, s, "avt_stem_conv_x3_merged") : launch<2, false, 1>(a, batch, s, "avt_stem_conv_x3_merged");
 }
 
 // the training forward (train_ops._StemX3): fp32 NDHWC out, no bias, no ReLU (BatchNorm follows in train mode); see include/avt.h

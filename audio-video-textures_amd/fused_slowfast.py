@@ -43,6 +43,7 @@ _STEM_LDS = 1        # both: the stems on the patch-resident kernel (csrc/stem_c
 _STEM_POOL = 1       # bf16: max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both (the MFMA-bound fast
 #                      stem loses 4 % to the recomputed ninth row).  The split-plane pooled stem was built in round 3, measured
 #                      slower than stem + pool (1.74 ms against 1.01 + 0.72 ms, profiles/r03/probe_stem_pool_x3.log) and removed
+_STEM_MERGE = 1      # contract grade, frame tables: the fast stem's frame taps that read one source frame are summed on the host
 _KW1_CAP = 32        # pixel grouping of temporal-tap layers stops at this output width (profiles/r01/probe_layers.log)
 
 # Optional launch observer for bench.py: PROFILER(name, launch_fn, flops, bytes) must call launch_fn().
@@ -335,6 +336,52 @@ def stem_lds_image(wt, kt, frame_major=False):
     return w.permute(0, 4, 5, 2, 6, 1, 3, 7).contiguous().reshape(cout // 32, -1)
 
 
+def merged_stem_taps(conv, win_len, device):
+    """The time-grouped fast stem for clips whose 32 slots are sampled from a `win_len`-frame window (linspace(0, W-1, 32)
+    .long(): W < 32 repeats frames).  Output-frame group `to` (frames 4 to .. 4 to + 3) meets slots 4 to - 2 .. 4 to + 5; the
+    slots that read ONE source frame have their weight slabs summed (a convolution is linear in its weights), so the group
+    walks its DISTINCT source frames only — 5 instead of 8 at W = 20: the MFMAs and the patch staging of the other taps are
+    never issued.  -> dict(wt_hi, wt_lo: frame-major LDS images over To * ktm slabs; bias, wscale; src int32 [To, ktm] source-
+    frame offset from the window start (-1 = no tap); tiles int32 [To * ktm] tile bit mask; ktm) or None without duplicates."""
+    hit = conv._merged.get(win_len)
+    if hit is not None or win_len in conv._merged:
+        return hit
+    wg, bias = conv.wg                      # [g, c, kt_g, 7, 4, 2, 4], [c]
+    g, c, kt_g = wg.shape[0], wg.shape[1], wg.shape[2]
+    fast_off, _ = ops.clip_sample_table(win_len)
+    n_slots, pt = len(fast_off), conv.pad[0]
+    n_grp = (n_slots + 2 * pt - kt_g) // g + 1
+    groups = []
+    for to in range(n_grp):
+        by_src = {}
+        for dt in range(kt_g):
+            k = g * to - pt + dt
+            if 0 <= k < n_slots:
+                by_src.setdefault(int(fast_off[k]), []).append(dt)
+        groups.append(sorted(by_src.items()))
+    ktm = max(len(x) for x in groups)
+    if ktm >= kt_g:  # every slot of some group is its own frame: nothing to merge
+        conv._merged[win_len] = None
+        return None
+    kt0 = kt_g - g + 1                       # tile n (output frames 2n, 2n + 1) meets taps 2n .. 2n + kt0 of the unmerged image
+    wflat = wg.reshape(g * c, kt_g, -1)
+    wm = torch.zeros((g * c, n_grp * ktm, wflat.shape[2]))
+    src = torch.full((n_grp, ktm), -1, dtype=torch.int32)
+    tiles = torch.zeros((n_grp * ktm,), dtype=torch.int32)
+    for to, items in enumerate(groups):
+        for j, (off, dts) in enumerate(items):
+            wm[:, to * ktm + j] = sum(wflat[:, dt] for dt in dts)
+            src[to, j] = off
+            tiles[to * ktm + j] = sum(1 << n for n in range(2) if any(2 * n <= dt <= 2 * n + kt0 for dt in dts))
+    m = FusedConv(None, None, True, device,
+                  packed=(wm.reshape(g * c, -1), bias.repeat(g), 8, (n_grp * ktm, conv.kernel[1], 4), conv.stride, conv.pad, (0, 0, 1)),
+                  x3=conv.x3)
+    out = {"wt_hi": stem_lds_image(m.wt, n_grp * ktm, True), "wt_lo": stem_lds_image(m.wt_lo, n_grp * ktm, True), "bias": m.bias,
+           "wscale": m.wscale, "src": src.to(device), "tiles": tiles.to(device), "ktm": ktm, "groups": n_grp}
+    conv._merged[win_len] = out
+    return out
+
+
 def stem_conv(stem, device, tgroup=1, x3=None):
     """Stem Conv3d(3, C, [kt,7,7], stride [1,2,2], pad [kt//2,3,3]) + BN + ReLU in pixel-pair form (see module doc).
 
@@ -366,6 +413,7 @@ def stem_conv(stem, device, tgroup=1, x3=None):
         fm = conv.frames_per_tile > 0
         conv.wt_lds = stem_lds_image(conv.wt, kt + g - 1, fm) if conv.cout % 32 == 0 else None
         conv.wt_lds_lo = stem_lds_image(conv.wt_lo, kt + g - 1, fm) if conv.cout % 32 == 0 and x3 is not None else None
+        conv.wg, conv._merged = (wg, bias) if fm else None, {}  # (fp32 block-Toeplitz weights: merged_stem_taps sums their taps)
         return conv
     conv = FusedConv(None, None, True, device,
                      packed=(wp.reshape(c, -1), bias, 8, (kt, kh, 4), (1, 2, 1), (kt // 2, 3, 2), (0, 0, 1)), x3=x3)
@@ -984,7 +1032,30 @@ class SlowFastMFMA(nn.Module):
         sb, st_ = (nf, 1) if per_frame else (b, t)
         x = Act(clip.hi.view(nf * h * (w // 2), 8), (sb, st_, h, w // 2), lo=clip.lo.view(nf * h * (w // 2), 8))
         pool_idx = clip.idx.reshape(-1) if per_frame else None
-        if lds_path:
+        merged = None
+        if (table and lds_path and _STEM_MERGE and conv.frames_per_tile == 2 and getattr(conv, "wg", None) is not None and
+                clip.start is not None and t == 32):
+            merged = merged_stem_taps(conv, clip.win_len, self.dev)
+        if merged is not None:
+            # the fast stem on a frame table, the frame taps of one source frame summed into one (5 patches and weight slabs per
+            # output-frame group instead of 8 at W = 20)
+            od = conv.out_dims(x.dims)
+            m_out = od[0] * od[1] * od[2] * od[3]
+            y = new_act(m_out, conv.cout, od, self.dev, True)
+            src = merged["src"]
+            taps = torch.where(src.unsqueeze(0) >= 0, clip.start.view(-1, 1, 1) + src.unsqueeze(0), src.unsqueeze(0)).contiguous()
+
+            def launch():
+                ops.stem_conv_x3_merged(x.ptrs, merged["wt_hi"], merged["wt_lo"], merged["bias"], merged["wscale"], y.ptrs, b, t, h,
+                                        w // 2, conv.cout, conv.kernel[0], conv.stride[0], conv.pad[0], self.x3, taps,
+                                        merged["tiles"], merged["ktm"], nf, relu=True)
+
+            if PROFILER is None:
+                launch()
+            else:
+                PROFILER("stem_kernel<x3>", launch, m_out * conv.alg_flops_per_row,
+                         4.0 * (x.buf.numel() + m_out * conv.cout) + conv.wt.numel() * 4)
+        elif lds_path:
             # production shape: the patch-resident stem kernel in its plane-pair form (no im2col gather)
             od = conv.out_dims(x.dims)
             m_out = od[0] * od[1] * od[2] * od[3]

@@ -91,8 +91,10 @@ class FrameClip:
     166 windows at W = 20, S = 4.  Quacks like SplitClip ([n, T, hw, hw, 4]); the patch-resident stem kernel reads it through the
     index (avt_stem_conv_x3 frame_idx), anything else asks for .dense()."""
 
-    def __init__(self, hi, lo, idx, plane_dtype):
+    def __init__(self, hi, lo, idx, plane_dtype, start=None, win_len=None):
         self.hi, self.lo, self.idx, self.plane_dtype = hi, lo, idx, plane_dtype
+        # when the index is a regular sampling of windows (clip_pack_frames): clip i = table frames start[i] + sample_table(win_len)
+        self.start, self.win_len = start, win_len
 
     @property
     def shape(self):
@@ -103,11 +105,13 @@ class FrameClip:
         return int(self.hi.shape[0])
 
     def chunk(self, parts):
-        return [FrameClip(self.hi, self.lo, i.contiguous(), self.plane_dtype) for i in self.idx.chunk(parts)]
+        starts = self.start.chunk(parts) if self.start is not None else [None] * parts
+        return [FrameClip(self.hi, self.lo, i.contiguous(), self.plane_dtype, s, self.win_len) for i, s in zip(self.idx.chunk(parts), starts)]
 
     def record_stream(self, st):
-        for t_ in (self.hi, self.lo, self.idx):
-            t_.record_stream(st)
+        for t_ in (self.hi, self.lo, self.idx, self.start):
+            if t_ is not None:
+                t_.record_stream(st)
 
     def dense(self):
         """-> the SplitClip [n, T, hw, hw, 4] this table stands for (a gather: shapes the table kernels do not cover)."""
@@ -190,8 +194,9 @@ def clip_pack_frames(frames_u8, win_start, win_len, out_hw=224, mean=0.45, std=0
     fast_off, slow_off = clip_sample_table(win_len)
     idx_f = torch.from_numpy((win_start[:, None] + fast_off[None, :]).astype(np.int32)).to(dev, non_blocking=True)
     idx_s = torch.from_numpy((win_start[:, None] + slow_off[None, :]).astype(np.int32)).to(dev, non_blocking=True)
+    start = torch.from_numpy(win_start.astype(np.int32)).to(dev, non_blocking=True)
     hi, lo = hi[:n_frames], lo[:n_frames]
-    return FrameClip(hi, lo, idx_s, pd), FrameClip(hi, lo, idx_f, pd)
+    return FrameClip(hi, lo, idx_s, pd, start, int(win_len)), FrameClip(hi, lo, idx_f, pd, start, int(win_len))
 
 
 def clip_pack_gather(frames_u8, win_start_dev, win_len, out_hw=224, mean=0.45, std=0.225, bgr=True, dtype=torch.float32):
@@ -483,6 +488,20 @@ def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, 
                                            int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(bool(relu)),
                                            int(plane_dtype), int(frames_per_tile), _p(frame_idx), int(table_frames), _stream()),
                "avt_stem_conv_x3")
+
+
+def stem_conv_x3_merged(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, tap_frames,
+                        tap_tiles, ktm, table_frames, relu=True):
+    """The time-grouped fast stem over a frame table with the taps of one source frame merged (include/avt.h)."""
+    _dev(wt_hi, "wt_hi", torch.bfloat16)
+    _dev(wt_lo, "wt_lo", torch.bfloat16)
+    _dev(tap_frames, "tap_frames", torch.int32)
+    _dev(tap_tiles, "tap_tiles", torch.int32)
+    _lib.check(_lib.lib().avt_stem_conv_x3_merged(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), _p(wt_hi), _p(wt_lo), _p(bias),
+                                                  _p(wscale), C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]), int(batch), int(t),
+                                                  int(h), int(pw), int(cout), int(kt), int(st), int(pt), int(bool(relu)),
+                                                  int(plane_dtype), _p(tap_frames), _p(tap_tiles), int(ktm), int(table_frames),
+                                                  _stream()), "avt_stem_conv_x3_merged")
 
 
 def clip_planes_f32(x, plane_dtype):

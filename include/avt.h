@@ -412,6 +412,19 @@ int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void* wt_hi, co
                      const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
                      int kt, int st, int pt, int relu, int plane_dtype, int frames_per_tile, const int32_t* frame_idx,
                      int n_table_frames, void* stream);
+/* The time-grouped fast stem (st = 4 output frames x 8 channels, frame-major tiles) over a frame TABLE with the taps of one
+ * source frame MERGED (round 4).  The fast pathway samples its 32 slots with linspace(0, W-1, 32).long() (reference:
+ * models/models.py:365 via process_cv2_inputs): for W = 20 the 8 slots an output-frame group meets are only ~5 distinct frames.
+ * A convolution is linear in its weights, so the caller sums the taps that read one source frame (fused_slowfast.
+ * merged_stem_taps) and packs, per group `to` (To of them) and merged tap j < ktm, one weight slab: wt_* is the frame-major LDS
+ * image over To * ktm slabs.  tap_frames int32 [batch * To * ktm] (device): table frame of (clip, group, tap), -1 ends a group's
+ * list; tap_tiles int32 [To * ktm]: bit n set = tile n (output frames 2n, 2n + 1) has non-zero weights in that slab.  t, kt, st,
+ * pt describe the unmerged geometry (To = (t + 2 pt - kt) / st + 1).  Same function as avt_stem_conv_x3 up to the rounding of
+ * the summed weights (2^-22 relative per product). */
+int avt_stem_conv_x3_merged(const void* in_hi, const void* in_lo, const void* wt_hi, const void* wt_lo, const float* bias,
+                            const float* wscale, void* out_hi, void* out_lo, int batch, int t, int h, int pw, int cout,
+                            int kt, int st, int pt, int relu, int plane_dtype, const int32_t* tap_frames,
+                            const int32_t* tap_tiles, int ktm, int n_table_frames, void* stream);
 /* avt_clip_pack_u8_ndhwc4 writing (hi, lo) planes: slow_* [n,8,hw,hw,4], fast_* [n,32,hw,hw,4]. */
 int avt_clip_pack_u8_ndhwc4_x3(const uint8_t* frames, int n_frames, int height, int width,
                                const int32_t* dst_off, const int32_t* dst_slot, int n_win, int out_hw,

@@ -5,9 +5,9 @@
 #   3. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE    -> pmc_fetch_write_summary.json (separate passes, kernel-trace only,
 #      over tools/pmc_kernels.py: every hand-written kernel at the bench shapes; FETCH_SIZE is doubled by the READER
 #      (bench.py attach_pmc_traffic) as MI355X_MICROARCH.md prescribes for gfx950)
-# usage: bash tools/gpu_profile_round.sh r03   -> gpurun_out/profile_r02/
+# usage: bash tools/gpu_profile_round.sh r04   -> gpurun_out/profile_r04/
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd $R

@@ -39,7 +39,7 @@ for _ in range(2):
 # ... and one forward of each contract-grade mode (split-plane kernels: conv_x3_kernel, the plane-pair pool / mean / pack)
 for mode in ("f16x3", "bf16x3"):
     encx = SlowFastMFMA(SlowFast(), dev, precision=mode)
-    sx, fx = ops.clip_pack(video, starts, W, out_hw=224, layout="ndhwc4", planes=mode)
+    sx, fx = ops.clip_pack_frames(video, starts, W, out_hw=224, planes=mode)  # the product's form: a frame table + the windows' index
     for _ in range(2):
         encx.forward_ndhwc4(sx, fx)
 torch.cuda.synchronize()

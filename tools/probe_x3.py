@@ -75,6 +75,18 @@ def spy_stem(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout
                      frame_idx, table_frames)
 
 
+orig_stem_m = ops.stem_conv_x3_merged
+
+
+def spy_stem_m(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, tap_frames, tap_tiles, ktm,
+               table_frames, relu=True):
+    shapes.append("stem (LDS patch) cout%d kt%d st%d in(%d, %d, %d, %d) frame-major via a table of %d frames, %d merged taps per group" % (
+        cout, kt, st, batch, t, h, pw, table_frames, ktm))
+    return orig_stem_m(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, tap_frames, tap_tiles,
+                       ktm, table_frames, relu)
+
+
+ops.stem_conv_x3_merged = spy_stem_m
 pool_recs = []
 orig_pool = ops.maxpool_hw3s2_x3
 
