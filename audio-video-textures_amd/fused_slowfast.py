@@ -43,6 +43,9 @@ _STEM_LDS = 1        # both: the stems on the patch-resident kernel (csrc/stem_c
 _STEM_POOL = 1       # bf16: max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both (the MFMA-bound fast
 #                      stem loses 4 % to the recomputed ninth row).  The split-plane pooled stem was built in round 3, measured
 #                      slower than stem + pool (1.74 ms against 1.01 + 0.72 ms, profiles/r03/probe_stem_pool_x3.log) and removed
+# (cin, cout) of pointwise layers that run FASTER on the general 128 x 128 tile than on pw_x3: wide-K, 128-output layers without
+# a residual (slow res3's a convs: 2.02 -> 1.80 ms and 1.79 -> 1.69 ms per 166 clips; every other pointwise layer is slower there)
+_PW_X3_SKIP = {(512, 128), (320, 128)}
 _STEM_MERGE = 1      # contract grade, frame tables: the fast stem's frame taps that read one source frame are summed on the host
 _KW1_CAP = 32        # pixel grouping of temporal-tap layers stops at this output width (profiles/r01/probe_layers.log)
 
@@ -199,7 +202,8 @@ class FusedConv:
             # pointwise stride-1 layers: the streaming kernel (csrc/pw_x3.hip) with LDS-resident weight fragments
             self.pw = None
             if (_PW_X3 and relu != 2 and self.kernel == (1, 1, 1) and self.stride == (1, 1, 1) and self.pad == (0, 0, 0) and
-                    not any(self.crop) and cout % 32 == 0 and ops.pw_x3_supported(self.cin, cout)):
+                    not any(self.crop) and cout % 32 == 0 and ops.pw_x3_supported(self.cin, cout) and
+                    (self.cin, cout) not in _PW_X3_SKIP):
                 self.pw = (pack_pw_planes(hi).to(device), pack_pw_planes(lo).to(device))
         else:
             self.wt = wt.to(torch.bfloat16).contiguous().to(device)
