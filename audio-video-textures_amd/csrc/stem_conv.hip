@@ -430,7 +430,7 @@ int launch(const StemArgs& a, int batch, hipStream_t st, const char* what) {
 }
 
 int fill(StemArgs& a, const char* what, const void* in, const void* wt, const float* bias, void* out, int batch, int t,
-         int h, int pw, int cout, int kt, int st, int pt, int relu) {
+         int h, int pw, int cout, int kt, int st, int pt, int relu, bool dense_input = true) {
   AVT_REQUIRE(in && wt && out, "%s: NULL pointer", what);
   AVT_REQUIRE(batch > 0 && t > 0 && kt > 0 && st > 0 && pt >= 0 && pt < kt, "%s: bad sizes", what);
   AVT_REQUIRE(avt_stem_conv_supported(h, pw, cout),
@@ -464,9 +464,10 @@ int fill(StemArgs& a, const char* what, const void* in, const void* wt, const fl
   a.ktm = 0;
   AVT_REQUIRE(a.To > 0, "%s: no output frames", what);
   const int64_t in_b = (int64_t)batch * t * h * pw * 16, wt_b = (int64_t)cout * kt * KF * 2;
-  AVT_REQUIRE(in_b < (1ll << 32) - 64 && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
+  // (dense_input = false: `in` is a frame table whose own size the caller checks — the clips it stands for may exceed 4 GB)
+  AVT_REQUIRE((!dense_input || in_b < (1ll << 32) - 64) && wt_b < (1ll << 31) && (int64_t)batch * a.To * a.Ho * pw < (1ll << 31),
               "%s: tensor too large for 32-bit offsets", what);
-  a.in_bytes = (unsigned)in_b;
+  a.in_bytes = dense_input ? (unsigned)in_b : 0u;
   a.wt_bytes = (unsigned)wt_b;
   return AVT_OK;
 }
@@ -517,7 +518,7 @@ extern "C" int avt_stem_conv_x3(const void* in_hi, const void* in_lo, const void
                                 int st, int pt, int relu, int plane_dtype, int frames_per_tile, const int32_t* frame_idx,
                                 int n_table_frames, void* stream) {
   StemArgs a;
-  int rc = fill(a, "avt_stem_conv_x3", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu);
+  int rc = fill(a, "avt_stem_conv_x3", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu, frame_idx == nullptr);
   if (rc) return rc;
   if (frame_idx) {  // the input is a table of distinct frames (entries of frame_idx must lie in [0, n_table_frames): the
     // buffer descriptor's range check turns an index beyond it into zeros, never into a fault)
@@ -548,7 +549,7 @@ extern "C" int avt_stem_conv_x3_merged(const void* in_hi, const void* in_lo, con
                                        int kt, int st, int pt, int relu, int plane_dtype, const int32_t* tap_frames,
                                        const int32_t* tap_tiles, int ktm, int n_table_frames, void* stream) {
   StemArgs a;
-  int rc = fill(a, "avt_stem_conv_x3_merged", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu);
+  int rc = fill(a, "avt_stem_conv_x3_merged", in_hi, wt_hi, bias, out_hi, batch, t, h, pw, cout, kt, st, pt, relu, false);
   if (rc) return rc;
   rc = fm_arg(a, "avt_stem_conv_x3_merged", 2, cout, kt, st);  // the frame-major 4-frame x 8-channel form only
   if (rc) return rc;

@@ -97,9 +97,9 @@ def build_parser():
       help="similarity arithmetic of the SHARDED aligned build (world > 1): f32 = exact, bit-identical to one GPU (all-gathers "
            "fp32 rows); bf16x3 = bf16 hi/lo planes through the MFMA bf16 pipe (all-gathers the planes, scores within 5e-6); "
            "bf16 = one plane (outside the 1e-3 score contract)")
-    a("--enc_batch", default=166, type=int,
-      help="windows per encoder batch (83 k: whole rounds of the 256 x 256 tile on the 256 CUs; 166 measured +2 %% over 83; "
-           "~25 GB of activations at 224^2)")
+    a("--enc_batch", default=249, type=int,
+      help="windows per encoder batch (83 k: whole rounds of the 256 x 256 tile on the 256 CUs; 166 measured +2 %% over 83, "
+           "249 +1.3-2 %% more and is the largest the kernels' 32-bit byte offsets allow; ~37 GB of activations at 224^2)")
     a("--enc_impl", default="auto", choices=["auto", "mfma", "module"],
       help="SlowFast at -e: hand-written MFMA convolutions (auto/mfma) or the nn.Module on MIOpen (module)")
     a("--dump_png", default=False, action="store_true",

@@ -97,6 +97,10 @@ class TextureEngine:
         self.planes = getattr(q_encoder, "planes", None) if self.layout == "ndhwc4" else None
         if self.layout == "ndhwc4" and getattr(t_encoder, "planes", None) != self.planes:
             raise AvtError("q and t encoders must use the same precision mode (they share the packed clips)")
+        if self.layout == "ndhwc4" and self.planes is None and self.hw >= 224:
+            # bf16 MFMA encoders read DENSE packed clips and keep wider concat buffers: 166 clips is what their kernels' 32-bit
+            # offsets take at 224^2 (the contract-grade path reads a frame table and goes to 249)
+            self.enc_batch = min(self.enc_batch, 166)
         self.frames = None
         self.A = self.A_da = self.Ad = None
         self._cache = {"q": {}, "t": {}}

@@ -233,7 +233,7 @@ def validate(model, args, video_name="", epoch=None, tb_logger=None, model_type=
     eng = texture.TextureEngine(q_enc, t_enc, a_enc,
                                 window=W, stride=S, temp=net.temp, img_size=args.img_size,
                                 model_type=net.model_type, device=dev,
-                                enc_batch=getattr(args, "enc_batch", 166),
+                                enc_batch=getattr(args, "enc_batch", 249),
                                 enc_arch=getattr(args, "enc_arch", "slowfast"))
     assert eng.set_video(input_video) == L
     validate.last_engine = eng  # (handle for tests / probes: the resident tables of the last run)

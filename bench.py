@@ -126,6 +126,7 @@ def run_mode(args, precision, video, q_mod, t_mod, rank, world, dev):
         q_enc, t_enc = prepare_encoder(copy.deepcopy(q_mod), dev, dt), prepare_encoder(copy.deepcopy(t_mod), dev, dt)
     eng = TextureEngine(q_enc, t_enc, None, window=W, stride=S, temp=temp, img_size=224, model_type=1, device=dev,
                         enc_batch=args.enc_batch)
+    enc_batch = eng.enc_batch  # (the bf16 leg's dense clips cap it at 166)
     n_streams = args.streams or (2 if precision == "bf16" else 1)
     assert eng.set_video(video) == N
     starts = np.arange(N, dtype=np.int64) * S
@@ -140,8 +141,8 @@ def run_mode(args, precision, video, q_mod, t_mod, rank, world, dev):
     def step():
         outs = [[], []]
         with torch.no_grad():
-            for i in range(0, N, args.enc_batch):
-                st = starts[i : i + args.enc_batch]
+            for i in range(0, N, enc_batch):
+                st = starts[i : i + enc_batch]
                 lo, hi = int(st.min()), int(st.max()) + W
                 if eng.planes is not None and eng.layout == "ndhwc4" and texture_mod.FRAME_TABLE:
                     # contract-grade leg: every distinct frame packed once (ops.FrameClip: a frame table + the windows' index)
@@ -161,7 +162,7 @@ def run_mode(args, precision, video, q_mod, t_mod, rank, world, dev):
                                       n_el * (esz if eng.layout == "ndhwc4" else slow.element_size()))
                 # every 8th batch runs on ONE stream with per-launch HIP events around the convolutions (the events
                 # must sit on the launching stream); all other batches run q and t encoders on two streams
-                timer.sample_conv = (i // args.enc_batch) % 8 == 0
+                timer.sample_conv = (i // enc_batch) % 8 == 0
                 eng.n_streams = 1 if (timer.on and timer.sample_conv) else n_streams
                 if eng.n_streams == 1:
                     eng.join_streams()  # the sampled batch is timed alone on the device
@@ -211,7 +212,7 @@ def run_mode(args, precision, video, q_mod, t_mod, rank, world, dev):
 
     rows = timer.rows()
     kern = []
-    batches = -(-N // args.enc_batch)
+    batches = -(-N // enc_batch)
     sampled_batches = len(range(0, batches, 8)) * args.steps
     enc_peak = ENC_PEAK_TFLOPS.get(precision, 2500.0)
 
@@ -575,7 +576,7 @@ def build_parser():
     ap.add_argument("--no-fast", action="store_true", help="skip the second timed leg (bf16 fast mode)")
     ap.add_argument("--encoder", default="mfma", choices=["mfma", "miopen"],
                     help="mfma: hand-written implicit-GEMM convolutions (fused_slowfast); miopen: stock nn.Module")
-    ap.add_argument("--enc-batch", type=int, default=166, help="clips per encoder launch (83 k: whole rounds of the 256 x 256 tile on 256 CUs; 166: +2 %% over 83, 249: +1 %% more but within 7 %% of the 32-bit element limit)")
+    ap.add_argument("--enc-batch", type=int, default=249, help="clips per encoder launch (83 k: whole rounds of the 256 x 256 tile on 256 CUs; 166: +2 %% over 83, 249: +1.3-2 %% more — the largest: the slow res2 concat buffer is 4.0 GB of the kernels' 32-bit byte offsets there)")
     ap.add_argument("--sim-precision", default="f32", choices=["f32", "bf16x3", "bf16"], help="similarity MFMA mode")
     ap.add_argument("--threshold", type=float, default=0.3)
     ap.add_argument("--frame-hw", type=int, default=128)
@@ -794,8 +795,8 @@ def baseline_metric():
 # the encoder streams run their batches back to back and are joined once per step (texture.TextureEngine.run_encoders(join=False))
 JOIN_EVERY_BATCH = False
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "pmc_fetch_write_summary.json")  # written by tools/gpu_profile_round.sh r03
-PMC_BATCH = 166  # the encoder batch tools/pmc_kernels.py launches at
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "pmc_fetch_write_summary.json")  # written by tools/gpu_profile_round.sh r04
+PMC_BATCH = 249  # the encoder batch tools/pmc_kernels.py launches at
 
 
 def attach_pmc_traffic(kern, args, precision):
@@ -840,7 +841,7 @@ def attach_pmc_traffic(kern, args, precision):
         sym = sym.replace(",bf16>", ",false>").replace(",f16>", ",true>").replace(" ", "")
         k["traffic"] = kb(sym)
         if k["traffic"]:
-            k["traffic_source"] = "profiles/r03/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
+            k["traffic_source"] = "profiles/r04/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
 
 
 def cpu_baseline(video, q_mod, t_mod, W, S, N, D, temp, args):

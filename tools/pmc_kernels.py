@@ -10,16 +10,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import avtex
 from avtex import ops
 dev = torch.device("cuda:0")
-N, D, W, S, B = 4096, 2304, 20, 4, 166  # B = bench.py's --enc-batch default
+N, D, W, S, B = 4096, 2304, 20, 4, 249  # B = bench.py's --enc-batch default
 g = torch.Generator().manual_seed(123)
 video = torch.randint(0, 256, (B * S + W, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
 starts = np.arange(B, dtype=np.int64) * S
 q = torch.randn((N, D), generator=torch.Generator().manual_seed(0)).to(dev)
 t = torch.randn((N, D), generator=torch.Generator().manual_seed(1)).to(dev)
 q_ids = torch.arange(N, device=dev, dtype=torch.int64)
+BD = 166  # dense packed clips (the bf16 path, the module path): what their kernels' 32-bit offsets take
 for _ in range(3):
-    ops.clip_pack(video, starts, W, out_hw=224, dtype=torch.bfloat16, layout="ndhwc4")
-    ops.clip_pack(video, starts, W, out_hw=224, dtype=torch.bfloat16, layout="ncthw")
+    ops.clip_pack(video, starts[:BD], W, out_hw=224, dtype=torch.bfloat16, layout="ndhwc4")
+    ops.clip_pack(video, starts[:BD], W, out_hw=224, dtype=torch.bfloat16, layout="ncthw")
     qn, _, _ = ops.l2norm_rows(q)  # (as bench.py's default f32 similarity mode calls it: fp32 rows only)
     tn, _, _ = ops.l2norm_rows(t)
     sim = ops.sim_gemm_nt(qn, tn, 0.1, "f32")
@@ -33,9 +34,10 @@ from avtex.slowfast import SlowFast
 from avtex.fused_slowfast import SlowFastMFMA
 torch.manual_seed(0)
 enc = SlowFastMFMA(SlowFast(), dev)
-slow, fast = ops.clip_pack(video, starts, W, out_hw=224, dtype=torch.bfloat16, layout="ndhwc4")
+slow, fast = ops.clip_pack(video, starts[:BD], W, out_hw=224, dtype=torch.bfloat16, layout="ndhwc4")
 for _ in range(2):
     enc.forward_ndhwc4(slow, fast)
+del slow, fast
 # ... and one forward of each contract-grade mode (split-plane kernels: conv_x3_kernel, the plane-pair pool / mean / pack)
 for mode in ("f16x3", "bf16x3"):
     encx = SlowFastMFMA(SlowFast(), dev, precision=mode)
