@@ -75,6 +75,8 @@ SIGNATURES = {
     "avt_clip_pack_gather_u8": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                 C.c_int, _vp, _vp, C.c_int, _vp],
     "avt_stem_conv_x3": [_vp] * 8 + [C.c_int] * 11 + [_vp, C.c_int, _vp],
+    "avt_lateral_x3_supported": [C.c_int] * 3,
+    "avt_lateral_x3": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 10 + [_vp],
     "avt_stem_conv_x3_merged": [_vp] * 8 + [C.c_int] * 10 + [_vp, _vp, C.c_int, C.c_int, _vp],
     "avt_clip_planes_f32": [_vp] + [C.c_int] * 4 + [C.c_int64] * 5 + [_vp, _vp, C.c_int, _vp],
     "avt_stem_conv_x3_f32": [_vp] * 6 + [C.c_int] * 11 + [_vp],

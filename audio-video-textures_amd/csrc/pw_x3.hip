@@ -39,6 +39,13 @@ struct PxArgs {
   const float* wscale; // [N] or NULL
   int M, ldx, ldr, ldy, k1c, ntiles, relu;
   int n_chunks, n_rg;  // channel chunks per row group, row groups (grid = 8-aligned n_rg * n_chunks)
+  // temporal-tap form (avt_lateral_x3, round 4): the layer is Conv3d [taps,1,1] with temporal stride tst and padding tpad — the
+  // lateral fast -> slow connections ([7,1,1] stride 4).  Output row p = ((b * To + to) * HW + pos); its K axis is tap-major
+  // (k = dt * Cin + c, the convolution's own weight order), so 8-channel chunk ch of the operand is channels 8 (ch % cin8) .. + 7
+  // of INPUT row ((b * T + to * tst - tpad + ch / cin8) * HW + pos): the same streaming kernel with a gathered operand — no im2col
+  // pass, no tap table; frames outside [0, T) and chunks past the last tap are zero operands.  taps = 1: plain pointwise
+  int taps, cin8, T, To, HW, tst, tpad;
+  int n_valid;  // output channels that exist (the last 16-channel tile pair may be padding: cout 16 runs as one pair)
 };
 
 template <bool F16>
@@ -95,12 +102,28 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_kernel(PxArgs a) {
     asm volatile("" : "+v"(lofs));
     const int64_t pc = ok ? p : a.M - 1;
     i32x4 xh[K1S], xl[K1S];
+    if (a.taps > 1) {  // uniform: the temporal-tap form
+      const int bto = (int)pc / a.HW, pos = (int)pc - bto * a.HW;
+      const int b = bto / a.To, to = bto - b * a.To;
+#pragma unroll
+      for (int ks = 0; ks < K1S; ++ks) {
+        const int ch = 4 * ks + q;
+        const int dt = ch / a.cin8, cc = ch - dt * a.cin8;
+        const int t_in = to * a.tst - a.tpad + dt;
+        const bool valid = dt < a.taps && (unsigned)t_in < (unsigned)a.T;
+        const int64_t o = (((int64_t)b * a.T + (valid ? t_in : 0)) * a.HW + pos) * a.ldx + cc * 8;
+        const i32x4 vh = *reinterpret_cast<const i32x4*>(a.xh + o), vl = *reinterpret_cast<const i32x4*>(a.xl + o);
+        xh[ks] = valid ? vh : i32x4{0, 0, 0, 0};
+        xl[ks] = valid ? vl : i32x4{0, 0, 0, 0};
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < K1S; ++ks) {
       int ch = 4 * ks + q;  // past the row's end the weights are zero: any finite value will do
       ch = ch < a.k1c ? ch : a.k1c - 1;
       xh[ks] = *reinterpret_cast<const i32x4*>(a.xh + pc * a.ldx + ch * 8);
       xl[ks] = *reinterpret_cast<const i32x4*>(a.xl + pc * a.ldx + ch * 8);
+    }
     }
     uint4 rfh[NT1 / 2], rfl[NT1 / 2];
     if (has_res && !PW_SKIP(4)) {
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_kernel(PxArgs a) {
       avt::split2<F16>(v[2], v[3], oh.y, ol.y);
       avt::split2<F16>(v[4], v[5], oh.z, ol.z);
       avt::split2<F16>(v[6], v[7], oh.w, ol.w);
-      if (ok && (!PW_SKIP(1) || (oh.x ^ ol.x) == 0x12345678u)) {
+      if (ok && c0 + cl < a.n_valid && (!PW_SKIP(1) || (oh.x ^ ol.x) == 0x12345678u)) {
         const int64_t o = pc * a.ldy + c0 + cl;
         *reinterpret_cast<uint4*>(a.yh + o) = oh;
         *reinterpret_cast<uint4*>(a.yl + o) = ol;
@@ -378,8 +401,10 @@ int dispatch_k(PxArgs& a, int k1s, int nt1, hipStream_t st) {
     case 3: return dispatch_nt<3, F16>(a, nt1, st);
     case 4: return dispatch_nt<4, F16>(a, nt1, st);
     case 5: return dispatch_nt<5, F16>(a, nt1, st);
+    case 7: return dispatch_nt<7, F16>(a, nt1, st);
     case 8: return dispatch_nt<8, F16>(a, nt1, st);
     case 10: return dispatch_nt<10, F16>(a, nt1, st);
+    case 14: return dispatch_nt<14, F16>(a, nt1, st);
     case 16: return dispatch_nt<16, F16>(a, nt1, st);
   }
   avt::set_error("avt_pw_x3: unsupported K (%d steps of 32)", k1s);
@@ -429,8 +454,65 @@ extern "C" int avt_pw_x3(const void* x_hi, const void* x_lo, int ldx, int k, con
   a.ntiles = (int)((m + 15) / 16);
   a.relu = relu;
   a.n_chunks = n / (16 * nt1);
+  a.taps = 1;
+  a.cin8 = a.T = a.To = a.HW = a.tst = a.tpad = 0;
+  a.n_valid = n;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return plane_dtype == AVT_X3_F16 ? dispatch_k<true>(a, k1s, nt1, st) : dispatch_k<false>(a, k1s, nt1, st);
+}
+
+// Conv3d [kt,1,1], temporal stride st, padding pt, on plane pairs: the lateral fast -> slow connections (FuseFastToSlow: [7,1,1]
+// stride 4 + BN + ReLU of the third-party SlowFast model the reference runs per clip window, models/models.py:335, 399)
+extern "C" int avt_lateral_x3_supported(int cin, int cout, int kt) {
+  const int k = kt * cin, k1s = (k + 31) / 32, n = (cout + 31) / 32 * 32;
+  if (cin % 8 || kt < 2 || !(k1s == 2 || k1s == 7 || k1s == 14)) return 0;
+  const int nt1 = pick_nt1(k1s, n);
+  return (nt1 && cout % 16 == 0 && n / (16 * nt1) <= 8) ? 1 : 0;
+}
+
+extern "C" int avt_lateral_x3(const void* x_hi, const void* x_lo, int ldx, int cin, const void* w_hi, const void* w_lo, const float* bias,
+                              const float* wscale, void* y_hi, void* y_lo, int ldy, int cout, int batch, int t, int hw, int kt, int st,
+                              int pt, int relu, int plane_dtype, void* stream) {
+  AVT_REQUIRE(x_hi && x_lo && w_hi && w_lo && y_hi && y_lo, "avt_lateral_x3: NULL pointer");
+  AVT_REQUIRE(avt_lateral_x3_supported(cin, cout, kt), "avt_lateral_x3: unsupported layer Cin=%d Cout=%d kt=%d", cin, cout, kt);
+  AVT_REQUIRE(batch > 0 && t > 0 && hw > 0 && st > 0 && pt >= 0 && pt < kt && ldx >= cin && ldy >= cout && ldx % 8 == 0 && ldy % 8 == 0,
+              "avt_lateral_x3: bad sizes / leading dimensions");
+  AVT_REQUIRE(avt::aligned16(x_hi) && avt::aligned16(x_lo) && avt::aligned16(w_hi) && avt::aligned16(w_lo) && avt::aligned16(y_hi) &&
+                  avt::aligned16(y_lo) && (!bias || avt::aligned16(bias)) && (!wscale || avt::aligned16(wscale)),
+              "avt_lateral_x3: pointers must be 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_lateral_x3: bad plane_dtype");
+  const int to = (t + 2 * pt - kt) / st + 1;
+  const int64_t m = (int64_t)batch * to * hw;
+  AVT_REQUIRE(to > 0 && m < (1ll << 31) - 16, "avt_lateral_x3: no output frames / too many rows");
+  const int k = kt * cin, k1s = (k + 31) / 32, n = (cout + 31) / 32 * 32, nt1 = pick_nt1(k1s, n);
+  PxArgs a;
+  a.xh = static_cast<const uint16_t*>(x_hi);
+  a.xl = static_cast<const uint16_t*>(x_lo);
+  a.rh = a.rl = nullptr;
+  a.yh = static_cast<uint16_t*>(y_hi);
+  a.yl = static_cast<uint16_t*>(y_lo);
+  a.wh = static_cast<const i32x4*>(w_hi);  // fused_slowfast.pack_pw_planes over the conv's own [Cout (padded to 32), kt * Cin] rows
+  a.wl = static_cast<const i32x4*>(w_lo);
+  a.bias = bias;      // [n] (padded with the weights)
+  a.wscale = wscale;
+  a.M = (int)m;
+  a.ldx = ldx;
+  a.ldr = 0;
+  a.ldy = ldy;
+  a.k1c = k / 8;
+  a.ntiles = (int)((m + 15) / 16);
+  a.relu = relu;
+  a.n_chunks = n / (16 * nt1);
+  a.taps = kt;
+  a.cin8 = cin / 8;
+  a.T = t;
+  a.To = to;
+  a.HW = hw;
+  a.tst = st;
+  a.tpad = pt;
+  a.n_valid = cout;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return plane_dtype == AVT_X3_F16 ? dispatch_k<true>(a, k1s, nt1, s) : dispatch_k<false>(a, k1s, nt1, s);
 }
 
 // (k1, n1, n2) of the chained form: the slow res2 pair 64 -> 256 (+ residual) -> 64
@@ -473,6 +555,9 @@ extern "C" int avt_pw_chain_x3(const void* x_hi, const void* x_lo, int ldx, int 
   a.relu = relu1;
   a.n_chunks = 1;
   a.n_rg = 0;
+  a.taps = 1;
+  a.cin8 = a.T = a.To = a.HW = a.tst = a.tpad = 0;
+  a.n_valid = n1;
   c.w2h = static_cast<const i32x4*>(w2_hi);
   c.w2l = static_cast<const i32x4*>(w2_lo);
   c.bias2 = bias2;

@@ -46,6 +46,10 @@ _STEM_POOL = 1       # bf16: max-pool fused into the stem kernel: 1 = the slow s
 # (cin, cout) of pointwise layers that run FASTER on the general 128 x 128 tile than on pw_x3: wide-K, 128-output layers without
 # a residual (slow res3's a convs: 2.02 -> 1.80 ms and 1.79 -> 1.69 ms per 166 clips; every other pointwise layer is slower there)
 _PW_X3_SKIP = {(512, 128), (320, 128)}
+# contract grade: (cin, cout) of the lateral [7,1,1] stride-4 connections that run on the streaming kernel's temporal-tap form
+# (avt_lateral_x3).  Measured per 166 clips: 32 -> 64 0.91 -> 0.73 ms; 64 -> 128 (two channel chunks re-read the operand) 0.48 ->
+# 0.56 and 8 -> 16 0.35 -> 0.37 are faster on the general tile; tests set _LATERAL_X3 = "all" to cover the three forms
+_LATERAL_X3 = {(32, 64)}
 _STEM_MERGE = 1      # contract grade, frame tables: the fast stem's frame taps that read one source frame are summed on the host
 _KW1_CAP = 32        # pixel grouping of temporal-tap layers stops at this output width (profiles/r01/probe_layers.log)
 
@@ -205,6 +209,15 @@ class FusedConv:
                     not any(self.crop) and cout % 32 == 0 and ops.pw_x3_supported(self.cin, cout) and
                     (self.cin, cout) not in _PW_X3_SKIP):
                 self.pw = (pack_pw_planes(hi).to(device), pack_pw_planes(lo).to(device))
+            # Conv3d [kt,1,1] with a temporal stride (the lateral fast -> slow connections): the streaming kernel's temporal-tap
+            # form — the operand gathered from the kt input frames of a position, no tap table (avt_lateral_x3, round 4)
+            self.lat = None
+            if ((_LATERAL_X3 == "all" or (self.cin, cout) in _LATERAL_X3) and relu != 2 and self.kernel[0] > 1 and self.kernel[1:] == (1, 1) and self.stride[1:] == (1, 1) and
+                    self.pad[1:] == (0, 0) and not any(self.crop) and ops.lateral_x3_supported(self.cin, cout, self.kernel[0])):
+                n_pad = -(-cout // 32) * 32
+                padr = lambda p: torch.cat([p.cpu(), torch.zeros((n_pad - cout, p.shape[1]), dtype=p.dtype)], 0) if n_pad > cout else p
+                padv = lambda v, fill: None if v is None else torch.cat([v.cpu().float(), torch.full((n_pad - cout,), fill)]).contiguous().to(device)
+                self.lat = (pack_pw_planes(padr(hi)).to(device), pack_pw_planes(padr(lo)).to(device), padv(bias, 0.0), padv(self.wscale, 1.0))
         else:
             self.wt = wt.to(torch.bfloat16).contiguous().to(device)
             if _XB and ops.conv3d_wfrag_supported(self.cin, cout, self.kernel):
@@ -225,7 +238,7 @@ class FusedConv:
         """The device kernel the dispatcher of csrc/conv_igemm.hip / conv_x3.hip picks for this layer (bench.py names its
         roofline rows by it; mirrors avt_conv3d_igemm_wfrag_bf16 / avt_conv3d_igemm_x3)."""
         if self.x3 is not None:
-            if getattr(self, "pw", None) is not None:
+            if getattr(self, "pw", None) is not None or getattr(self, "lat", None) is not None:
                 return "pw_x3_kernel<%s>" % ("f16" if self.x3 == ops.X3_F16 else "bf16")
             if ops.conv3d_igemm_x3_xl_picked(self.cout, self.wt.shape[1], m_out):
                 return "conv_x3_xl_kernel<%s>" % ("f16" if self.x3 == ops.X3_F16 else "bf16")
@@ -243,6 +256,8 @@ class FusedConv:
         """Pixel-group factor along W for few-channel layers (see group_weights_w); 1 = plain."""
         if self._folded is None or self.stride[2] != 1 or self.pad[2] != self.kernel[2] // 2:
             return 1
+        if getattr(self, "lat", None) is not None and res is None:
+            return 1  # the temporal-tap streaming kernel takes the layer as it is
         if x.ld != x.C or x.c0 or (out is not None and (out.ld != out.C or out.c0)) or \
                 (res is not None and (res.ld != res.C or res.c0)):
             return 1  # channel slices of wider rows cannot be re-viewed
@@ -308,8 +323,15 @@ class FusedConv:
                       res.ptrs if res is not None else None, res.ld if res is not None else 0, out.ptrs, out.ld, self.cout,
                       m_rows, self.relu if relu is None else relu, self.x3)
 
+        def launch_lat():
+            b_, t_, h_, w_ = x.dims
+            ops.lateral_x3(x.ptrs, x.ld, self.cin, self.lat[0], self.lat[1], self.lat[2], self.lat[3], out.ptrs, out.ld, self.cout, b_, t_,
+                           h_ * w_, self.kernel[0], self.stride[0], self.pad[0], self.relu if relu is None else relu, self.x3)
+
         def launch():
             if self.x3 is not None:
+                if getattr(self, "lat", None) is not None and out_rows is None and res is None:
+                    return launch_lat()
                 return launch_pw() if (self.pw is not None and out_rows is None) else launch_x3()
             ops.conv3d_igemm(x.ptr, self.wt, self.bias, res.ptr if res is not None else 0, out.ptr, tab, x.dims,
                              self.cin, self.cout, self.kernel, self.stride, self.pad, x.ld, out.ld,

@@ -490,6 +490,21 @@ def stem_conv_x3(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, 
                "avt_stem_conv_x3")
 
 
+def lateral_x3_supported(cin, cout, kt):
+    return bool(_lib.lib().avt_lateral_x3_supported(int(cin), int(cout), int(kt)))
+
+
+def lateral_x3(x_ptrs, ldx, cin, w_hi, w_lo, bias, wscale, y_ptrs, ldy, cout, batch, t, hw, kt, st, pt, relu, plane_dtype):
+    """Conv3d [kt,1,1] stride (st,1,1) pad (pt,0,0) + bias (+ ReLU) on plane pairs as one streaming pass (csrc/pw_x3.hip's
+    temporal-tap form): SlowFast's lateral connections; w_* = fused_slowfast.pack_pw_planes of the conv's [cout -> 32 k, kt * cin] rows."""
+    _dev(w_hi, "w_hi", torch.bfloat16)
+    _dev(w_lo, "w_lo", torch.bfloat16)
+    _lib.check(_lib.lib().avt_lateral_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), int(ldx), int(cin), _p(w_hi), _p(w_lo), _p(bias),
+                                         _p(wscale), C.c_void_p(y_ptrs[0]), C.c_void_p(y_ptrs[1]), int(ldy), int(cout), int(batch),
+                                         int(t), int(hw), int(kt), int(st), int(pt), int(relu), int(plane_dtype), _stream()),
+               "avt_lateral_x3")
+
+
 def stem_conv_x3_merged(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, cout, kt, st, pt, plane_dtype, tap_frames,
                         tap_tiles, ktm, table_frames, relu=True):
     """The time-grouped fast stem over a frame table with the taps of one source frame merged (include/avt.h)."""

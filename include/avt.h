@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 4  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index (round 4) */
+#define AVT_ABI_VERSION 4  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4) */
 
 typedef enum {
   AVT_OK = 0,
@@ -397,6 +397,17 @@ int avt_pw_chain_x3(const void* x_hi, const void* x_lo, int ldx, int k1, const v
                     const float* wscale1, const void* res_hi, const void* res_lo, int ldr, void* y_hi, void* y_lo, int ldy,
                     int n1, int relu1, const void* w2_hi, const void* w2_lo, const float* bias2, const float* wscale2,
                     void* z_hi, void* z_lo, int ldz, int n2, int64_t m, int plane_dtype, void* stream);
+/* Conv3d [kt,1,1] with temporal stride st and padding pt (+ bias, ReLU) on plane pairs, as a STREAMING pass (round 4): the
+ * lateral fast -> slow connections of SlowFast (FuseFastToSlow: [7,1,1], stride 4; third-party model the reference runs per clip
+ * window, models/models.py:335, 399).  x_* rows [batch * t * hw, ldx] (NDHWC), y_* rows [batch * to * hw, ldy], to = (t + 2 pt -
+ * kt) / st + 1; w_* = fused_slowfast.pack_pw_planes of the convolution's own weight rows [cout rounded up to 32, kt * cin]
+ * (tap-major K), bias / wscale [that many] or NULL.  avt_pw_x3's kernel with a gathered operand: chunk ch of output row
+ * ((b, to), pos) is channels 8 (ch % (cin / 8)) .. + 7 of input frame to * st - pt + ch / (cin / 8) at pos; frames outside [0, t)
+ * are zero operands.  Supported: kt * cin = 56 (8 channels), 224 (32), 448 (64); cout % 16 == 0. */
+int avt_lateral_x3_supported(int cin, int cout, int kt);
+int avt_lateral_x3(const void* x_hi, const void* x_lo, int ldx, int cin, const void* w_hi, const void* w_lo, const float* bias,
+                   const float* wscale, void* y_hi, void* y_lo, int ldy, int cout, int batch, int t, int hw, int kt, int st,
+                   int pt, int relu, int plane_dtype, void* stream);
 /* avt_stem_conv_bf16 in the same arithmetic (csrc/stem_conv.hip, patch-resident): in / wt / out as plane pairs, wt_* in the
  * LDS image order of avt_stem_conv_bf16 (fused_slowfast.stem_lds_image of each plane), wscale [cout] or NULL. */
 /* frames_per_tile (round 3, ABI 3): 0 = that image; 2 = its FRAME-MAJOR form for the time-grouped fast stem (st = 4 output

@@ -685,3 +685,45 @@ def test_frame_table_equals_dense_clips(avt, dev, mode, W, S):
         outs.append(eng.embed_windows([enc], starts=starts)[0].clone())
         texture.FRAME_TABLE = keep
     assert float((outs[0] - outs[1]).abs().max()) < 1e-4 * float(outs[1].abs().max()) and torch.equal(outs[1], e_dense)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("cin,cout,dims", [(32, 64, (2, 32, 9, 7)), (8, 16, (1, 32, 12, 12)), (64, 128, (2, 13, 5, 6))])
+def test_lateral_x3_streaming_form_equals_the_general_tile(avt, dev, mode, cin, cout, dims):
+    """avt_lateral_x3 (Conv3d [7,1,1] stride 4 + bias + ReLU as one streaming pass with a gathered operand: SlowFast's lateral
+    connections) against the same FusedConv on the general split-plane tile and against torch's fp32 convolution: clip ends
+    (temporal zero padding), a frame count that is not a multiple of the stride, a 16-channel output (half a tile pair), writes
+    into a channel slice of a wider buffer."""
+    import avtex.fused_slowfast as fsf
+    from avtex.fused_slowfast import Act, new_act
+
+    pd = X3[mode]
+    torch.manual_seed(cin + cout)
+    conv = nn.Conv3d(cin, cout, (7, 1, 1), stride=(4, 1, 1), padding=(3, 0, 0), bias=False)
+    bn = nn.BatchNorm3d(cout).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3); bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    b, t, h, w = dims
+    x = torch.randn(b, cin, t, h, w)
+    with torch.no_grad():
+        ref = torch.relu(bn(conv(x)))  # [b, cout, to, h, w]
+    want = ref.permute(0, 2, 3, 4, 1).reshape(-1, cout)
+    xa = new_act(b * t * h * w, cin, dims, dev, True)
+    hi, lo = fsf.split_planes(x.permute(0, 2, 3, 4, 1).reshape(-1, cin).to(dev), pd)
+    xa.buf.copy_(hi); xa.lo.copy_(lo)
+    outs = {}
+    for flag in ("all", set()):
+        keep, fsf._LATERAL_X3 = fsf._LATERAL_X3, flag
+        fc = fsf.FusedConv(conv, bn, True, dev, x3=pd)
+        fsf._LATERAL_X3 = keep
+        assert (fc.lat is not None) == (flag == "all")
+        od = fc.out_dims(dims)
+        wide = new_act(od[0] * od[1] * od[2] * od[3], cout + 24, od, dev, True)
+        wide.buf.zero_(); wide.lo.zero_()
+        fc(xa, out=Act(wide.buf, od, 8, cout, lo=wide.lo))
+        torch.cuda.synchronize()
+        full = wide.float(pd).cpu()
+        assert float(full[:, :8].abs().max()) == 0.0 and float(full[:, 8 + cout:].abs().max()) == 0.0  # nothing outside the slice
+        outs[str(flag)] = full[:, 8 : 8 + cout]
+    tol = (2e-6 if mode == "f16x3" else 1e-4) * float(want.abs().max())
+    assert float((outs["all"] - want).abs().max()) < 4 * tol and float((outs["all"] - outs["set()"]).abs().max()) < 2 * tol

@@ -86,6 +86,15 @@ def spy_stem_m(x_ptrs, wt_hi, wt_lo, bias, wscale, out_ptrs, batch, t, h, pw, co
                        ktm, table_frames, relu)
 
 
+orig_lat = ops.lateral_x3
+
+
+def spy_lat(x_ptrs, ldx, cin, w_hi, w_lo, bias, wscale, y_ptrs, ldy, cout, batch, t, hw, kt, st, pt, relu, plane_dtype):
+    shapes.append("lateral (streaming) cin%d cout%d k(%d, 1, 1) s(%d, 1, 1) in(%d, %d, hw %d)" % (cin, cout, kt, st, batch, t, hw))
+    return orig_lat(x_ptrs, ldx, cin, w_hi, w_lo, bias, wscale, y_ptrs, ldy, cout, batch, t, hw, kt, st, pt, relu, plane_dtype)
+
+
+ops.lateral_x3 = spy_lat
 ops.stem_conv_x3_merged = spy_stem_m
 pool_recs = []
 orig_pool = ops.maxpool_hw3s2_x3
