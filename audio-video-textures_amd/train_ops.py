@@ -385,7 +385,7 @@ class _ConvX3(torch.autograd.Function):
             xin[:, :cin] = x
             xin[:, cin:] = 0
         # (the stems keep the padded channels-last copy: their weight gradient reads it 4 channels at a time)
-        ctx.save_for_backward(xin if (cin % 8 and _STEM_WGRAD_X3) else x, weight)
+        ctx.save_for_backward(xin if (cin % 8 and (_STEM_WGRAD_X3 or cin != 3)) else x, weight)
         CALLS["conv_fwd_x3"] += 1
         return _conv_x3_rows(xin, _weight_planes(weight, False), ops.X3_F16, xin.shape[1], cout, kernel, stride, padding)
 
@@ -417,6 +417,15 @@ def _conv_backward(ctx, dy, dalias):
                 dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
                 ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1), dims, cin, cout,
                                         kernel, stride, padding, cin, cout)
+        elif (_WGRAD_X3 and cin % 8 and cin != 3 and x.shape[1] == 8 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64):
+            # a few-channel first layer (VGGish: 1 mel channel) on its zero-padded 8-channel copy; the padded taps' gradient is dropped
+            CALLS["wgrad_x3"] += 1
+            dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
+            dw8 = torch.empty((cout, 8) + tuple(kernel), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last_3d)
+            ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw8.permute(0, 2, 3, 4, 1), dims, 8, cout, kernel,
+                                    stride, padding, 8, cout)
+            dw = torch.empty_like(weight)
+            dw.copy_(dw8[:, :cin])
         elif (_WGRAD_X3 and _STEM_WGRAD_X3 and cin == 3 and x.shape[1] == 8 and kernel[1] * kernel[2] <= 49 and
               max(x.numel(), dy.numel()) < (1 << 31) - 64):
             # the stems: 3 input channels travel as 4 of the forward's 8-channel padded clip; a [kt,7,7] filter is kt slices of
@@ -696,6 +705,25 @@ def conv_fusable(x, conv):
             not isinstance(conv.padding, str) and x.numel() < (1 << 30) - 64 and
             conv.weight.is_contiguous(memory_format=torch.channels_last_3d) and  # the model was put in the training layout
             (max(conv.kernel_size) > 1 or x.is_contiguous(memory_format=torch.channels_last_3d)))  # (a 1x1x1 weight is both layouts)
+
+
+def conv2d(x, conv):
+    """conv(x) for a Conv2d module (VGGish, models/audio_models/vggish.py:15-33, in the m=2 training branch, models.py:343-345,
+    405-407): the same split-plane kernels, the image as a one-frame clip — NHWC rows are NDHWC rows with T = 1 — forward,
+    input gradient and weight gradient; the bias is added by torch.  The module's weight is put in channels-last memory on first
+    use (its [cout][kh][kw][cin] order is the kernels' K order).  Stock op otherwise (eval mode, CPU, other dtypes)."""
+    ok = (_CONV_X3 and conv.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and
+          tuple(conv.dilation) == (1, 1) and conv.out_channels % 8 == 0 and conv.weight.dtype == torch.float32 and
+          conv.padding_mode == "zeros" and not isinstance(conv.padding, str) and max(conv.kernel_size) <= 5 and
+          (conv.in_channels % 8 == 0 or (conv.in_channels < 8 and not x.requires_grad)) and x.numel() < (1 << 30) - 64)
+    if not ok:
+        return conv(x)
+    if not conv.weight.is_contiguous(memory_format=torch.channels_last):
+        conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)  # once; a layout change, not a value change
+    x5 = x.contiguous(memory_format=torch.channels_last).unsqueeze(2)   # [n, C, 1, H, W]: channels_last_3d strides
+    w5 = conv.weight.unsqueeze(2)                                       # [cout, cin, 1, kh, kw], a view (autograd folds it back)
+    y = _ConvX3.apply(x5, w5, (1,) + tuple(conv.stride), (0,) + tuple(conv.padding)).squeeze(2)
+    return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
 
 
 def conv3d_fork(x, conv):

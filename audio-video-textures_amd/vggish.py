@@ -6,6 +6,8 @@ layers exist (so `pytorch_vggish.pth` loads, main.py:337-338) but are never appl
 """
 import torch.nn as nn
 
+from .train_ops import conv2d
+
 
 class VGGish(nn.Module):
     def __init__(self):
@@ -22,5 +24,12 @@ class VGGish(nn.Module):
                                 nn.ReLU(inplace=True), nn.Linear(4096, 128), nn.ReLU(inplace=True))
 
     def forward(self, x):
-        x = self.features(x).permute(0, 2, 3, 1).contiguous()
+        if self.training and x.is_cuda:
+            # the m = 2 training branch (models.py:343-345, 405-407): the six convolutions forward and backward on the hand-written
+            # split-plane kernels (train_ops.conv2d), ReLU / max-pool by torch — no MIOpen convolution
+            for layer in self.features:
+                x = conv2d(x, layer) if isinstance(layer, nn.Conv2d) else layer(x)
+        else:
+            x = self.features(x)
+        x = x.permute(0, 2, 3, 1).contiguous()
         return x.view(x.size(0), -1)

@@ -370,3 +370,36 @@ def test_stem_max_pool_forward_and_gradient_equal_torch(dims, c):
     #  in a fixed one — equal up to fp32 rounding of that sum; a different tie rule would move whole gradients instead)
     assert float((xa.grad - xb.grad).abs().max()) <= 4e-7 * float(xb.grad.abs().max())
     assert train_ops.max_pool_hw(x0, pool).shape == yb.shape and train_ops.CALLS["maxpool_hip"] == before + 1  # no gradient: the module
+
+
+def test_vggish_training_convolutions_run_on_the_hand_written_kernels(avt, dev):
+    """The m = 2 training branch's audio encoder (reference models/models.py:343-345, 405-407; VERDICT r3 'missing' #6): VGGish's six
+    Conv2d forward / input gradient / weight gradient through train_ops.conv2d (the image as a one-frame clip) against the stock
+    fp32 autograd of the same module — no MIOpen convolution is launched; the 1-channel first layer runs on its zero-padded copy."""
+    import copy
+
+    from avtex import train_ops
+
+    torch.manual_seed(0)
+    ref = avt.VGGish().to(dev).train()
+    net = copy.deepcopy(ref)
+    x = torch.randn(6, 1, 100, 64, device=dev)
+    gy = torch.randn(6, 12288, device=dev)
+    keep, train_ops._CONV_X3 = train_ops._CONV_X3, 0
+    y0 = ref(x)
+    y0.backward(gy)
+    train_ops._CONV_X3 = keep
+    before = dict(train_ops.CALLS)
+    y1 = net(x)
+    y1.backward(gy)
+    torch.cuda.synchronize()
+    d = {k: train_ops.CALLS[k] - before.get(k, 0) for k in train_ops.CALLS}
+    assert d["conv_fwd_x3"] == 6 and d["wgrad_x3"] == 6 and d["dgrad_x3"] == 5, d
+    assert d.get("miopen_wgrad", 0) == 0 and d.get("miopen_dgrad", 0) == 0, d
+    assert float((y1 - y0).detach().abs().max()) < 2e-5 * float(y0.detach().abs().max())
+    for (k, p0), (_, p1) in zip(ref.named_parameters(), net.named_parameters()):
+        if p0.grad is None:
+            assert p1.grad is None  # the fc stack is never applied
+            continue
+        rel = float((p1.grad - p0.grad).norm() / p0.grad.norm())
+        assert rel < 2e-4, (k, rel)
