@@ -360,12 +360,70 @@ def _weight_planes(weight, transposed):
     return planes
 
 
-def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=None):
+# ---- few-channel layers: g adjacent pixels along W as g * C channels (round 4; the inference path's group_weights_w in the training
+# step).  The fast pathway's 8-channel layers ran their forward / input gradient at 0.8-2.3 TB/s on the general tile (rows of 32
+# bytes, a 32-wide MFMA tile that is 3/4 padding); the same bytes viewed as [.., W / g, g * C] rows with block-Toeplitz weights along W
+# give 4 x fewer, 4 x fuller rows.  The weight gradient keeps the plain form (grouping would multiply its flops by g * g).
+_GROUP = 1
+_GROUP_IDX = {}
+
+
+def _group_factor(cin, cout, kernel, stride, pad, w):
+    if not _GROUP or tuple(stride) != (1, 1, 1) or pad[2] != kernel[2] // 2 or kernel[2] % 2 == 0 or cin % 8 or cout % 8:
+        return 1
+    small = min(cin, cout)
+    g = 4 if small <= 16 else (2 if small <= 32 else 1)
+    if kernel[2] == 1 and kernel[1] == 1 and kernel[0] > 1:  # temporal taps only: grouping just fills the tile; stop at 32 outputs
+        while g > 1 and g * cout > 32:
+            g //= 2
+    while g > 1 and w % g:
+        g //= 2
+    return g
+
+
+def _grouped_planes(weight, g, transposed, plane_dtype):
+    """Planes of the pixel-grouped form of a Conv3d weight (transposed: of the input gradient's filter W'[ci][flipped taps][co]):
+    rows [(po, n)][(dt, dh, dg)][(pi, c)], block-Toeplitz along W over groups of g pixels -> (hi, lo, wscale | None), (kt, kh, kwg), rg."""
+    from . import ops
+    key = (id(weight), "group", g, bool(transposed))
+    hit = _PLANES.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    with torch.no_grad():
+        w = weight.detach().float()
+        if transposed:
+            w = w.flip(2, 3, 4).transpose(0, 1)  # the input gradient as a convolution of dY: filter [cin][cout][flipped taps]
+        co, ci, kt, kh, kw = w.shape
+        r = kw // 2
+        rg = -(-r // g)
+        kwg = 1 + 2 * rg
+        ikey = (g, kw, str(w.device))
+        idx = _GROUP_IDX.get(ikey)
+        if idx is None:  # tap of the ORIGINAL filter that (output pixel po, input pixel pi, group tap dg) meets; kw = the zero tap
+            po, pi, dg = torch.meshgrid(torch.arange(g), torch.arange(g), torch.arange(kwg), indexing="ij")
+            dw = g * (dg - rg) + pi - po + r
+            idx = torch.where((dw >= 0) & (dw < kw), dw, torch.full_like(dw, kw)).to(w.device)
+            _GROUP_IDX[ikey] = idx
+        w_ext = torch.cat([w, w.new_zeros((co, ci, kt, kh, 1))], 4)
+        wg = w_ext[..., idx]  # [co, ci, kt, kh, po, pi, dg]
+        rows = wg.permute(4, 0, 2, 3, 6, 5, 1).reshape(g * co, kt * kh * kwg * g * ci).contiguous()
+        planes = (ops.weight_planes_f32(rows, plane_dtype), (kt, kh, kwg), rg)
+    _PLANES[key] = (weakref.ref(weight), weight._version, planes)
+    return planes
+
+
+def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=None, group=None):
     """x [B, Cin, T, H, W] channels-last fp32 -> [B, Cout, To, Ho, Wo] channels-last fp32 (+ add, same shape, in the epilogue)."""
     from . import ops
     b, _, t, h, w = x.shape
     od = [(n + 2 * p - k) // s_ + 1 for n, p, k, s_ in zip((t, h, w), pad, kernel, stride)]
     y = torch.empty((b, cout, od[0], od[1], od[2]), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+    if group is not None:  # (g, grouped kernel, rg): the same memory as [.., w / g, g * C] rows, block-Toeplitz planes
+        g, gk, rg = group
+        ops.conv3d_igemm_x3_f32(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
+                                _ktab(g * cin, gk, h, w // g, g * cin, x.device), (b, t, h, w // g), g * cin, g * cout, gk, (1, 1, 1),
+                                (pad[0], pad[1], rg), g * cin, g * cout, plane_dtype, add=None if add is None else add.permute(0, 2, 3, 4, 1))
+        return y
     ops.conv3d_igemm_x3_f32(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
                             _ktab(cin, kernel, h, w, cin, x.device), (b, t, h, w), cin, cout, kernel, stride, pad, cin, cout, plane_dtype,
                             add=None if add is None else add.permute(0, 2, 3, 4, 1))
@@ -387,6 +445,10 @@ class _ConvX3(torch.autograd.Function):
         # (the stems keep the padded channels-last copy: their weight gradient reads it 4 channels at a time)
         ctx.save_for_backward(xin if (cin % 8 and (_STEM_WGRAD_X3 or cin != 3)) else x, weight)
         CALLS["conv_fwd_x3"] += 1
+        g = _group_factor(xin.shape[1], cout, kernel, stride, padding, xin.shape[4]) if xin is x else 1
+        if g > 1:
+            planes, gk, rg = _grouped_planes(weight, g, False, ops.X3_F16)
+            return _conv_x3_rows(xin, planes, ops.X3_F16, cin, cout, kernel, stride, padding, group=(g, gk, rg))
         return _conv_x3_rows(xin, _weight_planes(weight, False), ops.X3_F16, xin.shape[1], cout, kernel, stride, padding)
 
     @staticmethod
@@ -452,7 +514,12 @@ def _conv_backward(ctx, dy, dalias):
         if (cin % 8 == 0 and stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(padding, kernel)) and
                 dy.numel() < (1 << 30) - 64):
             CALLS["dgrad_x3"] += 1
-            dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias)
+            g = _group_factor(cout, cin, kernel, (1, 1, 1), padding, dy.shape[4])
+            if g > 1:
+                planes, gk, rg = _grouped_planes(weight, g, True, ops.X3_BF16)
+                dx = _conv_x3_rows(dy, planes, ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias, group=(g, gk, rg))
+            else:
+                dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias)
         else:
             dx = _dgrad_strided(dy, weight, stride, padding, kernel, tuple(x.shape)) if (_DGRAD_S_X3 and cin % 8 == 0) else None
             if dx is not None:
