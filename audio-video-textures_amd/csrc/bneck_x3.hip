@@ -94,9 +94,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* wl = lds;                                             // [NF][2][1 KB]
   float* cf = reinterpret_cast<float*>(lds + NF * 2048);      // [NCOEF]
-  char* aoh = lds + NF * 2048 + NCOEF * 4;                    // a-output strip, hi plane: [APOS][CMP]
+  // the a-output strips are DOUBLE-BUFFERED by frame parity (round 4): frame t + 1's a stage may overwrite nothing a slower wave
+  // still reads in frame t's b stage, so the barrier between b and the next a is gone — and the one between b and c was never
+  // needed (a wave reads back only the b rows of its OWN tiles): ONE workgroup barrier per frame instead of two
+  // (DB: where both copies fit the LDS — every form but res4's strided first block, whose 108 KB of weight fragments leave no room;
+  //  that one keeps the barrier after its b stage)
+  constexpr bool DB = NF * 2048 + NCOEF * 4 + 4 * ABYTES + 2 * BBYTES <= 160 * 1024;
+  char* aoh = lds + NF * 2048 + NCOEF * 4;                    // a-output strip, hi plane: [2 parities][hi | lo][APOS][CMP]
   char* aol = aoh + ABYTES;
-  char* boh = aol + ABYTES;                                   // b-output strip: [MTB * 16][CMP]
+  char* boh = aoh + (DB ? 4 : 2) * ABYTES;                    // b-output strip: [MTB * 16][CMP]
   char* bol = boh + BBYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
   for (int f = wid; f < NF * 2; f += NW) *reinterpret_cast<i32x4*>(wl + f * 1024 + lane * 16) = a.wf[f * 64 + lane];
   for (int i = tid; i < NCOEF; i += NW * 64) cf[i] = a.coef[i];
   // both a strips start as zeros: border columns, rows outside the image and tile padding stay zero for the whole walk
-  for (int i = tid * 16; i < 2 * ABYTES; i += NW * 64 * 16) *reinterpret_cast<i32x4*>(aoh + i) = i32x4{0, 0, 0, 0};
+  for (int i = tid * 16; i < (DB ? 4 : 2) * ABYTES; i += NW * 64 * 16) *reinterpret_cast<i32x4*>(aoh + i) = i32x4{0, 0, 0, 0};
 
   const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)a.xh, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)a.xl, 0, a.x_bytes, 0x00020000);
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
   // one frame; R = rotation of the ring: slot R holds frame t-1, R+1 frame t, R+2 frame t+1
   auto body = [&](auto rot_c, int t) __attribute__((always_inline)) {
     constexpr int R = decltype(rot_c)::value;
+    const int aofs = DB ? ((t - t0) & 1) * 2 * ABYTES : 0;  // this frame's a strips
     constexpr int PV = R % 3, CU = (R + 1) % 3, NX = (R + 2) % 3;
     if constexpr (FIRST) {
       if (t > t0) {  // the operand moves one frame on: groups 0,1 take their right neighbour's chunk, group 2 the new frame
@@ -291,8 +298,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           avt::split2<F16>(avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y), h.x, l.x);
           avt::split2<F16>(avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w), h.y, l.y);
           if (a_st[it] >= 0) {
-            *reinterpret_cast<uint2*>(aoh + a_st[it] + n * 32) = h;
-            *reinterpret_cast<uint2*>(aol + a_st[it] + n * 32) = l;
+            *reinterpret_cast<uint2*>(aoh + aofs + a_st[it] + n * 32) = h;
+            *reinterpret_cast<uint2*>(aol + aofs + a_st[it] + n * 32) = l;
           }
         }
       }
@@ -311,8 +318,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
         for (int n = 0; n < NTA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          const i32x4 fh = *reinterpret_cast<const i32x4*>(aoh + b_rd[it] + tapoff[j]);
-          const i32x4 fl = *reinterpret_cast<const i32x4*>(aol + b_rd[it] + tapoff[j]);
+          const i32x4 fh = *reinterpret_cast<const i32x4*>(aoh + aofs + b_rd[it] + tapoff[j]);
+          const i32x4 fl = *reinterpret_cast<const i32x4*>(aol + aofs + b_rd[it] + tapoff[j]);
 #pragma unroll
           for (int n = 0; n < NTA; ++n) {
             const int f = NFA + j * NTA + n;
@@ -332,7 +339,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
         }
       }
     }
-    __syncthreads();  // b strips complete
+    // (no workgroup barrier: the c stage reads the b rows of this wave's own tiles; its LDS writes above are ordered before the
+    //  reads below by the wave's own queue — the wait keeps the compiler from moving them)
+    if constexpr (DB)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+      __syncthreads();  // single a strips: nobody may start the next frame's a stage while a wave still reads them
     // ---- [c] pointwise conv (+ shortcut conv) + bias + residual (the ring's frame t) -> relu -> split -> global
     const unsigned obase = (unsigned)((b * a.T + t) * Ho) * (unsigned)(WO * C * 2);
 #pragma unroll
@@ -406,7 +418,9 @@ int launch(BxArgs& a, int batch, int h, hipStream_t st) {
   constexpr int KA = FIRST ? 1 : CIN / 32, NTA = CMP / 16, NB = CMP == 16 ? 5 : 9, KS = STR ? CIN / 32 : 1;
   constexpr int NF = (FIRST ? 1 : 3) * KA * NTA + NB * NTA + C / 16 + (FIRST || STR ? (C / 16) * KS : 0);
   constexpr int MTB = (HT * (W / ST) + 15) / 16, RX = STR ? 2 * HT + 1 : HT + 2;
-  constexpr int lds_bytes = NF * 2048 + (4 * CMP + 2 * C) * 4 + 2 * (RX * (W + 2) * CMP * 2) + 2 * (MTB * 16 * CMP * 2);
+  constexpr int lds_one = NF * 2048 + (4 * CMP + 2 * C) * 4 + 2 * (RX * (W + 2) * CMP * 2) + 2 * (MTB * 16 * CMP * 2);
+  constexpr int lds_two = lds_one + 2 * (RX * (W + 2) * CMP * 2);  // the a strips double-buffered where that fits (the kernel's DB)
+  constexpr int lds_bytes = lds_two <= 160 * 1024 ? lds_two : lds_one;
   static_assert(lds_bytes <= 160 * 1024, "strips do not fit the LDS");
   a.strips = (h / ST + HT - 1) / HT;
   a.swz = 1;  // XCD-contiguous work order
