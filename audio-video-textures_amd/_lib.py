@@ -58,9 +58,9 @@ SIGNATURES = {
     "avt_conv3d_igemm_bf16": [_vp] * 6 + [C.c_int] * 22 + [_vp],
     "avt_conv3d_igemm_rows_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp],
     "avt_bn_train_fwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_float, C.c_float, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, _vp,
-                         _vp, _vp, _vp, _vp],
+                         _vp, _vp, _vp, C.c_int64, _vp],
     "avt_bn_train_bwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
-                         _vp],
+                         C.c_int64, _vp],
     "avt_bn_train_ws_bytes": [C.c_int64, C.c_int, C.c_int],
     "avt_conv3d_igemm_x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 19 + [_vp],
     "avt_conv3d_igemm_x3_f32_ex": [_vp] * 6 + [C.c_int] * 21 + [_vp],
@@ -82,8 +82,8 @@ SIGNATURES = {
     "avt_stem_conv_x3_f32": [_vp] * 6 + [C.c_int] * 11 + [_vp],
     "avt_weight_planes_f32": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp],
     "avt_weight_planes_t_f32": [_vp, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _vp, _vp, _vp],
-    "avt_maxpool_train_fwd": [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp],
-    "avt_maxpool_train_bwd": [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp],
+    "avt_maxpool_train_fwd": [_vp, _vp, _vp] + [C.c_int] * 4 + [C.c_int64, _vp],
+    "avt_maxpool_train_bwd": [_vp, _vp, _vp] + [C.c_int] * 4 + [C.c_int64, _vp],
     "avt_stem_wgrad_x3_supported": [C.c_int] * 4,
     "avt_stem_wgrad_x3": [_vp] * 4 + [C.c_int] * 7 + [_vp],
     "avt_pw_x3_supported": [C.c_int] * 2,
@@ -138,7 +138,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 4  # include/avt.h AVT_ABI_VERSION
+ABI_VERSION = 5  # include/avt.h AVT_ABI_VERSION
 _RETURNS_I64 = {"avt_bn_train_ws_bytes"}  # sizes; every other entry returns an AVT_* status
 
 

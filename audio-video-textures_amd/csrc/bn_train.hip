@@ -72,6 +72,9 @@ struct BnArgs {
   int blocks;
   int nq;               // quads a workgroup sees: min(C / 4, kT)
   int unit;             // workgroups per row when a row is wider than one (C / 4 > kT), else 1
+  int64_t ld4;          // leading dimension, in float4 chunks, of the ONE tensor that may be a channel slice of wider rows: the forward's
+                        // out, the backward's dy (a concatenation buffer's slice: no torch.cat copy, no .contiguous() of its gradient);
+                        // C / 4 when contiguous
 };
 
 // this thread's four channels (fixed for the whole walk)
@@ -79,6 +82,15 @@ __device__ __forceinline__ int my_quad(const BnArgs& a) {
   const int64_t i0 = (int64_t)blockIdx.x * kT + threadIdx.x;
   return (int)(i0 % (a.C / 4));
 }
+
+// the walk over the strided tensor (a.ld4): this thread's first chunk and its step — chunk i of the contiguous walk is (row i / (C/4),
+// quad i % (C/4)); the stride is a whole number of rows, so the quad stays and the row advances by stride / (C/4)
+__device__ __forceinline__ int64_t strided_first(const BnArgs& a) {
+  const int64_t i0 = (int64_t)blockIdx.x * kT + threadIdx.x;
+  const int q4 = a.C / 4;
+  return ((int64_t)blockIdx.y * a.M + i0 / q4) * a.ld4 + i0 % q4;
+}
+__device__ __forceinline__ int64_t strided_step(const BnArgs& a) { return a.stride / (a.C / 4) * a.ld4; }
 
 // per-thread fp64 partials -> halving tree in LDS (threads t and t + w share their quad for every power of two w >= nq)
 // -> this workgroup's row of partials.  Fixed order: deterministic.
@@ -195,17 +207,18 @@ __global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // gri
 __global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
   const int quad = my_quad(a);
   a.x += 4 * slab(a);
-  a.out += 4 * slab(a);
   if (a.res) a.res += 4 * slab(a);
   a.coef += (size_t)blockIdx.y * 2 * a.C;
   a.save_mean += (size_t)blockIdx.y * a.C;
   if (a.mask) a.mask += slab(a);
+  int64_t io = strided_first(a);
+  const int64_t so = strided_step(a);
   // y = (x - mean) * (invstd * gamma) + beta, the subtraction FIRST as stock BatchNorm does it: the folded form
   // x * sc + (beta - mean * sc) cancels two large terms when |mean| >> std (error ~ 2^-24 |mean| / std of the result)
   const float4 sc = reinterpret_cast<const float4*>(a.coef)[quad];
   const float4 mu = reinterpret_cast<const float4*>(a.save_mean)[quad];
   const float4 be = reinterpret_cast<const float4*>(a.beta)[quad];
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride, io += so) {
     const float4 v = ldg4(a.x, i);
     float4 o = make_float4((v.x - mu.x) * sc.x + be.x, (v.y - mu.y) * sc.y + be.y, (v.z - mu.z) * sc.z + be.z,
                            (v.w - mu.w) * sc.w + be.w);
@@ -217,19 +230,20 @@ __global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
       if (a.mask) a.mask[i] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
-    reinterpret_cast<float4*>(a.out)[i] = o;  // (a non-temporal store here measured equal: the next convolution reads y at once)
+    reinterpret_cast<float4*>(a.out)[io] = o;  // (a non-temporal store here measured equal: the next convolution reads y at once)
   }
 }
 
 __global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
   const int quad = my_quad(a);
-  a.dy += 4 * slab(a);
   a.x += 4 * slab(a);
   if (a.y) a.y += 4 * slab(a);
   if (a.mask) a.mask += slab(a);
   a.mean += (size_t)blockIdx.y * a.C;
   a.invstd += (size_t)blockIdx.y * a.C;
   a.part += (size_t)blockIdx.y * a.blocks * a.nq * 8;
+  int64_t id = strided_first(a);
+  const int64_t sd = strided_step(a);
   const float4 mu = reinterpret_cast<const float4*>(a.mean)[quad];
   const float4 is = reinterpret_cast<const float4*>(a.invstd)[quad];
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), be = sc;
@@ -239,8 +253,8 @@ __global__ __launch_bounds__(kT) void bn_bwd_stats_kernel(BnArgs a) {
     be = reinterpret_cast<const float4*>(a.beta)[quad];
   }
   double p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
-    float4 g = ldg4(a.dy, i);
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride, id += sd) {
+    float4 g = ldg4(a.dy, id);
     const float4 v = ldg4(a.x, i);
     if (a.mask) {  // ReLU backward: the gradient passes where the forward output was positive — from the saved bits,
       const unsigned mk = a.mask[i];
@@ -283,7 +297,8 @@ __global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(BnArgs a) {
 
 __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(BnArgs a) {
   const int quad = my_quad(a);
-  a.dy += 4 * slab(a);
+  int64_t id = strided_first(a);
+  const int64_t sd = strided_step(a);
   a.x += 4 * slab(a);
   a.out += 4 * slab(a);
   if (a.y) a.y += 4 * slab(a);
@@ -301,8 +316,8 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(BnArgs a) {
   const float4 sc = make_float4(is.x * gm.x, is.y * gm.y, is.z * gm.z, is.w * gm.w);  // the forward's scale (same product)
   float4 be = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!a.y && a.relu) be = reinterpret_cast<const float4*>(a.beta)[quad];
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride) {
-    float4 g = ldg4(a.dy, i);
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < a.nchunk; i += a.stride, id += sd) {
+    float4 g = ldg4(a.dy, id);
     const float4 v = ldg4(a.x, i);
     if (a.mask) {
       const unsigned mk = a.mask[i];
@@ -379,7 +394,7 @@ extern "C" int64_t avt_bn_train_ws_bytes(int64_t m, int c, int groups) {
 extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
                                 float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,
                                 float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                void* relu_mask, void* stream) {
+                                void* relu_mask, int64_t ldy, void* stream) {
   AVT_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && (!running_mean == !running_var), "avt_bn_train_fwd: NULL pointer");
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && (!res || avt::aligned16(res)), "avt_bn_train_fwd: rows must be 16-byte aligned");
   AVT_REQUIRE(avt::aligned16(beta) && avt::aligned16(save_mean), "avt_bn_train_fwd: beta / save_mean must be 16-byte aligned");
@@ -390,6 +405,8 @@ extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int6
   a.save_mean = save_mean; a.save_invstd = save_invstd; a.running_mean = running_mean; a.running_var = running_var;
   a.tracked = reinterpret_cast<long long*>(num_batches_tracked);
   a.mask = relu ? static_cast<uint8_t*>(relu_mask) : nullptr;
+  AVT_REQUIRE(ldy == 0 || (ldy >= c && ldy % 4 == 0), "avt_bn_train_fwd: ldy = %lld must be 0 (contiguous) or a multiple of 4 >= c", (long long)ldy);
+  a.ld4 = (ldy ? ldy : c) / 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);
@@ -399,7 +416,7 @@ extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int6
 
 extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma, const float* beta,
                                 const float* save_mean, const float* save_invstd, int relu, int groups, const void* relu_mask, void* ws,
-                                int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
+                                int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta, int64_t ld_dy, void* stream) {
   AVT_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "avt_bn_train_bwd: NULL pointer");
   AVT_REQUIRE(!relu || y || relu_mask || (beta && avt::aligned16(beta) && !dres),
               "avt_bn_train_bwd: a ReLU needs the forward's mask, its output y, or (no shortcut) beta to recompute the mask from x");
@@ -413,6 +430,8 @@ extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x,
   a.relu = relu;
   a.mask = relu ? const_cast<uint8_t*>(static_cast<const uint8_t*>(relu_mask)) : nullptr;
   a.out = dx; a.dres = dres; a.dgamma = dgamma; a.dbeta = dbeta;
+  AVT_REQUIRE(ld_dy == 0 || (ld_dy >= c && ld_dy % 4 == 0), "avt_bn_train_bwd: ld_dy = %lld must be 0 (contiguous) or a multiple of 4 >= c", (long long)ld_dy);
+  a.ld4 = (ld_dy ? ld_dy : c) / 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);

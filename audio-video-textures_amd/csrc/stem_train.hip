@@ -238,6 +238,7 @@ struct MpArgs {
   const float* dy;
   float* dx;
   int bt, H, W, C, Ho, Wo;
+  int64_t ld;  // floats between consecutive rows of the forward's y / the backward's dy (C, or a concatenation buffer's width)
 };
 
 __global__ __launch_bounds__(256) void maxpool_train_fwd_kernel(MpArgs a) {
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void maxpool_train_fwd_kernel(MpArgs a) {
         first = false;
       }
     }
-    *reinterpret_cast<float4*>(a.y + (int64_t)p * a.C + cc * 4) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(a.y + (int64_t)p * a.ld + cc * 4) = make_float4(m[0], m[1], m[2], m[3]);
     *reinterpret_cast<uint16_t*>(a.tap + ((int64_t)p * a.C + cc * 4) / 2) = (uint16_t)(t[0] | (t[1] << 4) | (t[2] << 8) | (t[3] << 12));
   }
 }
@@ -297,9 +298,9 @@ __global__ __launch_bounds__(256) void maxpool_train_bwd_kernel(MpArgs a) {
       for (int dw = 0; dw < 3; ++dw) {
         const int ww = w + 1 - dw;
         if (ww < 0 || (ww & 1) || (ww >> 1) >= a.Wo) continue;
-        const int64_t o = ((int64_t)(b * a.Ho + (hh >> 1)) * a.Wo + (ww >> 1)) * a.C + cc * 4;
-        const unsigned t = *reinterpret_cast<const uint16_t*>(a.tap + o / 2);
-        const float4 d = *reinterpret_cast<const float4*>(a.dy + o);
+        const int64_t row = (int64_t)(b * a.Ho + (hh >> 1)) * a.Wo + (ww >> 1);
+        const unsigned t = *reinterpret_cast<const uint16_t*>(a.tap + (row * a.C + cc * 4) / 2);
+        const float4 d = *reinterpret_cast<const float4*>(a.dy + row * a.ld + cc * 4);
         const unsigned me = (unsigned)(dh * 3 + dw);
         g[0] += ((t & 15u) == me) ? d.x : 0.f;
         g[1] += (((t >> 4) & 15u) == me) ? d.y : 0.f;
@@ -457,13 +458,15 @@ extern "C" int avt_stem_wgrad_x3(const void* x_hi, const void* x_lo, const float
 }
 
 // MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the training step on fp32 NDHWC rows (see include/avt.h)
-extern "C" int avt_maxpool_train_fwd(const float* x, float* y, void* tap, int bt, int h, int w, int c, void* stream) {
+extern "C" int avt_maxpool_train_fwd(const float* x, float* y, void* tap, int bt, int h, int w, int c, int64_t ldy, void* stream) {
   AVT_REQUIRE(x && y && tap && bt > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "avt_maxpool_train_fwd: NULL pointer / bad sizes (c %% 4 == 0)");
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && avt::aligned16(tap), "avt_maxpool_train_fwd: pointers must be 16-byte aligned");
   MpArgs a = {};
   a.x = x; a.y = y; a.tap = static_cast<uint8_t*>(tap);
   a.bt = bt; a.H = h; a.W = w; a.C = c;
   a.Ho = (h - 1) / 2 + 1; a.Wo = (w - 1) / 2 + 1;
+  AVT_REQUIRE(ldy == 0 || (ldy >= c && ldy % 4 == 0), "avt_maxpool_train_fwd: ldy = %lld must be 0 (contiguous) or a multiple of 4 >= c", (long long)ldy);
+  a.ld = ldy ? ldy : c;
   const int64_t total = (int64_t)bt * a.Ho * a.Wo * (c / 4);
   AVT_REQUIRE((int64_t)bt * h * w * (c / 4) < (1ll << 32), "avt_maxpool_train_fwd: more than 2^32 chunks");
   const int64_t blocks = (total + 255) / 256;
@@ -472,13 +475,15 @@ extern "C" int avt_maxpool_train_fwd(const float* x, float* y, void* tap, int bt
   return avt::check_launch("avt_maxpool_train_fwd");
 }
 
-extern "C" int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx, int bt, int h, int w, int c, void* stream) {
+extern "C" int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx, int bt, int h, int w, int c, int64_t ld_dy, void* stream) {
   AVT_REQUIRE(dy && dx && tap && bt > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "avt_maxpool_train_bwd: NULL pointer / bad sizes (c %% 4 == 0)");
   AVT_REQUIRE(avt::aligned16(dy) && avt::aligned16(dx) && avt::aligned16(tap), "avt_maxpool_train_bwd: pointers must be 16-byte aligned");
   MpArgs a = {};
   a.dy = dy; a.dx = dx; a.tap = const_cast<uint8_t*>(static_cast<const uint8_t*>(tap));
   a.bt = bt; a.H = h; a.W = w; a.C = c;
   a.Ho = (h - 1) / 2 + 1; a.Wo = (w - 1) / 2 + 1;
+  AVT_REQUIRE(ld_dy == 0 || (ld_dy >= c && ld_dy % 4 == 0), "avt_maxpool_train_bwd: ld_dy = %lld must be 0 (contiguous) or a multiple of 4 >= c", (long long)ld_dy);
+  a.ld = ld_dy ? ld_dy : c;
   const int64_t total = (int64_t)bt * h * w * (c / 4);
   AVT_REQUIRE(total < (1ll << 32), "avt_maxpool_train_bwd: more than 2^32 chunks");
   const int64_t blocks = (total + 255) / 256;

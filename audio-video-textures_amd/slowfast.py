@@ -16,7 +16,7 @@ and `--train_conv fp32` send it to MIOpen.
 import torch
 import torch.nn as nn
 
-from .train_ops import bn_act, conv3d, conv3d_fork, max_pool_hw
+from .train_ops import bn_act, conv3d, conv3d_fork, join_channels, max_pool_hw
 
 ALPHA, BETA_INV, FUSION_RATIO, FUSION_KERNEL = 4, 8, 2, 7
 WIDTH = 64
@@ -34,8 +34,10 @@ class Stem(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.pool_layer = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
 
-    def forward(self, x):
-        return max_pool_hw(bn_act(conv3d(x, self.conv), self.bn, relu=True), self.pool_layer)  # (train mode on the GPU: fused HIP passes)
+    def forward(self, x, cat_extra=0):
+        # (train mode on the GPU: fused HIP passes; cat_extra: the pooled output as the first channels of the lateral fusion's
+        #  concatenation buffer, train_ops.join_channels)
+        return max_pool_hw(bn_act(conv3d(x, self.conv), self.bn, relu=True), self.pool_layer, cat_extra=cat_extra)
 
 
 class VideoModelStem(nn.Module):
@@ -44,8 +46,8 @@ class VideoModelStem(nn.Module):
         self.pathway0_stem = Stem(WIDTH, STEM_TK[0])
         self.pathway1_stem = Stem(WIDTH // BETA_INV, STEM_TK[1])
 
-    def forward(self, x):
-        return [self.pathway0_stem(x[0]), self.pathway1_stem(x[1])]
+    def forward(self, x, cat_extra=0):
+        return [self.pathway0_stem(x[0], cat_extra), self.pathway1_stem(x[1])]
 
 
 class FuseFastToSlow(nn.Module):
@@ -55,9 +57,14 @@ class FuseFastToSlow(nn.Module):
                                   padding=(FUSION_KERNEL // 2, 0, 0), bias=False)
         self.bn = nn.BatchNorm3d(c_fast * FUSION_RATIO)
         self.relu = nn.ReLU(inplace=True)
+        self.extra = c_fast * FUSION_RATIO  # channels this fusion appends to the slow pathway
 
     def forward(self, x):
-        return [torch.cat([x[0], bn_act(conv3d(x[1], self.conv_f2s), self.bn, relu=True)], 1), x[1]]
+        # torch.cat([slow, lateral], 1); in train mode on the GPU the slow pathway's producer left room for the lateral channels
+        # (cat_extra) and the lateral BatchNorm writes them in place: no copy either way (train_ops.join_channels)
+        tag = getattr(x[0], "_avt_cat", None)
+        lat = bn_act(conv3d(x[1], self.conv_f2s), self.bn, relu=True, cat_into=None if tag is None else (tag[0], x[0].shape[1]))
+        return [join_channels(x[0], lat), x[1]]
 
 
 class BottleneckTransform(nn.Module):
@@ -87,7 +94,7 @@ class ResBlock(nn.Module):
         self.branch2 = BottleneckTransform(cin, cout, cinner, tk, stride)
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x):
+    def forward(self, x, cat_extra=0):
         t = self.branch2
         # (train mode on the GPU: the shortcut's gradient is summed into a's input gradient inside that kernel, train_ops)
         h, xs = conv3d_fork(x, t.a)
@@ -95,7 +102,7 @@ class ResBlock(nn.Module):
         h = bn_act(h, t.a_bn, relu=True)
         h = bn_act(conv3d(h, t.b), t.b_bn, relu=True)
         # c's BatchNorm, the shortcut add and the block's ReLU: one pass in train mode (csrc/bn_train.hip), the stock ops else
-        return bn_act(conv3d(h, t.c), t.c_bn, res=sc, relu=True)
+        return bn_act(conv3d(h, t.c), t.c_bn, res=sc, relu=True, cat_extra=cat_extra)
 
 
 class ResStage(nn.Module):
@@ -108,12 +115,14 @@ class ResStage(nn.Module):
                                 ResBlock(cin[p] if i == 0 else cout[p], cout[p], cinner[p], tks[p],
                                          stride if i == 0 else 1))
 
-    def forward(self, x):
+    def forward(self, x, cat_extra=0):
+        """cat_extra: channels the lateral fusion after this stage appends to the slow pathway (its last block writes into the
+        concatenation buffer, train_ops.join_channels)."""
         out = []
         for p in range(2):
             y = x[p]
             for i in range(self.depth):
-                y = getattr(self, "pathway%d_res%d" % (p, i))(y)
+                y = getattr(self, "pathway%d_res%d" % (p, i))(y, cat_extra if (p == 0 and i == self.depth - 1) else 0)
             out.append(y)
         return out
 
@@ -167,10 +176,10 @@ class SlowFast(nn.Module):
                 nn.init.zeros_(m.c_bn.weight)
 
     def forward(self, x):
-        x = self.s1_fuse(self.s1(x))
-        x = self.s2_fuse(self.s2(x))
-        x = self.s3_fuse(self.s3(x))
-        x = self.s4_fuse(self.s4(x))
+        x = self.s1_fuse(self.s1(x, self.s1_fuse.extra))
+        x = self.s2_fuse(self.s2(x, self.s2_fuse.extra))
+        x = self.s3_fuse(self.s3(x, self.s3_fuse.extra))
+        x = self.s4_fuse(self.s4(x, self.s4_fuse.extra))
         return self.head(self.s5(x))
 
 

@@ -172,8 +172,9 @@ class TextureEngine:
     # ---- packing + encoding ----------------------------------------------------------
     def _pack(self, frames, starts):
         lo, hi = int(starts.min()), int(starts.max()) + self.W
-        if self.planes is not None and self.layout == "ndhwc4" and FRAME_TABLE:
-            # contract-grade encoders: every distinct frame packed once, the windows' sampling as an index (ops.FrameClip)
+        if self.planes is not None and self.layout == "ndhwc4" and FRAME_TABLE and hi - lo <= len(starts) * self.W:
+            # contract-grade encoders: every distinct frame packed once, the windows' sampling as an index (ops.FrameClip);
+            # windows scattered so thinly that the span holds more frames than the dense clips would keep the dense form
             return ops.clip_pack_frames(frames[lo:hi], starts - lo, self.W, out_hw=self.hw, mean=self.mean, std=self.std,
                                         bgr=True, planes=self.planes)
         return ops.clip_pack(frames[lo:hi], starts - lo, self.W, out_hw=self.hw, mean=self.mean, std=self.std,

@@ -123,11 +123,74 @@ def fusable(x, bn, res=None):
                              res.is_contiguous(memory_format=torch.channels_last_3d))))
 
 
+# Concatenation without the copy (round 4).  SlowFast's lateral fusion is torch.cat([slow, lateral], 1): on channels-last tensors a
+# strided copy of both operands forward and, backward, a .contiguous() of each gradient slice — 13 GB per config-5 step that no
+# convolution needs.  Instead the two producers (the stage's last BatchNorm / the stem's max-pool, and the lateral's BatchNorm)
+# write channel slices of ONE buffer: bn_act / max_pool_hw(cat_extra = e) allocate rows of c + e channels and return their first
+# c as a view tagged `_avt_cat = (buffer, c)`; bn_act(cat_into = (buffer, offset)) fills the rest; join_channels hands out the
+# buffer as the concatenation, and its backward hands each producer its slice of the gradient, which the kernels read through a
+# leading dimension (avt_bn_train_bwd ld_dy).  Only the fused HIP paths set the tag: anything else keeps torch.cat.
+_JOIN = 1  # (tests set 0: torch.cat and contiguous gradients, the same numbers)
+
+
+def _cat_buffer(shape, c_total, device):
+    b, _, t, h, w = shape
+    return torch.empty((b, c_total, t, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last_3d)
+
+
+def _alias(buf, c_off, c):
+    """Channels c_off .. c_off + c of the buffer's rows as a tensor that SHARES the storage without being an autograd view of it
+    (set_: a version counter of its own) — the producers fill the slices through raw pointers, and the view bookkeeping ("a view's
+    base was modified in place") has nothing to say about tensors whose only writers are those kernels."""
+    t = torch.empty(0, dtype=buf.dtype, device=buf.device)
+    size = (buf.shape[0], c) + tuple(buf.shape[2:])
+    return t.set_(buf.untyped_storage(), buf.storage_offset() + c_off, size, buf.stride())
+
+
+def _row_ld(t):
+    """Leading dimension of a [B,C,T,H,W] tensor that is channels-last ROWS with a constant row pitch (a channel slice of a
+    channels-last tensor, or a contiguous one: pitch C), else None."""
+    if t.dim() != 5 or t.dtype != torch.float32 or t.data_ptr() % 16:
+        return None
+    b, c, tt, h, w = t.shape
+    st = t.stride()
+    if c > 1 and st[1] != 1:
+        return None
+    ld = st[4] if w > 1 else (st[3] if h > 1 else (st[2] if tt > 1 else (st[0] if b > 1 else c)))
+    want = (tt * h * w * ld, 1, h * w * ld, w * ld, ld)
+    if any(n > 1 and s != e for n, s, e in zip(t.shape, st, want)) or ld < c or ld % 4:
+        return None
+    return ld
+
+
+class _JoinChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ctx.c0 = a.shape[1]
+        return _alias(buf, 0, buf.shape[1])  # the buffer both producers wrote, as a tensor of this node's own
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[:, : ctx.c0], d[:, ctx.c0 :], None
+
+
+def join_channels(a, b):
+    """torch.cat([a, b], 1) — without a copy when a and b are the two channel slices of one buffer (see above)."""
+    ta, tb = getattr(a, "_avt_cat", None), getattr(b, "_avt_cat", None)
+    if (ta is not None and tb is not None and ta[0] is tb[0] and ta[1] == 0 and tb[1] == a.shape[1] and
+            ta[0].shape[1] == a.shape[1] + b.shape[1]):
+        return _JoinChannels.apply(a, b, ta[0])
+    return torch.cat([a, b], 1)
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps, tracked=None, groups=1):
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps, tracked=None, groups=1, cat=None):
         m, c = _rows(x)
-        y = torch.empty_like(x)  # keeps the channels-last strides
+        if cat is None:
+            y, ldy = torch.empty_like(x), 0  # keeps the channels-last strides
+        else:  # (buffer, channel offset): the output is that slice of the concatenation buffer's rows
+            y, ldy = _alias(cat[0], cat[1], c), cat[0].shape[1]
         ws = _workspace(m, c, groups, x.device)
         save_mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
@@ -137,7 +200,8 @@ class _BNAct(torch.autograd.Function):
         mask = torch.empty(m * c // 4, dtype=torch.uint8, device=x.device) if (relu and res is not None) else None
         _lib.check(_lib.lib().avt_bn_train_fwd(_p(x), _p(res), _p(y), m, c, _p(weight), _p(bias), float(eps), float(momentum),
                                                1 if relu else 0, groups, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
-                                               _p(running_mean), _p(running_var), _p(tracked), _p(mask), _stream()), "avt_bn_train_fwd")
+                                               _p(running_mean), _p(running_var), _p(tracked), _p(mask), ldy, _stream()),
+                   "avt_bn_train_fwd")
         ctx.save_for_backward(x, mask, weight, bias, save_mean, save_invstd)
         ctx.has_res = res is not None
         ctx.relu = bool(relu)
@@ -148,7 +212,9 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, mask, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         m, c = _rows(x)
-        dy = dy.contiguous(memory_format=torch.channels_last_3d)
+        ld_dy = _row_ld(dy)  # a slice of a concatenation's gradient is read in place (rows with a pitch)
+        if ld_dy is None:
+            dy, ld_dy = dy.contiguous(memory_format=torch.channels_last_3d), c
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         ws = _workspace(m, c, ctx.groups, x.device)
@@ -157,14 +223,16 @@ class _BNAct(torch.autograd.Function):
         CALLS["bn_bwd"] += 1
         _lib.check(_lib.lib().avt_bn_train_bwd(_p(dy), None, _p(x), m, c, _p(weight), _p(bias), _p(save_mean), _p(save_invstd),
                                                1 if ctx.relu else 0, ctx.groups, _p(mask), _p(ws), ws.numel(), _p(dx), _p(dres),
-                                               _p(dgamma), _p(dbeta), _stream()), "avt_bn_train_bwd")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+                                               _p(dgamma), _p(dbeta), ld_dy, _stream()), "avt_bn_train_bwd")
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
 
-def bn_act(x, bn, res=None, relu=True):
+def bn_act(x, bn, res=None, relu=True, cat_extra=0, cat_into=None):
     """act(bn(x) [+ res]) for a BatchNorm3d module `bn`: the fused HIP pass in train mode on channels-last fp32 device tensors,
     the stock torch ops otherwise (eval mode, other layouts / dtypes, CPU) — same result, same running-statistics update.
-    Inside `bn_replicas(n)` the batch is n groups with statistics of their own (the stock path: a loop over the groups)."""
+    Inside `bn_replicas(n)` the batch is n groups with statistics of their own (the stock path: a loop over the groups).
+    cat_extra = e / cat_into = (buffer, offset): the output is the first / a later channel slice of a concatenation buffer
+    (join_channels; fused path only — the stock path returns a tensor of its own and the caller's join falls back to torch.cat)."""
     groups = _BN_GROUPS if (bn.training and _BN_GROUPS > 1) else 1
     if groups > 1 and x.shape[0] % groups:
         raise ValueError("bn_replicas(%d): a batch of %d samples does not split into the replicas" % (groups, x.shape[0]))
@@ -188,7 +256,18 @@ def bn_act(x, bn, res=None, relu=True):
         tracked = None
     # (otherwise num_batches_tracked is incremented by the statistics kernel itself: a launch per BatchNorm and pass less)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps, tracked, groups)
+    cat = None
+    if not _JOIN:
+        pass
+    elif (cat_into is not None and cat_into[0].shape[1] >= cat_into[1] + x.shape[1] and cat_into[0].shape[0] == x.shape[0] and
+            cat_into[0].shape[2:] == x.shape[2:]):
+        cat = cat_into
+    elif cat_extra:
+        cat = (_cat_buffer(x.shape, x.shape[1] + int(cat_extra), x.device), 0)
+    y = _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps, tracked, groups, cat)
+    if cat is not None:
+        y._avt_cat = cat
+    return y
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -731,13 +810,16 @@ class _MaxPoolHW(torch.autograd.Function):
     maximum (4 bits per element), the backward gathers the gradient from it."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, cat=None):
         b, c, t, h, w = x.shape
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-        y = torch.empty((b, c, t, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+        if cat is None:
+            y, ldy = torch.empty((b, c, t, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d), 0
+        else:  # the first c channels of a concatenation buffer's rows (join_channels)
+            y, ldy = _alias(cat[0], cat[1], c), cat[0].shape[1]
         tap = torch.empty(y.numel() // 2, dtype=torch.uint8, device=x.device)
         CALLS["maxpool_hip"] += 1
-        _lib.check(_lib.lib().avt_maxpool_train_fwd(_p(x), _p(y), _p(tap), b * t, h, w, c, _stream()), "avt_maxpool_train_fwd")
+        _lib.check(_lib.lib().avt_maxpool_train_fwd(_p(x), _p(y), _p(tap), b * t, h, w, c, ldy, _stream()), "avt_maxpool_train_fwd")
         ctx.save_for_backward(tap)
         ctx.dims = (b, c, t, h, w)
         return y
@@ -746,20 +828,28 @@ class _MaxPoolHW(torch.autograd.Function):
     def backward(ctx, dy):
         (tap,) = ctx.saved_tensors
         b, c, t, h, w = ctx.dims
-        dy = dy.contiguous(memory_format=torch.channels_last_3d)
+        ld_dy = _row_ld(dy)
+        if ld_dy is None:
+            dy, ld_dy = dy.contiguous(memory_format=torch.channels_last_3d), c
         dx = torch.empty((b, c, t, h, w), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last_3d)
-        _lib.check(_lib.lib().avt_maxpool_train_bwd(_p(dy), _p(tap), _p(dx), b * t, h, w, c, _stream()), "avt_maxpool_train_bwd")
-        return dx
+        _lib.check(_lib.lib().avt_maxpool_train_bwd(_p(dy), _p(tap), _p(dx), b * t, h, w, c, ld_dy, _stream()), "avt_maxpool_train_bwd")
+        return dx, None
 
 
-def max_pool_hw(x, pool):
+def max_pool_hw(x, pool, cat_extra=0):
     """pool(x) for the stems' nn.MaxPool3d((1,3,3),(1,2,2),(0,1,1)): the HIP pair above on channels-last fp32 device tensors
-    that carry a gradient in train mode, the module itself otherwise."""
+    that carry a gradient in train mode, the module itself otherwise.  cat_extra: as in bn_act (the HIP path only)."""
     if (_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.requires_grad and x.shape[1] % 4 == 0 and
             x.is_contiguous(memory_format=torch.channels_last_3d) and tuple(pool.kernel_size) == (1, 3, 3) and
             tuple(pool.stride) == (1, 2, 2) and tuple(pool.padding) == (0, 1, 1) and not pool.ceil_mode and
             pool.dilation in (1, (1, 1, 1)) and x.numel() // 4 < (1 << 32)):
-        return _MaxPoolHW.apply(x)
+        if not cat_extra or not _JOIN:
+            return _MaxPoolHW.apply(x)
+        b, c, t, h, w = x.shape
+        cat = (_cat_buffer((b, c, t, (h - 1) // 2 + 1, (w - 1) // 2 + 1), c + int(cat_extra), x.device), 0)
+        y = _MaxPoolHW.apply(x, cat)
+        y._avt_cat = cat
+        return y
     return pool(x)
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 4  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4) */
+#define AVT_ABI_VERSION 5  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4) */
 
 typedef enum {
   AVT_OK = 0,
@@ -447,7 +447,9 @@ int avt_maxpool_hw2s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_h
                                int ldi, int ldo, int plane_dtype, void* stream);
 /* avt_maxpool_hw3s2_ndhwc_bf16 / avt_mean_positions_bf16 on plane pairs (max / sum of the fp32 values hi + lo).
  * frame_idx (round 4, ABI 4; tgroup == 1): NULL, or int32 [bt] on the device: output frame b pools INPUT frame frame_idx[b] —
- * the slow stem ([1,7,7]: no temporal taps) runs once per distinct source frame and the pool hands every (window, slot) its frame. */
+ * the slow stem ([1,7,7]: no temporal taps) runs once per distinct source frame and the pool hands every (window, slot) its frame.
+ * The entries are NOT range-checked on the device (plain global loads): the caller guarantees 0 <= frame_idx[b] < input frames
+ * (ops.clip_pack_frames validates the window starts they are built from). */
 int avt_maxpool_hw3s2_ndhwc_x3(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int bt, int h,
                                int w, int c, int ldi, int ldo, int tgroup, int plane_dtype, const int32_t* frame_idx,
                                void* stream);
@@ -484,14 +486,20 @@ int64_t avt_bn_train_ws_bytes(int64_t m, int c, int groups); /* workspace both c
 /* relu_mask (round 3; may be NULL): m * c / 4 bytes, 4 bits per float4 chunk of the rows — the forward writes where its output
  * is positive, the backward reads it INSTEAD of y (with a shortcut the mask cannot be recomputed from x: a sixteenth of y's bytes
  * in each of the backward's two passes). */
+/* ldy / ld_dy (round 4, ABI 5; 0 = c): floats between consecutive rows of the forward's y / the backward's dy — a channel slice
+ * of a wider row.  SlowFast's lateral fusion concatenates the slow pathway with the fast pathway's lateral convolution
+ * (torch.cat([slow, lateral], 1), the third-party model under train.py:114-141): with the two producers writing their slices of
+ * ONE buffer and their backward passes reading slices of its gradient, neither the concatenation nor the gradient's
+ * .contiguous() copies exist (13 GB of strided copies per config-5 step).  Everything else stays contiguous [m, c]. */
 int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma,
                      const float* beta, float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size,
                      float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                     int64_t* num_batches_tracked /* incremented (by groups) when not NULL */, void* relu_mask, void* stream);
+                     int64_t* num_batches_tracked /* incremented (by groups) when not NULL */, void* relu_mask, int64_t ldy,
+                     void* stream);
 int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma,
                      const float* beta, const float* save_mean, const float* save_invstd, int relu, int groups,
                      const void* relu_mask, void* ws, int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta,
-                     void* stream);
+                     int64_t ld_dy, void* stream);
 
 /* The training form of avt_conv3d_igemm_x3 (csrc/conv_x3.hip, IO32): fp32 NDHWC rows in [batch*t*h*w, ldi], fp32 rows out
  * [M, ldo], no bias / residual / activation — an fp32-grade Conv3d(bias=False) on channels-last tensors for the forward
@@ -564,8 +572,10 @@ int avt_weight_planes_t_f32(const float* w, int cout, int taps, int cin, const i
  * the reference: the third-party SlowFast stem under autograd, train.py:114-141).  fwd: y [bt, ho, wo, c] and `tap`
  * (bt*ho*wo*c/2 bytes: 4 bits per element = which of the 9 taps held the maximum; the first one on ties, a NaN wins — torch's
  * rule).  bwd: dx = the gradient routed to those taps, as a gather (no atomics, fixed order).  c % 4 == 0. */
-int avt_maxpool_train_fwd(const float* x, float* y, void* tap, int bt, int h, int w, int c, void* stream);
-int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx, int bt, int h, int w, int c, void* stream);
+/* ldy / ld_dy (round 4, ABI 5; 0 = c): as for avt_bn_train_*: y / dy as a channel slice of wider rows (the slow stem's pool feeds
+ * the first lateral fusion). */
+int avt_maxpool_train_fwd(const float* x, float* y, void* tap, int bt, int h, int w, int c, int64_t ldy, void* stream);
+int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx, int bt, int h, int w, int c, int64_t ld_dy, void* stream);
 
 /* SuperSloMo interpolation at the jumps of the stitched video (contrastive_video_textures/interpolate.py:75-147, called from
  * validate.py:588-611): the passes around the two UNets, whose convolutions are avt_conv3d_igemm_x3 with relu = 2

@@ -195,3 +195,52 @@ def test_replica_groups_equal_a_loop_over_the_groups(c, dims, groups, res, relu)
     assert int(bn1.num_batches_tracked) == keep[2] == 1
     for p1, p2 in ((bn1.weight.grad, bn2.weight.grad), (bn1.bias.grad, bn2.bias.grad)):
         assert float((p1 - p2).abs().max()) <= 2e-6 * float(p2.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("c_a,c_b,shape,groups,res", [
+    (64, 16, (2, 4, 14, 14), 1, False),    # pool-like producer + lateral
+    (256, 64, (4, 2, 7, 7), 2, True),      # block exit (+ shortcut) + lateral, replica groups
+    (1024, 256, (2, 2, 5, 3), 1, True),    # rows wider than one workgroup (C / 4 > 256) in the first slice
+    (8, 8, (3, 8, 9, 7), 3, False),        # narrow, ragged
+])
+def test_concatenation_without_the_copy_equals_torch_cat(c_a, c_b, shape, groups, res):
+    """The lateral fusion's torch.cat([slow, lateral], 1) with both producers writing slices of one buffer (bn_act cat_extra /
+    cat_into, join_channels) and their backward passes reading slices of its gradient through a leading dimension: the same
+    numbers, bit for bit, as the tensors of their own + torch.cat + contiguous gradients (SlowFast's FuseFastToSlow under
+    train.py:114-141)."""
+    from avtex import train_ops
+    dev = "cuda:0"
+    b, t, h, w = shape
+    torch.manual_seed(c_a + c_b)
+    xa0 = _cl(torch.randn(b, c_a, t, h, w, device=dev) * 1.5 + 0.3)
+    xb0 = _cl(torch.randn(b, c_b, t, h, w, device=dev) - 0.2)
+    r0 = _cl(torch.randn(b, c_a, t, h, w, device=dev)) if res else None
+    gy = _cl(torch.randn(b, c_a + c_b, t, h, w, device=dev))
+    wmix = torch.randn(c_a + c_b, device=dev).view(1, -1, 1, 1, 1)
+
+    def run(join):
+        train_ops._JOIN = join
+        try:
+            bna, bnb = nn.BatchNorm3d(c_a).to(dev).train(), nn.BatchNorm3d(c_b).to(dev).train()
+            xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+            r = r0.clone().requires_grad_(True) if res else None
+            with train_ops.bn_replicas(groups):
+                ya = train_ops.bn_act(xa, bna, res=r, relu=True, cat_extra=c_b)
+                tag = getattr(ya, "_avt_cat", None)
+                assert (tag is not None) == bool(join)
+                yb = train_ops.bn_act(xb, bnb, relu=True, cat_into=None if tag is None else (tag[0], c_a))
+            z = train_ops.join_channels(ya, yb)
+            assert z.is_contiguous(memory_format=torch.channels_last_3d)
+            if join:
+                assert z.data_ptr() == ya.data_ptr() and yb.data_ptr() == ya.data_ptr() + 4 * c_a  # no copy was made
+            (z * wmix).backward(gy)  # (a consumer whose gradient is a fresh contiguous tensor, as a convolution's is)
+            return (z.detach().clone(), xa.grad, xb.grad, None if r is None else r.grad, bna.weight.grad, bna.bias.grad, bnb.weight.grad,
+                    bnb.bias.grad, bna.running_mean.clone(), bnb.running_var.clone())
+        finally:
+            train_ops._JOIN = 1
+
+    a, e = run(1), run(0)
+    for u, v in zip(a, e):
+        assert (u is None) == (v is None)
+        if u is not None:
+            assert torch.equal(u, v)

@@ -372,6 +372,51 @@ def test_stem_max_pool_forward_and_gradient_equal_torch(dims, c):
     assert train_ops.max_pool_hw(x0, pool).shape == yb.shape and train_ops.CALLS["maxpool_hip"] == before + 1  # no gradient: the module
 
 
+@pytest.mark.parametrize("dims,c,extra", [((2, 3, 12, 12), 8, 4), ((1, 2, 11, 9), 64, 16)])
+def test_stem_max_pool_writes_the_first_slice_of_a_concatenation(dims, c, extra):
+    """max_pool_hw(cat_extra): the pooled rows as the first c channels of c + extra wide rows (the slow stem's pool feeds the first
+    lateral fusion, train_ops.join_channels), and its backward reading a slice of the concatenation's gradient: bit-equal to the
+    pool's own tensor + torch.cat + a contiguous gradient."""
+    from avtex import train_ops
+    torch.manual_seed(dims[3])
+    b, t, h, w = dims
+    x0 = torch.relu(torch.randn(b, c, t, h, w, device=DEV)).contiguous(memory_format=torch.channels_last_3d)
+    pool = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    lat0 = _cl(torch.randn(b, extra, t, ho, wo, device=DEV))
+    gy = _cl(torch.randn(b, c + extra, t, ho, wo, device=DEV))
+
+    def run(join):
+        x, lat = x0.clone().requires_grad_(True), lat0.clone().requires_grad_(True)
+        if join:
+            y = train_ops.max_pool_hw(x, pool, cat_extra=extra)
+            buf, off = y._avt_cat
+            assert off == 0 and buf.shape[1] == c + extra and y.data_ptr() == buf.data_ptr()
+
+            class Fill(torch.autograd.Function):  # stands for the lateral BatchNorm: writes the other slice of the buffer
+                @staticmethod
+                def forward(ctx, v):
+                    o = train_ops._alias(buf, c, extra)
+                    o.copy_(v)
+                    return o
+
+                @staticmethod
+                def backward(ctx, d):
+                    return d.contiguous(memory_format=torch.channels_last_3d)
+
+            yl = Fill.apply(lat)
+            yl._avt_cat = (buf, c)
+            z = train_ops.join_channels(y, yl)
+            assert z.data_ptr() == buf.data_ptr()
+        else:
+            z = torch.cat([train_ops.max_pool_hw(x, pool), lat], 1)
+        (z * 1.5).backward(gy)
+        return z.detach().clone(), x.grad, lat.grad
+
+    for u, v in zip(run(True), run(False)):
+        assert torch.equal(u, v)
+
+
 def test_vggish_training_convolutions_run_on_the_hand_written_kernels(avt, dev):
     """The m = 2 training branch's audio encoder (reference models/models.py:343-345, 405-407; VERDICT r3 'missing' #6): VGGish's six
     Conv2d forward / input gradient / weight gradient through train_ops.conv2d (the image as a one-frame clip) against the stock

@@ -169,3 +169,49 @@ def test_items_as_one_batch_equal_the_loop_over_items(avt, dev):
     b1 = dict(m1.named_buffers())
     worst = max(float((b1[k].float() - b2[k].float()).abs().max()) / (float(b2[k].float().abs().max()) + 1e-12) for k in b2)
     assert worst < 1e-5, worst
+
+
+def test_lateral_fusions_concatenate_without_copies_and_give_the_same_step(avt, dev):
+    """The four lateral fusions of a SlowFast encoder in train mode: the slow pathway's producers and the lateral BatchNorms write
+    slices of one buffer, the gradient slices are read in place (train_ops.join_channels) — same embeddings and the same
+    gradients (up to the weight-gradient kernels' atomic summation order) as torch.cat + contiguous gradient copies; and no torch.cat runs inside the encoder."""
+    from avtex import synth, train_ops
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(1)
+    base = SlowFast()
+    synth.randomise_bn(base, 2, 0.0)
+    base = base.to(dev).train().to(memory_format=torch.channels_last_3d)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    slow = torch.randn(2, 3, 8, 64, 64, generator=g).to(dev)
+    fast = torch.randn(2, 3, 32, 64, 64, generator=g).to(dev)
+
+    def step(join):
+        train_ops._JOIN = join
+        cats = []
+        real_cat = torch.cat
+
+        def spy(ts, dim=0, **k):
+            cats.append(tuple(ts[0].shape))
+            return real_cat(ts, dim, **k)
+
+        torch.cat = spy
+        try:
+            m = copy.deepcopy(base)
+            with train_ops.bn_replicas(2):
+                z = m([slow, fast])
+            (z * torch.linspace(-1, 1, z.shape[1], device=dev)).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            torch.cat = real_cat
+            train_ops._JOIN = 1
+        return z.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, [c for c in cats if len(c) == 5 and c[0] == 2 and c[3] > 1]  # (activations of the 2-clip batch before the head's pooled
+        # concatenation; weight-shaped concatenations are the plane builders')
+
+    z1, g1, cats1 = step(1)
+    z0, g0, cats0 = step(0)
+    assert len(cats0) == 4 and cats1 == [], (cats0, cats1)  # the four fusions: copies without the buffer protocol, none with it
+    assert torch.equal(z1, z0)
+    assert set(g1) == set(g0)
+    for k in g0:  # (the weight-gradient kernels add their K-slices with fp32 atomics: equal up to that order)
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-5 * float(g0[k].abs().max()) + 1e-12, k
