@@ -89,7 +89,8 @@ def save_video_raw(frames_u8, outfile, fps, audio_file=""):
         raise ValueError("save_video_raw expects uint8 [n, H, W, 3]")
     arr = v.contiguous().cpu().numpy()
     if shutil.which("ffmpeg") is None:
-        np.savez_compressed(os.path.splitext(outfile)[0] + ".npz", video=arr, fps=float(fps))
+        # (stored, not deflated: zlib took 4 of the 9.5 s of an at-size validate() run — tools/r04_runs/gpu_r04_e2e_profile.sh)
+        np.savez(os.path.splitext(outfile)[0] + ".npz", video=arr, fps=float(fps))
         print("save_video_raw: ffmpeg not found; wrote {}.npz".format(os.path.splitext(outfile)[0]))
         return False
     n, h, w, _ = arr.shape
