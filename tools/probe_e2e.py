@@ -27,7 +27,7 @@ model = avt.ContrastivePredictionTemporal(q_mod, t_mod, None, 1, 128, 0.1, W, S,
 args = SimpleNamespace(vdata=None, adata=None, dadata=None, subsample_rate=1, fps=fps, stride=S, window=W, enc_arch="slowfast",
                        img_size=224, model_type=1, mini_batchsize=100, threshold=0.3, alpha=0.5, temp=0.1, driving_audio=None,
                        da_feats="VGG", interpolation=True, SF=5, slomo_ckpt="random", new_video_length=30, results_folder="/tmp/avt_e2e",
-                       logname="e2e", batch_size=8, stitch_mode="aligned", enc_batch=64, enc_impl="mfma", enc_dtype="fp32", frames_bar=False)
+                       logname="e2e", batch_size=8, stitch_mode="aligned", enc_batch=249, enc_impl="mfma", enc_dtype="fp32", frames_bar=False)
 np.random.seed(0)
 torch.cuda.synchronize()
 t0 = time.time()
