@@ -485,3 +485,29 @@ def test_committed_pmc_summary_resolves_the_headline_kernels_traffic():
     bench.attach_pmc_traffic(kern, args, "f16x3")
     missing = [k["kernel"] for k in kern if not k.get("traffic")]
     assert not missing, missing
+
+
+def test_concatenation_protocol_host_side(avt):
+    """train_ops.join_channels / _row_ld / _alias (the in-place lateral fusion of the training step): on the CPU — where no
+    producer tags its output — the join is torch.cat; the row-pitch detector accepts channel slices of channels-last tensors
+    and contiguous ones, and refuses anything else; an alias shares storage without being an autograd view."""
+    from avtex import train_ops
+
+    a, b = torch.randn(2, 8, 3, 4, 5), torch.randn(2, 4, 3, 4, 5)
+    assert torch.equal(train_ops.join_channels(a, b), torch.cat([a, b], 1))
+    buf = torch.zeros((2, 12, 3, 4, 5)).contiguous(memory_format=torch.channels_last_3d)
+    assert train_ops._row_ld(buf) == 12 and train_ops._row_ld(buf[:, :8]) == 12 and train_ops._row_ld(buf[:, 8:]) == 12
+    assert train_ops._row_ld(torch.zeros(2, 12, 3, 4, 5)) is None            # NCDHW memory
+    assert train_ops._row_ld(buf[:, :, :, ::2]) is None                       # rows without a constant pitch
+    assert train_ops._row_ld(buf[:, 2:10]) is None                            # a slice that is not 16-byte aligned
+    assert train_ops._row_ld(buf.double()) is None
+    one = torch.zeros((1, 16, 1, 1, 7)).contiguous(memory_format=torch.channels_last_3d)
+    assert train_ops._row_ld(one[:, :8]) == 16                                # size-1 dimensions: their strides do not matter
+    y = train_ops._alias(buf, 8, 4)
+    assert y._base is None and y.shape == (2, 4, 3, 4, 5) and y.data_ptr() == buf.data_ptr() + 8 * 4
+    y.fill_(1.0)
+    assert float(buf[:, 8:].sum()) == y.numel() and float(buf[:, :8].abs().sum()) == 0.0
+    # tags that do not describe the two halves of one buffer fall back to the copy
+    a2, b2 = train_ops._alias(buf, 0, 8), torch.randn(2, 4, 3, 4, 5)
+    a2._avt_cat, b2._avt_cat = (buf, 0), (torch.zeros_like(buf), 8)
+    assert torch.equal(train_ops.join_channels(a2, b2), torch.cat([a2, b2], 1))
