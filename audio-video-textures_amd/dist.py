@@ -50,7 +50,14 @@ def all_gather_rows(local, n_total, group=None):
         pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         pad[: local.shape[0]] = local
     out = torch.empty((world * width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # device rows under a gloo group (several ranks SHARING one GPU: the sharded path with the real kernels on a one-GPU
+        # box — tests/test_gpu_e2e.py; RCCL refuses two ranks on one device): gloo gathers host tensors, staged here
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, pad.contiguous().cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
     if all(hi - lo == width for lo, hi in sizes):
         return out
     return torch.cat([out[r * width : r * width + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
@@ -65,11 +72,22 @@ def gather_to_root(local, n_total, group=None, root=0):
     return full if dist.get_rank(group) == root else None
 
 
+def _all_reduce_max(t):
+    """In-place MAX over the ranks (device tensors under a gloo group travel through the host, as in all_gather_rows)."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
 def barrier_max_time(seconds, device):
     """Max over ranks of a local wall time (bench contract)."""
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _all_reduce_max(t)
     return float(t.item())
 
 
@@ -120,7 +138,7 @@ def sharded_survivors(encode_block, n_total, threshold, compute, rank=0, world=1
     sel = compute.select(sim, q_ids, threshold, n_total)
     kmax = sel["cnt"].max().to(torch.int64).reshape(1) if hi > lo else torch.zeros(1, dtype=torch.int64, device=sim.device)
     if dist.is_initialized():
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        _all_reduce_max(kmax)
     k = max(int(kmax.item()), 1)
     out = {}
     for key in ("idx", "seg", "p"):

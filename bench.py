@@ -594,6 +594,9 @@ def build_parser():
     ap.add_argument("--train-pass-items", type=int, default=0,
                     help="--mode train: items per forward/backward pass (0 = all of the rank's items as one batch with per-item "
                          "BatchNorm groups; 1 = one pass per item, round 2's loop)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend under torch.distributed.run: nccl = RCCL over xGMI, one GPU per rank (default); gloo = the "
+                         "ranks may share a GPU and the exchange is staged through the host (the N > 1 path on a one-GPU box: tests)")
     ap.add_argument("--item-streams", type=int, default=1,
                     help="--mode train: streams the items of a step alternate between (2: forward of item k+1 under backward of item k)")
     ap.add_argument("--no-grad-accumulator", dest="grad_accumulator", action="store_false",
@@ -628,9 +631,10 @@ def main():
     import avtex
     from avtex import dist as adist, ops
 
-    rank, world, local = adist.init_from_env()
+    rank, world, local = adist.init_from_env(backend=None if args.dist_backend == "nccl" else args.dist_backend)
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d (plain `python bench.py --gpus N` launches its own ranks)" % (world, args.gpus)
-    dev = torch.device("cuda", local)
+    # (--dist-backend gloo: the ranks may share a GPU — the N > 1 path of this script on a one-GPU box; RCCL ranks own one each)
+    dev = torch.device("cuda", local % torch.cuda.device_count() if args.dist_backend == "gloo" else local)
     torch.cuda.set_device(dev)
     # MIOpen find mode (the reference sets it, main.py:421) only where MIOpen is what is measured: the BatchNorm calibration and
     # the fp32 reference tables of the precision block run a handful of untimed forwards, and an exhaustive solver search there
@@ -640,10 +644,10 @@ def main():
     # what a SCALE record needs to be self-verifying: the number of ranks RCCL itself saw (a real all-reduce of ones over xGMI)
     rccl_ranks = None
     if torch.distributed.is_initialized():
-        one = torch.ones(1, device=dev)
+        one = torch.ones(1, device=dev if args.dist_backend == "nccl" else "cpu")
         torch.distributed.all_reduce(one)
         rccl_ranks = int(one.item())
-        assert rccl_ranks == world, "RCCL all-reduce saw %d ranks, WORLD_SIZE is %d" % (rccl_ranks, world)
+        assert rccl_ranks == world, "the all-reduce saw %d ranks, WORLD_SIZE is %d" % (rccl_ranks, world)
     if args.mode == "train":
         line = train_bench(args, rank, world, dev)
         if rank == 0:
@@ -687,8 +691,8 @@ def main():
         "roofline": roof, "nxn_build_ms": main_res["nxn_build_ms"], "survivors_per_row": main_res["survivors_per_row"],
         "survivors_per_row_th0": main_res["survivors_per_row_th0"], "survivor_fraction": main_res["survivor_fraction"],
     }
-    if rccl_ranks is not None:  # a process group exists: the exchange ran over RCCL
-        out["rccl_ranks"], out["allgather_ms"] = rccl_ranks, main_res["allgather_ms"]
+    if rccl_ranks is not None:  # a process group exists: the exchange ran over RCCL (or, --dist-backend gloo, through the host)
+        out["rccl_ranks" if args.dist_backend == "nccl" else "gloo_ranks"], out["allgather_ms"] = rccl_ranks, main_res["allgather_ms"]
         out["allgather_bytes_per_rank"] = N * D * (4 if args.sim_precision == "f32" else (4 if args.sim_precision == "bf16x3" else 2))
     if args.config == 4 or args.topk:
         out["config"]["baseline_config"] = args.config

@@ -159,10 +159,10 @@ from avtex import dist as adist, synth
 from avtex.validate import validate
 sys.path.insert(0, os.path.join(%(root)r, "tests"))
 from test_gpu_e2e import _args, _encoders, W, S, FPS
-rank, world, local = adist.init_from_env()
-dev = torch.device("cuda", local)
+rank, world, local = adist.init_from_env(backend=os.environ.get("AVT_TEST_BACKEND") or None)
+dev = torch.device("cuda", local %% torch.cuda.device_count())  # (gloo ranks may share one GPU; RCCL ranks have one each)
 torch.cuda.set_device(dev)
-n = 256
+n = int(os.environ.get("AVT_TEST_WINDOWS", "256"))
 video = synth.structured_video(11, n * S + W + 1, 128, 128, variety=1)
 import test_gpu_e2e
 test_gpu_e2e.L = n
@@ -198,3 +198,43 @@ def test_validate_world2_over_rccl_equals_world1(dev, tmp_path):
     two = frames_of(_run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29533", str(script)]))
     assert one == two and len(one) >= 150
+
+
+def test_validate_two_ranks_sharing_one_gpu_equal_one_rank(dev, tmp_path):
+    """The sharded validate() path with the REAL kernels on a one-GPU box: two ranks under a gloo group share cuda:0 (RCCL
+    refuses two ranks on a device; gloo carries the exchange through the host, avtex.dist.all_gather_rows) — index blocks,
+    the all-gather of T_hat, row blocks of the similarity + select, survivors to rank 0 — and rank 0 walks the same frames
+    list as a single process.  What the two-GPU RCCL test above checks, minus RCCL itself, where a second GPU is absent
+    (reference: the DataParallel scatter / gather of validate.py:320, 349-363, 442-445)."""
+    import json
+
+    script = tmp_path / "world.py"
+    script.write_text(_WORLD_SCRIPT % {"root": ROOT})
+
+    def frames_of(r):
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("FRAMES ")][-1][7:])
+
+    small = {"AVT_TEST_WINDOWS": "96"}
+    one = frames_of(_run([sys.executable, str(script)], small))
+    two = frames_of(_run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29541", str(script)], dict(small, AVT_TEST_BACKEND="gloo")))
+    assert one == two and len(one) >= 150
+
+
+def test_bench_self_launch_two_ranks_sharing_one_gpu(dev):
+    """`python bench.py --gpus 2 --dist-backend gloo` on a one-GPU box: bench starts its own two ranks (children of
+    torch.distributed.run), both on cuda:0, shards 2 x 128 windows, exchanges T_hat (staged through the host under gloo),
+    takes the max-over-ranks time and rank 0 prints ONE line that names the world it ran in — the N > 1 control flow of the
+    bench contract with the real kernels, where the RCCL form above needs a second GPU."""
+    import json
+
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--windows", "128", "--steps", "1", "--warmup", "1",
+              "--enc-batch", "64", "--no-fast", "--no-train-leg", "--no-cpu-baseline", "--no-nxn-legs", "--no-precision-block"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["gloo_ranks"] == 2 and "rccl_ranks" not in line
+    assert line["config"]["windows_total"] == 256 and line["config"]["windows_per_gpu"] == 128
+    assert line["allgather_ms"] is not None and line["allgather_ms"] > 0 and line["value"] > 0 and line["scaling"] == "weak"
