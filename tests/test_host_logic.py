@@ -363,7 +363,9 @@ def test_cli_and_bench_usage_text_renders(avt):
     p = avt.main.build_parser() if hasattr(avt, "main") else __import__("avtex.main", fromlist=["x"]).build_parser()
     assert "--enc_batch" in p.format_help()
     text = _load_bench().build_parser().format_help()
-    assert "--enc-batch" in text and "--config" in text
+    assert "--enc-batch" in text and "--config" in text and "--dist-backend" in text
+    a = _load_bench().build_parser().parse_args([])
+    assert a.dist_backend == "nccl" and a.gpus == 1  # RCCL unless asked otherwise
 
 
 def test_bench_config4_is_one_flag(monkeypatch):
