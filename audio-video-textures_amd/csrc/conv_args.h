@@ -66,6 +66,8 @@ struct ConvArgs {
   uint16_t* out_lo;
   const float* wscale;  // per-output-channel power-of-two factor applied to the accumulator (fp16 planes: weights are stored
                         // pre-scaled into the fp16 normal range), or NULL
+  int cf_ofs;           // x3 kernels: LDS byte offset of the tile's [bias BN | scale BN] floats (set by the launchers; filled in the
+                        // prologue, read by the epilogue from LDS instead of one global load per accumulator group)
 };
 
 

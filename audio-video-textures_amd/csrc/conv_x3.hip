@@ -290,6 +290,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       *reinterpret_cast<i32x4*>(lds + B_LO + o) = rbl[u];
     }
   };
+  // the tile's bias / scale, once, into LDS behind everything else (the epilogue used to fetch them from global memory one
+  // accumulator group at a time: a chain of L2 round trips per tile, each wait also sitting out earlier stores)
+  float* cfl = reinterpret_cast<float*>(lds + a.cf_ofs);
+  for (int i = tid; i < 2 * BN; i += 256) {
+    const int n = n0 + (i < BN ? i : i - BN);
+    float v = i < BN ? 0.0f : 1.0f;
+    if (n < a.Cout) {
+      if (i < BN) { if (a.bias) v = a.bias[n]; } else if (a.wscale) v = a.wscale[n];
+    }
+    cfl[i] = v;
+  }
   __syncthreads();
   STAMP_BEGIN();
   gload(0);
@@ -330,9 +341,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nl = wn * WN + i * 32 + 8 * g + 4 * lh;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (a.bias && n0 + nl < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
-      if (a.wscale && n0 + nl < a.Cout) sv = *reinterpret_cast<const float4*>(a.wscale + n0 + nl);  // exact powers of two
+      const float4 bv = *reinterpret_cast<const float4*>(cfl + nl);
+      const float4 sv = *reinterpret_cast<const float4*>(cfl + BN + nl);  // exact powers of two
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         float4 v;
@@ -593,6 +603,16 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       }
   };
 
+  // the tile's 256 bias / scale values, once, into LDS behind the stages and the table (see the epilogue)
+  float* cfl = reinterpret_cast<float*>(lds + a.cf_ofs);
+  {
+    const int n = n0 + (tid & 255);
+    float v = tid < 256 ? 0.0f : 1.0f;
+    if (n < a.Cout) {
+      if (tid < 256) { if (a.bias) v = a.bias[n]; } else if (a.wscale) v = a.wscale[n];
+    }
+    cfl[tid] = v;
+  }
   __syncthreads();
   STAMP_BEGIN();
   gprep(0);
@@ -685,10 +705,11 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = i * 32 + 8 * g + 4 * lh;  // column inside the slab
-        const int ng = n0 + pass * 64 + nl;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (a.bias && ng < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + ng);
-        if (a.wscale && ng < a.Cout) sv = *reinterpret_cast<const float4*>(a.wscale + ng);
+        // (from LDS, filled in the prologue.  Fetched from global memory here, each (i, g) pair waited for its own two loads —
+        //  eight L2 round trips in a row, and the first wait (vmcnt counts stores too) also sat out the previous slab's stores:
+        //  ~4.7 us per pass with six waves idle at the barrier, 19 us per tile = 45 % of a K = 512 layer's workgroup time)
+        const float4 bv = *reinterpret_cast<const float4*>(cfl + pass * 64 + nl);
+        const float4 sv = *reinterpret_cast<const float4*>(cfl + 256 + pass * 64 + nl);
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
           float4 v;
@@ -777,8 +798,9 @@ int launch_x3_xl(ConvArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.Cout + 255) / 256;
   a.nblk = tiles_m * a.tiles_n;
-  constexpr int lds_max = 2 * 4 * 256 * 64 + kMaxTabSteps * 64;
-  const int lds_bytes = lds_max;  // (the epilogue's second staging buffer reaches into the table area)
+  constexpr int lds_max = 2 * 4 * 256 * 64 + kMaxTabSteps * 64 + 2 * 256 * 4;
+  const int lds_bytes = lds_max;  // (the epilogue's second staging buffer reaches into the table area; then bias | scale)
+  a.cf_ofs = lds_max - 2 * 256 * 4;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16, IO32>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
@@ -796,11 +818,14 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
   a.nblk = tiles_m * a.tiles_n;
   // operand slabs + the tap table of THIS layer (not the 128-step maximum): the wide tile then needs 73.7 + <= 6 KB for
   // every K loop of up to 96 steps, so two workgroups (2 waves per SIMD) share a CU's 160 KB
-  constexpr int lds_max = 2 * (BM + BN) * LSTR + kMaxTabSteps * 64;
+  constexpr int epi_bytes = BM * (BN * 4 + 16);
+  constexpr int opnd_max = 2 * (BM + BN) * LSTR + kMaxTabSteps * 64;
+  constexpr int lds_max = (opnd_max > epi_bytes ? opnd_max : epi_bytes) + 2 * BN * 4;
   const int tab_bytes = (a.nk <= kMaxTabSteps ? a.nk : 0) * 64;
   int lds_bytes = 2 * (BM + BN) * LSTR + tab_bytes;
-  constexpr int epi_bytes = BM * (BN * 4 + 16);
   if (lds_bytes < epi_bytes) lds_bytes = epi_bytes;
+  a.cf_ofs = lds_bytes;       // the tile's bias | scale floats behind the operand slabs / the table / the epilogue staging
+  lds_bytes += 2 * BN * 4;
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<BM, BN, WTM, F16, IO32>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
