@@ -32,6 +32,8 @@
 // itself, so enforcing the alternation trades the free-running form's fine-grained sharing of the pipe for barrier bubbles.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "avt_common.h"
 #include "conv_args.h"
 #include "split_planes.h"
@@ -435,8 +437,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   constexpr int AU = BM / 128, BU = BN / 128;              // 16-byte chunks per thread, plane and K-step
   constexpr int PL = BM * 64;                              // bytes of one operand plane in a stage (BM == BN)
   constexpr int STG = 4 * PL;                              // A hi | A lo | B hi | B lo
-  constexpr int ESTR = 64 * 4 + 16;                        // epilogue staging row stride: one 64-column slab in fp32
-  static_assert(BM * ESTR <= 2 * STG, "epilogue staging fits the operand stages");
+  constexpr int ESTR = BN * 4 + 16;                        // epilogue staging row stride: a slab row = all 256 columns in fp32
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   const int swz = avt::xcd_contiguous(blockIdx.x, a.nblk);
@@ -689,40 +690,46 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
     fmul(f1, NPIECE, false, lds);
   }
 
-  // ---- epilogue: one 64-column slab per pass, staged in fp32 in one of TWO buffers (the operand stages + the table area are
-  // free now): the waves of column block p + 1 write their accumulators while every thread splits and stores slab p — one
-  // barrier per pass instead of two, and the stores of a slab run under the next slab's LDS writes
-  constexpr int CPR = 8;                       // 8-channel chunks per slab row
-  constexpr int EU = (BM * CPR) / NTHR;        // 4 chunks per thread and pass
-  constexpr int EBUF = BM * ESTR;
+  // ---- epilogue: one 64-ROW slab (all 256 columns) per pass, staged in fp32 in one of TWO buffers (the operand stages + the
+  // table area are free now): while every thread splits and stores slab p, the FOUR waves that own rows 64 (p + 1) .. of the
+  // tile write their accumulators for slab p + 1 — one barrier per pass.  (Round 4: the slabs used to be 64 COLUMNS wide, owned by
+  // the two waves wid = wn and wn + 4 — which share a SIMD — so a pass waited for ~1000 VALU instructions of staging on one SIMD
+  // with the other three idle at the barrier: 7.6 k cycles per pass, 30 k per tile, profiles/r04/probe_xl_stamps_epilogue.log.
+  // A row slab is staged by the waves wid = 4 wm .. 4 wm + 3, one per SIMD, half of their accumulators each, and a slab row is
+  // 512 contiguous bytes per plane in the output instead of 128.)
+  constexpr int SR = 64;                       // rows per slab
+  constexpr int CPR = BN / 8;                  // 32 eight-channel chunks per slab row
+  constexpr int EU = (SR * CPR) / NTHR;        // 4 chunks per thread and pass
+  constexpr int EBUF = SR * ESTR;
   static_assert(2 * EBUF <= 2 * STG + kMaxTabSteps * 64, "two staging buffers fit the operand stages + the table area");
   const bool has_res = !IO32 && a.res != nullptr;  // (IO32: `res` is an fp32 tensor added in the store loop)
-  auto stage_slab = [&](int pass) {  // the two waves rows x this column block write their 128 x 64 accumulators
+  auto stage_slab = [&](auto half, int pass) {  // rows 64 pass .. + 63 = row tiles j = 2 half, 2 half + 1 of the waves wm = pass >> 1
+    constexpr int H = decltype(half)::value;
     char* eb = lds + (pass & 1) * EBUF;
     // D layout: column (lane & 31) = m, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = n
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nl = i * 32 + 8 * g + 4 * lh;  // column inside the slab
+        const int nl = wn * 64 + i * 32 + 8 * g + 4 * lh;  // column inside the tile
         // (from LDS, filled in the prologue.  Fetched from global memory here, each (i, g) pair waited for its own two loads —
-        //  eight L2 round trips in a row, and the first wait (vmcnt counts stores too) also sat out the previous slab's stores:
-        //  ~4.7 us per pass with six waves idle at the barrier, 19 us per tile = 45 % of a K = 512 layer's workgroup time)
-        const float4 bv = *reinterpret_cast<const float4*>(cfl + pass * 64 + nl);
-        const float4 sv = *reinterpret_cast<const float4*>(cfl + 256 + pass * 64 + nl);
+        //  eight L2 round trips in a row, and the first wait (vmcnt counts stores too) also sat out the previous slab's stores)
+        const float4 bv = *reinterpret_cast<const float4*>(cfl + nl);
+        const float4 sv = *reinterpret_cast<const float4*>(cfl + 256 + nl);
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * H + jj;
           float4 v;
           v.x = acc[i][j][4 * g + 0] * sv.x + bv.x;
           v.y = acc[i][j][4 * g + 1] * sv.y + bv.y;
           v.z = acc[i][j][4 * g + 2] * sv.z + bv.z;
           v.w = acc[i][j][4 * g + 3] * sv.w + bv.w;
-          const int ml = wm * 128 + j * 32 + lr;
-          *reinterpret_cast<float4*>(eb + ml * ESTR + nl * 4) = v;
+          const int rl = jj * 32 + lr;  // row inside the slab
+          *reinterpret_cast<float4*>(eb + rl * ESTR + nl * 4) = v;
         }
       }
   };
-  if (wn == 0) stage_slab(0);
+  if (wm == 0) stage_slab(std::integral_constant<int, 0>{}, 0);
   __syncthreads();
 #pragma unroll 1
   for (int pass = 0; pass < 4; ++pass) {
@@ -732,18 +739,21 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
 #pragma unroll
       for (int u = 0; u < EU; ++u) {
         const int c = tid + NTHR * u;
-        const int m = m0 + c / CPR, n = n0 + pass * 64 + (c % CPR) * 8;
+        const int m = m0 + pass * SR + c / CPR, n = n0 + (c % CPR) * 8;
         const bool ok = m < a.M && n < a.Cout;
         rrh[u] = ok ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
         rrl[u] = ok ? *reinterpret_cast<const uint4*>(a.res_lo + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
       }
     }
-    if (pass + 1 < 4 && wn == pass + 1) stage_slab(pass + 1);  // into the other buffer (its last readers passed the barrier below)
+    if (pass + 1 < 4 && wm == ((pass + 1) >> 1)) {  // into the other buffer (its last readers passed the barrier below)
+      if ((pass + 1) & 1) stage_slab(std::integral_constant<int, 1>{}, pass + 1);
+      else stage_slab(std::integral_constant<int, 0>{}, pass + 1);
+    }
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       const int c = tid + NTHR * u;
       const int row = c / CPR, cc = c % CPR;
-      const int m = m0 + row, n = n0 + pass * 64 + cc * 8;
+      const int m = m0 + pass * SR + row, n = n0 + cc * 8;
       if (m < a.M && n < a.Cout) {
         const float4 v0 = *reinterpret_cast<const float4*>(eb + row * ESTR + cc * 32);
         const float4 v1 = *reinterpret_cast<const float4*>(eb + row * ESTR + cc * 32 + 16);
