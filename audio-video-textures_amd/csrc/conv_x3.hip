@@ -52,9 +52,20 @@ namespace {
 #define AVT_DBG_CONST 0
 #endif
 #define DBG_SKIP(bit) (((AVT_DBG_CONST) & (bit)) != 0)
+// -DAVT_STAMP_EPI (STAMP_EXTRA of `make stamp`): the XL tile's slots 1..4 time the EPILOGUE's sub-phases instead of the K loop's
+// (1 first slab staged + barrier, 2 residual requests + staging of the next slab, 3 LDS reads / split / stores, 4 barrier)
+#ifdef AVT_STAMP_EPI
+#define KSTAMP(i) STAMP(0)
+#define EPI_STAMP(i) STAMP(i)
+#else
+#define KSTAMP(i) STAMP(i)
+#define EPI_STAMP(i)
+#endif
 #else
 #define STAMP_BEGIN()
 #define STAMP(i)
+#define KSTAMP(i)
+#define EPI_STAMP(i)
 #define STAMP_END()
 #define DBG_SKIP(bit) false
 #endif
@@ -677,15 +688,15 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       if (more) gcalc(kt + 1, e);
       __builtin_amdgcn_sched_barrier(0);
       fmul(f1, 0, more, nst);  // second slice of stage kt - 1 + the DMA of stage kt + 1
-      STAMP(1);
+      KSTAMP(1);
       fload(f1, cur, 1);
       __builtin_amdgcn_sched_barrier(0);
       fmul(f0, NPIECE, false, nst);  // first slice of stage kt
-      STAMP(2);
+      KSTAMP(2);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // own DMA pieces landed, own reads of stage kt done
-      STAMP(3);
+      KSTAMP(3);
       __syncthreads();
-      STAMP(4);
+      KSTAMP(4);
     }
     fmul(f1, NPIECE, false, lds);
   }
@@ -729,8 +740,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         }
       }
   };
+  KSTAMP(5);  // (the last k-slice's MFMAs)
   if (wm == 0) stage_slab(std::integral_constant<int, 0>{}, 0);
   __syncthreads();
+  EPI_STAMP(1);
 #pragma unroll 1
   for (int pass = 0; pass < 4; ++pass) {
     const char* eb = lds + (pass & 1) * EBUF;
@@ -749,6 +762,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       if ((pass + 1) & 1) stage_slab(std::integral_constant<int, 1>{}, pass + 1);
       else stage_slab(std::integral_constant<int, 0>{}, pass + 1);
     }
+    EPI_STAMP(2);
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       const int c = tid + NTHR * u;
@@ -798,7 +812,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         }
       }
     }
+    EPI_STAMP(3);
     __syncthreads();  // slab pass + 1 is staged; buffer pass & 1 is free for slab pass + 2
+    EPI_STAMP(4);
   }
   STAMP_END();
 }
