@@ -391,10 +391,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = avt::relu_keep_nan(v[i]);
         uint4 oh, ol;
-        avt::split2<F16>(v[0], v[1], oh.x, ol.x);
-        avt::split2<F16>(v[2], v[3], oh.y, ol.y);
-        avt::split2<F16>(v[4], v[5], oh.z, ol.z);
-        avt::split2<F16>(v[6], v[7], oh.w, ol.w);
+        if constexpr (!FIRST && !STR) {
+          avt::split8<F16>(v, oh, ol);  // one wave-wide range test per 8 values: -6..7 % on the identity blocks ...
+        } else {  // ... and +8..23 % on the first / strided blocks (profiles/r04/split8_ab.log): they keep the per-pair form
+          avt::split2<F16>(v[0], v[1], oh.x, ol.x);
+          avt::split2<F16>(v[2], v[3], oh.y, ol.y);
+          avt::split2<F16>(v[4], v[5], oh.z, ol.z);
+          avt::split2<F16>(v[6], v[7], oh.w, ol.w);
+        }
         const int off = (int)(c_out[it] != kOob ? obase + c_out[it] + (unsigned)(np * 64) : kOob);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, oh), roh, off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ol), rol, off, 0, 0);

@@ -285,10 +285,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
         const float* fa = reinterpret_cast<const float*>(&rah[u]);
         const float* fb = reinterpret_cast<const float*>(&ral[u]);
         uint4 h, l;
-        avt::split2<F16>(fa[0], fa[1], h.x, l.x);
-        avt::split2<F16>(fa[2], fa[3], h.y, l.y);
-        avt::split2<F16>(fb[0], fb[1], h.z, l.z);
-        avt::split2<F16>(fb[2], fb[3], h.w, l.w);
+        const float f8[8] = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
+        avt::split8<F16>(f8, h, l);
         *reinterpret_cast<uint4*>(lds + o) = h;
         *reinterpret_cast<uint4*>(lds + A_LO + o) = l;
       } else {
@@ -410,10 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
         __builtin_nontemporal_store(f32x4n{x[4], x[5], x[6], x[7]}, reinterpret_cast<f32x4n*>(of + 4));
       } else {
         uint4 oh, ol;
-        avt::split2<F16>(x[0], x[1], oh.x, ol.x);
-        avt::split2<F16>(x[2], x[3], oh.y, ol.y);
-        avt::split2<F16>(x[4], x[5], oh.z, ol.z);
-        avt::split2<F16>(x[6], x[7], oh.w, ol.w);
+        avt::split8<F16>(x, oh, ol);
         *reinterpret_cast<uint4*>(a.out + o) = oh;
         *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
       }
@@ -567,10 +562,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         const float* fa = reinterpret_cast<const float*>(&ra[u][0]);
         const float* fb = reinterpret_cast<const float*>(&ra[u][1]);
         uint4 h, l;
-        avt::split2<F16>(fa[0], fa[1], h.x, l.x);
-        avt::split2<F16>(fa[2], fa[3], h.y, l.y);
-        avt::split2<F16>(fb[0], fb[1], h.z, l.z);
-        avt::split2<F16>(fb[2], fb[3], h.w, l.w);
+        const float f8[8] = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
+        avt::split8<F16>(f8, h, l);
         const int o = (r0 + 128 * u) * 64 + (tid & 3) * 16;
         *reinterpret_cast<uint4*>(st + o) = h;
         *reinterpret_cast<uint4*>(st + PL + o) = l;
@@ -803,10 +796,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
           __builtin_nontemporal_store(f32x4n{x[4], x[5], x[6], x[7]}, reinterpret_cast<f32x4n*>(of + 4));
         } else {
           uint4 oh, ol;
-          avt::split2<F16>(x[0], x[1], oh.x, ol.x);
-          avt::split2<F16>(x[2], x[3], oh.y, ol.y);
-          avt::split2<F16>(x[4], x[5], oh.z, ol.z);
-          avt::split2<F16>(x[6], x[7], oh.w, ol.w);
+          avt::split8<F16>(x, oh, ol);
           *reinterpret_cast<uint4*>(a.out + o) = oh;  // (non-temporal stores here measured equal)
           *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
         }

@@ -202,10 +202,7 @@ __global__ __launch_bounds__(256) void maxpool3_x3_kernel(const uint16_t* __rest
       }
     }
     uint4 oh, ol;
-    avt::split2<F16>(m[0], m[1], oh.x, ol.x);
-    avt::split2<F16>(m[2], m[3], oh.y, ol.y);
-    avt::split2<F16>(m[4], m[5], oh.z, ol.z);
-    avt::split2<F16>(m[6], m[7], oh.w, ol.w);
+    avt::split8<F16>(m, oh, ol);
     const unsigned j = (cc * 8) / cg, c0 = (cc * 8) - j * cg;
     const int64_t o = ((((int64_t)b * tgroup + j) * Ho + ho) * Wo + wo) * ldo + c0;
     *reinterpret_cast<uint4*>(out_hi + o) = oh;

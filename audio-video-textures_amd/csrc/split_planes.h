@@ -30,6 +30,43 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
     lo = avt::pack_bf16x2(x0 - avt::bf16x2_lo(hi), x1 - avt::bf16x2_hi(hi));
   }
 }
+// Four / two pairs at once (an epilogue's 16-byte / 8-byte store per plane).  fp16 planes: ONE wave-wide test — is any of the values
+// outside the fp16 range or not a number? — decides between split2's careful form and the plain one (convert, convert back,
+// subtract, convert: 6 VALU operations per pair instead of ~18).  For values inside the range the clamps and selects of split2 are
+// identities, so the planes are the same bits; the test is a v_cmp per value whose result is already a wave mask (ORed in the scalar
+// unit) and the branch is uniform.  The x3 epilogues are VALU-bound (profiles/r04/xl_epilogue_row_slabs_ab.log): this is ~45 % of
+// their instructions.  Used where it measured faster (both conv_x3 tiles, the identity blocks of bneck_x3, the stems' max-pool:
+// profiles/r04/split8_ab.log); pw_x3 / conv33_x3 / the stems were equal or slower with it and keep split2.
+template <bool F16, int NP>
+__device__ __forceinline__ void split_pairs(const float* x, uint32_t* hi, uint32_t* lo) {
+  if constexpr (F16) {
+    unsigned long long odd = 0ull;
+#pragma unroll
+    for (int e = 0; e < 2 * NP; ++e) odd |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(x[e]) <= 65504.0f));  // (a NaN is "odd" too)
+    if (odd == 0ull) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const f32x2 v = {x[2 * p], x[2 * p + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        const f32x2 hf = __builtin_convertvector(h, f32x2);
+        const f32x2 r = {v.x - hf.x, v.y - hf.y};
+        hi[p] = __builtin_bit_cast(uint32_t, h);
+        lo[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) split2<F16>(x[2 * p], x[2 * p + 1], hi[p], lo[p]);
+}
+template <bool F16>
+__device__ __forceinline__ void split8(const float* x, uint4& hi, uint4& lo) {
+  split_pairs<F16, 4>(x, reinterpret_cast<uint32_t*>(&hi), reinterpret_cast<uint32_t*>(&lo));
+}
+template <bool F16>
+__device__ __forceinline__ void split4(const float* x, uint2& hi, uint2& lo) {
+  split_pairs<F16, 2>(x, reinterpret_cast<uint32_t*>(&hi), reinterpret_cast<uint32_t*>(&lo));
+}
 // ReLU that keeps a NaN a NaN, like torch.relu (fmaxf(NaN, 0) = 0 under IEEE maxNum would turn a poisoned activation into a
 // plausible zero; an infinity times a weight's low plane of either sign arrives here as a NaN too)
 __device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.0f ? 0.0f : v; }
