@@ -295,8 +295,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           const float4 s = *reinterpret_cast<const float4*>(cf + 16 * n + 4 * q);
           const float4 bb_ = *reinterpret_cast<const float4*>(cf + CMP + 16 * n + 4 * q);
           uint2 h, l;
-          avt::split2<F16>(avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y), h.x, l.x);
-          avt::split2<F16>(avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w), h.y, l.y);
+          if constexpr (!FIRST && !STR && C == 128) {  // (the 14-wide identity block: the wave-wide range test here too, -10 %;
+                                                       //  the 28- and 56-wide ones measured equal / +1 % with it)
+            const float v4[4] = {avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y),
+                                 avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w)};
+            avt::split4<F16>(v4, h, l);
+          } else {
+            avt::split2<F16>(avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y), h.x, l.x);
+            avt::split2<F16>(avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w), h.y, l.y);
+          }
           if (a_st[it] >= 0) {
             *reinterpret_cast<uint2*>(aoh + aofs + a_st[it] + n * 32) = h;
             *reinterpret_cast<uint2*>(aol + aofs + a_st[it] + n * 32) = l;
@@ -331,8 +338,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           const float4 s = *reinterpret_cast<const float4*>(cf + 2 * CMP + 16 * n + 4 * q);
           const float4 bb_ = *reinterpret_cast<const float4*>(cf + 3 * CMP + 16 * n + 4 * q);
           uint2 h, l;
-          avt::split2<F16>(avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y), h.x, l.x);
-          avt::split2<F16>(avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w), h.y, l.y);
+          if constexpr (!FIRST && !STR && C == 128) {  // (the 14-wide identity block: the wave-wide range test here too, -10 %;
+                                                       //  the 28- and 56-wide ones measured equal / +1 % with it)
+            const float v4[4] = {avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y),
+                                 avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w)};
+            avt::split4<F16>(v4, h, l);
+          } else {
+            avt::split2<F16>(avt::relu_keep_nan(acc[n][0] * s.x + bb_.x), avt::relu_keep_nan(acc[n][1] * s.y + bb_.y), h.x, l.x);
+            avt::split2<F16>(avt::relu_keep_nan(acc[n][2] * s.z + bb_.z), avt::relu_keep_nan(acc[n][3] * s.w + bb_.w), h.y, l.y);
+          }
           const int o = (m * 16 + l15) * AREC + n * 32 + q * 8;
           *reinterpret_cast<uint2*>(boh + o) = h;
           *reinterpret_cast<uint2*>(bol + o) = l;
