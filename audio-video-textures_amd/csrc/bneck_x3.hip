@@ -397,7 +397,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           const i32x4 rh = xr[it][CU][np][0], rl = xr[it][CU][np][1];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const avt::f32x2 r = avt::join2<F16>((uint32_t)rh[e], (uint32_t)rl[e]);
+            avt::f32x2 r;
+            if constexpr (F16 && C == 128) r = avt::join2_mix_f16((uint32_t)rh[e], (uint32_t)rl[e]);
+            else r = avt::join2<F16>((uint32_t)rh[e], (uint32_t)rl[e]);
             v[2 * e] += r.x;
             v[2 * e + 1] += r.y;
           }

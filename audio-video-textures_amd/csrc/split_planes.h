@@ -82,4 +82,15 @@ __device__ __forceinline__ f32x2 join2(uint32_t hi, uint32_t lo) {
   }
 }
 
+// join2 for fp16 planes as ONE mixed-precision FMA per value: fp32(hi half) * 1.0 + fp32(lo half), rounded once — the bits of the two
+// conversions and the fp32 add of join2 (both addends are exact in fp32), 2 VALU operations per pair instead of 5.  Used where it
+// measured faster (bneck_x3's 14-wide identity block: -10 %); the max-pool was 3 % slower with it, the other kernels equal
+// (profiles/r04/split8_ab.log)
+__device__ __forceinline__ f32x2 join2_mix_f16(uint32_t hi, uint32_t lo) {
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r.x) : "v"(hi), "v"(lo));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r.y) : "v"(hi), "v"(lo));
+  return r;
+}
+
 }  // namespace avt
