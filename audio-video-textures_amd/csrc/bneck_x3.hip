@@ -56,6 +56,18 @@ __device__ __forceinline__ f32x4 mfma3(i32x4 wh, i32x4 wl, i32x4 xh, i32x4 xl, f
   return mfma16<F16>(wh, xh, c);
 }
 
+// two products into two accumulators, their passes interleaved: no MFMA reads the result of the one issued just before it (the
+// same three terms per accumulator in the same order: identical bits)
+template <bool F16>
+__device__ __forceinline__ void mfma3x2(i32x4 wh0, i32x4 wl0, i32x4 wh1, i32x4 wl1, i32x4 xh, i32x4 xl, f32x4& c0, f32x4& c1) {
+  c0 = mfma16<F16>(wl0, xh, c0);
+  c1 = mfma16<F16>(wl1, xh, c1);
+  c0 = mfma16<F16>(wh0, xl, c0);
+  c1 = mfma16<F16>(wh1, xl, c1);
+  c0 = mfma16<F16>(wh0, xh, c0);
+  c1 = mfma16<F16>(wh1, xh, c1);
+}
+
 struct BxArgs {
   const uint16_t* xh;
   const uint16_t* xl;
@@ -283,10 +295,19 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
             for (int dt = 0; dt < 3; ++dt) {
               constexpr int slots[3] = {PV, CU, NX};
               const int s = slots[dt];
+              if constexpr (NTA % 2 == 0) {
 #pragma unroll
-              for (int n = 0; n < NTA; ++n) {
-                const int f = (dt * KA + k) * NTA + n;
-                acc[n] = mfma3<F16>(WF(f, 0, lofs), WF(f, 1, lofs), xr[it][s][k][0], xr[it][s][k][1], acc[n]);
+                for (int n = 0; n < NTA; n += 2) {
+                  const int f = (dt * KA + k) * NTA + n;
+                  mfma3x2<F16>(WF(f, 0, lofs), WF(f, 1, lofs), WF(f + 1, 0, lofs), WF(f + 1, 1, lofs), xr[it][s][k][0], xr[it][s][k][1],
+                               acc[n], acc[n + 1]);
+                }
+              } else {
+#pragma unroll
+                for (int n = 0; n < NTA; ++n) {
+                  const int f = (dt * KA + k) * NTA + n;
+                  acc[n] = mfma3<F16>(WF(f, 0, lofs), WF(f, 1, lofs), xr[it][s][k][0], xr[it][s][k][1], acc[n]);
+                }
               }
             }
         }
@@ -327,10 +348,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
         for (int j = 0; j < NB; ++j) {
           const i32x4 fh = *reinterpret_cast<const i32x4*>(aoh + aofs + b_rd[it] + tapoff[j]);
           const i32x4 fl = *reinterpret_cast<const i32x4*>(aol + aofs + b_rd[it] + tapoff[j]);
+          if constexpr (NTA % 2 == 0) {
 #pragma unroll
-          for (int n = 0; n < NTA; ++n) {
-            const int f = NFA + j * NTA + n;
-            acc[n] = mfma3<F16>(WF(f, 0, lofs), WF(f, 1, lofs), fh, fl, acc[n]);
+            for (int n = 0; n < NTA; n += 2) {
+              const int f = NFA + j * NTA + n;
+              mfma3x2<F16>(WF(f, 0, lofs), WF(f, 1, lofs), WF(f + 1, 0, lofs), WF(f + 1, 1, lofs), fh, fl, acc[n], acc[n + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int n = 0; n < NTA; ++n) {
+              const int f = NFA + j * NTA + n;
+              acc[n] = mfma3<F16>(WF(f, 0, lofs), WF(f, 1, lofs), fh, fl, acc[n]);
+            }
           }
         }
 #pragma unroll
@@ -373,19 +402,16 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
       for (int np = 0; np < NTC / 2; ++np) {
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
         const int f0 = NFA + NFB + 2 * np;
-        c0 = mfma3<F16>(WF(f0, 0, lofs), WF(f0, 1, lofs), fh, fl, c0);
-        c1 = mfma3<F16>(WF(f0 + 1, 0, lofs), WF(f0 + 1, 1, lofs), fh, fl, c1);
+        mfma3x2<F16>(WF(f0, 0, lofs), WF(f0, 1, lofs), WF(f0 + 1, 0, lofs), WF(f0 + 1, 1, lofs), fh, fl, c0, c1);
         if constexpr (FIRST) {  // shortcut = 1x1x1 conv of x(t) (k-group 1 of the operand) into the same tile; bc = bc + b_shortcut
           const int s0 = NFA + NFB + NTC + 2 * np;
-          c0 = mfma3<F16>(WF(s0, 0, lofs), WF(s0, 1, lofs), xr[it][0][0][0], xr[it][0][0][1], c0);
-          c1 = mfma3<F16>(WF(s0 + 1, 0, lofs), WF(s0 + 1, 1, lofs), xr[it][0][0][0], xr[it][0][0][1], c1);
+          mfma3x2<F16>(WF(s0, 0, lofs), WF(s0, 1, lofs), WF(s0 + 1, 0, lofs), WF(s0 + 1, 1, lofs), xr[it][0][0][0], xr[it][0][0][1], c0, c1);
         }
         if constexpr (STR) {  // strided shortcut: KS k-steps over the input channels of x(t) at (2 ho, 2 wo)
 #pragma unroll
           for (int k = 0; k < KS; ++k) {
             const int s0 = NFA + NFB + NTC + (2 * np) * KS + k;
-            c0 = mfma3<F16>(WF(s0, 0, lofs), WF(s0, 1, lofs), sx[it][k][0], sx[it][k][1], c0);
-            c1 = mfma3<F16>(WF(s0 + KS, 0, lofs), WF(s0 + KS, 1, lofs), sx[it][k][0], sx[it][k][1], c1);
+            mfma3x2<F16>(WF(s0, 0, lofs), WF(s0, 1, lofs), WF(s0 + KS, 0, lofs), WF(s0 + KS, 1, lofs), sx[it][k][0], sx[it][k][1], c0, c1);
           }
         }
         const float* sp = cf + 4 * CMP + 32 * np + 8 * q;
