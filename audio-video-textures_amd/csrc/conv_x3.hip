@@ -346,6 +346,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       rrl[u] = ok ? *reinterpret_cast<const uint4*>(a.res_lo + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
     }
   }
+  if constexpr (IO32) {
+    if (a.res) {  // the fp32 `add` operand (train_ops.conv3d_fork), requested here in one go: fetched chunk by chunk in the store loop,
+                  // every chunk waited (vmcnt(0)) for its own two loads AND the previous chunk's stores — eight round trips per tile
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c = tid + 256 * u;
+        const int m = m0 + c / CPR, n = n0 + (c % CPR) * 8;
+        const bool ok = m < a.M && n < a.Cout;
+        const float* rf = reinterpret_cast<const float*>(a.res) + (int64_t)m * a.ldr + n;
+        rrh[u] = ok ? *reinterpret_cast<const uint4*>(rf) : make_uint4(0u, 0u, 0u, 0u);
+        rrl[u] = ok ? *reinterpret_cast<const uint4*>(rf + 4) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
   // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n -> regs 4g..4g+3 are 4 consecutive n
 #pragma unroll
   for (int i = 0; i < NT; ++i)
@@ -396,8 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       if constexpr (IO32) {
         if (a.res) {  // out = conv + add: a gradient that reaches the same tensor by another path, summed here instead of
                       // in a separate pass (train_ops.conv3d_fork)
-          const float* rf = reinterpret_cast<const float*>(a.res) + (int64_t)m * a.ldr + n;
-          const float4 r0_ = *reinterpret_cast<const float4*>(rf), r1_ = *reinterpret_cast<const float4*>(rf + 4);
+          const float4 r0_ = __builtin_bit_cast(float4, rrh[u]), r1_ = __builtin_bit_cast(float4, rrl[u]);
           x[0] += r0_.x; x[1] += r0_.y; x[2] += r0_.z; x[3] += r0_.w;
           x[4] += r1_.x; x[5] += r1_.y; x[6] += r1_.z; x[7] += r1_.w;
         }
@@ -751,6 +764,19 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         rrl[u] = ok ? *reinterpret_cast<const uint4*>(a.res_lo + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
       }
     }
+    if constexpr (IO32) {
+      if (a.res) {  // the fp32 `add` operand of this slab, requested in one go (see the 128-wide tile's epilogue)
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+          const int c = tid + NTHR * u;
+          const int m = m0 + pass * SR + c / CPR, n = n0 + (c % CPR) * 8;
+          const bool ok = m < a.M && n < a.Cout;
+          const float* rf = reinterpret_cast<const float*>(a.res) + (int64_t)m * a.ldr + n;
+          rrh[u] = ok ? *reinterpret_cast<const uint4*>(rf) : make_uint4(0u, 0u, 0u, 0u);
+          rrl[u] = ok ? *reinterpret_cast<const uint4*>(rf + 4) : make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+    }
     if (pass + 1 < 4 && wm == ((pass + 1) >> 1)) {  // into the other buffer (its last readers passed the barrier below)
       if ((pass + 1) & 1) stage_slab(std::integral_constant<int, 1>{}, pass + 1);
       else stage_slab(std::integral_constant<int, 0>{}, pass + 1);
@@ -785,8 +811,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         const int64_t o = (int64_t)out_row(a, m) * a.ldo + n;
         if constexpr (IO32) {
           if (a.res) {  // out = conv + add (train_ops.conv3d_fork): fp32 rows
-            const float* rf = reinterpret_cast<const float*>(a.res) + (int64_t)m * a.ldr + n;
-            const float4 q0 = *reinterpret_cast<const float4*>(rf), q1 = *reinterpret_cast<const float4*>(rf + 4);
+            const float4 q0 = __builtin_bit_cast(float4, rrh[u]), q1 = __builtin_bit_cast(float4, rrl[u]);
             x[0] += q0.x; x[1] += q0.y; x[2] += q0.z; x[3] += q0.w;
             x[4] += q1.x; x[5] += q1.y; x[6] += q1.z; x[7] += q1.w;
           }
