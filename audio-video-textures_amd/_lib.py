@@ -89,6 +89,8 @@ SIGNATURES = {
     "avt_pw_x3_supported": [C.c_int] * 2,
     "avt_pw_x3": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int64,
                   C.c_int, C.c_int, _vp],
+    "avt_pw_x3_f32_supported": [C.c_int] * 2,
+    "avt_pw_x3_f32": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, _vp],
     "avt_pw_chain_x3_supported": [C.c_int] * 3,
     "avt_pw_chain_x3": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
                         _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, _vp],
@@ -138,7 +140,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 5  # include/avt.h AVT_ABI_VERSION
+ABI_VERSION = 6  # include/avt.h AVT_ABI_VERSION
 _RETURNS_I64 = {"avt_bn_train_ws_bytes"}  # sizes; every other entry returns an AVT_* status
 
 

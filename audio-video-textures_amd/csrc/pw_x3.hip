@@ -365,6 +365,178 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_chain_x3_kernel(PcArgs c) {
   }
 }
 
+// ---- the TRAINING form: fp32 rows in, fp32 rows out (train_ops.conv3d's pointwise layers: forward and stride-1 input gradient) -----
+// The expanding 1x1x1 convolutions of the bottlenecks (64 -> 256, 128 -> 512, 256 -> 1024 and the fast pathway's 8 -> 32 ... 64 -> 256)
+// and the input gradients of the reducing ones are the widest-output layers of the step, and K is one to four 64-wide steps: on
+// the 128 x 128 tile a workgroup's prologue and epilogue were 26 + 29 % of its cycles and the layer ran at 1.1 TB/s (128 -> 512 at
+// 28^2: 1.86 ms per 128 clips, profiles/r04/train_pw_f32_ab.log).  Same streaming structure as pw_x3_kernel: a wave owns 16 positions
+// from load to store; its fp32 operand chunks (8 consecutive channels = two 16-byte loads) are split into the two planes in registers
+// and are the MFMA B operand; the weight planes arrive in their plain [N][K] layout (they change every optimizer step: no host
+// packing) and the prologue of the persistent workgroup lays them out as fragments in LDS; the epilogue scales (fp16 planes' row
+// scales), adds the optional fp32 `add` rows and stores 8 consecutive channels per lane as two non-temporal 16-byte stores.
+struct PfArgs {
+  const float* x;        // [M, ldx]
+  const float* add;      // [M, lda] or NULL
+  float* y;              // [M, ldy]
+  const uint16_t* wh;    // [N][K] plain planes
+  const uint16_t* wl;
+  const float* wscale;   // [N] or NULL
+  int M, ldx, lda, ldy, K, k1c, ntiles, n_chunks, n_rg;
+};
+
+template <int K1S, int NT1, bool F16>
+__global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
+  constexpr int NC = NT1 * 16;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* whl = lds;
+  char* wll = whl + NT1 * K1S * 1024;
+  float* sl = reinterpret_cast<float*>(wll + NT1 * K1S * 1024);  // [NC] scale
+
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int chunk = j % a.n_chunks;
+  const int rg = (j / a.n_chunks) * 8 + xcd;
+  if (rg >= a.n_rg) return;
+  const int c0 = chunk * NC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  // fragments from the plain planes (fused_slowfast.pack_pw_planes' order): fragment (nt, ks), lane (n = l15, q): 8 consecutive k of
+  // output row 32 (nt / 2) + 8 (n >> 2) + 4 (nt % 2) + (n & 3), k = 32 ks + 8 q ..; k past the row's end = zeros
+  for (int f = wid; f < NT1 * K1S; f += PX_NW) {
+    const int nt = f / K1S, ks = f - nt * K1S;
+    const int row = c0 + 32 * (nt >> 1) + 8 * (l15 >> 2) + 4 * (nt & 1) + (l15 & 3);
+    const int col = 32 * ks + 8 * q;
+    i32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
+    if (col < a.K) {
+      vh = *reinterpret_cast<const i32x4*>(a.wh + (int64_t)row * a.K + col);
+      vl = *reinterpret_cast<const i32x4*>(a.wl + (int64_t)row * a.K + col);
+    }
+    *reinterpret_cast<i32x4*>(whl + f * 1024 + lane * 16) = vh;
+    *reinterpret_cast<i32x4*>(wll + f * 1024 + lane * 16) = vl;
+  }
+  for (int i = tid; i < NC; i += PX_NW * 64) sl[i] = a.wscale ? a.wscale[c0 + i] : 1.0f;
+  __syncthreads();
+  const bool has_add = a.add != nullptr;
+
+  for (int tile = rg * PX_NW + wid; tile < a.ntiles; tile += a.n_rg * PX_NW) {
+    const int p = tile * 16 + l15;
+    const bool ok = p < a.M;
+    int lofs = lane * 16;  // opaque per tile: keeps the loop-invariant fragment reads from being hoisted into registers
+    asm volatile("" : "+v"(lofs));
+    const int64_t pc = ok ? p : a.M - 1;
+    float4 xa[K1S], xb[K1S];
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks) {
+      int ch = 4 * ks + q;  // past the row's end the weights are zero: any finite value will do
+      ch = ch < a.k1c ? ch : a.k1c - 1;
+      const float* px = a.x + pc * a.ldx + ch * 8;
+      xa[ks] = *reinterpret_cast<const float4*>(px);
+      xb[ks] = *reinterpret_cast<const float4*>(px + 4);
+    }
+    float4 ra[NT1 / 2], rb[NT1 / 2];
+    if (has_add) {
+#pragma unroll
+      for (int jj = 0; jj < NT1 / 2; ++jj) {
+        const float* pr = a.add + pc * a.lda + c0 + 32 * jj + 8 * q;
+        ra[jj] = *reinterpret_cast<const float4*>(pr);
+        rb[jj] = *reinterpret_cast<const float4*>(pr + 4);
+      }
+    }
+    i32x4 xh[K1S], xl[K1S];
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks) {
+      const float f8[8] = {xa[ks].x, xa[ks].y, xa[ks].z, xa[ks].w, xb[ks].x, xb[ks].y, xb[ks].z, xb[ks].w};
+      uint4 h, l;
+      avt::split8<F16>(f8, h, l);
+      xh[ks] = __builtin_bit_cast(i32x4, h);
+      xl[ks] = __builtin_bit_cast(i32x4, l);
+    }
+    f32x4 acc[NT1];
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < K1S; ++ks) {
+#pragma unroll
+      for (int n = 0; n < NT1; n += PW_IL) {
+        i32x4 wh[PW_IL], wl[PW_IL];
+#pragma unroll
+        for (int u = 0; u < PW_IL; ++u) {
+          const int f = (n + u) * K1S + ks;
+          wh[u] = *reinterpret_cast<const i32x4*>(whl + f * 1024 + lofs);
+          wl[u] = *reinterpret_cast<const i32x4*>(wll + f * 1024 + lofs);
+        }
+#pragma unroll
+        for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wl[u], xh[ks], acc[n + u]);
+#pragma unroll
+        for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wh[u], xl[ks], acc[n + u]);
+#pragma unroll
+        for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wh[u], xh[ks], acc[n + u]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < NT1 / 2; ++jj) {  // tiles 2jj, 2jj+1 -> channels c0 + 32 jj + 8 q .. + 7
+      const int cl = 32 * jj + 8 * q;
+      const float4 sa = *reinterpret_cast<const float4*>(sl + cl), sb = *reinterpret_cast<const float4*>(sl + cl + 4);
+      typedef float f32x4n __attribute__((ext_vector_type(4)));
+      f32x4n o0 = {acc[2 * jj][0] * sa.x, acc[2 * jj][1] * sa.y, acc[2 * jj][2] * sa.z, acc[2 * jj][3] * sa.w};
+      f32x4n o1 = {acc[2 * jj + 1][0] * sb.x, acc[2 * jj + 1][1] * sb.y, acc[2 * jj + 1][2] * sb.z, acc[2 * jj + 1][3] * sb.w};
+      if (has_add) {
+        o0 += f32x4n{ra[jj].x, ra[jj].y, ra[jj].z, ra[jj].w};
+        o1 += f32x4n{rb[jj].x, rb[jj].y, rb[jj].z, rb[jj].w};
+      }
+      if (ok) {
+        float* po = a.y + pc * a.ldy + c0 + cl;
+        __builtin_nontemporal_store(o0, reinterpret_cast<f32x4n*>(po));
+        __builtin_nontemporal_store(o1, reinterpret_cast<f32x4n*>(po + 4));
+      }
+    }
+  }
+}
+
+template <int K1S, int NT1, bool F16>
+int launch_pf(PfArgs& a, hipStream_t st) {
+  constexpr int lds_bytes = 2 * NT1 * K1S * 1024 + NT1 * 16 * 4;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_x3_f32_kernel<K1S, NT1, F16>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_pw_x3_f32: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 52 * 1024 ? 2 : 3);
+  int n_rg = (256 * per_cu) / a.n_chunks;
+  n_rg = n_rg < 8 ? 8 : (n_rg / 8) * 8;
+  const int max_rg = (a.ntiles + PX_NW - 1) / PX_NW;
+  if (n_rg > ((max_rg + 7) / 8) * 8) n_rg = ((max_rg + 7) / 8) * 8;
+  a.n_rg = n_rg;
+  hipLaunchKernelGGL((pw_x3_f32_kernel<K1S, NT1, F16>), dim3((unsigned)(n_rg * a.n_chunks)), dim3(PX_NW * 64), lds_bytes, st, a);
+  return avt::check_launch("avt_pw_x3_f32");
+}
+
+template <int K1S, bool F16>
+int dispatch_pf_nt(PfArgs& a, int nt1, hipStream_t st) {
+  switch (nt1) {
+    case 16: if constexpr (K1S <= 4) return launch_pf<K1S, 16, F16>(a, st); break;
+    case 8: if constexpr (K1S <= 8) return launch_pf<K1S, 8, F16>(a, st); break;
+    case 4: return launch_pf<K1S, 4, F16>(a, st);
+    case 2: return launch_pf<K1S, 2, F16>(a, st);
+  }
+  avt::set_error("avt_pw_x3_f32: no kernel for K steps %d, tiles %d", K1S, nt1);
+  return AVT_ERR_UNSUPPORTED;
+}
+
+template <bool F16>
+int dispatch_pf_k(PfArgs& a, int k1s, int nt1, hipStream_t st) {
+  switch (k1s) {
+    case 1: return dispatch_pf_nt<1, F16>(a, nt1, st);
+    case 2: return dispatch_pf_nt<2, F16>(a, nt1, st);
+    case 4: return dispatch_pf_nt<4, F16>(a, nt1, st);
+    case 8: return dispatch_pf_nt<8, F16>(a, nt1, st);
+  }
+  avt::set_error("avt_pw_x3_f32: unsupported K (%d steps of 32)", k1s);
+  return AVT_ERR_UNSUPPORTED;
+}
+
 // tiles per workgroup chunk for (K1S, N): the widest of 16 / 8 / 4 / 2 that divides N/16 and keeps both planes' fragments
 // within 128 KB of LDS; 0 = unsupported
 int pick_nt1(int k1s, int n) {
@@ -597,4 +769,37 @@ extern "C" int avt_pw_chain_x3(const void* x_hi, const void* x_lo, int ldx, int 
   else
     hipLaunchKernelGGL((pw_chain_x3_kernel<K1S, NT1, NT2, false>), dim3((unsigned)grid), dim3(PX_NW * 64), lds_bytes, st, c);
   return avt::check_launch("avt_pw_chain_x3");
+}
+
+// The training form of avt_pw_x3 (see include/avt.h): fp32 rows in / out, plain [n][k] weight planes
+extern "C" int avt_pw_x3_f32_supported(int k, int n) {
+  const int k1s = (k + 31) / 32;
+  if (k % 8 || n % 32 || !(k1s == 1 || k1s == 2 || k1s == 4 || k1s == 8)) return 0;
+  const int nt1 = pick_nt1(k1s, n);
+  if (!nt1) return 0;
+  if ((nt1 == 16 && k1s > 4) || (nt1 == 8 && k1s > 8)) return 0;
+  return n / (16 * nt1) <= 8 ? 1 : 0;
+}
+
+extern "C" int avt_pw_x3_f32(const float* x, int ldx, int k, const void* w_hi, const void* w_lo, const float* wscale, const float* add,
+                             int lda, float* y, int ldy, int n, int64_t m, int plane_dtype, void* stream) {
+  AVT_REQUIRE(x && w_hi && w_lo && y, "avt_pw_x3_f32: NULL pointer");
+  AVT_REQUIRE(avt_pw_x3_f32_supported(k, n), "avt_pw_x3_f32: unsupported layer K=%d N=%d", k, n);
+  AVT_REQUIRE(m > 0 && m < (1ll << 31) - 16 && ldx >= k && ldy >= n && ldx % 4 == 0 && ldy % 4 == 0 && (!add || (lda >= n && lda % 4 == 0)),
+              "avt_pw_x3_f32: bad sizes / leading dimensions");
+  AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(w_hi) && avt::aligned16(w_lo) && avt::aligned16(y) && (!add || avt::aligned16(add)) &&
+                  (!wscale || avt::aligned16(wscale)),
+              "avt_pw_x3_f32: pointers must be 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_pw_x3_f32: bad plane_dtype");
+  const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  PfArgs a;
+  a.x = x; a.add = add; a.y = y;
+  a.wh = static_cast<const uint16_t*>(w_hi);
+  a.wl = static_cast<const uint16_t*>(w_lo);
+  a.wscale = wscale;
+  a.M = (int)m; a.ldx = ldx; a.lda = lda; a.ldy = ldy; a.K = k; a.k1c = k / 8;
+  a.ntiles = (int)((m + 15) / 16);
+  a.n_chunks = n / (16 * nt1);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return plane_dtype == AVT_X3_F16 ? dispatch_pf_k<true>(a, k1s, nt1, st) : dispatch_pf_k<false>(a, k1s, nt1, st);
 }

@@ -408,6 +408,24 @@ def conv3d_igemm_x3_f32(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, ker
                                                   int(cout), int(plane_dtype), _stream()), "avt_conv3d_igemm_x3_f32")
 
 
+def pw_x3_f32_supported(k, n):
+    return bool(_lib.lib().avt_pw_x3_f32_supported(int(k), int(n)))
+
+
+def pw_x3_f32(x, k, wt_hi, wt_lo, wscale, out, n, plane_dtype, add=None):
+    """A 1x1x1 / stride 1 convolution on fp32 channels-last rows in the streaming form (csrc/pw_x3.hip, training): x [.., k] -> out [.., n],
+    wt_hi / wt_lo the plain [n, k] planes of weight_planes_f32 / weight_planes_t_f32, add = fp32 rows summed into the result."""
+    _dev(x, "x", torch.float32)
+    _dev(out, "out", torch.float32)
+    _dev(wt_hi, "wt_hi", torch.bfloat16)
+    _dev(wt_lo, "wt_lo", torch.bfloat16)
+    if add is not None:
+        _dev(add, "add", torch.float32)
+    m = x.numel() // k
+    _lib.check(_lib.lib().avt_pw_x3_f32(_p(x), int(k), int(k), _p(wt_hi), _p(wt_lo), _p(wscale), _p(add), int(n), _p(out), int(n), int(n),
+                                        int(m), int(plane_dtype), _stream()), "avt_pw_x3_f32")
+
+
 def conv3d_igemm_x3_f32_ex(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, kernel, pad, out_dims, ldi, ldo, plane_dtype,
                            out_rows=(1, 0, 0)):
     """conv3d_igemm_x3_f32 at stride 1 with an explicit output extent and the output-row remap (out_rows = (stride, grid h, grid w));

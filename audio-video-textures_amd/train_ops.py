@@ -60,7 +60,7 @@ def invalidate_weight_cache():
 
 # per-process launch counters of the hand-written training kernels (tests assert that the default path really runs them)
 CALLS = {"conv_fwd_x3": 0, "dgrad_x3": 0, "dgrad_strided_x3": 0, "wgrad_x3": 0, "wgrad_stem_x3": 0, "bn_fwd": 0, "bn_bwd": 0,
-         "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0, "maxpool_hip": 0}
+         "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0, "maxpool_hip": 0, "pw_f32": 0}
 
 
 def _p(t):
@@ -444,10 +444,15 @@ def _weight_planes(weight, transposed):
 # bytes, a 32-wide MFMA tile that is 3/4 padding); the same bytes viewed as [.., W / g, g * C] rows with block-Toeplitz weights along W
 # give 4 x fewer, 4 x fuller rows.  The weight gradient keeps the plain form (grouping would multiply its flops by g * g).
 _GROUP = 1
+_PW_F32 = 1         # pointwise layers (forward / stride-1 input gradient) on the streaming fp32-in / fp32-out kernel (csrc/pw_x3.hip)
 _GROUP_IDX = {}
 
 
 def _group_factor(cin, cout, kernel, stride, pad, w):
+    if _PW_F32 and tuple(kernel) == (1, 1, 1) and tuple(stride) == (1, 1, 1) and tuple(pad) == (0, 0, 0):
+        from . import ops
+        if ops.pw_x3_f32_supported(cin, cout):
+            return 1  # (a pointwise layer the streaming kernel takes as it is: _conv_x3_rows)
     if not _GROUP or tuple(stride) != (1, 1, 1) or pad[2] != kernel[2] // 2 or kernel[2] % 2 == 0 or cin % 8 or cout % 8:
         return 1
     small = min(cin, cout)
@@ -502,6 +507,14 @@ def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=No
         ops.conv3d_igemm_x3_f32(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
                                 _ktab(g * cin, gk, h, w // g, g * cin, x.device), (b, t, h, w // g), g * cin, g * cout, gk, (1, 1, 1),
                                 (pad[0], pad[1], rg), g * cin, g * cout, plane_dtype, add=None if add is None else add.permute(0, 2, 3, 4, 1))
+        return y
+    if (_PW_F32 and tuple(kernel) == (1, 1, 1) and tuple(stride) == (1, 1, 1) and tuple(pad) == (0, 0, 0) and x.numel() // cin < (1 << 31) - 16 and
+            ops.pw_x3_f32_supported(cin, cout)):
+        # the pointwise layers with few K-steps and many outputs (the bottlenecks' expanding convolutions, the input gradients of the
+        # reducing ones) on the streaming kernel: the 128 x 128 tile spent 55 % of a workgroup in its prologue + epilogue on them
+        CALLS["pw_f32"] += 1
+        ops.pw_x3_f32(x.permute(0, 2, 3, 4, 1), cin, planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1), cout, plane_dtype,
+                      add=None if add is None else add.permute(0, 2, 3, 4, 1))
         return y
     ops.conv3d_igemm_x3_f32(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
                             _ktab(cin, kernel, h, w, cin, x.device), (b, t, h, w), cin, cout, kernel, stride, pad, cin, cout, plane_dtype,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 5  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4) */
+#define AVT_ABI_VERSION 6  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4); 6: avt_pw_x3_f32 (round 4) */
 
 typedef enum {
   AVT_OK = 0,
@@ -387,6 +387,16 @@ int avt_pw_x3_supported(int k, int n);
 int avt_pw_x3(const void* x_hi, const void* x_lo, int ldx, int k, const void* w_hi, const void* w_lo,
               const float* bias, const float* wscale, const void* res_hi, const void* res_lo, int ldr,
               void* y_hi, void* y_lo, int ldy, int n, int64_t m, int relu, int plane_dtype, void* stream);
+/* The TRAINING form of avt_pw_x3 (round 4, ABI 6): fp32 rows in, fp32 rows out — the pointwise layers of train_ops.conv3d (forward and
+ * stride-1 input gradient of the 1x1x1 convolutions of the SlowFast bottlenecks in train(), contrastive_video_textures/train.py:114-141),
+ * which the 128 x 128 IO32 tile served at 1.1 TB/s when K is one to four K-steps (a workgroup's prologue + epilogue: 55 % of its cycles).
+ * y [m, ldy] = (W x) * wscale [+ add]; x [m, ldx] fp32 (k valid channels), add [m, lda] fp32 or NULL; w_hi / w_lo = the PLAIN planes
+ * [n][k] of avt_weight_planes_f32 / avt_weight_planes_t_f32 (no host packing: the weights change every optimizer step; the kernel's
+ * prologue lays them out as fragments); wscale [n] or NULL.  avt_pw_x3_f32_supported(k, n): k % 8 == 0, ceil(k / 32) in {1, 2, 4, 8},
+ * n % 32 == 0, at most 8 channel chunks. */
+int avt_pw_x3_f32_supported(int k, int n);
+int avt_pw_x3_f32(const float* x, int ldx, int k, const void* w_hi, const void* w_lo, const float* wscale, const float* add, int lda,
+                  float* y, int ldy, int n, int64_t m, int plane_dtype, void* stream);
 /* Two pointwise layers of consecutive slow-pathway bottlenecks in ONE pass over the rows, on plane pairs (csrc/pw_x3.hip; the
  * contract-grade form of avt_pw_chain_bf16):  y = act(W1 x + b1 [+ res]) (block i's expanding conv + residual + ReLU) and
  * z = relu(W2 y + b2) (block i + 1's reducing conv).  The first GEMM's result, already split into the planes it stores, is the

@@ -448,3 +448,49 @@ def test_vggish_training_convolutions_run_on_the_hand_written_kernels(avt, dev):
             continue
         rel = float((p1.grad - p0.grad).norm() / p0.grad.norm())
         assert rel < 2e-4, (k, rel)
+
+
+@pytest.mark.parametrize("cin,cout,dims,with_fork", [
+    (64, 256, (2, 3, 9, 7), False),     # res2 c
+    (128, 512, (1, 2, 5, 6), True),     # res3 c, + the fork's add operand in the input gradient of the next test row
+    (256, 64, (2, 2, 4, 5), True),      # a reducing layer: its INPUT gradient (64 -> 256 rows) takes the streaming form
+    (8, 32, (2, 4, 6, 10), False),      # fast pathway: K = 8 (one partial k-step), two 16-channel tiles
+    (32, 128, (1, 3, 7, 4), False),
+    (256, 1024, (1, 1, 3, 5), False),   # eight channel chunks
+])
+def test_pointwise_layers_take_the_streaming_f32_kernel(cin, cout, dims, with_fork):
+    """train_ops.conv3d on a 1x1x1 convolution: forward and input gradient on csrc/pw_x3.hip's fp32-in / fp32-out form
+    (avt_pw_x3_f32: plain weight planes laid out as fragments by the kernel's prologue) against fp32 autograd on the same tensors,
+    ragged row counts included; conv3d_fork's second gradient path is summed in the kernel's epilogue."""
+    from avtex import train_ops
+    torch.manual_seed(cin + cout)
+    b, t, h, w = dims
+    conv = nn.Conv3d(cin, cout, 1, bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+    x0 = _cl(torch.randn(b, cin, t, h, w, device=DEV))
+    gy = _cl(torch.randn(b, cout, t, h, w, device=DEV))
+    gx2 = _cl(torch.randn(b, cin, t, h, w, device=DEV)) if with_fork else None
+
+    def run(fused):
+        conv.weight.grad = None
+        x = x0.clone().requires_grad_(True)
+        before = train_ops.CALLS["pw_f32"]
+        if fused:
+            if with_fork:
+                y, xs = train_ops.conv3d_fork(x, conv)
+                loss = (y * gy).sum() + (xs * gx2).sum()
+            else:
+                y = train_ops.conv3d(x, conv)
+                loss = (y * gy).sum()
+        else:
+            y = torch.nn.functional.conv3d(x, conv.weight)
+            loss = (y * gy).sum() + ((x * gx2).sum() if with_fork else 0.0)
+        loss.backward()
+        return y.detach(), x.grad.detach(), conv.weight.grad.detach().clone(), train_ops.CALLS["pw_f32"] - before
+
+    ya, gxa, gwa, calls = run(True)
+    ye, gxe, gwe, _ = run(False)
+    fwd_pw = train_ops._lib.lib().avt_pw_x3_f32_supported(cin, cout)
+    bwd_pw = train_ops._lib.lib().avt_pw_x3_f32_supported(cout, cin)
+    assert calls == int(bool(fwd_pw)) + int(bool(bwd_pw)) and calls >= 1
+    for got, want, tol in ((ya, ye, 3e-6), (gxa, gxe, 2e-4), (gwa, gwe, 2e-4)):
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max()) + 1e-12
