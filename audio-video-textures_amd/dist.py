@@ -64,12 +64,30 @@ def all_gather_rows(local, n_total, group=None):
 
 
 def gather_to_root(local, n_total, group=None, root=0):
-    """Row blocks [n_r, ...] -> [n_total, ...] on `root` (None elsewhere)."""
+    """Row blocks [n_r, ...] -> [n_total, ...] on `root` (None elsewhere): a real gather — every other rank SENDS its block and
+    receives nothing (as an all-gather, the driving-audio path's `want_sim` moved the whole N x N matrix to all
+    ranks, 1 GB x 8 at N = 16 384).  Ragged shards are padded to the widest block on the wire and cut on the root."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local
-    full = all_gather_rows(local, n_total, group)
-    return full if dist.get_rank(group) == root else None
+    rank = dist.get_rank(group)
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    width = max(hi - lo for lo, hi in sizes)
+    pad = local
+    if local.shape[0] < width:
+        pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    pad = pad.contiguous()
+    host = local.is_cuda and dist.get_backend(group) == "gloo"  # (ranks sharing one GPU under gloo: staged through the host)
+    send = pad.cpu() if host else pad
+    dst = dist.get_global_rank(group, root) if group is not None else root
+    if rank != root:
+        dist.gather(send, None, dst=dst, group=group)
+        return None
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, bufs, dst=dst, group=group)
+    full = torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+    return full.to(local.device) if host else full
 
 
 def _all_reduce_max(t):

@@ -99,7 +99,8 @@ def build_parser():
            "bf16 = one plane (outside the 1e-3 score contract)")
     a("--enc_batch", default=249, type=int,
       help="windows per encoder batch (83 k: whole rounds of the 256 x 256 tile on the 256 CUs; 166 measured +2 %% over 83, "
-           "249 +1.3-2 %% more and is the largest the kernels' 32-bit byte offsets allow; ~37 GB of activations at 224^2)")
+           "249 +1.3-2 %% more; ~37 GB of activations at 224^2).  Cut to texture.max_enc_batch(img_size) — the kernels' signed "
+           "32-bit element offsets allow 267 clips at 224^2, 204 at 256^2; the bf16 path's dense clips 166 at 224^2")
     a("--enc_impl", default="auto", choices=["auto", "mfma", "module"],
       help="SlowFast at -e: hand-written MFMA convolutions (auto/mfma) or the nn.Module on MIOpen (module)")
     a("--dump_png", default=False, action="store_true",

@@ -72,6 +72,18 @@ def compat_window_frames(q_id, n_frames, W, S, mbs, n_gpus):
     return out, seg
 
 
+def max_enc_batch(img_size, planes=True):
+    """Largest SlowFast encoder batch the hand-written kernels take at `img_size`^2: their offsets are signed 32-bit ELEMENT
+    counts (csrc/conv_args.h conv_args_fill), and the widest tensor of a forward is the slow res2 input with its lateral
+    channels, [n, 8, hw/4, hw/4, 64 + 16 .. 256 + 64 = 320] (267 clips at 224^2, 204 at 256^2).  The bf16 path (planes=False)
+    also reads DENSE packed fast clips [n, 32, hw, hw, 4] through 32-bit BYTE offsets (2 bytes each: 166 at 224^2)."""
+    q = -(-int(img_size) // 4)
+    cap = ((1 << 31) - 64) // (8 * q * q * 320)
+    if not planes:
+        cap = min(cap, ((1 << 30) - 64) // (32 * int(img_size) ** 2 * 4) - 1)
+    return max(1, cap)
+
+
 class TextureEngine:
     # per-channel statistics of the reference's non-SlowFast transform (validate.py:90-92, dataset.py:50-52)
     GENERIC_MEAN = (0.4345, 0.4051, 0.3775)
@@ -97,10 +109,12 @@ class TextureEngine:
         self.planes = getattr(q_encoder, "planes", None) if self.layout == "ndhwc4" else None
         if self.layout == "ndhwc4" and getattr(t_encoder, "planes", None) != self.planes:
             raise AvtError("q and t encoders must use the same precision mode (they share the packed clips)")
-        if self.layout == "ndhwc4" and self.planes is None and self.hw >= 224:
-            # bf16 MFMA encoders read DENSE packed clips and keep wider concat buffers: 166 clips is what their kernels' 32-bit
-            # offsets take at 224^2 (the contract-grade path reads a frame table and goes to 249)
-            self.enc_batch = min(self.enc_batch, 166)
+        if self.layout == "ndhwc4" and self.slowfast:
+            # the MFMA kernels address a tensor with signed 32-bit element offsets: the batch is cut to what the widest
+            # activation of THIS image size allows (the default of 249 is the 224^2 figure, 256^2 needs <= 204)
+            cap = max_enc_batch(self.hw, self.planes is not None)
+            if self.enc_batch > cap:
+                self.enc_batch = cap
         self.frames = None
         self.A = self.A_da = self.Ad = None
         self._cache = {"q": {}, "t": {}}
@@ -172,7 +186,9 @@ class TextureEngine:
     # ---- packing + encoding ----------------------------------------------------------
     def _pack(self, frames, starts):
         lo, hi = int(starts.min()), int(starts.max()) + self.W
-        if self.planes is not None and self.layout == "ndhwc4" and FRAME_TABLE and hi - lo <= len(starts) * self.W:
+        # (the table's slow stem runs on EVERY frame of [lo, hi): worth it while that is no more than the 8 slow frames per window
+        #  the dense form convolves — overlapping windows, the default; windows scattered more thinly keep the dense clips)
+        if self.planes is not None and self.layout == "ndhwc4" and FRAME_TABLE and hi - lo <= len(starts) * 8:
             # contract-grade encoders: every distinct frame packed once, the windows' sampling as an index (ops.FrameClip);
             # windows scattered so thinly that the span holds more frames than the dense clips would keep the dense form
             return ops.clip_pack_frames(frames[lo:hi], starts - lo, self.W, out_hw=self.hw, mean=self.mean, std=self.std,

@@ -202,6 +202,41 @@ def test_sharded_walk_world4_equals_world1():
     assert np.array_equal(four["cnt"], one["cnt"]) and np.array_equal(four["sim"], one["sim"])
 
 
+def test_sharded_walk_world8_equals_world1():
+    """Eight ranks — the node north_star names — with ragged shards (51 = 3 x 7 + 5 x 6) and the audio columns: same frames list,
+    same matrix bits and survivor counts as one rank (dist.gather_to_root: ranks 1..7 send their blocks and get nothing back)."""
+    n = 51
+    mgr = mp.Manager()
+    one, eight = mgr.dict(), mgr.dict()
+    _walk_worker(0, 1, 0, n, True, one)
+    mp.spawn(_walk_worker, args=(8, 29761, n, True, eight), nprocs=8, join=True)
+    assert list(eight["frames"]) == list(one["frames"]) and len(one["frames"]) >= 200
+    assert np.array_equal(eight["cnt"], one["cnt"]) and np.array_equal(eight["sim"], one["sim"]) and eight["k"] == one["k"]
+
+
+def _gather_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import avtex  # noqa: F401
+    from avtex import dist as adist
+
+    adist.init_from_env(backend="gloo")
+    n = 11  # 11 rows over 3 ranks: 4 + 4 + 3
+    lo, hi = adist.shard_range(n, rank, world)
+    full = torch.arange(n * 5, dtype=torch.float32).view(n, 5)
+    got = adist.gather_to_root(full[lo:hi].contiguous(), n, root=0)
+    ret[rank] = None if got is None else got.numpy()
+    dist.destroy_process_group()
+
+
+def test_gather_to_root_sends_nothing_back():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_worker, args=(3, 29771, ret), nprocs=3, join=True)
+    assert ret[1] is None and ret[2] is None
+    assert np.array_equal(ret[0], np.arange(55, dtype=np.float32).reshape(11, 5))
+
+
 def test_sharded_plane_exchange_world2_equals_world1():
     """--sim_precision bf16x3 on the sharded route (validate.py): the all-gather carries the two bf16 planes of T_hat
     (N*D*2 B each, north_star's exchange) instead of fp32 rows; rows computed from gathered planes are bit-identical to

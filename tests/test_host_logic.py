@@ -105,6 +105,43 @@ def test_cli_flags_match_reference(avt):
     assert a.interpolation is False and a.model_type == 2 and a.stitch_mode == "compat" and a.vcam is False
 
 
+def test_every_reference_flag_is_frozen_in_the_parser(avt):
+    """every flag of the reference's main.py:41-296 with the same option strings, dest, default, type, action,
+    choices and nargs.  tests/golden/g11_cli.npz holds the 47 add_argument calls as data (tools/gen_golden.py gen_g11 reads the
+    reference's syntax tree); a default that drifts here fails by name."""
+    import json
+    import os
+
+    import numpy as np
+
+    rows = [json.loads(x) for x in np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_cli.npz"))["flags"]]
+    assert len(rows) == 47
+    p = __import__("avtex.main", fromlist=["x"]).build_parser()
+    by_dest = {}
+    for act in p._actions:
+        by_dest.setdefault(act.dest, act)
+    kinds = {"_StoreAction": "store", "_StoreTrueAction": "store_true", "_StoreFalseAction": "store_false"}
+    for r in rows:
+        act = by_dest.get(r["dest"])
+        assert act is not None, "flag %s (main.py:%d) is missing" % (r["opts"], r["line"])
+        assert sorted(act.option_strings) == sorted(r["opts"]), (r["dest"], act.option_strings, r["opts"])
+        assert kinds[type(act).__name__] == r["action"], (r["dest"], type(act).__name__, r["action"])
+        assert act.default == r["default"] and type(act.default) is type(r["default"]), (r["dest"], act.default, r["default"])
+        assert (act.type.__name__ if act.type is not None else None) == r["type"], (r["dest"], act.type, r["type"])
+        assert (list(act.choices) if act.choices is not None else None) == r["choices"], (r["dest"], act.choices, r["choices"])
+        nargs = act.nargs if r["action"] == "store" else None  # (argparse gives the flag actions an implicit nargs = 0)
+        assert nargs == r["nargs"] and bool(act.required) == r["required"], (r["dest"], act.nargs, act.required)
+
+
+def test_max_enc_batch_follows_the_image_size(avt):
+    """the encoder batch is cut to what the kernels' 32-bit element offsets take at THIS image size."""
+    from avtex.texture import max_enc_batch
+
+    assert max_enc_batch(224) >= 249 and max_enc_batch(224) * 8 * 56 * 56 * 320 < (1 << 31)
+    assert max_enc_batch(256) < 249 and max_enc_batch(256) * 8 * 64 * 64 * 320 < (1 << 31)
+    assert max_enc_batch(224, planes=False) == 166 and max_enc_batch(64, planes=False) > 249
+
+
 def test_checkpoint_keys_are_the_reference_prefixes(avt):
     from avtex.slowfast import SlowFast
 

@@ -501,13 +501,45 @@ def gen_g10():
     np.savez_compressed(os.path.join(OUT, "g10_interp.npz"), **out)
 
 
+def gen_g11():
+    """The reference CLI as data ("every flag in main.py:41-296 with same names, defaults, types"): one record per
+    parser.add_argument call of contrastive_video_textures/main.py, read from its syntax tree (the module itself is not
+    imported: its parser runs parse_args() at import) -> option strings, dest, default, type name, action, choices, nargs."""
+    import ast
+    import json
+
+    src = open(os.path.join(REF, "contrastive_video_textures", "main.py")).read()
+    rows = []
+    for node in ast.walk(ast.parse(src)):
+        if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument"
+                and isinstance(node.func.value, ast.Name) and node.func.value.id == "parser"):
+            continue
+        opts = [ast.literal_eval(a) for a in node.args]
+        kw = {}
+        for k in node.keywords:
+            if k.arg == "type":
+                kw["type"] = k.value.id if isinstance(k.value, ast.Name) else ast.unparse(k.value)
+            elif k.arg in ("default", "action", "choices", "nargs", "dest", "required", "const"):
+                kw[k.arg] = ast.literal_eval(k.value)
+        longs = [o for o in opts if o.startswith("--")]
+        dest = kw.get("dest") or (longs[0][2:] if longs else opts[0].lstrip("-")).replace("-", "_")
+        action = kw.get("action", "store")
+        default = kw.get("default", False if action == "store_true" else (True if action == "store_false" else None))
+        rows.append({"line": node.lineno, "opts": opts, "dest": dest, "default": default, "type": kw.get("type"), "action": action,
+                     "choices": kw.get("choices"), "nargs": kw.get("nargs"), "required": kw.get("required", False)})
+    rows.sort(key=lambda r: r["line"])
+    assert 41 <= rows[0]["line"] and rows[-1]["line"] <= 296, (rows[0]["line"], rows[-1]["line"])
+    np.savez_compressed(os.path.join(OUT, "g11_cli.npz"), flags=np.array([json.dumps(r, sort_keys=True) for r in rows]))
+    print("g11: %d add_argument calls, lines %d..%d" % (len(rows), rows[0]["line"], rows[-1]["line"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     import models  # noqa: F401  (reference)
     import utils as ref_utils
 
-    which = sys.argv[1:] or ["g1", "g3", "g5", "g6", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g3", "g5", "g6", "g8", "g9", "g10", "g11"]
     with torch.no_grad():
         if "g1" in which:
             gen_g1(ref_utils)
@@ -519,6 +551,8 @@ def main():
             gen_g9()
         if "g10" in which:
             gen_g10()
+    if "g11" in which:
+        gen_g11()
     if "g3" in which:
         gen_g3_g4(models)
     if "g8" in which:
