@@ -62,6 +62,11 @@ SIGNATURES = {
     "avt_bn_train_bwd": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                          C.c_int64, _vp],
     "avt_bn_train_ws_bytes": [C.c_int64, C.c_int, C.c_int],
+    "avt_bn_train_ws_bytes_pre": [C.c_int, C.c_int, C.c_int],
+    "avt_bn_train_fwd_pre": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_float, C.c_float, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp,
+                             _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp],
+    "avt_conv3d_igemm_x3_f32_stat_rows": [C.c_int, C.c_int, C.c_int64, C.c_int],
+    "avt_conv3d_igemm_x3_f32_stats": [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 18 + [_vp, C.c_int, C.c_int, _vp],
     "avt_conv3d_igemm_x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 19 + [_vp],
     "avt_conv3d_igemm_x3_f32_ex": [_vp] * 6 + [C.c_int] * 21 + [_vp],
     "avt_conv3d_wgrad_x3_f32": [_vp, _vp, _vp] + [C.c_int] * 17 + [_vp],
@@ -140,8 +145,8 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 6  # include/avt.h AVT_ABI_VERSION
-_RETURNS_I64 = {"avt_bn_train_ws_bytes"}  # sizes; every other entry returns an AVT_* status
+ABI_VERSION = 7  # include/avt.h AVT_ABI_VERSION
+_RETURNS_I64 = {"avt_bn_train_ws_bytes", "avt_bn_train_ws_bytes_pre"}  # sizes; every other entry returns an AVT_* status
 
 
 def check(status, what):

@@ -391,15 +391,60 @@ extern "C" int64_t avt_bn_train_ws_bytes(int64_t m, int c, int groups) {
   return (int64_t)ws_bytes(a);
 }
 
+// pre_rows > 0: the statistics pass is NOT run — the producing convolution's epilogue left `pre_rows` rows of partial sums per group
+// at the head of the workspace (avt_conv3d_igemm_x3_f32_stats / avt_pw_x3_f32_stats, in channel_sums' layout); the finalize
+// launch sums those instead.  Workspace: groups * (pre_rows * min(C / 4, 256) * 8 doubles) + groups * 2 C floats
+// (avt_bn_train_ws_bytes_pre).
+static int bn_train_fwd_impl(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
+                             float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,
+                             float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                             void* relu_mask, int64_t ldy, int pre_rows, void* stream);
+
+extern "C" int64_t avt_bn_train_ws_bytes_pre(int c, int groups, int pre_rows) {
+  if (!shape_ok(1, c) || groups < 1 || pre_rows < 1) return -1;
+  const int q = c / 4, nq = q < kT ? q : kT;
+  return (int64_t)groups * ((int64_t)pre_rows * nq * 8 * (int64_t)sizeof(double) + (int64_t)2 * c * (int64_t)sizeof(float));
+}
+
 extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
                                 float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,
                                 float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                 void* relu_mask, int64_t ldy, void* stream) {
+  return bn_train_fwd_impl(x, res, y, m, c, gamma, beta, eps, momentum, relu, groups, ws, ws_size, save_mean, save_invstd, running_mean,
+                           running_var, num_batches_tracked, relu_mask, ldy, 0, stream);
+}
+
+extern "C" int avt_bn_train_fwd_pre(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
+                                    float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,
+                                    float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                    void* relu_mask, int64_t ldy, int pre_rows, void* stream) {
+  AVT_REQUIRE(pre_rows > 0, "avt_bn_train_fwd_pre: pre_rows must be positive");
+  return bn_train_fwd_impl(x, res, y, m, c, gamma, beta, eps, momentum, relu, groups, ws, ws_size, save_mean, save_invstd, running_mean,
+                           running_var, num_batches_tracked, relu_mask, ldy, pre_rows, stream);
+}
+
+static int bn_train_fwd_impl(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
+                             float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,
+                             float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                             void* relu_mask, int64_t ldy, int pre_rows, void* stream) {
   AVT_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && (!running_mean == !running_var), "avt_bn_train_fwd: NULL pointer");
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(y) && (!res || avt::aligned16(res)), "avt_bn_train_fwd: rows must be 16-byte aligned");
   AVT_REQUIRE(avt::aligned16(beta) && avt::aligned16(save_mean), "avt_bn_train_fwd: beta / save_mean must be 16-byte aligned");
   BnArgs a = {};
-  const int rc = geometry(a, "avt_bn_train_fwd", m, c, groups, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
+  int rc;
+  if (pre_rows > 0) {  // the streaming geometry as usual (the apply pass), the partials' geometry from the producer
+    AVT_REQUIRE(shape_ok(m, c) && groups >= 1 && groups <= 65535 && m % groups == 0, "avt_bn_train_fwd_pre: bad shape");
+    a.groups = groups;
+    layout(a, m / groups, c);
+    const int64_t need = avt_bn_train_ws_bytes_pre(c, groups, pre_rows);
+    AVT_REQUIRE(ws && avt::aligned16(ws) && ws_size >= need && pre_rows % a.unit == 0,
+                "avt_bn_train_fwd_pre: workspace of %lld bytes needed (avt_bn_train_ws_bytes_pre), got %lld", (long long)need, (long long)ws_size);
+    a.part = static_cast<double*>(ws);
+    a.coef = reinterpret_cast<float*>(a.part + (size_t)groups * pre_rows * a.nq * 8);
+    rc = AVT_OK;
+  } else {
+    rc = geometry(a, "avt_bn_train_fwd", m, c, groups, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
+  }
   if (rc) return rc;
   a.x = x; a.res = res; a.out = y; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.relu = relu;
   a.save_mean = save_mean; a.save_invstd = save_invstd; a.running_mean = running_mean; a.running_var = running_var;
@@ -408,8 +453,14 @@ extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int6
   AVT_REQUIRE(ldy == 0 || (ldy >= c && ldy % 4 == 0), "avt_bn_train_fwd: ldy = %lld must be 0 (contiguous) or a multiple of 4 >= c", (long long)ldy);
   a.ld4 = (ldy ? ldy : c) / 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);
+  if (pre_rows > 0) {
+    BnArgs f = a;
+    f.blocks = pre_rows;  // rows of partials per group, as the producer wrote them
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, f);
+  } else {
+    hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, a);
+  }
   hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
   return avt::check_launch("avt_bn_train_fwd");
 }

@@ -68,7 +68,47 @@ struct ConvArgs {
                         // pre-scaled into the fp16 normal range), or NULL
   int cf_ofs;           // x3 kernels: LDS byte offset of the tile's [bias BN | scale BN] floats (set by the launchers; filled in the
                         // prologue, read by the epilogue from LDS instead of one global load per accumulator group)
+  // BatchNorm statistics on the epilogue (round 5; IO32 tiles, avt_conv3d_igemm_x3_f32_stats): the layer's output feeds a train-mode
+  // BatchNorm, whose statistics pass would re-read it.  The rows are `stat_groups` slabs of `stat_mg` rows with statistics of their
+  // own (bn_train.hip GROUPS); the M tiles are laid PER GROUP (stat_tpg tiles each, the last one short) so that no tile straddles
+  // two groups, and every tile leaves the per-channel sum / sum of squares of its rows in `stat_part` in the layout
+  // bn_fwd_finalize_kernel sums over (one row of partials per tile).  stat_part = NULL: off, tiles walk the rows 0 .. M.
+  double* stat_part;
+  int stat_groups, stat_mg, stat_tpg;
+  int stat_c;           // BatchNorm channels: Cout, or Cout / g for the pixel-grouped form (columns n and n + stat_c are one channel)
 };
+
+// this tile's first row and the end of the rows it may touch (its group's end when the tiles are laid per group)
+__device__ __forceinline__ void tile_rows(const ConvArgs& a, int tm, int bm, int& m0, int& m_end) {
+  if (a.stat_part) {
+    const int g = tm / a.stat_tpg, t = tm - g * a.stat_tpg;
+    m0 = g * a.stat_mg + t * bm;
+    m_end = (g + 1) * a.stat_mg;
+  } else {
+    m0 = tm * bm;
+    m_end = a.M;
+  }
+}
+
+// BatchNorm partials of one tile: `red` = [nrow][2][BN] floats in LDS (per thread-row sums / sums of squares of the tile's
+// columns); thread i < 2 * nch folds the thread-rows (and, pixel-grouped form, the columns of one channel) in fp64 and writes the
+// slot bn_train.hip's channel_sums reads: row (tm * unit + quad / 256), slot (quad % nq) * 8 + e (+ 4 for the squares)
+template <int BN, int NTHR>
+__device__ __forceinline__ void stat_fold_store(const ConvArgs& a, const float* red, int nrow, int tm, int n0, int tid) {
+  const int C = a.stat_c;
+  int ncols = a.Cout - n0;
+  ncols = ncols < BN ? ncols : BN;
+  const int nch = ncols < C ? ncols : C;
+  const int q4 = C / 4, nq = q4 < 256 ? q4 : 256, unit = q4 > 256 ? q4 / 256 : 1;
+  for (int i = tid; i < 2 * nch; i += NTHR) {
+    const int qi = i / nch, ch = i - qi * nch;
+    double acc = 0.0;
+    for (int col = ch; col < ncols; col += C)
+      for (int r = 0; r < nrow; ++r) acc += (double)red[(r * 2 + qi) * BN + col];
+    const int c = (n0 + ch) % C, quad = c >> 2, e = c & 3;
+    a.stat_part[((size_t)tm * unit + (quad >> 8)) * nq * 8 + (size_t)(quad % nq) * 8 + e + 4 * qi] = acc;
+  }
+}
 
 
 
@@ -158,6 +198,8 @@ inline int conv_args_fill(ConvArgs& a, const char* who, const void* in, const vo
   a.ors = out_row_stride;
   a.oH = remap ? out_h : 0;
   a.oW = remap ? out_w : 0;
+  a.stat_part = nullptr;
+  a.stat_groups = a.stat_mg = a.stat_tpg = a.stat_c = 0;
   return AVT_OK;
 }
 

@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 
   const int swz = avt::xcd_contiguous(blockIdx.x, a.nblk);  // consecutive tiles of one XCD share activation rows
   const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int n0 = tn * BN;
+  int m0, m_end;  // (IO32 with BatchNorm statistics: the tiles are laid per group and end with their group; else 0 .. M)
+  if constexpr (IO32) tile_rows(a, tm, BM, m0, m_end);
+  else { m0 = tm * BM; m_end = a.M; }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -122,10 +125,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     const int m = m0 + r0 + 32 * u;
     rowoff[u] = 0;
     rowmask[u] = 0u;
-    if (m < a.M && a.pointwise) {
+    if (m < m_end && a.pointwise) {
       rowoff[u] = m * a.ldi;
       rowmask[u] = 0x010101u;
-    } else if (m < a.M) {
+    } else if (m < m_end) {
       const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
       const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
       const int b = (int)fastdiv((uint32_t)t2, a.dTo), to = t2 - b * a.To;
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     for (int u = 0; u < EU; ++u) {
       const int c = tid + 256 * u;
       const int m = m0 + c / CPR, n = n0 + (c % CPR) * 8;
-      const bool ok = m < a.M && n < a.Cout;
+      const bool ok = m < m_end && n < a.Cout;
       rrh[u] = ok ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
       rrl[u] = ok ? *reinterpret_cast<const uint4*>(a.res_lo + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
     }
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       for (int u = 0; u < EU; ++u) {
         const int c = tid + 256 * u;
         const int m = m0 + c / CPR, n = n0 + (c % CPR) * 8;
-        const bool ok = m < a.M && n < a.Cout;
+        const bool ok = m < m_end && n < a.Cout;
         const float* rf = reinterpret_cast<const float*>(a.res) + (int64_t)m * a.ldr + n;
         rrh[u] = ok ? *reinterpret_cast<const uint4*>(rf) : make_uint4(0u, 0u, 0u, 0u);
         rrl[u] = ok ? *reinterpret_cast<const uint4*>(rf + 4) : make_uint4(0u, 0u, 0u, 0u);
@@ -380,12 +383,18 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       }
     }
   __syncthreads();
+  // BatchNorm statistics of the rows this thread stores (its 8 channels are the same in every row: 256 % CPR == 0)
+  float st_s[IO32 ? 8 : 1], st_q[IO32 ? 8 : 1];
+  if constexpr (IO32) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.0f;
+  }
 #pragma unroll
   for (int u = 0; u < EU; ++u) {
     const int c = tid + 256 * u;
     const int row = c / CPR, cc = c % CPR;
     const int m = m0 + row, n = n0 + cc * 8;
-    if (m < a.M && n < a.Cout) {
+    if (m < m_end && n < a.Cout) {
       const float4 v0 = *reinterpret_cast<const float4*>(lds + row * ESTR + cc * 32);
       const float4 v1 = *reinterpret_cast<const float4*>(lds + row * ESTR + cc * 32 + 16);
       float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -414,6 +423,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
           x[0] += r0_.x; x[1] += r0_.y; x[2] += r0_.z; x[3] += r0_.w;
           x[4] += r1_.x; x[5] += r1_.y; x[6] += r1_.z; x[7] += r1_.w;
         }
+        if (a.stat_part) {  // (uniform) the values as stored: what the BatchNorm's own statistics pass would read back
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            st_s[e] += x[e];
+            st_q[e] += x[e] * x[e];
+          }
+        }
         float* of = reinterpret_cast<float*>(a.out) + o;
         // (whole 128-byte lines of a tensor far larger than the caches: non-temporal stores, +0.8 % on the training step)
         typedef float f32x4n __attribute__((ext_vector_type(4)));
@@ -425,6 +441,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
         *reinterpret_cast<uint4*>(a.out + o) = oh;
         *reinterpret_cast<uint4*>(a.out_lo + o) = ol;
       }
+    }
+  }
+  if constexpr (IO32) {
+    if (a.stat_part) {  // per-thread sums (fp32 over <= 8 rows) -> LDS [thread-row][sum | squares][column] -> fp64 fold -> the tile's row
+      __syncthreads();  // (the staging rows have been read)
+      float* red = reinterpret_cast<float*>(lds);
+      const int tr = tid / CPR, cc = tid % CPR;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(tr * 2 + 0) * BN + cc * 8 + e] = st_s[e];
+        red[(tr * 2 + 1) * BN + cc * 8 + e] = st_q[e];
+      }
+      __syncthreads();
+      stat_fold_store<BN, 256>(a, red, 256 / CPR, tm, n0, tid);
     }
   }
   STAMP_END();
@@ -461,7 +491,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
 
   const int swz = avt::xcd_contiguous(blockIdx.x, a.nblk);
   const int tm = swz / a.tiles_n, tn = swz % a.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int n0 = tn * BN;
+  int m0, m_end;  // (IO32 with BatchNorm statistics: tiles laid per group; see conv_args.h)
+  if constexpr (IO32) tile_rows(a, tm, BM, m0, m_end);
+  else { m0 = tm * BM; m_end = a.M; }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
@@ -477,10 +510,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
     const int m = m0 + r0 + 128 * u;
     rowoff[u] = 0;
     rowmask[u] = 0u;
-    if (m < a.M && a.pointwise) {
+    if (m < m_end && a.pointwise) {
       rowoff[u] = m * a.ldi;
       rowmask[u] = 0x010101u;
-    } else if (m < a.M) {
+    } else if (m < m_end) {
       const int t1 = (int)fastdiv((uint32_t)m, a.dWo), wo = m - t1 * a.Wo;
       const int t2 = (int)fastdiv((uint32_t)t1, a.dHo), ho = t1 - t2 * a.Ho;
       const int b = (int)fastdiv((uint32_t)t2, a.dTo), to = t2 - b * a.To;
@@ -750,6 +783,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   if (wm == 0) stage_slab(std::integral_constant<int, 0>{}, 0);
   __syncthreads();
   EPI_STAMP(1);
+  // BatchNorm statistics of the rows this thread stores over the four passes (its 8 channels are the same in every row)
+  float st_s[IO32 ? 8 : 1], st_q[IO32 ? 8 : 1];
+  if constexpr (IO32) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.0f;
+  }
 #pragma unroll 1
   for (int pass = 0; pass < 4; ++pass) {
     const char* eb = lds + (pass & 1) * EBUF;
@@ -759,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       for (int u = 0; u < EU; ++u) {
         const int c = tid + NTHR * u;
         const int m = m0 + pass * SR + c / CPR, n = n0 + (c % CPR) * 8;
-        const bool ok = m < a.M && n < a.Cout;
+        const bool ok = m < m_end && n < a.Cout;
         rrh[u] = ok ? *reinterpret_cast<const uint4*>(a.res + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
         rrl[u] = ok ? *reinterpret_cast<const uint4*>(a.res_lo + (int64_t)m * a.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
       }
@@ -770,7 +809,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
         for (int u = 0; u < EU; ++u) {
           const int c = tid + NTHR * u;
           const int m = m0 + pass * SR + c / CPR, n = n0 + (c % CPR) * 8;
-          const bool ok = m < a.M && n < a.Cout;
+          const bool ok = m < m_end && n < a.Cout;
           const float* rf = reinterpret_cast<const float*>(a.res) + (int64_t)m * a.ldr + n;
           rrh[u] = ok ? *reinterpret_cast<const uint4*>(rf) : make_uint4(0u, 0u, 0u, 0u);
           rrl[u] = ok ? *reinterpret_cast<const uint4*>(rf + 4) : make_uint4(0u, 0u, 0u, 0u);
@@ -787,7 +826,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
       const int c = tid + NTHR * u;
       const int row = c / CPR, cc = c % CPR;
       const int m = m0 + pass * SR + row, n = n0 + cc * 8;
-      if (m < a.M && n < a.Cout) {
+      if (m < m_end && n < a.Cout) {
         const float4 v0 = *reinterpret_cast<const float4*>(eb + row * ESTR + cc * 32);
         const float4 v1 = *reinterpret_cast<const float4*>(eb + row * ESTR + cc * 32 + 16);
         float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -815,6 +854,13 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
             x[0] += q0.x; x[1] += q0.y; x[2] += q0.z; x[3] += q0.w;
             x[4] += q1.x; x[5] += q1.y; x[6] += q1.z; x[7] += q1.w;
           }
+          if (a.stat_part) {  // (uniform)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              st_s[e] += x[e];
+              st_q[e] += x[e] * x[e];
+            }
+          }
           float* of = reinterpret_cast<float*>(a.out) + o;
           typedef float f32x4n __attribute__((ext_vector_type(4)));
           __builtin_nontemporal_store(f32x4n{x[0], x[1], x[2], x[3]}, reinterpret_cast<f32x4n*>(of));
@@ -831,12 +877,26 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
     __syncthreads();  // slab pass + 1 is staged; buffer pass & 1 is free for slab pass + 2
     EPI_STAMP(4);
   }
+  if constexpr (IO32) {
+    if (a.stat_part) {  // 16 thread-rows x [sum | squares] x 256 columns in the (free) staging area -> fp64 fold -> the tile's row
+      float* red = reinterpret_cast<float*>(lds);
+      const int tr = tid / CPR, cc = tid % CPR;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(tr * 2 + 0) * BN + cc * 8 + e] = st_s[e];
+        red[(tr * 2 + 1) * BN + cc * 8 + e] = st_q[e];
+      }
+      __syncthreads();
+      stat_fold_store<BN, NTHR>(a, red, NTHR / CPR, tm, n0, tid);
+    }
+  }
   STAMP_END();
 }
 
 template <bool F16, bool IO32 = false>
 int launch_x3_xl(ConvArgs& a, hipStream_t st) {
-  const int tiles_m = (a.M + 255) / 256;
+  if (a.stat_part) a.stat_tpg = (a.stat_mg + 255) / 256;
+  const int tiles_m = a.stat_part ? a.stat_groups * a.stat_tpg : (a.M + 255) / 256;
   a.tiles_n = (a.Cout + 255) / 256;
   a.nblk = tiles_m * a.tiles_n;
   constexpr int lds_max = 2 * 4 * 256 * 64 + kMaxTabSteps * 64 + 2 * 256 * 4;
@@ -854,7 +914,8 @@ int launch_x3_xl(ConvArgs& a, hipStream_t st) {
 
 template <int BM, int BN, int WTM, bool F16, bool IO32 = false>
 int launch_x3(ConvArgs& a, hipStream_t st) {
-  const int tiles_m = (a.M + BM - 1) / BM;
+  if (a.stat_part) a.stat_tpg = (a.stat_mg + BM - 1) / BM;
+  const int tiles_m = a.stat_part ? a.stat_groups * a.stat_tpg : (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
   a.nblk = tiles_m * a.tiles_n;
   // operand slabs + the tap table of THIS layer (not the 128-step maximum): the wide tile then needs 73.7 + <= 6 KB for
@@ -949,10 +1010,16 @@ extern "C" int avt_conv3d_igemm_x3_wblk(const void* in_hi, const void* in_lo, co
 }
 
 // fp32 rows in, fp32 rows out, split-plane arithmetic in between (the IO32 form of the kernel): see include/avt.h
+// the IO32 tile that avt_conv3d_igemm_x3_f32 launches for (cout, K, M): 256 = the XL tile, else 128 (rows per tile)
+static int io32_tile_rows(int cout, int k, int64_t m) {
+  return (k % 32 == 0 && m < (1ll << 31) && avt_conv3d_igemm_x3_xl_picked(cout, k, (int)m) && m >= 256 * 256) ? 256 : 128;
+}
+
 static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
                              float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
                              int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi, int ldo, int lda,
-                             int out_row_stride, int out_h, int out_w, int plane_dtype, void* stream) {
+                             int out_row_stride, int out_h, int out_w, int plane_dtype, void* stream, double* stat_part = nullptr,
+                             int stat_groups = 0, int stat_c = 0) {
   AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_conv3d_igemm_x3_f32: plane_dtype must be 0 (bf16) or 1 (fp16)");
   AVT_REQUIRE(wt_lo && avt::aligned16(wt_lo) && (!wscale || avt::aligned16(wscale)), "avt_conv3d_igemm_x3_f32: weight planes / wscale NULL or unaligned");
   AVT_REQUIRE((int64_t)batch * t * h * w * ldi < (1ll << 30) - 64, "avt_conv3d_igemm_x3_f32: input too large for 32-bit byte offsets");
@@ -969,9 +1036,19 @@ static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_
   a.wfrag = nullptr;
   a.nup = 0;
   a.wblk = 0;
+  if (stat_part) {
+    AVT_REQUIRE(stat_groups >= 1 && a.M % stat_groups == 0 && stat_c >= 8 && cout % stat_c == 0 && a.oH == 0 && !add && avt::aligned16(stat_part),
+                "avt_conv3d_igemm_x3_f32_stats: %d rows in %d groups, %d channels of %d columns, no row remap, no add operand", a.M,
+                stat_groups, stat_c, cout);
+    a.stat_part = stat_part;
+    a.stat_groups = stat_groups;
+    a.stat_mg = a.M / stat_groups;
+    a.stat_c = stat_c;
+    AVT_REQUIRE((int64_t)stat_groups * ((a.stat_mg + 127) / 128) < (1ll << 24), "avt_conv3d_igemm_x3_f32_stats: too many tiles");
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   // long-K layers at a batch that fills 256 x 256 tiles (a rank's items as one batch): the XL tile's IO32 form
-  if (a.K % 32 == 0 && a.oH == 0 && avt_conv3d_igemm_x3_xl_picked(cout, a.K, a.M) && a.M >= 256 * 256)
+  if (a.oH == 0 && io32_tile_rows(cout, a.K, a.M) == 256)
     return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, true>(a, s) : launch_x3_xl<false, true>(a, s);
   if (plane_dtype == AVT_X3_F16) {
     if (cout <= 32) return launch_x3<128, 32, 32, true, true>(a, s);
@@ -989,6 +1066,23 @@ extern "C" int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const
                                        void* stream) {
   return igemm_x3_f32_impl(in, wt_hi, wt_lo, wscale, add, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw, st, sh, sw, pt, ph, pw, 0, 0, 0,
                            ldi, ldo, lda, 1, 0, 0, plane_dtype, stream);
+}
+
+// ... leaving the train-mode BatchNorm statistics of its output behind (see include/avt.h): per-tile sums in `stat_part`, the rows as
+// `groups` slabs with statistics of their own; avt_conv3d_igemm_x3_f32_stat_rows = rows of partials per group it writes
+extern "C" int avt_conv3d_igemm_x3_f32_stat_rows(int cout, int k, int64_t m, int groups) {
+  if (groups < 1 || m <= 0 || m % groups) return -1;
+  const int bm = io32_tile_rows(cout, k, m);
+  return (int)((m / groups + bm - 1) / bm);
+}
+
+extern "C" int avt_conv3d_igemm_x3_f32_stats(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
+                                             const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
+                                             int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype,
+                                             void* stat_part, int groups, int stat_c, void* stream) {
+  AVT_REQUIRE(stat_part, "avt_conv3d_igemm_x3_f32_stats: NULL stat_part");
+  return igemm_x3_f32_impl(in, wt_hi, wt_lo, wscale, nullptr, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw, st, sh, sw, pt, ph, pw, 0, 0, 0,
+                           ldi, ldo, 0, 1, 0, 0, plane_dtype, stream, static_cast<double*>(stat_part), groups, stat_c);
 }
 
 // ... with an explicit output extent (any padding on the far side) and the output-row remap of avt_conv3d_igemm_x3: one class of

@@ -109,6 +109,19 @@ def barrier_max_time(seconds, device):
     return float(t.item())
 
 
+def all_ranks_scalar(value, device):
+    """A local scalar of every rank -> list in rank order on every rank (bench.py: per-rank step times, so that a straggler is
+    visible next to the max-over-ranks figure the contract reports)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    world = dist.get_world_size()
+    host = dist.get_backend() == "gloo"
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if host else device)
+    out = torch.empty(world, dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return [float(v) for v in out.cpu()]
+
+
 class HipCompute:
     """The device arithmetic of the sharded build: the C-ABI kernels (include/avt.h).  The orchestration below only
     needs these three calls; tests/test_dist_gloo.py injects the CPU oracle in their place to run the collectives and

@@ -170,7 +170,7 @@ def main(args, video_name, itr=0):
         # default) is split-plane MFMA, not bit-for-bit fp32 — printed so that a log says which one trained the model.
         from . import train_ops
 
-        model = model.to(memory_format=torch.channels_last_3d)
+        model = train_ops.training_layout(model)
         mode = train_ops.set_conv_mode(getattr(args, "train_conv", "x3"))
         if rank == 0:
             print("training convolutions: %s" % ("split-plane MFMA (x3: fp16 planes forward 2^-22, bf16 planes gradients 2^-16, "

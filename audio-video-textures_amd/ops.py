@@ -408,6 +408,28 @@ def conv3d_igemm_x3_f32(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, ker
                                                   int(cout), int(plane_dtype), _stream()), "avt_conv3d_igemm_x3_f32")
 
 
+def conv3d_igemm_x3_f32_stats(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype, groups, stat_c):
+    """conv3d_igemm_x3_f32 that also leaves the train-mode BatchNorm statistics of its output behind (include/avt.h): -> (ws, pre_rows),
+    the BatchNorm workspace with the per-tile partial sums at its head, for avt_bn_train_fwd_pre."""
+    b, t, h, w = dims
+    _dev(x, "x", torch.float32)
+    _dev(out, "out", torch.float32)
+    _dev(wt_hi, "wt_hi", torch.bfloat16)
+    _dev(wt_lo, "wt_lo", torch.bfloat16)
+    k = int(kernel[0]) * int(kernel[1]) * int(kernel[2]) * int(cin)
+    m = out.numel() // int(cout)
+    rows = _lib.lib().avt_conv3d_igemm_x3_f32_stat_rows(int(cout), k, int(m), int(groups))
+    if rows <= 0:
+        raise _lib.AvtError("conv3d_igemm_x3_f32_stats: %d rows do not split into %d groups" % (m, groups))
+    pre_rows = rows * max(1, int(stat_c) // 1024)
+    ws = torch.empty(_lib.lib().avt_bn_train_ws_bytes_pre(int(stat_c), int(groups), pre_rows), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().avt_conv3d_igemm_x3_f32_stats(_p(x), _p(wt_hi), _p(wt_lo), _p(wscale), _p(out), _p(ktab), int(b), int(t), int(h),
+                                                        int(w), int(cin), int(cout), *[int(v) for v in kernel], *[int(v) for v in stride],
+                                                        *[int(v) for v in pad], int(ldi), int(ldo), int(plane_dtype), _p(ws), int(groups),
+                                                        int(stat_c), _stream()), "avt_conv3d_igemm_x3_f32_stats")
+    return ws, pre_rows
+
+
 def pw_x3_f32_supported(k, n):
     return bool(_lib.lib().avt_pw_x3_f32_supported(int(k), int(n)))
 

@@ -63,7 +63,7 @@ class FuseFastToSlow(nn.Module):
         # torch.cat([slow, lateral], 1); in train mode on the GPU the slow pathway's producer left room for the lateral channels
         # (cat_extra) and the lateral BatchNorm writes them in place: no copy either way (train_ops.join_channels)
         tag = getattr(x[0], "_avt_cat", None)
-        lat = bn_act(conv3d(x[1], self.conv_f2s), self.bn, relu=True, cat_into=None if tag is None else (tag[0], x[0].shape[1]))
+        lat = bn_act(conv3d(x[1], self.conv_f2s, stats=self.bn), self.bn, relu=True, cat_into=None if tag is None else (tag[0], x[0].shape[1]))
         return [join_channels(x[0], lat), x[1]]
 
 
@@ -97,12 +97,13 @@ class ResBlock(nn.Module):
     def forward(self, x, cat_extra=0):
         t = self.branch2
         # (train mode on the GPU: the shortcut's gradient is summed into a's input gradient inside that kernel, train_ops)
-        h, xs = conv3d_fork(x, t.a)
-        sc = bn_act(conv3d(xs, self.branch1), self.branch1_bn, relu=False) if hasattr(self, "branch1") else xs
+        # (stats=bn: the convolution's epilogue leaves that BatchNorm's batch statistics behind — no statistics pass over its output)
+        h, xs = conv3d_fork(x, t.a, stats=t.a_bn)
+        sc = bn_act(conv3d(xs, self.branch1, stats=self.branch1_bn), self.branch1_bn, relu=False) if hasattr(self, "branch1") else xs
         h = bn_act(h, t.a_bn, relu=True)
-        h = bn_act(conv3d(h, t.b), t.b_bn, relu=True)
+        h = bn_act(conv3d(h, t.b, stats=t.b_bn), t.b_bn, relu=True)
         # c's BatchNorm, the shortcut add and the block's ReLU: one pass in train mode (csrc/bn_train.hip), the stock ops else
-        return bn_act(conv3d(h, t.c), t.c_bn, res=sc, relu=True, cat_extra=cat_extra)
+        return bn_act(conv3d(h, t.c, stats=t.c_bn), t.c_bn, res=sc, relu=True, cat_extra=cat_extra)
 
 
 class ResStage(nn.Module):

@@ -36,6 +36,7 @@ _STEM_WGRAD_X3 = 1  # the stems' weight gradient on the hand-written kernels
 _PLANES_HIP = 1     # weight planes by csrc/stem_train.hip's two kernels (0: torch ops)
 _STEM_PATCH = 1     # the stems on the patch-resident kernels (0: conv_x3 + wgrad slices)
 _FORK = 1           # the shortcut's gradient summed in the a-convolution's input-gradient epilogue
+_EPI_STATS = 1      # BatchNorm forward statistics on the producing convolution's epilogue (round 5: no statistics pass over its output)
 
 
 def set_conv_mode(mode):
@@ -60,7 +61,8 @@ def invalidate_weight_cache():
 
 # per-process launch counters of the hand-written training kernels (tests assert that the default path really runs them)
 CALLS = {"conv_fwd_x3": 0, "dgrad_x3": 0, "dgrad_strided_x3": 0, "wgrad_x3": 0, "wgrad_stem_x3": 0, "bn_fwd": 0, "bn_bwd": 0,
-         "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0, "maxpool_hip": 0, "pw_f32": 0}
+         "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0, "maxpool_hip": 0, "pw_f32": 0,
+         "bn_fwd_pre": 0}
 
 
 def _p(t):
@@ -167,10 +169,21 @@ class _JoinChannels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, buf):
         ctx.c0 = a.shape[1]
-        return _alias(buf, 0, buf.shape[1])  # the buffer both producers wrote, as a tensor of this node's own
+        # INVARIANT: the slices and the joined tensor share storage OUTSIDE autograd's view tracking — their only
+        # writers are the producing kernels, and nothing may modify them in place afterwards (an nn.ReLU(inplace=True) or `+=` on
+        # one of them would corrupt the others' saved activations without autograd noticing).  The version counters are stamped
+        # here and compared in backward, so that such an edit raises instead of training on garbage.
+        out = _alias(buf, 0, buf.shape[1])  # the buffer both producers wrote, as a tensor of this node's own
+        ctx.stamp = ((a, a._version), (b, b._version), (out, out._version))
+        return out
 
     @staticmethod
     def backward(ctx, d):
+        for t, v in ctx.stamp:
+            if t._version != v:
+                raise RuntimeError("train_ops.join_channels: a channel slice of the concatenation buffer (or the joined tensor) was "
+                                   "modified in place after the join; the slices share storage outside autograd's view tracking")
+        ctx.stamp = None
         return d[:, : ctx.c0], d[:, ctx.c0 :], None
 
 
@@ -185,23 +198,31 @@ def join_channels(a, b):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps, tracked=None, groups=1, cat=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps, tracked=None, groups=1, cat=None, pre=None):
         m, c = _rows(x)
         if cat is None:
             y, ldy = torch.empty_like(x), 0  # keeps the channels-last strides
         else:  # (buffer, channel offset): the output is that slice of the concatenation buffer's rows
             y, ldy = _alias(cat[0], cat[1], c), cat[0].shape[1]
-        ws = _workspace(m, c, groups, x.device)
         save_mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         CALLS["bn_fwd"] += 1
         # ReLU with a shortcut: the mask leaves the apply pass as 4 bits per float4 chunk and is what the backward reads;
         # without a shortcut the backward recomputes it from x.  Either way the output is not read again, nor kept alive here
         mask = torch.empty(m * c // 4, dtype=torch.uint8, device=x.device) if (relu and res is not None) else None
-        _lib.check(_lib.lib().avt_bn_train_fwd(_p(x), _p(res), _p(y), m, c, _p(weight), _p(bias), float(eps), float(momentum),
-                                               1 if relu else 0, groups, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
-                                               _p(running_mean), _p(running_var), _p(tracked), _p(mask), ldy, _stream()),
-                   "avt_bn_train_fwd")
+        if pre is not None:  # (workspace, rows of partials per group): the producing convolution's epilogue has summed the rows
+            ws, pre_rows = pre
+            CALLS["bn_fwd_pre"] += 1
+            _lib.check(_lib.lib().avt_bn_train_fwd_pre(_p(x), _p(res), _p(y), m, c, _p(weight), _p(bias), float(eps), float(momentum),
+                                                       1 if relu else 0, groups, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
+                                                       _p(running_mean), _p(running_var), _p(tracked), _p(mask), ldy, int(pre_rows),
+                                                       _stream()), "avt_bn_train_fwd_pre")
+        else:
+            ws = _workspace(m, c, groups, x.device)
+            _lib.check(_lib.lib().avt_bn_train_fwd(_p(x), _p(res), _p(y), m, c, _p(weight), _p(bias), float(eps), float(momentum),
+                                                   1 if relu else 0, groups, _p(ws), ws.numel(), _p(save_mean), _p(save_invstd),
+                                                   _p(running_mean), _p(running_var), _p(tracked), _p(mask), ldy, _stream()),
+                       "avt_bn_train_fwd")
         ctx.save_for_backward(x, mask, weight, bias, save_mean, save_invstd)
         ctx.has_res = res is not None
         ctx.relu = bool(relu)
@@ -224,7 +245,7 @@ class _BNAct(torch.autograd.Function):
         _lib.check(_lib.lib().avt_bn_train_bwd(_p(dy), None, _p(x), m, c, _p(weight), _p(bias), _p(save_mean), _p(save_invstd),
                                                1 if ctx.relu else 0, ctx.groups, _p(mask), _p(ws), ws.numel(), _p(dx), _p(dres),
                                                _p(dgamma), _p(dbeta), ld_dy, _stream()), "avt_bn_train_bwd")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 def bn_act(x, bn, res=None, relu=True, cat_extra=0, cat_into=None):
@@ -264,7 +285,12 @@ def bn_act(x, bn, res=None, relu=True, cat_extra=0, cat_into=None):
         cat = cat_into
     elif cat_extra:
         cat = (_cat_buffer(x.shape, x.shape[1] + int(cat_extra), x.device), 0)
-    y = _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps, tracked, groups, cat)
+    # statistics the producing convolution left behind (conv3d(..., stats=bn)): valid for exactly this BatchNorm geometry
+    pre = getattr(x, "_avt_stats", None)
+    if pre is not None and (pre[2] != groups or pre[3] != x.shape[1]):
+        pre = None
+    y = _BNAct.apply(x, bn.weight, bn.bias, rm, rv, res, relu, 0.0 if momentum is None else momentum, bn.eps, tracked, groups, cat,
+                     None if pre is None else pre[:2])
     if cat is not None:
         y._avt_cat = cat
     return y
@@ -399,10 +425,13 @@ def _weight_planes(weight, transposed):
     changes the tensor.  transposed: the dgrad filter W'[ci, co, flipped taps], as bf16 planes."""
     from . import ops
     from .fused_slowfast import split_planes
-    key = (id(weight), bool(transposed))
+    # keyed on the tensor that OWNS the storage: conv2d hands over `conv.weight.unsqueeze(2)`, a fresh view per call, which never
+    # hit the cache and left an entry per call behind (ADVICE r4); a view shares its base's version counter
+    owner = weight._base if weight._base is not None else weight
+    key = (id(owner), bool(transposed), tuple(weight.shape))
     hit = _PLANES.get(key)
     # (the entry remembers WHICH tensor it was made from: an id — like an address — can be reused after the first one died)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+    if hit is not None and hit[0]() is owner and hit[1] == owner._version:
         return hit[2]
     with torch.no_grad():
         w = weight.detach()
@@ -435,7 +464,7 @@ def _weight_planes(weight, transposed):
     if len(_PLANES) > 4096:  # entries of models that are gone
         for k in [k for k, v in _PLANES.items() if v[0]() is None]:
             del _PLANES[k]
-    _PLANES[key] = (weakref.ref(weight), weight._version, planes)
+    _PLANES[key] = (weakref.ref(owner), owner._version, planes)
     return planes
 
 
@@ -496,14 +525,28 @@ def _grouped_planes(weight, g, transposed, plane_dtype):
     return planes
 
 
-def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=None, group=None):
-    """x [B, Cin, T, H, W] channels-last fp32 -> [B, Cout, To, Ho, Wo] channels-last fp32 (+ add, same shape, in the epilogue)."""
+_LAST_STATS = None  # (output data_ptr, workspace, rows of partials per group, groups, channels) of the last convolution that left
+#                     BatchNorm statistics behind: handed from inside the autograd Function to conv3d(), which tags the output
+
+
+def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=None, group=None, stats=0):
+    """x [B, Cin, T, H, W] channels-last fp32 -> [B, Cout, To, Ho, Wo] channels-last fp32 (+ add, same shape, in the epilogue).
+    stats = n > 0: the output feeds a train-mode BatchNorm of n replica groups — the kernel's epilogue leaves its statistics'
+    partial sums (ops.conv3d_igemm_x3_f32_stats; recorded in _LAST_STATS).  Layers on the streaming pointwise kernel do not yet."""
+    global _LAST_STATS
     from . import ops
     b, _, t, h, w = x.shape
     od = [(n + 2 * p - k) // s_ + 1 for n, p, k, s_ in zip((t, h, w), pad, kernel, stride)]
     y = torch.empty((b, cout, od[0], od[1], od[2]), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+    stats = int(stats) if (stats and add is None and (cout & (cout - 1)) == 0 and cout >= 8 and b % int(stats) == 0) else 0
     if group is not None:  # (g, grouped kernel, rg): the same memory as [.., w / g, g * C] rows, block-Toeplitz planes
         g, gk, rg = group
+        if stats:
+            ws, pre_rows = ops.conv3d_igemm_x3_f32_stats(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
+                                                         _ktab(g * cin, gk, h, w // g, g * cin, x.device), (b, t, h, w // g), g * cin, g * cout,
+                                                         gk, (1, 1, 1), (pad[0], pad[1], rg), g * cin, g * cout, plane_dtype, stats, cout)
+            _LAST_STATS = (y.data_ptr(), ws, pre_rows, stats, cout)
+            return y
         ops.conv3d_igemm_x3_f32(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
                                 _ktab(g * cin, gk, h, w // g, g * cin, x.device), (b, t, h, w // g), g * cin, g * cout, gk, (1, 1, 1),
                                 (pad[0], pad[1], rg), g * cin, g * cout, plane_dtype, add=None if add is None else add.permute(0, 2, 3, 4, 1))
@@ -516,15 +559,30 @@ def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=No
         ops.pw_x3_f32(x.permute(0, 2, 3, 4, 1), cin, planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1), cout, plane_dtype,
                       add=None if add is None else add.permute(0, 2, 3, 4, 1))
         return y
+    if stats:
+        ws, pre_rows = ops.conv3d_igemm_x3_f32_stats(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
+                                                     _ktab(cin, kernel, h, w, cin, x.device), (b, t, h, w), cin, cout, kernel, stride, pad,
+                                                     cin, cout, plane_dtype, stats, cout)
+        _LAST_STATS = (y.data_ptr(), ws, pre_rows, stats, cout)
+        return y
     ops.conv3d_igemm_x3_f32(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
                             _ktab(cin, kernel, h, w, cin, x.device), (b, t, h, w), cin, cout, kernel, stride, pad, cin, cout, plane_dtype,
                             add=None if add is None else add.permute(0, 2, 3, 4, 1))
     return y
 
 
+def _tag_stats(y):
+    """The statistics the convolution that produced y left behind (if it did) become an attribute of y: bn_act picks them up."""
+    global _LAST_STATS
+    st, _LAST_STATS = _LAST_STATS, None
+    if st is not None and st[0] == y.data_ptr():
+        y._avt_stats = st[1:]
+    return y
+
+
 class _ConvX3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride, padding):
+    def forward(ctx, x, weight, stride, padding, stats=0):
         from . import ops
         cout, cin = weight.shape[0], weight.shape[1]
         kernel = tuple(weight.shape[2:])
@@ -540,12 +598,12 @@ class _ConvX3(torch.autograd.Function):
         g = _group_factor(xin.shape[1], cout, kernel, stride, padding, xin.shape[4]) if xin is x else 1
         if g > 1:
             planes, gk, rg = _grouped_planes(weight, g, False, ops.X3_F16)
-            return _conv_x3_rows(xin, planes, ops.X3_F16, cin, cout, kernel, stride, padding, group=(g, gk, rg))
-        return _conv_x3_rows(xin, _weight_planes(weight, False), ops.X3_F16, xin.shape[1], cout, kernel, stride, padding)
+            return _conv_x3_rows(xin, planes, ops.X3_F16, cin, cout, kernel, stride, padding, group=(g, gk, rg), stats=stats)
+        return _conv_x3_rows(xin, _weight_planes(weight, False), ops.X3_F16, xin.shape[1], cout, kernel, stride, padding, stats=stats)
 
     @staticmethod
     def backward(ctx, dy):
-        return _conv_backward(ctx, dy, None) + (None, None)
+        return _conv_backward(ctx, dy, None) + (None, None, None)
 
 
 def _conv_backward(ctx, dy, dalias):
@@ -713,15 +771,15 @@ class _ConvX3Fork(torch.autograd.Function):
     otherwise sum the two contributions to x with a separate elementwise pass (5.5 % of the step's device time)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding):
-        y = _ConvX3.forward(ctx, x, weight, stride, padding)
+    def forward(ctx, x, weight, stride, padding, stats=0):
+        y = _ConvX3.forward(ctx, x, weight, stride, padding, stats)
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dalias):
         if dy is None:  # (the convolution's output was not used: only the alias carries a gradient)
-            return (dalias if ctx.needs_input_grad[0] else None), None, None, None
-        return _conv_backward(ctx, dy, dalias) + (None, None)
+            return (dalias if ctx.needs_input_grad[0] else None), None, None, None, None
+        return _conv_backward(ctx, dy, dalias) + (None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -889,27 +947,53 @@ def conv2d(x, conv):
     if not ok:
         return conv(x)
     if not conv.weight.is_contiguous(memory_format=torch.channels_last):
-        conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)  # once; a layout change, not a value change
+        # (main.py puts the model in the training layout BEFORE the optimizer / DDP buckets exist: training_layout(); this is the
+        #  guard for callers that did not — a layout change, not a value change)
+        conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
     x5 = x.contiguous(memory_format=torch.channels_last).unsqueeze(2)   # [n, C, 1, H, W]: channels_last_3d strides
     w5 = conv.weight.unsqueeze(2)                                       # [cout, cin, 1, kh, kw], a view (autograd folds it back)
     y = _ConvX3.apply(x5, w5, (1,) + tuple(conv.stride), (0,) + tuple(conv.padding)).squeeze(2)
     return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
 
 
-def conv3d_fork(x, conv):
+def training_layout(model):
+    """The model in the layout the hand-written training passes read: channels_last_3d Conv3d weights / activations, channels_last
+    Conv2d weights (VGGish) — once, at setup, before optimizers or DDP buckets are built over the parameters."""
+    model = model.to(memory_format=torch.channels_last_3d)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.Conv2d) and not m.weight.is_contiguous(memory_format=torch.channels_last):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return model
+
+
+def _stat_groups(x, bn):
+    """Replica groups of the train-mode BatchNorm `bn` that consumes a convolution's output (conv3d(..., stats=bn)), or 0 when the
+    fused BatchNorm pass will not run on it (eval mode, switched off, a channel count outside its domain)."""
+    if bn is None or not (_EPI_STATS and _FUSED and bn.training and bn.weight is not None and bn.weight.dtype == torch.float32):
+        return 0
+    groups = _BN_GROUPS if _BN_GROUPS > 1 else 1
+    return groups if x.shape[0] % groups == 0 else 0
+
+
+def conv3d_fork(x, conv, stats=None):
     """-> (conv(x), x'): x' is x for every purpose but autograd's — hand it to the OTHER consumers of x (the block's shortcut
-    or projection) and their gradient is summed into conv's input gradient inside its kernel.  Stock path: (conv(x), x)."""
+    or projection) and their gradient is summed into conv's input gradient inside its kernel.  Stock path: (conv(x), x).
+    stats = the BatchNorm module conv(x) feeds (see conv3d)."""
     if not _FORK:
-        return conv3d(x, conv), x
+        return conv3d(x, conv, stats), x
     if not conv_fusable(x, conv) or conv.in_channels % 8:
         return conv(x), x
     x = x.contiguous(memory_format=torch.channels_last_3d)
-    return _ConvX3Fork.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding))
+    y, alias = _ConvX3Fork.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding), _stat_groups(x, stats))
+    return _tag_stats(y), alias
 
 
-def conv3d(x, conv):
+def conv3d(x, conv, stats=None):
     """conv(x) for a Conv3d module: the split-plane MFMA kernels in train mode on fp32 device tensors of a model in the
-    training layout (forward, stride-1 input gradient, weight gradient), the module itself otherwise."""
+    training layout (forward, stride-1 input gradient, weight gradient), the module itself otherwise.
+    stats = the nn.BatchNorm3d the output goes into next (bn_act(conv3d(x, conv, stats=bn), bn)): the convolution's epilogue sums
+    the statistics that BatchNorm needs while the tile is still in the LDS, and bn_act skips its pass over the output."""
     if not conv_fusable(x, conv):
         return conv(x)
     if conv.in_channels == 3 and stem_patch_ok(x, conv):
@@ -918,4 +1002,4 @@ def conv3d(x, conv):
         pass  # (the stem's padded copy is built channels-last from any layout)
     else:
         x = x.contiguous(memory_format=torch.channels_last_3d)  # no-op inside the network; a clip handed over as NCDHW is transposed once
-    return _ConvX3.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding))
+    return _tag_stats(_ConvX3.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding), _stat_groups(x, stats)))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 6  /* 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4); 6: avt_pw_x3_f32 (round 4) */
+#define AVT_ABI_VERSION 7  /* 7: BatchNorm statistics on the producing convolution's epilogue: avt_conv3d_igemm_x3_f32_stats, avt_bn_train_fwd_pre (round 5); 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4); 6: avt_pw_x3_f32 (round 4) */
 
 typedef enum {
   AVT_OK = 0,
@@ -521,6 +521,27 @@ int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_l
                             float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
                             int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int lda,
                             int plane_dtype, void* stream);
+/* BatchNorm statistics on the producing convolution's epilogue (round 5).  In train() every convolution of the
+ * SlowFast blocks is followed by a train-mode BatchNorm (train.py:114-141; per-replica statistics, main.py:420), whose statistics
+ * pass re-reads the whole activation the convolution has just written.  avt_conv3d_igemm_x3_f32_stats = avt_conv3d_igemm_x3_f32
+ * (no add operand) whose epilogue also leaves, per M tile, the per-channel sum and sum of squares of the rows it stores: the m rows
+ * are `groups` equal slabs with statistics of their own, the M tiles are laid per group (the last tile of a group is short: no tile
+ * straddles two groups), and tile t of group g writes row (g * rows + t) of `stat_part` — doubles, in the layout the BatchNorm's
+ * finalize kernel sums in a fixed order (bitwise reproducible; per-thread fp32 sums over at most 16 rows, everything above in fp64).
+ * stat_c = the BatchNorm's channel count: cout, or cout / g for a pixel-grouped layer (columns n and n + stat_c are one channel).
+ * avt_conv3d_igemm_x3_f32_stat_rows -> rows of partials per group that call writes (tile height 128 or 256 by the layer's shape).
+ * avt_bn_train_fwd_pre = avt_bn_train_fwd without its statistics pass: `ws` holds pre_rows rows per group written by the producer
+ * (pre_rows = stat_rows * max(1, c / 1024)), sized by avt_bn_train_ws_bytes_pre(c, groups, pre_rows). */
+int avt_conv3d_igemm_x3_f32_stat_rows(int cout, int k, int64_t m, int groups);
+int avt_conv3d_igemm_x3_f32_stats(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
+                                  const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
+                                  int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype,
+                                  void* stat_part, int groups, int stat_c, void* stream);
+int64_t avt_bn_train_ws_bytes_pre(int c, int groups, int pre_rows);
+int avt_bn_train_fwd_pre(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
+                         float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,
+                         float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         void* relu_mask, int64_t ldy, int pre_rows, void* stream);
 /* avt_conv3d_igemm_x3_f32 (stride 1) with an explicit output extent to x ho x wo (positions past the symmetric-padding formula's
  * far edge are not allowed, fewer are: padding after = whatever the extent needs) and the output-row remap of avt_conv3d_igemm_x3
  * (position (f, ho, wo) -> row (f * out_h + out_row_stride * ho) * out_w + out_row_stride * wo; out_h = out_w = 0: none).  One

@@ -494,3 +494,57 @@ def test_pointwise_layers_take_the_streaming_f32_kernel(cin, cout, dims, with_fo
     assert calls == int(bool(fwd_pw)) + int(bool(bwd_pw)) and calls >= 1
     for got, want, tol in ((ya, ye, 3e-6), (gxa, gxe, 2e-4), (gwa, gwe, 2e-4)):
         assert float((got - want).abs().max()) <= tol * float(want.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("cin,cout,kernel,stride,pad,dims,groups", [
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 2, 14, 14), 2),       # <128,64,64> tile; 784 rows per group = 6.1 tiles: short last tile
+    (64, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 2, 14, 14), 4),       # strided forward, 98 rows per group < one tile
+    (32, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (6, 4, 10, 10), 3),      # <128,128,64> tile
+    (8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 4, 12, 16), 2),         # pixel-grouped form: 4 columns fold into one channel
+    (16, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 8, 8), 1),         # grouped temporal layer, one group
+    (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 4, 64, 64), 2),     # the 256 x 256 tile (K = 2304, 65 536 rows)
+    (512, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (6, 8, 38, 38), 3),     # ... with 23 104 rows per group: a short tile per group
+    (320, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (4, 2, 14, 14), 2),      # a pointwise layer the streaming kernel does not take (K = 320)
+])
+def test_batchnorm_statistics_on_the_convolution_epilogue(cin, cout, kernel, stride, pad, dims, groups):
+    """conv3d(x, conv, stats=bn) leaves the BatchNorm's batch statistics behind (per-tile partial sums from the
+    epilogue, tiles laid per replica group) and bn_act(…) runs without its statistics pass: same convolution output bit for bit,
+    BatchNorm output / running statistics / every gradient equal to the two-pass path to fp32 rounding of the sums."""
+    import torch.nn as nn
+
+    from avtex import train_ops
+
+    dev = "cuda:0"
+    torch.manual_seed(cin + cout)
+    b, t, h, w = dims
+    x0 = (torch.randn(b, cin, t, h, w, device=dev) * 1.5 + 0.4).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(epi):
+        torch.manual_seed(7)
+        conv = nn.Conv3d(cin, cout, kernel, stride=stride, padding=pad, bias=False).to(dev).to(memory_format=torch.channels_last_3d).train()
+        bn = nn.BatchNorm3d(cout).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, cout))
+        x = x0.clone().requires_grad_(True)
+        keep, train_ops._EPI_STATS = train_ops._EPI_STATS, epi
+        for k in train_ops.CALLS:
+            train_ops.CALLS[k] = 0
+        try:
+            with train_ops.bn_replicas(groups):
+                y0 = train_ops.conv3d(x, conv, stats=bn)
+                tagged = hasattr(y0, "_avt_stats")
+                y = train_ops.bn_act(y0, bn, relu=True)
+            y.square().sum().backward()
+        finally:
+            train_ops._EPI_STATS = keep
+        return (y0.detach(), y.detach(), x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(),
+                bn.running_var.clone(), tagged, dict(train_ops.CALLS))
+
+    a, e = run(1), run(0)
+    assert a[8] and not e[8] and a[9]["bn_fwd_pre"] == 1 and e[9]["bn_fwd_pre"] == 0 and a[9]["pw_f32"] == 0
+    assert torch.equal(a[0], e[0])  # the convolution itself is untouched by the per-group tile layout
+    for k, name in ((1, "y"), (2, "dx"), (3, "dw"), (4, "dgamma"), (5, "dbeta"), (6, "running_mean"), (7, "running_var")):
+        err = float((a[k] - e[k]).norm() / e[k].norm().clamp_min(1e-20))
+        assert err < 3e-6, (name, err)
+    assert float((a[1] - e[1]).abs().max()) < 2e-5 * float(e[1].abs().max())

@@ -380,6 +380,10 @@ def test_bench_line_is_compact_and_round_trips():
         "frames_lists_identical": {"0.0": "3/3", "0.3": "3/3"}, "nxn_build_ms_seeded_th0": 0.91,
         "cpu_baseline": {"value": 1.4544949820793884, "unit": "clip-windows/s", "cores": 16, "kind": "port", "sample": "s" * 200},
         "train_clips_per_s": 174.123, "train_ms_per_step": 735.12,
+        "hbm_GBps": {"step_pmc": 2987.123456, "pmc_coverage": 0.9712345, "hbm_bound_family_algorithmic": 4123.123456, "peak": 8000.0},
+        "value_inputs_r03": 1301.123456, "value_inputs_r03_steps": 4, "ms_per_step_rank_min": 3301.123456, "ms_per_step_rank_max": 3318.123456,
+        "rccl_ranks": 8, "allgather_ms": 0.123456, "allgather_bytes_per_rank": 37748736,
+        "trained_weights": {"value": 1388.123456, "survivor_fraction": 0.0712345, "precision_max_abs_dscore": 3.1e-05, "frames_lists_identical": "3/3"},
     }
     line = bench.compact_line(out)
     assert len(line.encode()) < bench.LINE_LIMIT <= 4096 and "\n" not in line

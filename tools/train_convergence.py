@@ -70,7 +70,7 @@ def train_run(mode, args, dev, video, keep=False):
     bat.seed_from_numpy()
     rng = np.random.RandomState(99)
     labels = torch.zeros(B, dtype=torch.long, device=dev)
-    losses, t_steps = [], []
+    losses, t_steps, top1 = [], [], []
     torch.cuda.synchronize()
     for it in range(args.steps):
         t0 = time.perf_counter()
@@ -85,16 +85,19 @@ def train_run(mode, args, dev, video, keep=False):
         opt.step()
         train_ops.invalidate_weight_cache()
         losses.append(float(loss))
+        top1.append(float((out.detach().argmax(1) == 0).float().mean()))  # items whose positive has the best logit
         t_steps.append(time.perf_counter() - t0)
         if it % 20 == 0 or it == args.steps - 1:
-            print("[%s] step %d loss %.4f (%.0f ms)" % (mode, it, losses[-1], t_steps[-1] * 1e3), file=sys.stderr, flush=True)
+            print("[%s] step %d loss %.4f top1 %.2f (%.0f ms)" % (mode, it, losses[-1], float(np.mean(top1[-20:])), t_steps[-1] * 1e3),
+                  file=sys.stderr, flush=True)
         if not np.isfinite(losses[-1]):
             break
     ema, e = [], None
     for v in losses:
         e = v if e is None else 0.9 * e + 0.1 * v
         ema.append(e)
-    rec = {"mode": mode, "lr": args.lr, "steps": len(losses), "loss": losses, "loss_ema": ema,
+    rec = {"mode": mode, "lr": args.lr, "steps": len(losses), "loss": losses, "loss_ema": ema, "top1": top1,
+           "top1_last50": float(np.mean(top1[-50:])),
            "ms_per_step_median": float(np.median(t_steps[5:]) * 1e3) if len(t_steps) > 5 else None,
            "max_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
            "calls": {k: v for k, v in train_ops.CALLS.items() if v}}
@@ -206,6 +209,7 @@ def main():
     ap.add_argument("--init", default="bench", choices=["bench", "default"])
     ap.add_argument("--frames", type=int, default=1500)
     ap.add_argument("--frame-hw", type=int, default=128)
+    ap.add_argument("--scene-len", type=int, default=24, help="frames per scene of the synthetic video (24 = bench.py's)")
     ap.add_argument("--roundtrip", action="store_true")
     ap.add_argument("--workdir", default="/tmp/avt_train_convergence")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "train_convergence.json"))
@@ -217,9 +221,10 @@ def main():
     torch.cuda.set_device(dev)
     ops.device_check()
     torch.backends.cudnn.benchmark = True
-    video = synth.structured_video(123, args.frames, args.frame_hw, args.frame_hw, variety=1)
+    video = synth.structured_video(123, args.frames, args.frame_hw, args.frame_hw, scene_len=args.scene_len, variety=1)
     res = {"config": {"steps": args.steps, "lr": args.lr, "init": args.init, "batch": 8, "negs": 14, "temp": 0.1, "img_size": 224,
-                      "video": "synth.structured_video(123, %d, %d, %d, variety=1), fps 30 -> W 15, S 6" % (args.frames, args.frame_hw, args.frame_hw),
+                      "video": "synth.structured_video(123, %d, %d, %d, scene_len=%d, variety=1), fps 30 -> W 15, S 6" % (
+                          args.frames, args.frame_hw, args.frame_hw, args.scene_len),
                       "log_1_plus_negs": float(np.log(15.0))}, "runs": {}}
     kept = None
     for k, mode in enumerate(args.modes):
@@ -237,7 +242,8 @@ def main():
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)
-    brief = {m: {"first": r["loss"][0], "ema_last": r["loss_ema"][-1], "ms": r["ms_per_step_median"]} for m, r in res["runs"].items()}
+    brief = {m: {"first": r["loss"][0], "ema_last": r["loss_ema"][-1], "top1_last50": r["top1_last50"], "ms": r["ms_per_step_median"]}
+             for m, r in res["runs"].items()}
     print(json.dumps({"brief": brief, "ema_gap_max_after_20": res.get("ema_gap_max_after_20"),
                       "roundtrip": {k: v for k, v in res.get("roundtrip", {}).items() if k not in ("cli_frames_head",)}}, default=str))
 
