@@ -204,6 +204,42 @@ __global__ __launch_bounds__(kT) void bn_fwd_finalize_kernel(BnArgs a) {  // gri
   }
 }
 
+// Pre-reduction of a producer's partial rows (avt_bn_train_fwd_pre): a convolution leaves one row per M tile — thousands per group on
+// the early layers — and the finalize launch (one wavefront per channel walking ALL rows, a few workgroups in all) doubled in time
+// on them (profiles/r05: 19 -> 40 us per BatchNorm).  Here every workgroup sums kPreRows consecutive rows of one group (same `unit`
+// phase) into one row of a second array, in a fixed order; the finalize launch then walks rows / kPreRows rows.
+constexpr int kPreRows = 64;
+struct PreArgs {
+  const double* src;   // [groups][rows * unit][len]
+  double* dst;         // [groups][ceil(rows / kPreRows) * unit][len]
+  int rows, unit, len; // len = nq * 8 doubles per row
+};
+__global__ __launch_bounds__(kT) void bn_pre_reduce_kernel(PreArgs a) {
+  __shared__ double sh[kT];
+  const int chunk = blockIdx.x, u = blockIdx.y % a.unit, g = blockIdx.y / a.unit;
+  const int nchunk = (a.rows + kPreRows - 1) / kPreRows;
+  const int cols = a.len < kT ? a.len : kT, slices = kT / cols;  // (len is a power of two: 64 .. 2048)
+  const int r0 = chunk * kPreRows, r1 = r0 + kPreRows < a.rows ? r0 + kPreRows : a.rows;
+  const double* src = a.src + ((size_t)g * a.rows * a.unit + u) * a.len;
+  double* dst = a.dst + (((size_t)g * nchunk + chunk) * a.unit + u) * a.len;
+  const int sl = threadIdx.x / cols, c = threadIdx.x % cols;
+  for (int col = c; col < a.len; col += cols) {
+    double acc = 0.0;
+    for (int r = r0 + sl; r < r1; r += slices) acc += src[(size_t)r * a.unit * a.len + col];
+    if (slices > 1) {
+      sh[threadIdx.x] = acc;
+      __syncthreads();
+      if (sl == 0) {
+        for (int k = 1; k < slices; ++k) acc += sh[k * cols + c];
+        dst[col] = acc;
+      }
+      __syncthreads();
+    } else {
+      dst[col] = acc;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kT) void bn_fwd_apply_kernel(BnArgs a) {
   const int quad = my_quad(a);
   a.x += 4 * slab(a);
@@ -400,10 +436,18 @@ static int bn_train_fwd_impl(const float* x, const float* res, float* y, int64_t
                              float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                              void* relu_mask, int64_t ldy, int pre_rows, void* stream);
 
+// rows (per group) the finalize launch walks for pre_rows producer rows: pre-reduced by kPreRows when there are many
+static int pre_rows_final(int pre_rows, int unit) {
+  const int r = pre_rows / unit;
+  return r > 2 * kPreRows ? ((r + kPreRows - 1) / kPreRows) * unit : 0;  // 0: no pre-reduction
+}
+
 extern "C" int64_t avt_bn_train_ws_bytes_pre(int c, int groups, int pre_rows) {
   if (!shape_ok(1, c) || groups < 1 || pre_rows < 1) return -1;
-  const int q = c / 4, nq = q < kT ? q : kT;
-  return (int64_t)groups * ((int64_t)pre_rows * nq * 8 * (int64_t)sizeof(double) + (int64_t)2 * c * (int64_t)sizeof(float));
+  const int q = c / 4, nq = q < kT ? q : kT, unit = q > kT ? q / kT : 1;
+  if (pre_rows % unit) return -1;
+  const int64_t rows = (int64_t)pre_rows + pre_rows_final(pre_rows, unit);
+  return (int64_t)groups * (rows * nq * 8 * (int64_t)sizeof(double) + (int64_t)2 * c * (int64_t)sizeof(float));
 }
 
 extern "C" int avt_bn_train_fwd(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
@@ -440,7 +484,7 @@ static int bn_train_fwd_impl(const float* x, const float* res, float* y, int64_t
     AVT_REQUIRE(ws && avt::aligned16(ws) && ws_size >= need && pre_rows % a.unit == 0,
                 "avt_bn_train_fwd_pre: workspace of %lld bytes needed (avt_bn_train_ws_bytes_pre), got %lld", (long long)need, (long long)ws_size);
     a.part = static_cast<double*>(ws);
-    a.coef = reinterpret_cast<float*>(a.part + (size_t)groups * pre_rows * a.nq * 8);
+    a.coef = reinterpret_cast<float*>(a.part + (size_t)groups * (pre_rows + pre_rows_final(pre_rows, a.unit)) * a.nq * 8);
     rc = AVT_OK;
   } else {
     rc = geometry(a, "avt_bn_train_fwd", m, c, groups, ws, (size_t)(ws_size < 0 ? 0 : ws_size));
@@ -456,6 +500,18 @@ static int bn_train_fwd_impl(const float* x, const float* res, float* y, int64_t
   if (pre_rows > 0) {
     BnArgs f = a;
     f.blocks = pre_rows;  // rows of partials per group, as the producer wrote them
+    const int fin = pre_rows_final(pre_rows, a.unit);
+    if (fin) {  // many rows: kPreRows of them into one first
+      PreArgs p;
+      p.src = a.part;
+      p.dst = a.part + (size_t)groups * pre_rows * a.nq * 8;
+      p.rows = pre_rows / a.unit;
+      p.unit = a.unit;
+      p.len = a.nq * 8;
+      hipLaunchKernelGGL(bn_pre_reduce_kernel, dim3(fin / a.unit, a.unit * groups), dim3(kT), 0, st, p);
+      f.part = p.dst;
+      f.blocks = fin;
+    }
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, f);
   } else {
     hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);

@@ -382,9 +382,23 @@ struct PfArgs {
   const uint16_t* wl;
   const float* wscale;   // [N] or NULL
   int M, ldx, lda, ldy, K, k1c, ntiles, n_chunks, n_rg;
+  // STATS (round 5; avt_pw_x3_f32_stats): the output feeds a train-mode BatchNorm — blockIdx.y walks its replica groups (slabs of
+  // M rows each: `M` / `ntiles` are PER GROUP then), and every wave leaves the per-channel sum / sum of squares of the rows it
+  // stored as one row of partials in bn_train.hip's channel_sums layout (row (group * n_rg + rg) * 8 + wave)
+  double* stat_part;
+  int n_total;           // channels of the whole layer (the BatchNorm's C)
 };
 
-template <int K1S, int NT1, bool F16>
+// pass width (channels) of the STATS transpose: the per-wave LDS scratch must fit beside the weight fragments
+template <int K1S, int NT1>
+struct PfStat {
+  static constexpr int NC = NT1 * 16;
+  static constexpr int PW = NC < 64 ? NC : ((2 * NT1 * K1S * 1024 >= 96 * 1024) ? 32 : 64);
+  static constexpr int RS = PW + 4;                      // floats per scratch row (padded)
+  static constexpr int BYTES = PX_NW * 16 * RS * 4;      // all waves
+};
+
+template <int K1S, int NT1, bool F16, bool STATS = false>
 __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
   constexpr int NC = NT1 * 16;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -397,6 +411,11 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
   const int rg = (j / a.n_chunks) * 8 + xcd;
   if (rg >= a.n_rg) return;
   const int c0 = chunk * NC;
+  if constexpr (STATS) {  // this workgroup's group: its slab of the rows
+    const int64_t g = blockIdx.y;
+    a.x += g * a.M * a.ldx;
+    a.y += g * a.M * a.ldy;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -417,7 +436,17 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
   }
   for (int i = tid; i < NC; i += PX_NW * 64) sl[i] = a.wscale ? a.wscale[c0 + i] : 1.0f;
   __syncthreads();
-  const bool has_add = a.add != nullptr;
+  const bool has_add = !STATS && a.add != nullptr;
+  // STATS: per-wave scratch [16 rows][PW channels] behind the scale floats; lane l owns column l of every pass (PW = 32: column
+  // l & 31, rows 8 (l >> 5) ..), its sums over the wave's tiles in fp64 (fp32 over the 16 / 8 rows of one tile)
+  typedef PfStat<K1S, NT1> PS;
+  constexpr int NPASS = NC / PS::PW;
+  float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(sl) + NC * 4) + wid * 16 * PS::RS;
+  double st_s[STATS ? NPASS : 1], st_q[STATS ? NPASS : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) st_s[ps] = st_q[ps] = 0.0;
+  }
 
   for (int tile = rg * PX_NW + wid; tile < a.ntiles; tile += a.n_rg * PX_NW) {
     const int p = tile * 16 + l15;
@@ -490,48 +519,127 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
         __builtin_nontemporal_store(o0, reinterpret_cast<f32x4n*>(po));
         __builtin_nontemporal_store(o1, reinterpret_cast<f32x4n*>(po + 4));
       }
+      if constexpr (STATS) {
+        // the 16 x PW block of this pass goes through the wave's scratch: written as it lies (row = position, 8 consecutive
+        // channels per lane; rows past the slab as zeros), read back one COLUMN per lane — LDS operations of one wave complete in
+        // order, so a wait on the counter is the only synchronisation; no cross-lane traffic, 8 accumulator registers per pass
+        constexpr int JPP = PS::PW / 32;  // jj's per pass
+        const int jl = jj % JPP;
+        if (!ok) o0 = o1 = f32x4n{0.f, 0.f, 0.f, 0.f};
+        float* pw_ = scr + l15 * PS::RS + 32 * jl + 8 * q;
+        *reinterpret_cast<f32x4n*>(pw_) = o0;
+        *reinterpret_cast<f32x4n*>(pw_ + 4) = o1;
+        if (jl == JPP - 1) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          constexpr int NR = PS::PW == 64 ? 16 : 8;
+          const float* pr = scr + (PS::PW == 64 ? lane : (lane & 31) + (lane >> 5) * 8 * PS::RS);
+          float ts = 0.f, tq = 0.f;
+          if (PS::PW >= 32 || lane < PS::PW) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              const float v = pr[r * PS::RS];
+              ts += v;
+              tq += v * v;
+            }
+          }
+          st_s[jj / JPP] += (double)ts;
+          st_q[jj / JPP] += (double)tq;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the reads are done before the next pass overwrites the block)
+        }
+      }
+    }
+  }
+  if constexpr (STATS) {  // this wave's row of partials: channel c0 + PW * pass + column
+    const int C = a.n_total, q4 = C / 4, nq = q4 < 256 ? q4 : 256, unit = q4 > 256 ? q4 / 256 : 1;
+    const size_t row = ((size_t)blockIdx.y * a.n_rg + rg) * PX_NW + wid;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      double s0 = st_s[ps], s1 = st_q[ps];
+      if (PS::PW == 32) {  // the two row halves of a 32-wide pass meet here
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+      }
+      if (lane < PS::PW) {
+        const int c = c0 + ps * PS::PW + lane, quad = c >> 2, e = c & 3;
+        double* dst = a.stat_part + (row * unit + (quad >> 8)) * nq * 8 + (size_t)(quad % nq) * 8 + e;
+        dst[0] = s0;
+        dst[4] = s1;
+      }
     }
   }
 }
 
+// row groups (persistent workgroups along the rows) of one launch: as many workgroups as stay resident, over `groups` slabs
+int pf_row_groups(int lds_bytes, int n_chunks, int ntiles, int groups) {
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 52 * 1024 ? 2 : 3);
+  int n_rg = (256 * per_cu) / (n_chunks * groups);
+  n_rg = n_rg < 8 ? 8 : (n_rg / 8) * 8;
+  const int max_rg = (ntiles + PX_NW - 1) / PX_NW;
+  if (n_rg > ((max_rg + 7) / 8) * 8) n_rg = ((max_rg + 7) / 8) * 8;
+  return n_rg;
+}
+
+template <int K1S, int NT1>
+constexpr int pf_lds_bytes(bool stats) {
+  return 2 * NT1 * K1S * 1024 + NT1 * 16 * 4 + (stats ? PfStat<K1S, NT1>::BYTES : 0);
+}
+
 template <int K1S, int NT1, bool F16>
-int launch_pf(PfArgs& a, hipStream_t st) {
-  constexpr int lds_bytes = 2 * NT1 * K1S * 1024 + NT1 * 16 * 4;
+int launch_pf(PfArgs& a, hipStream_t st, int groups = 0) {
+  if (groups > 0) {  // STATS: blockIdx.y = the BatchNorm's replica group, a.M / a.ntiles per group
+    constexpr int lds_bytes = pf_lds_bytes<K1S, NT1>(true);
+    static_assert(lds_bytes <= 160 * 1024, "weights + the statistics scratch fit the LDS");
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_x3_f32_kernel<K1S, NT1, F16, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+      avt::set_error("avt_pw_x3_f32_stats: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+      return AVT_ERR_LAUNCH;
+    }
+    a.n_rg = pf_row_groups(lds_bytes, a.n_chunks, a.ntiles, groups);
+    hipLaunchKernelGGL((pw_x3_f32_kernel<K1S, NT1, F16, true>), dim3((unsigned)(a.n_rg * a.n_chunks), (unsigned)groups), dim3(PX_NW * 64),
+                       lds_bytes, st, a);
+    return avt::check_launch("avt_pw_x3_f32_stats");
+  }
+  constexpr int lds_bytes = pf_lds_bytes<K1S, NT1>(false);
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_x3_f32_kernel<K1S, NT1, F16>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_pw_x3_f32: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  const int per_cu = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 52 * 1024 ? 2 : 3);
-  int n_rg = (256 * per_cu) / a.n_chunks;
-  n_rg = n_rg < 8 ? 8 : (n_rg / 8) * 8;
-  const int max_rg = (a.ntiles + PX_NW - 1) / PX_NW;
-  if (n_rg > ((max_rg + 7) / 8) * 8) n_rg = ((max_rg + 7) / 8) * 8;
-  a.n_rg = n_rg;
-  hipLaunchKernelGGL((pw_x3_f32_kernel<K1S, NT1, F16>), dim3((unsigned)(n_rg * a.n_chunks)), dim3(PX_NW * 64), lds_bytes, st, a);
+  a.n_rg = pf_row_groups(lds_bytes, a.n_chunks, a.ntiles, 1);
+  hipLaunchKernelGGL((pw_x3_f32_kernel<K1S, NT1, F16>), dim3((unsigned)(a.n_rg * a.n_chunks)), dim3(PX_NW * 64), lds_bytes, st, a);
   return avt::check_launch("avt_pw_x3_f32");
 }
 
+// LDS bytes of the (K1S, NT1) instance, for the row-group query (avt_pw_x3_f32_stat_rows)
+int pf_lds_of(int k1s, int nt1, bool stats) {
+#define PF_CASE(K, N) if (k1s == K && nt1 == N) return pf_lds_bytes<K, N>(stats);
+  PF_CASE(1, 16) PF_CASE(1, 8) PF_CASE(1, 4) PF_CASE(1, 2) PF_CASE(2, 16) PF_CASE(2, 8) PF_CASE(2, 4) PF_CASE(2, 2)
+  PF_CASE(4, 16) PF_CASE(4, 8) PF_CASE(4, 4) PF_CASE(4, 2) PF_CASE(8, 8) PF_CASE(8, 4) PF_CASE(8, 2)
+#undef PF_CASE
+  return 0;
+}
+
 template <int K1S, bool F16>
-int dispatch_pf_nt(PfArgs& a, int nt1, hipStream_t st) {
+int dispatch_pf_nt(PfArgs& a, int nt1, hipStream_t st, int groups) {
   switch (nt1) {
-    case 16: if constexpr (K1S <= 4) return launch_pf<K1S, 16, F16>(a, st); break;
-    case 8: if constexpr (K1S <= 8) return launch_pf<K1S, 8, F16>(a, st); break;
-    case 4: return launch_pf<K1S, 4, F16>(a, st);
-    case 2: return launch_pf<K1S, 2, F16>(a, st);
+    case 16: if constexpr (K1S <= 4) return launch_pf<K1S, 16, F16>(a, st, groups); break;
+    case 8: if constexpr (K1S <= 8) return launch_pf<K1S, 8, F16>(a, st, groups); break;
+    case 4: return launch_pf<K1S, 4, F16>(a, st, groups);
+    case 2: return launch_pf<K1S, 2, F16>(a, st, groups);
   }
   avt::set_error("avt_pw_x3_f32: no kernel for K steps %d, tiles %d", K1S, nt1);
   return AVT_ERR_UNSUPPORTED;
 }
 
 template <bool F16>
-int dispatch_pf_k(PfArgs& a, int k1s, int nt1, hipStream_t st) {
+int dispatch_pf_k(PfArgs& a, int k1s, int nt1, hipStream_t st, int groups = 0) {
   switch (k1s) {
-    case 1: return dispatch_pf_nt<1, F16>(a, nt1, st);
-    case 2: return dispatch_pf_nt<2, F16>(a, nt1, st);
-    case 4: return dispatch_pf_nt<4, F16>(a, nt1, st);
-    case 8: return dispatch_pf_nt<8, F16>(a, nt1, st);
+    case 1: return dispatch_pf_nt<1, F16>(a, nt1, st, groups);
+    case 2: return dispatch_pf_nt<2, F16>(a, nt1, st, groups);
+    case 4: return dispatch_pf_nt<4, F16>(a, nt1, st, groups);
+    case 8: return dispatch_pf_nt<8, F16>(a, nt1, st, groups);
   }
   avt::set_error("avt_pw_x3_f32: unsupported K (%d steps of 32)", k1s);
   return AVT_ERR_UNSUPPORTED;
@@ -800,6 +908,43 @@ extern "C" int avt_pw_x3_f32(const float* x, int ldx, int k, const void* w_hi, c
   a.M = (int)m; a.ldx = ldx; a.lda = lda; a.ldy = ldy; a.K = k; a.k1c = k / 8;
   a.ntiles = (int)((m + 15) / 16);
   a.n_chunks = n / (16 * nt1);
+  a.stat_part = nullptr;
+  a.n_total = n;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return plane_dtype == AVT_X3_F16 ? dispatch_pf_k<true>(a, k1s, nt1, st) : dispatch_pf_k<false>(a, k1s, nt1, st);
+}
+
+// ... leaving the train-mode BatchNorm statistics of its output behind (include/avt.h; the streaming counterpart of
+// avt_conv3d_igemm_x3_f32_stats): rows of partials per group = 8 x the row groups of the launch
+extern "C" int avt_pw_x3_f32_stat_rows(int k, int n, int64_t m, int groups) {
+  if (!avt_pw_x3_f32_supported(k, n) || groups < 1 || m <= 0 || m % groups) return -1;
+  const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  const int ntiles = (int)((m / groups + 15) / 16);
+  return pf_row_groups(pf_lds_of(k1s, nt1, true), n / (16 * nt1), ntiles, groups) * PX_NW;
+}
+
+extern "C" int avt_pw_x3_f32_stats(const float* x, int ldx, int k, const void* w_hi, const void* w_lo, const float* wscale, float* y, int ldy,
+                                   int n, int64_t m, int plane_dtype, void* stat_part, int groups, void* stream) {
+  AVT_REQUIRE(x && w_hi && w_lo && y && stat_part, "avt_pw_x3_f32_stats: NULL pointer");
+  AVT_REQUIRE(avt_pw_x3_f32_supported(k, n), "avt_pw_x3_f32_stats: unsupported layer K=%d N=%d", k, n);
+  AVT_REQUIRE(groups >= 1 && groups <= 65535 && m > 0 && m % groups == 0 && m < (1ll << 31) - 16 && ldx >= k && ldy >= n && ldx % 4 == 0 &&
+                  ldy % 4 == 0 && n >= 8 && (n & (n - 1)) == 0 && n <= 4096,
+              "avt_pw_x3_f32_stats: bad sizes / leading dimensions / groups (n a power of two: the BatchNorm's domain)");
+  AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(w_hi) && avt::aligned16(w_lo) && avt::aligned16(y) && avt::aligned16(stat_part) &&
+                  (!wscale || avt::aligned16(wscale)),
+              "avt_pw_x3_f32_stats: pointers must be 16-byte aligned");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_pw_x3_f32_stats: bad plane_dtype");
+  const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  PfArgs a;
+  a.x = x; a.add = nullptr; a.y = y;
+  a.wh = static_cast<const uint16_t*>(w_hi);
+  a.wl = static_cast<const uint16_t*>(w_lo);
+  a.wscale = wscale;
+  a.M = (int)(m / groups); a.ldx = ldx; a.lda = 0; a.ldy = ldy; a.K = k; a.k1c = k / 8;
+  a.ntiles = (a.M + 15) / 16;
+  a.n_chunks = n / (16 * nt1);
+  a.stat_part = static_cast<double*>(stat_part);
+  a.n_total = n;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return plane_dtype == AVT_X3_F16 ? dispatch_pf_k<true>(a, k1s, nt1, st, groups) : dispatch_pf_k<false>(a, k1s, nt1, st, groups);
 }

@@ -448,6 +448,24 @@ def pw_x3_f32(x, k, wt_hi, wt_lo, wscale, out, n, plane_dtype, add=None):
                                         int(m), int(plane_dtype), _stream()), "avt_pw_x3_f32")
 
 
+def pw_x3_f32_stats(x, k, wt_hi, wt_lo, wscale, out, n, plane_dtype, groups):
+    """pw_x3_f32 that also leaves the train-mode BatchNorm statistics of its output behind: -> (ws, pre_rows) as conv3d_igemm_x3_f32_stats,
+    or None when the layer / group count is outside the kernel's domain (the caller runs the plain form)."""
+    _dev(x, "x", torch.float32)
+    _dev(out, "out", torch.float32)
+    _dev(wt_hi, "wt_hi", torch.bfloat16)
+    _dev(wt_lo, "wt_lo", torch.bfloat16)
+    m = x.numel() // k
+    rows = _lib.lib().avt_pw_x3_f32_stat_rows(int(k), int(n), int(m), int(groups))
+    if rows <= 0 or n & (n - 1):
+        return None
+    pre_rows = rows * max(1, int(n) // 1024)
+    ws = torch.empty(_lib.lib().avt_bn_train_ws_bytes_pre(int(n), int(groups), pre_rows), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().avt_pw_x3_f32_stats(_p(x), int(k), int(k), _p(wt_hi), _p(wt_lo), _p(wscale), _p(out), int(n), int(n), int(m),
+                                              int(plane_dtype), _p(ws), int(groups), _stream()), "avt_pw_x3_f32_stats")
+    return ws, pre_rows
+
+
 def conv3d_igemm_x3_f32_ex(x, wt_hi, wt_lo, wscale, out, ktab, dims, cin, cout, kernel, pad, out_dims, ldi, ldo, plane_dtype,
                            out_rows=(1, 0, 0)):
     """conv3d_igemm_x3_f32 at stride 1 with an explicit output extent and the output-row remap (out_rows = (stride, grid h, grid w));

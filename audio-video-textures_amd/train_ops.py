@@ -532,7 +532,7 @@ _LAST_STATS = None  # (output data_ptr, workspace, rows of partials per group, g
 def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=None, group=None, stats=0):
     """x [B, Cin, T, H, W] channels-last fp32 -> [B, Cout, To, Ho, Wo] channels-last fp32 (+ add, same shape, in the epilogue).
     stats = n > 0: the output feeds a train-mode BatchNorm of n replica groups — the kernel's epilogue leaves its statistics'
-    partial sums (ops.conv3d_igemm_x3_f32_stats; recorded in _LAST_STATS).  Layers on the streaming pointwise kernel do not yet."""
+    partial sums (ops.conv3d_igemm_x3_f32_stats / ops.pw_x3_f32_stats; recorded in _LAST_STATS)."""
     global _LAST_STATS
     from . import ops
     b, _, t, h, w = x.shape
@@ -556,6 +556,12 @@ def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=No
         # the pointwise layers with few K-steps and many outputs (the bottlenecks' expanding convolutions, the input gradients of the
         # reducing ones) on the streaming kernel: the 128 x 128 tile spent 55 % of a workgroup in its prologue + epilogue on them
         CALLS["pw_f32"] += 1
+        if stats:
+            st = ops.pw_x3_f32_stats(x.permute(0, 2, 3, 4, 1), cin, planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1), cout,
+                                     plane_dtype, stats)
+            if st is not None:
+                _LAST_STATS = (y.data_ptr(), st[0], st[1], stats, cout)
+                return y
         ops.pw_x3_f32(x.permute(0, 2, 3, 4, 1), cin, planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1), cout, plane_dtype,
                       add=None if add is None else add.permute(0, 2, 3, 4, 1))
         return y

@@ -537,6 +537,13 @@ int avt_conv3d_igemm_x3_f32_stats(const float* in, const void* wt_hi, const void
                                   const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
                                   int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype,
                                   void* stat_part, int groups, int stat_c, void* stream);
+/* The streaming pointwise counterpart (csrc/pw_x3.hip): avt_pw_x3_f32 without an add operand over `groups` equal slabs of the m rows
+ * (blockIdx.y = group), every wave leaving ONE row of partials — the sums over all the 16-row tiles it stored, taken column-wise
+ * through a per-wave LDS block (fp32 over the 16 rows of a tile, fp64 across tiles).  n must be a power of two (the BatchNorm's
+ * domain); avt_pw_x3_f32_stat_rows -> rows of partials per group (8 x the launch's row groups), or -1. */
+int avt_pw_x3_f32_stat_rows(int k, int n, int64_t m, int groups);
+int avt_pw_x3_f32_stats(const float* x, int ldx, int k, const void* w_hi, const void* w_lo, const float* wscale, float* y, int ldy,
+                        int n, int64_t m, int plane_dtype, void* stat_part, int groups, void* stream);
 int64_t avt_bn_train_ws_bytes_pre(int c, int groups, int pre_rows);
 int avt_bn_train_fwd_pre(const float* x, const float* res, float* y, int64_t m, int c, const float* gamma, const float* beta,
                          float eps, float momentum, int relu, int groups, void* ws, int64_t ws_size, float* save_mean,

@@ -505,6 +505,14 @@ def test_pointwise_layers_take_the_streaming_f32_kernel(cin, cout, dims, with_fo
     (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 4, 64, 64), 2),     # the 256 x 256 tile (K = 2304, 65 536 rows)
     (512, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (6, 8, 38, 38), 3),     # ... with 23 104 rows per group: a short tile per group
     (320, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (4, 2, 14, 14), 2),      # a pointwise layer the streaming kernel does not take (K = 320)
+    (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (4, 2, 14, 14), 2),      # the streaming pointwise kernel <2, 16>: 4 passes of 64 channels
+    (128, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (6, 1, 7, 7), 3),       # <4, 16>: two channel chunks, 32-wide passes, 49 rows per group
+    (8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (4, 4, 12, 12), 4),        # <1, 2>: one 32-wide pass
+    (32, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 12, 12), 1),       # <1, 4>
+    (512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (4, 1, 7, 7), 2),      # 2048 channels: two rows of partials per wave slot
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 8, 56, 56), 2),       # 196 tiles per group: the partial rows are pre-reduced by 64
+    (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 8, 56, 56), 2),      # ... streaming kernel: a row per wave, 1568 tiles per group
+    (256, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (4, 8, 28, 28), 1),    # ... 2048 channels (two row phases) through the pre-reduction
 ])
 def test_batchnorm_statistics_on_the_convolution_epilogue(cin, cout, kernel, stride, pad, dims, groups):
     """conv3d(x, conv, stats=bn) leaves the BatchNorm's batch statistics behind (per-tile partial sums from the
@@ -542,7 +550,9 @@ def test_batchnorm_statistics_on_the_convolution_epilogue(cin, cout, kernel, str
                 bn.running_var.clone(), tagged, dict(train_ops.CALLS))
 
     a, e = run(1), run(0)
-    assert a[8] and not e[8] and a[9]["bn_fwd_pre"] == 1 and e[9]["bn_fwd_pre"] == 0 and a[9]["pw_f32"] == 0
+    assert a[8] and not e[8] and a[9]["bn_fwd_pre"] == 1 and e[9]["bn_fwd_pre"] == 0
+    streaming = kernel == (1, 1, 1) and bool(__import__("avtex.ops", fromlist=["x"]).pw_x3_f32_supported(cin, cout))
+    assert a[9]["pw_f32"] == e[9]["pw_f32"] and (not streaming or a[9]["pw_f32"] >= 1)  # (the same kernels either way)
     assert torch.equal(a[0], e[0])  # the convolution itself is untouched by the per-group tile layout
     for k, name in ((1, "y"), (2, "dx"), (3, "dw"), (4, "dgamma"), (5, "dbeta"), (6, "running_mean"), (7, "running_var")):
         err = float((a[k] - e[k]).norm() / e[k].norm().clamp_min(1e-20))
