@@ -66,7 +66,13 @@ SIGNATURES = {
     "avt_bn_train_fwd_pre": [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_float, C.c_float, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp,
                              _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp],
     "avt_conv3d_igemm_x3_f32_stat_rows": [C.c_int, C.c_int, C.c_int64, C.c_int],
+    "avt_conv3d_igemm_x3_f32_bwdstats_rows": [C.c_int, C.c_int, C.c_int64, C.c_int],
+    "avt_conv3d_igemm_x3_f32_bwdstats": [_vp] * 7 + [C.c_int] * 16 + [_vp] * 6 + [C.c_int, _vp, C.c_int, C.c_int, _vp],
+    "avt_bn_train_bwd_pre": [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp],
     "avt_pw_x3_f32_stat_rows": [C.c_int, C.c_int, C.c_int64, C.c_int],
+    "avt_pw_x3_f32_bwdstats_rows": [C.c_int, C.c_int, C.c_int64, C.c_int],
+    "avt_pw_x3_f32_bwdstats": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int64, C.c_int] + [_vp] * 6 +
+                              [C.c_int, _vp, C.c_int, _vp],
     "avt_pw_x3_f32_stats": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, _vp],
     "avt_conv3d_igemm_x3_f32_stats": [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 18 + [_vp, C.c_int, C.c_int, _vp],
     "avt_conv3d_igemm_x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 19 + [_vp],

@@ -521,6 +521,50 @@ static int bn_train_fwd_impl(const float* x, const float* res, float* y, int64_t
   return avt::check_launch("avt_bn_train_fwd");
 }
 
+// avt_bn_train_bwd without its statistics pass: `g` is the ALREADY MASKED output gradient and `ws` holds pre_rows rows per group of
+// the partial sums of g and g * xhat, both left by the launch that produced g (avt_conv3d_igemm_x3_f32_bwdstats).  The shortcut's
+// gradient of a BatchNorm with a shortcut IS g: the caller aliases it, nothing is written for it here.
+extern "C" int avt_bn_train_bwd_pre(const float* g, const float* x, int64_t m, int c, const float* gamma, const float* save_mean,
+                                    const float* save_invstd, int groups, void* ws, int64_t ws_size, int pre_rows, float* dx, float* dgamma,
+                                    float* dbeta, void* stream) {
+  AVT_REQUIRE(g && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && pre_rows > 0, "avt_bn_train_bwd_pre: NULL pointer / no rows");
+  AVT_REQUIRE(avt::aligned16(g) && avt::aligned16(x) && avt::aligned16(dx) && avt::aligned16(gamma) && avt::aligned16(save_mean) &&
+                  avt::aligned16(save_invstd),
+              "avt_bn_train_bwd_pre: rows and per-channel vectors must be 16-byte aligned");
+  AVT_REQUIRE(shape_ok(m, c) && groups >= 1 && groups <= 65535 && m % groups == 0, "avt_bn_train_bwd_pre: bad shape");
+  BnArgs a = {};
+  a.groups = groups;
+  layout(a, m / groups, c);
+  const int64_t need = avt_bn_train_ws_bytes_pre(c, groups, pre_rows);
+  AVT_REQUIRE(ws && avt::aligned16(ws) && ws_size >= need && pre_rows % a.unit == 0,
+              "avt_bn_train_bwd_pre: workspace of %lld bytes needed (avt_bn_train_ws_bytes_pre), got %lld", (long long)need, (long long)ws_size);
+  a.part = static_cast<double*>(ws);
+  const int fin = pre_rows_final(pre_rows, a.unit);
+  a.coef = reinterpret_cast<float*>(a.part + (size_t)groups * (pre_rows + fin) * a.nq * 8);
+  a.dy = g; a.y = nullptr; a.x = x; a.gamma = gamma; a.beta = nullptr; a.mean = save_mean; a.invstd = save_invstd;
+  a.relu = 0;  // (g is masked already)
+  a.mask = nullptr;
+  a.out = dx; a.dres = nullptr; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.ld4 = c / 4;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BnArgs f = a;
+  f.blocks = pre_rows;
+  if (fin) {
+    PreArgs p;
+    p.src = a.part;
+    p.dst = a.part + (size_t)groups * pre_rows * a.nq * 8;
+    p.rows = pre_rows / a.unit;
+    p.unit = a.unit;
+    p.len = a.nq * 8;
+    hipLaunchKernelGGL(bn_pre_reduce_kernel, dim3(fin / a.unit, a.unit * groups), dim3(kT), 0, st, p);
+    f.part = p.dst;
+    f.blocks = fin;
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 4), dim3(kT), 0, st, f);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(a.blocks, groups), dim3(kT), 0, st, a);
+  return avt::check_launch("avt_bn_train_bwd_pre");
+}
+
 extern "C" int avt_bn_train_bwd(const float* dy, const float* y, const float* x, int64_t m, int c, const float* gamma, const float* beta,
                                 const float* save_mean, const float* save_invstd, int relu, int groups, const void* relu_mask, void* ws,
                                 int64_t ws_size, float* dx, float* dres, float* dgamma, float* dbeta, int64_t ld_dy, void* stream) {

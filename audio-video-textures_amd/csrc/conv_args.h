@@ -76,7 +76,49 @@ struct ConvArgs {
   double* stat_part;
   int stat_groups, stat_mg, stat_tpg;
   int stat_c;           // BatchNorm channels: Cout, or Cout / g for the pixel-grouped form (columns n and n + stat_c are one channel)
+  // BatchNorm BACKWARD statistics on the epilogue of an input-gradient launch (round 5; avt_conv3d_igemm_x3_f32_bwdstats): the
+  // launch's output dz is the gradient of a train-mode BatchNorm (+ ReLU)'s OUTPUT.  The epilogue reads that BatchNorm's input
+  // rows (bst_x, same geometry as the output), rebuilds the ReLU mask — from x with the forward's own expression, or from the
+  // 4-bits-per-chunk mask the forward saved when there was a shortcut — stores g = mask * dz (what the BatchNorm's apply pass
+  // wants), and leaves the per-tile sums of g and g * xhat in stat_part: the BatchNorm's backward statistics pass (dy and x read
+  // once more) is gone.  bst_x = NULL: off (stat_part then means the FORWARD statistics above).
+  const float* bst_x;
+  const float* bst_mean;    // [groups][C]
+  const float* bst_invstd;  // [groups][C]
+  const float* bst_gamma;   // [C]
+  const float* bst_beta;    // [C]: mask recomputed from x ((x - mean) * (invstd * gamma) + beta > 0); unused with bst_mask
+  const uint8_t* bst_mask;  // [M * C / 4] the forward's saved mask bits, or NULL
+  int bst_relu;             // 0: no activation (g = dz)
 };
+
+// The eight per-channel coefficients of one thread (its channel octet is the same in every row it stores) and the masking /
+// accumulation of one row's octet for the backward statistics.
+struct BstCoef {
+  float mu[8], sc[8], be[8];  // (invstd itself multiplies the folded sum once per channel: stat_fold_store)
+};
+__device__ __forceinline__ void bst_load(const ConvArgs& a, int group, int n, BstCoef& k) {
+  const int C = a.stat_c;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = (n + e) % C;  // (pixel-grouped form: column n is channel n % C)
+    k.mu[e] = a.bst_mean[(size_t)group * C + c];
+    k.sc[e] = a.bst_invstd[(size_t)group * C + c] * a.bst_gamma[c];   // the forward's scale: the same product, the same rounding
+    k.be[e] = a.bst_beta ? a.bst_beta[c] : 0.0f;
+  }
+}
+// x[8] = dz of (row m, columns n ..): -> g in place; s / q += g, g * (x - mean).  xv = the BatchNorm input's octet, bits = its two mask nibbles
+__device__ __forceinline__ void bst_apply(const ConvArgs& a, const BstCoef& k, const float* xv, unsigned bits, float* x, float* s, float* q) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float xc = xv[e] - k.mu[e];
+    bool keep = true;
+    if (a.bst_relu) keep = a.bst_mask ? ((bits >> e) & 1u) != 0u : (xc * k.sc[e] + k.be[e] > 0.0f);
+    const float g = keep ? x[e] : 0.0f;
+    x[e] = g;
+    s[e] += g;
+    q[e] += g * xc;
+  }
+}
 
 // this tile's first row and the end of the rows it may touch (its group's end when the tiles are laid per group)
 __device__ __forceinline__ void tile_rows(const ConvArgs& a, int tm, int bm, int& m0, int& m_end) {
@@ -106,6 +148,7 @@ __device__ __forceinline__ void stat_fold_store(const ConvArgs& a, const float* 
     for (int col = ch; col < ncols; col += C)
       for (int r = 0; r < nrow; ++r) acc += (double)red[(r * 2 + qi) * BN + col];
     const int c = (n0 + ch) % C, quad = c >> 2, e = c & 3;
+    if (a.bst_x && qi == 1) acc *= (double)a.bst_invstd[(size_t)(tm / a.stat_tpg) * C + c];  // sum of g * (x - mean) -> of g * xhat
     a.stat_part[((size_t)tm * unit + (quad >> 8)) * nq * 8 + (size_t)(quad % nq) * 8 + e + 4 * qi] = acc;
   }
 }
@@ -200,6 +243,9 @@ inline int conv_args_fill(ConvArgs& a, const char* who, const void* in, const vo
   a.oW = remap ? out_w : 0;
   a.stat_part = nullptr;
   a.stat_groups = a.stat_mg = a.stat_tpg = a.stat_c = 0;
+  a.bst_x = a.bst_mean = a.bst_invstd = a.bst_gamma = a.bst_beta = nullptr;
+  a.bst_mask = nullptr;
+  a.bst_relu = 0;
   return AVT_OK;
 }
 

@@ -90,7 +90,9 @@ __device__ __forceinline__ f32x16 mfma(i32x4 w, i32x4 x, f32x16 c) {
 // activations are read as fp32 NDHWC rows and split into the two planes in registers on their way to the LDS (same number
 // of 16-byte loads as two planes; ~4 VALU operations per element next to 48 MFMAs per K-step), the result is written as
 // fp32: a drop-in for an fp32 convolution on channels-last tensors, no plane-pair tensors in the autograd graph.
-template <int BM, int BN, int WTM, bool F16, bool IO32 = false>
+// BST (IO32 only): the backward-statistics epilogue of conv_args.h (a separate instance: its 40 extra live registers stay out of
+// the forward / plain input-gradient launches)
+template <int BM, int BN, int WTM, bool F16, bool IO32 = false, bool BST = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   constexpr int WAVES_M = BM / WTM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -363,6 +365,28 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       }
     }
   }
+  // backward statistics of the BatchNorm whose output gradient this launch computes (conv_args.h): its input's octets for the rows
+  // this thread stores, the mask nibbles and the octet's coefficients — requested here, used in the store loop
+  float4 bxa[BST ? EU : 1], bxb[BST ? EU : 1];
+  unsigned bbits[BST ? EU : 1];
+  BstCoef bk;
+  if constexpr (BST) {
+    {
+      const int n = n0 + (tid % CPR) * 8;
+      bst_load(a, tm / a.stat_tpg, n < a.Cout ? n : 0, bk);
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c = tid + 256 * u;
+        const int m = m0 + c / CPR;
+        const bool ok = m < m_end && n < a.Cout;
+        const int64_t o = ok ? (int64_t)m * a.ldo + n : 0;
+        bxa[u] = *reinterpret_cast<const float4*>(a.bst_x + o);
+        bxb[u] = *reinterpret_cast<const float4*>(a.bst_x + o + 4);
+        bbits[u] = a.bst_mask ? *reinterpret_cast<const uint16_t*>(a.bst_mask + (o >> 2)) : 0u;
+        bbits[u] = (bbits[u] & 0xFu) | ((bbits[u] >> 4) & 0xF0u);
+      }
+    }
+  }
   // D layout: column (lane & 31) = m, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) = n -> regs 4g..4g+3 are 4 consecutive n
 #pragma unroll
   for (int i = 0; i < NT; ++i)
@@ -423,7 +447,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
           x[0] += r0_.x; x[1] += r0_.y; x[2] += r0_.z; x[3] += r0_.w;
           x[4] += r1_.x; x[5] += r1_.y; x[6] += r1_.z; x[7] += r1_.w;
         }
-        if (a.stat_part) {  // (uniform) the values as stored: what the BatchNorm's own statistics pass would read back
+        if constexpr (BST) {  // backward statistics: x becomes g = mask * dz; sums of g and g * xhat
+          const float xv[8] = {bxa[u].x, bxa[u].y, bxa[u].z, bxa[u].w, bxb[u].x, bxb[u].y, bxb[u].z, bxb[u].w};
+          bst_apply(a, bk, xv, bbits[u], x, st_s, st_q);
+        } else if (a.stat_part) {  // (uniform) forward statistics of the values as stored: what the BatchNorm's own pass would read back
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             st_s[e] += x[e];
@@ -912,7 +939,7 @@ int launch_x3_xl(ConvArgs& a, hipStream_t st) {
   return avt::check_launch("avt_conv3d_igemm_x3");
 }
 
-template <int BM, int BN, int WTM, bool F16, bool IO32 = false>
+template <int BM, int BN, int WTM, bool F16, bool IO32 = false, bool BST = false>
 int launch_x3(ConvArgs& a, hipStream_t st) {
   if (a.stat_part) a.stat_tpg = (a.stat_mg + BM - 1) / BM;
   const int tiles_m = a.stat_part ? a.stat_groups * a.stat_tpg : (a.M + BM - 1) / BM;
@@ -928,13 +955,13 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
   if (lds_bytes < epi_bytes) lds_bytes = epi_bytes;
   a.cf_ofs = lds_bytes;       // the tile's bias | scale floats behind the operand slabs / the table / the epilogue staging
   lds_bytes += 2 * BN * 4;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<BM, BN, WTM, F16, IO32>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<BM, BN, WTM, F16, IO32, BST>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_max, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WTM, F16, IO32>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WTM, F16, IO32, BST>), dim3((unsigned)a.nblk), dim3(256), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_x3");
 }
 
@@ -1019,7 +1046,7 @@ static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_
                              float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh,
                              int kw, int st, int sh, int sw, int pt, int ph, int pw, int to, int ho, int wo, int ldi, int ldo, int lda,
                              int out_row_stride, int out_h, int out_w, int plane_dtype, void* stream, double* stat_part = nullptr,
-                             int stat_groups = 0, int stat_c = 0) {
+                             int stat_groups = 0, int stat_c = 0, const ConvArgs* bst = nullptr) {
   AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_conv3d_igemm_x3_f32: plane_dtype must be 0 (bf16) or 1 (fp16)");
   AVT_REQUIRE(wt_lo && avt::aligned16(wt_lo) && (!wscale || avt::aligned16(wscale)), "avt_conv3d_igemm_x3_f32: weight planes / wscale NULL or unaligned");
   AVT_REQUIRE((int64_t)batch * t * h * w * ldi < (1ll << 30) - 64, "avt_conv3d_igemm_x3_f32: input too large for 32-bit byte offsets");
@@ -1037,9 +1064,17 @@ static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_
   a.nup = 0;
   a.wblk = 0;
   if (stat_part) {
-    AVT_REQUIRE(stat_groups >= 1 && a.M % stat_groups == 0 && stat_c >= 8 && cout % stat_c == 0 && a.oH == 0 && !add && avt::aligned16(stat_part),
+    AVT_REQUIRE(stat_groups >= 1 && a.M % stat_groups == 0 && stat_c >= 8 && cout % stat_c == 0 && a.oH == 0 && (!add || bst) &&
+                    avt::aligned16(stat_part),
                 "avt_conv3d_igemm_x3_f32_stats: %d rows in %d groups, %d channels of %d columns, no row remap, no add operand", a.M,
                 stat_groups, stat_c, cout);
+    if (bst) {  // backward statistics: the BatchNorm input has the output's geometry, contiguous rows
+      AVT_REQUIRE(bst->bst_x && bst->bst_mean && bst->bst_invstd && bst->bst_gamma && ldo == cout && avt::aligned16(bst->bst_x) &&
+                      (!bst->bst_relu || bst->bst_mask || bst->bst_beta),
+                  "avt_conv3d_igemm_x3_f32_bwdstats: BatchNorm input / statistics / scale missing, or the output rows are not contiguous");
+      a.bst_x = bst->bst_x; a.bst_mean = bst->bst_mean; a.bst_invstd = bst->bst_invstd; a.bst_gamma = bst->bst_gamma;
+      a.bst_beta = bst->bst_beta; a.bst_mask = bst->bst_mask; a.bst_relu = bst->bst_relu;
+    }
     a.stat_part = stat_part;
     a.stat_groups = stat_groups;
     a.stat_mg = a.M / stat_groups;
@@ -1047,6 +1082,13 @@ static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_
     AVT_REQUIRE((int64_t)stat_groups * ((a.stat_mg + 127) / 128) < (1ll << 24), "avt_conv3d_igemm_x3_f32_stats: too many tiles");
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (bst) {  // backward statistics: the 128-row tiles only (bf16 planes: gradients)
+    AVT_REQUIRE(plane_dtype == AVT_X3_BF16 && io32_tile_rows(cout, a.K, a.M) == 128,
+                "avt_conv3d_igemm_x3_f32_bwdstats: bf16 planes, layers of the 128-row tile (avt_conv3d_igemm_x3_f32_bwdstats_rows)");
+    if (cout <= 32) return launch_x3<128, 32, 32, false, true, true>(a, s);
+    if (cout <= 64) return launch_x3<128, 64, 64, false, true, true>(a, s);
+    return launch_x3<128, 128, 64, false, true, true>(a, s);
+  }
   // long-K layers at a batch that fills 256 x 256 tiles (a rank's items as one batch): the XL tile's IO32 form
   if (a.oH == 0 && io32_tile_rows(cout, a.K, a.M) == 256)
     return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, true>(a, s) : launch_x3_xl<false, true>(a, s);
@@ -1083,6 +1125,27 @@ extern "C" int avt_conv3d_igemm_x3_f32_stats(const float* in, const void* wt_hi,
   AVT_REQUIRE(stat_part, "avt_conv3d_igemm_x3_f32_stats: NULL stat_part");
   return igemm_x3_f32_impl(in, wt_hi, wt_lo, wscale, nullptr, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw, st, sh, sw, pt, ph, pw, 0, 0, 0,
                            ldi, ldo, 0, 1, 0, 0, plane_dtype, stream, static_cast<double*>(stat_part), groups, stat_c);
+}
+
+// rows of partials per group avt_conv3d_igemm_x3_f32_bwdstats writes, or -1 where it does not apply (the 256 x 256 tile's layers)
+extern "C" int avt_conv3d_igemm_x3_f32_bwdstats_rows(int cout, int k, int64_t m, int groups) {
+  if (groups < 1 || m <= 0 || m % groups || io32_tile_rows(cout, k, m) != 128) return -1;
+  return (int)((m / groups + 127) / 128);
+}
+
+// The stride-1 INPUT GRADIENT whose result is the output gradient of a train-mode BatchNorm (+ ReLU): see include/avt.h
+extern "C" int avt_conv3d_igemm_x3_f32_bwdstats(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
+                                                float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
+                                                int kh, int kw, int pt, int ph, int pw, int ldi, int ldo, int lda, int plane_dtype,
+                                                const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                                const float* bn_beta, const void* bn_mask, int relu, void* stat_part, int groups, int stat_c,
+                                                void* stream) {
+  AVT_REQUIRE(stat_part, "avt_conv3d_igemm_x3_f32_bwdstats: NULL stat_part");
+  ConvArgs b = {};
+  b.bst_x = bn_x; b.bst_mean = bn_mean; b.bst_invstd = bn_invstd; b.bst_gamma = bn_gamma; b.bst_beta = bn_beta;
+  b.bst_mask = static_cast<const uint8_t*>(bn_mask); b.bst_relu = relu;
+  return igemm_x3_f32_impl(in, wt_hi, wt_lo, wscale, add, out, ktab, batch, t, h, w, cin, cout, kt, kh, kw, 1, 1, 1, pt, ph, pw, 0, 0, 0, ldi,
+                           ldo, lda, 1, 0, 0, plane_dtype, stream, static_cast<double*>(stat_part), groups, stat_c, &b);
 }
 
 // ... with an explicit output extent (any padding on the far side) and the output-row remap of avt_conv3d_igemm_x3: one class of

@@ -16,6 +16,8 @@
 // v_mfma_f32_16x16x32_{f16,bf16}: three passes per product, wl*xh + wh*xl + wh*xh, fp32 accumulate.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "avt_common.h"
 #include "split_planes.h"
 
@@ -387,6 +389,16 @@ struct PfArgs {
   // stored as one row of partials in bn_train.hip's channel_sums layout (row (group * n_rg + rg) * 8 + wave)
   double* stat_part;
   int n_total;           // channels of the whole layer (the BatchNorm's C)
+  // STATS = 2 (avt_pw_x3_f32_bwdstats): the launch is an input gradient whose result is the OUTPUT gradient of a train-mode
+  // BatchNorm (+ ReLU) — see conv_args.h (bst_*): the BatchNorm's input rows [M, ldy], its saved statistics [groups][N], scale,
+  // shift (mask recomputed) or saved mask bits; the result is stored MASKED and the partial rows hold the sums of g and g * xhat
+  const float* bst_x;
+  const float* bst_mean;
+  const float* bst_invstd;
+  const float* bst_gamma;
+  const float* bst_beta;
+  const uint8_t* bst_mask;
+  int bst_relu;
 };
 
 // pass width (channels) of the STATS transpose: the per-wave LDS scratch must fit beside the weight fragments
@@ -398,7 +410,7 @@ struct PfStat {
   static constexpr int BYTES = PX_NW * 16 * RS * 4;      // all waves
 };
 
-template <int K1S, int NT1, bool F16, bool STATS = false>
+template <int K1S, int NT1, bool F16, int STATS = 0>
 __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
   constexpr int NC = NT1 * 16;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -411,10 +423,15 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
   const int rg = (j / a.n_chunks) * 8 + xcd;
   if (rg >= a.n_rg) return;
   const int c0 = chunk * NC;
-  if constexpr (STATS) {  // this workgroup's group: its slab of the rows
+  if constexpr (STATS != 0) {  // this workgroup's group: its slab of the rows
     const int64_t g = blockIdx.y;
     a.x += g * a.M * a.ldx;
     a.y += g * a.M * a.ldy;
+    if constexpr (STATS == 2) {
+      if (a.add) a.add += g * a.M * a.lda;
+      a.bst_x += g * a.M * a.ldy;
+      if (a.bst_mask) a.bst_mask += g * a.M * a.ldy / 4;
+    }
   }
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -435,15 +452,25 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
     *reinterpret_cast<i32x4*>(wll + f * 1024 + lane * 16) = vl;
   }
   for (int i = tid; i < NC; i += PX_NW * 64) sl[i] = a.wscale ? a.wscale[c0 + i] : 1.0f;
+  // STATS = 2: this (group, chunk)'s BatchNorm coefficients [mean | invstd * gamma | beta] behind the statistics scratch
+  float* kc = reinterpret_cast<float*>(reinterpret_cast<char*>(sl) + NC * 4 + PfStat<K1S, NT1>::BYTES);
+  if constexpr (STATS == 2) {
+    for (int i = tid; i < NC; i += PX_NW * 64) {
+      const size_t gc = (size_t)blockIdx.y * a.n_total + c0 + i;
+      kc[i] = a.bst_mean[gc];
+      kc[NC + i] = a.bst_invstd[gc] * a.bst_gamma[c0 + i];  // the forward's scale: the same product
+      kc[2 * NC + i] = a.bst_beta ? a.bst_beta[c0 + i] : 0.0f;
+    }
+  }
   __syncthreads();
-  const bool has_add = !STATS && a.add != nullptr;
+  const bool has_add = STATS != 1 && a.add != nullptr;
   // STATS: per-wave scratch [16 rows][PW channels] behind the scale floats; lane l owns column l of every pass (PW = 32: column
   // l & 31, rows 8 (l >> 5) ..), its sums over the wave's tiles in fp64 (fp32 over the 16 / 8 rows of one tile)
   typedef PfStat<K1S, NT1> PS;
   constexpr int NPASS = NC / PS::PW;
   float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(sl) + NC * 4) + wid * 16 * PS::RS;
-  double st_s[STATS ? NPASS : 1], st_q[STATS ? NPASS : 1];
-  if constexpr (STATS) {
+  double st_s[STATS != 0 ? NPASS : 1], st_q[STATS != 0 ? NPASS : 1];
+  if constexpr (STATS != 0) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) st_s[ps] = st_q[ps] = 0.0;
   }
@@ -453,6 +480,8 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
     const bool ok = p < a.M;
     int lofs = lane * 16;  // opaque per tile: keeps the loop-invariant fragment reads from being hoisted into registers
     asm volatile("" : "+v"(lofs));
+    int kz = 0;            // ... and the STATS = 2 coefficient reads
+    asm volatile("" : "+v"(kz));
     const int64_t pc = ok ? p : a.M - 1;
     float4 xa[K1S], xb[K1S];
 #pragma unroll
@@ -463,15 +492,31 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
       xa[ks] = *reinterpret_cast<const float4*>(px);
       xb[ks] = *reinterpret_cast<const float4*>(px + 4);
     }
+    // the epilogue's operands (`add` rows, STATS = 2: the BatchNorm input's octets + mask nibbles), requested ahead of their use.
+    // STATS = 2 with 16 tiles per wave: in TWO batches — the second after the MFMAs, when the operand registers are free (all at
+    // once, the kernel spilled 40-115 registers)
+    constexpr int HB = (STATS == 2 && NT1 > 8) ? NT1 / 4 : NT1 / 2;
     float4 ra[NT1 / 2], rb[NT1 / 2];
-    if (has_add) {
+    float4 bxa[STATS == 2 ? NT1 / 2 : 1], bxb[STATS == 2 ? NT1 / 2 : 1];
+    unsigned bbits[STATS == 2 ? NT1 / 2 : 1];
+    auto epi_request = [&](auto j0, auto j1) {  // (compile-time bounds: the arrays stay in registers)
 #pragma unroll
-      for (int jj = 0; jj < NT1 / 2; ++jj) {
-        const float* pr = a.add + pc * a.lda + c0 + 32 * jj + 8 * q;
-        ra[jj] = *reinterpret_cast<const float4*>(pr);
-        rb[jj] = *reinterpret_cast<const float4*>(pr + 4);
+      for (int jj = decltype(j0)::value; jj < decltype(j1)::value; ++jj) {
+        if (has_add) {
+          const float* pr = a.add + pc * a.lda + c0 + 32 * jj + 8 * q;
+          ra[jj] = *reinterpret_cast<const float4*>(pr);
+          rb[jj] = *reinterpret_cast<const float4*>(pr + 4);
+        }
+        if constexpr (STATS == 2) {
+          const int64_t o = pc * a.ldy + c0 + 32 * jj + 8 * q;
+          bxa[jj] = *reinterpret_cast<const float4*>(a.bst_x + o);
+          bxb[jj] = *reinterpret_cast<const float4*>(a.bst_x + o + 4);
+          const unsigned v = a.bst_mask ? *reinterpret_cast<const uint16_t*>(a.bst_mask + (o >> 2)) : 0u;
+          bbits[jj] = (v & 0xFu) | ((v >> 4) & 0xF0u);
+        }
       }
-    }
+    };
+    epi_request(std::integral_constant<int, 0>{}, std::integral_constant<int, HB>{});
     i32x4 xh[K1S], xl[K1S];
 #pragma unroll
     for (int ks = 0; ks < K1S; ++ks) {
@@ -482,44 +527,114 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
       xl[ks] = __builtin_bit_cast(i32x4, l);
     }
     f32x4 acc[NT1];
+    auto mfma_part = [&](auto n0_, auto n1_) {  // output tiles n0 .. n1 - 1: every accumulator sees its own terms in the one order
 #pragma unroll
-    for (int n = 0; n < NT1; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int n = decltype(n0_)::value; n < decltype(n1_)::value; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < K1S; ++ks) {
+      for (int ks = 0; ks < K1S; ++ks) {
 #pragma unroll
-      for (int n = 0; n < NT1; n += PW_IL) {
-        i32x4 wh[PW_IL], wl[PW_IL];
+        for (int n = decltype(n0_)::value; n < decltype(n1_)::value; n += PW_IL) {
+          i32x4 wh[PW_IL], wl[PW_IL];
 #pragma unroll
-        for (int u = 0; u < PW_IL; ++u) {
-          const int f = (n + u) * K1S + ks;
-          wh[u] = *reinterpret_cast<const i32x4*>(whl + f * 1024 + lofs);
-          wl[u] = *reinterpret_cast<const i32x4*>(wll + f * 1024 + lofs);
+          for (int u = 0; u < PW_IL; ++u) {
+            const int f = (n + u) * K1S + ks;
+            wh[u] = *reinterpret_cast<const i32x4*>(whl + f * 1024 + lofs);
+            wl[u] = *reinterpret_cast<const i32x4*>(wll + f * 1024 + lofs);
+          }
+#pragma unroll
+          for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wl[u], xh[ks], acc[n + u]);
+#pragma unroll
+          for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wh[u], xl[ks], acc[n + u]);
+#pragma unroll
+          for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wh[u], xh[ks], acc[n + u]);
         }
-#pragma unroll
-        for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wl[u], xh[ks], acc[n + u]);
-#pragma unroll
-        for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wh[u], xl[ks], acc[n + u]);
-#pragma unroll
-        for (int u = 0; u < PW_IL; ++u) acc[n + u] = mfma16<F16>(wh[u], xh[ks], acc[n + u]);
       }
-    }
+    };
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    f32x4n hv[4];  // (STATS = 2: the second statistic's addends of one pass)
+    auto epilogue = [&](auto j0_, auto j1_) {
 #pragma unroll
-    for (int jj = 0; jj < NT1 / 2; ++jj) {  // tiles 2jj, 2jj+1 -> channels c0 + 32 jj + 8 q .. + 7
+    for (int jj = decltype(j0_)::value; jj < decltype(j1_)::value; ++jj) {  // tiles 2jj, 2jj+1 -> channels c0 + 32 jj + 8 q .. + 7
       const int cl = 32 * jj + 8 * q;
-      const float4 sa = *reinterpret_cast<const float4*>(sl + cl), sb = *reinterpret_cast<const float4*>(sl + cl + 4);
-      typedef float f32x4n __attribute__((ext_vector_type(4)));
-      f32x4n o0 = {acc[2 * jj][0] * sa.x, acc[2 * jj][1] * sa.y, acc[2 * jj][2] * sa.z, acc[2 * jj][3] * sa.w};
-      f32x4n o1 = {acc[2 * jj + 1][0] * sb.x, acc[2 * jj + 1][1] * sb.y, acc[2 * jj + 1][2] * sb.z, acc[2 * jj + 1][3] * sb.w};
+      f32x4n o0, o1;
+      if constexpr (STATS == 2) {  // (gradients: bf16 planes, no row scales — and no 4 NT1 scale registers held across the tile loop)
+        o0 = f32x4n{acc[2 * jj][0], acc[2 * jj][1], acc[2 * jj][2], acc[2 * jj][3]};
+        o1 = f32x4n{acc[2 * jj + 1][0], acc[2 * jj + 1][1], acc[2 * jj + 1][2], acc[2 * jj + 1][3]};
+      } else {
+        const float4 sa = *reinterpret_cast<const float4*>(sl + cl), sb = *reinterpret_cast<const float4*>(sl + cl + 4);
+        o0 = f32x4n{acc[2 * jj][0] * sa.x, acc[2 * jj][1] * sa.y, acc[2 * jj][2] * sa.z, acc[2 * jj][3] * sa.w};
+        o1 = f32x4n{acc[2 * jj + 1][0] * sb.x, acc[2 * jj + 1][1] * sb.y, acc[2 * jj + 1][2] * sb.z, acc[2 * jj + 1][3] * sb.w};
+      }
       if (has_add) {
         o0 += f32x4n{ra[jj].x, ra[jj].y, ra[jj].z, ra[jj].w};
         o1 += f32x4n{rb[jj].x, rb[jj].y, rb[jj].z, rb[jj].w};
+      }
+      f32x4n v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;  // STATS = 2: g * (x - mean), the second statistic's addends
+      if constexpr (STATS == 2) {  // o becomes g = mask * dz (what is stored)
+        // (coefficients through an offset that is opaque per tile: read at constant addresses they are loop-invariant, and the
+        //  compiler kept all 24 x NT1 / 2 of them in registers across the tile loop — 54-108 spilled registers)
+        const float* kct = kc + kz;
+        const float4 m0 = *reinterpret_cast<const float4*>(kct + cl), m1 = *reinterpret_cast<const float4*>(kct + cl + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(kct + NC + cl), s1 = *reinterpret_cast<const float4*>(kct + NC + cl + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(kct + 2 * NC + cl), b1 = *reinterpret_cast<const float4*>(kct + 2 * NC + cl + 4);
+        const float xc[8] = {bxa[jj].x - m0.x, bxa[jj].y - m0.y, bxa[jj].z - m0.z, bxa[jj].w - m0.w,
+                             bxb[jj].x - m1.x, bxb[jj].y - m1.y, bxb[jj].z - m1.z, bxb[jj].w - m1.w};
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float gg[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]}, vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bool keep = true;
+          if (a.bst_relu) keep = a.bst_mask ? ((bbits[jj] >> e) & 1u) != 0u : (xc[e] * sc[e] + be[e] > 0.0f);
+          gg[e] = keep ? gg[e] : 0.0f;
+          vv[e] = gg[e] * xc[e];
+        }
+        o0 = f32x4n{gg[0], gg[1], gg[2], gg[3]};
+        o1 = f32x4n{gg[4], gg[5], gg[6], gg[7]};
+        v0 = f32x4n{vv[0], vv[1], vv[2], vv[3]};
+        v1 = f32x4n{vv[4], vv[5], vv[6], vv[7]};
       }
       if (ok) {
         float* po = a.y + pc * a.ldy + c0 + cl;
         __builtin_nontemporal_store(o0, reinterpret_cast<f32x4n*>(po));
         __builtin_nontemporal_store(o1, reinterpret_cast<f32x4n*>(po + 4));
       }
-      if constexpr (STATS) {
+      if constexpr (STATS == 2) {
+        // as below, with two blocks per pass: g for the first statistic, g * (x - mean) for the second (held in registers — at
+        // most two octets — until the first block has been read back)
+        constexpr int JPP = PS::PW / 32;
+        const int jl = jj % JPP;
+        if (!ok) o0 = o1 = v0 = v1 = f32x4n{0.f, 0.f, 0.f, 0.f};
+        float* pw_ = scr + l15 * PS::RS + 32 * jl + 8 * q;
+        *reinterpret_cast<f32x4n*>(pw_) = o0;
+        *reinterpret_cast<f32x4n*>(pw_ + 4) = o1;
+        if (jl == 0) { hv[0] = v0; hv[1] = v1; } else { hv[2] = v0; hv[3] = v1; }
+        if (jl == JPP - 1) {
+          constexpr int NR = PS::PW == 64 ? 16 : 8;
+          const float* pr = scr + (PS::PW == 64 ? lane : (lane & 31) + (lane >> 5) * 8 * PS::RS);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          float ts = 0.f, tq = 0.f;
+          if (PS::PW >= 32 || lane < PS::PW) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) ts += pr[r * PS::RS];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < JPP; ++k) {
+            float* pv = scr + l15 * PS::RS + 32 * k + 8 * q;
+            *reinterpret_cast<f32x4n*>(pv) = hv[2 * k];
+            *reinterpret_cast<f32x4n*>(pv + 4) = hv[2 * k + 1];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (PS::PW >= 32 || lane < PS::PW) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) tq += pr[r * PS::RS];
+          }
+          st_s[jj / JPP] += (double)ts;
+          st_q[jj / JPP] += (double)tq;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+      if constexpr (STATS == 1) {
         // the 16 x PW block of this pass goes through the wave's scratch: written as it lies (row = position, 8 consecutive
         // channels per lane; rows past the slab as zeros), read back one COLUMN per lane — LDS operations of one wave complete in
         // order, so a wait on the counter is the only synchronisation; no cross-lane traffic, 8 accumulator registers per pass
@@ -548,8 +663,27 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
         }
       }
     }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, HB> IH;
+    typedef std::integral_constant<int, NT1 / 2> IE;
+    if constexpr (HB < NT1 / 2) {  // (STATS = 2, 16 tiles) two halves: the second half's epilogue operands are requested under its MFMAs
+      // (sched_barrier: the scheduler otherwise lifts the second batch's loads and MFMAs over the first half's epilogue, and the
+      //  register pressure of the unsplit form is back)
+      mfma_part(I0{}, std::integral_constant<int, 2 * HB>{});
+      __builtin_amdgcn_sched_barrier(0);
+      epilogue(I0{}, IH{});
+      __builtin_amdgcn_sched_barrier(0);
+      epi_request(IH{}, IE{});
+      mfma_part(std::integral_constant<int, 2 * HB>{}, std::integral_constant<int, NT1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      epilogue(IH{}, IE{});
+    } else {
+      mfma_part(I0{}, std::integral_constant<int, NT1>{});
+      epilogue(I0{}, IE{});
+    }
   }
-  if constexpr (STATS) {  // this wave's row of partials: channel c0 + PW * pass + column
+  if constexpr (STATS != 0) {  // this wave's row of partials: channel c0 + PW * pass + column
     const int C = a.n_total, q4 = C / 4, nq = q4 < 256 ? q4 : 256, unit = q4 > 256 ? q4 / 256 : 1;
     const size_t row = ((size_t)blockIdx.y * a.n_rg + rg) * PX_NW + wid;
 #pragma unroll
@@ -561,6 +695,7 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
       }
       if (lane < PS::PW) {
         const int c = c0 + ps * PS::PW + lane, quad = c >> 2, e = c & 3;
+        if constexpr (STATS == 2) s1 *= (double)a.bst_invstd[(size_t)blockIdx.y * C + c];  // sum of g * (x - mean) -> of g * xhat
         double* dst = a.stat_part + (row * unit + (quad >> 8)) * nq * 8 + (size_t)(quad % nq) * 8 + e;
         dst[0] = s0;
         dst[4] = s1;
@@ -580,27 +715,37 @@ int pf_row_groups(int lds_bytes, int n_chunks, int ntiles, int groups) {
 }
 
 template <int K1S, int NT1>
-constexpr int pf_lds_bytes(bool stats) {
-  return 2 * NT1 * K1S * 1024 + NT1 * 16 * 4 + (stats ? PfStat<K1S, NT1>::BYTES : 0);
+constexpr int pf_lds_bytes(int stats) {  // 0 none, 1 forward statistics, 2 backward (+ the coefficient table)
+  return 2 * NT1 * K1S * 1024 + NT1 * 16 * 4 + (stats ? PfStat<K1S, NT1>::BYTES : 0) + (stats == 2 ? 3 * NT1 * 16 * 4 : 0);
+}
+
+template <int K1S, int NT1, bool F16, int MODE>
+int launch_pf_stats(PfArgs& a, hipStream_t st, int groups) {  // blockIdx.y = the BatchNorm's replica group, a.M / a.ntiles per group
+  constexpr int lds_bytes = pf_lds_bytes<K1S, NT1>(MODE);
+  static_assert(lds_bytes <= 160 * 1024, "weights + the statistics scratch fit the LDS");
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_x3_f32_kernel<K1S, NT1, F16, MODE>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_pw_x3_f32_stats: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  a.n_rg = pf_row_groups(lds_bytes, a.n_chunks, a.ntiles, groups);
+  hipLaunchKernelGGL((pw_x3_f32_kernel<K1S, NT1, F16, MODE>), dim3((unsigned)(a.n_rg * a.n_chunks), (unsigned)groups), dim3(PX_NW * 64),
+                     lds_bytes, st, a);
+  return avt::check_launch("avt_pw_x3_f32_stats");
 }
 
 template <int K1S, int NT1, bool F16>
 int launch_pf(PfArgs& a, hipStream_t st, int groups = 0) {
-  if (groups > 0) {  // STATS: blockIdx.y = the BatchNorm's replica group, a.M / a.ntiles per group
-    constexpr int lds_bytes = pf_lds_bytes<K1S, NT1>(true);
-    static_assert(lds_bytes <= 160 * 1024, "weights + the statistics scratch fit the LDS");
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_x3_f32_kernel<K1S, NT1, F16, true>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) {
-      avt::set_error("avt_pw_x3_f32_stats: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
-      return AVT_ERR_LAUNCH;
+  if (groups > 0) {
+    if (a.bst_x) {
+      if constexpr (!F16) return launch_pf_stats<K1S, NT1, false, 2>(a, st, groups);  // (gradients: bf16 planes)
+      avt::set_error("avt_pw_x3_f32_bwdstats: bf16 planes only");
+      return AVT_ERR_UNSUPPORTED;
     }
-    a.n_rg = pf_row_groups(lds_bytes, a.n_chunks, a.ntiles, groups);
-    hipLaunchKernelGGL((pw_x3_f32_kernel<K1S, NT1, F16, true>), dim3((unsigned)(a.n_rg * a.n_chunks), (unsigned)groups), dim3(PX_NW * 64),
-                       lds_bytes, st, a);
-    return avt::check_launch("avt_pw_x3_f32_stats");
+    return launch_pf_stats<K1S, NT1, F16, 1>(a, st, groups);
   }
-  constexpr int lds_bytes = pf_lds_bytes<K1S, NT1>(false);
+  constexpr int lds_bytes = pf_lds_bytes<K1S, NT1>(0);
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_x3_f32_kernel<K1S, NT1, F16>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
@@ -613,7 +758,7 @@ int launch_pf(PfArgs& a, hipStream_t st, int groups = 0) {
 }
 
 // LDS bytes of the (K1S, NT1) instance, for the row-group query (avt_pw_x3_f32_stat_rows)
-int pf_lds_of(int k1s, int nt1, bool stats) {
+int pf_lds_of(int k1s, int nt1, int stats) {
 #define PF_CASE(K, N) if (k1s == K && nt1 == N) return pf_lds_bytes<K, N>(stats);
   PF_CASE(1, 16) PF_CASE(1, 8) PF_CASE(1, 4) PF_CASE(1, 2) PF_CASE(2, 16) PF_CASE(2, 8) PF_CASE(2, 4) PF_CASE(2, 2)
   PF_CASE(4, 16) PF_CASE(4, 8) PF_CASE(4, 4) PF_CASE(4, 2) PF_CASE(8, 8) PF_CASE(8, 4) PF_CASE(8, 2)
@@ -910,6 +1055,7 @@ extern "C" int avt_pw_x3_f32(const float* x, int ldx, int k, const void* w_hi, c
   a.n_chunks = n / (16 * nt1);
   a.stat_part = nullptr;
   a.n_total = n;
+  a.bst_x = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return plane_dtype == AVT_X3_F16 ? dispatch_pf_k<true>(a, k1s, nt1, st) : dispatch_pf_k<false>(a, k1s, nt1, st);
 }
@@ -920,7 +1066,7 @@ extern "C" int avt_pw_x3_f32_stat_rows(int k, int n, int64_t m, int groups) {
   if (!avt_pw_x3_f32_supported(k, n) || groups < 1 || m <= 0 || m % groups) return -1;
   const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
   const int ntiles = (int)((m / groups + 15) / 16);
-  return pf_row_groups(pf_lds_of(k1s, nt1, true), n / (16 * nt1), ntiles, groups) * PX_NW;
+  return pf_row_groups(pf_lds_of(k1s, nt1, 1), n / (16 * nt1), ntiles, groups) * PX_NW;
 }
 
 extern "C" int avt_pw_x3_f32_stats(const float* x, int ldx, int k, const void* w_hi, const void* w_lo, const float* wscale, float* y, int ldy,
@@ -945,6 +1091,45 @@ extern "C" int avt_pw_x3_f32_stats(const float* x, int ldx, int k, const void* w
   a.n_chunks = n / (16 * nt1);
   a.stat_part = static_cast<double*>(stat_part);
   a.n_total = n;
+  a.bst_x = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return plane_dtype == AVT_X3_F16 ? dispatch_pf_k<true>(a, k1s, nt1, st, groups) : dispatch_pf_k<false>(a, k1s, nt1, st, groups);
+}
+
+// The streaming input gradient whose result is a train-mode BatchNorm's OUTPUT gradient (include/avt.h; the counterpart of
+// avt_conv3d_igemm_x3_f32_bwdstats for the pointwise layers)
+extern "C" int avt_pw_x3_f32_bwdstats_rows(int k, int n, int64_t m, int groups) {
+  if (!avt_pw_x3_f32_supported(k, n) || groups < 1 || m <= 0 || m % groups || n < 8 || (n & (n - 1)) || n > 4096) return -1;
+  const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  const int ntiles = (int)((m / groups + 15) / 16);
+  return pf_row_groups(pf_lds_of(k1s, nt1, 2), n / (16 * nt1), ntiles, groups) * PX_NW;
+}
+
+extern "C" int avt_pw_x3_f32_bwdstats(const float* x, int ldx, int k, const void* w_hi, const void* w_lo, const float* add, int lda, float* y,
+                                      int ldy, int n, int64_t m, int plane_dtype, const float* bn_x, const float* bn_mean,
+                                      const float* bn_invstd, const float* bn_gamma, const float* bn_beta, const void* bn_mask, int relu,
+                                      void* stat_part, int groups, void* stream) {
+  AVT_REQUIRE(x && w_hi && w_lo && y && stat_part && bn_x && bn_mean && bn_invstd && bn_gamma, "avt_pw_x3_f32_bwdstats: NULL pointer");
+  AVT_REQUIRE(avt_pw_x3_f32_bwdstats_rows(k, n, m, groups) > 0, "avt_pw_x3_f32_bwdstats: unsupported layer K=%d N=%d / %lld rows in %d groups",
+              k, n, (long long)m, groups);
+  AVT_REQUIRE(m < (1ll << 31) - 16 && ldx >= k && ldy == n && ldx % 4 == 0 && (!add || (lda >= n && lda % 4 == 0)) &&
+                  (!relu || bn_mask || bn_beta) && plane_dtype == AVT_X3_BF16,
+              "avt_pw_x3_f32_bwdstats: contiguous output rows (ldy == n), bf16 planes, a mask or beta for the ReLU");
+  AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(w_hi) && avt::aligned16(w_lo) && avt::aligned16(y) && avt::aligned16(stat_part) &&
+                  avt::aligned16(bn_x) && (!add || avt::aligned16(add)),
+              "avt_pw_x3_f32_bwdstats: pointers must be 16-byte aligned");
+  const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  PfArgs a;
+  a.x = x; a.add = add; a.y = y;
+  a.wh = static_cast<const uint16_t*>(w_hi);
+  a.wl = static_cast<const uint16_t*>(w_lo);
+  a.wscale = nullptr;
+  a.M = (int)(m / groups); a.ldx = ldx; a.lda = lda; a.ldy = ldy; a.K = k; a.k1c = k / 8;
+  a.ntiles = (a.M + 15) / 16;
+  a.n_chunks = n / (16 * nt1);
+  a.stat_part = static_cast<double*>(stat_part);
+  a.n_total = n;
+  a.bst_x = bn_x; a.bst_mean = bn_mean; a.bst_invstd = bn_invstd; a.bst_gamma = bn_gamma; a.bst_beta = bn_beta;
+  a.bst_mask = static_cast<const uint8_t*>(bn_mask); a.bst_relu = relu;
+  return dispatch_pf_k<false>(a, k1s, nt1, static_cast<hipStream_t>(stream), groups);
 }

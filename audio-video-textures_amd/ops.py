@@ -448,6 +448,47 @@ def pw_x3_f32(x, k, wt_hi, wt_lo, wscale, out, n, plane_dtype, add=None):
                                         int(m), int(plane_dtype), _stream()), "avt_pw_x3_f32")
 
 
+def conv3d_igemm_x3_f32_bwdstats(dy, wt_hi, wt_lo, out, ktab, dims, cin, cout, kernel, pad, plane_dtype, bn, groups, stat_c, add=None):
+    """The stride-1 input gradient (a convolution of dy [.., cin] with the transposed filter -> out [.., cout]) that is the OUTPUT
+    gradient of a train-mode BatchNorm: out = mask * (conv + add), and the BatchNorm's backward statistics as per-tile partials
+    (include/avt.h).  bn = (x, save_mean, save_invstd, gamma, beta | None, mask | None, relu).  -> (ws, pre_rows) for
+    avt_bn_train_bwd_pre, or None where the kernel does not apply (the 256 x 256 tile's layers): nothing was launched."""
+    b, t, h, w = dims
+    _dev(dy, "dy", torch.float32)
+    _dev(out, "out", torch.float32)
+    k = int(kernel[0]) * int(kernel[1]) * int(kernel[2]) * int(cin)
+    m = out.numel() // int(cout)
+    rows = _lib.lib().avt_conv3d_igemm_x3_f32_bwdstats_rows(int(cout), k, int(m), int(groups))
+    if rows <= 0:
+        return None
+    bx, mean, invstd, gamma, beta, mask, relu = bn
+    pre_rows = rows * max(1, int(stat_c) // 1024)
+    ws = torch.empty(_lib.lib().avt_bn_train_ws_bytes_pre(int(stat_c), int(groups), pre_rows), dtype=torch.uint8, device=dy.device)
+    _lib.check(_lib.lib().avt_conv3d_igemm_x3_f32_bwdstats(
+        _p(dy), _p(wt_hi), _p(wt_lo), None, _p(add), _p(out), _p(ktab), int(b), int(t), int(h), int(w), int(cin), int(cout),
+        *[int(v) for v in kernel], *[int(v) for v in pad], int(cin), int(cout), int(cout), int(plane_dtype), _p(bx), _p(mean), _p(invstd),
+        _p(gamma), _p(beta), _p(mask), 1 if relu else 0, _p(ws), int(groups), int(stat_c), _stream()), "avt_conv3d_igemm_x3_f32_bwdstats")
+    return ws, pre_rows
+
+
+def pw_x3_f32_bwdstats(dy, k, wt_hi, wt_lo, out, n, plane_dtype, bn, groups, add=None):
+    """The streaming pointwise form of conv3d_igemm_x3_f32_bwdstats: dy [.., k] -> out [.., n] = mask * (dy W + add), the BatchNorm's
+    backward statistics as one row of partials per wave and group.  -> (ws, pre_rows), or None outside the kernel's domain."""
+    _dev(dy, "dy", torch.float32)
+    _dev(out, "out", torch.float32)
+    m = dy.numel() // k
+    rows = _lib.lib().avt_pw_x3_f32_bwdstats_rows(int(k), int(n), int(m), int(groups))
+    if rows <= 0 or plane_dtype != X3_BF16:
+        return None
+    bx, mean, invstd, gamma, beta, mask, relu = bn
+    pre_rows = rows * max(1, int(n) // 1024)
+    ws = torch.empty(_lib.lib().avt_bn_train_ws_bytes_pre(int(n), int(groups), pre_rows), dtype=torch.uint8, device=dy.device)
+    _lib.check(_lib.lib().avt_pw_x3_f32_bwdstats(_p(dy), int(k), int(k), _p(wt_hi), _p(wt_lo), _p(add), int(n), _p(out), int(n), int(n), int(m),
+                                                 int(plane_dtype), _p(bx), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(mask),
+                                                 1 if relu else 0, _p(ws), int(groups), _stream()), "avt_pw_x3_f32_bwdstats")
+    return ws, pre_rows
+
+
 def pw_x3_f32_stats(x, k, wt_hi, wt_lo, wscale, out, n, plane_dtype, groups):
     """pw_x3_f32 that also leaves the train-mode BatchNorm statistics of its output behind: -> (ws, pre_rows) as conv3d_igemm_x3_f32_stats,
     or None when the layer / group count is outside the kernel's domain (the caller runs the plain form)."""

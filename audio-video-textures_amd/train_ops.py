@@ -37,6 +37,7 @@ _PLANES_HIP = 1     # weight planes by csrc/stem_train.hip's two kernels (0: tor
 _STEM_PATCH = 1     # the stems on the patch-resident kernels (0: conv_x3 + wgrad slices)
 _FORK = 1           # the shortcut's gradient summed in the a-convolution's input-gradient epilogue
 _EPI_STATS = 1      # BatchNorm forward statistics on the producing convolution's epilogue (round 5: no statistics pass over its output)
+_EPI_BWD = 1        # BatchNorm backward statistics on the epilogue of the consuming convolution's input-gradient launch (round 5)
 
 
 def set_conv_mode(mode):
@@ -62,7 +63,7 @@ def invalidate_weight_cache():
 # per-process launch counters of the hand-written training kernels (tests assert that the default path really runs them)
 CALLS = {"conv_fwd_x3": 0, "dgrad_x3": 0, "dgrad_strided_x3": 0, "wgrad_x3": 0, "wgrad_stem_x3": 0, "bn_fwd": 0, "bn_bwd": 0,
          "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0, "maxpool_hip": 0, "pw_f32": 0,
-         "bn_fwd_pre": 0}
+         "bn_fwd_pre": 0, "bn_bwd_pre": 0, "dgrad_bwdstats": 0}
 
 
 def _p(t):
@@ -196,6 +197,21 @@ def join_channels(a, b):
     return torch.cat([a, b], 1)
 
 
+class _BnHandle:
+    """What the input-gradient launch of the convolution that consumes a fused BatchNorm's output needs to know about it (the
+    tensors are the ones the BatchNorm's own backward keeps: no extra memory).  Travels as `y._avt_bn` on the BatchNorm's output."""
+    __slots__ = ("x", "mask", "weight", "bias", "mean", "invstd", "relu", "groups", "has_res", "c")
+
+    def __init__(self, x, mask, weight, bias, mean, invstd, relu, groups, has_res):
+        self.x, self.mask, self.weight, self.bias, self.mean, self.invstd = x, mask, weight, bias, mean, invstd
+        self.relu, self.groups, self.has_res, self.c = bool(relu), int(groups), bool(has_res), x.shape[1]
+
+
+_LAST_BN = None   # the handle of the last _BNAct.forward, for bn_act to tag its output with
+_BWD_STATS = {}   # data_ptr of a masked output gradient -> (workspace, rows of partials, handle): written by the input-gradient
+#                   launch (_conv_backward), consumed by that BatchNorm's backward a moment later; emptied at the next forward
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, res, relu, momentum, eps, tracked=None, groups=1, cat=None, pre=None):
@@ -227,12 +243,33 @@ class _BNAct(torch.autograd.Function):
         ctx.has_res = res is not None
         ctx.relu = bool(relu)
         ctx.groups = groups
+        global _LAST_BN
+        if _BWD_STATS:
+            _BWD_STATS.clear()  # (left-overs of a backward pass whose BatchNorm did not pick them up)
+        ctx.handle = _LAST_BN = _BnHandle(x, mask, weight, bias, save_mean, save_invstd, relu, groups, res is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mask, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         m, c = _rows(x)
+        pre = _BWD_STATS.pop(dy.data_ptr(), None) if _BWD_STATS else None
+        # (valid only for the very tensor the launch wrote: autograd sums gradients that reach a tensor by several paths — into a
+        #  new tensor, or IN PLACE into one of them, which the version counter shows; a summed gradient takes the plain passes
+        #  below, where masking an already masked part again changes nothing)
+        if (pre is not None and pre[2] is ctx.handle and dy._version == pre[3] and dy.shape == x.shape and dy.dtype == torch.float32 and
+                dy.is_contiguous(memory_format=torch.channels_last_3d)):
+            # dy is ALREADY g = mask * dz, and its producer (the input-gradient launch of the convolution that consumed this
+            # BatchNorm's output) left the sums of g and g * xhat behind: finalize + apply; the shortcut's gradient is g itself
+            dx = torch.empty_like(x)
+            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+            CALLS["bn_bwd"] += 1
+            CALLS["bn_bwd_pre"] += 1
+            _lib.check(_lib.lib().avt_bn_train_bwd_pre(_p(dy), _p(x), m, c, _p(weight), _p(save_mean), _p(save_invstd), ctx.groups,
+                                                       _p(pre[0]), pre[0].numel(), int(pre[1]), _p(dx), _p(dgamma), _p(dbeta), _stream()),
+                       "avt_bn_train_bwd_pre")
+            return dx, dgamma, dbeta, None, None, (dy if ctx.has_res else None), None, None, None, None, None, None, None
         ld_dy = _row_ld(dy)  # a slice of a concatenation's gradient is read in place (rows with a pitch)
         if ld_dy is None:
             dy, ld_dy = dy.contiguous(memory_format=torch.channels_last_3d), c
@@ -293,6 +330,10 @@ def bn_act(x, bn, res=None, relu=True, cat_extra=0, cat_into=None):
                      None if pre is None else pre[:2])
     if cat is not None:
         y._avt_cat = cat
+    global _LAST_BN
+    if _LAST_BN is not None and _EPI_BWD and cat is None:
+        y._avt_bn = _LAST_BN  # (the convolution that consumes y hands it to its input-gradient launch: conv3d / conv3d_fork)
+    _LAST_BN = None
     return y
 
 
@@ -529,7 +570,11 @@ _LAST_STATS = None  # (output data_ptr, workspace, rows of partials per group, g
 #                     BatchNorm statistics behind: handed from inside the autograd Function to conv3d(), which tags the output
 
 
-def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=None, group=None, stats=0):
+def _bwd_bn_args(h):
+    return (h.x, h.mean, h.invstd, h.weight, None if h.mask is not None else h.bias, h.mask, h.relu)
+
+
+def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=None, group=None, stats=0, bwd_bn=None):
     """x [B, Cin, T, H, W] channels-last fp32 -> [B, Cout, To, Ho, Wo] channels-last fp32 (+ add, same shape, in the epilogue).
     stats = n > 0: the output feeds a train-mode BatchNorm of n replica groups — the kernel's epilogue leaves its statistics'
     partial sums (ops.conv3d_igemm_x3_f32_stats / ops.pw_x3_f32_stats; recorded in _LAST_STATS)."""
@@ -539,6 +584,31 @@ def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=No
     od = [(n + 2 * p - k) // s_ + 1 for n, p, k, s_ in zip((t, h, w), pad, kernel, stride)]
     y = torch.empty((b, cout, od[0], od[1], od[2]), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
     stats = int(stats) if (stats and add is None and (cout & (cout - 1)) == 0 and cout >= 8 and b % int(stats) == 0) else 0
+    if bwd_bn is not None:
+        # an input gradient that is the output gradient of the BatchNorm `bwd_bn` (a _BnHandle): masked on the way out, that
+        # BatchNorm's backward statistics summed in the epilogue (ops.conv3d_igemm_x3_f32_bwdstats / ops.pw_x3_f32_bwdstats; the
+        # 256 x 256 tile does not: st is None, the plain launch below runs)
+        st = None
+        addr = None if add is None else add.permute(0, 2, 3, 4, 1)
+        if group is not None:
+            g, gk, rg = group
+            st = ops.conv3d_igemm_x3_f32_bwdstats(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], y.permute(0, 2, 3, 4, 1),
+                                                  _ktab(g * cin, gk, h, w // g, g * cin, x.device), (b, t, h, w // g), g * cin, g * cout, gk,
+                                                  (pad[0], pad[1], rg), plane_dtype, _bwd_bn_args(bwd_bn), bwd_bn.groups, cout, add=addr)
+        elif (_PW_F32 and tuple(kernel) == (1, 1, 1) and tuple(pad) == (0, 0, 0) and x.numel() // cin < (1 << 31) - 16 and
+              ops.pw_x3_f32_supported(cin, cout)):
+            st = ops.pw_x3_f32_bwdstats(x.permute(0, 2, 3, 4, 1), cin, planes[0], planes[1], y.permute(0, 2, 3, 4, 1), cout, plane_dtype,
+                                        _bwd_bn_args(bwd_bn), bwd_bn.groups, add=addr)
+            if st is not None:
+                CALLS["pw_f32"] += 1
+        else:
+            st = ops.conv3d_igemm_x3_f32_bwdstats(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], y.permute(0, 2, 3, 4, 1),
+                                                  _ktab(cin, kernel, h, w, cin, x.device), (b, t, h, w), cin, cout, kernel, pad, plane_dtype,
+                                                  _bwd_bn_args(bwd_bn), bwd_bn.groups, cout, add=addr)
+        if st is not None:
+            CALLS["dgrad_bwdstats"] += 1
+            _BWD_STATS[y.data_ptr()] = (st[0], st[1], bwd_bn, y._version)
+            return y
     if group is not None:  # (g, grouped kernel, rg): the same memory as [.., w / g, g * C] rows, block-Toeplitz planes
         g, gk, rg = group
         if stats:
@@ -588,11 +658,12 @@ def _tag_stats(y):
 
 class _ConvX3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, stats=0):
+    def forward(ctx, x, weight, stride, padding, stats=0, bn_in=None):
         from . import ops
         cout, cin = weight.shape[0], weight.shape[1]
         kernel = tuple(weight.shape[2:])
         ctx.conf = (stride, padding, kernel, cin, cout)
+        ctx.bn_in = bn_in  # the fused BatchNorm whose output x is (a _BnHandle), or None: see _conv_backward
         xin = x
         if cin % 8:  # stem: [B, 3, T, H, W] -> 8 channels-last channels, the last 5 zero (weights padded to match)
             xin = torch.empty((x.shape[0], 8) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device, memory_format=torch.channels_last_3d)
@@ -609,7 +680,7 @@ class _ConvX3(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return _conv_backward(ctx, dy, None) + (None, None, None)
+        return _conv_backward(ctx, dy, None) + (None, None, None, None)
 
 
 def _conv_backward(ctx, dy, dalias):
@@ -670,12 +741,16 @@ def _conv_backward(ctx, dy, dalias):
         if (cin % 8 == 0 and stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(padding, kernel)) and
                 dy.numel() < (1 << 30) - 64):
             CALLS["dgrad_x3"] += 1
+            hb = getattr(ctx, "bn_in", None)  # x is a fused BatchNorm's output: dx is that BatchNorm's output gradient
+            if hb is not None and not (_EPI_BWD and hb.c == cin and tuple(hb.x.shape) == tuple(x.shape) and x.shape[0] % hb.groups == 0):
+                hb = None
             g = _group_factor(cout, cin, kernel, (1, 1, 1), padding, dy.shape[4])
             if g > 1:
                 planes, gk, rg = _grouped_planes(weight, g, True, ops.X3_BF16)
-                dx = _conv_x3_rows(dy, planes, ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias, group=(g, gk, rg))
+                dx = _conv_x3_rows(dy, planes, ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias, group=(g, gk, rg), bwd_bn=hb)
             else:
-                dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias)
+                dx = _conv_x3_rows(dy, _weight_planes(weight, True), ops.X3_BF16, cout, cin, kernel, (1, 1, 1), padding, add=dalias,
+                                   bwd_bn=hb)
         else:
             dx = _dgrad_strided(dy, weight, stride, padding, kernel, tuple(x.shape)) if (_DGRAD_S_X3 and cin % 8 == 0) else None
             if dx is not None:
@@ -777,15 +852,15 @@ class _ConvX3Fork(torch.autograd.Function):
     otherwise sum the two contributions to x with a separate elementwise pass (5.5 % of the step's device time)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, stats=0):
-        y = _ConvX3.forward(ctx, x, weight, stride, padding, stats)
+    def forward(ctx, x, weight, stride, padding, stats=0, bn_in=None):
+        y = _ConvX3.forward(ctx, x, weight, stride, padding, stats, bn_in)
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dalias):
         if dy is None:  # (the convolution's output was not used: only the alias carries a gradient)
-            return (dalias if ctx.needs_input_grad[0] else None), None, None, None, None
-        return _conv_backward(ctx, dy, dalias) + (None, None, None)
+            return (dalias if ctx.needs_input_grad[0] else None), None, None, None, None, None
+        return _conv_backward(ctx, dy, dalias) + (None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -991,7 +1066,8 @@ def conv3d_fork(x, conv, stats=None):
     if not conv_fusable(x, conv) or conv.in_channels % 8:
         return conv(x), x
     x = x.contiguous(memory_format=torch.channels_last_3d)
-    y, alias = _ConvX3Fork.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding), _stat_groups(x, stats))
+    y, alias = _ConvX3Fork.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding), _stat_groups(x, stats),
+                                 getattr(x, "_avt_bn", None) if _EPI_BWD else None)
     return _tag_stats(y), alias
 
 
@@ -1008,4 +1084,5 @@ def conv3d(x, conv, stats=None):
         pass  # (the stem's padded copy is built channels-last from any layout)
     else:
         x = x.contiguous(memory_format=torch.channels_last_3d)  # no-op inside the network; a clip handed over as NCDHW is transposed once
-    return _tag_stats(_ConvX3.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding), _stat_groups(x, stats)))
+    return _tag_stats(_ConvX3.apply(x, conv.weight, tuple(conv.stride), tuple(conv.padding), _stat_groups(x, stats),
+                                    getattr(x, "_avt_bn", None) if _EPI_BWD else None))

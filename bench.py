@@ -441,6 +441,7 @@ def train_bench(args, rank, world, dev):
 
     from avtex import train_ops
     train_ops._EPI_STATS = int(getattr(args, "train_epi_stats", 1))
+    train_ops._EPI_BWD = int(getattr(args, "train_epi_bwd", 1))
     grads = train_ops.MicroBatchGradients(model.parameters()) if args.grad_accumulator else None
 
     # --item-streams 2: consecutive items alternate between two streams; the forward of item k + 1 is ordered after the forward
@@ -619,6 +620,9 @@ def build_parser():
     ap.add_argument("--train-epi-stats", type=int, default=1, choices=[0, 1],
                     help="--mode train: BatchNorm forward statistics on the producing convolution's epilogue (1, the default) or by the "
                          "BatchNorm's own pass over its input (0: round 4's step, for A/Bs)")
+    ap.add_argument("--train-epi-bwd", type=int, default=1, choices=[0, 1],
+                    help="--mode train: BatchNorm backward statistics on the consuming convolution's input-gradient epilogue (1) or by the "
+                         "BatchNorm's own statistics pass (0: for A/Bs)")
     ap.add_argument("--train-pass-items", type=int, default=0,
                     help="--mode train: items per forward/backward pass (0 = all of the rank's items as one batch with per-item "
                          "BatchNorm groups; 1 = one pass per item, round 2's loop)")

@@ -537,6 +537,33 @@ int avt_conv3d_igemm_x3_f32_stats(const float* in, const void* wt_hi, const void
                                   const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,
                                   int st, int sh, int sw, int pt, int ph, int pw, int ldi, int ldo, int plane_dtype,
                                   void* stat_part, int groups, int stat_c, void* stream);
+/* BatchNorm BACKWARD statistics on the epilogue of an input-gradient launch (round 5).  The stride-1 input
+ * gradient of the convolution that CONSUMES a train-mode BatchNorm (+ ReLU)'s output computes that BatchNorm's output gradient dz;
+ * the BatchNorm's backward then read dz and its own input x twice each (statistics pass, apply pass).  avt_conv3d_igemm_x3_f32_bwdstats
+ * = avt_conv3d_igemm_x3_f32 (stride 1; `add` allowed: the shortcut's gradient, train_ops.conv3d_fork) whose epilogue reads the
+ * BatchNorm's input rows bn_x [M, cout] (the geometry of the output), rebuilds the ReLU mask — bn_mask: the forward's 4 bits per
+ * float4 chunk when the BatchNorm had a shortcut; else recomputed as (x - mean) * (invstd * gamma) + beta > 0, the forward's own
+ * expression — stores g = mask * (dz + add) instead of dz, and leaves the per-tile sums of g and g * xhat in stat_part (layout,
+ * groups and stat_c as in avt_conv3d_igemm_x3_f32_stats).  avt_bn_train_bwd_pre finishes the BatchNorm's backward from g and those
+ * rows: finalize + apply, no statistics pass, and the shortcut's gradient IS g (nothing written for it).  bf16 planes; layers of the
+ * 128-row tile (avt_conv3d_igemm_x3_f32_bwdstats_rows = rows of partials per group, -1 elsewhere). */
+int avt_conv3d_igemm_x3_f32_bwdstats_rows(int cout, int k, int64_t m, int groups);
+int avt_conv3d_igemm_x3_f32_bwdstats(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
+                                     float* out, const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt,
+                                     int kh, int kw, int pt, int ph, int pw, int ldi, int ldo, int lda, int plane_dtype,
+                                     const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                     const float* bn_beta, const void* bn_mask, int relu, void* stat_part, int groups, int stat_c,
+                                     void* stream);
+/* ... and its streaming pointwise counterpart (csrc/pw_x3.hip; rows of the partials as avt_pw_x3_f32_stats: one per wave and group;
+ * output rows contiguous: ldy == n) */
+int avt_pw_x3_f32_bwdstats_rows(int k, int n, int64_t m, int groups);
+int avt_pw_x3_f32_bwdstats(const float* x, int ldx, int k, const void* w_hi, const void* w_lo, const float* add, int lda, float* y,
+                           int ldy, int n, int64_t m, int plane_dtype, const float* bn_x, const float* bn_mean,
+                           const float* bn_invstd, const float* bn_gamma, const float* bn_beta, const void* bn_mask, int relu,
+                           void* stat_part, int groups, void* stream);
+int avt_bn_train_bwd_pre(const float* g, const float* x, int64_t m, int c, const float* gamma, const float* save_mean,
+                         const float* save_invstd, int groups, void* ws, int64_t ws_size, int pre_rows, float* dx, float* dgamma,
+                         float* dbeta, void* stream);
 /* The streaming pointwise counterpart (csrc/pw_x3.hip): avt_pw_x3_f32 without an add operand over `groups` equal slabs of the m rows
  * (blockIdx.y = group), every wave leaving ONE row of partials — the sums over all the 16-row tiles it stored, taken column-wise
  * through a per-wave LDS block (fp32 over the 16 rows of a tile, fp64 across tiles).  n must be a power of two (the BatchNorm's

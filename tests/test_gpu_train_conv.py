@@ -558,3 +558,104 @@ def test_batchnorm_statistics_on_the_convolution_epilogue(cin, cout, kernel, str
         err = float((a[k] - e[k]).norm() / e[k].norm().clamp_min(1e-20))
         assert err < 3e-6, (name, err)
     assert float((a[1] - e[1]).abs().max()) < 2e-5 * float(e[1].abs().max())
+
+
+@pytest.mark.parametrize("c,cout,kernel,pad,dims,groups,res", [
+    (64, 64, (1, 3, 3), (0, 1, 1), (4, 2, 14, 14), 2, False),     # a_bn -> b: mask recomputed from x; <128,64,64> tile, short tiles
+    (128, 32, (3, 1, 1), (1, 0, 0), (6, 4, 10, 10), 3, True),     # c_bn (+ shortcut: saved mask bits) -> the next block's a; <128,128,64>
+    (8, 8, (1, 3, 3), (0, 1, 1), (4, 4, 12, 16), 2, False),       # pixel-grouped input gradient: columns fold into channels
+    (32, 16, (3, 1, 1), (1, 0, 0), (2, 8, 8, 8), 1, True),        # grouped temporal layer, one group, mask bits
+    (512, 128, (1, 1, 1), (0, 0, 0), (4, 2, 14, 14), 2, False),   # b_bn -> c with K = 512: a pointwise layer on the general tile
+    (64, 64, (1, 3, 3), (0, 1, 1), (2, 8, 56, 56), 2, True),      # 196 tiles per group: pre-reduced partial rows
+    (256, 64, (1, 1, 1), (0, 0, 0), (4, 2, 14, 14), 2, True),     # the streaming pointwise kernel <2, 16> in two halves, mask bits, + shortcut add
+    (512, 128, (1, 1, 1), (0, 0, 0), (6, 1, 7, 7), 3, True),      # <4, 16>: two channel chunks, 32-wide passes, 49 rows per group
+    (64, 256, (1, 1, 1), (0, 0, 0), (4, 2, 14, 14), 2, False),    # b_bn -> c (K = 256 -> N = 64: <8, 4>), mask recomputed
+    (32, 8, (1, 1, 1), (0, 0, 0), (4, 4, 12, 12), 4, True),       # <1, 2>
+    (256, 64, (1, 1, 1), (0, 0, 0), (2, 8, 56, 56), 2, True),     # 1568 tiles per group, a row of partials per wave
+])
+def test_batchnorm_backward_statistics_on_the_input_gradient_epilogue(c, cout, kernel, pad, dims, groups, res):
+    """y = bn_act(x, bn[, res]) -> conv(y).  The convolution's stride-1 input-gradient launch masks its result with
+    the BatchNorm's ReLU mask and sums the BatchNorm's backward statistics in its epilogue; the BatchNorm's backward then runs
+    finalize + apply only (CALLS['bn_bwd_pre']) and hands the masked gradient itself to the shortcut.  Everything equal to the
+    three-pass path to rounding: dx, d(shortcut), dgamma, dbeta, and the convolution's own dW."""
+    import torch.nn as nn
+
+    from avtex import train_ops
+
+    dev = "cuda:0"
+    torch.manual_seed(c + cout)
+    b, t, h, w = dims
+    x0 = (torch.randn(b, c, t, h, w, device=dev) * 1.5 + 0.4).contiguous(memory_format=torch.channels_last_3d)
+    r0 = torch.randn(b, c, t, h, w, device=dev).contiguous(memory_format=torch.channels_last_3d) if res else None
+    gy = torch.randn(b, cout, t, h, w, device=dev).contiguous(memory_format=torch.channels_last_3d)
+    ga = torch.randn(b, c, t, h, w, device=dev).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(epi):
+        torch.manual_seed(7)
+        conv = nn.Conv3d(c, cout, kernel, padding=pad, bias=False).to(dev).to(memory_format=torch.channels_last_3d).train()
+        bn = nn.BatchNorm3d(c).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if res else None
+        keep, train_ops._EPI_BWD = train_ops._EPI_BWD, epi
+        for k in train_ops.CALLS:
+            train_ops.CALLS[k] = 0
+        try:
+            with train_ops.bn_replicas(groups):
+                y = train_ops.bn_act(x, bn, res=r, relu=True)
+                if res:  # the block shape: the consumer is a fork whose alias (the next shortcut) carries a gradient of its own,
+                    z, alias = train_ops.conv3d_fork(y, conv)  # summed into the input gradient inside the launch (`add`)
+                    loss = (z * gy).sum() + (alias * ga).sum()
+                else:
+                    loss = (train_ops.conv3d(y, conv) * gy).sum()
+            loss.backward()
+        finally:
+            train_ops._EPI_BWD = keep
+        return (x.grad, None if r is None else r.grad, bn.weight.grad, bn.bias.grad, conv.weight.grad, dict(train_ops.CALLS))
+
+    a, e = run(1), run(0)
+    assert a[5]["bn_bwd_pre"] == 1 and a[5]["dgrad_bwdstats"] == 1 and e[5]["bn_bwd_pre"] == 0 and e[5]["dgrad_bwdstats"] == 0
+    for k, name in ((0, "dx"), (1, "dres"), (2, "dgamma"), (3, "dbeta"), (4, "dw")):
+        if a[k] is None:
+            assert e[k] is None
+            continue
+        err = float((a[k] - e[k]).norm() / e[k].norm().clamp_min(1e-20))
+        assert err < 5e-6, (name, err)
+    if res:  # the shortcut's gradient is the masked gradient itself: bit for bit the three-pass path's
+        assert torch.equal(a[1], e[1])
+
+
+def test_summed_gradients_do_not_take_the_fused_backward_statistics():
+    """The BatchNorm output feeds TWO convolutions: autograd sums their input gradients (possibly in place into the first, masked
+    one) — the sum must go through the plain backward passes, and come out right."""
+    import torch.nn as nn
+
+    from avtex import train_ops
+
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    x0 = (torch.randn(4, 64, 2, 14, 14, device=dev) + 0.3).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(epi):
+        torch.manual_seed(7)
+        c1 = nn.Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1), bias=False).to(dev).to(memory_format=torch.channels_last_3d).train()
+        c2 = nn.Conv3d(64, 32, (3, 1, 1), padding=(1, 0, 0), bias=False).to(dev).to(memory_format=torch.channels_last_3d).train()
+        bn = nn.BatchNorm3d(64).to(dev).train()
+        x = x0.clone().requires_grad_(True)
+        keep, train_ops._EPI_BWD = train_ops._EPI_BWD, epi
+        for k in train_ops.CALLS:
+            train_ops.CALLS[k] = 0
+        try:
+            with train_ops.bn_replicas(2):
+                y = train_ops.bn_act(x, bn, relu=True)
+                loss = train_ops.conv3d(y, c1).square().sum() + train_ops.conv3d(y, c2).square().sum()
+            loss.backward()
+        finally:
+            train_ops._EPI_BWD = keep
+        return x.grad, bn.weight.grad, dict(train_ops.CALLS)
+
+    a, e = run(1), run(0)
+    assert a[2]["bn_bwd_pre"] == 0 and a[2]["dgrad_bwdstats"] == 2  # both launches masked their part; the sum took the plain passes
+    assert float((a[0] - e[0]).norm() / e[0].norm()) < 5e-6 and float((a[1] - e[1]).norm() / e[1].norm()) < 5e-6
