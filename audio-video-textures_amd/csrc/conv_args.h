@@ -107,13 +107,18 @@ __device__ __forceinline__ void bst_load(const ConvArgs& a, int group, int n, Bs
   }
 }
 // x[8] = dz of (row m, columns n ..): -> g in place; s / q += g, g * (x - mean).  xv = the BatchNorm input's octet, bits = its two mask nibbles
+// (The launch-uniform choices — no activation / saved mask bits / recomputed mask — are folded into the OPERANDS of one data-flow select
+//  per element.  Written as `if (relu) keep = mask ? bit : recomputed; g = keep ? x : 0`, hipcc 7.2 lowered the three-way uniform
+//  branch around a divergent select to "g = 0; if (keep) {}" — every gradient zeroed; found by tools/experimental/debug_bwdstats.py.)
 __device__ __forceinline__ void bst_apply(const ConvArgs& a, const BstCoef& k, const float* xv, unsigned bits, float* x, float* s, float* q) {
+  const bool by_bits = a.bst_relu != 0 && a.bst_mask != nullptr, by_x = a.bst_relu != 0 && a.bst_mask == nullptr;
+  const unsigned mbits = by_bits ? bits : 0xFFu;  // not masked by bits: all ones
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float xc = xv[e] - k.mu[e];
-    bool keep = true;
-    if (a.bst_relu) keep = a.bst_mask ? ((bits >> e) & 1u) != 0u : (xc * k.sc[e] + k.be[e] > 0.0f);
-    const float g = keep ? x[e] : 0.0f;
+    const float act = by_x ? xc * k.sc[e] + k.be[e] : 1.0f;  // not masked by the recomputed activation: positive
+    const float sel = (((mbits >> e) & 1u) != 0u && act > 0.0f) ? 1.0f : 0.0f;
+    const float g = sel != 0.0f ? x[e] : 0.0f;
     x[e] = g;
     s[e] += g;
     q[e] += g * xc;

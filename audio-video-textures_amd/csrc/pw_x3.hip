@@ -581,11 +581,14 @@ __global__ __launch_bounds__(PX_NW * 64) void pw_x3_f32_kernel(PfArgs a) {
                              bxb[jj].x - m1.x, bxb[jj].y - m1.y, bxb[jj].z - m1.z, bxb[jj].w - m1.w};
         const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float gg[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]}, vv[8];
+        // (uniform choices folded into the select's operands: see bst_apply in conv_args.h)
+        const bool by_bits = a.bst_relu != 0 && a.bst_mask != nullptr, by_x = a.bst_relu != 0 && a.bst_mask == nullptr;
+        const unsigned mbits = by_bits ? bbits[jj] : 0xFFu;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          bool keep = true;
-          if (a.bst_relu) keep = a.bst_mask ? ((bbits[jj] >> e) & 1u) != 0u : (xc[e] * sc[e] + be[e] > 0.0f);
-          gg[e] = keep ? gg[e] : 0.0f;
+          const float act = by_x ? xc[e] * sc[e] + be[e] : 1.0f;
+          const float sel = (((mbits >> e) & 1u) != 0u && act > 0.0f) ? 1.0f : 0.0f;
+          gg[e] = sel != 0.0f ? gg[e] : 0.0f;
           vv[e] = gg[e] * xc[e];
         }
         o0 = f32x4n{gg[0], gg[1], gg[2], gg[3]};

@@ -467,7 +467,7 @@ def conv3d_igemm_x3_f32_bwdstats(dy, wt_hi, wt_lo, out, ktab, dims, cin, cout, k
     _lib.check(_lib.lib().avt_conv3d_igemm_x3_f32_bwdstats(
         _p(dy), _p(wt_hi), _p(wt_lo), None, _p(add), _p(out), _p(ktab), int(b), int(t), int(h), int(w), int(cin), int(cout),
         *[int(v) for v in kernel], *[int(v) for v in pad], int(cin), int(cout), int(cout), int(plane_dtype), _p(bx), _p(mean), _p(invstd),
-        _p(gamma), _p(beta), _p(mask), 1 if relu else 0, _p(ws), int(groups), int(stat_c), _stream()), "avt_conv3d_igemm_x3_f32_bwdstats")
+        _p(gamma), _p(beta), _p(mask), int(relu), _p(ws), int(groups), int(stat_c), _stream()), "avt_conv3d_igemm_x3_f32_bwdstats")
     return ws, pre_rows
 
 
