@@ -78,6 +78,7 @@ SIGNATURES = {
     "avt_conv3d_igemm_x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 19 + [_vp],
     "avt_conv3d_igemm_x3_f32_ex": [_vp] * 6 + [C.c_int] * 21 + [_vp],
     "avt_conv3d_wgrad_x3_f32": [_vp, _vp, _vp] + [C.c_int] * 17 + [_vp],
+    "avt_wgrad_x3_set_xl": [C.c_int],
     "avt_conv3d_wgrad_x3_sub_f32": [_vp, _vp, _vp] + [C.c_int] * 22 + [_vp],
     "avt_interp_pack_pair_u8": [_vp, _vp, C.c_int, C.c_int, _f32p, _vp, _vp, _vp, C.c_int, _vp],
     "avt_avgpool2_x3": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp],

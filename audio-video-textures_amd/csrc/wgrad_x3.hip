@@ -24,6 +24,8 @@
 // of a longer filter (the fast stem's [5,7,7] = five [1,7,7] slices) is a sub-problem: explicit output extent, any pt, ldw.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "avt_common.h"
 #include "conv_args.h"
 
@@ -339,8 +341,285 @@ int launch(WgArgs& a, int s_count, hipStream_t st) {
   return avt::check_launch("avt_conv3d_wgrad_x3_f32");
 }
 
+
+// ---- the 256 x 128 tile (round 5) ---------------------------------------------------------------------------
+// What bounds the 128-wide tile is not one thing: without its global loads, its LDS stage or its MFMAs it ran 1.7-1.8 x faster
+// each (profiles/r03/probe_wgrad_phases_b120.log) — three phases that follow each other inside a workgroup (load -> barrier -> split
+// + ds_write -> barrier -> fragments + MFMAs) and overlap only through the CU's second workgroup.  Here they overlap inside ONE
+// workgroup of 8 waves: 32-position steps in TWO LDS stages (48 KB each); in step s a wave issues the global loads of step s + 2
+// (into the register set that step s's data left free), multiplies step s out of its stage, and between its two k-slices splits
+// and writes step s + 1's data — loaded during step s - 1 — into the other stage; one barrier per step, the position tables in a
+// ring of four decoded three steps ahead.  256 x 128 outputs per workgroup (8 waves as 4 x 2, 64 x 64 each, the 128-wide tile's
+// wave): 48 KB per 6.3 MFLOP instead of 64 KB.  Layers with >= 256 on the longer axis and >= 128 on the shorter, <= 28 taps.
+constexpr int XP = 32;                 // positions per step
+constexpr int XPL = XP * 256;          // one 128-channel plane of a stage: [32 positions][256 B]
+constexpr int XSTAGE = 6 * XPL;        // R0 hi | R0 lo | R1 hi | R1 lo | S hi | S lo
+constexpr int XTABS = 2 * XSTAGE;      // ytab [4][32], then xtab [4][32][kMaxTaps]
+
+__device__ __forceinline__ void put4x(char* base, int off, float4 v) {  // put4 with this tile's plane pitch
+  const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2));
+  const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.z, v.w}, bf16x2));
+  const float r0 = v.x - __builtin_bit_cast(float, h01 << 16), r1 = v.y - __builtin_bit_cast(float, h01 & 0xFFFF0000u);
+  const float r2 = v.z - __builtin_bit_cast(float, h23 << 16), r3 = v.w - __builtin_bit_cast(float, h23 & 0xFFFF0000u);
+  const uint32_t l01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+  const uint32_t l23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r2, r3}, bf16x2));
+  *reinterpret_cast<uint2*>(base + off) = make_uint2(h01, h23);
+  *reinterpret_cast<uint2*>(base + XPL + off) = make_uint2(l01, l23);
+}
+
+template <bool SWAP>
+__global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
+  constexpr int RQ = 4, SQ = 2;        // float4 loads per thread and step: 256 / 128 channels x 32 positions over 512 threads
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int* const ytab = reinterpret_cast<int*>(lds + XTABS);             // [4][32]
+  int* const xtab = ytab + 4 * XP;                                   // [4][32][tapcap]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;                             // 4 (R) x 2 (S) waves, 64 x 64 each
+  const int lr = lane & 31, lh = lane >> 5;
+
+  int b_ = avt::xcd_contiguous(blockIdx.x, gridDim.x);
+  const int ts = b_ % a.s_tiles; b_ /= a.s_tiles;
+  const int tr = b_ % a.r_tiles;
+  const int chunk = b_ / a.r_tiles;
+  const int r0 = tr * 256, s0 = ts * 128;
+  const int st0 = chunk * a.slabs_per_chunk;                         // (steps of 32 positions here)
+  const int st1 = min(a.nslab, st0 + a.slabs_per_chunk);
+  const int x0 = SWAP ? s0 : r0;
+
+  // this thread's pieces: R quad (tid & 63) of position (q * 8 + (tid >> 6)), S quad (tid & 31) of position (q * 16 + (tid >> 5));
+  // the x operand's (tap, ci) is the same for all of a thread's pieces
+  const int rcq = tid & 63, scq = tid & 31;
+  const int xe = x0 + 4 * (SWAP ? scq : rcq);
+  const int xtap = xe < a.E ? (int)fastdiv((uint32_t)xe, a.dCin) : -1;
+  const int xci = xe - xtap * a.Cin;
+  const int ych = (SWAP ? r0 + 4 * rcq : s0 + 4 * scq);              // the dy operand's first channel
+  const bool y_ok = ych < a.Cout;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto decode = [&](int step) {  // thread -> position tid & 31, taps (tid >> 5), + 16
+    const int slot = step & 3, p = tid & 31, m = step * XP + p;
+    const bool ok = m < a.M;
+    const int q1 = (int)fastdiv((uint32_t)(ok ? m : 0), a.dWo), wo = (ok ? m : 0) - q1 * a.Wo;
+    const int q2 = (int)fastdiv((uint32_t)q1, a.dHo), ho = q1 - q2 * a.Ho;
+    const int bb = (int)fastdiv((uint32_t)q2, a.dTo), to = q2 - bb * a.To;
+    if (tid < XP) ytab[slot * XP + p] = ok ? m * a.ldy : -1;
+    for (int tap = tid >> 5; tap < a.taps; tap += 16) {
+      const int t1 = (int)fastdiv((uint32_t)tap, a.dKW), dw_ = tap - t1 * a.KW;
+      const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
+      const int ti = to * a.st - a.pt + dt, hi = ho * a.sh - a.ph + dh, wi = wo * a.sw - a.pw + dw_;
+      const bool in = ok && (unsigned)ti < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      xtab[(slot * XP + p) * a.tapcap + tap] = in ? (((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx : -1;
+    }
+  };
+
+  float4 rq[2][RQ], sq[2][SQ];
+  unsigned rmask[2] = {0u, 0u}, smask[2] = {0u, 0u};
+  auto gload = [&](auto set_, int step) {  // all table reads first, then the loads, unconditional (see the 128-wide tile)
+    constexpr int SET = decltype(set_)::value;
+    const int slot = step & 3;
+    int rrow[RQ], srow[SQ];
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int p = q * 8 + (tid >> 6);
+      rrow[q] = SWAP ? ytab[slot * XP + p] : xtab[(slot * XP + p) * a.tapcap + (xtap < 0 ? 0 : xtap)];
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+      const int p = q * 16 + (tid >> 5);
+      srow[q] = SWAP ? xtab[(slot * XP + p) * a.tapcap + (xtap < 0 ? 0 : xtap)] : ytab[slot * XP + p];
+    }
+    rmask[SET] = smask[SET] = 0u;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const bool ok = rrow[q] >= 0 && (SWAP ? y_ok : xtap >= 0);
+      const int64_t off = (int64_t)rrow[q] + (SWAP ? ych : xci);
+      rmask[SET] |= ok ? 1u << q : 0u;
+      rq[SET][q] = *reinterpret_cast<const float4*>((SWAP ? a.dy : a.x) + (ok ? off : 0));
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+      const bool ok = srow[q] >= 0 && (SWAP ? xtap >= 0 : y_ok);
+      const int64_t off = (int64_t)srow[q] + (SWAP ? xci : ych);
+      smask[SET] |= ok ? 1u << q : 0u;
+      sq[SET][q] = *reinterpret_cast<const float4*>((SWAP ? a.x : a.dy) + (ok ? off : 0));
+    }
+  };
+  const int rsub = (rcq >> 5) * 2 * XPL, rc = rcq & 31;
+  auto lstore = [&](auto set_, char* stg) {
+    constexpr int SET = decltype(set_)::value;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int p = q * 8 + (tid >> 6);
+      put4x(stg + rsub, swz(p, rc >> 1) + 8 * (rc & 1), (rmask[SET] >> q) & 1u ? rq[SET][q] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+      const int p = q * 16 + (tid >> 5);
+      put4x(stg + 4 * XPL, swz(p, scq >> 1) + 8 * (scq & 1), (smask[SET] >> q) & 1u ? sq[SET][q] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  };
+  // transposed-read addresses inside a stage (k-slice 0; + 4096 per 16 positions): see the 128-wide tile
+  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  int raddr[2][2], saddr[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+      raddr[j][h2] = (wm >> 1) * 2 * XPL + swz(8 * (g >> 1) + 4 * h2 + tq, ((wm & 1) * 64 + j * 32 + 16 * (g & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+      saddr[i][h2] = 4 * XPL + swz(8 * (g >> 1) + 4 * h2 + tq, (wn * 64 + i * 32 + 16 * (g & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+  struct Frags {
+    i32x4 rh[2], rl[2], sh[2], sl[2];
+  };
+  auto fload = [&](Frags& f, const char* stg, int ks) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto frag = [&](int a0, int a1) {
+      const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(stg + a0)));
+      const uint2 v = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(stg + a1)));
+      return i32x4{(int)u.x, (int)u.y, (int)v.x, (int)v.y};
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f.rh[j] = frag(raddr[j][0] + 4096 * ks, raddr[j][1] + 4096 * ks);
+      f.rl[j] = frag(raddr[j][0] + XPL + 4096 * ks, raddr[j][1] + XPL + 4096 * ks);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f.sh[i] = frag(saddr[i][0] + 4096 * ks, saddr[i][1] + 4096 * ks);
+      f.sl[i] = frag(saddr[i][0] + XPL + 4096 * ks, saddr[i][1] + XPL + 4096 * ks);
+    }
+  };
+  auto fmul = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = mfma(f.sl[i], f.rh[j], acc[i][j]);  // small terms first
+        acc[i][j] = mfma(f.sh[i], f.rl[j], acc[i][j]);
+        acc[i][j] = mfma(f.sh[i], f.rh[j], acc[i][j]);
+      }
+  };
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  auto step = [&](auto par_, int s) {  // par = (s - st0) & 1: stage and register set of step s
+    constexpr int P = decltype(par_)::value;
+    char* cur = lds + P * XSTAGE;
+    char* nxt = lds + (P ^ 1) * XSTAGE;
+    __syncthreads();  // stage P is complete; the other stage's readers (step s - 1) are done; the table of step s + 2 is decoded
+    Frags f0, f1;
+    fload(f0, cur, 0);
+    fload(f1, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fmul(f0);  // (issued first: the table reads, address arithmetic and the split + ds_write below run under the matrix pipe)
+    if (s + 2 < st1) gload(std::integral_constant<int, P>{}, s + 2);
+    if (s + 3 < st1) decode(s + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    fmul(f1);
+    if (s + 1 < st1) lstore(std::integral_constant<int, P ^ 1>{}, nxt);  // step s + 1's data, requested during step s - 1
+  };
+
+  if (st0 < st1) {
+    decode(st0);
+    if (st0 + 1 < st1) decode(st0 + 1);
+    if (st0 + 2 < st1) decode(st0 + 2);
+    __syncthreads();
+    gload(S0{}, st0);
+    if (st0 + 1 < st1) gload(S1{}, st0 + 1);
+    lstore(S0{}, lds);
+  }
+  for (int s = st0; s < st1; s += 2) {
+    step(S0{}, s);
+    if (s + 1 < st1) step(S1{}, s + 1);
+  }
+
+  // D layout: column (lane & 31) = index on the R axis, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = index on the S axis
+  if constexpr (!SWAP) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = r0 + wm * 64 + j * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = s0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.ldw + e, acc[i][j][r]);
+        }
+      }
+  } else {  // lanes would walk co (rows 4 E bytes apart): through the LDS, one half of the R axis (128 co) at a time
+    constexpr int ES = 128 + 1;
+    float* const stage = reinterpret_cast<float*>(lds);
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if ((wm >> 1) == half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = (wm & 1) * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[col * ES + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[i][j][r];
+          }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 128 * 128; idx += 512) {
+        const int col = idx >> 7, el = idx & 127;
+        const int co = r0 + half * 128 + col, e = s0 + el;
+        if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.ldw + e, stage[col * ES + el]);
+      }
+    }
+  }
+}
+
+template <bool SWAP>
+int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
+  a.r_tiles = (r_count + 255) / 256;
+  a.s_tiles = (s_count + 127) / 128;
+  const int tiles = a.r_tiles * a.s_tiles;
+  a.nslab = (a.M + XP - 1) / XP;  // steps of 32 positions
+  int chunks = (512 + tiles - 1) / tiles;  // one workgroup per CU: two rounds' worth of work items
+  const int most = a.nslab / 32 > 1 ? a.nslab / 32 : 1;  // at least 32 steps each (the epilogue is 256 x 128 atomics)
+  if (chunks > most) chunks = most;
+  if (chunks < 1) chunks = 1;
+  a.slabs_per_chunk = (a.nslab + chunks - 1) / chunks;
+  a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
+  constexpr int lds_bytes = XTABS + 4 * XP * 4 + 4 * XP * kMaxTaps * 4;
+  static_assert(128 * 129 * 4 <= XTABS && lds_bytes <= 160 * 1024, "the swapped epilogue's staging and the whole layout fit");
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_xl_kernel<SWAP>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    avt::set_error("avt_conv3d_wgrad_x3_f32: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+    return AVT_ERR_LAUNCH;
+  }
+  const int64_t grid = (int64_t)tiles * a.nchunk;
+  AVT_REQUIRE(grid < (1ll << 31), "avt_conv3d_wgrad_x3_f32: grid too large");
+  hipLaunchKernelGGL((wgrad_x3_xl_kernel<SWAP>), dim3((unsigned)grid), dim3(512), lds_bytes, st, a);
+  return avt::check_launch("avt_conv3d_wgrad_x3_f32");
+}
+
+// which tile avt_conv3d_wgrad_x3_f32 launches for (longer axis, shorter axis, taps, positions): 1 = the 256 x 128 tile
+int g_wgrad_xl = 1;  // (avt_wgrad_x3_set_xl: A/B switch for tools and tests; the shipped default is on)
+// g_wgrad_xl: 1 = where it measured faster (profiles/r05/probe_wgrad_xl.log: the long-(tap, ci) layers with >= 256 output channels,
+// +2 ... +32 %; the swapped pointwise layers and the 128-channel ones are 1-9 % slower on it — their epilogue is twice the atomics per
+// flop / they have one S tile); 2 = every layer the tile can take (tests, probes); 0 = never
+static bool wgrad_xl_picked(bool swap, int r_count, int s_count, int taps, int m) {
+  if (!(r_count >= 256 && s_count >= 128 && taps <= kMaxTaps && m >= 64 * XP)) return false;
+  return g_wgrad_xl == 2 || (g_wgrad_xl == 1 && !swap && r_count >= 1024 && s_count >= 256);
+}
+
 template <bool SWAP>
 int dispatch(WgArgs& a, int r_count, int s_count, hipStream_t s) {
+  if (wgrad_xl_picked(SWAP, r_count, s_count, a.taps, a.M)) return launch_xl<SWAP>(a, r_count, s_count, s);
   a.r_tiles = (r_count + 127) / 128;
   if (s_count <= 32) return launch<32, SWAP>(a, s_count, s);
   if (s_count <= 64) return launch<64, SWAP>(a, s_count, s);
@@ -391,6 +670,13 @@ extern "C" int avt_conv3d_wgrad_x3_sub_f32(const float* dy, const float* x, floa
   // the longer axis — x's (tap, ci) or dy's co — takes the 128-wide side of the tile
   if (cout > a.E) return dispatch<true>(a, cout, a.E, s);
   return dispatch<false>(a, a.E, cout, s);
+}
+
+// 1 (default): the layers the 256 x 128 pipelined tile measured faster on take it; 2: every layer it can take; 0: none (A/Bs, tests)
+extern "C" int avt_wgrad_x3_set_xl(int on) {
+  const int was = g_wgrad_xl;
+  g_wgrad_xl = on < 0 ? 0 : (on > 2 ? 2 : on);
+  return was;
 }
 
 extern "C" int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,

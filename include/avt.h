@@ -593,6 +593,11 @@ int avt_conv3d_igemm_x3_f32_ex(const float* in, const void* wt_hi, const void* w
 int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
                             int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldx, int ldy,
                             void* stream);
+/* Tile choice of the weight gradient (round 5): layers with >= 256 on their longer axis ((tap, ci) or cout), >= 128 on the shorter and
+ * <= 28 taps run on a 256 x 128 tile whose global loads, bf16 split + LDS stage and MFMAs overlap inside one 8-wave workgroup (32-position
+ * steps, two LDS stages, loads two steps ahead).  avt_wgrad_x3_set_xl: 1 (default) = only where it measured faster (not swapped, >= 1024
+ * on the (tap, ci) axis, >= 256 output channels), 2 = every layer it can take (tests, probes), 0 = never.  -> the previous setting. */
+int avt_wgrad_x3_set_xl(int on);
 /* The general form of avt_conv3d_wgrad_x3_f32: input channels in multiples of 4 (the SlowFast stems' 3 channels travel as 4:
  * ldx may be wider than cin), up to 49 taps ([1,7,7]), an explicit output extent (to, ho, wo; 0 = the symmetric-padding
  * formula) and any pt / ph / pw — so one frame-tap slice of a longer filter (the fast stem's [5,7,7] = five [1,7,7] slices,

@@ -205,10 +205,18 @@ def test_stem_patch_path_follows_the_optimizer_and_can_be_switched_off():
     (24, 40, (3, 3, 3), (1, 2, 2), (1, 1, 1), (2, 3, 9, 11)),         # ragged everything, channel counts not powers of two
     (136, 264, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 9, 9)),        # more than one tile on both sides, swapped operands
     (264, 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 9, 9)),
+    # the 256 x 128 pipelined tile (>= 256 x 128 on the two axes, >= 2048 positions): both orientations, ragged tiles on both axes,
+    # a position count that is not a multiple of the 32-position step, strides, several chunks of steps
+    (64, 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 21, 19)),       # E = 576 (3 R tiles, the last ragged), cout 136 (2 S tiles), 2394 positions
+    (264, 520, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 2, 20, 20)),      # swapped: cout 520 on the long axis, E = 264
+    (128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 14, 14)),      # temporal taps, exact tiles
+    (136, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 57, 59)),      # strided, odd extents
+    (256, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 8, 28, 28)),      # 50 176 positions: many chunks of steps, atomics from all of them
 ])
 def test_weight_gradient_kernel_edges(cin, cout, kernel, stride, pad, dims):
-    from avtex import ops
+    from avtex import _lib, ops
     torch.manual_seed(cin)
+    _lib.lib().avt_wgrad_x3_set_xl(2)  # (every layer the 256 x 128 tile can take runs on it here; the default picks by measurement)
     b, t, h, w = dims
     x = torch.randn(b, cin, t, h, w, device=DEV)
     wgt = torch.randn(cout, cin, *kernel, device=DEV, requires_grad=True)
@@ -218,6 +226,7 @@ def test_weight_gradient_kernel_edges(cin, cout, kernel, stride, pad, dims):
     dw = torch.empty((cout,) + tuple(kernel) + (cin,), device=DEV)
     ops.conv3d_wgrad_x3_f32(gy.permute(0, 2, 3, 4, 1).contiguous(), x.permute(0, 2, 3, 4, 1).contiguous(), dw, (b, t, h, w), cin, cout,
                             kernel, stride, pad, cin, cout)
+    _lib.lib().avt_wgrad_x3_set_xl(1)
     exp = wgt.grad.permute(0, 2, 3, 4, 1)
     err = float((dw - exp).norm()) / float(exp.norm())
     assert err < 1e-4, err
