@@ -811,12 +811,12 @@ def main():
         del video, q_mod, t_mod
         torch.cuda.empty_cache()
         targs = argparse.Namespace(**vars(args))
-        targs.steps, targs.warmup, targs.train_profile = 3, 2, False  # (the second warm-up step is the first with a sized gradient arena)
+        targs.steps, targs.warmup, targs.train_profile = 6, 3, False  # (the second warm-up step is the first with a sized gradient arena)
         torch.backends.cudnn.benchmark = True
         tl = train_bench(targs, rank, world, dev)
         detail["train"] = tl
         out["train_clips_per_s"], out["train_ms_per_step"] = tl["value"], tl["ms_per_step"]
-        note("training leg (config 5, 3 timed steps) done")
+        note("training leg (config 5, 6 timed steps) done")
     emit(out, detail)
 
 

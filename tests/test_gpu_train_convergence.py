@@ -23,33 +23,46 @@ def _tool():
 
 def test_x3_training_tracks_fp32_and_its_checkpoint_evaluates(avt, dev, tmp_path):
     """40 optimizer steps of config 5 at size (8 items x 16 clips at 224^2, real SlowFast pair, per-item BatchNorm groups, SGD lr 0.1)
-    with the split-plane convolutions and 40 with MIOpen's fp32 ones from the same seed and the same batches: the first losses are
-    equal (same forward to 1e-3), the smoothed curves stay within 0.12 of each other and neither diverges.  Then the x3-trained pair
+    with the split-plane convolutions, held to the RECORDED curve of the same 40 steps on MIOpen's fp32 convolutions — same seed, same
+    video, same batches: profiles/r05/train_convergence.json, the first 40 of its 600 fp32 steps (running MIOpen's fp32 training
+    kernels inside the suite costs ~25 minutes of solver search: the long form is tools/train_convergence.py).  The first losses are
+    equal (same forward to 1e-3), the smoothed curves stay within 0.12 of each other, nothing diverges.  Then the x3-trained pair
     is saved with the reference's checkpoint keys, evaluated through `main.py -e --resume` (a frames list comes out), and held to
     the north_star contract ON ITS OWN WEIGHTS: f16x3 MFMA encoders vs the fp32 modules on the same frames — scores within 1e-3
-    (measured ~3e-5), identical survivors in every row and identical frames lists at th 0.0 and 0.3 — with the largest activation
-    a factor > 100 below the fp16 planes' clamp."""
+    (measured ~4e-6 after 600 steps), identical survivors in every row and identical frames lists at th 0.0 and 0.3 — with the
+    largest activation a factor > 100 below the fp16 planes' clamp."""
+    import json
+
     from avtex import synth, train_ops
 
     tc = _tool()
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05", "train_convergence.json")))
+    assert rec["config"]["lr"] == 0.1 and rec["config"]["init"] == "default" and "scene_len=24" in rec["config"]["video"]
+    ref = np.asarray(rec["runs"]["fp32"]["loss"][:40])
     args = SimpleNamespace(steps=40, lr=0.1, init="default", workdir=str(tmp_path))
     video = synth.structured_video(123, 1500, 128, 128, variety=1)
     keep_mode = train_ops.conv_mode()
     try:
         rx, model = tc.train_run("x3", args, dev, video, keep=True)
-        rf, _ = tc.train_run("fp32", args, dev, video)
     finally:
         train_ops.set_conv_mode(keep_mode)
-    assert rx["calls"].get("conv_fwd_x3", 0) > 0 and rx["calls"].get("bn_fwd_pre", 0) > 0  # the hand-written passes (and the fused statistics) ran
-    assert rf["calls"].get("conv_fwd_x3", 0) == 0                                           # ... and did not in the fp32 run
-    lx, lf = np.asarray(rx["loss"]), np.asarray(rf["loss"])
-    assert np.isfinite(lx).all() and np.isfinite(lf).all() and len(lx) == len(lf) == 40
-    assert abs(lx[0] - lf[0]) < 1e-3, (lx[0], lf[0])
-    ex, ef = np.asarray(rx["loss_ema"]), np.asarray(rf["loss_ema"])
+    assert rx["calls"].get("conv_fwd_x3", 0) > 0 and rx["calls"].get("bn_fwd_pre", 0) > 0 and rx["calls"].get("bn_bwd_pre", 0) > 0
+    lx = np.asarray(rx["loss"])
+    assert np.isfinite(lx).all() and len(lx) == 40
+    assert abs(lx[0] - ref[0]) < 1e-3, (lx[0], ref[0])
+
+    def ema(v):
+        out, e = [], None
+        for x in v:
+            e = x if e is None else 0.9 * e + 0.1 * x
+            out.append(e)
+        return np.asarray(out)
+
+    ex, ef = ema(lx), ema(ref)
     gap = float(np.abs(ex - ef)[5:].max())
-    print("CONVERGENCE40 gap %.4f  x3 %.4f -> %.4f  fp32 %.4f -> %.4f" % (gap, ex[0], ex[-1], ef[0], ef[-1]))
+    print("CONVERGENCE40 gap %.4f  x3 %.4f -> %.4f  recorded fp32 %.4f -> %.4f" % (gap, ex[0], ex[-1], ef[0], ef[-1]))
     assert gap < 0.12, gap
-    assert ex[-1] < np.log(15.0) * 1.05 and ef[-1] < np.log(15.0) * 1.05
+    assert ex[-1] < np.log(15.0) * 1.05
     out = tc.roundtrip(model, video, args, dev, str(tmp_path / "rt"))
     print("ROUNDTRIP", {k: v for k, v in out.items() if k != "cli_frames_head"})
     assert out["cli_frames"] >= 250  # -nvl 10 at 30 fps: at least 300 - W frames
