@@ -26,7 +26,7 @@ def test_x3_training_tracks_fp32_and_its_checkpoint_evaluates(avt, dev, tmp_path
     with the split-plane convolutions, held to the RECORDED curve of the same 40 steps on MIOpen's fp32 convolutions — same seed, same
     video, same batches: profiles/r05/train_convergence.json, the first 40 of its 600 fp32 steps (running MIOpen's fp32 training
     kernels inside the suite costs ~25 minutes of solver search: the long form is tools/train_convergence.py).  The first losses are
-    equal (same forward to 1e-3), the smoothed curves stay within 0.12 of each other, nothing diverges.  Then the x3-trained pair
+    equal (same forward to 1e-3), the smoothed curves stay within 0.05 of each other (measured 0.004), nothing diverges.  Then the x3-trained pair
     is saved with the reference's checkpoint keys, evaluated through `main.py -e --resume` (a frames list comes out), and held to
     the north_star contract ON ITS OWN WEIGHTS: f16x3 MFMA encoders vs the fp32 modules on the same frames — scores within 1e-3
     (measured ~4e-6 after 600 steps), identical survivors in every row and identical frames lists at th 0.0 and 0.3 — with the
@@ -61,7 +61,7 @@ def test_x3_training_tracks_fp32_and_its_checkpoint_evaluates(avt, dev, tmp_path
     ex, ef = ema(lx), ema(ref)
     gap = float(np.abs(ex - ef)[5:].max())
     print("CONVERGENCE40 gap %.4f  x3 %.4f -> %.4f  recorded fp32 %.4f -> %.4f" % (gap, ex[0], ex[-1], ef[0], ef[-1]))
-    assert gap < 0.12, gap
+    assert gap < 0.05, gap  # (measured 0.004)
     assert ex[-1] < np.log(15.0) * 1.05
     out = tc.roundtrip(model, video, args, dev, str(tmp_path / "rt"))
     print("ROUNDTRIP", {k: v for k, v in out.items() if k != "cli_frames_head"})

@@ -6,7 +6,13 @@ ROUNDED operands (the rounding is what the hardware would see; the accumulation 
 go through the same gate as tests/test_gpu_x3.py::test_contract_on_the_same_frames (agreement.compare_tables against the plain
 fp32 module on the same frames: max |dscore| < 1e-3, identical survivors on every row at th 0.0 and 0.3, 3/3 frames lists).
 The same emulation of f16x3 and bf16x3 (known: 2.4e-5 / 2.0e-4) calibrates it.
-usage: probe_f16f8_numerics.py [windows=256] [inputs=r04|r03]"""
+Round 5: the INT8 form of the same idea — hi x hi on the fp16 pipe, both cross terms on v_mfma_i32_32x32x32_i8
+(twice the fp16 rate) with the 8-bit operands scaled per (row, K-block) / (output channel, K-block): `f16i8_b<block>`; block = the
+number of consecutive input channels of one tap that share a scale (32 = one MFMA's K; 0 = the whole row / filter: one scale per
+position / output channel, the only form whose rescaling is free — a block's int32 partial sum has to be converted and scaled into
+the fp32 accumulator, 32 VALU operations per MFMA at block 32).  Emulated exactly: integer products of quantised operands times
+their scales = fp32 products of the DEQUANTISED operands.
+usage: probe_f16f8_numerics.py [windows=256] [inputs=r04|r03|trained[:steps]]"""
 import sys
 
 import numpy as np
@@ -26,7 +32,24 @@ dev = torch.device("cuda:0")
 W, S = 20, 4
 torch.backends.cudnn.benchmark = False
 
-if inputs == "r04":
+if inputs.startswith("trained"):  # the pair trained by the product's own config-5 step (tools/train_convergence.py), on ITS video
+    import importlib.util
+    import os
+    from types import SimpleNamespace
+
+    spec = importlib.util.spec_from_file_location("tc", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "train_convergence.py"))
+    tc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tc)
+    steps = int(inputs.split(":")[1]) if ":" in inputs else 300
+    video = synth.structured_video(123, max(1500, n * S + W), 128, 128, variety=1)
+    torch.backends.cudnn.benchmark = True
+    rec, model = tc.train_run("x3", SimpleNamespace(steps=steps, lr=0.1, init="default"), dev, video[:1500], keep=True)
+    torch.backends.cudnn.benchmark = False
+    print("trained %d steps: loss %.3f -> EMA %.3f" % (steps, rec["loss"][0], rec["loss_ema"][-1]), flush=True)
+    model = model.to(memory_format=torch.contiguous_format).eval()
+    q_mod, t_mod = model.q_encoder.float(), model.t_encoder.float()
+    video = video[: n * S + W]
+elif inputs == "r04":
     video = synth.structured_video(5, n * S + W, 128, 128, variety=1)
     torch.manual_seed(0)
     q_mod = synth.randomise_bn(SlowFast().eval(), 10, 2.0, 0.1).to(dev)
@@ -37,11 +60,12 @@ else:
     q_mod = synth.randomise_bn(SlowFast().eval(), 10, 0.5).to(dev)
     torch.manual_seed(1)
     t_mod = synth.randomise_bn(SlowFast().eval(), 11, 0.5).to(dev)
-cal = np.linspace(0, n - 1, 8).astype(np.int64) * S
-slow, fast = ops.clip_pack(video.to(dev), cal, W, out_hw=224, dtype=torch.float32)
-synth.calibrate_bn(q_mod, slow, fast)
-synth.calibrate_bn(t_mod, slow, fast)
-del slow, fast
+if not inputs.startswith("trained"):
+    cal = np.linspace(0, n - 1, 8).astype(np.int64) * S
+    slow, fast = ops.clip_pack(video.to(dev), cal, W, out_hw=224, dtype=torch.float32)
+    synth.calibrate_bn(q_mod, slow, fast)
+    synth.calibrate_bn(t_mod, slow, fast)
+    del slow, fast
 q_mod, t_mod = q_mod.eval(), t_mod.eval()
 
 MODE = [None]
@@ -65,6 +89,31 @@ def pow2_scale_for(x, top=256.0):
     return 2.0 ** np.floor(np.log2(top / m))
 
 
+def q8_blocks(a, block):
+    """int8 quantisation of a [N, C, ...] tensor along C in blocks of `block` channels (0: all of C), one real scale per (N, block,
+    position): max|block| / 127, round to nearest -> the DEQUANTISED tensor (what the integer product times the scales equals)."""
+    n_, c = a.shape[0], a.shape[1]
+    bs = c if (block <= 0 or block >= c) else block
+    if c % bs:
+        bs = c
+    v = a.reshape(n_, c // bs, bs, *a.shape[2:])
+    m = v.abs().amax(2, keepdim=True).clamp_min(1e-30)
+    sc = m / 127.0
+    return ((v / sc).round().clamp(-127, 127) * sc).reshape(a.shape)
+
+
+def q8_act(a, block):
+    """activations [B, C, T, H, W]: block 0 = one scale per POSITION over the whole receptive row is not expressible before the im2col, so
+    block 0 means one scale per (position, all C) — per tap of the row, i.e. still finer than per row; the pessimistic end is `f16i8_t`
+    (one scale per tensor)."""
+    return q8_blocks(a, block)
+
+
+def q8_w(wt, block):
+    """weights [Cout, Cin, kt, kh, kw]: scale per (cout, cin-block, tap); block 0 = per (cout, tap)."""
+    return q8_blocks(wt, block)
+
+
 def emulated_conv(self, x, w, b):
     mode = MODE[0]
     if mode is None:
@@ -86,6 +135,13 @@ def emulated_conv(self, x, w, b):
         y = y + conv(fp8(xl, pow2_scale_for(xl)), fp8(wh, pow2_scale_for(wh))) + conv(fp8(xh, pow2_scale_for(xh)), fp8(wl, pow2_scale_for(wl)))
     elif mode == "f16f8w":  # only the weight-side low plane in 8 bits (wl8 * xh fp16 would still be an fp16 pass: reference point)
         y = y + conv(xl, wh) + conv(xh, fp8(wl, pow2_scale_for(wl)))
+    elif mode.startswith("f16i8"):  # int8 cross terms; f16i8_b32 / _b256 / _b0 (per position and tap) / _t (one scale per tensor)
+        if mode.endswith("_t"):
+            qt = lambda a: (a / (a.abs().max().clamp_min(1e-30) / 127.0)).round().clamp(-127, 127) * (a.abs().max().clamp_min(1e-30) / 127.0)
+            y = y + conv(qt(xl), qt(wh)) + conv(qt(xh), qt(wl))
+        else:
+            blk = int(mode.split("_b")[1])
+            y = y + conv(q8_act(xl, blk), q8_w(wh, blk)) + conv(q8_act(xh, blk), q8_w(wl, blk))
     elif mode == "f16x2":   # no cross terms at all
         pass
     y = y / s.view(1, -1, 1, 1, 1)
@@ -108,7 +164,7 @@ def tables(mode):
 
 q32, t32 = tables(None)
 print("inputs %s, %d windows; reference = fp32 nn.Module (MIOpen)" % (inputs, n), flush=True)
-for mode in ("f16x3", "bf16x3", "f16f8", "f16f8w", "f16x2"):
+for mode in ("f16x3", "f16i8_b32", "f16i8_b256", "f16i8_b0", "f16i8_t", "f16f8", "f16x2"):
     qv, tv = tables(mode)
     r = agreement.compare_tables(qv, tv, q32, t32, 0.1, W, S)
     th = r["thresholds"]
