@@ -880,7 +880,7 @@ def baseline_metric():
 # the encoder streams run their batches back to back and are joined once per step (texture.TextureEngine.run_encoders(join=False))
 JOIN_EVERY_BATCH = False
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "pmc_fetch_write_summary.json")  # written by tools/gpu_profile_round.sh r04
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "pmc_fetch_write_summary.json")  # written by tools/gpu_profile_round.sh r05
 PMC_BATCH = 249  # the encoder batch tools/pmc_kernels.py launches at
 
 
@@ -926,7 +926,7 @@ def attach_pmc_traffic(kern, args, precision):
         sym = sym.replace(",bf16>", ",false>").replace(",f16>", ",true>").replace(" ", "")
         k["traffic"] = kb(sym)
         if k["traffic"]:
-            k["traffic_source"] = "profiles/r04/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
+            k["traffic_source"] = "profiles/r05/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
 
 
 def cpu_baseline(video, q_mod, t_mod, W, S, N, D, temp, args):
