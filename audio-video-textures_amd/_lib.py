@@ -24,6 +24,7 @@ SIGNATURES = {
                          C.c_int, _vp, _vp, C.c_int, _vp],
     "avt_l2norm_rows": [_vp, C.c_int, _vp, C.c_int, C.c_int64, C.c_float, _vp, _vp, _vp, _vp],
     "avt_sim_gemm_nt": [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, _vp, C.c_int64, _vp],
+    "avt_gemm_nt_x3_f32out": [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp],
     "avt_row_transition": [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_float,
                            C.c_float, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "avt_row_topk": [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int, _vp, _vp, _vp],

@@ -66,6 +66,8 @@ struct ConvArgs {
   uint16_t* out_lo;
   const float* wscale;  // per-output-channel power-of-two factor applied to the accumulator (fp16 planes: weights are stored
                         // pre-scaled into the fp16 normal range), or NULL
+  float odiv;           // x3 256 x 256 tile with fp32 output from plane inputs (avt_gemm_nt_x3_f32out): every result is DIVIDED by this
+                        // (the similarity's temperature: out = <q, t> / temp with one correctly rounded division), 0 = off
   int cf_ofs;           // x3 kernels: LDS byte offset of the tile's [bias BN | scale BN] floats (set by the launchers; filled in the
                         // prologue, read by the epilogue from LDS instead of one global load per accumulator group)
   // BatchNorm statistics on the epilogue (round 5; IO32 tiles, avt_conv3d_igemm_x3_f32_stats): the layer's output feeds a train-mode
@@ -247,6 +249,7 @@ inline int conv_args_fill(ConvArgs& a, const char* who, const void* in, const vo
   a.oH = remap ? out_h : 0;
   a.oW = remap ? out_w : 0;
   a.stat_part = nullptr;
+  a.odiv = 0.0f;
   a.stat_groups = a.stat_mg = a.stat_tpg = a.stat_c = 0;
   a.bst_x = a.bst_mean = a.bst_invstd = a.bst_gamma = a.bst_beta = nullptr;
   a.bst_mask = nullptr;

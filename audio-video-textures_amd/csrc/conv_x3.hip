@@ -506,7 +506,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 // registers (four 16-byte loads) under this step's MFMAs and splits them into the two planes on the way to the LDS after them;
 // the weight planes still arrive by LDS-DMA; ONE fragment set instead of two pays for the staging registers; fp32 epilogue
 // with the `add` operand.
-template <bool F16, bool IO32 = false>
+// OUT32 without IO32 (round 5): plane inputs by LDS-DMA, fp32 rows out, every result divided by a.odiv — the bf16x3 similarity
+// (avt_gemm_nt_x3_f32out: Q_hat / T_hat planes are "activations" / "weights" of a pointwise layer with K = D).
+template <bool F16, bool IO32 = false, bool OUT32 = IO32>
 __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   constexpr int BM = 256, BN = 256, NTHR = 512, KB = 32;  // K-step in elements
   constexpr int MT = 4, NT = 2;                            // 32 x 32 sub-tiles of a wave's 128 x 64
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   constexpr int EU = (SR * CPR) / NTHR;        // 4 chunks per thread and pass
   constexpr int EBUF = SR * ESTR;
   static_assert(2 * EBUF <= 2 * STG + kMaxTabSteps * 64, "two staging buffers fit the operand stages + the table area");
-  const bool has_res = !IO32 && a.res != nullptr;  // (IO32: `res` is an fp32 tensor added in the store loop)
+  const bool has_res = !OUT32 && a.res != nullptr;  // (IO32: `res` is an fp32 tensor added in the store loop)
   auto stage_slab = [&](auto half, int pass) {  // rows 64 pass .. + 63 = row tiles j = 2 half, 2 half + 1 of the waves wm = pass >> 1
     constexpr int H = decltype(half)::value;
     char* eb = lds + (pass & 1) * EBUF;
@@ -875,17 +877,23 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
           for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.1f * x[e]);
         }
         const int64_t o = (int64_t)out_row(a, m) * a.ldo + n;
-        if constexpr (IO32) {
-          if (a.res) {  // out = conv + add (train_ops.conv3d_fork): fp32 rows
+        if constexpr (OUT32) {
+          if (a.odiv != 0.0f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = __fdiv_rn(x[e], a.odiv);
+          }
+          if (IO32 && a.res) {  // out = conv + add (train_ops.conv3d_fork): fp32 rows
             const float4 q0 = __builtin_bit_cast(float4, rrh[u]), q1 = __builtin_bit_cast(float4, rrl[u]);
             x[0] += q0.x; x[1] += q0.y; x[2] += q0.z; x[3] += q0.w;
             x[4] += q1.x; x[5] += q1.y; x[6] += q1.z; x[7] += q1.w;
           }
-          if (a.stat_part) {  // (uniform)
+          if constexpr (IO32) {
+            if (a.stat_part) {  // (uniform)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              st_s[e] += x[e];
-              st_q[e] += x[e] * x[e];
+              for (int e = 0; e < 8; ++e) {
+                st_s[e] += x[e];
+                st_q[e] += x[e] * x[e];
+              }
             }
           }
           float* of = reinterpret_cast<float*>(a.out) + o;
@@ -920,7 +928,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_xl_kernel(ConvArgs a) {
   STAMP_END();
 }
 
-template <bool F16, bool IO32 = false>
+template <bool F16, bool IO32 = false, bool OUT32 = IO32>
 int launch_x3_xl(ConvArgs& a, hipStream_t st) {
   if (a.stat_part) a.stat_tpg = (a.stat_mg + 255) / 256;
   const int tiles_m = a.stat_part ? a.stat_groups * a.stat_tpg : (a.M + 255) / 256;
@@ -929,13 +937,13 @@ int launch_x3_xl(ConvArgs& a, hipStream_t st) {
   constexpr int lds_max = 2 * 4 * 256 * 64 + kMaxTabSteps * 64 + 2 * 256 * 4;
   const int lds_bytes = lds_max;  // (the epilogue's second staging buffer reaches into the table area; then bias | scale)
   a.cf_ofs = lds_max - 2 * 256 * 4;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16, IO32>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_xl_kernel<F16, IO32, OUT32>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_igemm_x3: hipFuncSetAttribute(%d B LDS): %s", lds_max, hipGetErrorString(e));
     return AVT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((conv_x3_xl_kernel<F16, IO32>), dim3((unsigned)a.nblk), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_x3_xl_kernel<F16, IO32, OUT32>), dim3((unsigned)a.nblk), dim3(512), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_igemm_x3");
 }
 
@@ -1034,6 +1042,32 @@ extern "C" int avt_conv3d_igemm_x3_wblk(const void* in_hi, const void* in_lo, co
   return igemm_x3_impl(in_hi, in_lo, wt_hi, wt_lo, bias, res_hi, res_lo, out_hi, out_lo, ktab, batch, t, h, w, cin, cout, kt, kh, kw,
                        st, sh, sw, pt, ph, pw, to, ho, wo, ldi, ldo, ldr, relu, out_row_stride, out_h, out_w, plane_dtype, wscale,
                        stream, 1);
+}
+
+// out[m][n] = (sum_k A[m][k] * B[n][k]) / divisor with A, B as plane pairs and an fp32 result: the 256 x 256 LDS-DMA tile as a plain
+// NT GEMM (see include/avt.h) — the bf16x3 similarity Q_hat T_hat^T / temp.  ktab = avt_conv3d_ktab(k, 1, 1, 1, 1, m, lda).
+extern "C" int avt_gemm_nt_x3_f32out(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, float* out, int64_t ldo,
+                                     int m, int n, int k, float divisor, const int32_t* ktab, int plane_dtype, void* stream) {
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_gemm_nt_x3_f32out: plane_dtype must be 0 (bf16) or 1 (fp16)");
+  AVT_REQUIRE(a_lo && b_lo && avt::aligned16(a_lo) && avt::aligned16(b_lo) && divisor != 0.0f, "avt_gemm_nt_x3_f32out: both planes, divisor != 0");
+  AVT_REQUIRE(m > 0 && n % 256 == 0 && k % 32 == 0 && k >= 256 && k <= kMaxTabSteps * 64 && ldo >= n && ldo % 4 == 0 && ldo < (1ll << 31),
+              "avt_gemm_nt_x3_f32out: n %% 256 == 0, 256 <= k <= %d in multiples of 32 (got m %d n %d k %d)", kMaxTabSteps * 64, m, n, k);
+  ConvArgs a;
+  const int rc = conv_args_fill(a, "avt_gemm_nt_x3_f32out", a_hi, b_hi, nullptr, nullptr, out, ktab, 1, 1, 1, m, k, n, 1, 1, 1, 1, 1, 1, 0, 0, 0,
+                                0, 0, 0, lda, 8 * (int)((ldo + 7) / 8), 0, 0, 1, 0, 0);
+  if (rc != AVT_OK) return rc;
+  a.ldo = (int)ldo;
+  a.in_lo = static_cast<const uint16_t*>(a_lo);
+  a.wt_lo = static_cast<const uint16_t*>(b_lo);
+  a.res_lo = nullptr;
+  a.out_lo = nullptr;
+  a.wscale = nullptr;
+  a.wfrag = nullptr;
+  a.nup = 0;
+  a.wblk = 0;
+  a.odiv = divisor;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, false, true>(a, s) : launch_x3_xl<false, false, true>(a, s);
 }
 
 // fp32 rows in, fp32 rows out, split-plane arithmetic in between (the IO32 form of the kernel): see include/avt.h

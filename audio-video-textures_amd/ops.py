@@ -246,9 +246,38 @@ def l2norm_rows(x0, x1=None, eps=1e-12, want_f32=True, want_split=False):
 
 
 # ---- similarity -----------------------------------------------------------------
+SIM_XL = True   # the bf16x3 similarity on the encoder's 256 x 256 LDS-DMA tile where the shape allows (avt_gemm_nt_x3_f32out)
+_GEMM_TABS = {}
+
+
+def _gemm_ktab(k, lda, device):
+    key = (int(k), int(lda), str(device))
+    tab = _GEMM_TABS.get(key)
+    if tab is None:
+        tab = torch.from_numpy(conv3d_ktab(int(k), (1, 1, 1), 1, 1, int(lda))).to(device)
+        _GEMM_TABS[key] = tab
+    return tab
+
+
 def sim_gemm_nt(q, t, temp, precision="f32", q_lo=None, t_lo=None, out=None):
     """out[i,j] = <q_i, t_j> / temp.  precision: "f32" (exact, canonical) | "bf16" | "bf16x3"."""
     prec = _PREC[precision]
+    if (SIM_XL and prec == SIM_BF16X3 and q_lo is not None and t_lo is not None and q.dim() == 2 and t.shape[0] % 256 == 0 and
+            q.shape[1] % 32 == 0 and 256 <= q.shape[1] <= 8192 and (SIM_XL == "always" or -(-q.shape[0] // 256) * (t.shape[0] // 256) >= 192) and
+            (out is None or out.stride(0) % 4 == 0)):
+        # (>= 192 tiles: three quarters of a round of the 256 CUs — 4096^2 is exactly one round, the config-4 shard two; at 2048^2 (64
+        #  tiles) the 128 x 128 tile's 256 workgroups win: tools/probe_sim_xl.py)
+        for name, v in (("q", q), ("q_lo", q_lo), ("t", t), ("t_lo", t_lo)):
+            _dev(v, name, torch.bfloat16)
+        nq, d = q.shape
+        nt = t.shape[0]
+        if out is None:
+            out = torch.empty((nq, nt), dtype=torch.float32, device=q.device)
+        else:
+            _dev(out, "out", torch.float32, contiguous=False)
+        _lib.check(_lib.lib().avt_gemm_nt_x3_f32out(_p(q), _p(q_lo), d, _p(t), _p(t_lo), _p(out), out.stride(0), nq, nt, d, float(temp),
+                                                    _p(_gemm_ktab(d, d, q.device)), X3_BF16, _stream()), "avt_gemm_nt_x3_f32out")
+        return out
     want = torch.float32 if prec == SIM_F32 else torch.bfloat16
     _dev(q, "q", want)
     _dev(t, "t", want)

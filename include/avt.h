@@ -131,6 +131,14 @@ int avt_l2norm_rows(const float* x0, int d0, const float* x1, int d1, int64_t n,
 int avt_sim_gemm_nt(const void* q, const void* q_lo, const void* t,
                     const void* t_lo, int64_t nq, int64_t nt, int d, float temp,
                     int precision, float* out, int64_t ldo, void* stream);
+/* out[m][n] = (sum_k A[m][k] * B[n][k]) / divisor with both operands as split-plane pairs (hi + lo, bf16 or fp16) and an fp32 result:
+ * the contract-grade encoder's 256 x 256 LDS-DMA tile (csrc/conv_x3.hip: operands staged by `buffer_load ... lds` into two 64 KB LDS
+ * stages, three MFMA passes per product, one correctly rounded division on the way out) as a plain NT GEMM.  Round 5: the bf16x3
+ * similarity Q_hat T_hat^T / temp (models/models.py:416-417) runs on it when n % 256 == 0 and 256 <= k <= 8192 (k % 32 == 0) —
+ * 0.35 -> 0.5 of the 833 TFLOP/s x3 roof; avt_sim_gemm_nt's own bf16x3 tile stays for every other shape.  ktab: the K-chunk table of
+ * avt_conv3d_ktab(k, 1, 1, 1, 1, m, lda). */
+int avt_gemm_nt_x3_f32out(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, float* out, int64_t ldo,
+                          int m, int n, int k, float divisor, const int32_t* ktab, int plane_dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * row_transition — replaces the CPU row post-process of validate.py:524-572.

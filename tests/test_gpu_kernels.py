@@ -66,7 +66,8 @@ def test_sim_f32_identity_asymmetric(avt, dev):
 
 
 @pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-5), ("bf16", 4e-3)])
-@pytest.mark.parametrize("nq,nt,d", [(256, 384, 2304), (70, 45, 200), (9, 5, 13)])
+@pytest.mark.parametrize("nq,nt,d", [(256, 384, 2304), (70, 45, 200), (9, 5, 13),
+                                     (300, 512, 2304), (1024, 768, 256)])  # (bf16x3: the 256 x 256 LDS-DMA tile — ragged rows, the shortest K)
 def test_sim_bf16_modes(avt, dev, mode, tol, nq, nt, d):
     """bf16 MFMA modes: vs their own fp64 emulation (tight) and vs the canonical fp32 scores.
     Score tolerance (cos/0.1): bf16x3 2e-5 << the 1e-3 contract; plain bf16 4e-3 (not used for index decisions)."""
@@ -81,6 +82,29 @@ def test_sim_bf16_modes(avt, dev, mode, tol, nq, nt, d):
     assert err_emu < 5e-6 * 10 + 1e-6  # fp32-accumulate noise only
     if d >= 2304:  # the contract is stated at the embedding widths of the path (D=2304 / 14592)
         assert err_can < tol
+
+
+def test_sim_bf16x3_on_the_encoder_tile_equals_the_plain_tile(avt, dev):
+    """Round 5: the bf16x3 similarity runs on the encoder's 256 x 256 LDS-DMA tile when the shape allows (ops.SIM_XL).  Same three
+    products per term, fp32 accumulation in another order: within 6e-6 of the plain tile's scores (cos / 0.1), written through a
+    row pitch wider than the row, rows past a ragged M untouched."""
+    g = torch.Generator().manual_seed(2)
+    nq, nt, d = 700, 1024, 2304
+    q = torch.nn.functional.normalize(torch.randn((nq, d), generator=g), dim=1).to(dev)
+    t = torch.nn.functional.normalize(torch.randn((nt, d), generator=g), dim=1).to(dev)
+    _, qh, ql = avt.ops.l2norm_rows(q, want_split=True)
+    _, th, tl = avt.ops.l2norm_rows(t, want_split=True)
+    buf = torch.full((nq + 3, nt + 64), 7.0, device=dev)
+    keep = avt.ops.SIM_XL
+    try:
+        avt.ops.SIM_XL = "always"  # (the default takes the tile from 192 tiles up; 3 x 4 here)
+        a = avt.ops.sim_gemm_nt(qh, th, 0.1, "bf16x3", q_lo=ql, t_lo=tl, out=buf[:nq, :nt])
+        avt.ops.SIM_XL = False
+        b = avt.ops.sim_gemm_nt(qh, th, 0.1, "bf16x3", q_lo=ql, t_lo=tl)
+    finally:
+        avt.ops.SIM_XL = keep
+    assert float((a - b).abs().max()) < 6e-6  # (measured 3-4e-6 on scores of +-10)
+    assert float((buf[nq:] - 7.0).abs().max()) == 0.0 and float((buf[:, nt:] - 7.0).abs().max()) == 0.0
 
 
 # ---------------------------------------------------------------- transition select
