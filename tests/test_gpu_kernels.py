@@ -74,7 +74,11 @@ def test_sim_bf16_modes(avt, dev, mode, tol, nq, nt, d):
     q, qh, ql = cref.l2norm_rows(_rand((nq, d), 5))
     t, th, tl = cref.l2norm_rows(_rand((nt, d), 6))
     tq = lambda a: torch.from_numpy(a.view(np.int16)).view(torch.bfloat16).to(dev)
-    out = avt.ops.sim_gemm_nt(tq(qh), tq(th), 0.1, mode, q_lo=tq(ql), t_lo=tq(tl)).cpu().numpy()
+    keep, avt.ops.SIM_XL = avt.ops.SIM_XL, "always"  # (the shapes the 256 x 256 tile can take run on it, whatever their tile count)
+    try:
+        out = avt.ops.sim_gemm_nt(tq(qh), tq(th), 0.1, mode, q_lo=tq(ql), t_lo=tq(tl)).cpu().numpy()
+    finally:
+        avt.ops.SIM_XL = keep
     emu = cref.sim_bf16(qh, ql, th, tl, 0.1, mode == "bf16x3")
     err_emu = np.abs(out - emu).max()
     err_can = np.abs(out - cref.sim_f32(q, t, 0.1)).max()
