@@ -114,11 +114,23 @@ _SIDE_STREAMS = {}
 
 def _side_stream(device, cur):
     """The side stream that belongs to stream `cur` of `device` (a training loop that runs its items on several streams gets
-    one per stream: the query encoders of two items in flight do not queue behind each other)."""
+    one per stream: the query encoders of two items in flight do not queue behind each other).  Taken from the process-wide list
+    of ops.side_streams — the SAME streams the synthesis engine's two-stream mode uses: which hardware queue a torch stream lands
+    on depends on how many streams the process has created before it, and a side stream created after bench.py's two-stream bf16
+    leg shared a queue with the step's own stream (the query encoder no longer overlapped the target encoder: the config-5 leg ran
+    3.5 % slower inside the default bench run than alone, profiles/r05/trainleg_order.log)."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
     s = _SIDE_STREAMS.get(key)
     if s is None:
-        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        taken = {v.cuda_stream for v in _SIDE_STREAMS.values()} | {cur.cuda_stream}
+        n = 1
+        while s is None:
+            for cand in ops.side_streams(device, n):
+                if cand.cuda_stream not in taken:
+                    s = cand
+                    break
+            n += 1
+        _SIDE_STREAMS[key] = s
     return s
 
 

@@ -34,6 +34,21 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE = {}
+
+
+def side_streams(device, n):
+    """The first n of the process-wide side streams of `device` (created on first use, never more than asked for in total): every
+    multi-stream path of the package — the synthesis engine's q / t encoder streams, the training step's query-encoder stream —
+    draws from this one list, so that a given role always runs on the same stream (and hardware queue) whatever ran before it."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    lst = _SIDE.setdefault(key, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[:n]
+
+
 def device_check():
     buf = C.create_string_buffer(64)
     _lib.check(_lib.lib().avt_device_check(buf, 64), "avt_device_check")

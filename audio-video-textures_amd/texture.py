@@ -214,7 +214,7 @@ class TextureEngine:
             return [self._run(e, slow, fast) for e in encoders]
         main = torch.cuda.current_stream()
         if self._streams is None or len(self._streams) < self.n_streams:
-            self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)]
+            self._streams = ops.side_streams(self.dev, self.n_streams)  # (process-wide: see ops.side_streams)
         parts = 2 if self.n_streams >= 4 and slow.shape[0] >= 2 else 1
         sl, fa = slow.chunk(parts), fast.chunk(parts)
         tasks = [(e, k) for k in range(parts) for e in range(2)]

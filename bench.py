@@ -633,6 +633,7 @@ def build_parser():
     ap.add_argument("--no-precision-block", action="store_true")
     ap.add_argument("--no-nxn-legs", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the 2-step config-5 training leg of the default run")
+    ap.add_argument("--train-leg-idle", type=float, default=0.0, help="(diagnostic) seconds of idle before the config-5 leg of the default run")
     ap.add_argument("--no-inputs-r03-leg", action="store_true", help="skip the short second leg on round 3's inputs (value_inputs_r03)")
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
                     help="synth: the synthesis hot path (headline); train: BASELINE config 5, contrastive training at size")
@@ -809,10 +810,17 @@ def main():
         note("CPU baseline done")
     if world == 1 and not args.no_train_leg:
         del video, q_mod, t_mod
+        import gc
+
+        gc.collect()  # (the earlier legs' engines / encoder objects sit in reference cycles: without this their ~100 GB of buffers are
+        #               still allocated while the training leg runs, and it measures 3-4 % slower than alone — profiles/r05)
         torch.cuda.empty_cache()
         targs = argparse.Namespace(**vars(args))
         targs.steps, targs.warmup, targs.train_profile = 6, 3, False  # (the second warm-up step is the first with a sized gradient arena)
         torch.backends.cudnn.benchmark = True
+        if args.train_leg_idle > 0:  # (diagnostic: is the leg slower here than alone because of the chip's state after ~90 s of load?)
+            torch.cuda.synchronize()
+            time.sleep(args.train_leg_idle)
         tl = train_bench(targs, rank, world, dev)
         detail["train"] = tl
         out["train_clips_per_s"], out["train_ms_per_step"] = tl["value"], tl["ms_per_step"]
