@@ -110,6 +110,7 @@ class InfoNCECriterion(nn.Module):
 
 _TRAIN_STREAMS = 1  # the query encoder on a side stream next to the target encoder (tests set 0 for the single-stream step)
 _SIDE_STREAMS = {}
+_SIDE_SKIP = 0  # (tools/experimental/probe_side_stream_index.py: leave the first k process-wide side streams to others)
 
 
 def _side_stream(device, cur):
@@ -123,6 +124,7 @@ def _side_stream(device, cur):
     s = _SIDE_STREAMS.get(key)
     if s is None:
         taken = {v.cuda_stream for v in _SIDE_STREAMS.values()} | {cur.cuda_stream}
+        taken |= {v.cuda_stream for v in ops.side_streams(device, _SIDE_SKIP)} if _SIDE_SKIP else set()
         n = 1
         while s is None:
             for cand in ops.side_streams(device, n):
