@@ -215,3 +215,22 @@ def test_lateral_fusions_concatenate_without_copies_and_give_the_same_step(avt, 
     assert set(g1) == set(g0)
     for k in g0:  # (the weight-gradient kernels add their K-slices with fp32 atomics: equal up to that order)
         assert float((g1[k] - g0[k]).abs().max()) <= 2e-5 * float(g0[k].abs().max()) + 1e-12, k
+
+
+def test_side_streams_are_one_process_wide_list(avt, dev):
+    """The synthesis engine's two-stream mode and the training step's query-encoder stream draw from ONE list (ops.side_streams): the
+    k-th stream a process creates lands on another hardware queue, and a training side stream created after a two-stream engine run
+    shared a queue with the step's own stream (3.5 % slower config-5 leg inside the default bench run: profiles/r05/trainleg_order.log)."""
+    from avtex import models, ops
+
+    a = ops.side_streams(dev, 2)
+    b = ops.side_streams(dev, 1)
+    c = ops.side_streams(dev, 3)
+    assert len(a) == 2 and b[0] is a[0] and c[0] is a[0] and c[1] is a[1] and len({s.cuda_stream for s in c}) == 3
+    cur = torch.cuda.current_stream(dev)
+    s = models._side_stream(dev, cur)
+    assert s is models._side_stream(dev, cur) and s.cuda_stream != cur.cuda_stream
+    assert any(s is x for x in ops.side_streams(dev, 4))
+    with torch.cuda.stream(a[1]):  # a step that itself runs on a side stream gets a different one for its query encoder
+        s2 = models._side_stream(dev, torch.cuda.current_stream(dev))
+    assert s2.cuda_stream not in (a[1].cuda_stream, s.cuda_stream)
