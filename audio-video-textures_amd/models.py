@@ -137,9 +137,11 @@ def _side_stream(device, cur):
 
 
 def training_side_streams(device):
-    """The side streams training forwards have used on `device` (main.wrap_ddp's gradient hook waits for them: a bucket can
-    hold gradients written on the query encoder's stream and on the step's own)."""
-    return [s for k, s in _SIDE_STREAMS.items() if k[1] == (device.index if device.index is not None else torch.cuda.current_device())]
+    """Every side stream a training forward may have used on `device` (main.wrap_ddp's gradient hook waits for them: a bucket can
+    hold gradients written on the query encoder's stream, on the target encoder's fast-pathway stream and on the step's own):
+    the whole process-wide list of ops.side_streams."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return list(ops._SIDE.get((device.type, idx), []))
 
 
 class ContrastivePredictionTemporal(nn.Module):

@@ -19,6 +19,8 @@ import torch.nn as nn
 from .train_ops import bn_act, conv3d, conv3d_fork, join_channels, max_pool_hw
 
 ALPHA, BETA_INV, FUSION_RATIO, FUSION_KERNEL = 4, 8, 2, 7
+PATHWAY_STREAMS = 1  # train mode: the fast pathway of a default-stream forward on a side stream (SlowFast._forward_two_streams:
+#                      config 5 390 -> 411 clips/s, same losses; profiles/r05/train_pathway_streams_ab.log); tests set 0 for the reference
 WIDTH = 64
 DEPTHS = (3, 4, 6, 3)
 # temporal kernel of conv `a` per stage, (slow, fast): SLOWFAST_8x8: slow 1,1,3,3 / fast 3,3,3,3
@@ -116,16 +118,16 @@ class ResStage(nn.Module):
                                 ResBlock(cin[p] if i == 0 else cout[p], cout[p], cinner[p], tks[p],
                                          stride if i == 0 else 1))
 
+    def pathway(self, p, y, cat_extra=0):
+        """The blocks of pathway p (0 slow, 1 fast) of this stage."""
+        for i in range(self.depth):
+            y = getattr(self, "pathway%d_res%d" % (p, i))(y, cat_extra if (p == 0 and i == self.depth - 1) else 0)
+        return y
+
     def forward(self, x, cat_extra=0):
         """cat_extra: channels the lateral fusion after this stage appends to the slow pathway (its last block writes into the
         concatenation buffer, train_ops.join_channels)."""
-        out = []
-        for p in range(2):
-            y = x[p]
-            for i in range(self.depth):
-                y = getattr(self, "pathway%d_res%d" % (p, i))(y, cat_extra if (p == 0 and i == self.depth - 1) else 0)
-            out.append(y)
-        return out
+        return [self.pathway(0, x[0], cat_extra), self.pathway(1, x[1])]
 
 
 class Head(nn.Module):
@@ -177,11 +179,47 @@ class SlowFast(nn.Module):
                 nn.init.zeros_(m.c_bn.weight)
 
     def forward(self, x):
+        if PATHWAY_STREAMS and self.training and x[0].is_cuda and torch.is_grad_enabled():
+            cur = torch.cuda.current_stream(x[0].device)
+            if cur.cuda_stream == torch.cuda.default_stream(x[0].device).cuda_stream:
+                return self._forward_two_streams(x, cur)
         x = self.s1_fuse(self.s1(x, self.s1_fuse.extra))
         x = self.s2_fuse(self.s2(x, self.s2_fuse.extra))
         x = self.s3_fuse(self.s3(x, self.s3_fuse.extra))
         x = self.s4_fuse(self.s4(x, self.s4_fuse.extra))
         return self.head(self.s5(x))
+
+    def _forward_two_streams(self, x, cur):
+        """The training forward with the FAST pathway on a side stream (round 5 experiment, PATHWAY_STREAMS): the fast pathway depends
+        on nothing of the slow one, so its stem and stages run ahead on their own stream; the slow pathway's stream waits for the
+        fast features of a stage only where the lateral connection reads them.  autograd replays every backward node on its
+        forward's stream and orders the streams itself.  Only for a forward that runs on the device's default stream (the target
+        encoder of a training step: the query encoder already has a side stream of its own — three hardware queues in all)."""
+        from . import ops
+
+        dev = x[0].device
+        side = [s for s in ops.side_streams(dev, 3) if s.cuda_stream != cur.cuda_stream]
+        fs = side[1]  # (side[0] is the query encoder's: models._side_stream)
+        fs.wait_stream(cur)
+        stages, fuses = (self.s2, self.s3, self.s4, self.s5), (self.s1_fuse, self.s2_fuse, self.s3_fuse, self.s4_fuse)
+        with torch.cuda.stream(fs):
+            f = self.s1.pathway1_stem(x[1])
+            ev = torch.cuda.Event()
+            ev.record(fs)
+        s = self.s1.pathway0_stem(x[0], self.s1_fuse.extra)
+        for k, stage in enumerate(stages):
+            cur.wait_event(ev)           # the fast features the lateral connection reads
+            f.record_stream(cur)
+            f_in = f
+            with torch.cuda.stream(fs):  # the fast pathway's next stage is queued first: it runs under the slow pathway's
+                f = stage.pathway(1, f_in)
+                ev = torch.cuda.Event()
+                ev.record(fs)
+            s = fuses[k]([s, f_in])[0]
+            s = stage.pathway(0, s, fuses[k + 1].extra if k + 1 < len(fuses) else 0)
+        cur.wait_event(ev)
+        f.record_stream(cur)
+        return self.head([s, f])
 
 
 def prepare_encoder(module, device, dtype=torch.bfloat16, channels_last=False):

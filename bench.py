@@ -466,6 +466,10 @@ def train_bench(args, rank, world, dev):
     from avtex import train_ops
     train_ops._EPI_STATS = int(getattr(args, "train_epi_stats", 1))
     train_ops._EPI_BWD = int(getattr(args, "train_epi_bwd", 1))
+    if getattr(args, "train_pathway_streams", None) is not None:
+        import avtex.slowfast as _sf
+
+        _sf.PATHWAY_STREAMS = int(args.train_pathway_streams)
     grads = train_ops.MicroBatchGradients(model.parameters()) if args.grad_accumulator else None
 
     # --item-streams 2: consecutive items alternate between two streams; the forward of item k + 1 is ordered after the forward
@@ -648,6 +652,8 @@ def build_parser():
     ap.add_argument("--train-epi-bwd", type=int, default=1, choices=[0, 1],
                     help="--mode train: BatchNorm backward statistics on the consuming convolution's input-gradient epilogue (1) or by the "
                          "BatchNorm's own statistics pass (0: for A/Bs)")
+    ap.add_argument("--train-pathway-streams", type=int, default=None, choices=[0, 1],
+                    help="--mode train: the target encoder's fast pathway on a side stream (slowfast.PATHWAY_STREAMS; default: the module's)")
     ap.add_argument("--train-pass-items", type=int, default=0,
                     help="--mode train: items per forward/backward pass (0 = all of the rank's items as one batch with per-item "
                          "BatchNorm groups; 1 = one pass per item, round 2's loop)")

@@ -234,3 +234,41 @@ def test_side_streams_are_one_process_wide_list(avt, dev):
     with torch.cuda.stream(a[1]):  # a step that itself runs on a side stream gets a different one for its query encoder
         s2 = models._side_stream(dev, torch.cuda.current_stream(dev))
     assert s2.cuda_stream not in (a[1].cuda_stream, s.cuda_stream)
+
+
+def test_fast_pathway_on_a_side_stream_equals_one_stream(avt, dev):
+    """slowfast.PATHWAY_STREAMS: a training forward on the default stream runs its fast pathway on a side stream (and autograd its
+    backward there).  Same kernels on the same data in the same per-tensor order: the embedding is bit-identical, the gradients equal
+    up to the weight gradient's fp32 atomics."""
+    import avtex.slowfast as sf
+    from avtex.slowfast import SlowFast
+
+    torch.manual_seed(0)
+    net = SlowFast().to(dev).to(memory_format=torch.channels_last_3d).train()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.uniform_(0.5, 1.0)
+    g = torch.Generator().manual_seed(1)
+    slow = torch.randn((4, 3, 8, 64, 64), generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    fast = torch.randn((4, 3, 32, 64, 64), generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    wout = torch.randn((4, 2304), generator=g).to(dev)
+
+    def run(flag):
+        keep, sf.PATHWAY_STREAMS = sf.PATHWAY_STREAMS, flag
+        try:
+            net.zero_grad(set_to_none=True)
+            with avt.train_ops.bn_replicas(2):
+                y = net([slow, fast])
+            (y * wout).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            sf.PATHWAY_STREAMS = keep
+        return y.detach().clone(), [p.grad.detach().clone() for p in net.parameters()]
+
+    y1, g1 = run(1)
+    y0, g0 = run(0)
+    assert torch.equal(y1, y0)
+    num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(g1, g0)) ** 0.5
+    den = sum(float(b.double().pow(2).sum()) for b in g0) ** 0.5
+    assert num / den < 1e-5, num / den
