@@ -196,7 +196,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   // (two pieces per triple: every load is out within the first half of the slab's MFMAs, so the last one has the second
   // half to land before the stores need it — issued evenly, the wait for the late pieces was 24 % of a workgroup's time)
   constexpr int NPIECE = 2 * (AU + BU), NGROUP = 4 * NT * MT, PPG = 2 * ((NPIECE + NGROUP - 1) / NGROUP);
-  auto fmul = [&](const Frags& f, int g0, bool more, auto&& piece) {
+  // `more` (this is not the tile's last slab: the next slab's loads ride along) is a COMPILE-TIME constant — the K loop below is
+  // peeled.  As a run-time flag every load sat in a branch of its own, and the compiler, which cannot know that the branch around
+  // the ds_writes consuming the loads is taken exactly when the branches issuing them are, put `s_waitcnt vmcnt(0)` in front of
+  // every load pair of the fp32 (IO32) form (its second offset is computed in the load's destination register): four serialized
+  // L2 round trips per slab inside the MFMA sequence (round 5, tools/diag/isa_loop_summary.py)
+  auto fmul = [&](const Frags& f, int g0, auto more_, auto&& piece) {
+    constexpr bool more = decltype(more_)::value;
     // small terms first, the leading product last: D[n][m] += wl*ah + wh*al + wh*ah
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -217,12 +223,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
   };
-  auto compute = [&](bool more, auto&& prep, auto&& piece) {
+  auto compute = [&](auto more, auto&& prep, auto&& piece) {
     // (sched_barrier: without it the machine scheduler sinks every read back to just before its first use)
     Frags f0, f1;
     fload(f0, 0);
     fload(f1, 1);
-    if (more) prep();  // the next slab's offsets: its table read joins the fragment reads, its VALU the first MFMAs
+    if constexpr (decltype(more)::value) prep();  // the next slab's offsets: its table read joins the fragment reads, its VALU the first MFMAs
     __builtin_amdgcn_sched_barrier(0);
     fmul(f0, 0, more, piece);
     fload(f0, 2);
@@ -244,8 +250,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     for (int i = tid; i < a.nk * 8; i += 256) ltab[i] = a.ktab[i];
   i32x4 rah[AU], ral[AU], rbh[BU], rbl[BU];
   unsigned aoffs[AU], boffs[BU];
-  auto gprep = [&](int kt) {  // byte offsets of the slab's chunks (out of range = zero fill)
-    const int2 e = tab_lds ? ltab[kt * 8 + c16] : a.ktab[kt * 8 + c16];
+  // (TL: the table is in the LDS — a compile-time constant per instance of the K loop below: read through `tab_lds ? ltab : a.ktab`
+  //  the compiler selects the POINTER and emits a flat load, whose use waits for every fragment read issued before it)
+  auto gprep = [&](auto tl_, int kt) {  // byte offsets of the slab's chunks (out of range = zero fill)
+    int2 e;
+    if constexpr (decltype(tl_)::value) e = ltab[kt * 8 + c16];
+    else e = a.ktab[kt * 8 + c16];
     const unsigned ebits = (unsigned)e.y;
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     }
   };
   auto gload = [&](int kt) {
-    gprep(kt);
+    gprep(std::false_type{}, kt);
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) gpiece(p);
   };
@@ -323,20 +333,26 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   lstore();
   __syncthreads();
   STAMP(0);  // prologue
-  for (int kt = 0; kt < a.nk; ++kt) {
-    const bool more = kt + 1 < a.nk;
-    STAMP(1);
-    compute(more, [&]() { gprep(kt + 1); }, gpiece);
-    STAMP(2);  // fragment reads + MFMAs + the next slab's loads, one per MFMA triple
-    __syncthreads();
-    STAMP(3);  // barrier after compute
-    if (kt + 1 < a.nk) {
+  auto kloop = [&](auto tl) {  // every slab but the last: no branch in the body
+    for (int kt = 0; kt + 1 < a.nk; ++kt) {
+      STAMP(1);
+      compute(std::true_type{}, [&]() { gprep(tl, kt + 1); }, gpiece);
+      STAMP(2);  // fragment reads + MFMAs + the next slab's loads, one per MFMA triple
+      __syncthreads();
+      STAMP(3);  // barrier after compute
       if (!DBG_SKIP(1)) lstore();
       STAMP(4);  // wait for the loads + ds_write
       __syncthreads();
       STAMP(5);  // barrier after the stores
     }
-  }
+  };
+  if (tab_lds) kloop(std::true_type{});
+  else kloop(std::false_type{});
+  STAMP(1);
+  compute(std::false_type{}, []() {}, gpiece);  // the last slab
+  STAMP(2);
+  __syncthreads();
+  STAMP(3);
 
   // ---- epilogue: residual planes requested first, tile staged in fp32, split on the final value
   const bool has_res = !IO32 && a.res != nullptr;  // (IO32: `res` is an fp32 tensor added in the store loop below)

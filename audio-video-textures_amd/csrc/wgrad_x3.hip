@@ -437,16 +437,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
       srow[q] = SWAP ? xtab[(slot * XP + p) * a.tapcap + (xtap < 0 ? 0 : xtap)] : ytab[slot * XP + p];
     }
     rmask[SET] = smask[SET] = 0u;
+    const bool live = step < st1;  // (a step past the chunk's end belongs to the next chunk's workgroup: zeros here)
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
-      const bool ok = rrow[q] >= 0 && (SWAP ? y_ok : xtap >= 0);
+      const bool ok = live && rrow[q] >= 0 && (SWAP ? y_ok : xtap >= 0);
       const int64_t off = (int64_t)rrow[q] + (SWAP ? ych : xci);
       rmask[SET] |= ok ? 1u << q : 0u;
       rq[SET][q] = *reinterpret_cast<const float4*>((SWAP ? a.dy : a.x) + (ok ? off : 0));
     }
 #pragma unroll
     for (int q = 0; q < SQ; ++q) {
-      const bool ok = srow[q] >= 0 && (SWAP ? xtap >= 0 : y_ok);
+      const bool ok = live && srow[q] >= 0 && (SWAP ? xtap >= 0 : y_ok);
       const int64_t off = (int64_t)srow[q] + (SWAP ? xci : ych);
       smask[SET] |= ok ? 1u << q : 0u;
       sq[SET][q] = *reinterpret_cast<const float4*>((SWAP ? a.x : a.dy) + (ok ? off : 0));
@@ -522,25 +523,27 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
     fload(f1, cur, 1);
     __builtin_amdgcn_sched_barrier(0);
     fmul(f0);  // (issued first: the table reads, address arithmetic and the split + ds_write below run under the matrix pipe)
-    if (s + 2 < st1) gload(std::integral_constant<int, P>{}, s + 2);
-    if (s + 3 < st1) decode(s + 3);
+    // NO branch around the loads, the decode or the stores (steps past the chunk's end are masked to zeros instead): a load
+    // under a condition makes the compiler count the loads in flight for the path that skipped it, and the s_waitcnt in front of
+    // the ds_writes of step s + 1's data then ALSO waits for the loads of step s + 2 issued a moment ago — the two-step
+    // prefetch distance was one step minus the second k-slice's MFMAs (vmcnt(5..0) where vmcnt(11..6) was meant)
+    gload(std::integral_constant<int, P>{}, s + 2);
+    decode(s + 3);
     __builtin_amdgcn_sched_barrier(0);
     fmul(f1);
-    if (s + 1 < st1) lstore(std::integral_constant<int, P ^ 1>{}, nxt);  // step s + 1's data, requested during step s - 1
+    lstore(std::integral_constant<int, P ^ 1>{}, nxt);  // step s + 1's data, requested during step s - 1
   };
 
-  if (st0 < st1) {
-    decode(st0);
-    if (st0 + 1 < st1) decode(st0 + 1);
-    if (st0 + 2 < st1) decode(st0 + 2);
-    __syncthreads();
-    gload(S0{}, st0);
-    if (st0 + 1 < st1) gload(S1{}, st0 + 1);
-    lstore(S0{}, lds);
-  }
-  for (int s = st0; s < st1; s += 2) {
+  decode(st0);
+  decode(st0 + 1);
+  decode(st0 + 2);
+  __syncthreads();
+  gload(S0{}, st0);
+  gload(S1{}, st0 + 1);
+  lstore(S0{}, lds);
+  for (int s = st0; s < st1; s += 2) {  // in pairs: an odd chunk's last pair multiplies one step of zeros
     step(S0{}, s);
-    if (s + 1 < st1) step(S1{}, s + 1);
+    step(S1{}, s + 1);
   }
 
   // D layout: column (lane & 31) = index on the R axis, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = index on the S axis
@@ -592,6 +595,7 @@ int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
   if (chunks > most) chunks = most;
   if (chunks < 1) chunks = 1;
   a.slabs_per_chunk = (a.nslab + chunks - 1) / chunks;
+  a.slabs_per_chunk += a.slabs_per_chunk & 1;  // (the kernel walks its steps in pairs)
   a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
   constexpr int lds_bytes = XTABS + 4 * XP * 4 + 4 * XP * kMaxTaps * 4;
   static_assert(128 * 129 * 4 <= XTABS && lds_bytes <= 160 * 1024, "the swapped epilogue's staging and the whole layout fit");
@@ -609,12 +613,12 @@ int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
 
 // which tile avt_conv3d_wgrad_x3_f32 launches for (longer axis, shorter axis, taps, positions): 1 = the 256 x 128 tile
 int g_wgrad_xl = 1;  // (avt_wgrad_x3_set_xl: A/B switch for tools and tests; the shipped default is on)
-// g_wgrad_xl: 1 = where it measured faster (profiles/r05/probe_wgrad_xl.log: the long-(tap, ci) layers with >= 256 output channels,
-// +2 ... +32 %; the swapped pointwise layers and the 128-channel ones are 1-9 % slower on it — their epilogue is twice the atomics per
-// flop / they have one S tile); 2 = every layer the tile can take (tests, probes); 0 = never
+// g_wgrad_xl: 1 = where it measured faster (profiles/r05/probe_wgrad_xl.log, the last table: with the loads really two steps ahead
+// every layer the tile can take is +2 ... +46 % except the multi-tap layers with ONE 128-wide S tile, -2 %); 2 = every layer the
+// tile can take (tests, probes); 0 = never
 static bool wgrad_xl_picked(bool swap, int r_count, int s_count, int taps, int m) {
   if (!(r_count >= 256 && s_count >= 128 && taps <= kMaxTaps && m >= 64 * XP)) return false;
-  return g_wgrad_xl == 2 || (g_wgrad_xl == 1 && !swap && r_count >= 1024 && s_count >= 256);
+  return g_wgrad_xl == 2 || (g_wgrad_xl == 1 && (s_count >= 256 || taps == 1));
 }
 
 template <bool SWAP>

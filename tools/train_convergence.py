@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--scene-len", type=int, default=24, help="frames per scene of the synthetic video (24 = bench.py's)")
     ap.add_argument("--roundtrip", action="store_true")
     ap.add_argument("--workdir", default="/tmp/avt_train_convergence")
+    ap.add_argument("--against", default=None, help="a recorded result of this tool (same config): the largest EMA distance of each "
+                    "run here to each recorded curve goes into the output as `against`")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "train_convergence.json"))
     args = ap.parse_args()
 
@@ -237,6 +239,18 @@ def main():
         n = min(len(a), len(b))
         res["ema_gap_max_after_20"] = float(max(abs(a[i] - b[i]) for i in range(min(20, n - 1), n)))
         res["ema_final"] = {m: res["runs"][m]["loss_ema"][-1] for m in args.modes}
+    if args.against:
+        with open(args.against) as f:
+            old = json.load(f)
+        same = all(old["config"].get(k) == res["config"].get(k) for k in ("lr", "init", "batch", "negs", "temp", "img_size", "video"))
+        res["against"] = {"file": os.path.relpath(args.against, ROOT), "same_config": bool(same)}
+        for m, r in res["runs"].items():
+            for om, orun in old["runs"].items():
+                a, b = r["loss_ema"], orun["loss_ema"]
+                n = min(len(a), len(b))
+                res["against"]["%s_vs_recorded_%s" % (m, om)] = {
+                    "steps": n, "ema_gap_max_after_20": float(max(abs(a[i] - b[i]) for i in range(min(20, n - 1), n))),
+                    "ema_last": [a[n - 1], b[n - 1]]}
     if kept is not None:
         res["roundtrip"] = roundtrip(kept, video, args, dev, args.workdir)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
@@ -244,7 +258,7 @@ def main():
         json.dump(res, f, indent=1)
     brief = {m: {"first": r["loss"][0], "ema_last": r["loss_ema"][-1], "top1_last50": r["top1_last50"], "ms": r["ms_per_step_median"]}
              for m, r in res["runs"].items()}
-    print(json.dumps({"brief": brief, "ema_gap_max_after_20": res.get("ema_gap_max_after_20"),
+    print(json.dumps({"brief": brief, "ema_gap_max_after_20": res.get("ema_gap_max_after_20"), "against": res.get("against"),
                       "roundtrip": {k: v for k, v in res.get("roundtrip", {}).items() if k not in ("cli_frames_head",)}}, default=str))
 
 
