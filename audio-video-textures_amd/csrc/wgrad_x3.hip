@@ -56,6 +56,8 @@ struct WgArgs {
   int r_tiles, s_tiles;  // tiles of the 128-wide / BN-wide operand axis
   int nslab, slabs_per_chunk, nchunk;
   FastDiv dWo, dHo, dTo, dKW, dKH, dCin;
+  int pointwise;               // 1x1x1 / stride 1 / no padding: input row = output position
+  unsigned x_bytes, dy_bytes;  // the pipelined tile's buffer loads (tensors below kRowOob bytes, or the phase-serial tile runs)
 };
 
 __device__ __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {
@@ -351,6 +353,11 @@ int launch(WgArgs& a, int s_count, hipStream_t st) {
 // and writes step s + 1's data — loaded during step s - 1 — into the other stage; one barrier per step, the position tables in a
 // ring of four decoded three steps ahead.  256 x 128 outputs per workgroup (8 waves as 4 x 2, 64 x 64 each, the 128-wide tile's
 // wave): 48 KB per 6.3 MFLOP instead of 64 KB.  Layers with >= 256 on the longer axis and >= 128 on the shorter, <= 28 taps.
+// Its loads are BUFFER loads: the position tables hold byte offsets of rows, kRowOob for "no row" (padding taps, positions past the
+// tensor or past the chunk) — a thread adds its channel's bytes and the hardware bounds check returns zeros: no per-piece mask
+// registers, no selects in front of the ds_writes, 32-bit address arithmetic (the tile is VALU-bound: ~315 vector instructions per
+// wave and 32-position step against 24 MFMAs, counted in the ISA).
+constexpr unsigned kRowOob = 0xFFF00000u;  // (+ a channel offset of < 1 MB stays beyond every buffer and does not wrap)
 constexpr int XP = 32;                 // positions per step
 constexpr int XPL = XP * 256;          // one 128-channel plane of a stage: [32 positions][256 B]
 constexpr int XSTAGE = 6 * XPL;        // R0 hi | R0 lo | R1 hi | R1 lo | S hi | S lo
@@ -367,65 +374,85 @@ __device__ __forceinline__ void put4x(char* base, int off, float4 v) {  // put4 
   *reinterpret_cast<uint2*>(base + XPL + off) = make_uint2(l01, l23);
 }
 
-template <bool SWAP>
+// SW = width of the S axis' tile: 128 (waves as 4 (R) x 2 (S), 64 x 64 outputs each), 64 (4 x 2, 64 x 32) or 32 (8 x 1, 32 x 32).  The narrow
+// forms are for the layers the 128-wide tile ran LATENCY-bound (64 -> 64 [1,3,3]: 4 us per 64-position slab of which 0.3 us are MFMAs;
+// the 8- to 32-channel fast-pathway layers at 0.9 TB/s): the same pipeline, the S planes of a stage only partly used.
+template <bool SWAP, int SW>
 __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
-  constexpr int RQ = 4, SQ = 2;        // float4 loads per thread and step: 256 / 128 channels x 32 positions over 512 threads
+  constexpr int RQ = 4;                        // float4 loads per thread and step on the R axis: 256 channels x 32 positions over 512 threads
+  constexpr int SQT = SW / 4;                  // S quads per position (32 / 16 / 8) ...
+  constexpr int SPP = 512 / SQT;               // ... positions one pass of the 512 threads covers (16 / 32 / 64)
+  constexpr int SQ = SPP >= XP ? 1 : XP / SPP; // ... passes per step (2 / 1 / 1)
+  constexpr int WS = SW >= 64 ? 2 : 1, WR = 8 / WS;       // waves along S / R
+  constexpr int RWV = 256 / WR, SWV = SW / WS;            // a wave's outputs: 64 x 64, 64 x 32, 32 x 32
+  constexpr int NI = SWV / 32, NJ = RWV / 32;             // 32 x 32 blocks of a wave along S / R
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  int* const ytab = reinterpret_cast<int*>(lds + XTABS);             // [4][32]
-  int* const xtab = ytab + 4 * XP;                                   // [4][32][tapcap]
+  unsigned* const ytab = reinterpret_cast<unsigned*>(lds + XTABS);   // [4][32] byte offsets of dy rows
+  unsigned* const xtab = ytab + 4 * XP;                              // [4][32][tapcap] ... of x rows under every tap
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;                             // 4 (R) x 2 (S) waves, 64 x 64 each
+  const int wm = wid / WS, wn = wid % WS;
   const int lr = lane & 31, lh = lane >> 5;
 
   int b_ = avt::xcd_contiguous(blockIdx.x, gridDim.x);
   const int ts = b_ % a.s_tiles; b_ /= a.s_tiles;
   const int tr = b_ % a.r_tiles;
   const int chunk = b_ / a.r_tiles;
-  const int r0 = tr * 256, s0 = ts * 128;
+  const int r0 = tr * 256, s0 = ts * SW;
   const int st0 = chunk * a.slabs_per_chunk;                         // (steps of 32 positions here)
   const int st1 = min(a.nslab, st0 + a.slabs_per_chunk);
   const int x0 = SWAP ? s0 : r0;
 
   // this thread's pieces: R quad (tid & 63) of position (q * 8 + (tid >> 6)), S quad (tid & 31) of position (q * 16 + (tid >> 5));
   // the x operand's (tap, ci) is the same for all of a thread's pieces
-  const int rcq = tid & 63, scq = tid & 31;
+  const int rcq = tid & 63, scq = tid % SQT, sp0 = tid / SQT;       // (S: position sp0 + SPP * pass; beyond the step for SW = 32's upper half)
   const int xe = x0 + 4 * (SWAP ? scq : rcq);
   const int xtap = xe < a.E ? (int)fastdiv((uint32_t)xe, a.dCin) : -1;
   const int xci = xe - xtap * a.Cin;
   const int ych = (SWAP ? r0 + 4 * rcq : s0 + 4 * scq);              // the dy operand's first channel
   const bool y_ok = ych < a.Cout;
+  // bytes this thread adds to a row's offset on either axis; a column past the operand's end never loads (kRowOob, below)
+  const unsigned rcb = 4u * (unsigned)(SWAP ? ych : xci), scb = 4u * (unsigned)(SWAP ? xci : ych);
+  const bool r_ok = SWAP ? y_ok : xtap >= 0, s_ok = (SWAP ? xtap >= 0 : y_ok) && (SPP <= XP || sp0 < XP);
 
-  f32x16 acc[2][2];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   auto decode = [&](int step) {  // thread -> position tid & 31, taps (tid >> 5), + 16
     const int slot = step & 3, p = tid & 31, m = step * XP + p;
-    const bool ok = m < a.M;
+    const bool ok = m < a.M && step < st1;  // (a step past the chunk's end belongs to the next chunk's workgroup: zeros here)
+    if (a.pointwise) {  // 1x1x1, stride 1, no padding: output position m reads input row m (half of the step's launches)
+      if (tid < XP) {
+        ytab[slot * XP + p] = ok ? 4u * (unsigned)(m * a.ldy) : kRowOob;
+        xtab[(slot * XP + p) * a.tapcap] = ok ? 4u * (unsigned)(m * a.ldx) : kRowOob;
+      }
+      return;
+    }
     const int q1 = (int)fastdiv((uint32_t)(ok ? m : 0), a.dWo), wo = (ok ? m : 0) - q1 * a.Wo;
     const int q2 = (int)fastdiv((uint32_t)q1, a.dHo), ho = q1 - q2 * a.Ho;
     const int bb = (int)fastdiv((uint32_t)q2, a.dTo), to = q2 - bb * a.To;
-    if (tid < XP) ytab[slot * XP + p] = ok ? m * a.ldy : -1;
+    if (tid < XP) ytab[slot * XP + p] = ok ? 4u * (unsigned)(m * a.ldy) : kRowOob;
     for (int tap = tid >> 5; tap < a.taps; tap += 16) {
       const int t1 = (int)fastdiv((uint32_t)tap, a.dKW), dw_ = tap - t1 * a.KW;
       const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
       const int ti = to * a.st - a.pt + dt, hi = ho * a.sh - a.ph + dh, wi = wo * a.sw - a.pw + dw_;
       const bool in = ok && (unsigned)ti < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      xtab[(slot * XP + p) * a.tapcap + tap] = in ? (((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx : -1;
+      xtab[(slot * XP + p) * a.tapcap + tap] = in ? 4u * (unsigned)((((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx) : kRowOob;
     }
   };
 
-  float4 rq[2][RQ], sq[2][SQ];
-  unsigned rmask[2] = {0u, 0u}, smask[2] = {0u, 0u};
+  i32x4 rq[2][RQ], sq[2][SQ];
   auto gload = [&](auto set_, int step) {  // all table reads first, then the loads, unconditional (see the 128-wide tile)
     constexpr int SET = decltype(set_)::value;
     const int slot = step & 3;
-    int rrow[RQ], srow[SQ];
+    unsigned rrow[RQ], srow[SQ];
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
       const int p = q * 8 + (tid >> 6);
@@ -433,25 +460,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < SQ; ++q) {
-      const int p = q * 16 + (tid >> 5);
+      const int p = (q * SPP + sp0) & (XP - 1);
       srow[q] = SWAP ? xtab[(slot * XP + p) * a.tapcap + (xtap < 0 ? 0 : xtap)] : ytab[slot * XP + p];
     }
-    rmask[SET] = smask[SET] = 0u;
-    const bool live = step < st1;  // (a step past the chunk's end belongs to the next chunk's workgroup: zeros here)
 #pragma unroll
-    for (int q = 0; q < RQ; ++q) {
-      const bool ok = live && rrow[q] >= 0 && (SWAP ? y_ok : xtap >= 0);
-      const int64_t off = (int64_t)rrow[q] + (SWAP ? ych : xci);
-      rmask[SET] |= ok ? 1u << q : 0u;
-      rq[SET][q] = *reinterpret_cast<const float4*>((SWAP ? a.dy : a.x) + (ok ? off : 0));
-    }
+    for (int q = 0; q < RQ; ++q)
+      rq[SET][q] = __builtin_amdgcn_raw_buffer_load_b128(SWAP ? rsy : rsx, (int)(r_ok ? rrow[q] + rcb : kRowOob), 0, 0);
 #pragma unroll
-    for (int q = 0; q < SQ; ++q) {
-      const bool ok = live && srow[q] >= 0 && (SWAP ? xtap >= 0 : y_ok);
-      const int64_t off = (int64_t)srow[q] + (SWAP ? xci : ych);
-      smask[SET] |= ok ? 1u << q : 0u;
-      sq[SET][q] = *reinterpret_cast<const float4*>((SWAP ? a.x : a.dy) + (ok ? off : 0));
-    }
+    for (int q = 0; q < SQ; ++q)
+      sq[SET][q] = __builtin_amdgcn_raw_buffer_load_b128(SWAP ? rsx : rsy, (int)(s_ok ? srow[q] + scb : kRowOob), 0, 0);
   };
   const int rsub = (rcq >> 5) * 2 * XPL, rc = rcq & 31;
   auto lstore = [&](auto set_, char* stg) {
@@ -459,31 +476,48 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
       const int p = q * 8 + (tid >> 6);
-      put4x(stg + rsub, swz(p, rc >> 1) + 8 * (rc & 1), (rmask[SET] >> q) & 1u ? rq[SET][q] : make_float4(0.f, 0.f, 0.f, 0.f));
+      put4x(stg + rsub, swz(p, rc >> 1) + 8 * (rc & 1), __builtin_bit_cast(float4, rq[SET][q]));
     }
 #pragma unroll
     for (int q = 0; q < SQ; ++q) {
-      const int p = q * 16 + (tid >> 5);
-      put4x(stg + 4 * XPL, swz(p, scq >> 1) + 8 * (scq & 1), (smask[SET] >> q) & 1u ? sq[SET][q] : make_float4(0.f, 0.f, 0.f, 0.f));
+      const int p = q * SPP + sp0;
+      if (SPP <= XP || p < XP) put4x(stg + 4 * XPL, swz(p, scq >> 1) + 8 * (scq & 1), __builtin_bit_cast(float4, sq[SET][q]));
     }
   };
   // transposed-read addresses inside a stage (k-slice 0; + 4096 per 16 positions): see the 128-wide tile
   const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  int raddr[2][2], saddr[2][2];
+  int raddr0_[NJ][2], saddr0_[NI][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int rofs = wm * RWV + j * 32;  // first R channel of the block: plane pair rofs >> 7, channel rofs & 127 inside it
+      raddr0_[j][h2] = (rofs >> 7) * 2 * XPL + swz(8 * (g >> 1) + 4 * h2 + tq, ((rofs & 127) + 16 * (g & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+    }
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2)
-      raddr[j][h2] = (wm >> 1) * 2 * XPL + swz(8 * (g >> 1) + 4 * h2 + tq, ((wm & 1) * 64 + j * 32 + 16 * (g & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-      saddr[i][h2] = 4 * XPL + swz(8 * (g >> 1) + 4 * h2 + tq, (wn * 64 + i * 32 + 16 * (g & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+      saddr0_[i][h2] = 4 * XPL + swz(8 * (g >> 1) + 4 * h2 + tq, (wn * SWV + i * 32 + 16 * (g & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
   struct Frags {
-    i32x4 rh[2], rl[2], sh[2], sl[2];
+    i32x4 rh[NJ], rl[NJ], sh[NI], sl[NI];
   };
-  auto fload = [&](Frags& f, const char* stg, int ks) {
+  // (the second stage's addresses in registers of their own: stage base + plane + k-slice exceeds the 16-bit offset field of a
+  //  ds_read, and the compiler spent one v_add per transposing read — 32 per step — on them)
+  int raddr1[NJ][2], saddr1[NI][2];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) raddr1[j][h2] = raddr0_[j][h2] + XSTAGE;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) saddr1[i][h2] = saddr0_[i][h2] + XSTAGE;
+  auto fload = [&](Frags& f, auto par_, int ks) {
+    constexpr int P = decltype(par_)::value;
+    const char* const stg = lds;
+    auto& raddr = *(P ? &raddr1 : &raddr0_);
+    auto& saddr = *(P ? &saddr1 : &saddr0_);
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     auto frag = [&](int a0, int a1) {
       const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(stg + a0)));
@@ -491,21 +525,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
       return i32x4{(int)u.x, (int)u.y, (int)v.x, (int)v.y};
     };
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       f.rh[j] = frag(raddr[j][0] + 4096 * ks, raddr[j][1] + 4096 * ks);
       f.rl[j] = frag(raddr[j][0] + XPL + 4096 * ks, raddr[j][1] + XPL + 4096 * ks);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       f.sh[i] = frag(saddr[i][0] + 4096 * ks, saddr[i][1] + 4096 * ks);
       f.sl[i] = frag(saddr[i][0] + XPL + 4096 * ks, saddr[i][1] + XPL + 4096 * ks);
     }
   };
   auto fmul = [&](const Frags& f) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         acc[i][j] = mfma(f.sl[i], f.rh[j], acc[i][j]);  // small terms first
         acc[i][j] = mfma(f.sh[i], f.rl[j], acc[i][j]);
         acc[i][j] = mfma(f.sh[i], f.rh[j], acc[i][j]);
@@ -515,12 +549,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
   typedef std::integral_constant<int, 1> S1;
   auto step = [&](auto par_, int s) {  // par = (s - st0) & 1: stage and register set of step s
     constexpr int P = decltype(par_)::value;
-    char* cur = lds + P * XSTAGE;
     char* nxt = lds + (P ^ 1) * XSTAGE;
     __syncthreads();  // stage P is complete; the other stage's readers (step s - 1) are done; the table of step s + 2 is decoded
     Frags f0, f1;
-    fload(f0, cur, 0);
-    fload(f1, cur, 1);
+    fload(f0, par_, 0);
+    fload(f1, par_, 1);
     __builtin_amdgcn_sched_barrier(0);
     fmul(f0);  // (issued first: the table reads, address arithmetic and the split + ds_write below run under the matrix pipe)
     // NO branch around the loads, the decode or the stores (steps past the chunk's end are masked to zeros instead): a load
@@ -549,34 +582,35 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
   // D layout: column (lane & 31) = index on the R axis, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = index on the S axis
   if constexpr (!SWAP) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = r0 + wm * 64 + j * 32 + lr;
+      for (int j = 0; j < NJ; ++j) {
+        const int e = r0 + wm * RWV + j * 32 + lr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = s0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int co = s0 + wn * SWV + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.ldw + e, acc[i][j][r]);
         }
       }
   } else {  // lanes would walk co (rows 4 E bytes apart): through the LDS, one half of the R axis (128 co) at a time
-    constexpr int ES = 128 + 1;
+    constexpr int ES = SW + 1;
     float* const stage = reinterpret_cast<float*>(lds);
     for (int half = 0; half < 2; ++half) {
       __syncthreads();
-      if ((wm >> 1) == half) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NJ; ++j) {
+        const int rofs = wm * RWV + j * 32;
+        if ((rofs >> 7) == half) {
+          const int col = (rofs & 127) + lr;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int col = (wm & 1) * 64 + j * 32 + lr;
+          for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stage[col * ES + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[i][j][r];
-          }
+            for (int r = 0; r < 16; ++r) stage[col * ES + wn * SWV + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[i][j][r];
+        }
       }
       __syncthreads();
-      for (int idx = tid; idx < 128 * 128; idx += 512) {
-        const int col = idx >> 7, el = idx & 127;
+      for (int idx = tid; idx < 128 * SW; idx += 512) {
+        const int col = idx / SW, el = idx % SW;
         const int co = r0 + half * 128 + col, e = s0 + el;
         if (e < a.E && co < a.Cout) unsafeAtomicAdd(a.dw + (int64_t)co * a.ldw + e, stage[col * ES + el]);
       }
@@ -584,10 +618,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
   }
 }
 
-template <bool SWAP>
+template <bool SWAP, int SW>
 int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
   a.r_tiles = (r_count + 255) / 256;
-  a.s_tiles = (s_count + 127) / 128;
+  a.s_tiles = (s_count + SW - 1) / SW;
   const int tiles = a.r_tiles * a.s_tiles;
   a.nslab = (a.M + XP - 1) / XP;  // steps of 32 positions
   int chunks = (512 + tiles - 1) / tiles;  // one workgroup per CU: two rounds' worth of work items
@@ -599,7 +633,7 @@ int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
   a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
   constexpr int lds_bytes = XTABS + 4 * XP * 4 + 4 * XP * kMaxTaps * 4;
   static_assert(128 * 129 * 4 <= XTABS && lds_bytes <= 160 * 1024, "the swapped epilogue's staging and the whole layout fit");
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_xl_kernel<SWAP>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_xl_kernel<SWAP, SW>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_wgrad_x3_f32: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
@@ -607,23 +641,32 @@ int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
   }
   const int64_t grid = (int64_t)tiles * a.nchunk;
   AVT_REQUIRE(grid < (1ll << 31), "avt_conv3d_wgrad_x3_f32: grid too large");
-  hipLaunchKernelGGL((wgrad_x3_xl_kernel<SWAP>), dim3((unsigned)grid), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((wgrad_x3_xl_kernel<SWAP, SW>), dim3((unsigned)grid), dim3(512), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_wgrad_x3_f32");
 }
 
 // which tile avt_conv3d_wgrad_x3_f32 launches for (longer axis, shorter axis, taps, positions): 1 = the 256 x 128 tile
 int g_wgrad_xl = 1;  // (avt_wgrad_x3_set_xl: A/B switch for tools and tests; the shipped default is on)
-// g_wgrad_xl: 1 = where it measured faster (profiles/r05/probe_wgrad_xl.log, the last table: with the loads really two steps ahead
-// every layer the tile can take is +2 ... +46 % except the multi-tap layers with ONE 128-wide S tile, -2 %); 2 = every layer the
-// tile can take (tests, probes); 0 = never
-static bool wgrad_xl_picked(bool swap, int r_count, int s_count, int taps, int m) {
-  if (!(r_count >= 256 && s_count >= 128 && taps <= kMaxTaps && m >= 64 * XP)) return false;
-  return g_wgrad_xl == 2 || (g_wgrad_xl == 1 && (s_count >= 256 || taps == 1));
+int g_wgrad_narrow = 1;  // (avt_wgrad_x3_set_xl(3) / (4): the 64- and 32-wide pipelined forms on / off under mode 1)
+// g_wgrad_xl: 1 = where it measured faster; 2 = every layer, at the S width that fits (tests, probes); 0 = never
+// -> the S width of the pipelined tile to launch (128 / 64 / 32), or 0 for the 128-wide phase-serial tile
+static int wgrad_xl_picked(bool swap, int r_count, int s_count, int taps, int spatial_taps, int m, bool fits32) {
+  if (!(taps <= kMaxTaps && m >= 64 * XP && fits32) || g_wgrad_xl == 0) return 0;
+  const int sw = s_count > 64 ? 128 : (s_count > 32 ? 64 : 32);
+  if (g_wgrad_xl >= 2) return sw;
+  // mode 1, by profiles/r05/probe_wgrad_xl.log (its last table): every layer with more than 64 on the shorter axis (+11 ... +56 %);
+  // 33-64: the pointwise and temporal-tap layers (+13 ... +28 %), not the [1,3,3] ones (64 -> 64 at 56 x 56: -9 %); the 32-wide
+  // form loses on the 8-channel layers (-22 ... -39 %) and wins on few small ones: tests / probes only
+  if (sw == 128) return 128;
+  return (g_wgrad_narrow && sw == 64 && spatial_taps == 1) ? 64 : 0;
 }
 
 template <bool SWAP>
 int dispatch(WgArgs& a, int r_count, int s_count, hipStream_t s) {
-  if (wgrad_xl_picked(SWAP, r_count, s_count, a.taps, a.M)) return launch_xl<SWAP>(a, r_count, s_count, s);
+  const int xl = wgrad_xl_picked(SWAP, r_count, s_count, a.taps, a.KH * a.KW, a.M, a.x_bytes != 0u && a.dy_bytes != 0u && a.ldx < (1 << 17) && a.ldy < (1 << 17));
+  if (xl == 128) return launch_xl<SWAP, 128>(a, r_count, s_count, s);
+  if (xl == 64) return launch_xl<SWAP, 64>(a, r_count, s_count, s);
+  if (xl == 32) return launch_xl<SWAP, 32>(a, r_count, s_count, s);
   a.r_tiles = (r_count + 127) / 128;
   if (s_count <= 32) return launch<32, SWAP>(a, s_count, s);
   if (s_count <= 64) return launch<64, SWAP>(a, s_count, s);
@@ -660,6 +703,12 @@ extern "C" int avt_conv3d_wgrad_x3_sub_f32(const float* dy, const float* x, floa
   a.ldw = ldw > 0 ? ldw : a.E;
   AVT_REQUIRE(a.ldw >= a.E, "avt_conv3d_wgrad_x3_f32: ldw (%d) < taps * cin (%d)", a.ldw, a.E);
   a.dCin = make_fastdiv((uint32_t)cin);
+  a.pointwise = (a.taps == 1 && st == 1 && sh == 1 && sw == 1 && pt == 0 && ph == 0 && pw == 0 && a.To == t && a.Ho == h && a.Wo == w) ? 1 : 0;
+  {
+    const int64_t xb = (int64_t)batch * t * h * w * ldx * 4, yb = M * ldy * 4;
+    a.x_bytes = xb < (int64_t)kRowOob ? (unsigned)xb : 0u;  // (0: too large for the pipelined tile's 32-bit byte offsets)
+    a.dy_bytes = yb < (int64_t)kRowOob ? (unsigned)yb : 0u;
+  }
   a.nslab = (int)((M + 63) / 64);
   a.dWo = make_fastdiv((uint32_t)a.Wo); a.dHo = make_fastdiv((uint32_t)a.Ho); a.dTo = make_fastdiv((uint32_t)a.To);
   a.dKW = make_fastdiv((uint32_t)kw); a.dKH = make_fastdiv((uint32_t)kh);
@@ -679,6 +728,11 @@ extern "C" int avt_conv3d_wgrad_x3_sub_f32(const float* dy, const float* x, floa
 // 1 (default): the layers the 256 x 128 pipelined tile measured faster on take it; 2: every layer it can take; 0: none (A/Bs, tests)
 extern "C" int avt_wgrad_x3_set_xl(int on) {
   const int was = g_wgrad_xl;
+  if (on == 3 || on == 4) {  // (probes: mode 1 with / without the narrow pipelined forms)
+    g_wgrad_xl = 1;
+    g_wgrad_narrow = on == 3 ? 1 : 0;
+    return was;
+  }
   g_wgrad_xl = on < 0 ? 0 : (on > 2 ? 2 : on);
   return was;
 }

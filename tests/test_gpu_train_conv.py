@@ -212,6 +212,14 @@ def test_stem_patch_path_follows_the_optimizer_and_can_be_switched_off():
     (128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 14, 14)),      # temporal taps, exact tiles
     (136, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 57, 59)),      # strided, odd extents
     (256, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 8, 28, 28)),      # 50 176 positions: many chunks of steps, atomics from all of them
+    # the pipelined tile's 64- and 32-wide forms (the narrow layers: one ragged R tile, S tiles of 64 / 32, both orientations)
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 21, 19)),        # E = 576, cout 64: one 64-wide S tile
+    (8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 24, 23)),          # E = 72 of a 256-wide R tile, cout 8 of a 32-wide S tile
+    (32, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 6, 20, 20)),         # E = 96, cout 8
+    (8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 5, 22, 22)),         # swapped: cout 32 on the R axis, E = 8 on a 32-wide S tile
+    (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 29, 30)),       # swapped: cout 256, E = 64 (64-wide S tile), ragged positions
+    (40, 72, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 41, 43)),        # E = 360 (2 R tiles), cout 72 -> 128-wide S, strided
+    (16, 48, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 5, 15, 16)),        # E = 48, cout 48: equal axes, 64-wide S tile
 ])
 def test_weight_gradient_kernel_edges(cin, cout, kernel, stride, pad, dims):
     from avtex import _lib, ops

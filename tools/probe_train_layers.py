@@ -64,6 +64,63 @@ def wgs(dy, x, dw, dims, cin, cout, kernel, stride, pad, out_dims, ldx, ldy, ldw
 
 
 ops.conv3d_igemm_x3_f32, ops.conv3d_wgrad_x3_f32, ops.conv3d_wgrad_x3_sub_f32 = fwd, wg, wgs
+
+# round 5's forms: BatchNorm statistics on the epilogues (forward: _stats, input gradient: _bwdstats), the streaming pointwise
+# kernel with fp32 I/O (pw), the strided input gradient's classes (_ex)
+_fs, _fb, _pw, _pws, _pwb, _fex = (ops.conv3d_igemm_x3_f32_stats, ops.conv3d_igemm_x3_f32_bwdstats, ops.pw_x3_f32, ops.pw_x3_f32_stats,
+                                   ops.pw_x3_f32_bwdstats, ops.conv3d_igemm_x3_f32_ex)
+
+
+def _ckey(what, cin, cout, kernel, dims, tail):
+    return "%s cin%-4d cout%-4d k%s in%s%s" % (what, cin, cout, tuple(kernel), tuple(dims), tail)
+
+
+def fwd_stats(x, wh, wl, ws, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype, groups, stat_c):
+    mo, taps = out.numel() // cout, kernel[0] * kernel[1] * kernel[2]
+    return timed(_ckey("fwd  ", cin, cout, kernel, dims, " +stats"),
+                 lambda: _fs(x, wh, wl, ws, out, ktab, dims, cin, cout, kernel, stride, pad, ldi, ldo, plane_dtype, groups, stat_c),
+                 2.0 * mo * taps * cin * cout, 4.0 * (x.numel() + out.numel()))
+
+
+def dgrad_bst(dy, wh, wl, out, ktab, dims, cin, cout, kernel, pad, plane_dtype, bn, groups, stat_c, add=None):
+    mo, taps = out.numel() // cout, kernel[0] * kernel[1] * kernel[2]
+    return timed(_ckey("dgrad", cin, cout, kernel, dims, " +bst" + (" +add" if add is not None else "")),
+                 lambda: _fb(dy, wh, wl, out, ktab, dims, cin, cout, kernel, pad, plane_dtype, bn, groups, stat_c, add=add),
+                 2.0 * mo * taps * cin * cout, 4.0 * (dy.numel() + out.numel() * (3 if add is not None else 2)))
+
+
+def pw(x, k, wh, wl, ws, out, n, plane_dtype, add=None):
+    what = "fwd  " if plane_dtype == ops.X3_F16 else "dgrad"
+    return timed("%s pw cin%-4d cout%-4d rows %d%s" % (what, k, n, x.numel() // x.shape[-1], " +add" if add is not None else ""),
+                 lambda: _pw(x, k, wh, wl, ws, out, n, plane_dtype, add=add), 2.0 * (out.numel() // out.shape[-1]) * k * n,
+                 4.0 * (x.numel() + out.numel() * (2 if add is not None else 1)))
+
+
+def pw_stats(x, k, wh, wl, ws, out, n, plane_dtype, groups):
+    r = [None]
+
+    def run():
+        r[0] = _pws(x, k, wh, wl, ws, out, n, plane_dtype, groups)
+        return r[0]
+    return timed("fwd   pw cin%-4d cout%-4d rows %d +stats" % (k, n, x.numel() // x.shape[-1]), run,
+                 2.0 * (out.numel() // out.shape[-1]) * k * n, 4.0 * (x.numel() + out.numel()))
+
+
+def pw_bst(dy, k, wh, wl, out, n, plane_dtype, bn, groups, add=None):
+    return timed("dgrad pw cin%-4d cout%-4d rows %d +bst%s" % (k, n, dy.numel() // dy.shape[-1], " +add" if add is not None else ""),
+                 lambda: _pwb(dy, k, wh, wl, out, n, plane_dtype, bn, groups, add=add), 2.0 * (out.numel() // out.shape[-1]) * k * n,
+                 4.0 * (dy.numel() + out.numel() * (3 if add is not None else 2)))
+
+
+def fwd_ex(x, wh, wl, ws, out, ktab, dims, cin, cout, kernel, pad, out_dims, ldi, ldo, plane_dtype, out_rows=(1, 0, 0)):
+    mo, taps = out_dims[0] * out_dims[1] * out_dims[2] * dims[0], kernel[0] * kernel[1] * kernel[2]
+    return timed(_ckey("dgrad-class", cin, cout, kernel, dims, ""),
+                 lambda: _fex(x, wh, wl, ws, out, ktab, dims, cin, cout, kernel, pad, out_dims, ldi, ldo, plane_dtype, out_rows=out_rows),
+                 2.0 * mo * taps * cin * cout, 4.0 * (x.numel() + mo * cout))
+
+
+(ops.conv3d_igemm_x3_f32_stats, ops.conv3d_igemm_x3_f32_bwdstats, ops.pw_x3_f32, ops.pw_x3_f32_stats, ops.pw_x3_f32_bwdstats,
+ ops.conv3d_igemm_x3_f32_ex) = fwd_stats, dgrad_bst, pw, pw_stats, pw_bst, fwd_ex
 _sf, _sw, _cp = ops.stem_conv_x3_f32, ops.stem_wgrad_x3, ops.clip_planes_f32
 
 
@@ -140,7 +197,7 @@ def main():
     for k, r in ROWS.items():
         cat[k.split()[0]] += r[1]
     print("  by kind: " + ", ".join("%s %.1f ms" % kv for kv in sorted(cat.items(), key=lambda kv: -kv[1])))
-    for k, r in sorted(ROWS.items(), key=lambda kv: -kv[1][1])[:70]:
+    for k, r in sorted(ROWS.items(), key=lambda kv: -kv[1][1])[:110]:
         print("  %7.3f ms x%-2d %-84s %6.1f TF/s %6.0f GB/s" % (r[1], r[0], k, r[2] / r[1] * 1e-9, r[3] / r[1] * 1e-6))
 
 

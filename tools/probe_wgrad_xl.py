@@ -17,6 +17,14 @@ layers = [  # cin, cout, kernel, stride, pad, (t, h, w)
     (512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 7, 7)), (512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 7, 7)),
     (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 56, 56)), (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 56, 56)),
     (256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 56, 56)), (128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 14, 14)),
+    # the fast pathway's few-channel layers and the lateral connections (the 64- / 32-wide forms of the pipelined tile)
+    (8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 56, 56)), (8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (32, 56, 56)),
+    (32, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 56, 56)), (16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 28, 28)),
+    (64, 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 28, 28)), (16, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (32, 28, 28)),
+    (32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 14, 14)), (128, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 14, 14)),
+    (32, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (32, 14, 14)), (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 7, 7)),
+    (256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 7, 7)), (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (32, 7, 7)),
+    (8, 16, (7, 1, 1), (4, 1, 1), (3, 0, 0), (32, 56, 56)), (32, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (32, 56, 56)),
 ]
 tot = [0.0, 0.0]
 for cin, cout, k, st, pd, (t, h, w) in layers:
