@@ -69,6 +69,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kPlane = 64 * 256;  // one plane of one operand: [64 positions][128 channels x 2 B]
+// BUF forms (tensors below 4 GB): the position tables hold BYTE offsets of rows, kRowOob for "no row"; a thread adds its channel's
+// bytes and loads through a buffer resource, whose bounds check returns zeros — see the pipelined tile below
+constexpr unsigned kRowOob = 0xFFF00000u;  // (+ a channel offset of < 1 MB stays beyond every buffer and does not wrap)
 
 // byte offset of 16-byte chunk `ch` (8 channels) of position row `row`: 256-byte rows, chunks XOR-swizzled so that the row
 // writes and the transposed reads are both conflict-free (cdna_hip_programming.md T10, image (b))
@@ -87,7 +90,7 @@ __device__ __forceinline__ void put4(char* lds, int hi_base, int off, float4 v) 
 }
 
 // SWAP = false: the 128-wide axis is x's (tap, ci), the BN-wide one dy's co; true: the other way round (Cout > taps * Cin).
-template <int BN, bool SWAP>
+template <int BN, bool SWAP, bool BUF>
 __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
   constexpr int BM = 128;
   constexpr int WTM = BN == 32 ? 32 : 64;
@@ -136,21 +139,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // table entries: element offsets, -1 = none; BUF: byte offsets, kRowOob = none
+  const int none = BUF ? (int)kRowOob : -1;
+  auto enc = [](int elem) { return BUF ? (int)(4u * (unsigned)elem) : elem; };
   auto decode = [&](int slab, int buf) {  // thread -> position tid & 63, taps (tid >> 6), + 4, + 8, ...
     const int p = tid & 63, m = slab * 64 + p;
     const bool ok = m < a.M;
+    if (BUF && a.pointwise) {  // 1x1x1, stride 1, no padding: output position m reads input row m
+      if (tid < 64) {
+        ytab[buf * 64 + p] = ok ? enc(m * a.ldy) : none;
+        xtab[(buf * 64 + p) * a.tapcap] = ok ? enc(m * a.ldx) : none;
+      }
+      return;
+    }
     const int q1 = (int)fastdiv((uint32_t)(ok ? m : 0), a.dWo), wo = (ok ? m : 0) - q1 * a.Wo;
     const int q2 = (int)fastdiv((uint32_t)q1, a.dHo), ho = q1 - q2 * a.Ho;
     const int bb = (int)fastdiv((uint32_t)q2, a.dTo), to = q2 - bb * a.To;
-    if (tid < 64) ytab[buf * 64 + p] = ok ? m * a.ldy : -1;
+    if (tid < 64) ytab[buf * 64 + p] = ok ? enc(m * a.ldy) : none;
     for (int tap = tid >> 6; tap < a.taps; tap += 4) {
       const int t1 = (int)fastdiv((uint32_t)tap, a.dKW), dw_ = tap - t1 * a.KW;
       const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
       const int ti = to * a.st - a.pt + dt, hi = ho * a.sh - a.ph + dh, wi = wo * a.sw - a.pw + dw_;
       const bool in = ok && (unsigned)ti < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      xtab[(buf * 64 + p) * a.tapcap + tap] = in ? (((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx : -1;
+      xtab[(buf * 64 + p) * a.tapcap + tap] = in ? enc((((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx) : none;
     }
   };
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
   float4 rq[RQ], sq[SQ];
   unsigned rmask = 0u, smask = 0u;  // which pieces are real (the others are zeroed when they are staged, not when they are loaded)
   // Table reads first, all of them, then the 16-byte loads, all unconditional (an out-of-range piece reads the tensor's
@@ -169,6 +184,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
       const int idx = q * 256 + tid, p = idx / (BN / 4);
       if constexpr (SWAP) srow[q] = xtab[(buf * 64 + p) * a.tapcap + (xtap[q] < 0 ? 0 : xtap[q])];
       else srow[q] = ytab[buf * 64 + p];
+    }
+    if constexpr (BUF) {  // one add + one select per piece; out-of-range pieces come back as zeros (rmask / smask stay all-ones)
+      rmask = smask = 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) {
+        const int idx = q * 256 + tid, c = r0 + 4 * (idx & 31);
+        const bool col = SWAP ? c < a.Cout : xtap[q] >= 0;
+        const unsigned off = col ? (unsigned)rrow[q] + 4u * (unsigned)(SWAP ? c : xci[q]) : kRowOob;
+        rq[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(SWAP ? rsy : rsx, (int)off, 0, 0));
+      }
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int idx = q * 256 + tid, c = s0 + 4 * (idx % (BN / 4));
+        const bool col = SWAP ? xtap[q] >= 0 : c < a.Cout;
+        const unsigned off = col ? (unsigned)srow[q] + 4u * (unsigned)(SWAP ? xci[q] : c) : kRowOob;
+        sq[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(SWAP ? rsx : rsy, (int)off, 0, 0));
+      }
+      return;
     }
     rmask = smask = 0u;
 #pragma unroll
@@ -208,12 +241,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
       const int idx = q * 256 + tid, p = idx >> 5, cq = idx & 31;
-      put4(lds, R_HI, swz(p, cq >> 1) + 8 * (cq & 1), (rmask >> q) & 1u ? rq[q] : make_float4(0.f, 0.f, 0.f, 0.f));
+      put4(lds, R_HI, swz(p, cq >> 1) + 8 * (cq & 1), (BUF || ((rmask >> q) & 1u)) ? rq[q] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
 #pragma unroll
     for (int q = 0; q < SQ; ++q) {
       const int idx = q * 256 + tid, p = idx / (BN / 4), cq = idx % (BN / 4);
-      put4(lds, S_HI, swz(p, cq >> 1) + 8 * (cq & 1), (smask >> q) & 1u ? sq[q] : make_float4(0.f, 0.f, 0.f, 0.f));
+      put4(lds, S_HI, swz(p, cq >> 1) + 8 * (cq & 1), (BUF || ((smask >> q) & 1u)) ? sq[q] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   };
   // transposed-read addresses at k-slice 0 (T10: lane 4q + p of a 16-lane group supplies row q, channels 4p .. 4p + 3 of
@@ -313,8 +346,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
   (void)y0;
 }
 
+extern int g_wgrad_buf;
+template <int BN, bool SWAP, bool BUF>
+int launch_b(WgArgs& a, int s_count, hipStream_t st);
+
 template <int BN, bool SWAP>
 int launch(WgArgs& a, int s_count, hipStream_t st) {
+  const bool fits32 = g_wgrad_buf && a.x_bytes != 0u && a.dy_bytes != 0u && a.ldx < (1 << 17) && a.ldy < (1 << 17);
+  return fits32 ? launch_b<BN, SWAP, true>(a, s_count, st) : launch_b<BN, SWAP, false>(a, s_count, st);
+}
+
+template <int BN, bool SWAP, bool BUF>
+int launch_b(WgArgs& a, int s_count, hipStream_t st) {
   a.s_tiles = (s_count + BN - 1) / BN;
   const int tiles = a.r_tiles * a.s_tiles;
   // split over positions: enough workgroups to fill the chip (256 CUs x 2), but at least 16 slabs each — a workgroup's
@@ -331,7 +374,7 @@ int launch(WgArgs& a, int s_count, hipStream_t st) {
   static_assert(128 * (BN + 1) * 4 <= lds_small, "the swapped epilogue stages its tile over the operand planes (and tables)");
   static_assert(lds_small <= 80 * 1024, "two workgroups per CU");
   const int lds_bytes = a.tapcap > kMaxTaps ? lds_big : lds_small;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<BN, SWAP>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<BN, SWAP, BUF>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
   if (e != hipSuccess) {
     avt::set_error("avt_conv3d_wgrad_x3_f32: hipFuncSetAttribute(%d B LDS): %s", lds_big, hipGetErrorString(e));
@@ -339,7 +382,7 @@ int launch(WgArgs& a, int s_count, hipStream_t st) {
   }
   const int64_t grid = (int64_t)tiles * a.nchunk;
   AVT_REQUIRE(grid < (1ll << 31), "avt_conv3d_wgrad_x3_f32: grid too large");
-  hipLaunchKernelGGL((wgrad_x3_kernel<BN, SWAP>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((wgrad_x3_kernel<BN, SWAP, BUF>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
   return avt::check_launch("avt_conv3d_wgrad_x3_f32");
 }
 
@@ -357,7 +400,6 @@ int launch(WgArgs& a, int s_count, hipStream_t st) {
 // tensor or past the chunk) — a thread adds its channel's bytes and the hardware bounds check returns zeros: no per-piece mask
 // registers, no selects in front of the ds_writes, 32-bit address arithmetic (the tile is VALU-bound: ~315 vector instructions per
 // wave and 32-position step against 24 MFMAs, counted in the ISA).
-constexpr unsigned kRowOob = 0xFFF00000u;  // (+ a channel offset of < 1 MB stays beyond every buffer and does not wrap)
 constexpr int XP = 32;                 // positions per step
 constexpr int XPL = XP * 256;          // one 128-channel plane of a stage: [32 positions][256 B]
 constexpr int XSTAGE = 6 * XPL;        // R0 hi | R0 lo | R1 hi | R1 lo | S hi | S lo
@@ -647,6 +689,7 @@ int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
 
 // which tile avt_conv3d_wgrad_x3_f32 launches for (longer axis, shorter axis, taps, positions): 1 = the 256 x 128 tile
 int g_wgrad_xl = 1;  // (avt_wgrad_x3_set_xl: A/B switch for tools and tests; the shipped default is on)
+int g_wgrad_buf = 1;     // (avt_wgrad_x3_set_xl(5) / (6): the phase-serial tile's buffer-load form off / on — off is what tensors of 4 GB and more get)
 int g_wgrad_narrow = 1;  // (avt_wgrad_x3_set_xl(3) / (4): the 64- and 32-wide pipelined forms on / off under mode 1)
 // g_wgrad_xl: 1 = where it measured faster; 2 = every layer, at the S width that fits (tests, probes); 0 = never
 // -> the S width of the pipelined tile to launch (128 / 64 / 32), or 0 for the 128-wide phase-serial tile
@@ -654,11 +697,12 @@ static int wgrad_xl_picked(bool swap, int r_count, int s_count, int taps, int sp
   if (!(taps <= kMaxTaps && m >= 64 * XP && fits32) || g_wgrad_xl == 0) return 0;
   const int sw = s_count > 64 ? 128 : (s_count > 32 ? 64 : 32);
   if (g_wgrad_xl >= 2) return sw;
-  // mode 1, by profiles/r05/probe_wgrad_xl.log (its last table): every layer with more than 64 on the shorter axis (+11 ... +56 %);
-  // 33-64: the pointwise and temporal-tap layers (+13 ... +28 %), not the [1,3,3] ones (64 -> 64 at 56 x 56: -9 %); the 32-wide
-  // form loses on the 8-channel layers (-22 ... -39 %) and wins on few small ones: tests / probes only
-  if (sw == 128) return 128;
-  return (g_wgrad_narrow && sw == 64 && spatial_taps == 1) ? 64 : 0;
+  // mode 1, by profiles/r05/probe_wgrad_xl.log (its last table, both tiles on buffer loads): the pipelined tile wins on the
+  // pointwise and temporal-tap layers (+3 ... +31 %) and is equal or behind on the [1,3,3] ones (0 ... -2 %; 64 -> 64 at 56 x 56:
+  // -22 %) and on the short-axis-heavy 128 x 384 layer (-7 %); its 32-wide form loses on the 8-channel layers: tests / probes only
+  if (spatial_taps != 1) return 0;
+  if (sw == 128) return r_count >= 512 ? 128 : 0;
+  return (g_wgrad_narrow && sw == 64 && r_count >= 224) ? 64 : 0;
 }
 
 template <bool SWAP>
@@ -731,6 +775,10 @@ extern "C" int avt_wgrad_x3_set_xl(int on) {
   if (on == 3 || on == 4) {  // (probes: mode 1 with / without the narrow pipelined forms)
     g_wgrad_xl = 1;
     g_wgrad_narrow = on == 3 ? 1 : 0;
+    return was;
+  }
+  if (on == 5 || on == 6) {  // (tests: the phase-serial tile without / with buffer loads; the tile mode stays)
+    g_wgrad_buf = on == 6 ? 1 : 0;
     return was;
   }
   g_wgrad_xl = on < 0 ? 0 : (on > 2 ? 2 : on);

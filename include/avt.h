@@ -601,10 +601,13 @@ int avt_conv3d_igemm_x3_f32_ex(const float* in, const void* wt_hi, const void* w
 int avt_conv3d_wgrad_x3_f32(const float* dy, const float* x, float* dw, int batch, int t, int h, int w, int cin, int cout,
                             int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ldx, int ldy,
                             void* stream);
-/* Tile choice of the weight gradient (round 5): layers with >= 256 on their longer axis ((tap, ci) or cout), >= 128 on the shorter and
- * <= 28 taps run on a 256 x 128 tile whose global loads, bf16 split + LDS stage and MFMAs overlap inside one 8-wave workgroup (32-position
- * steps, two LDS stages, loads two steps ahead).  avt_wgrad_x3_set_xl: 1 (default) = only where it measured faster (not swapped, >= 1024
- * on the (tap, ci) axis, >= 256 output channels), 2 = every layer it can take (tests, probes), 0 = never.  -> the previous setting. */
+/* Tile choice of the weight gradient (round 5).  Two tiles: the phase-serial one (128 x {128, 64, 32} outputs, 64-position slabs, two
+ * workgroups per CU) and the pipelined one (256 x {128, 64, 32} outputs, 8 waves; global loads two 32-position steps ahead, bf16 split +
+ * LDS stage and MFMAs overlapped inside the workgroup; <= 28 taps).  Tensors below 4 GB are read with buffer loads (position tables of
+ * byte offsets, hardware zero fill); larger ones by the phase-serial tile with plain loads.
+ * avt_wgrad_x3_set_xl: 1 (default) = the pipelined tile where it measured faster (pointwise / temporal-tap layers with >= 512 x 65 or
+ * >= 224 x 33 on the longer x shorter axis), 2 = on every layer at the width that fits (tests, probes), 0 = never; 3 / 4 = mode 1 with /
+ * without its 64-wide form; 5 / 6 = the phase-serial tile's buffer-load form off / on (tile mode unchanged).  -> the previous mode. */
 int avt_wgrad_x3_set_xl(int on);
 /* The general form of avt_conv3d_wgrad_x3_f32: input channels in multiples of 4 (the SlowFast stems' 3 channels travel as 4:
  * ldx may be wider than cin), up to 49 taps ([1,7,7]), an explicit output extent (to, ho, wo; 0 = the symmetric-padding

@@ -221,10 +221,14 @@ def test_stem_patch_path_follows_the_optimizer_and_can_be_switched_off():
     (40, 72, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 41, 43)),        # E = 360 (2 R tiles), cout 72 -> 128-wide S, strided
     (16, 48, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 5, 15, 16)),        # E = 48, cout 48: equal axes, 64-wide S tile
 ])
-def test_weight_gradient_kernel_edges(cin, cout, kernel, stride, pad, dims):
+@pytest.mark.parametrize("mode", ["pipelined", "serial", "serial-plain-loads"])
+def test_weight_gradient_kernel_edges(cin, cout, kernel, stride, pad, dims, mode):
+    """mode: every layer on the pipelined tile at the S width that fits / on the phase-serial 128-wide tile with buffer loads / the
+    same with plain loads and mask registers (what tensors of 4 GB and more get) — the default picks among them by measurement."""
     from avtex import _lib, ops
     torch.manual_seed(cin)
-    _lib.lib().avt_wgrad_x3_set_xl(2)  # (every layer the 256 x 128 tile can take runs on it here; the default picks by measurement)
+    _lib.lib().avt_wgrad_x3_set_xl(2 if mode == "pipelined" else 0)
+    _lib.lib().avt_wgrad_x3_set_xl(5 if mode == "serial-plain-loads" else 6)
     b, t, h, w = dims
     x = torch.randn(b, cin, t, h, w, device=DEV)
     wgt = torch.randn(cout, cin, *kernel, device=DEV, requires_grad=True)
@@ -235,6 +239,7 @@ def test_weight_gradient_kernel_edges(cin, cout, kernel, stride, pad, dims):
     ops.conv3d_wgrad_x3_f32(gy.permute(0, 2, 3, 4, 1).contiguous(), x.permute(0, 2, 3, 4, 1).contiguous(), dw, (b, t, h, w), cin, cout,
                             kernel, stride, pad, cin, cout)
     _lib.lib().avt_wgrad_x3_set_xl(1)
+    _lib.lib().avt_wgrad_x3_set_xl(6)
     exp = wgt.grad.permute(0, 2, 3, 4, 1)
     err = float((dw - exp).norm()) / float(exp.norm())
     assert err < 1e-4, err
