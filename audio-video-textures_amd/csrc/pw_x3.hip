@@ -1103,7 +1103,8 @@ extern "C" int avt_pw_x3_f32_stats(const float* x, int ldx, int k, const void* w
 // avt_conv3d_igemm_x3_f32_bwdstats for the pointwise layers)
 extern "C" int avt_pw_x3_f32_bwdstats_rows(int k, int n, int64_t m, int groups) {
   if (!avt_pw_x3_f32_supported(k, n) || groups < 1 || m <= 0 || m % groups || n < 8 || (n & (n - 1)) || n > 4096) return -1;
-  const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  if (nt1 == 16) nt1 = 8;  // (as the launch below)
   const int ntiles = (int)((m / groups + 15) / 16);
   return pf_row_groups(pf_lds_of(k1s, nt1, 2), n / (16 * nt1), ntiles, groups) * PX_NW;
 }
@@ -1121,7 +1122,10 @@ extern "C" int avt_pw_x3_f32_bwdstats(const float* x, int ldx, int k, const void
   AVT_REQUIRE(avt::aligned16(x) && avt::aligned16(w_hi) && avt::aligned16(w_lo) && avt::aligned16(y) && avt::aligned16(stat_part) &&
                   avt::aligned16(bn_x) && (!add || avt::aligned16(add)),
               "avt_pw_x3_f32_bwdstats: pointers must be 16-byte aligned");
-  const int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  int k1s = (k + 31) / 32, nt1 = pick_nt1(k1s, n);
+  // (16 tiles per wave spill 13-84 registers in this mode, and a scratch reload's s_waitcnt vmcnt(0) serializes the tile's loads: 8
+  //  tiles and twice the chunks — the dy rows read twice, a small operand here — are 10 % (K = 64) to 27 % (K = 128) faster)
+  if (nt1 == 16) nt1 = 8;
   PfArgs a;
   a.x = x; a.add = add; a.y = y;
   a.wh = static_cast<const uint16_t*>(w_hi);
