@@ -15,7 +15,7 @@ from avtex import _lib, ops, synth, train_ops  # noqa: E402
 from avtex.dataset import DeviceSegmentBatcher  # noqa: E402
 from avtex.slowfast import SlowFast  # noqa: E402
 
-ROWS = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])  # key -> [calls, ms, flops, bytes]
+ROWS = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0, 0.0])  # key -> [calls, ms, flops, bytes, longest call ms]
 ON = [False]
 
 
@@ -29,7 +29,9 @@ def timed(key, fn, flops, nbytes):
     e1.synchronize()
     row = ROWS[key]
     row[0] += 1
-    row[1] += e0.elapsed_time(e1)
+    ms = e0.elapsed_time(e1)
+    row[1] += ms
+    row[4] = max(row[4], ms)
     row[2] += flops
     row[3] += nbytes
     return r
@@ -198,7 +200,7 @@ def main():
         cat[k.split()[0]] += r[1]
     print("  by kind: " + ", ".join("%s %.1f ms" % kv for kv in sorted(cat.items(), key=lambda kv: -kv[1])))
     for k, r in sorted(ROWS.items(), key=lambda kv: -kv[1][1])[:110]:
-        print("  %7.3f ms x%-2d %-84s %6.1f TF/s %6.0f GB/s" % (r[1], r[0], k, r[2] / r[1] * 1e-9, r[3] / r[1] * 1e-6))
+        print("  %7.3f ms x%-2d %-84s %6.1f TF/s %6.0f GB/s  longest %.3f" % (r[1], r[0], k, r[2] / r[1] * 1e-9, r[3] / r[1] * 1e-6, r[4]))
 
 
 if __name__ == "__main__":
