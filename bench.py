@@ -25,8 +25,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (before the HIP runtime initialises: see audio-video-textures_amd/__init__.py)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -441,6 +443,15 @@ def train_bench(args, rank, world, dev):
 
     B, negs, fps = 8, 14, 30.0
     assert B % world == 0, "the batch of 8 items splits over 1, 2, 4 or 8 ranks"
+    if getattr(args, "train_extra_streams", 0) > 0:
+        # (diagnostic: other users of HIP streams in the process — a collective library's, another engine's — take hardware queues:
+        #  GPU_MAX_HW_QUEUES is 4 by default, and a stream that shares a queue waits for its neighbour; profiles/r05/trainleg_order.log)
+        extra = [torch.cuda.Stream(device=dev) for _ in range(args.train_extra_streams)]
+        for st in extra:
+            with torch.cuda.stream(st):
+                torch.zeros(1024, device=dev).add_(1.0)
+        torch.cuda.synchronize()
+        args._extra_streams = extra  # (kept alive)
     video = synth.structured_video(123 + rank, 1500, args.frame_hw, args.frame_hw)
     dargs = SimpleNamespace(vdata="/tmp", adata=None, n_negs=negs, img_size=224, enc_arch="slowfast", window=0, stride=0)
     torch.manual_seed(5)
@@ -637,6 +648,8 @@ def build_parser():
     ap.add_argument("--no-precision-block", action="store_true")
     ap.add_argument("--no-nxn-legs", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the 2-step config-5 training leg of the default run")
+    ap.add_argument("--train-extra-streams", type=int, default=0,
+                    help="(diagnostic) --mode train: create N more HIP streams with work on them before the step's own streams exist")
     ap.add_argument("--train-leg-idle", type=float, default=0.0, help="(diagnostic) seconds of idle before the config-5 leg of the default run")
     ap.add_argument("--no-inputs-r03-leg", action="store_true", help="skip the short second leg on round 3's inputs (value_inputs_r03)")
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
