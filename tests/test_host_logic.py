@@ -554,3 +554,18 @@ def test_concatenation_protocol_host_side(avt):
     a2, b2 = train_ops._alias(buf, 0, 8), torch.randn(2, 4, 3, 4, 5)
     a2._avt_cat, b2._avt_cat = (buf, 0), (torch.zeros_like(buf), 8)
     assert torch.equal(train_ops.join_channels(a2, b2), torch.cat([a2, b2], 1))
+
+
+def test_hardware_queue_default_is_set_before_hip_initialises():
+    """The package asks for 8 HIP hardware queues unless the environment already says otherwise (profiles/r05/hw_queues.log: the
+    three-stream training step shares queues with any other stream of the process on HIP's default of 4)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.path.insert(0, %r); import avtex; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % root
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "8"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "4"
