@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int* const ytab = reinterpret_cast<int*>(lds + YTAB);  // [2][64]: element offset of a position's dy row, -1 = none
   int* const xtab = reinterpret_cast<int*>(lds + XTAB);  // [2][64][tapcap]: ... of its x row under every tap, -1 = padding
+  int* const ttab = xtab + 2 * 64 * a.tapcap;            // [taps]: dt | dh << 8 | dw << 16, once per workgroup (two divisions per tap and
+                                                         // slab otherwise: the tile is bound by its vector instructions)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -157,8 +159,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
     const int bb = (int)fastdiv((uint32_t)q2, a.dTo), to = q2 - bb * a.To;
     if (tid < 64) ytab[buf * 64 + p] = ok ? enc(m * a.ldy) : none;
     for (int tap = tid >> 6; tap < a.taps; tap += 4) {
-      const int t1 = (int)fastdiv((uint32_t)tap, a.dKW), dw_ = tap - t1 * a.KW;
-      const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
+      const int pk = ttab[tap], dt = pk & 255, dh = (pk >> 8) & 255, dw_ = pk >> 16;
       const int ti = to * a.st - a.pt + dt, hi = ho * a.sh - a.ph + dh, wi = wo * a.sw - a.pw + dw_;
       const bool in = ok && (unsigned)ti < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
       xtab[(buf * 64 + p) * a.tapcap + tap] = in ? enc((((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx) : none;
@@ -295,6 +296,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(WgArgs a) {
     }
   };
 
+  for (int tap = tid; tap < a.taps; tap += 256) {
+    const int t1 = (int)fastdiv((uint32_t)tap, a.dKW), dw_ = tap - t1 * a.KW;
+    const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
+    ttab[tap] = dt | (dh << 8) | (dw_ << 16);
+  }
+  __syncthreads();
   if (slab0 < slab1) {
     decode(slab0, slab0 & 1);
     __syncthreads();
@@ -369,8 +376,8 @@ int launch_b(WgArgs& a, int s_count, hipStream_t st) {
   if (chunks < 1) chunks = 1;
   a.slabs_per_chunk = (a.nslab + chunks - 1) / chunks;
   a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
-  constexpr int lds_small = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTaps * 4;
-  constexpr int lds_big = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTapsBig * 4;
+  constexpr int lds_small = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTaps * 4 + 64 * 4;  // (+ the tap table)
+  constexpr int lds_big = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTapsBig * 4 + 64 * 4;
   static_assert(128 * (BN + 1) * 4 <= lds_small, "the swapped epilogue stages its tile over the operand planes (and tables)");
   static_assert(lds_small <= 80 * 1024, "two workgroups per CU");
   const int lds_bytes = a.tapcap > kMaxTaps ? lds_big : lds_small;
@@ -431,6 +438,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   unsigned* const ytab = reinterpret_cast<unsigned*>(lds + XTABS);   // [4][32] byte offsets of dy rows
   unsigned* const xtab = ytab + 4 * XP;                              // [4][32][tapcap] ... of x rows under every tap
+  int* const ttab = reinterpret_cast<int*>(xtab + 4 * XP * kMaxTaps); // [taps]: dt | dh << 8 | dw << 16 (see the 128-wide tile)
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
 
@@ -482,8 +490,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
     const int bb = (int)fastdiv((uint32_t)q2, a.dTo), to = q2 - bb * a.To;
     if (tid < XP) ytab[slot * XP + p] = ok ? 4u * (unsigned)(m * a.ldy) : kRowOob;
     for (int tap = tid >> 5; tap < a.taps; tap += 16) {
-      const int t1 = (int)fastdiv((uint32_t)tap, a.dKW), dw_ = tap - t1 * a.KW;
-      const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
+      const int pk = ttab[tap], dt = pk & 255, dh = (pk >> 8) & 255, dw_ = pk >> 16;
       const int ti = to * a.st - a.pt + dt, hi = ho * a.sh - a.ph + dh, wi = wo * a.sw - a.pw + dw_;
       const bool in = ok && (unsigned)ti < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
       xtab[(slot * XP + p) * a.tapcap + tap] = in ? 4u * (unsigned)((((bb * a.T + ti) * a.H + hi) * a.W + wi) * a.ldx) : kRowOob;
@@ -609,6 +616,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_xl_kernel(WgArgs a) {
     lstore(std::integral_constant<int, P ^ 1>{}, nxt);  // step s + 1's data, requested during step s - 1
   };
 
+  if (tid < a.taps) {
+    const int t1 = (int)fastdiv((uint32_t)tid, a.dKW), dw_ = tid - t1 * a.KW;
+    const int dt = (int)fastdiv((uint32_t)t1, a.dKH), dh = t1 - dt * a.KH;
+    ttab[tid] = dt | (dh << 8) | (dw_ << 16);
+  }
+  __syncthreads();
   decode(st0);
   decode(st0 + 1);
   decode(st0 + 2);
@@ -673,7 +686,7 @@ int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
   a.slabs_per_chunk = (a.nslab + chunks - 1) / chunks;
   a.slabs_per_chunk += a.slabs_per_chunk & 1;  // (the kernel walks its steps in pairs)
   a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
-  constexpr int lds_bytes = XTABS + 4 * XP * 4 + 4 * XP * kMaxTaps * 4;
+  constexpr int lds_bytes = XTABS + 4 * XP * 4 + 4 * XP * kMaxTaps * 4 + 64 * 4;  // (+ the tap table)
   static_assert(128 * 129 * 4 <= XTABS && lds_bytes <= 160 * 1024, "the swapped epilogue's staging and the whole layout fit");
   static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_xl_kernel<SWAP, SW>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
