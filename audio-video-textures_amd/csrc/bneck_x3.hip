@@ -192,6 +192,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
   }
   const int cchunk = (CMP == 16 ? (q & 1) : q) * 16;  // c: this lane's k-group inside a b-strip record
   int b_rd[CIT];
+  constexpr bool CO_RECOMPUTE = F16 && C == 128 && CIN == 128 && ST == 1;  // (see the c stage)
   unsigned c_out[CIT];  // byte offset inside an output frame (one plane) of this lane's 8 channels of pair 0, or out of bounds
   unsigned s_off[STR ? CIT : 1];  // strided form: byte offset inside an x frame of the shortcut's operand chunk (k-step 0)
   const int Ho = a.H / ST;
@@ -398,6 +399,21 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
       const i32x4 fl = *reinterpret_cast<const i32x4*>(bol + pr * AREC + cchunk);
       int lofs = lane * 16;
       asm volatile("" : "+v"(lofs));
+      // this tile's output offset.  In the instance that keeps c_out[] in SPILLED registers (C = CIN = 128, fp16 planes: 168 registers,
+      // 2 spilled) every use was a scratch reload, and the s_waitcnt vmcnt(0) its result needs ALSO waits for the ~37 loads of the next
+      // frames the wave has in flight — twice per frame; there the offset is recomputed from an opaque copy of the lane index instead
+      unsigned co_it;
+      if constexpr (CO_RECOMPUTE) {
+        int l15o = l15;
+        asm volatile("" : "+v"(l15o));
+        const int p = m * 16 + l15o;
+        const bool ok = m < MTB && p < PB;
+        const int pc = ok ? p : PB - 1;
+        const int r = pc / WO, w = pc - r * WO;
+        co_it = (ok && h0 + r < Ho) ? (unsigned)((((h0 + r) * WO + w) * C + 8 * q) * 2) : kOob;
+      } else {
+        co_it = c_out[it];
+      }
 #pragma unroll
       for (int np = 0; np < NTC / 2; ++np) {
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
@@ -441,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void bneck_x3_kernel(BxArgs 
           avt::split2<F16>(v[4], v[5], oh.z, ol.z);
           avt::split2<F16>(v[6], v[7], oh.w, ol.w);
         }
-        const int off = (int)(c_out[it] != kOob ? obase + c_out[it] + (unsigned)(np * 64) : kOob);
+        const int off = (int)(co_it != kOob ? obase + co_it + (unsigned)(np * 64) : kOob);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, oh), roh, off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ol), rol, off, 0, 0);
       }
