@@ -569,3 +569,34 @@ def test_hardware_queue_default_is_set_before_hip_initialises():
     env["GPU_MAX_HW_QUEUES"] = "4"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "4"
+
+
+def test_isa_loop_tools_read_a_loop(tmp_path, capsys, monkeypatch):
+    """tools/diag/isa_loop_summary.py / isa_loop_mix.py on a hand-made listing: the loop is found by its backward branch, the
+    wait in front of the ds_write shows up between the runs of loads and MFMAs, the mix counts by instruction class."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    listing = "\n".join([
+        "_ZN12_GLOBAL__N_18toy_kernelEv:",
+        "\ts_load_dwordx2 s[0:1], s[4:5], 0x0",
+        ".LBB0_1:",
+        "\tbuffer_load_dwordx4 v[0:3], v8, s[0:3], 0 offen",
+        "\tbuffer_load_dwordx4 v[4:7], v9, s[0:3], 0 offen",
+        "\tv_mfma_f32_32x32x16_bf16 v[16:31], v[10:13], v[12:15], v[16:31]",
+        "\tv_add_u32_e32 v8, 64, v8",
+        "\ts_waitcnt vmcnt(0)",
+        "\tds_write_b128 v40, v[0:3]",
+        "\ts_cbranch_scc1 .LBB0_1",
+        "\ts_endpgm",
+    ])
+    path = tmp_path / "toy.s"
+    path.write_text(listing)
+    for name in ("isa_loop_summary", "isa_loop_mix"):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", "diag", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        monkeypatch.setattr(sys, "argv", [name, str(path), "toy_kernel"])
+        mod.main()
+    out = capsys.readouterr().out
+    assert "vmload x2" in out and "s_waitcnt vmcnt(0)" in out and "ds_write x1" in out  # the summary
+    assert "'mfma': 1" in out and "'valu': 1" in out and "'vmem': 2" in out and "v_add_u32 x1" in out  # the mix
