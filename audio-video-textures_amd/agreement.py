@@ -66,7 +66,21 @@ def compare_tables(qa, ta, qb, tb, temp, W, S, thresholds=(0.0, 0.3), walk_frame
             steps_same += first_diff
             steps += m
             lists_same += int(fa == fb)
+        # threshold 0.0 keeps the candidates that TIE with the row maximum (validate.py:553).  Where the fp32 reference itself has
+        # exact ties (two candidates with bit-identical scores: e.g. windows whose features are all dead embed to one constant
+        # vector), which of them another arithmetic calls equal is decided in the last bit: such rows are counted apart, and on
+        # them the question is whether A's survivors are a SUBSET of the reference's tie set (A picked among the tied ones)
+        tie_rows = np.nonzero(host[1]["cnt"] > 1)[0] if th == 0.0 else np.zeros(0, dtype=np.int64)
+        same_h = same.cpu().numpy()
+        no_tie = np.ones(n, dtype=bool)
+        no_tie[tie_rows] = False
+        subset = sum(1 for r in tie_rows if set(host[0]["seg"][r, : host[0]["cnt"][r]].tolist()) <= set(host[1]["seg"][r, : host[1]["cnt"][r]].tolist()))
+        ties = {} if th != 0.0 else {
+            "rows_with_exact_ties_ref": int(len(tie_rows)),
+            "rows_identical_survivors_outside_tie_rows": float(same_h[no_tie].mean()) if no_tie.any() else 1.0,
+            "tie_rows_survivors_subset_of_ref_ties": "%d/%d" % (subset, len(tie_rows))}
         out["thresholds"]["%.1f" % th] = {
+            **ties,
             "rows_identical_survivors": float(same.float().mean()),
             "mean_survivors": float(rb["cnt"].float().mean()),
             "walk_steps_identical_before_first_divergence": steps_same / max(steps, 1),

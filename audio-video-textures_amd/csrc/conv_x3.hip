@@ -1118,6 +1118,15 @@ static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_
                     avt::aligned16(stat_part),
                 "avt_conv3d_igemm_x3_f32_stats: %d rows in %d groups, %d channels of %d columns, no row remap, no add operand", a.M,
                 stat_groups, stat_c, cout);
+    // pixel-grouped form (stat_c < cout: column n is channel n % stat_c): stat_fold_store folds the pixel copies of a channel
+    // INSIDE one N tile and writes the channel's slot with a plain store — two N tiles of one M tile would overwrite each
+    // other's partial sums, so every copy of a channel must lie in the launch's single N tile
+    {
+      const int bn_launch = (!bst && a.oH == 0 && io32_tile_rows(cout, a.K, a.M) == 256) ? 256 : (cout <= 32 ? 32 : (cout <= 64 ? 64 : 128));
+      AVT_REQUIRE(stat_c == cout || cout <= bn_launch,
+                  "avt_conv3d_igemm_x3_f32_stats: %d pixel copies of %d channels span more than one %d-column tile", cout / stat_c, stat_c,
+                  bn_launch);
+    }
     if (bst) {  // backward statistics: the BatchNorm input has the output's geometry, contiguous rows
       AVT_REQUIRE(bst->bst_x && bst->bst_mean && bst->bst_invstd && bst->bst_gamma && ldo == cout && avt::aligned16(bst->bst_x) &&
                       (!bst->bst_relu || bst->bst_mask || bst->bst_beta),

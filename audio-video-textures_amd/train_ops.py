@@ -175,16 +175,20 @@ class _JoinChannels(torch.autograd.Function):
         # one of them would corrupt the others' saved activations without autograd noticing).  The version counters are stamped
         # here and compared in backward, so that such an edit raises instead of training on garbage.
         out = _alias(buf, 0, buf.shape[1])  # the buffer both producers wrote, as a tensor of this node's own
-        ctx.stamp = ((a, a._version), (b, b._version), (out, out._version))
+        # (the joined tensor by weak reference: a strong one is the cycle out -> grad_fn -> ctx -> out, which only backward broke —
+        #  a grad-enabled forward that is never backpropagated kept the whole buffer until the cyclic collector ran)
+        ctx.stamp = ((a, a._version), (b, b._version))
+        ctx.out_ref, ctx.out_version = weakref.ref(out), out._version
         return out
 
     @staticmethod
     def backward(ctx, d):
-        for t, v in ctx.stamp:
+        out = ctx.out_ref()
+        for t, v in ctx.stamp + (((out, ctx.out_version),) if out is not None else ()):
             if t._version != v:
                 raise RuntimeError("train_ops.join_channels: a channel slice of the concatenation buffer (or the joined tensor) was "
                                    "modified in place after the join; the slices share storage outside autograd's view tracking")
-        ctx.stamp = None
+        ctx.stamp = ctx.out_ref = None
         return d[:, : ctx.c0], d[:, ctx.c0 :], None
 
 
@@ -254,10 +258,13 @@ class _BNAct(torch.autograd.Function):
         x, mask, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         m, c = _rows(x)
         pre = _BWD_STATS.pop(dy.data_ptr(), None) if _BWD_STATS else None
+        # (autograd frees saved_tensors after backward but never ctx.__dict__ — the handle holds x and the mask, so it
+        #  is dropped here, before anything else can keep the node alive through the next step's forward)
+        handle, ctx.handle = ctx.handle, None
         # (valid only for the very tensor the launch wrote: autograd sums gradients that reach a tensor by several paths — into a
         #  new tensor, or IN PLACE into one of them, which the version counter shows; a summed gradient takes the plain passes
         #  below, where masking an already masked part again changes nothing)
-        if (pre is not None and pre[2] is ctx.handle and dy._version == pre[3] and dy.shape == x.shape and dy.dtype == torch.float32 and
+        if (pre is not None and pre[2] is handle and dy._version == pre[3] and dy.shape == x.shape and dy.dtype == torch.float32 and
                 dy.is_contiguous(memory_format=torch.channels_last_3d)):
             # dy is ALREADY g = mask * dz, and its producer (the input-gradient launch of the convolution that consumed this
             # BatchNorm's output) left the sums of g and g * xhat behind: finalize + apply; the shortcut's gradient is g itself
@@ -566,6 +573,8 @@ def _grouped_planes(weight, g, transposed, plane_dtype):
     return planes
 
 
+_STAT_GROUP_COLS = 128  # widest pixel-grouped output (g * cout columns) whose BatchNorm statistics ride on the epilogue: the copies of
+#                         a channel must share one N tile (csrc/conv_args.h stat_fold_store; conv_x3.hip rejects wider forms)
 _LAST_STATS = None  # (output data_ptr, workspace, rows of partials per group, groups, channels) of the last convolution that left
 #                     BatchNorm statistics behind: handed from inside the autograd Function to conv3d(), which tags the output
 
@@ -592,7 +601,8 @@ def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=No
         addr = None if add is None else add.permute(0, 2, 3, 4, 1)
         if group is not None:
             g, gk, rg = group
-            st = ops.conv3d_igemm_x3_f32_bwdstats(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], y.permute(0, 2, 3, 4, 1),
+            # (pixel-grouped statistics fold a channel's pixel copies inside ONE N tile of <= 128 columns: wider forms keep the pass)
+            st = None if g * cout > _STAT_GROUP_COLS else ops.conv3d_igemm_x3_f32_bwdstats(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], y.permute(0, 2, 3, 4, 1),
                                                   _ktab(g * cin, gk, h, w // g, g * cin, x.device), (b, t, h, w // g), g * cin, g * cout, gk,
                                                   (pad[0], pad[1], rg), plane_dtype, _bwd_bn_args(bwd_bn), bwd_bn.groups, cout, add=addr)
         elif (_PW_F32 and tuple(kernel) == (1, 1, 1) and tuple(pad) == (0, 0, 0) and x.numel() // cin < (1 << 31) - 16 and
@@ -611,7 +621,7 @@ def _conv_x3_rows(x, planes, plane_dtype, cin, cout, kernel, stride, pad, add=No
             return y
     if group is not None:  # (g, grouped kernel, rg): the same memory as [.., w / g, g * C] rows, block-Toeplitz planes
         g, gk, rg = group
-        if stats:
+        if stats and g * cout <= _STAT_GROUP_COLS:
             ws, pre_rows = ops.conv3d_igemm_x3_f32_stats(x.permute(0, 2, 3, 4, 1), planes[0], planes[1], planes[2], y.permute(0, 2, 3, 4, 1),
                                                          _ktab(g * cin, gk, h, w // g, g * cin, x.device), (b, t, h, w // g), g * cin, g * cout,
                                                          gk, (1, 1, 1), (pad[0], pad[1], rg), g * cin, g * cout, plane_dtype, stats, cout)
@@ -742,6 +752,7 @@ def _conv_backward(ctx, dy, dalias):
                 dy.numel() < (1 << 30) - 64):
             CALLS["dgrad_x3"] += 1
             hb = getattr(ctx, "bn_in", None)  # x is a fused BatchNorm's output: dx is that BatchNorm's output gradient
+            ctx.bn_in = None  # (the handle holds that BatchNorm's input and mask: not past this backward)
             if hb is not None and not (_EPI_BWD and hb.c == cin and tuple(hb.x.shape) == tuple(x.shape) and x.shape[0] % hb.groups == 0):
                 hb = None
             g = _group_factor(cout, cin, kernel, (1, 1, 1), padding, dy.shape[4])

@@ -681,3 +681,89 @@ def test_summed_gradients_do_not_take_the_fused_backward_statistics():
     a, e = run(1), run(0)
     assert a[2]["bn_bwd_pre"] == 0 and a[2]["dgrad_bwdstats"] == 2  # both launches masked their part; the sum took the plain passes
     assert float((a[0] - e[0]).norm() / e[0].norm()) < 5e-6 and float((a[1] - e[1]).norm() / e[1].norm()) < 5e-6
+
+
+@pytest.mark.parametrize("direction", ["fwd", "bwd"])
+def test_pixel_grouped_statistics_wider_than_a_tile_keep_the_statistics_pass(direction):
+    """the pixel-grouped form folds a channel's pixel copies inside ONE N tile (csrc/conv_args.h stat_fold_store).  With
+    g * C > 128 columns (Conv3d(16, 64, [1,3,3]): g = 4 -> 256 columns; the input gradient of a 64 -> 16 layer likewise) two N tiles
+    would overwrite each other's partial sums, so these layers must keep the BatchNorm's own statistics pass — and give the numbers
+    of the two-pass path."""
+    import torch.nn as nn
+
+    from avtex import train_ops
+
+    dev = "cuda:0"
+    torch.manual_seed(11)
+    cin, cout = (16, 64) if direction == "fwd" else (64, 16)
+    b, t, h, w = 4, 2, 12, 16
+    x0 = (torch.randn(b, cin, t, h, w, device=dev) * 1.5 + 0.4).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(epi):
+        torch.manual_seed(7)
+        conv = nn.Conv3d(cin, cout, (1, 3, 3), padding=(0, 1, 1), bias=False).to(dev).to(memory_format=torch.channels_last_3d).train()
+        bn = nn.BatchNorm3d(cout if direction == "fwd" else cin).to(dev).train()
+        x = x0.clone().requires_grad_(True)
+        keep = (train_ops._EPI_STATS, train_ops._EPI_BWD)
+        train_ops._EPI_STATS = train_ops._EPI_BWD = epi
+        for k in train_ops.CALLS:
+            train_ops.CALLS[k] = 0
+        try:
+            with train_ops.bn_replicas(2):
+                if direction == "fwd":
+                    y = train_ops.bn_act(train_ops.conv3d(x, conv, stats=bn), bn, relu=True)
+                else:
+                    y = train_ops.conv3d(train_ops.bn_act(x, bn, relu=True), conv)
+            y.square().sum().backward()
+        finally:
+            train_ops._EPI_STATS, train_ops._EPI_BWD = keep
+        return y.detach(), x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad, dict(train_ops.CALLS)
+
+    a, e = run(1), run(0)
+    assert a[5]["bn_fwd_pre"] == 0 and a[5]["bn_bwd_pre"] == 0 and a[5]["dgrad_bwdstats"] == 0, a[5]  # the fused forms were NOT taken
+    for k in range(5):
+        assert torch.equal(a[k], e[k]), k
+    # ... and the statistics are right: against torch's own BatchNorm on the same convolution output
+    torch.manual_seed(7)
+    conv = nn.Conv3d(cin, cout, (1, 3, 3), padding=(0, 1, 1), bias=False).to(dev).train()
+    bn = nn.BatchNorm3d(cout if direction == "fwd" else cin).to(dev).train()
+    xs = x0.contiguous().chunk(2, 0)
+    ref = torch.cat([torch.relu(bn(conv(v))) if direction == "fwd" else conv(torch.relu(bn(v))) for v in xs], 0)
+    assert float((a[0] - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
+def test_backward_releases_what_the_batchnorm_handles_hold():
+    """_BNAct / _ConvX3 kept a _BnHandle (the BatchNorm's fp32 input and ReLU mask) as plain ctx attributes, which
+    autograd never frees — with the loss still referenced, every fused BatchNorm's input of step k stayed allocated through step
+    k + 1's forward.  After backward(), with the loss and the output alive, only the output, the loss and the gradients remain."""
+    import gc
+
+    from avtex import train_ops
+    from avtex.slowfast import ResBlock
+
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    blocks = [ResBlock(64, 64, 16, 3, 1).to(dev).to(memory_format=torch.channels_last_3d).train() for _ in range(3)]
+    x = torch.randn(2, 64, 4, 24, 24, device=dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    for _ in range(2):  # (the first pass sizes the caches: weight planes, workspaces, tap tables)
+        for m in blocks:
+            m.zero_grad(set_to_none=True)
+        x.grad = None
+        gc.collect()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        with train_ops.bn_replicas(1):
+            y = x
+            for m in blocks:
+                y = m(y)
+        loss = y.square().mean()
+        torch.cuda.synchronize()
+        peak_fwd = torch.cuda.memory_allocated() - base
+        loss.backward()
+        torch.cuda.synchronize()
+        held = torch.cuda.memory_allocated() - base
+    grads = sum(p.grad.numel() * 4 for m in blocks for p in m.parameters() if p.grad is not None) + x.grad.numel() * 4
+    expect = y.numel() * 4 + grads
+    act = x.numel() * 4  # one full-width activation
+    assert peak_fwd > expect + 4 * act  # (the forward did keep activations: the test can see a leak)
+    assert held <= expect + act, (held, expect, act)  # at most one activation's worth of allocator slack / cached workspaces

@@ -286,6 +286,38 @@ def test_contract_on_the_same_frames(avt, dev):
         assert d["thresholds"][th]["frames_lists_identical"] == "3/3", d
 
 
+def test_th0_exact_ties_on_the_config4_calibration(avt, dev):
+    """Threshold 0.0 keeps the candidates that tie EXACTLY with the row maximum (validate.py:553-554).  bench.py --config 4 /
+    --windows 2048 calibrates the synthetic BatchNorms on 8 clips spread over 2048 windows, which leaves a block of the first 128
+    windows with every feature dead: they embed to one constant vector and the fp32 reference ITSELF has rows with several
+    bit-identical maxima — there a "0/3 frames lists at th 0.0" says nothing about the kernels.  This pins
+    what does hold on that calibration: outside the reference's tie rows every row's survivors are identical; on the tie rows the
+    contract-grade survivors are picked among the reference's tied candidates; th 0.3 is identical everywhere."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from avtex import agreement
+    from avtex.fused_slowfast import SlowFastMFMA
+
+    args = bench.build_parser().parse_args(["--windows", "2048"])
+    video, q_mod, t_mod = bench.build_inputs(args, 0, dev)
+    n, W, S = 128, 20, 4
+    sub = video[: n * S + W]
+    q32, t32 = _tables(dev, sub, q_mod.float(), t_mod.float(), W, S, 16)
+    qv, tv = _tables(dev, sub, SlowFastMFMA(q_mod, dev, precision="f16x3"), SlowFastMFMA(t_mod, dev, precision="f16x3"), W, S, 32)
+    r = agreement.compare_tables(qv, tv, q32, t32, 0.1, W, S)
+    print("TH0-TIES " + json.dumps(r))
+    t0, t3 = r["thresholds"]["0.0"], r["thresholds"]["0.3"]
+    assert r["max_abs_dscore"] < 1e-4, r
+    assert t0["rows_with_exact_ties_ref"] > 0, "the calibration no longer produces exact ties in the fp32 reference: re-derive this test"
+    assert t0["rows_identical_survivors_outside_tie_rows"] == 1.0, r
+    k, m = (int(v) for v in t0["tie_rows_survivors_subset_of_ref_ties"].split("/"))
+    assert m == t0["rows_with_exact_ties_ref"] and k >= 0.9 * m, r
+    assert t3["rows_identical_survivors"] == 1.0 and t3["frames_lists_identical"] == "3/3", r
+
+
 @pytest.mark.parametrize("bad", [float("nan"), float("inf")])
 def test_x3_fp16_planes_propagate_nan_and_inf(avt, dev, bad):
     """A poisoned activation must reach the output: the fp16-plane split clamps FINITE values to 65504 but keeps a NaN a NaN

@@ -530,6 +530,51 @@ def test_committed_pmc_summary_resolves_the_headline_kernels_traffic():
     assert not missing, missing
 
 
+def test_committed_roofline_follows_from_the_committed_rocprof_stats():
+    """the roofline of the committed bench line must be reproducible from the committed profile of the SAME
+    command — tools/roofline_from_rocprof.py divides the per-symbol algorithmic flops per step (bench_detail) by the profiler's
+    total duration of that symbol; the dominant kernel's fraction in the line (HIP events, sampled in the run) agrees within 5 %."""
+    import importlib.util
+
+    prof_dir = os.path.join(ROOT, "profiles", "r06")
+    stats, detail = os.path.join(prof_dir, "rocprof_kernel_stats.csv"), os.path.join(prof_dir, "bench_detail_profiled.json")
+    if not (os.path.exists(stats) and os.path.exists(detail)):
+        pytest.skip("no committed round-6 profile pair")
+    spec = importlib.util.spec_from_file_location("roofline_from_rocprof", os.path.join(ROOT, "tools", "roofline_from_rocprof.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.recompute(stats, detail)
+    dom = out["dominant"]
+    assert dom is not None and dom["rocprof_achieved"], out
+    assert abs(dom["rocprof_frac"] / out["line_frac"] - 1.0) < 0.05, (dom, out["line_frac"])
+    # every encoder symbol of the line resolves to profiler rows, and the launches the line counts are the launches the profiler saw
+    for r in out["rows"]:
+        assert r["rocprof_achieved"], r
+        assert abs(r["rocprof_calls_per_step"] / r["bench_launches_per_step"] - 1.0) < 0.02, r
+    # the breakdown sums to about the wall time (the sampler extrapolates by clips from full batches)
+    import json
+
+    head = json.load(open(detail))["headline"]
+    b = head["breakdown_ms_per_step"]
+    assert 0.9 < sum(v for k, v in b.items() if k != "wall") / b["wall"] < 1.1, b
+
+
+def test_bench_symbol_matching_names():
+    import bench
+
+    xl = "void (anonymous namespace)::conv_x3_xl_kernel<true, false, false>((anonymous namespace)::ConvArgs)"
+    assert bench.symbol_matches("conv_x3_xl_kernel<f16>", xl, "f16x3") and not bench.symbol_matches("conv_x3_xl_kernel<f16>", xl, "bf16x3")
+    pw = "void (anonymous namespace)::pw_x3_kernel<8, 8, true>((anonymous namespace)::PxArgs)"
+    assert bench.symbol_matches("pw_x3_kernel<f16>", pw, "f16x3") and not bench.symbol_matches("pw_x3_kernel<bf16>", pw, "f16x3")
+    ct = "void (anonymous namespace)::conv_x3_kernel<128, 128, 64, true, false, false>((anonymous namespace)::ConvArgs)"
+    assert bench.symbol_matches("conv_x3_kernel<128,128,64,f16>", ct, "f16x3")
+    assert not bench.symbol_matches("conv_x3_kernel<128,64,64,f16>", ct, "f16x3")
+    st = "void (anonymous namespace)::stem_kernel<7, false, 2>((anonymous namespace)::StemArgs)"
+    assert bench.symbol_matches("stem_kernel<x3>", st, "f16x3") and not bench.symbol_matches("stem_kernel", st, "f16x3")
+    pc = "void (anonymous namespace)::pw_chain_x3_kernel<2, 16, 4, true>((anonymous namespace)::PcArgs)"
+    assert bench.symbol_matches("pw_chain_x3_kernel", pc, "f16x3") and not bench.symbol_matches("pw_x3_kernel<f16>", pc, "f16x3")
+
+
 def test_concatenation_protocol_host_side(avt):
     """train_ops.join_channels / _row_ld / _alias (the in-place lateral fusion of the training step): on the CPU — where no
     producer tags its output — the join is torch.cat; the row-pitch detector accepts channel slices of channels-last tensors

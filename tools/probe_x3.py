@@ -17,6 +17,9 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+for arg in sys.argv[4:]:  # e.g. pwskip=256x1024: that pointwise layer leaves the streaming kernel for the general / 256 x 256 tile
+    if arg.startswith("pwskip="):
+        fsf._PW_X3_SKIP = set(fsf._PW_X3_SKIP) | {tuple(int(v) for v in p.split("x")) for p in arg[7:].split(",")}
 m = fsf.SlowFastMFMA(SlowFast(), dev, precision=mode)
 pd = fsf.PRECISIONS[mode]
 if len(sys.argv) > 3 and sys.argv[3] == "table":  # the product's input form: every distinct frame packed once + the windows' index

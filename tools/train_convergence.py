@@ -72,9 +72,20 @@ def train_run(mode, args, dev, video, keep=False):
     labels = torch.zeros(B, dtype=torch.long, device=dev)
     losses, t_steps, top1 = [], [], []
     torch.cuda.synchronize()
-    for it in range(args.steps):
+    # --epochs E: the reference's own loop shape — every epoch walks a shuffled permutation of the segments in
+    # batches of 8 (main.py:195-198, DataLoader shuffle), the epoch loss is the mean of its steps' losses (train.py:210) and
+    # training STOPS when it falls below --stop-loss (main.py:475-477: `if loss < 0.07: break`)
+    per_epoch = (len(ds) // B) if args.epochs else 0
+    n_steps = args.epochs * per_epoch if args.epochs else args.steps
+    epoch_loss, stopped_at, perm = [], None, None
+    for it in range(n_steps):
         t0 = time.perf_counter()
-        ids = [int(i) for i in rng.randint(0, len(ds), size=B)]
+        if args.epochs:
+            if it % per_epoch == 0:
+                perm = rng.permutation(len(ds))
+            ids = [int(i) for i in perm[(it % per_epoch) * B : (it % per_epoch + 1) * B]]
+        else:
+            ids = [int(i) for i in rng.randint(0, len(ds), size=B)]
         q, t, _, _ = bat.batch(torch.tensor(ids))
         q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
         opt.zero_grad(set_to_none=True)
@@ -92,6 +103,12 @@ def train_run(mode, args, dev, video, keep=False):
                   file=sys.stderr, flush=True)
         if not np.isfinite(losses[-1]):
             break
+        if args.epochs and (it + 1) % per_epoch == 0:
+            epoch_loss.append(float(np.mean(losses[-per_epoch:])))
+            print("[%s] epoch %d loss %.4f" % (mode, len(epoch_loss) - 1, epoch_loss[-1]), file=sys.stderr, flush=True)
+            if epoch_loss[-1] < args.stop_loss:
+                stopped_at = len(epoch_loss) - 1
+                break
     ema, e = [], None
     for v in losses:
         e = v if e is None else 0.9 * e + 0.1 * v
@@ -101,6 +118,9 @@ def train_run(mode, args, dev, video, keep=False):
            "ms_per_step_median": float(np.median(t_steps[5:]) * 1e3) if len(t_steps) > 5 else None,
            "max_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
            "calls": {k: v for k, v in train_ops.CALLS.items() if v}}
+    if args.epochs:
+        rec.update({"segments": len(ds), "steps_per_epoch": per_epoch, "epoch_loss": epoch_loss, "stop_loss": args.stop_loss,
+                    "stopped_at_epoch": stopped_at, "epochs_run": len(epoch_loss)})
     for k in train_ops.CALLS:
         train_ops.CALLS[k] = 0
     if keep:
@@ -210,6 +230,9 @@ def main():
     ap.add_argument("--frames", type=int, default=1500)
     ap.add_argument("--frame-hw", type=int, default=128)
     ap.add_argument("--scene-len", type=int, default=24, help="frames per scene of the synthetic video (24 = bench.py's)")
+    ap.add_argument("--epochs", type=int, default=0, help="epoch mode: at most this many epochs over a shuffled permutation of the segments "
+                    "(batches of 8), stopping at the reference's rule (epoch loss < --stop-loss, main.py:475-477); 0 = --steps random batches")
+    ap.add_argument("--stop-loss", type=float, default=0.07)
     ap.add_argument("--roundtrip", action="store_true")
     ap.add_argument("--workdir", default="/tmp/avt_train_convergence")
     ap.add_argument("--against", default=None, help="a recorded result of this tool (same config): the largest EMA distance of each "
