@@ -121,6 +121,9 @@ SIGNATURES = {
     "avt_conv33_x3": [_vp] * 6 + [C.c_int] * 8 + [_vp],
     "avt_bneck_x3_supported": [C.c_int] * 3,
     "avt_bneck_x3": [_vp] * 6 + [C.c_int] * 8 + [_vp],
+    "avt_res2_x3_supported": [C.c_int] * 3,
+    "avt_res2_x3_wfrag_bytes": [],
+    "avt_res2_x3": [_vp] * 6 + [C.c_int] * 7 + [_vp],
     "avt_conv3d_igemm_wfrag_supported": [C.c_int] * 5,
     "avt_conv3d_igemm_wfrag_bf16": [_vp] * 6 + [C.c_int] * 25 + [_vp, C.c_int, _vp],
 }
@@ -155,7 +158,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 7  # include/avt.h AVT_ABI_VERSION
+ABI_VERSION = 8  # include/avt.h AVT_ABI_VERSION
 _RETURNS_I64 = {"avt_bn_train_ws_bytes", "avt_bn_train_ws_bytes_pre"}  # sizes; every other entry returns an AVT_* status
 
 

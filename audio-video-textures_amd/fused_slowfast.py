@@ -38,6 +38,7 @@ _CHAIN_X3 = 1        # contract grade: slow res2 c (+ residual) -> next a in one
 _WBLK_X3 = 1         # contract grade: K-blocked weight planes for the 256 x 256 tile
 _STEM_FM_X3 = 1      # contract grade: frame-major tiles in the time-grouped fast stem
 _C33_X3 = 1          # contract grade: slow res2 b conv on the direct-operand kernel (csrc/conv33_x3.hip)
+_RES2_X3 = 1         # contract grade (fp16 planes): slow res2 identity bottlenecks as ONE kernel, weights streamed (csrc/res2_x3.hip)
 _PW_X3 = 1           # contract grade: pointwise layers on the streaming kernel (csrc/pw_x3.hip)
 _STEM_LDS = 1        # both: the stems on the patch-resident kernel (csrc/stem_conv.hip)
 _STEM_POOL = 1       # bf16: max-pool fused into the stem kernel: 1 = the slow stem (one frame tap), 2 = both (the MFMA-bound fast
@@ -629,6 +630,57 @@ def pack_c33_x3(wb, bias, x3, device):
     return wfrag, coef
 
 
+def pack_res2_x3(wa, ba, wb, bb, wc, bc, x3, device):
+    """BN-folded weights of a slow-res2 identity bottleneck (wa [64,256,1,1,1], wb [64,64,1,3,3], wc [256,64,1,1,1]) -> csrc/res2_x3.hip's
+    (wfrag, coef) (include/avt.h avt_res2_x3): the weight STREAM of 17 chunks x 8 pairs x 2 planes of 32 x 32 x 16 MFMA operands in the
+    order the kernel consumes them, output rows permuted as pack_c33_x3's (a lane of the accumulator ends with runs of 8 consecutive
+    channels); fp16 planes: every output channel scaled by a power of two into [2^9, 2^10), undone by coef's scales."""
+    wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]
+    cm, c = wa.shape[0], wc.shape[0]
+    assert (cm, c) == (64, 256) and wa.shape[1] == c and tuple(wb.shape) == (cm, cm, 1, 3, 3) and wc.shape[1] == cm
+
+    def scale_of(w):
+        if x3 != ops.X3_F16:
+            return torch.ones(w.shape[0])
+        mx = w.reshape(w.shape[0], -1).abs().amax(dim=1).clamp_min(1e-30)
+        return torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
+
+    sa, sb, sc = scale_of(wa), scale_of(wb), scale_of(wc)
+    a2 = wa.reshape(cm, c) * sa.view(-1, 1)                       # [64, 256]
+    b9 = wb[:, :, 0].reshape(cm, cm, 9) * sb.view(-1, 1, 1)       # [out, in, tap]
+    c2 = wc.reshape(c, cm) * sc.view(-1, 1)                       # [256, 64]
+    lane = torch.arange(64)
+    rho, kh = lane & 31, lane >> 5
+    h = (rho >> 2) & 1
+    r = (rho & 3) + 4 * (rho >> 3)
+    chan = (2 * (r >> 3) + h) * 8 + (r & 7)                       # channel of an n-tile an operand row feeds
+    e = torch.arange(8)
+
+    def frag(mat, n, k):  # mat [out, K] -> [64 lanes, 8]: lane l holds mat[32 n + chan(l & 31)][16 k + 8 (l >> 5) + e]
+        rows = (32 * n + chan).view(-1, 1).expand(64, 8)
+        cols = (16 * k + 8 * kh).view(-1, 1) + e.view(1, -1)
+        return mat[rows, cols]
+
+    pairs = []
+    for jc in range(4):          # a: chunk jc = k-slices 4 jc .. + 3, pair index 2 kk + n
+        for kk in range(4):
+            for n in range(2):
+                pairs.append(frag(a2, n, 4 * jc + kk))
+    for t in range(9):           # b: one tap per chunk, pair index 2 k + n
+        for k in range(4):
+            for n in range(2):
+                pairs.append(frag(b9[:, :, t], n, k))
+    for jc in range(4):          # c: chunk jc = n-tiles 2 jc, 2 jc + 1, pair index 4 nn + k
+        for nn in range(2):
+            for k in range(4):
+                pairs.append(frag(c2, 2 * jc + nn, k))
+    allf = torch.stack(pairs)    # [136, 64, 8] fp32
+    hi, lo = split_planes(allf, x3)
+    wfrag = torch.stack([hi, lo], 1).contiguous().to(device)  # [136 pairs][2 planes][64][8]
+    coef = torch.cat([1.0 / sa, ba, 1.0 / sb, bb, 1.0 / sc, bc]).float().contiguous().to(device)
+    return wfrag, coef
+
+
 def pack_pw(w, device):
     """BN-folded pointwise weights [N, K(,1,1,1)] -> csrc/pw_chain.hip's fragments [N/16][ceil(K/32)][64][8]: output
     rows permuted so a lane ends with 8 consecutive channels (include/avt.h), K zero-padded to whole 32-wide k-steps."""
@@ -859,6 +911,15 @@ class _BlockX3:
         if (_C33_X3 and self.fused is None and self.b.kernel == (1, 3, 3) and self.b.stride == (1, 1, 1) and
                 self.b._folded is not None and ops.conv33_x3_supported(self.b.cin, self.b.cout)):
             self.c33 = pack_c33_x3(self.b._folded[0], self.b._folded[1], x3, device)
+        # slow res2's identity blocks (256 -> 64 -> [1,3,3] 64 -> 256 at width 56): the whole bottleneck in ONE kernel, the weights
+        # streamed from L2 (csrc/res2_x3.hip, round 6; fp16 planes)
+        self.res2 = None
+        if (_RES2_X3 and x3 == ops.X3_F16 and self.fused is None and self.b1 is None and self.a.kernel == (1, 1, 1) and
+                self.a.stride == (1, 1, 1) and self.b.kernel == (1, 3, 3) and self.b.stride == (1, 1, 1) and self.c.kernel == (1, 1, 1) and
+                self.c.stride == (1, 1, 1) and self.a.cin == self.c.cout and all(v._folded is not None for v in (self.a, self.b, self.c)) and
+                ops.res2_x3_supported(self.c.cout, self.a.cout, 56)):
+            (wa, ba), (wb, bb), (wc, bc) = self.a._folded, self.b._folded, self.c._folded
+            self.res2 = pack_res2_x3(wa, ba, wb, bb, wc, bc, x3, device)
         self.ccat, self.extra = None, 0
         if (_FUSE_KCAT and self.b1 is not None and self.fused is None and self.a.kernel == (1, 1, 1) and
                 self.c.kernel == (1, 1, 1) and self.b1.kernel == (1, 1, 1) and self.a.stride == (1, 1, 1) and
@@ -871,6 +932,8 @@ class _BlockX3:
     def can_chain(self, nxt):
         """True when this block's c (+ residual + ReLU) and the next block's a (+ ReLU) run as ONE pointwise pass
         (csrc/pw_x3.hip, the chained form): both pointwise on the streaming kernel, identity shortcut here."""
+        if self.res2 is not None or (nxt is not None and nxt.res2 is not None):
+            return False  # (a block that runs as one kernel neither hands its c to a chain nor takes its a from one)
         return (_CHAIN_X3 and nxt is not None and self.b1 is None and self.fused is None and nxt.fused is None and
                 getattr(self.c, "pw", None) is not None and getattr(nxt.a, "pw", None) is not None and nxt.ccat is None and
                 nxt.a.cin == self.c.cout and ops.pw_chain_x3_supported(self.c.cin, self.c.cout, nxt.a.cout))
@@ -898,6 +961,21 @@ class _BlockX3:
                 PROFILER("pw_chain_x3_kernel", launch, rows * (self.c.alg_flops_per_row + chain.a.alg_flops_per_row),
                          4.0 * rows * (self.c.cin + 2 * self.c.cout + chain.a.cout))
             return y, z
+        if (self.res2 is not None and chain is None and a_pre is None and x.lo is not None and x.C == self.a.cin and
+                ops.res2_x3_supported(self.c.cout, self.a.cout, x.dims[3])):
+            b, t, h, w = x.dims
+            rows = b * t * h * w
+            y = out if out is not None else new_act(rows, self.c.cout, x.dims, self.dev, True)
+
+            def launch():
+                ops.res2_x3(x.ptrs, x.ld, y.ptrs, y.ld, self.res2, b, t, h, w, self.x3)
+
+            if PROFILER is None:
+                launch()
+            else:
+                fl = rows * (self.a.alg_flops_per_row + self.b.alg_flops_per_row + self.c.alg_flops_per_row)
+                PROFILER("res2_x3_kernel", launch, fl, 4.0 * rows * 2 * self.c.cout)
+            return y
         if (self.fused is not None and out is None and x.c0 == 0 and x.ld == x.C and
                 ops.bneck_x3_supported(x.C, self.c.cout, x.dims[3]) and x.dims[2] % self.st == 0):
             b, t, h, w = x.dims

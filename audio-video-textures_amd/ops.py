@@ -821,6 +821,24 @@ def conv33_x3(x_ptrs, packed, out_ptrs, batch, t, h, w, ldi, ldo, plane_dtype, r
                                         int(bool(relu)), int(plane_dtype), _stream()), "avt_conv33_x3")
 
 
+def res2_x3_supported(c, cm, w):
+    return bool(_lib.lib().avt_res2_x3_supported(int(c), int(cm), int(w)))
+
+
+def res2_x3(x_ptrs, ldi, out_ptrs, ldo, packed, batch, t, h, w, plane_dtype):
+    """One identity bottleneck of the slow pathway's res2 stage (256 -> 64 -> 64 -> 256 at width 56) on plane pairs in ONE kernel
+    (csrc/res2_x3.hip): the a output in an LDS ring, b's in registers, the weights streamed from L2; packed =
+    fused_slowfast.pack_res2_x3(...) = (wfrag, coef); raw plane addresses, row pitches in elements."""
+    wfrag, coef = packed
+    _dev(wfrag, "wfrag", torch.bfloat16)
+    _dev(coef, "coef", torch.float32)
+    if wfrag.numel() * 2 != _lib.lib().avt_res2_x3_wfrag_bytes():
+        raise _lib.AvtError("res2_x3: wfrag holds %d bytes, the kernel streams %d" % (wfrag.numel() * 2, _lib.lib().avt_res2_x3_wfrag_bytes()))
+    _lib.check(_lib.lib().avt_res2_x3(C.c_void_p(x_ptrs[0]), C.c_void_p(x_ptrs[1]), C.c_void_p(out_ptrs[0]), C.c_void_p(out_ptrs[1]),
+                                      _p(wfrag), _p(coef), int(batch), int(t), int(h), int(w), int(ldi), int(ldo), int(plane_dtype),
+                                      _stream()), "avt_res2_x3")
+
+
 def bneck_x3_supported(cin, c, w):
     return bool(_lib.lib().avt_bneck_x3_supported(int(cin), int(c), int(w)))
 

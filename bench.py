@@ -454,8 +454,9 @@ def train_bench(args, rank, world, dev):
     from avtex.main import wrap_ddp
     from avtex.slowfast import SlowFast
 
-    B, negs, fps = 8, 14, 30.0
-    assert B % world == 0, "the batch of 8 items splits over 1, 2, 4 or 8 ranks"
+    B, negs, fps = int(getattr(args, "train_items", 0) or 8), 14, 30.0
+    # (--train-items 1: ONE item = 16 clips per step and rank — config 5's real per-rank shape on 8 GPUs)
+    assert B % world == 0, "the batch of %d items does not split over %d ranks" % (B, world)
     if getattr(args, "train_extra_streams", 0) > 0:
         # (diagnostic: other users of HIP streams in the process — a collective library's, another engine's — take hardware queues:
         #  GPU_MAX_HW_QUEUES is 4 by default, and a stream that shares a queue waits for its neighbour; profiles/r05/trainleg_order.log)
@@ -592,13 +593,13 @@ def train_bench(args, rank, world, dev):
     hand = channels_last and args.train_dtype == "fp32"  # the hand-written split-plane convolution passes ran (train_ops.py)
     peak = (2500.0 / 3 if hand else 157.3) if args.train_dtype == "fp32" else 2500.0
     return {
-        "metric": "contrastive training (train.py) InfoNCE negs=14 temp=0.1, batch of 8 items: encoder clips/s through forward+backward",
+        "metric": "contrastive training (train.py) InfoNCE negs=14 temp=0.1, batch of %d items: encoder clips/s through forward+backward" % B,
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": total_s / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         # the arithmetic of the convolutions, not a precision claim: fp32 tensors in and out, products from 16-bit planes
         "dtype": ("x3 (f16 fwd / bf16 grad planes, fp32 I/O)" if (channels_last and args.train_dtype == "fp32") else args.train_dtype),
         "data": "synthetic",
-        "config": {"workload": "BASELINE config 5: batch 8 x (1 query + 1 positive + 14 negatives) = 128 clips/step at 224^2 "
+        "config": {"workload": "BASELINE config 5: batch %d x (1 query + 1 positive + 14 negatives) = %d clips/step at 224^2 " % (B, B * 16) +
                                "through SlowFast-8x8-R50 q/t encoders (train-mode BatchNorm per item = per DataParallel "
                                "replica), HIP InfoNCE + CE, SGD; inputs sampled and packed on the device",
                    "items_per_rank": items, "items_per_pass": plan["per_pass"], "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
@@ -606,7 +607,8 @@ def train_bench(args, rank, world, dev):
                                        "stride-1 dgrad, wgrad_x3, patch-resident stems (forward + weight gradient), bn_train; query encoder on a side stream; "
                                        "strided input gradients as residue-class convolutions, HIP max-pool; the rank's items as one batch of per-item BatchNorm groups") if hand
                    else "MIOpen convolutions through autograd (%s%s)" % (args.train_dtype, ", channels_last_3d" if channels_last else ""),
-                   "parallelism": "dp%d, gradient all-reduce once per step" % world},
+                   "parallelism": ("dp%d: DistributedDataParallel (avtex.main.wrap_ddp) — bucketed gradient all-reduce started under the "
+                                   "backward of the rank's last pass, earlier passes under no_sync" % world) if world > 1 else "single GPU"},
         "training_steps_per_s": args.steps / total_s, "items_per_s": B * args.steps / total_s,
         "max_memory_allocated_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         "loss_first_last": [losses[0], losses[-1]],
@@ -680,6 +682,10 @@ def build_parser():
                          "BatchNorm's own statistics pass (0: for A/Bs)")
     ap.add_argument("--train-pathway-streams", type=int, default=None, choices=[0, 1],
                     help="--mode train: the target encoder's fast pathway on a side stream (slowfast.PATHWAY_STREAMS; default: the module's)")
+    ap.add_argument("--train-items", type=int, default=0,
+                    help="--mode train: items of the global batch (0 = 8, BASELINE config 5); 1 = one item = 16 clips per step: the shape "
+                         "every rank of an 8-GPU run of config 5 sees (the default run reports it as train_clips_per_s_one_item)")
+    ap.add_argument("--no-train-one-item-leg", action="store_true", help="skip the one-item config-5 leg of the default run")
     ap.add_argument("--train-pass-items", type=int, default=0,
                     help="--mode train: items per forward/backward pass (0 = all of the rank's items as one batch with per-item "
                          "BatchNorm groups; 1 = one pass per item, round 2's loop)")
@@ -862,6 +868,16 @@ def main():
         detail["train"] = tl
         out["train_clips_per_s"], out["train_ms_per_step"] = tl["value"], tl["ms_per_step"]
         note("training leg (config 5, 6 timed steps) done")
+        if not args.no_train_one_item_leg:
+            # config 5 at its real per-rank shape: batch 8 over 8 GPUs = ONE item (16 clips) per rank and step
+            gc.collect()
+            torch.cuda.empty_cache()
+            t1 = argparse.Namespace(**vars(targs))
+            t1.train_items, t1.steps, t1.warmup = 1, 12, 4
+            tl1 = train_bench(t1, rank, world, dev)
+            detail["train_one_item"] = tl1
+            out["train_clips_per_s_one_item"], out["train_ms_per_step_one_item"] = tl1["value"], tl1["ms_per_step"]
+            note("one-item training leg (16 clips per step) done")
     emit(out, detail)
 
 
@@ -925,7 +941,9 @@ def baseline_metric():
 # the encoder streams run their batches back to back and are joined once per step (texture.TextureEngine.run_encoders(join=False))
 JOIN_EVERY_BATCH = False
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "pmc_fetch_write_summary.json")  # written by tools/gpu_profile_round.sh r05
+# written by tools/gpu_profile_round.sh rNN: the newest committed round's summary
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", r, "pmc_fetch_write_summary.json") for r in ("r06", "r05")) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r05", "pmc_fetch_write_summary.json"))
 PMC_BATCH = 249  # the encoder batch tools/pmc_kernels.py launches at
 
 
@@ -977,7 +995,7 @@ def attach_pmc_traffic(kern, args, precision):
         sym = table.get(k["kernel"], k["kernel"])
         k["traffic"] = kb(sym)
         if k["traffic"]:
-            k["traffic_source"] = "profiles/r05/pmc_fetch_write_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
+            k["traffic_source"] = os.path.relpath(PMC_SUMMARY, ROOT) + " (2*FETCH_SIZE + WRITE_SIZE per launch)"
 
 
 def cpu_baseline(video, q_mod, t_mod, W, S, N, D, temp, args):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 7  /* 7: BatchNorm statistics on the producing convolution's epilogue: avt_conv3d_igemm_x3_f32_stats, avt_bn_train_fwd_pre (round 5); 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4); 6: avt_pw_x3_f32 (round 4) */
+#define AVT_ABI_VERSION 8  /* 8: avt_res2_x3 (round 6); 7: BatchNorm statistics on the producing convolution's epilogue: avt_conv3d_igemm_x3_f32_stats, avt_bn_train_fwd_pre (round 5); 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4); 6: avt_pw_x3_f32 (round 4) */
 
 typedef enum {
   AVT_OK = 0,
@@ -384,6 +384,24 @@ int avt_conv33_x3(const void* x_hi, const void* x_lo, const void* wfrag, const f
 int avt_bneck_x3_supported(int cin, int c, int w);
 int avt_bneck_x3(const void* x_hi, const void* x_lo, void* out_hi, void* out_lo, const void* wfrag, const float* coef,
                  int batch, int t, int h, int w, int cin, int c, int tchunk, int plane_dtype, void* stream);
+
+/* One IDENTITY bottleneck of the SlowFast SLOW pathway's res2 stage in ONE kernel on plane pairs (csrc/res2_x3.hip, round 6; the
+ * blocks s2.pathway0_res1 / _res2 of the third-party SlowFast model the reference runs per clip window, models/models.py:335, 399 —
+ * round 5 ran them as three launches avt_pw_x3 / avt_conv33_x3 / avt_pw_chain_x3):
+ *     out = relu(c(relu(b(relu(a(x))))) + x),  a: 1x1x1 256 -> 64, b: [1,3,3] 64 -> 64, c: 1x1x1 64 -> 256, BatchNorms folded.
+ * x [batch*t*h*w, ldi], out [., ldo] plane pairs (channel slices of wider rows allowed; distinct buffers); fp16 planes only.
+ * The a output lives in an LDS ring, b's output in registers; x crosses HBM once (+ one re-read from L2 / Infinity Cache as the
+ * residual), out once; the weights STREAM from L2 by LDS-DMA.  wfrag = avt_res2_x3_wfrag_bytes() bytes: [17 chunks][8 pairs]
+ * [2 planes: hi, lo][64 lanes][8] 16-bit, a pair = one 32-row x 16-k MFMA operand: lane l holds W[channel(l & 31)][16 k + 8 (l >> 5)
+ * + e] with channel(rho) = 32 n + (2 (r >> 3) + h) * 8 + (r & 7), h = (rho >> 2) & 1, r = (rho & 3) + 4 (rho >> 3) (avt_conv33_x3's
+ * row order).  Chunks 0-3: a, pair (kk, n) = k-slice 4 chunk + kk, n-tile n, at index 2 kk + n; chunks 4-12: b, one tap each, pair
+ * (k, n) at 2 k + n; chunks 13-16: c, pair (nn, k) = n-tile 2 (chunk - 13) + nn, k-slice k, at 4 nn + k.  coef fp32 [sa 64 | ba 64 |
+ * sb 64 | bb 64 | sc 256 | bc 256]: the power-of-two factors that undo the fp16 planes' per-channel weight scaling, and the biases.
+ * Supported: w = 56 (and 12: tests), any h / t / batch within 32-bit byte offsets. */
+int avt_res2_x3_supported(int c, int cm, int w);
+int avt_res2_x3_wfrag_bytes(void);
+int avt_res2_x3(const void* x_hi, const void* x_lo, void* out_hi, void* out_lo, const void* wfrag, const float* coef, int batch,
+                int t, int h, int w, int ldi, int ldo, int plane_dtype, void* stream);
 
 /* Pointwise (1x1x1, stride 1) layers in the same arithmetic, streaming form (csrc/pw_x3.hip): a wave owns 16 rows from
  * load to store, weights are LDS-resident MFMA fragments of persistent workgroups.  y = act(W x + b [+ res]) on plane pairs;

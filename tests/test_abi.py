@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(avt):
     for n in names:
         assert hasattr(handle, n), "libavt_hip.so does not export %s" % n
     assert sorted(list(avt._lib.SIGNATURES) + ["avt_last_error"]) == names
-    assert avt._lib.lib().avt_abi_version() == avt._lib.ABI_VERSION == 7
+    assert avt._lib.lib().avt_abi_version() == avt._lib.ABI_VERSION == 8
 
 
 def test_no_torch_types_in_header(avt):

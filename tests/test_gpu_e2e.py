@@ -238,3 +238,32 @@ def test_bench_self_launch_two_ranks_sharing_one_gpu(dev):
     assert line["n_gpus"] == 2 and line["gloo_ranks"] == 2 and "rccl_ranks" not in line
     assert line["config"]["windows_total"] == 256 and line["config"]["windows_per_gpu"] == 128
     assert line["allgather_ms"] is not None and line["allgather_ms"] > 0 and line["value"] > 0 and line["scaling"] == "weak"
+
+
+def test_bench_eight_ranks_sharing_one_gpu_headline_and_one_item_training(dev):
+    """First-contact readiness for the driver's 8-GPU run, on a one-GPU box: `bench.py --gpus 8 --dist-backend
+    gloo` starts EIGHT ranks on cuda:0 — (1) the headline leg: 8 x 32 windows sharded by index, one all-gather of T_hat, row blocks
+    of the similarity + select, max-over-ranks time, one JSON line from rank 0; (2) `--mode train`: BASELINE config 5 at its real
+    per-rank shape — batch 8 over 8 ranks = ONE item (16 clips) per rank, DistributedDataParallel through main.wrap_ddp (bucketed
+    all-reduce behind the comm hook that orders it after every stream of the forward), strong scaling."""
+    import json
+
+    r = _run([sys.executable, "bench.py", "--gpus", "8", "--dist-backend", "gloo", "--windows", "32", "--steps", "1", "--warmup", "1",
+              "--enc-batch", "32", "--no-fast", "--no-train-leg", "--no-cpu-baseline", "--no-nxn-legs", "--no-precision-block"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["gloo_ranks"] == 8 and line["scaling"] == "weak"
+    assert line["config"]["windows_total"] == 256 and line["config"]["windows_per_gpu"] == 32
+    assert line["allgather_ms"] > 0 and line["value"] > 0 and line["ms_per_step_rank_max"] >= line["ms_per_step_rank_min"] > 0
+
+    r = _run([sys.executable, "bench.py", "--mode", "train", "--gpus", "8", "--dist-backend", "gloo", "--steps", "1", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["unit"] == "clips/s"
+    assert line["config"]["items_per_rank"] == 1 and line["config"]["clips_per_step"] == 128
+    assert "DistributedDataParallel" in line["config"]["parallelism"]
+    assert all(np.isfinite(v) for v in line["loss_first_last"]) and line["value"] > 0

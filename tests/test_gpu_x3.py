@@ -671,6 +671,96 @@ def test_pw_chain_x3_is_bit_identical_to_the_two_launches(avt, dev, mode):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dims,sliced", [((2, 2, 6, 12), False), ((1, 3, 5, 12), True), ((3, 1, 9, 56), False), ((1, 2, 56, 56), True),
+                                         ((5, 8, 56, 56), False)])
+def test_res2_x3_fused_block_equals_the_three_launches(avt, dev, dims, sliced):
+    """csrc/res2_x3.hip (round 6): a slow-res2 identity bottleneck (256 -> 64 -> [1,3,3] 64 -> 256, + x, ReLU) as ONE launch against the
+    launches it replaces (pw_x3 a, conv33_x3 b, pw_x3 c + residual).  Phase B is conv33_x3's arithmetic in conv33_x3's order; phases A
+    and C run 32 x 32 x 16 MFMAs where pw_x3 runs 16 x 16 x 32, so the fp32 accumulation order inside a product differs: equal to fp32
+    rounding (2^-22 products, a few 1e-7 relative), not bit for bit.  Covers: several 256-position steps and workgroups, ragged last
+    step, frame borders inside a step (zero padding in every direction), rows as channel slices of wider buffers (the lateral
+    fusion's concatenation on the output side), width 12 (test shape) and 56 (production)."""
+    import avtex.fused_slowfast as fsf
+    from avtex import ops
+    from avtex.fused_slowfast import Act, new_act
+    from avtex.slowfast import ResBlock
+
+    pd = ops.X3_F16
+    torch.manual_seed(17)
+    blk = ResBlock(256, 256, 64, 1, 1).eval()
+    with torch.no_grad():
+        for bn in (blk.branch2.a_bn, blk.branch2.b_bn, blk.branch2.c_bn):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+            bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    keep, fsf._RES2_X3 = fsf._RES2_X3, 1
+    try:
+        fused = fsf._BlockX3(blk, dev, pd)
+        fsf._RES2_X3 = 0
+        plain = fsf._BlockX3(blk, dev, pd)
+    finally:
+        fsf._RES2_X3 = keep
+    assert fused.res2 is not None and plain.res2 is None
+    m = dims[0] * dims[1] * dims[2] * dims[3]
+    ldi = 320 if sliced else 256
+    xf = torch.randn(m, ldi) * 1.5 + 0.2
+    xh, xl = _planes(xf, pd, dev)
+    x = Act(xh, dims, 32 if sliced else 0, 256, lo=xl)
+    out = None
+    if sliced:  # the output as the first 256 channels of a 320-wide concatenation buffer, pre-filled to catch stray stores
+        ob = new_act(m, 320, dims, dev, True)
+        ob.buf.fill_(7.0); ob.lo.fill_(7.0)
+        out = Act(ob.buf, dims, 0, 256, lo=ob.lo)
+    y = fused(x, out=out)
+    y_ref = plain(x)
+    torch.cuda.synchronize()
+    got, want = y.float(pd), y_ref.float(pd)
+    # also against the fp32 module itself (NCDHW)
+    with torch.no_grad():
+        xt = x.float(pd).cpu().view(*dims, 256).permute(0, 4, 1, 2, 3).contiguous()
+        ref32 = blk(xt).permute(0, 2, 3, 4, 1).reshape(m, 256)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 3e-6 * scale, float((got - want).abs().max()) / scale
+    assert float((got.cpu() - ref32).abs().max()) <= 2e-5 * scale
+    assert float((want.cpu() - ref32).abs().max()) <= 2e-5 * scale
+    if sliced:
+        assert bool((ob.buf[:, 256:].float() == 7.0).all()) and bool((ob.lo[:, 256:].float() == 7.0).all())
+
+
+def test_res2_x3_in_the_encoder(avt, dev):
+    """The whole contract-grade encoder with the slow res2 identity blocks fused (round 6) and as three launches: embeddings equal to
+    fp32 rounding of the two blocks (the fused phases A / C accumulate in another MFMA shape's order)."""
+    import avtex.fused_slowfast as fsf
+    from avtex import ops
+    from avtex.fused_slowfast import split_planes
+    from avtex.slowfast import SlowFast
+
+    pd = ops.X3_F16
+    torch.manual_seed(1)
+    net = synth_randomised(SlowFast().eval())
+    sx = ops.SplitClip(*split_planes(torch.randn(2, 8, 224, 224, 4, device=dev), pd), pd)
+    fx = ops.SplitClip(*split_planes(torch.randn(2, 32, 224, 224, 4, device=dev), pd), pd)
+    outs, launches = [], []
+    for flag in (1, 0):
+        keep, fsf._RES2_X3 = fsf._RES2_X3, flag
+        names = []
+        fsf.PROFILER = lambda name, launch, fl, nb: (names.append(name), launch())
+        try:
+            outs.append(fsf.SlowFastMFMA(net, dev, precision="f16x3").forward_ndhwc4(sx, fx).clone())
+        finally:
+            fsf._RES2_X3, fsf.PROFILER = keep, None
+        launches.append(names)
+    assert launches[0].count("res2_x3_kernel") == 2 and "res2_x3_kernel" not in launches[1]
+    assert "pw_chain_x3_kernel" not in launches[0] and launches[1].count("pw_chain_x3_kernel") == 1
+    rel = float(((outs[0] - outs[1]).norm(dim=1) / outs[1].norm(dim=1)).max())
+    assert rel < 2e-6, rel
+
+
+def synth_randomised(net):
+    from avtex import synth
+
+    return synth.randomise_bn(net, 3, 0.5)
+
+
 @pytest.mark.parametrize("mode,W,S", [("bf16x3", 20, 4), ("f16x3", 20, 4), ("f16x3", 15, 6), ("f16x3", 33, 5)])
 def test_frame_table_equals_dense_clips(avt, dev, mode, W, S):
     """ops.clip_pack_frames (every distinct frame packed once + the windows' sampling index, read by the stem kernel through

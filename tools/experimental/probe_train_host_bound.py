@@ -1,6 +1,6 @@
 """Is config 5's training step (bench.py --mode train) bound by the host's launch rate or by the device?  torch.cuda.synchronize /
 Event.synchronize are wrapped to add up the time the host spends WAITING for the device inside the timed steps: a device-bound step
-shows the host waiting for most of it, a host-bound one hardly at all.   python tools/experimental/probe_train_host_bound.py"""
+shows the host waiting for most of it, a host-bound one hardly at all.   python tools/experimental/probe_train_host_bound.py [bench.py arguments, e.g. --train-items 1 --steps 12 --warmup 4]"""
 import os
 import sys
 import time
@@ -27,7 +27,8 @@ def wrap(obj, name):
 
 
 def main():
-    args = bench.build_parser().parse_args(["--mode", "train", "--steps", "3", "--warmup", "2"])
+    # extra arguments go to bench.py's parser: `--train-items 1 --steps 12 --warmup 4` = config 5's per-rank shape on 8 GPUs
+    args = bench.build_parser().parse_args(["--mode", "train", "--steps", "3", "--warmup", "2"] + sys.argv[1:])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     torch.backends.cudnn.benchmark = True

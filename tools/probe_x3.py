@@ -18,6 +18,8 @@ b = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 for arg in sys.argv[4:]:  # e.g. pwskip=256x1024: that pointwise layer leaves the streaming kernel for the general / 256 x 256 tile
+    if arg.startswith("res2="):  # res2=0: the slow res2 identity blocks as three launches (round 5's path)
+        fsf._RES2_X3 = int(arg[5:])
     if arg.startswith("pwskip="):
         fsf._PW_X3_SKIP = set(fsf._PW_X3_SKIP) | {tuple(int(v) for v in p.split("x")) for p in arg[7:].split(",")}
 m = fsf.SlowFastMFMA(SlowFast(), dev, precision=mode)
@@ -136,6 +138,15 @@ def spy_pc(x_ptrs, ldx, k1, w1, bias1, wscale1, res_ptrs, ldr, y_ptrs, ldy, n1, 
     return orig_pc(x_ptrs, ldx, k1, w1, bias1, wscale1, res_ptrs, ldr, y_ptrs, ldy, n1, relu1, w2, bias2, wscale2, z_ptrs, ldz, n2, m_, plane_dtype)
 
 
+orig_r2 = ops.res2_x3
+
+
+def spy_r2(x_ptrs, ldi, out_ptrs, ldo, packed, batch, t, h, w, plane_dtype):
+    shapes.append("fused slow res2 block 256 -> 64 -> 64 -> 256 (+x) in(%d, %d, %d, %d) ldi %d ldo %d" % (batch, t, h, w, ldi, ldo))
+    return orig_r2(x_ptrs, ldi, out_ptrs, ldo, packed, batch, t, h, w, plane_dtype)
+
+
+ops.res2_x3 = spy_r2
 ops.pw_chain_x3 = spy_pc
 ops.conv33_x3 = spy_c33
 ops.bneck_x3 = spy_bn
