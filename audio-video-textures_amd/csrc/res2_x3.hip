@@ -36,6 +36,13 @@
 
 namespace {
 
+// phase-skip diagnostic (tools/r06_runs/gpu_r06_res2_phases.sh builds one library per -DR2_DBG=mask: 1 no stores, 2 no x loads after
+// the preamble, 4 no weight DMA after the preamble, 8 no barriers / counted waits, 16 no MFMAs, 32 plain epilogues (no split, no
+// ReLU)); the shipped library is built with 0
+#ifndef R2_DBG
+#define R2_DBG 0
+#endif
+#define R2_SKIP(bit) (((R2_DBG) & (bit)) != 0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -52,15 +59,21 @@ __device__ __forceinline__ f32x16 mfma(i32x4 w, i32x4 x, f32x16 c) {
 // one split-plane product, small terms first (conv_x3.hip's order)
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma3(i32x4 wh, i32x4 wl, i32x4 xh, i32x4 xl, f32x16 c) {
+  if (R2_SKIP(16)) {  // diagnostic: the operands stay live (one VALU op each), no matrix instruction
+    c[0] += __builtin_bit_cast(float, wh[0] ^ wl[1] ^ xh[2] ^ xl[3]);
+    return c;
+  }
   c = mfma<F16>(wl, xh, c);
   c = mfma<F16>(wh, xl, c);
   return mfma<F16>(wh, xh, c);
 }
 
 constexpr int C = 256, CM = 64;
-constexpr int NWV = 8, STEP = NWV * 32, LAG = 64, RING = 384;
+constexpr int NWV = 4, STEP = NWV * 32, RING = 384;
 constexpr int KA = C / 16;                       // k-slices of a
 constexpr int CH_PAIRS = 8, CH_BYTES = CH_PAIRS * 2048, NBUF = 3;
+constexpr int AHEAD = 3;                         // fragment pairs read ahead of the MFMAs that use them
+constexpr int PIECES = CH_BYTES / 1024 / NWV;    // 1 KB DMA pieces per wave and chunk
 constexpr int NCH_A = KA * 2 / CH_PAIRS;         // 4 chunks: (4 k-slices x 2 n-tiles) each
 constexpr int NCH_B = 9;                         // one tap each: 4 k-slices x 2 n-tiles
 constexpr int NCH_C = (C / 32) * 4 / CH_PAIRS;   // 4 chunks: 2 n-tiles x 4 k-slices each
@@ -73,20 +86,27 @@ constexpr int NCOEF = 4 * CM + 2 * C;
 constexpr int LDS_BYTES = CF_OFF + NCOEF * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-// "other" vector-memory operations a wave issues during chunk c (after the chunk-top DMA pieces): phase B taps 0..7 request the
-// residual of c's n-tile <tap> (2 g x 2 planes); every n-tile of phase C stores 2 g x 2 planes and requests two k-slices x 2
-// planes of the next step's x operand
+// "other" vector-memory operations a wave issues during chunk c (after the chunk-top DMA pieces): every n-tile of phase C stores
+// 2 g x 2 planes and requests two k-slices x 2 planes of the x tile after next; phases A and B issue none
 constexpr int other_ops(int c) {
   c = ((c % NCH) + NCH) % NCH;
-  if (c < NCH_A) return 0;
-  if (c < NCH_A + NCH_B) return (c - NCH_A) < 8 ? 4 : 0;
-  return 16;
+  return c < NCH_A + NCH_B ? 0 : 16;
 }
-constexpr int wait_count(int c) { return other_ops(c - 2) + 2 + other_ops(c - 1); }
+constexpr int wait_count(int c) { return other_ops(c - 2) + PIECES + other_ops(c - 1); }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool F16>
+__device__ __forceinline__ void r2_split(const float* v, uint4& h, uint4& l) {
+  if (R2_SKIP(32)) {  // diagnostic: no plane split
+    h = uint4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    l = uint4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+    return;
+  }
+  avt::split8<F16>(v, h, l);
 }
 
 struct R2Args {
@@ -98,15 +118,16 @@ struct R2Args {
   const float* coef;   // [sa CM | ba CM | sb CM | bb CM | sc C | bc C]
   int P, H, HW;        // positions; rows per frame; H * W
   int ldi, ldo;        // row pitch of x / out in elements
-  int nsteps, spw;     // 256-position steps; steps per workgroup
+  int nsteps, spw;     // 128-position steps; steps per workgroup
   unsigned x_bytes, o_bytes, w_bytes;
 };
 
 template <int W, bool F16>
 __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
-  // phase B of step s reads slots of [STEP s - (W + 1), STEP s + STEP + W]; phase A of step s + 1 writes up to STEP s + STEP + LAG + STEP - 1:
-  // nothing phase B of step s + 1 still needs (>= STEP (s + 1) - (W + 1)) may share a slot with it
-  static_assert(W + 1 <= LAG && STEP + LAG + W + 1 < RING, "the ring covers a step, its lag and both halos");
+  // iteration i: phase A of step i, then phases B / C of step i - 1.  B / C of step i - 1 read ring slots of positions
+  // [STEP (i - 1) - (W + 1), STEP i + W]; phase A of step i + 1 writes [STEP (i + 1), STEP (i + 2)) while B / C of step i still need
+  // [STEP i - (W + 1), ...): the live span is 2 STEP + W + 1 positions
+  static_assert(W + 1 <= STEP && 2 * STEP + W + 1 < RING, "the ring covers two steps and a halo");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -126,51 +147,63 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
   const __amdgpu_buffer_rsrc_t rol = __builtin_amdgcn_make_buffer_rsrc((void*)a.ol, 0, a.o_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwf = __builtin_amdgcn_make_buffer_rsrc((void*)a.wf, 0, a.w_bytes, 0x00020000);
 
-  // weight chunk `cc` (0 .. NCH-1, the same stream every step) -> rotation buffer `buf`: this wave's two 1 KB pieces
+  // weight chunk `cc` (0 .. NCH-1, the same stream every step) -> rotation buffer `buf`: this wave's 1 KB pieces
   auto dma_chunk = [&](int cc, int buf) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int piece = wid * 2 + j;
+    for (int j = 0; j < PIECES; ++j) {
+      const int piece = wid * PIECES + j;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rwf, (lds_ptr)(lds + WB_OFF + buf * CH_BYTES + piece * 1024), 16,
                                                cc * CH_BYTES + piece * 1024 + lane * 16, 0, 0, 0);
     }
   };
 
-  // ---- registers that live across phases
-  i32x4 xa[KA][2];       // phase A's operand: this lane's 8-channel chunk of k-slice k of its position, [plane]
-  i32x4 res[C / 32][2][2];  // phase C's residual: [n-tile][g][plane] = channels 32 n + (2 g + lh) * 8 .. + 7 of the position
+  // ---- the x tiles: xt[set][k][plane] = this lane's 8-channel chunk of k-slice k of its position.  Set (j & 1) holds the tile of
+  // local iteration j: phase A's operand there, and — the SAME registers, the same layout (k = 2 n + g) — phase C's residual one
+  // iteration later; as phase C releases it n-tile by n-tile, the tile of iteration j + 2 is requested into the freed registers
+  i32x4 xt[2][KA][2];
 
-  auto xa_off = [&](int s) -> unsigned {  // byte offset of this lane's chunk of k-slice 0 of phase A's position in step s
-    const int p = STEP * s + LAG + 32 * wid + lr;
+  auto x_off = [&](int step) -> unsigned {  // byte offset of this lane's chunk of k-slice 0 of its position in `step`
+    const int p = STEP * step + 32 * wid + lr;
     return (p >= 0 && p < a.P) ? ((unsigned)p * (unsigned)a.ldi + (unsigned)(lh * 8)) * 2u : kOob;
   };
-  auto load_xa = [&](int k, unsigned base) {
-    const int off = (int)(base != kOob ? base + (unsigned)(k * 32) : kOob);
-    xa[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
-    xa[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
-  };
 
-  // ---- preamble: chunks 0 and 1 of the first step, then the first step's x operand (the order the wait counts assume)
+  // ---- preamble: chunks 0 and 1, then the x tiles of the first two iterations (the order the wait counts assume: the second
+  // tile's loads are "other" operations older than every chunk wait that matters)
   int gc = 0;  // chunks consumed so far: chunk gc lives in rotation buffer gc % NBUF
+  {
+    const unsigned b1 = x_off(s0);  // iteration 1's tile first (older), then iteration 0's: 32 loads stay younger than DMA(1)
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      const int off = (int)(b1 != kOob ? b1 + (unsigned)(k * 32) : kOob);
+      xt[1][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+      xt[1][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
+    }
+  }
   asm volatile("" ::: "memory");
   dma_chunk(0, 0);
   dma_chunk(1, 1);
   asm volatile("" ::: "memory");
   {
-    const unsigned b0 = xa_off(s0 - 1);
+    const unsigned b0 = x_off(s0 - 1);
 #pragma unroll
-    for (int k = 0; k < KA; ++k) load_xa(k, b0);
+    for (int k = 0; k < KA; ++k) {
+      const int off = (int)(b0 != kOob ? b0 + (unsigned)(k * 32) : kOob);
+      xt[0][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+      xt[0][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
+    }
   }
   asm volatile("" ::: "memory");
 
   // top of chunk CC: its pieces have landed (every wave's: barrier), the buffer of chunk gc - 1 is free -> request chunk gc + 2
   auto chunk_top = [&](auto cc_c) -> const char* {
     constexpr int CC = decltype(cc_c)::value;
-    wait_vm<wait_count(CC)>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!R2_SKIP(8)) {
+      wait_vm<wait_count(CC)>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     asm volatile("" ::: "memory");
-    dma_chunk((CC + 2) % NCH, (gc + 2) % NBUF);
+    if (!R2_SKIP(4)) dma_chunk((CC + 2) % NCH, (gc + 2) % NBUF);
     asm volatile("" ::: "memory");
     const char* cur = lds + WB_OFF + (gc % NBUF) * CH_BYTES;
     ++gc;
@@ -180,21 +213,24 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
     return *reinterpret_cast<const i32x4*>(cur + (pair * 2 + plane) * 1024 + lofs);
   };
 
-  // this lane's phase-B position inside its frame, carried from step to step (a runtime modulo per step kept its magic number in
-  // a SPILLED register, and the reload's vmcnt(0) drained the x operand prefetch at the top of every step)
+  // this lane's phase-B/C position inside its frame, carried from iteration to iteration (a runtime modulo per step kept its
+  // magic number in a spilled register)
   int qf;
   {
-    const int pb0 = STEP * (s0 - 1) + 32 * wid + lr;
+    const int pb0 = STEP * (s0 - 2) + 32 * wid + lr;
     qf = pb0 % a.HW;
     if (qf < 0) qf += a.HW;
   }
-  for (int s = s0 - 1; s < s1; ++s) {
-    const bool store_ok = s >= s0;
-    // ---- geometry of this lane's positions in this step
-    const int pa = STEP * s + LAG + 32 * wid + lr;  // phase A's position (may lie before / after the tensor: its ring slot is never read)
-    const int pb = STEP * s + 32 * wid + lr;        // phase B / C's position
-    const unsigned ra = (unsigned)(pa + 4 * RING) % (unsigned)RING;
-    const unsigned rb = (unsigned)(pb + 4 * RING) % (unsigned)RING;
+
+  // local iteration j (step i = s0 - 1 + j): phase A of step i on tile set SET = j & 1, phases B / C of step i - 1 with tile set
+  // SET ^ 1 as the residual
+  auto iteration = [&](auto set_c, int i) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value, OLD = SET ^ 1;
+    const bool store_ok = i - 1 >= s0 && i - 1 < s1;
+    const int pa = STEP * i + 32 * wid + lr;  // phase A's position (before / after the tensor: its ring slot is never read)
+    const int pb = pa - STEP;                 // phase B / C's position
+    const unsigned ra = (unsigned)(pa + 8 * RING) % (unsigned)RING;
+    const unsigned rb = (unsigned)(pb + 8 * RING) % (unsigned)RING;
     const bool pb_in = pb >= 0 && pb < a.P;
     const int q = qf;
     const int y = q / W, xc = q - y * W;
@@ -213,14 +249,17 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
         const char* cur = chunk_top(std::integral_constant<int, JC>{});
         int lofs = lane * 16;
         asm volatile("" : "+v"(lofs));
+        // the chunk's 8 fragment pairs, read AHEAD of their MFMAs (one wave per SIMD: nobody else hides the LDS latency)
+        i32x4 wf_[CH_PAIRS][2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int k = JC * 4 + kk;
+        for (int pr = 0; pr < AHEAD; ++pr) { wf_[pr][0] = WP(cur, pr, 0, lofs); wf_[pr][1] = WP(cur, pr, 1, lofs); }
 #pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            const int pr = kk * 2 + n;
-            acc[n] = mfma3<F16>(WP(cur, pr, 0, lofs), WP(cur, pr, 1, lofs), xa[k][0], xa[k][1], acc[n]);
-          }
+        for (int pr = 0; pr < CH_PAIRS; ++pr) {
+          if (pr + AHEAD < CH_PAIRS) { wf_[pr + AHEAD][0] = WP(cur, pr + AHEAD, 0, lofs); wf_[pr + AHEAD][1] = WP(cur, pr + AHEAD, 1, lofs); }
+          __builtin_amdgcn_sched_barrier(0);
+          const int k = JC * 4 + pr / 2, n = pr % 2;
+          acc[n] = mfma3<F16>(wf_[pr][0], wf_[pr][1], xt[SET][k][0], xt[SET][k][1], acc[n]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
       a_chunk(std::integral_constant<int, 0>{});
@@ -237,7 +276,7 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(acc[n][8 * g + e] * cf[c0 + e] + cf[CM + c0 + e]);
           uint4 h, l;
-          avt::split8<F16>(v, h, l);
+          r2_split<F16>(v, h, l);
           const unsigned chunk = (unsigned)(4 * n + 2 * g + lh);
           const unsigned o = ra * 128u + ((chunk ^ sw) * 16u);
           *reinterpret_cast<uint4*>(lds + o) = h;
@@ -245,7 +284,7 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
         }
     }
 
-    // ================= phase B: b = relu(sb * (Wb * taps(a)) + bb), operands from the ring
+    // ================= phase B (step i - 1): b = relu(sb * (Wb * taps(a)) + bb), operands from the ring
     i32x4 zb[4][2];  // phase C's operand: k-slice k' = 2 n + g of b's output, [plane]
     {
       f32x16 acc[2];
@@ -253,7 +292,6 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-      const unsigned res_base = (pb_in && store_ok) ? ((unsigned)pb * (unsigned)a.ldi) * 2u : kOob;
       auto b_tap = [&](auto t_c) {
         constexpr int T = decltype(t_c)::value;
         constexpr int dy = T / 3 - 1, dx = T % 3 - 1;
@@ -265,24 +303,24 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
         const unsigned nsw = ((unsigned)nb >> 1) & 7u;
         int lofs = lane * 16;
         asm volatile("" : "+v"(lofs));
-        if constexpr (T < 8) {  // the residual of phase C's n-tile T: requested here, used >= 5 chunks later
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            const int off = (int)(res_base != kOob ? res_base + (unsigned)((32 * T + (2 * g + lh) * 8) * 2) : kOob);
-            res[T][g][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
-            res[T][g][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
-          }
-        }
+        // the tap's four operand k-slices from the ring, then the 8 weight pairs read ahead of their MFMAs
+        i32x4 fx[4][2];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const unsigned o = ok ? (unsigned)nb * 128u + ((((unsigned)(2 * k + lh)) ^ nsw) * 16u) : (unsigned)ZERO_OFF;
-          const i32x4 fh = *reinterpret_cast<const i32x4*>(lds + o);
-          const i32x4 fl = *reinterpret_cast<const i32x4*>(lds + (ok ? RING_PLANE : 0) + o);
+          fx[k][0] = *reinterpret_cast<const i32x4*>(lds + o);
+          fx[k][1] = *reinterpret_cast<const i32x4*>(lds + (ok ? RING_PLANE : 0) + o);
+        }
+        i32x4 wf_[CH_PAIRS][2];
 #pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            const int pr = k * 2 + n;
-            acc[n] = mfma3<F16>(WP(cur, pr, 0, lofs), WP(cur, pr, 1, lofs), fh, fl, acc[n]);
-          }
+        for (int pr = 0; pr < AHEAD; ++pr) { wf_[pr][0] = WP(cur, pr, 0, lofs); wf_[pr][1] = WP(cur, pr, 1, lofs); }
+#pragma unroll
+        for (int pr = 0; pr < CH_PAIRS; ++pr) {
+          if (pr + AHEAD < CH_PAIRS) { wf_[pr + AHEAD][0] = WP(cur, pr + AHEAD, 0, lofs); wf_[pr + AHEAD][1] = WP(cur, pr + AHEAD, 1, lofs); }
+          __builtin_amdgcn_sched_barrier(0);
+          const int k = pr / 2, n = pr % 2;
+          acc[n] = mfma3<F16>(wf_[pr][0], wf_[pr][1], fx[k][0], fx[k][1], acc[n]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
       b_tap(std::integral_constant<int, 0>{});
@@ -303,37 +341,43 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(acc[n][8 * g + e] * cf[2 * CM + c0 + e] + cf[3 * CM + c0 + e]);
           uint4 h, l;
-          avt::split8<F16>(v, h, l);
+          r2_split<F16>(v, h, l);
           zb[2 * n + g][0] = __builtin_bit_cast(i32x4, h);
           zb[2 * n + g][1] = __builtin_bit_cast(i32x4, l);
         }
     }
 
-    // ================= phase C: out = relu(sc * (Wc b) + bc + x); the next step's x operand is requested as registers free up
+    // ================= phase C (step i - 1): out = relu(sc * (Wc b) + bc + x); x = the tile phase A used one iteration ago, still in
+    // registers; the tile of step i + 1 is requested into them as they are released
     {
       const unsigned out_base = (pb_in && store_ok) ? ((unsigned)pb * (unsigned)a.ldo) * 2u : kOob;
-      const unsigned xn = s + 1 < s1 ? xa_off(s + 1) : kOob;  // (past the last step: nothing to fetch; the loads still issue)
+      const unsigned xn = i + 1 <= s1 ? x_off(i + 1) : kOob;  // (past the last iteration: nothing to fetch; the loads still issue)
       auto c_chunk = [&](auto jc_c) {
         constexpr int JC = decltype(jc_c)::value;
         const char* cur = chunk_top(std::integral_constant<int, NCH_A + NCH_B + JC>{});
         int lofs = lane * 16;
         asm volatile("" : "+v"(lofs));
+        // all 8 fragment pairs of the chunk up front (64 registers): the first n-tile's epilogue then runs under the second's MFMAs
+        i32x4 wf_[CH_PAIRS][2];
+#pragma unroll
+        for (int pr = 0; pr < CH_PAIRS; ++pr) { wf_[pr][0] = WP(cur, pr, 0, lofs); wf_[pr][1] = WP(cur, pr, 1, lofs); }
+        f32x16 accs[2];
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[nn][r] = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) accs[nn] = mfma3<F16>(wf_[nn * 4 + k][0], wf_[nn * 4 + k][1], zb[k][0], zb[k][1], accs[nn]);
+        }
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn) {
           const int N = JC * 2 + nn;
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int pr = nn * 4 + k;
-            acc = mfma3<F16>(WP(cur, pr, 0, lofs), WP(cur, pr, 1, lofs), zb[k][0], zb[k][1], acc);
-          }
+          const f32x16 acc = accs[nn];
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
             const int c0 = 32 * N + (2 * g + lh) * 8;
             float v[8];
-            const i32x4 rh = res[N][g][0], rl = res[N][g][1];
+            const i32x4 rh = xt[OLD][2 * N + g][0], rl = xt[OLD][2 * N + g][1];  // channels 16 (2 N + g) + 8 lh .. = c0 ..
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const avt::f32x2 r = avt::join2<F16>((uint32_t)rh[e], (uint32_t)rl[e]);
@@ -343,13 +387,18 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(v[e]);
             uint4 oh, ol;
-            avt::split8<F16>(v, oh, ol);
+            r2_split<F16>(v, oh, ol);
             const int off = (int)(out_base != kOob ? out_base + (unsigned)(c0 * 2) : kOob);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, oh), roh, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ol), rol, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, oh), roh, R2_SKIP(1) ? (int)kOob : off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ol), rol, R2_SKIP(1) ? (int)kOob : off, 0, 0);
           }
-          load_xa(2 * N, xn);  // k-slices 2 N, 2 N + 1 of the next step's operand (phase A consumed this step's long ago)
-          load_xa(2 * N + 1, xn);
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {  // k-slices 2 N, 2 N + 1 of the tile of step i + 1 into the registers just released
+            const int k = 2 * N + g;
+            const int off = (int)((xn != kOob && !R2_SKIP(2)) ? xn + (unsigned)(k * 32) : kOob);
+            xt[OLD][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+            xt[OLD][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
+          }
         }
       };
       c_chunk(std::integral_constant<int, 0>{});
@@ -357,6 +406,15 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
       c_chunk(std::integral_constant<int, 2>{});
       c_chunk(std::integral_constant<int, 3>{});
     }
+  };
+
+  // iterations i = s0 - 1 .. s1: phase A runs one step ahead of B / C (step s0 - 1 gives step s0 its upper halo; B / C of steps
+  // s0 - 2 and s0 - 1 compute on unwritten ring slots and store nothing)
+  for (int i = s0 - 1; i <= s1;) {
+    iteration(std::integral_constant<int, 0>{}, i);
+    if (++i > s1) break;
+    iteration(std::integral_constant<int, 1>{}, i);
+    ++i;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the two chunks requested past the end land before the LDS is released
 }

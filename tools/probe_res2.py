@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""GPU probe: the fused slow-res2 bottleneck (csrc/res2_x3.hip) alone at the production shape — HIP-event time per launch, algorithmic
+TFLOP/s and GB/s (x in + out once).  usage: probe_res2.py [batch=249] [reps=5]   (AVT_HIP_LIB selects a diagnostic build)"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import avtex  # noqa: E402,F401
+import avtex.fused_slowfast as fsf  # noqa: E402
+from avtex import ops  # noqa: E402
+from avtex.slowfast import ResBlock  # noqa: E402
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 249
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+blk = fsf._BlockX3(ResBlock(256, 256, 64, 1, 1).eval(), dev, ops.X3_F16)
+dims = (b, 8, 56, 56)
+m = b * 8 * 56 * 56
+x = fsf.new_act(m, 256, dims, dev, True)
+x.buf.view(torch.float16).normal_()
+x.lo.view(torch.float16).normal_(0, 1e-3)
+y = fsf.new_act(m, 256, dims, dev, True)
+for _ in range(2):
+    blk(x, out=y)
+a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(reps):
+    blk(x, out=y)
+e.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(e) / reps
+fl = m * 2.0 * (256 * 64 + 576 * 64 + 64 * 256)
+print("res2_x3 batch %d: %.3f ms per launch, %.1f TFLOP/s algorithmic (%.3f of 833), %.0f GB/s (x in + out)" % (
+    b, ms, fl / ms / 1e9, fl / ms / 1e9 / 833.3, m * 2048.0 / ms / 1e6))
