@@ -9,24 +9,30 @@
 // not fit the LDS beside anything (the fast pathway's bneck_x3 keeps its 30-110 KB resident).
 //
 // Form: the activations stay put, the WEIGHTS stream.
-//   * Positions are FLAT (frame-major, row-major): a workgroup of 8 waves owns a contiguous range of 256-position steps; wave w owns
-//     the 32 positions [256 s + 32 w, + 32) of step s in every phase — a 32 x 32 x 16 MFMA column block.
-//   * Phase A (a conv) runs one step AHEAD by LAG = 64 positions (>= one row + 1): its relu'd, split output lands in an LDS RING
-//     of 384 positions x 64 channels x 2 planes (96 KB, 16-byte chunks XOR-swizzled by position: conflict-free ds_read_b128), so
-//     the 3 x 3 taps of phase B read finished neighbours — no halo recompute, no barrier of their own.
+//   * Positions are FLAT (frame-major, row-major): a workgroup of 8 waves owns a contiguous range of 128-position steps; wave w owns
+//     the 16 positions [128 s + 16 w, + 16) of step s in every phase — a 16 x 16 x 32 MFMA column block (pw_x3's operand forms).
+//   * Iteration i runs phase A (the a conv) of step i, then phases B and C of step i - 1: A's relu'd, split output lands in an LDS
+//     RING of 384 positions x 64 channels x 2 planes (96 KB, 16-byte chunks XOR-swizzled by position), so the 3 x 3 taps of phase
+//     B read finished neighbours on both sides (a row + 1 = 57 positions) — no halo recompute.
 //   * Phase B (b conv): the taps' operands are ring reads at shifted slots; a neighbour outside the frame (row / column edge, the
 //     frame before / after in the flat order) reads a 16-byte ZERO slot instead (address select: the zero padding).
 //   * Phase C (c conv + bias + residual + ReLU): phase B's accumulator layout IS the operand layout of the next GEMM (output rows
-//     permuted in the packing, pw_chain's trick) — b's output never leaves registers.  The residual is x itself, re-read from
-//     L2 / Infinity Cache in the accumulator's layout (issued during phase B); the x operand of the NEXT step's phase A is
-//     requested during phase C, two to five chunks before its use.
-//   * The 136 weight-fragment pairs (2 KB each: hi + lo plane of a 32-row x 16-k MFMA operand) arrive in 17 CHUNKS of 8 pairs by
+//     permuted in the packing, pw_chain's trick) — b's output never leaves registers.  The RESIDUAL is the x tile phase A used one
+//     iteration earlier, still in registers (the operand chunk of k-step M, lane group q IS the residual of output channels
+//     32 M + 8 q ..): x crosses HBM exactly once.  As phase C releases the tile k-step by k-step, the tile of step i + 1 is
+//     requested into the freed registers, 3 to 17 chunks before phase A uses it.
+//   * The 136 weight-fragment pairs (2 KB each: hi + lo plane of a 16-row x 32-k MFMA operand) arrive in 17 CHUNKS of 8 pairs by
 //     LDS-DMA (buffer_load ... lds) into a three-deep 48 KB rotation, two chunks ahead of their use; one workgroup barrier per
-//     chunk.  They come from L2 (272 KB per 256 positions: 0.5 B per HBM byte, at L2's 34 TB/s).
+//     chunk.  They come from L2 (272 KB per 128 positions, the same every step).
+// History of the form (profiles/r06/README.md): v1 (8 waves x 32 positions, residual re-read from L2 / Infinity Cache) 5.15 ms per
+// 249-clip launch = the three launches' time; v2 (4 waves x 32 positions, one per SIMD with 448 registers, residual in registers) 4.95 ms
+// — its phase-skip builds (R2_DBG) showed 3.3 ms of compute SERIALIZED in the single wave of a SIMD (MFMA, the epilogues' VALU and the
+// LDS reads do not overlap without a second wave) and 1.7 ms of memory time exposed; this form keeps two waves per SIMD by halving
+// the tile (two x tiles live = 128 registers).
 // Counted waits: every wave issues the SAME sequence of vector-memory operations per chunk (loads and stores of out-of-range
 // positions carry an out-of-bounds offset), so "chunk c has landed" is s_waitcnt vmcnt(N(c)) with N(c) = the operations issued
-// after its two DMA pieces (vmcnt retires in order on gfx9-family parts; a scratch spill would only make a wait longer).
-// Roofline: HBM (2 * C * 4 B per position) — MFMA needs 408 x 32 cycles per wave and step against ~46 us of HBM time per step.
+// after its DMA pieces (vmcnt retires in order on gfx9-family parts; a scratch spill would only make a wait longer).
+// Roofline: HBM (2 * C * 4 B per position).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -37,28 +43,59 @@
 namespace {
 
 // phase-skip diagnostic (tools/r06_runs/gpu_r06_res2_phases.sh builds one library per -DR2_DBG=mask: 1 no stores, 2 no x loads after
-// the preamble, 4 no weight DMA after the preamble, 8 no barriers / counted waits, 16 no MFMAs, 32 plain epilogues (no split, no
-// ReLU)); the shipped library is built with 0
+// the preamble, 4 no weight DMA after the preamble, 8 no barriers / counted waits, 16 no MFMAs, 32 plain epilogues (no split));
+// the shipped library is built with 0
 #ifndef R2_DBG
 #define R2_DBG 0
 #endif
 #define R2_SKIP(bit) (((R2_DBG) & (bit)) != 0)
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// cycle stamps (diagnostic builds only: -DR2_STAMP; tools/r06_runs/gpu_r06_res2_stamps.sh): where a wave's cycles go, wave 0 of every
+// workgroup, summed: [0] chunk-top waits (own DMA pieces, LDS drain, barrier), [1] phase A chunks, [2] A epilogue, [3] phase B taps,
+// [4] B epilogue, [5] phase C MFMAs, [6] phase C epilogues (+ stores, next tile's loads), [7] workgroups, [8] memtime, [9] realtime
+#ifdef R2_STAMP
+__device__ unsigned long long g_r2_stamp[10];
+#define R2_ST_BEGIN()                                        \
+  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};     \
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();   \
+  const unsigned long long t0_ = last_, r0_ = __builtin_amdgcn_s_memrealtime()
+#define R2_ST(i)                                                  \
+  do {                                                            \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    seg_[i] += now_ - last_;                                      \
+    last_ = now_;                                                 \
+  } while (0)
+#define R2_ST_END()                                                             \
+  do {                                                                          \
+    if (threadIdx.x == 0) {                                                     \
+      for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_r2_stamp[i_], seg_[i_]);      \
+      atomicAdd(&g_r2_stamp[7], 1ull);                                          \
+      atomicAdd(&g_r2_stamp[8], __builtin_amdgcn_s_memtime() - t0_);            \
+      atomicAdd(&g_r2_stamp[9], __builtin_amdgcn_s_memrealtime() - r0_);        \
+    }                                                                           \
+  } while (0)
+#else
+#define R2_ST_BEGIN()
+#define R2_ST(i)
+#define R2_ST_END()
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOob = 0xFFFFFFF0u;
 
 template <bool F16>
-__device__ __forceinline__ f32x16 mfma(i32x4 w, i32x4 x, f32x16 c) {
+__device__ __forceinline__ f32x4 mfma(i32x4 w, i32x4 x, f32x4 c) {
   if constexpr (F16)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
   else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 // one split-plane product, small terms first (conv_x3.hip's order)
 template <bool F16>
-__device__ __forceinline__ f32x16 mfma3(i32x4 wh, i32x4 wl, i32x4 xh, i32x4 xl, f32x16 c) {
+__device__ __forceinline__ f32x4 mfma3(i32x4 wh, i32x4 wl, i32x4 xh, i32x4 xl, f32x4 c) {
   if (R2_SKIP(16)) {  // diagnostic: the operands stay live (one VALU op each), no matrix instruction
     c[0] += __builtin_bit_cast(float, wh[0] ^ wl[1] ^ xh[2] ^ xl[3]);
     return c;
@@ -69,14 +106,25 @@ __device__ __forceinline__ f32x16 mfma3(i32x4 wh, i32x4 wl, i32x4 xh, i32x4 xl, 
 }
 
 constexpr int C = 256, CM = 64;
-constexpr int NWV = 4, STEP = NWV * 32, RING = 384;
-constexpr int KA = C / 16;                       // k-slices of a
+constexpr int NWV = 8, TP = 16, STEP = NWV * TP, RING = 384;
+constexpr int KA = C / 32;                       // k-steps of a (and chunks of 8 channels x 4 lane groups of an x tile)
 constexpr int CH_PAIRS = 8, CH_BYTES = CH_PAIRS * 2048, NBUF = 3;
-constexpr int AHEAD = 3;                         // fragment pairs read ahead of the MFMAs that use them
+#ifndef R2_AHEAD
+#define R2_AHEAD 2  // (2, 3, 4 measured equal; 2 is the deepest without a spilled register)
+#endif
+constexpr int AHEAD = R2_AHEAD;                  // fragment pairs read ahead of the MFMAs that use them
+#ifndef R2_FENCE
+#define R2_FENCE 1
+#endif
+#if R2_FENCE
+#define R2_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define R2_SCHED_FENCE()
+#endif
 constexpr int PIECES = CH_BYTES / 1024 / NWV;    // 1 KB DMA pieces per wave and chunk
-constexpr int NCH_A = KA * 2 / CH_PAIRS;         // 4 chunks: (4 k-slices x 2 n-tiles) each
-constexpr int NCH_B = 9;                         // one tap each: 4 k-slices x 2 n-tiles
-constexpr int NCH_C = (C / 32) * 4 / CH_PAIRS;   // 4 chunks: 2 n-tiles x 4 k-slices each
+constexpr int NCH_A = KA * (CM / 16) / CH_PAIRS; // 4 chunks: 2 k-steps x 4 n-tiles each
+constexpr int NCH_B = 9;                         // one tap each: 2 k-steps x 4 n-tiles
+constexpr int NCH_C = (C / 16) * 2 / CH_PAIRS;   // 4 chunks: 4 n-tiles x 2 k-steps each
 constexpr int NCH = NCH_A + NCH_B + NCH_C;       // 17
 constexpr int RING_PLANE = RING * CM * 2;        // 49152 B
 constexpr int ZERO_OFF = 2 * RING_PLANE;         // 16 zero bytes (+ padding to 1 KB)
@@ -85,12 +133,13 @@ constexpr int CF_OFF = WB_OFF + NBUF * CH_BYTES;
 constexpr int NCOEF = 4 * CM + 2 * C;
 constexpr int LDS_BYTES = CF_OFF + NCOEF * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(NCH_A == 4 && NCH_C == 4 && PIECES == 2, "chunk layout");
 
-// "other" vector-memory operations a wave issues during chunk c (after the chunk-top DMA pieces): every n-tile of phase C stores
-// 2 g x 2 planes and requests two k-slices x 2 planes of the x tile after next; phases A and B issue none
+// "other" vector-memory operations a wave issues during chunk c (after the chunk-top DMA pieces): every output-channel group of 32 of
+// phase C (two per chunk) stores 2 planes and requests one k-step x 2 planes of the x tile after next; phases A and B issue none
 constexpr int other_ops(int c) {
   c = ((c % NCH) + NCH) % NCH;
-  return c < NCH_A + NCH_B ? 0 : 16;
+  return c < NCH_A + NCH_B ? 0 : 8;
 }
 constexpr int wait_count(int c) { return other_ops(c - 2) + PIECES + other_ops(c - 1); }
 template <int N>
@@ -132,7 +181,7 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 31, lh = lane >> 5;
+  const int lp = lane & 15, q = lane >> 4;
   float* cf = reinterpret_cast<float*>(lds + CF_OFF);
   for (int i = tid; i < NCOEF; i += NWV * 64) cf[i] = a.coef[i];
   if (tid < 64) *reinterpret_cast<i32x4*>(lds + ZERO_OFF + tid * 16) = i32x4{0, 0, 0, 0};
@@ -157,51 +206,53 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
     }
   };
 
-  // ---- the x tiles: xt[set][k][plane] = this lane's 8-channel chunk of k-slice k of its position.  Set (j & 1) holds the tile of
-  // local iteration j: phase A's operand there, and — the SAME registers, the same layout (k = 2 n + g) — phase C's residual one
-  // iteration later; as phase C releases it n-tile by n-tile, the tile of iteration j + 2 is requested into the freed registers
+  // ---- the x tiles: xt[set][k][plane] = this lane's 8 channels 32 k + 8 q .. of its position.  Set (j & 1) holds the tile of local
+  // iteration j: phase A's operand there, and — the SAME registers, the same layout — phase C's residual of output channels
+  // 32 k + 8 q .. one iteration later; as phase C releases it k-step by k-step, the tile of iteration j + 2 is requested into the
+  // freed registers
   i32x4 xt[2][KA][2];
 
-  auto x_off = [&](int step) -> unsigned {  // byte offset of this lane's chunk of k-slice 0 of its position in `step`
-    const int p = STEP * step + 32 * wid + lr;
-    return (p >= 0 && p < a.P) ? ((unsigned)p * (unsigned)a.ldi + (unsigned)(lh * 8)) * 2u : kOob;
+  auto x_off = [&](int p) -> unsigned {  // byte offset of this lane's chunk of k-step 0 of position p
+    return (p >= 0 && p < a.P) ? ((unsigned)p * (unsigned)a.ldi + (unsigned)(q * 8)) * 2u : kOob;
+  };
+  const int p_lane = TP * wid + lp;
+  auto load_tile = [&](auto set_c, int k, unsigned base) {
+    constexpr int SET = decltype(set_c)::value;
+    const int off = (int)((base != kOob) ? base + (unsigned)(k * 64) : kOob);
+    xt[SET][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+    xt[SET][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
   };
 
-  // ---- preamble: chunks 0 and 1, then the x tiles of the first two iterations (the order the wait counts assume: the second
-  // tile's loads are "other" operations older than every chunk wait that matters)
+  // ---- preamble: the tile of iteration 1 (older than everything that is waited for), chunks 0 and 1, then the tile of iteration 0
+  // (the order the wait counts assume: 2 K loads stay younger than chunk 0's pieces, like a phase C's operations)
   int gc = 0;  // chunks consumed so far: chunk gc lives in rotation buffer gc % NBUF
   {
-    const unsigned b1 = x_off(s0);  // iteration 1's tile first (older), then iteration 0's: 32 loads stay younger than DMA(1)
+    const unsigned b1 = x_off(STEP * s0 + p_lane);
 #pragma unroll
-    for (int k = 0; k < KA; ++k) {
-      const int off = (int)(b1 != kOob ? b1 + (unsigned)(k * 32) : kOob);
-      xt[1][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
-      xt[1][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
-    }
+    for (int k = 0; k < KA; ++k) load_tile(std::integral_constant<int, 1>{}, k, b1);
   }
   asm volatile("" ::: "memory");
   dma_chunk(0, 0);
   dma_chunk(1, 1);
   asm volatile("" ::: "memory");
   {
-    const unsigned b0 = x_off(s0 - 1);
+    const unsigned b0 = x_off(STEP * (s0 - 1) + p_lane);
 #pragma unroll
-    for (int k = 0; k < KA; ++k) {
-      const int off = (int)(b0 != kOob ? b0 + (unsigned)(k * 32) : kOob);
-      xt[0][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
-      xt[0][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
-    }
+    for (int k = 0; k < KA; ++k) load_tile(std::integral_constant<int, 0>{}, k, b0);
   }
   asm volatile("" ::: "memory");
 
+  R2_ST_BEGIN();
   // top of chunk CC: its pieces have landed (every wave's: barrier), the buffer of chunk gc - 1 is free -> request chunk gc + 2
-  auto chunk_top = [&](auto cc_c) -> const char* {
+  auto chunk_top = [&](auto cc_c, auto seg_c) -> const char* {
     constexpr int CC = decltype(cc_c)::value;
+    R2_ST(decltype(seg_c)::value);  // what ran since the last stamp belongs to the caller's segment
     if (!R2_SKIP(8)) {
       wait_vm<wait_count(CC)>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    R2_ST(0);
     asm volatile("" ::: "memory");
     if (!R2_SKIP(4)) dma_chunk((CC + 2) % NCH, (gc + 2) % NBUF);
     asm volatile("" ::: "memory");
@@ -217,85 +268,83 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
   // magic number in a spilled register)
   int qf;
   {
-    const int pb0 = STEP * (s0 - 2) + 32 * wid + lr;
+    const int pb0 = STEP * (s0 - 2) + p_lane;
     qf = pb0 % a.HW;
     if (qf < 0) qf += a.HW;
   }
 
   // local iteration j (step i = s0 - 1 + j): phase A of step i on tile set SET = j & 1, phases B / C of step i - 1 with tile set
   // SET ^ 1 as the residual
+  int pa_next = STEP * (s0 - 1) + p_lane;  // (carried: recomputing it from the lane index per iteration cost a spilled register)
   auto iteration = [&](auto set_c, int i) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value, OLD = SET ^ 1;
     const bool store_ok = i - 1 >= s0 && i - 1 < s1;
-    const int pa = STEP * i + 32 * wid + lr;  // phase A's position (before / after the tensor: its ring slot is never read)
+    const int pa = pa_next;                   // phase A's position (before / after the tensor: its ring slot is never read)
+    pa_next += STEP;
     const int pb = pa - STEP;                 // phase B / C's position
     const unsigned ra = (unsigned)(pa + 8 * RING) % (unsigned)RING;
     const unsigned rb = (unsigned)(pb + 8 * RING) % (unsigned)RING;
     const bool pb_in = pb >= 0 && pb < a.P;
-    const int q = qf;
-    const int y = q / W, xc = q - y * W;
+    const int qq = qf;
+    const int y = qq / W, xc = qq - y * W;
     qf += STEP;
     while (qf >= a.HW) qf -= a.HW;
 
     // ================= phase A: a = relu(sa * (Wa x) + ba) -> ring
     {
-      f32x16 acc[2];
+      f32x4 acc[4];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+      for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto a_chunk = [&](auto jc_c) {
         constexpr int JC = decltype(jc_c)::value;
-        const char* cur = chunk_top(std::integral_constant<int, JC>{});
+        const char* cur = chunk_top(std::integral_constant<int, JC>{}, std::integral_constant<int, (JC == 0 ? 6 : 1)>{});
         int lofs = lane * 16;
         asm volatile("" : "+v"(lofs));
-        // the chunk's 8 fragment pairs, read AHEAD of their MFMAs (one wave per SIMD: nobody else hides the LDS latency)
+        // the chunk's fragment pairs are read AHEAD of their MFMAs: with every wave of the CU reading, an LDS read returns after
+        // ~200 cycles — read-then-use per pair made the kernel LDS-latency-bound (v3a: 136 pairs x ~200 cycles per iteration)
         i32x4 wf_[CH_PAIRS][2];
 #pragma unroll
         for (int pr = 0; pr < AHEAD; ++pr) { wf_[pr][0] = WP(cur, pr, 0, lofs); wf_[pr][1] = WP(cur, pr, 1, lofs); }
 #pragma unroll
-        for (int pr = 0; pr < CH_PAIRS; ++pr) {
+        for (int pr = 0; pr < CH_PAIRS; ++pr) {  // pair (kk, nt) at 4 kk + nt: k-step 2 JC + kk, n-tile nt
           if (pr + AHEAD < CH_PAIRS) { wf_[pr + AHEAD][0] = WP(cur, pr + AHEAD, 0, lofs); wf_[pr + AHEAD][1] = WP(cur, pr + AHEAD, 1, lofs); }
-          __builtin_amdgcn_sched_barrier(0);
-          const int k = JC * 4 + pr / 2, n = pr % 2;
+          R2_SCHED_FENCE();
+          const int k = JC * 2 + pr / 4, n = pr % 4;
           acc[n] = mfma3<F16>(wf_[pr][0], wf_[pr][1], xt[SET][k][0], xt[SET][k][1], acc[n]);
-          __builtin_amdgcn_sched_barrier(0);
+          R2_SCHED_FENCE();
         }
       };
       a_chunk(std::integral_constant<int, 0>{});
       a_chunk(std::integral_constant<int, 1>{});
       a_chunk(std::integral_constant<int, 2>{});
       a_chunk(std::integral_constant<int, 3>{});
+      R2_ST(1);
       const unsigned sw = (ra >> 1) & 7u;
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int m = 0; m < 2; ++m) {  // n-tiles 2 m, 2 m + 1 give this lane channels 32 m + 8 q .. + 7 (the packing's row order)
+        const int c0 = 32 * m + 8 * q;
+        float v[8];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int c0 = 32 * n + (2 * g + lh) * 8;
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(acc[n][8 * g + e] * cf[c0 + e] + cf[CM + c0 + e]);
-          uint4 h, l;
-          r2_split<F16>(v, h, l);
-          const unsigned chunk = (unsigned)(4 * n + 2 * g + lh);
-          const unsigned o = ra * 128u + ((chunk ^ sw) * 16u);
-          *reinterpret_cast<uint4*>(lds + o) = h;
-          *reinterpret_cast<uint4*>(lds + RING_PLANE + o) = l;
-        }
+        for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(acc[2 * m + (e >> 2)][e & 3] * cf[c0 + e] + cf[CM + c0 + e]);
+        uint4 h, l;
+        r2_split<F16>(v, h, l);
+        const unsigned chunk = (unsigned)(4 * m + q);
+        const unsigned o = ra * 128u + ((chunk ^ sw) * 16u);
+        *reinterpret_cast<uint4*>(lds + o) = h;
+        *reinterpret_cast<uint4*>(lds + RING_PLANE + o) = l;
+      }
     }
 
     // ================= phase B (step i - 1): b = relu(sb * (Wb * taps(a)) + bb), operands from the ring
-    i32x4 zb[4][2];  // phase C's operand: k-slice k' = 2 n + g of b's output, [plane]
+    i32x4 zb[2][2];  // phase C's operand: k-step m of b's output, [plane]
     {
-      f32x16 acc[2];
+      f32x4 acc[4];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+      for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto b_tap = [&](auto t_c) {
         constexpr int T = decltype(t_c)::value;
         constexpr int dy = T / 3 - 1, dx = T % 3 - 1;
-        const char* cur = chunk_top(std::integral_constant<int, NCH_A + T>{});
+        const char* cur = chunk_top(std::integral_constant<int, NCH_A + T>{}, std::integral_constant<int, (T == 0 ? 2 : 3)>{});
         // the neighbour's ring slot, or the zero slot when it lies outside the frame
         const bool ok = pb_in && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(xc + dx) < (unsigned)W;
         int nb = (int)rb + dy * W + dx;
@@ -303,11 +352,10 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
         const unsigned nsw = ((unsigned)nb >> 1) & 7u;
         int lofs = lane * 16;
         asm volatile("" : "+v"(lofs));
-        // the tap's four operand k-slices from the ring, then the 8 weight pairs read ahead of their MFMAs
-        i32x4 fx[4][2];
+        i32x4 fx[2][2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned o = ok ? (unsigned)nb * 128u + ((((unsigned)(2 * k + lh)) ^ nsw) * 16u) : (unsigned)ZERO_OFF;
+        for (int k = 0; k < 2; ++k) {
+          const unsigned o = ok ? (unsigned)nb * 128u + ((((unsigned)(4 * k + q)) ^ nsw) * 16u) : (unsigned)ZERO_OFF;
           fx[k][0] = *reinterpret_cast<const i32x4*>(lds + o);
           fx[k][1] = *reinterpret_cast<const i32x4*>(lds + (ok ? RING_PLANE : 0) + o);
         }
@@ -315,12 +363,12 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
 #pragma unroll
         for (int pr = 0; pr < AHEAD; ++pr) { wf_[pr][0] = WP(cur, pr, 0, lofs); wf_[pr][1] = WP(cur, pr, 1, lofs); }
 #pragma unroll
-        for (int pr = 0; pr < CH_PAIRS; ++pr) {
+        for (int pr = 0; pr < CH_PAIRS; ++pr) {  // pair (kk, nt) at 4 kk + nt
           if (pr + AHEAD < CH_PAIRS) { wf_[pr + AHEAD][0] = WP(cur, pr + AHEAD, 0, lofs); wf_[pr + AHEAD][1] = WP(cur, pr + AHEAD, 1, lofs); }
-          __builtin_amdgcn_sched_barrier(0);
-          const int k = pr / 2, n = pr % 2;
+          R2_SCHED_FENCE();
+          const int k = pr / 4, n = pr % 4;
           acc[n] = mfma3<F16>(wf_[pr][0], wf_[pr][1], fx[k][0], fx[k][1], acc[n]);
-          __builtin_amdgcn_sched_barrier(0);
+          R2_SCHED_FENCE();
         }
       };
       b_tap(std::integral_constant<int, 0>{});
@@ -332,73 +380,71 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
       b_tap(std::integral_constant<int, 6>{});
       b_tap(std::integral_constant<int, 7>{});
       b_tap(std::integral_constant<int, 8>{});
+      R2_ST(3);
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int m = 0; m < 2; ++m) {
+        const int c0 = 32 * m + 8 * q;
+        float v[8];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int c0 = 32 * n + (2 * g + lh) * 8;
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(acc[n][8 * g + e] * cf[2 * CM + c0 + e] + cf[3 * CM + c0 + e]);
-          uint4 h, l;
-          r2_split<F16>(v, h, l);
-          zb[2 * n + g][0] = __builtin_bit_cast(i32x4, h);
-          zb[2 * n + g][1] = __builtin_bit_cast(i32x4, l);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(acc[2 * m + (e >> 2)][e & 3] * cf[2 * CM + c0 + e] + cf[3 * CM + c0 + e]);
+        uint4 h, l;
+        r2_split<F16>(v, h, l);
+        zb[m][0] = __builtin_bit_cast(i32x4, h);
+        zb[m][1] = __builtin_bit_cast(i32x4, l);
+      }
     }
 
     // ================= phase C (step i - 1): out = relu(sc * (Wc b) + bc + x); x = the tile phase A used one iteration ago, still in
     // registers; the tile of step i + 1 is requested into them as they are released
     {
-      const unsigned out_base = (pb_in && store_ok) ? ((unsigned)pb * (unsigned)a.ldo) * 2u : kOob;
-      const unsigned xn = i + 1 <= s1 ? x_off(i + 1) : kOob;  // (past the last iteration: nothing to fetch; the loads still issue)
+      const unsigned out_base = (pb_in && store_ok) ? ((unsigned)pb * (unsigned)a.ldo + (unsigned)(q * 8)) * 2u : kOob;
+      const unsigned xn = (i + 1 <= s1 && !R2_SKIP(2)) ? x_off(pa + STEP) : kOob;  // (past the last iteration: the loads still issue)
       auto c_chunk = [&](auto jc_c) {
         constexpr int JC = decltype(jc_c)::value;
-        const char* cur = chunk_top(std::integral_constant<int, NCH_A + NCH_B + JC>{});
+        const char* cur = chunk_top(std::integral_constant<int, NCH_A + NCH_B + JC>{}, std::integral_constant<int, (JC == 0 ? 4 : 6)>{});
         int lofs = lane * 16;
         asm volatile("" : "+v"(lofs));
-        // all 8 fragment pairs of the chunk up front (64 registers): the first n-tile's epilogue then runs under the second's MFMAs
-        i32x4 wf_[CH_PAIRS][2];
+        // all four n-tiles' MFMAs first (fragments read ahead), then the two epilogues: the epilogue VALU of this wave runs under the
+        // other wave's MFMAs
+        f32x4 acs[4];
+        {
+          i32x4 wf_[CH_PAIRS][2];
 #pragma unroll
-        for (int pr = 0; pr < CH_PAIRS; ++pr) { wf_[pr][0] = WP(cur, pr, 0, lofs); wf_[pr][1] = WP(cur, pr, 1, lofs); }
-        f32x16 accs[2];
+          for (int pr = 0; pr < AHEAD; ++pr) { wf_[pr][0] = WP(cur, pr, 0, lofs); wf_[pr][1] = WP(cur, pr, 1, lofs); }
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) accs[nn][r] = 0.0f;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) accs[nn] = mfma3<F16>(wf_[nn * 4 + k][0], wf_[nn * 4 + k][1], zb[k][0], zb[k][1], accs[nn]);
+          for (int pr = 0; pr < CH_PAIRS; ++pr) {  // pair (nn, kk) at 2 nn + kk
+            if (pr + AHEAD < CH_PAIRS) { wf_[pr + AHEAD][0] = WP(cur, pr + AHEAD, 0, lofs); wf_[pr + AHEAD][1] = WP(cur, pr + AHEAD, 1, lofs); }
+            R2_SCHED_FENCE();
+            const int nn = pr / 2, k = pr % 2;
+            if (k == 0) acs[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acs[nn] = mfma3<F16>(wf_[pr][0], wf_[pr][1], zb[k][0], zb[k][1], acs[nn]);
+            R2_SCHED_FENCE();
+          }
         }
+        R2_ST(5);
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-          const int N = JC * 2 + nn;
-          const f32x16 acc = accs[nn];
+        for (int mm = 0; mm < 2; ++mm) {  // output channels 32 M + 8 q .. + 7: n-tiles 2 M, 2 M + 1 = the chunk's n-tiles 2 mm, 2 mm + 1
+          const int M = JC * 2 + mm;
+          const f32x4 ac[2] = {acs[2 * mm], acs[2 * mm + 1]};
+          const int c0 = 32 * M + 8 * q;
+          float v[8];
+          const i32x4 rh = xt[OLD][M][0], rl = xt[OLD][M][1];  // channels 32 M + 8 q .. of this position: the residual
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            const int c0 = 32 * N + (2 * g + lh) * 8;
-            float v[8];
-            const i32x4 rh = xt[OLD][2 * N + g][0], rl = xt[OLD][2 * N + g][1];  // channels 16 (2 N + g) + 8 lh .. = c0 ..
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const avt::f32x2 r = avt::join2<F16>((uint32_t)rh[e], (uint32_t)rl[e]);
-              v[2 * e] = acc[8 * g + 2 * e] * cf[4 * CM + c0 + 2 * e] + cf[4 * CM + C + c0 + 2 * e] + r.x;
-              v[2 * e + 1] = acc[8 * g + 2 * e + 1] * cf[4 * CM + c0 + 2 * e + 1] + cf[4 * CM + C + c0 + 2 * e + 1] + r.y;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(v[e]);
-            uint4 oh, ol;
-            r2_split<F16>(v, oh, ol);
-            const int off = (int)(out_base != kOob ? out_base + (unsigned)(c0 * 2) : kOob);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, oh), roh, R2_SKIP(1) ? (int)kOob : off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ol), rol, R2_SKIP(1) ? (int)kOob : off, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            avt::f32x2 r;  // (fp16 planes: hi + lo as ONE mixed-precision FMA per value, the bits of join2's two conversions + add)
+            if constexpr (F16) r = avt::join2_mix_f16((uint32_t)rh[e], (uint32_t)rl[e]);
+            else r = avt::join2<F16>((uint32_t)rh[e], (uint32_t)rl[e]);
+            v[2 * e] = ac[(2 * e) >> 2][(2 * e) & 3] * cf[4 * CM + c0 + 2 * e] + cf[4 * CM + C + c0 + 2 * e] + r.x;
+            v[2 * e + 1] = ac[(2 * e + 1) >> 2][(2 * e + 1) & 3] * cf[4 * CM + c0 + 2 * e + 1] + cf[4 * CM + C + c0 + 2 * e + 1] + r.y;
           }
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {  // k-slices 2 N, 2 N + 1 of the tile of step i + 1 into the registers just released
-            const int k = 2 * N + g;
-            const int off = (int)((xn != kOob && !R2_SKIP(2)) ? xn + (unsigned)(k * 32) : kOob);
-            xt[OLD][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
-            xt[OLD][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
-          }
+          for (int e = 0; e < 8; ++e) v[e] = avt::relu_keep_nan(v[e]);
+          uint4 oh, ol;
+          r2_split<F16>(v, oh, ol);
+          const int off = (int)((out_base != kOob && !R2_SKIP(1)) ? out_base + (unsigned)(M * 64) : kOob);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, oh), roh, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ol), rol, off, 0, 0);
+          load_tile(std::integral_constant<int, OLD>{}, M, xn);  // k-step M of the tile of step i + 1 into the registers just released
         }
       };
       c_chunk(std::integral_constant<int, 0>{});
@@ -417,6 +463,8 @@ __global__ __launch_bounds__(NWV * 64) void res2_x3_kernel(R2Args a) {
     ++i;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the two chunks requested past the end land before the LDS is released
+  R2_ST(6);
+  R2_ST_END();
 }
 
 template <int W, bool F16>
@@ -435,6 +483,17 @@ int launch(R2Args& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef R2_STAMP
+extern "C" int avt_debug_stamps_res2(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_r2_stamp), sizeof(unsigned long long) * 10);
+  if (reset) {
+    unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_r2_stamp), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" int avt_res2_x3_supported(int c, int cm, int w) { return (c == C && cm == CM && (w == 56 || w == 12)) ? 1 : 0; }
 

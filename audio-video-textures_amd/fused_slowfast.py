@@ -632,9 +632,9 @@ def pack_c33_x3(wb, bias, x3, device):
 
 def pack_res2_x3(wa, ba, wb, bb, wc, bc, x3, device):
     """BN-folded weights of a slow-res2 identity bottleneck (wa [64,256,1,1,1], wb [64,64,1,3,3], wc [256,64,1,1,1]) -> csrc/res2_x3.hip's
-    (wfrag, coef) (include/avt.h avt_res2_x3): the weight STREAM of 17 chunks x 8 pairs x 2 planes of 32 x 32 x 16 MFMA operands in the
-    order the kernel consumes them, output rows permuted as pack_c33_x3's (a lane of the accumulator ends with runs of 8 consecutive
-    channels); fp16 planes: every output channel scaled by a power of two into [2^9, 2^10), undone by coef's scales."""
+    (wfrag, coef) (include/avt.h avt_res2_x3): the weight STREAM of 17 chunks x 8 pairs x 2 planes of 16 x 16 x 32 MFMA operands in the
+    order the kernel consumes them, every operand in pack_pw_planes' form (output rows permuted so that two n-tiles give a lane 8
+    consecutive channels); fp16 planes: every output channel scaled by a power of two into [2^9, 2^10), undone by coef's scales."""
     wa, ba, wb, bb, wc, bc = [v.detach().float().cpu() for v in (wa, ba, wb, bb, wc, bc)]
     cm, c = wa.shape[0], wc.shape[0]
     assert (cm, c) == (64, 256) and wa.shape[1] == c and tuple(wb.shape) == (cm, cm, 1, 3, 3) and wc.shape[1] == cm
@@ -649,34 +649,28 @@ def pack_res2_x3(wa, ba, wb, bb, wc, bc, x3, device):
     a2 = wa.reshape(cm, c) * sa.view(-1, 1)                       # [64, 256]
     b9 = wb[:, :, 0].reshape(cm, cm, 9) * sb.view(-1, 1, 1)       # [out, in, tap]
     c2 = wc.reshape(c, cm) * sc.view(-1, 1)                       # [256, 64]
-    lane = torch.arange(64)
-    rho, kh = lane & 31, lane >> 5
-    h = (rho >> 2) & 1
-    r = (rho & 3) + 4 * (rho >> 3)
-    chan = (2 * (r >> 3) + h) * 8 + (r & 7)                       # channel of an n-tile an operand row feeds
-    e = torch.arange(8)
 
-    def frag(mat, n, k):  # mat [out, K] -> [64 lanes, 8]: lane l holds mat[32 n + chan(l & 31)][16 k + 8 (l >> 5) + e]
-        rows = (32 * n + chan).view(-1, 1).expand(64, 8)
-        cols = (16 * k + 8 * kh).view(-1, 1) + e.view(1, -1)
-        return mat[rows, cols]
+    def frags(mat):  # [N, K] -> (hi, lo) [N/16][K/32][64][8] (raw 16-bit, typed bfloat16)
+        hi, lo = split_planes(mat, x3)
+        return pack_pw_planes(hi), pack_pw_planes(lo)
 
-    pairs = []
-    for jc in range(4):          # a: chunk jc = k-slices 4 jc .. + 3, pair index 2 kk + n
-        for kk in range(4):
-            for n in range(2):
-                pairs.append(frag(a2, n, 4 * jc + kk))
-    for t in range(9):           # b: one tap per chunk, pair index 2 k + n
-        for k in range(4):
-            for n in range(2):
-                pairs.append(frag(b9[:, :, t], n, k))
-    for jc in range(4):          # c: chunk jc = n-tiles 2 jc, 2 jc + 1, pair index 4 nn + k
-        for nn in range(2):
-            for k in range(4):
-                pairs.append(frag(c2, 2 * jc + nn, k))
-    allf = torch.stack(pairs)    # [136, 64, 8] fp32
-    hi, lo = split_planes(allf, x3)
-    wfrag = torch.stack([hi, lo], 1).contiguous().to(device)  # [136 pairs][2 planes][64][8]
+    pairs = []  # (hi [64, 8], lo [64, 8]) in stream order
+    ah, al = frags(a2)
+    for jc in range(4):          # a: chunk jc = k-steps 2 jc, 2 jc + 1; pair (kk, nt) at 4 kk + nt
+        for kk in range(2):
+            for nt in range(4):
+                pairs.append((ah[nt, 2 * jc + kk], al[nt, 2 * jc + kk]))
+    for t in range(9):           # b: one tap per chunk, pair (kk, nt) at 4 kk + nt
+        bh, bl = frags(b9[:, :, t].contiguous())
+        for kk in range(2):
+            for nt in range(4):
+                pairs.append((bh[nt, kk], bl[nt, kk]))
+    ch, cl = frags(c2)
+    for jc in range(4):          # c: chunk jc = n-tiles 4 jc .. + 3, pair (nn, kk) at 2 nn + kk
+        for nn in range(4):
+            for kk in range(2):
+                pairs.append((ch[4 * jc + nn, kk], cl[4 * jc + nn, kk]))
+    wfrag = torch.stack([torch.stack([h, l]) for h, l in pairs]).contiguous().to(device)  # [136 pairs][2 planes][64][8]
     coef = torch.cat([1.0 / sa, ba, 1.0 / sb, bb, 1.0 / sc, bc]).float().contiguous().to(device)
     return wfrag, coef
 

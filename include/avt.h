@@ -390,14 +390,14 @@ int avt_bneck_x3(const void* x_hi, const void* x_lo, void* out_hi, void* out_lo,
  * round 5 ran them as three launches avt_pw_x3 / avt_conv33_x3 / avt_pw_chain_x3):
  *     out = relu(c(relu(b(relu(a(x))))) + x),  a: 1x1x1 256 -> 64, b: [1,3,3] 64 -> 64, c: 1x1x1 64 -> 256, BatchNorms folded.
  * x [batch*t*h*w, ldi], out [., ldo] plane pairs (channel slices of wider rows allowed; distinct buffers); fp16 planes only.
- * The a output lives in an LDS ring, b's output in registers; x crosses HBM once (+ one re-read from L2 / Infinity Cache as the
- * residual), out once; the weights STREAM from L2 by LDS-DMA.  wfrag = avt_res2_x3_wfrag_bytes() bytes: [17 chunks][8 pairs]
- * [2 planes: hi, lo][64 lanes][8] 16-bit, a pair = one 32-row x 16-k MFMA operand: lane l holds W[channel(l & 31)][16 k + 8 (l >> 5)
- * + e] with channel(rho) = 32 n + (2 (r >> 3) + h) * 8 + (r & 7), h = (rho >> 2) & 1, r = (rho & 3) + 4 (rho >> 3) (avt_conv33_x3's
- * row order).  Chunks 0-3: a, pair (kk, n) = k-slice 4 chunk + kk, n-tile n, at index 2 kk + n; chunks 4-12: b, one tap each, pair
- * (k, n) at 2 k + n; chunks 13-16: c, pair (nn, k) = n-tile 2 (chunk - 13) + nn, k-slice k, at 4 nn + k.  coef fp32 [sa 64 | ba 64 |
- * sb 64 | bb 64 | sc 256 | bc 256]: the power-of-two factors that undo the fp16 planes' per-channel weight scaling, and the biases.
- * Supported: w = 56 (and 12: tests), any h / t / batch within 32-bit byte offsets. */
+ * The a output lives in an LDS ring, b's output in registers, and the x tile stays in registers as the residual: x crosses HBM once,
+ * out once; the weights STREAM from L2 by LDS-DMA.  wfrag = avt_res2_x3_wfrag_bytes() bytes: [17 chunks][8 pairs][2 planes: hi, lo]
+ * [64 lanes][8] 16-bit, a pair = one 16-row x 32-k MFMA operand in avt_pw_x3's fragment form: lane l holds W[channel(nt, l & 15)]
+ * [32 k + 8 (l >> 4) + e] with channel(nt, r) = 32 (nt / 2) + 8 (r / 4) + 4 (nt % 2) + r % 4 (two n-tiles give a lane of the
+ * accumulators 8 consecutive channels).  Chunks 0-3: a, pair (kk, nt) = k-step 2 chunk + kk, n-tile nt, at index 4 kk + nt; chunks
+ * 4-12: b, one tap each, pair (kk, nt) at 4 kk + nt; chunks 13-16: c, pair (nn, kk) = n-tile 4 (chunk - 13) + nn, k-step kk, at
+ * 2 nn + kk.  coef fp32 [sa 64 | ba 64 | sb 64 | bb 64 | sc 256 | bc 256]: the power-of-two factors that undo the fp16 planes'
+ * per-channel weight scaling, and the biases.  Supported: w = 56 (and 12: tests), any h / t / batch within 32-bit byte offsets. */
 int avt_res2_x3_supported(int c, int cm, int w);
 int avt_res2_x3_wfrag_bytes(void);
 int avt_res2_x3(const void* x_hi, const void* x_lo, void* out_hi, void* out_lo, const void* wfrag, const float* coef, int batch,

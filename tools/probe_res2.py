@@ -32,5 +32,19 @@ e.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(e) / reps
 fl = m * 2.0 * (256 * 64 + 576 * 64 + 64 * 256)
+import ctypes, os
+_h = ctypes.CDLL(os.environ["AVT_HIP_LIB"]) if os.environ.get("AVT_HIP_LIB") else None
+if _h is not None and hasattr(_h, "avt_debug_stamps_res2"):  # a -DR2_STAMP build: where wave 0's cycles went (summed over workgroups)
+    buf = (ctypes.c_ulonglong * 10)()
+    _h.avt_debug_stamps_res2(buf, 1)
+    blk(x, out=y)
+    torch.cuda.synchronize()
+    _h.avt_debug_stamps_res2(buf, 1)
+    names = ["chunk-top waits (DMA landed, LDS drain, barrier)", "phase A chunks", "A epilogue", "phase B taps", "B epilogue", "phase C MFMAs",
+             "phase C epilogues + stores + next tile's loads"]
+    tot = sum(buf[i] for i in range(7))
+    print("  stamps: %d workgroups, %.0f cycles each; shader clock %.0f MHz" % (buf[7], tot / max(buf[7], 1), 100.0 * buf[8] / max(buf[9], 1)))
+    for i, nm in enumerate(names):
+        print("    %-52s %5.1f %%  (%.0f cycles / workgroup)" % (nm, 100.0 * buf[i] / tot, buf[i] / max(buf[7], 1)))
 print("res2_x3 batch %d: %.3f ms per launch, %.1f TFLOP/s algorithmic (%.3f of 833), %.0f GB/s (x in + out)" % (
     b, ms, fl / ms / 1e9, fl / ms / 1e9 / 833.3, m * 2048.0 / ms / 1e6))
