@@ -75,7 +75,21 @@ def compare_tables(qa, ta, qb, tb, temp, W, S, thresholds=(0.0, 0.3), walk_frame
         no_tie = np.ones(n, dtype=bool)
         no_tie[tie_rows] = False
         subset = sum(1 for r in tie_rows if set(host[0]["seg"][r, : host[0]["cnt"][r]].tolist()) <= set(host[1]["seg"][r, : host[1]["cnt"][r]].tolist()))
+        # ... and where the survivors differ although the reference has no exact tie: how far apart, IN THE REFERENCE, are its own
+        # maximum and the worst candidate the other arithmetic kept?  (|A - B| <= d everywhere bounds this gap by 2 d: a row can only
+        # differ where the reference itself separates the candidates by less than the two arithmetics' distance)
+        gap = 0.0
+        if th == 0.0:
+            sb_h = None
+            for r in np.nonzero(~same_h)[0]:
+                if sb_h is None:
+                    sb_h = sb.cpu().numpy()
+                ka, kb = int(host[0]["cnt"][r]), int(host[1]["cnt"][r])
+                if ka and kb:
+                    ref_max = float(sb_h[r, host[1]["seg"][r, :kb]].max())
+                    gap = max(gap, ref_max - float(sb_h[r, host[0]["seg"][r, :ka]].min()))
         ties = {} if th != 0.0 else {
+            "max_ref_gap_on_differing_rows": gap,
             "rows_with_exact_ties_ref": int(len(tie_rows)),
             "rows_identical_survivors_outside_tie_rows": float(same_h[no_tie].mean()) if no_tie.any() else 1.0,
             "tie_rows_survivors_subset_of_ref_ties": "%d/%d" % (subset, len(tie_rows))}

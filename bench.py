@@ -836,7 +836,8 @@ def main():
         # (a th-0.0 disagreement is only meaningful outside the rows where the fp32 reference ITSELF has exact ties)
         out["th0_ties"] = {"rows_with_exact_ties_fp32": t0_.get("rows_with_exact_ties_ref"),
                            "rows_identical_outside_tie_rows": t0_.get("rows_identical_survivors_outside_tie_rows"),
-                           "tie_rows_subset_of_fp32_ties": t0_.get("tie_rows_survivors_subset_of_ref_ties")}
+                           "tie_rows_subset_of_fp32_ties": t0_.get("tie_rows_survivors_subset_of_ref_ties"),
+                           "max_fp32_gap_on_differing_rows": t0_.get("max_ref_gap_on_differing_rows")}
         note("precision block done")
     if world == 1 and not args.no_nxn_legs:
         detail["nxn_legs"] = nxn_legs(dev)

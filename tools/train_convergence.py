@@ -83,6 +83,11 @@ def train_run(mode, args, dev, video, keep=False):
         if args.epochs:
             if it % per_epoch == 0:
                 perm = rng.permutation(len(ds))
+                # the reference's schedule shape (main.py:448-449: StepLR, x 0.1 at fixed epochs): --lr-decay-epochs
+                if (it // per_epoch) in args.lr_decay_epochs:
+                    for g in opt.param_groups:
+                        g["lr"] *= 0.1
+                    print("[%s] epoch %d: lr -> %g" % (mode, it // per_epoch, opt.param_groups[0]["lr"]), file=sys.stderr, flush=True)
             ids = [int(i) for i in perm[(it % per_epoch) * B : (it % per_epoch + 1) * B]]
         else:
             ids = [int(i) for i in rng.randint(0, len(ds), size=B)]
@@ -120,6 +125,7 @@ def train_run(mode, args, dev, video, keep=False):
            "calls": {k: v for k, v in train_ops.CALLS.items() if v}}
     if args.epochs:
         rec.update({"segments": len(ds), "steps_per_epoch": per_epoch, "epoch_loss": epoch_loss, "stop_loss": args.stop_loss,
+                    "lr_decay_epochs": list(args.lr_decay_epochs),
                     "stopped_at_epoch": stopped_at, "epochs_run": len(epoch_loss)})
     for k in train_ops.CALLS:
         train_ops.CALLS[k] = 0
@@ -233,6 +239,10 @@ def main():
     ap.add_argument("--epochs", type=int, default=0, help="epoch mode: at most this many epochs over a shuffled permutation of the segments "
                     "(batches of 8), stopping at the reference's rule (epoch loss < --stop-loss, main.py:475-477); 0 = --steps random batches")
     ap.add_argument("--stop-loss", type=float, default=0.07)
+    ap.add_argument("--lr-decay-epochs", type=lambda v: [int(x) for x in v.split(",") if x], default=[],
+                    help="epoch mode: epochs at which the learning rate is multiplied by 0.1 (the reference's StepLR, main.py:448-449)")
+    ap.add_argument("--no-miopen-find", action="store_true", help="torch.backends.cudnn.benchmark off: the fp32 (MIOpen) mode without its "
+                    "exhaustive solver search (minutes before the first step)")
     ap.add_argument("--roundtrip", action="store_true")
     ap.add_argument("--workdir", default="/tmp/avt_train_convergence")
     ap.add_argument("--against", default=None, help="a recorded result of this tool (same config): the largest EMA distance of each "
@@ -245,7 +255,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     ops.device_check()
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = not args.no_miopen_find
     video = synth.structured_video(123, args.frames, args.frame_hw, args.frame_hw, scene_len=args.scene_len, variety=1)
     res = {"config": {"steps": args.steps, "lr": args.lr, "init": args.init, "batch": 8, "negs": 14, "temp": 0.1, "img_size": 224,
                       "video": "synth.structured_video(123, %d, %d, %d, scene_len=%d, variety=1), fps 30 -> W 15, S 6" % (
