@@ -274,13 +274,17 @@ def _gemm_ktab(k, lda, device):
     return tab
 
 
-def sim_gemm_nt(q, t, temp, precision="f32", q_lo=None, t_lo=None, out=None):
-    """out[i,j] = <q_i, t_j> / temp.  precision: "f32" (exact, canonical) | "bf16" | "bf16x3"."""
+def sim_gemm_nt(q, t, temp, precision="f32", q_lo=None, t_lo=None, out=None, nq_total=None):
+    """out[i,j] = <q_i, t_j> / temp.  precision: "f32" (exact, canonical) | "bf16" | "bf16x3".
+    nq_total: query rows of the WHOLE build when q is one rank's row block (default: max(rows of q, rows of t) — in a sharded build
+    every rank holds all of T).  The bf16x3 tile is chosen from it, not from this call's rows: the two tiles accumulate in different
+    orders (3-4e-6 apart), and a score must not depend on how many ranks built the matrix."""
     prec = _PREC[precision]
+    nq_all = max(int(q.shape[0]), int(t.shape[0])) if nq_total is None else int(nq_total)
     if (SIM_XL and prec == SIM_BF16X3 and q_lo is not None and t_lo is not None and q.dim() == 2 and t.shape[0] % 256 == 0 and
-            q.shape[1] % 32 == 0 and 256 <= q.shape[1] <= 8192 and (SIM_XL == "always" or -(-q.shape[0] // 256) * (t.shape[0] // 256) >= 192) and
+            q.shape[1] % 32 == 0 and 256 <= q.shape[1] <= 8192 and (SIM_XL == "always" or -(-nq_all // 256) * (t.shape[0] // 256) >= 192) and
             (out is None or out.stride(0) % 4 == 0)):
-        # (>= 192 tiles: three quarters of a round of the 256 CUs — 4096^2 is exactly one round, the config-4 shard two; at 2048^2 (64
+        # (>= 192 tiles of the whole build: three quarters of a round of the 256 CUs — 4096^2 is exactly one round; at 2048^2 (64
         #  tiles) the 128 x 128 tile's 256 workgroups win: tools/probe_sim_xl.py)
         for name, v in (("q", q), ("q_lo", q_lo), ("t", t), ("t_lo", t_lo)):
             _dev(v, name, torch.bfloat16)

@@ -181,7 +181,12 @@ class SlowFast(nn.Module):
     def forward(self, x):
         if PATHWAY_STREAMS and self.training and x[0].is_cuda and torch.is_grad_enabled():
             cur = torch.cuda.current_stream(x[0].device)
-            if cur.cuda_stream == torch.cuda.default_stream(x[0].device).cuda_stream:
+            # the encoder whose forward runs on the STEP's own stream (the target encoder) forks its fast pathway; the one that
+            # already runs on one of the package's side streams (the query encoder) does not.  (Round 5 asked for the default stream;
+            # a step captured as a HIP graph runs on a capture stream, train_ops.GraphedStep)
+            from . import ops
+
+            if all(s.cuda_stream != cur.cuda_stream for lst in ops._SIDE.values() for s in lst):
                 return self._forward_two_streams(x, cur)
         x = self.s1_fuse(self.s1(x, self.s1_fuse.extra))
         x = self.s2_fuse(self.s2(x, self.s2_fuse.extra))

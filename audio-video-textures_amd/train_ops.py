@@ -18,6 +18,7 @@ fp64 step by the deviation of the stock fp32 step.
 Weight planes are cached per tensor and rebuilt when `weight._version` changes (optimizer.step(), load_state_dict, any
 in-place op on the parameter).  In-place updates through `.data` (EMA / momentum encoders, `p.data.clamp_()`) do NOT bump
 that counter: call `invalidate_weight_cache()` after them (train.train() does after every optimizer step)."""
+import contextlib
 import ctypes as C
 import weakref
 
@@ -342,6 +343,37 @@ def bn_act(x, bn, res=None, relu=True, cat_extra=0, cat_into=None):
         y._avt_bn = _LAST_BN  # (the convolution that consumes y hands it to its input-gradient launch: conv3d / conv3d_fork)
     _LAST_BN = None
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# One training step as a replayed HIP graph (round 6).  Config 5 on 8 GPUs gives every rank ONE item (16 clips) per step: ~3000
+# launches whose device time is below the host's time to issue them — the host never waits for the device in that step
+# (profiles/r06/train_host_bound_one_item.log: 65 ms per step, 0.05 s of device waits in 4 s).  Every launch of the step goes to
+# torch's current stream (the C ABI takes the stream), autograd replays the backward on the forward's streams, the side streams
+# fork from and join the capturing stream by events, and no tensor of the step is read on the host — so the whole device side of a
+# step (sample + pack, forward, loss, backward, optimizer, weight planes) is capturable as it stands.
+class GraphedStep:
+    """step_fn() -> tensor (e.g. the loss): run `warmup` times eagerly on a side stream, then captured ONCE; every call replays the
+    graph and returns the same (graph-owned) result tensor.  Inputs must be STATIC tensors that step_fn closes over (fill them with
+    copy_ before each call); anything the host decides inside step_fn (branches, cache lookups, shapes) is frozen at capture."""
+
+    def __init__(self, step_fn, device, warmup=3):
+        self.graph, self.out = None, None
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.out = step_fn()
+        self.graph = g
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -700,51 +732,63 @@ def _conv_backward(ctx, dy, dalias):
     x, weight = ctx.saved_tensors
     stride, padding, kernel, cin, cout = ctx.conf
     dy = dy.contiguous(memory_format=torch.channels_last_3d)
-    dx = dw = None
-    if ctx.needs_input_grad[1]:
-        taps = kernel[0] * kernel[1] * kernel[2]
-        if (_WGRAD_X3 and cin % 8 == 0 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64 and
-                weight.is_contiguous(memory_format=torch.channels_last_3d)):
-            CALLS["wgrad_x3"] += 1
-            dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
-            flat = _ARENA.take(weight.numel(), weight.device) if _ARENA is not None else None
-            if flat is not None:  # a zeroed slice of the micro-batch's gradient arena: no memset launch per convolution
-                dw = flat.view(cout, kernel[0], kernel[1], kernel[2], cin).permute(0, 4, 1, 2, 3)
-                ops.conv3d_wgrad_x3_sub_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), flat, dims, cin, cout, kernel, stride,
-                                            padding, (0, 0, 0), cin, cout, taps * cin, False)
-            else:
-                dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
-                ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1), dims, cin, cout,
-                                        kernel, stride, padding, cin, cout)
-        elif (_WGRAD_X3 and cin % 8 and cin != 3 and x.shape[1] == 8 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64):
-            # a few-channel first layer (VGGish: 1 mel channel) on its zero-padded 8-channel copy; the padded taps' gradient is dropped
-            CALLS["wgrad_x3"] += 1
-            dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
-            dw8 = torch.empty((cout, 8) + tuple(kernel), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last_3d)
-            ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw8.permute(0, 2, 3, 4, 1), dims, 8, cout, kernel,
-                                    stride, padding, 8, cout)
-            dw = torch.empty_like(weight)
-            dw.copy_(dw8[:, :cin])
-        elif (_WGRAD_X3 and _STEM_WGRAD_X3 and cin == 3 and x.shape[1] == 8 and kernel[1] * kernel[2] <= 49 and
-              max(x.numel(), dy.numel()) < (1 << 31) - 64):
-            # the stems: 3 input channels travel as 4 of the forward's 8-channel padded clip; a [kt,7,7] filter is kt slices of
-            # 49 taps, each a weight-gradient problem of its own with the temporal padding shifted by its frame tap
-            kt, kh, kw = kernel
-            acc = torch.zeros((cout, kt, kh * kw, 4), dtype=torch.float32, device=dy.device)
-            xr, dyr = x.permute(0, 2, 3, 4, 1), dy.permute(0, 2, 3, 4, 1)
-            dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
-            for dt in range(kt):
-                ops.conv3d_wgrad_x3_sub_f32(dyr, xr, acc[:, dt], dims, 4, cout, (1, kh, kw), stride, (padding[0] - dt, padding[1], padding[2]),
-                                            (dy.shape[2], dy.shape[3], dy.shape[4]), 8, cout, kt * kh * kw * 4, False)
-            CALLS["wgrad_stem_x3"] += 1
-            dw = torch.empty_like(weight)
-            dw.copy_(acc.view(cout, kt, kh, kw, 4)[..., :3].permute(0, 4, 1, 2, 3))
-        else:  # (stems when AVT_TRAIN_STEM_WGRAD_X3=0, filters of more than 28 taps): MIOpen
-            if x.shape[1] != weight.shape[1]:  # the padded copy was saved: MIOpen wants the 3-channel clip
-                x = x[:, : weight.shape[1]].contiguous(memory_format=torch.channels_last_3d)
-            CALLS["miopen_wgrad"] += 1
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
-                                                     [False, True, False])[1]
+    dw = _conv_wgrad(ctx, dy, x, weight, stride, padding, kernel, cin, cout) if ctx.needs_input_grad[1] else None
+    return _conv_dgrad(ctx, dy, dalias, x, weight, stride, padding, kernel, cin, cout), dw
+
+
+def _conv_wgrad(ctx, dy, x, weight, stride, padding, kernel, cin, cout):
+    """dW of the convolution (split-plane weight-gradient kernels; MIOpen for the shapes they do not cover)."""
+    from . import ops
+    dw = None
+    taps = kernel[0] * kernel[1] * kernel[2]
+    if (_WGRAD_X3 and cin % 8 == 0 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64 and
+            weight.is_contiguous(memory_format=torch.channels_last_3d)):
+        CALLS["wgrad_x3"] += 1
+        dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
+        flat = _ARENA.take(weight.numel(), weight.device) if _ARENA is not None else None
+        if flat is not None:  # a zeroed slice of the micro-batch's gradient arena: no memset launch per convolution
+            dw = flat.view(cout, kernel[0], kernel[1], kernel[2], cin).permute(0, 4, 1, 2, 3)
+            ops.conv3d_wgrad_x3_sub_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), flat, dims, cin, cout, kernel, stride,
+                                        padding, (0, 0, 0), cin, cout, taps * cin, False)
+        else:
+            dw = torch.empty_like(weight)  # channels-last strides: memory [cout][kt][kh][kw][cin], the kernel's order
+            ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw.permute(0, 2, 3, 4, 1), dims, cin, cout,
+                                    kernel, stride, padding, cin, cout)
+    elif (_WGRAD_X3 and cin % 8 and cin != 3 and x.shape[1] == 8 and taps <= 28 and max(x.numel(), dy.numel()) < (1 << 31) - 64):
+        # a few-channel first layer (VGGish: 1 mel channel) on its zero-padded 8-channel copy; the padded taps' gradient is dropped
+        CALLS["wgrad_x3"] += 1
+        dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
+        dw8 = torch.empty((cout, 8) + tuple(kernel), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last_3d)
+        ops.conv3d_wgrad_x3_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), dw8.permute(0, 2, 3, 4, 1), dims, 8, cout, kernel,
+                                stride, padding, 8, cout)
+        dw = torch.empty_like(weight)
+        dw.copy_(dw8[:, :cin])
+    elif (_WGRAD_X3 and _STEM_WGRAD_X3 and cin == 3 and x.shape[1] == 8 and kernel[1] * kernel[2] <= 49 and
+          max(x.numel(), dy.numel()) < (1 << 31) - 64):
+        # the stems: 3 input channels travel as 4 of the forward's 8-channel padded clip; a [kt,7,7] filter is kt slices of
+        # 49 taps, each a weight-gradient problem of its own with the temporal padding shifted by its frame tap
+        kt, kh, kw = kernel
+        acc = torch.zeros((cout, kt, kh * kw, 4), dtype=torch.float32, device=dy.device)
+        xr, dyr = x.permute(0, 2, 3, 4, 1), dy.permute(0, 2, 3, 4, 1)
+        dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
+        for dt in range(kt):
+            ops.conv3d_wgrad_x3_sub_f32(dyr, xr, acc[:, dt], dims, 4, cout, (1, kh, kw), stride, (padding[0] - dt, padding[1], padding[2]),
+                                        (dy.shape[2], dy.shape[3], dy.shape[4]), 8, cout, kt * kh * kw * 4, False)
+        CALLS["wgrad_stem_x3"] += 1
+        dw = torch.empty_like(weight)
+        dw.copy_(acc.view(cout, kt, kh, kw, 4)[..., :3].permute(0, 4, 1, 2, 3))
+    else:  # (stems when AVT_TRAIN_STEM_WGRAD_X3=0, filters of more than 28 taps): MIOpen
+        if x.shape[1] != weight.shape[1]:  # the padded copy was saved: MIOpen wants the 3-channel clip
+            x = x[:, : weight.shape[1]].contiguous(memory_format=torch.channels_last_3d)
+        CALLS["miopen_wgrad"] += 1
+        dw = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1,
+                                                 [False, True, False])[1]
+    return dw
+
+
+def _conv_dgrad(ctx, dy, dalias, x, weight, stride, padding, kernel, cin, cout):
+    from . import ops
+    dx = None
     if ctx.needs_input_grad[0]:
         if dalias is not None:
             dalias = dalias.contiguous(memory_format=torch.channels_last_3d)
@@ -772,7 +816,7 @@ def _conv_backward(ctx, dy, dalias):
                                                          [True, False, False])[0]
             if dalias is not None:
                 dx = dx + dalias
-    return dx, dw
+    return dx
 
 
 def _stride_classes(k, s, p, x, y):

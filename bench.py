@@ -559,6 +559,40 @@ def train_bench(args, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # --train-graph: the device side of a step (sample + pack, forward, loss, backward, optimizer) captured once as a HIP graph and
+    # replayed — for steps whose launches the host cannot issue as fast as the device runs them (one item per rank).  One pass per
+    # step, one rank; the item indices travel through a static device tensor
+    graph_note = None
+    if getattr(args, "train_graph", 0) and world == 1 and not istreams and plan["passes"] == 1:
+        idx_buf = torch.zeros(items, dtype=torch.int64, device=dev)
+        labels0 = torch.zeros(items, dtype=torch.long, device=dev)
+
+        def device_step():
+            opt.zero_grad(set_to_none=True)
+            q, t, _, _ = bat.batch(idx_buf)
+            if channels_last:
+                q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
+            with amp(), train_ops.bn_replicas(items):
+                out = net(q, t)
+            loss = crit(out.float(), labels0)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
+        try:
+            idx_buf.copy_(torch.from_numpy(rng.randint(0, len(ds), size=items)))
+            gstep = train_ops.GraphedStep(device_step, dev, warmup=max(args.warmup, 3))
+
+            def step():  # noqa: F811 (the graphed form replaces the eager step)
+                idx_buf.copy_(torch.from_numpy(rng.randint(0, len(ds), size=items)), non_blocking=False)
+                losses.append(float(gstep()))
+
+            graph_note = "captured"
+        except Exception as e:  # (a step that cannot be captured runs eagerly, and the line says so)
+            graph_note = "capture failed: %s" % (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
+            print("[bench] --train-graph: %s" % graph_note, file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+
     for w in range(max(args.warmup, 1)):
         try:
             step()
@@ -602,7 +636,7 @@ def train_bench(args, rank, world, dev):
         "config": {"workload": "BASELINE config 5: batch %d x (1 query + 1 positive + 14 negatives) = %d clips/step at 224^2 " % (B, B * 16) +
                                "through SlowFast-8x8-R50 q/t encoders (train-mode BatchNorm per item = per DataParallel "
                                "replica), HIP InfoNCE + CE, SGD; inputs sampled and packed on the device",
-                   "items_per_rank": items, "items_per_pass": plan["per_pass"], "clips_per_step": clips, "window": ds.window, "stride": ds.stride,
+                   "items_per_rank": items, "items_per_pass": plan["per_pass"], "clips_per_step": clips, "hip_graph": graph_note, "window": ds.window, "stride": ds.stride,
                    "encoder_backend": ("hand-written HIP through torch.autograd.Function (fp32, channels_last_3d): conv_x3 IO32 forward + "
                                        "stride-1 dgrad, wgrad_x3, patch-resident stems (forward + weight gradient), bn_train; query encoder on a side stream; "
                                        "strided input gradients as residue-class convolutions, HIP max-pool; the rank's items as one batch of per-item BatchNorm groups") if hand
@@ -685,6 +719,9 @@ def build_parser():
     ap.add_argument("--train-items", type=int, default=0,
                     help="--mode train: items of the global batch (0 = 8, BASELINE config 5); 1 = one item = 16 clips per step: the shape "
                          "every rank of an 8-GPU run of config 5 sees (the default run reports it as train_clips_per_s_one_item)")
+    ap.add_argument("--train-graph", type=int, default=0, choices=[0, 1],
+                    help="--mode train: capture the device side of a step as ONE HIP graph and replay it (train_ops.GraphedStep): for "
+                         "steps the host cannot issue as fast as the device runs them (one item per rank); one pass per step, one rank")
     ap.add_argument("--no-train-one-item-leg", action="store_true", help="skip the one-item config-5 leg of the default run")
     ap.add_argument("--train-pass-items", type=int, default=0,
                     help="--mode train: items per forward/backward pass (0 = all of the rank's items as one batch with per-item "
@@ -874,11 +911,19 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             t1 = argparse.Namespace(**vars(targs))
-            t1.train_items, t1.steps, t1.warmup = 1, 12, 4
+            t1.train_items, t1.steps, t1.warmup, t1.train_graph = 1, 12, 4, 0
             tl1 = train_bench(t1, rank, world, dev)
-            detail["train_one_item"] = tl1
-            out["train_clips_per_s_one_item"], out["train_ms_per_step_one_item"] = tl1["value"], tl1["ms_per_step"]
-            note("one-item training leg (16 clips per step) done")
+            detail["train_one_item_eager"] = tl1
+            out["train_clips_per_s_one_item_eager"] = tl1["value"]
+            gc.collect()
+            torch.cuda.empty_cache()
+            t1.train_graph = 1  # the same step as ONE replayed HIP graph (the eager one-item step is bound by the host's launch rate)
+            tl1g = train_bench(t1, rank, world, dev)
+            detail["train_one_item"] = tl1g
+            best = tl1g if tl1g["config"]["hip_graph"] == "captured" else tl1
+            out["train_clips_per_s_one_item"], out["train_ms_per_step_one_item"] = best["value"], best["ms_per_step"]
+            out["train_one_item_hip_graph"] = tl1g["config"]["hip_graph"]
+            note("one-item training legs (16 clips per step: eager, HIP graph) done")
     emit(out, detail)
 
 

@@ -111,6 +111,22 @@ def test_sim_bf16x3_on_the_encoder_tile_equals_the_plain_tile(avt, dev):
     assert float((buf[nq:] - 7.0).abs().max()) == 0.0 and float((buf[:, nt:] - 7.0).abs().max()) == 0.0
 
 
+def test_sim_bf16x3_row_blocks_are_bitwise_the_unsharded_build(avt, dev):
+    """the bf16x3 tile is chosen from the WHOLE build's shape (rows of T), not from the rows of the call — so the row blocks
+    a sharded build computes (512 of 4096 rows per rank at world 8) are bit for bit the rows of the one-rank matrix, with the default
+    tile choice (4096^2 takes the 256 x 256 tile; a [512, 4096] block alone would have 32 tiles and used to take the plain one)."""
+    g = torch.Generator().manual_seed(5)
+    n, d = 4096, 2304
+    q = torch.nn.functional.normalize(torch.randn((n, d), generator=g), dim=1).to(dev)
+    t = torch.nn.functional.normalize(torch.randn((n, d), generator=g), dim=1).to(dev)
+    _, qh, ql = avt.ops.l2norm_rows(q, want_split=True)
+    _, th, tl = avt.ops.l2norm_rows(t, want_split=True)
+    whole = avt.ops.sim_gemm_nt(qh, th, 0.1, "bf16x3", q_lo=ql, t_lo=tl)
+    for lo in (0, 512, 3584):
+        part = avt.ops.sim_gemm_nt(qh[lo : lo + 512].contiguous(), th, 0.1, "bf16x3", q_lo=ql[lo : lo + 512].contiguous(), t_lo=tl)
+        assert torch.equal(part, whole[lo : lo + 512]), lo
+
+
 # ---------------------------------------------------------------- transition select
 def _check_transition(g, o, cap):
     cnt = o["cnt"]

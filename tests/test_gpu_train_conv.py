@@ -767,3 +767,40 @@ def test_backward_releases_what_the_batchnorm_handles_hold():
     act = x.numel() * 4  # one full-width activation
     assert peak_fwd > expect + 4 * act  # (the forward did keep activations: the test can see a leak)
     assert held <= expect + act, (held, expect, act)  # at most one activation's worth of allocator slack / cached workspaces
+
+
+@pytest.mark.parametrize("cin", [64, 320])  # 64 -> 64: the streaming pointwise kernel's STATS form; 320 -> 64: the general tile's epilogue
+def test_epilogue_statistics_with_a_large_mean_stay_within_the_fp32_partials_bound(cin):
+    """the convolution epilogues sum x and x^2 per thread in fp32 over 8-16 rows before the fp64 fold (the statistics
+    pass squares in fp64).  With var = E[x^2] - mean^2 that costs 2^-24 (mean / std)^2 of relative variance error: for activations
+    whose mean is 100 standard deviations (far from anything a BatchNorm input of SlowFast shows: the largest ratio in the trained pair
+    is below 3) the two paths' normalised outputs may differ by ~1e-3, and must not differ by more."""
+    import torch.nn as nn
+
+    from avtex import train_ops
+
+    dev = "cuda:0"
+    torch.manual_seed(21)
+    x0 = (torch.randn(4, cin, 2, 14, 14, device=dev) * 0.05 + 1.0).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(epi):
+        torch.manual_seed(7)
+        # (pointwise: no zero padding at the frame border, which would spread the outputs and hide the effect)
+        conv = nn.Conv3d(cin, 64, 1, bias=False).to(dev).to(memory_format=torch.channels_last_3d).train()
+        with torch.no_grad():
+            conv.weight.abs_()  # every output is a positive sum: mean >> spread
+        bn = nn.BatchNorm3d(64).to(dev).train()
+        keep, train_ops._EPI_STATS = train_ops._EPI_STATS, epi
+        try:
+            with torch.no_grad(), train_ops.bn_replicas(2):
+                y0 = train_ops.conv3d(x0, conv, stats=bn)
+                y = train_ops.bn_act(y0, bn, relu=False)
+        finally:
+            train_ops._EPI_STATS = keep
+        return y0, y
+
+    (y0a, ya), (y0e, ye) = run(1), run(0)
+    ratio = float((y0e.mean(dim=(0, 2, 3, 4)).abs() / y0e.std(dim=(0, 2, 3, 4))).max())
+    assert ratio > 20.0, ratio  # the input really is of the hard kind
+    err = float((ya - ye).abs().max())
+    assert err < 2.0 ** -24 * ratio * ratio * 8.0 + 1e-5, (err, ratio)  # normalised units: the variance's relative error, with slack

@@ -272,3 +272,72 @@ def test_fast_pathway_on_a_side_stream_equals_one_stream(avt, dev):
     num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(g1, g0)) ** 0.5
     den = sum(float(b.double().pow(2).sum()) for b in g0) ** 0.5
     assert num / den < 1e-5, num / den
+
+
+def test_graphed_step_equals_the_eager_step():
+    """train_ops.GraphedStep (round 6): the device side of a training step — convolutions forward / input gradient / weight gradient,
+    fused BatchNorm passes with epilogue statistics, the loss and SGD with momentum — captured ONCE as a HIP graph and replayed,
+    against the same steps run eagerly from the same state: same parameters and running statistics to the weight gradient's atomic
+    fp32 summation order.  Inputs travel through a static tensor; the host-side routing of the step (weight-plane caches keyed on
+    version counters, statistics handed over by data pointer) is frozen at capture and must stay valid on replay."""
+    import copy
+
+    from avtex import train_ops
+    from avtex.slowfast import ResBlock
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net0 = torch.nn.Sequential(ResBlock(16, 64, 16, 3, 1), ResBlock(64, 64, 16, 3, 1)).to(dev).to(memory_format=torch.channels_last_3d).train()
+    xs = [torch.randn(4, 16, 4, 12, 12, device=dev).contiguous(memory_format=torch.channels_last_3d) for _ in range(6)]
+
+    def run(graphed):
+        net = copy.deepcopy(net0)
+        train_ops.invalidate_weight_cache()
+        opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+        x_buf = xs[0].clone()
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            with train_ops.bn_replicas(2):
+                y = net(x_buf)
+            loss = y.square().mean()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
+        losses = []
+        if graphed:
+            # the three warm-up steps of GraphedStep run on xs[0..2] through the static buffer: feed them by hand
+            it = iter(xs)
+            orig = step
+
+            def warm_step():
+                x_buf.copy_(next(it))
+                return orig()
+
+            # warm-up (3 eager steps on xs[0], xs[1], xs[2], on a side stream as GraphedStep does it), capture, then replay on xs[3..5]
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    losses.append(float(warm_step()))
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            gs = train_ops.GraphedStep(step, dev, warmup=0)
+            for x in xs[3:]:
+                x_buf.copy_(x)
+                losses.append(float(gs()))
+        else:
+            for x in xs:
+                x_buf.copy_(x)
+                losses.append(float(step()))
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in net.parameters()], [b.detach().clone() for b in net.buffers()]
+
+    le, pe, be = run(False)
+    lg, pg, bg = run(True)
+    assert all(abs(a - b) <= 1e-5 * max(1.0, abs(a)) for a, b in zip(le, lg)), (le, lg)
+    for a, b in zip(pe, pg):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-7
+    for a, b in zip(be, bg):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-5 * float(a.float().abs().max()) + 1e-6

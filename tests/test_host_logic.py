@@ -575,6 +575,48 @@ def test_bench_symbol_matching_names():
     assert bench.symbol_matches("pw_chain_x3_kernel", pc, "f16x3") and not bench.symbol_matches("pw_x3_kernel<f16>", pc, "f16x3")
 
 
+def test_pack_res2_x3_is_the_documented_stream_order(avt):
+    """fused_slowfast.pack_res2_x3 -> include/avt.h avt_res2_x3's weight stream: [17 chunks][8 pairs][2 planes][64 lanes][8]; chunks 0-3 = a
+    (pair 4 kk + nt: k-step 2 chunk + kk, n-tile nt), 4-12 = b (one tap each, pair 4 kk + nt), 13-16 = c (pair 2 nn + kk: n-tile
+    4 (chunk - 13) + nn); lane l of a pair holds W[channel(nt, l & 15)][32 k + 8 (l >> 4) + e], channel(nt, r) = 32 (nt / 2) + 8 (r / 4)
+    + 4 (nt % 2) + r % 4; fp16 planes scaled per output channel into [2^9, 2^10), coef = [1/sa | ba | 1/sb | bb | 1/sc | bc]."""
+    import avtex.fused_slowfast as fsf
+    from avtex import ops
+
+    torch.manual_seed(4)
+    wa, wb, wc = torch.randn(64, 256, 1, 1, 1), torch.randn(64, 64, 1, 3, 3), torch.randn(256, 64, 1, 1, 1)
+    ba, bb, bc = torch.randn(64), torch.randn(64), torch.randn(256)
+    wf, cf = fsf.pack_res2_x3(wa, ba, wb, bb, wc, bc, ops.X3_F16, "cpu")
+    assert tuple(wf.shape) == (136, 2, 64, 8) and wf.dtype == torch.bfloat16 and tuple(cf.shape) == (768,)
+    val = wf.view(torch.float16).float()
+    full = val[:, 0] + val[:, 1]                      # hi + lo: the scaled weight to 2^-22
+    sa, sb, sc = 1.0 / cf[0:64], 1.0 / cf[128:192], 1.0 / cf[256:512]
+    assert torch.equal(cf[64:128], ba) and torch.equal(cf[192:256], bb) and torch.equal(cf[512:768], bc)
+    for scale, w in ((sa, wa), (sb, wb), (sc, wc)):   # powers of two that bring every channel's largest weight into [2^9, 2^10)
+        assert torch.equal(torch.exp2(torch.round(torch.log2(scale))), scale)
+        mx = (w.reshape(w.shape[0], -1).abs().amax(1) * scale)
+        assert bool(((mx >= 512) & (mx < 1024)).all())
+    chan = lambda nt, r: 32 * (nt // 2) + 8 * (r // 4) + 4 * (nt % 2) + r % 4
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        chunk, pr, lane, e = int(rng.randint(17)), int(rng.randint(8)), int(rng.randint(64)), int(rng.randint(8))
+        r, q = lane & 15, lane >> 4
+        if chunk < 4:
+            kk, nt = pr // 4, pr % 4
+            o, k = chan(nt, r), 32 * (2 * chunk + kk) + 8 * q + e
+            want = wa[o, k, 0, 0, 0] * sa[o]
+        elif chunk < 13:
+            kk, nt, tap = pr // 4, pr % 4, chunk - 4
+            o, k = chan(nt, r), 32 * kk + 8 * q + e
+            want = wb[o, k, 0, tap // 3, tap % 3] * sb[o]
+        else:
+            nn, kk = pr // 2, pr % 2
+            o, k = chan(4 * (chunk - 13) + nn, r), 32 * kk + 8 * q + e
+            want = wc[o, k, 0, 0, 0] * sc[o]
+        got = full[chunk * 8 + pr, lane, e]
+        assert abs(float(got) - float(want)) <= 2.0 ** -21 * abs(float(want)) + 1e-30, (chunk, pr, lane, e)
+
+
 def test_concatenation_protocol_host_side(avt):
     """train_ops.join_channels / _row_ld / _alias (the in-place lateral fusion of the training step): on the CPU — where no
     producer tags its output — the join is torch.cat; the row-pitch detector accepts channel slices of channels-last tensors
