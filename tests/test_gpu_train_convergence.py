@@ -71,3 +71,33 @@ def test_x3_training_tracks_fp32_and_its_checkpoint_evaluates(avt, dev, tmp_path
     for th in ("0.0", "0.3"):
         assert c["thresholds"][th]["rows_identical_survivors"] == 1.0 and c["thresholds"][th]["frames_lists_identical"] == "3/3", c
     assert out["activation_peak"]["margin_x"] > 100.0, out["activation_peak"]
+
+
+def test_stop_rule_loop_follows_the_recorded_curve(avt, dev):
+    """The reference's stop rule (main.py:475-477: `if loss < 0.07: break` on the epoch loss) in the short form: tools/train_convergence.py's
+    epoch mode — a shuffled permutation of a 39-segment video per epoch in batches of 8, the epoch loss = the mean of its steps,
+    StepLR-shaped decay, stop below --stop-loss — for 3 epochs, held to the first epochs of the RECORDED run that reaches the rule
+    (profiles/r06/train_stop_rule_x3_to_the_rule.json: lr 0.1 -> 0.01 at epoch 250, epoch loss 0.0684 < 0.07 at epoch 457, top-1 of 15
+    0.9975; fp32 MIOpen's first two epochs from the same seed: 2.6042, 2.5602 against 2.6045, 2.5600 here); and the rule itself stops
+    a run whose threshold it meets."""
+    import json
+
+    from avtex import synth, train_ops
+
+    tc = _tool()
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06", "train_stop_rule_x3_to_the_rule.json")))
+    run = rec["runs"]["x3"]
+    assert run["stopped_at_epoch"] == 457 and run["epoch_loss"][-1] < 0.07 <= min(run["epoch_loss"][:-1]) and run["segments"] == 39
+    video = synth.structured_video(123, 260, 128, 128, variety=1)
+    keep_mode = train_ops.conv_mode()
+    try:
+        args = SimpleNamespace(steps=0, epochs=3, stop_loss=0.07, lr_decay_epochs=[2], lr=0.1, init="default")
+        rx, _ = tc.train_run("x3", args, dev, video)
+        args2 = SimpleNamespace(steps=0, epochs=3, stop_loss=10.0, lr_decay_epochs=[], lr=0.1, init="default")
+        ry, _ = tc.train_run("x3", args2, dev, video)
+    finally:
+        train_ops.set_conv_mode(keep_mode)
+    assert rx["epochs_run"] == 3 and rx["stopped_at_epoch"] is None and rx["steps_per_epoch"] == run["steps_per_epoch"] == 4
+    # the same seed, video and batches: the first two epochs (before this run's decay) repeat the record to the weight gradient's atomics
+    assert np.allclose(rx["epoch_loss"][:2], run["epoch_loss"][:2], atol=2e-3), (rx["epoch_loss"], run["epoch_loss"][:3])
+    assert ry["stopped_at_epoch"] == 0 and ry["epochs_run"] == 1  # a threshold the first epoch meets stops the run there

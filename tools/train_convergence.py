@@ -75,16 +75,18 @@ def train_run(mode, args, dev, video, keep=False):
     # --epochs E: the reference's own loop shape — every epoch walks a shuffled permutation of the segments in
     # batches of 8 (main.py:195-198, DataLoader shuffle), the epoch loss is the mean of its steps' losses (train.py:210) and
     # training STOPS when it falls below --stop-loss (main.py:475-477: `if loss < 0.07: break`)
-    per_epoch = (len(ds) // B) if args.epochs else 0
-    n_steps = args.epochs * per_epoch if args.epochs else args.steps
+    # (callers that pass a bare namespace — bench.py --weights trained, the suite's 40-step form — get the step mode)
+    epochs, stop_loss, decay_at = getattr(args, "epochs", 0), getattr(args, "stop_loss", 0.07), list(getattr(args, "lr_decay_epochs", []))
+    per_epoch = (len(ds) // B) if epochs else 0
+    n_steps = epochs * per_epoch if epochs else args.steps
     epoch_loss, stopped_at, perm = [], None, None
     for it in range(n_steps):
         t0 = time.perf_counter()
-        if args.epochs:
+        if epochs:
             if it % per_epoch == 0:
                 perm = rng.permutation(len(ds))
                 # the reference's schedule shape (main.py:448-449: StepLR, x 0.1 at fixed epochs): --lr-decay-epochs
-                if (it // per_epoch) in args.lr_decay_epochs:
+                if (it // per_epoch) in decay_at:
                     for g in opt.param_groups:
                         g["lr"] *= 0.1
                     print("[%s] epoch %d: lr -> %g" % (mode, it // per_epoch, opt.param_groups[0]["lr"]), file=sys.stderr, flush=True)
@@ -108,10 +110,10 @@ def train_run(mode, args, dev, video, keep=False):
                   file=sys.stderr, flush=True)
         if not np.isfinite(losses[-1]):
             break
-        if args.epochs and (it + 1) % per_epoch == 0:
+        if epochs and (it + 1) % per_epoch == 0:
             epoch_loss.append(float(np.mean(losses[-per_epoch:])))
             print("[%s] epoch %d loss %.4f" % (mode, len(epoch_loss) - 1, epoch_loss[-1]), file=sys.stderr, flush=True)
-            if epoch_loss[-1] < args.stop_loss:
+            if epoch_loss[-1] < stop_loss:
                 stopped_at = len(epoch_loss) - 1
                 break
     ema, e = [], None
@@ -123,9 +125,9 @@ def train_run(mode, args, dev, video, keep=False):
            "ms_per_step_median": float(np.median(t_steps[5:]) * 1e3) if len(t_steps) > 5 else None,
            "max_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
            "calls": {k: v for k, v in train_ops.CALLS.items() if v}}
-    if args.epochs:
-        rec.update({"segments": len(ds), "steps_per_epoch": per_epoch, "epoch_loss": epoch_loss, "stop_loss": args.stop_loss,
-                    "lr_decay_epochs": list(args.lr_decay_epochs),
+    if epochs:
+        rec.update({"segments": len(ds), "steps_per_epoch": per_epoch, "epoch_loss": epoch_loss, "stop_loss": stop_loss,
+                    "lr_decay_epochs": decay_at,
                     "stopped_at_epoch": stopped_at, "epochs_run": len(epoch_loss)})
     for k in train_ops.CALLS:
         train_ops.CALLS[k] = 0
