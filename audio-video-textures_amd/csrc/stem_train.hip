@@ -493,6 +493,55 @@ extern "C" int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx
 }
 
 // Weight planes of a training convolution (see include/avt.h)
+// ... with the rows GATHERED through an index map (round 6): row r, column k = w[map[r * K + k]], or 0 where the map holds -1 — the
+// pixel-grouped (block-Toeplitz) forms of the few-channel layers' weights (train_ops._grouped_planes), which torch assembled with a flip,
+// a cat, an index, a permute and a copy per weight and step (~700 launches of a config-5 step) in front of weight_planes_kernel
+template <bool F16>
+__global__ __launch_bounds__(256) void weight_planes_gather_kernel(const float* __restrict__ w, const int32_t* __restrict__ map, int K,
+                                                                   uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                                   float* __restrict__ wscale) {
+  __shared__ float red[256];
+  const int32_t* mrow = map + (int64_t)blockIdx.x * K;
+  auto at = [&](int k) { const int32_t i = mrow[k]; return i >= 0 ? w[i] : 0.0f; };
+  float sc = 1.0f;
+  if (wscale) {
+    float mx = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(at(k)));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+      __syncthreads();
+    }
+    mx = fmaxf(red[0], 1e-30f);
+    int e;
+    (void)frexpf(mx, &e);
+    sc = ldexpf(1.0f, 10 - e);
+    if (threadIdx.x == 0) wscale[blockIdx.x] = ldexpf(1.0f, e - 10);
+  }
+  for (int k = 2 * threadIdx.x; k < K; k += 512) {
+    uint32_t h, l;
+    avt::split2<F16>(at(k) * sc, at(k + 1) * sc, h, l);
+    *reinterpret_cast<uint32_t*>(hi + (int64_t)blockIdx.x * K + k) = h;
+    *reinterpret_cast<uint32_t*>(lo + (int64_t)blockIdx.x * K + k) = l;
+  }
+}
+
+extern "C" int avt_weight_planes_gather_f32(const float* w, const int32_t* map, int rows, int k, void* hi, void* lo, float* wscale,
+                                            int plane_dtype, void* stream) {
+  AVT_REQUIRE(w && map && hi && lo && rows > 0 && k > 0 && k % 2 == 0, "avt_weight_planes_gather_f32: NULL pointer / bad sizes (k even)");
+  AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_weight_planes_gather_f32: bad plane_dtype");
+  AVT_REQUIRE((plane_dtype == AVT_X3_F16) == (wscale != nullptr),
+              "avt_weight_planes_gather_f32: fp16 planes are row-scaled (wscale), bf16 planes are not");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint16_t *h = static_cast<uint16_t*>(hi), *l = static_cast<uint16_t*>(lo);
+  if (plane_dtype == AVT_X3_F16)
+    hipLaunchKernelGGL(weight_planes_gather_kernel<true>, dim3((unsigned)rows), dim3(256), 0, s, w, map, k, h, l, wscale);
+  else
+    hipLaunchKernelGGL(weight_planes_gather_kernel<false>, dim3((unsigned)rows), dim3(256), 0, s, w, map, k, h, l, wscale);
+  return avt::check_launch("avt_weight_planes_gather_f32");
+}
+
 extern "C" int avt_weight_planes_f32(const float* w, int cout, int k, void* hi, void* lo, float* wscale, int plane_dtype, void* stream) {
   AVT_REQUIRE(w && hi && lo && cout > 0 && k > 0 && k % 2 == 0, "avt_weight_planes_f32: NULL pointer / bad sizes (k even)");
   AVT_REQUIRE(plane_dtype == AVT_X3_BF16 || plane_dtype == AVT_X3_F16, "avt_weight_planes_f32: bad plane_dtype");

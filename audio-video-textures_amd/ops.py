@@ -583,6 +583,20 @@ def weight_planes_f32(w2d, plane_dtype):
     return hi, lo, ws
 
 
+def weight_planes_gather_f32(w, idx_map, plane_dtype):
+    """w: a dense fp32 weight (any layout; read through its storage), idx_map int32 [rows, k] of storage offsets (-1: zero) ->
+    (hi, lo, wscale | None) like weight_planes_f32 on the gathered rows (csrc/stem_train.hip)."""
+    _dev(w, "w", torch.float32, contiguous=False)
+    _dev(idx_map, "idx_map", torch.int32)
+    rows, k = idx_map.shape
+    hi = torch.empty((rows, k), dtype=torch.bfloat16, device=w.device)
+    lo = torch.empty_like(hi)
+    ws = torch.empty(rows, dtype=torch.float32, device=w.device) if plane_dtype == X3_F16 else None
+    _lib.check(_lib.lib().avt_weight_planes_gather_f32(C.c_void_p(w.data_ptr()), _p(idx_map), int(rows), int(k), _p(hi), _p(lo), _p(ws),
+                                                       int(plane_dtype), _stream()), "avt_weight_planes_gather_f32")
+    return hi, lo, ws
+
+
 def weight_planes_t_f32(w3d, sel):
     """[cout, taps, cin] fp32 -> (hi, lo) bf16 planes [cin, len(sel) * cout] with out[ci][a][co] = w[co][sel[a]][ci]: the input
     gradient's filter (sel = all taps reversed) or one residue class of a strided layer's (csrc/stem_train.hip)."""

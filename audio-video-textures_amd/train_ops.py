@@ -574,33 +574,59 @@ def _group_factor(cin, cout, kernel, stride, pad, w):
     return g
 
 
+_GROUP_MAPS = {}  # (shape, strides, g, transposed, device) -> int32 [rows, cols] storage offsets of the grouped rows (-1: a zero tap)
+_GROUP_GATHER = 1  # the grouped planes by ONE gather launch per weight (0: the torch assembly of round 4, for tests)
+
+
+def _grouped_rows(w, g, transposed):
+    """The pixel-grouped row form of a [cout, cin, kt, kh, kw] tensor (the weight itself, or — round 6 — the tensor of its storage
+    offsets): rows [(po, n)][(dt, dh, dg)][(pi, c)], block-Toeplitz along W over groups of g pixels; `pad` fills the taps no original
+    tap meets.  -> rows [g * co, kt * kh * kwg * g * ci], (kt, kh, kwg), rg."""
+    pad = 0 if w.is_floating_point() else -1
+    if transposed:
+        w = w.flip(2, 3, 4).transpose(0, 1)  # the input gradient as a convolution of dY: filter [cin][cout][flipped taps]
+    co, ci, kt, kh, kw = w.shape
+    r = kw // 2
+    rg = -(-r // g)
+    kwg = 1 + 2 * rg
+    ikey = (g, kw, str(w.device))
+    idx = _GROUP_IDX.get(ikey)
+    if idx is None:  # tap of the ORIGINAL filter that (output pixel po, input pixel pi, group tap dg) meets; kw = the zero tap
+        po, pi, dg = torch.meshgrid(torch.arange(g), torch.arange(g), torch.arange(kwg), indexing="ij")
+        dw = g * (dg - rg) + pi - po + r
+        idx = torch.where((dw >= 0) & (dw < kw), dw, torch.full_like(dw, kw)).to(w.device)
+        _GROUP_IDX[ikey] = idx
+    w_ext = torch.cat([w, w.new_full((co, ci, kt, kh, 1), pad)], 4)
+    wg = w_ext[..., idx]  # [co, ci, kt, kh, po, pi, dg]
+    rows = wg.permute(4, 0, 2, 3, 6, 5, 1).reshape(g * co, kt * kh * kwg * g * ci).contiguous()
+    return rows, (kt, kh, kwg), rg
+
+
 def _grouped_planes(weight, g, transposed, plane_dtype):
-    """Planes of the pixel-grouped form of a Conv3d weight (transposed: of the input gradient's filter W'[ci][flipped taps][co]):
-    rows [(po, n)][(dt, dh, dg)][(pi, c)], block-Toeplitz along W over groups of g pixels -> (hi, lo, wscale | None), (kt, kh, kwg), rg."""
+    """Planes of the pixel-grouped form of a Conv3d weight (transposed: of the input gradient's filter W'[ci][flipped taps][co])
+    -> (hi, lo, wscale | None), (kt, kh, kwg), rg.  The grouped rows are a fixed GATHER of the weight's elements: the map of storage
+    offsets is built once per (shape, layout, g, direction) by running the assembly on the offsets themselves, and every step is one
+    launch (ops.weight_planes_gather_f32) instead of a flip, a cat, an index, a permute and a copy in front of the split."""
     from . import ops
     key = (id(weight), "group", g, bool(transposed))
     hit = _PLANES.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version:
         return hit[2]
     with torch.no_grad():
-        w = weight.detach().float()
-        if transposed:
-            w = w.flip(2, 3, 4).transpose(0, 1)  # the input gradient as a convolution of dY: filter [cin][cout][flipped taps]
-        co, ci, kt, kh, kw = w.shape
-        r = kw // 2
-        rg = -(-r // g)
-        kwg = 1 + 2 * rg
-        ikey = (g, kw, str(w.device))
-        idx = _GROUP_IDX.get(ikey)
-        if idx is None:  # tap of the ORIGINAL filter that (output pixel po, input pixel pi, group tap dg) meets; kw = the zero tap
-            po, pi, dg = torch.meshgrid(torch.arange(g), torch.arange(g), torch.arange(kwg), indexing="ij")
-            dw = g * (dg - rg) + pi - po + r
-            idx = torch.where((dw >= 0) & (dw < kw), dw, torch.full_like(dw, kw)).to(w.device)
-            _GROUP_IDX[ikey] = idx
-        w_ext = torch.cat([w, w.new_zeros((co, ci, kt, kh, 1))], 4)
-        wg = w_ext[..., idx]  # [co, ci, kt, kh, po, pi, dg]
-        rows = wg.permute(4, 0, 2, 3, 6, 5, 1).reshape(g * co, kt * kh * kwg * g * ci).contiguous()
-        planes = (ops.weight_planes_f32(rows, plane_dtype), (kt, kh, kwg), rg)
+        w = weight.detach()
+        dense = w.dtype == torch.float32 and (w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last_3d))
+        if _GROUP_GATHER and dense and w.is_cuda and w.numel() < (1 << 31):
+            mkey = (tuple(w.shape), tuple(w.stride()), g, bool(transposed), str(w.device))
+            ent = _GROUP_MAPS.get(mkey)
+            if ent is None:
+                offs = torch.arange(w.numel(), dtype=torch.int32).as_strided(tuple(w.shape), tuple(w.stride()))  # element -> storage offset
+                rows, kern, rg = _grouped_rows(offs, g, transposed)
+                ent = (rows.to(torch.int32).contiguous().to(w.device), kern, rg)
+                _GROUP_MAPS[mkey] = ent
+            planes = (ops.weight_planes_gather_f32(w, ent[0], plane_dtype), ent[1], ent[2])
+        else:
+            rows, kern, rg = _grouped_rows(w.float(), g, transposed)
+            planes = (ops.weight_planes_f32(rows, plane_dtype), kern, rg)
     _PLANES[key] = (weakref.ref(weight), weight._version, planes)
     return planes
 

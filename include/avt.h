@@ -664,6 +664,11 @@ int avt_stem_wgrad_x3(const void* x_hi, const void* x_lo, const float* dy, float
  *   out[ci][a][co] = w[co][sel[a]][ci] (sel = HOST array of nsel <= 32 source taps: all taps reversed for a stride-1 layer,
  *   one residue class's taps for a strided one, train_ops._dgrad_strided). */
 int avt_weight_planes_f32(const float* w, int cout, int k, void* hi, void* lo, float* wscale, int plane_dtype, void* stream);
+/* ... with the rows gathered through an index map (round 6): out row r, column k = w[map[r * k_cols + k]] (map < 0: zero) — the
+ * pixel-grouped (block-Toeplitz) forms of the few-channel layers' weights, forward and input-gradient filters alike
+ * (train_ops._grouped_planes: one launch where torch ran a flip, a cat, an index, a permute and a copy per weight and step). */
+int avt_weight_planes_gather_f32(const float* w, const int32_t* map, int rows, int k, void* hi, void* lo, float* wscale,
+                                 int plane_dtype, void* stream);
 int avt_weight_planes_t_f32(const float* w, int cout, int taps, int cin, const int32_t* sel, int nsel, void* hi, void* lo,
                             void* stream);
 

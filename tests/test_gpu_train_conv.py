@@ -804,3 +804,33 @@ def test_epilogue_statistics_with_a_large_mean_stay_within_the_fp32_partials_bou
     assert ratio > 20.0, ratio  # the input really is of the hard kind
     err = float((ya - ye).abs().max())
     assert err < 2.0 ** -24 * ratio * ratio * 8.0 + 1e-5, (err, ratio)  # normalised units: the variance's relative error, with slack
+
+
+@pytest.mark.parametrize("shape,g", [((8, 8, 1, 3, 3), 4), ((32, 8, 3, 1, 1), 4), ((16, 16, 1, 3, 3), 4), ((32, 32, 1, 3, 3), 2), ((64, 16, 1, 1, 1), 4)])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_grouped_planes_by_one_gather_equal_the_torch_assembly(shape, g, transposed):
+    """Round 6: the pixel-grouped planes of a few-channel layer's weight (forward filter / input-gradient filter) by ONE launch —
+    ops.weight_planes_gather_f32 through a cached map of storage offsets — are bit for bit what the torch assembly (flip, cat, index,
+    permute, copy) + weight_planes_f32 produced, scales included; channels-last and contiguous weights."""
+    from avtex import ops, train_ops
+
+    dev = "cuda:0"
+    torch.manual_seed(sum(shape) + g)
+    for cl in (True, False):
+        w = torch.randn(shape, device=dev)
+        if cl:
+            w = w.contiguous(memory_format=torch.channels_last_3d)
+        pd = ops.X3_BF16 if transposed else ops.X3_F16
+        out = []
+        for flag in (1, 0):
+            keep, train_ops._GROUP_GATHER = train_ops._GROUP_GATHER, flag
+            train_ops.invalidate_weight_cache()
+            try:
+                out.append(train_ops._grouped_planes(w, g, transposed, pd))
+            finally:
+                train_ops._GROUP_GATHER = keep
+        (pa, ka, ra), (pb, kb, rb) = out
+        assert ka == kb and ra == rb
+        for a, b in zip(pa, pb):
+            assert (a is None and b is None) or torch.equal(a, b)
+    train_ops.invalidate_weight_cache()

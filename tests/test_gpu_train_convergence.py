@@ -98,6 +98,8 @@ def test_stop_rule_loop_follows_the_recorded_curve(avt, dev):
     finally:
         train_ops.set_conv_mode(keep_mode)
     assert rx["epochs_run"] == 3 and rx["stopped_at_epoch"] is None and rx["steps_per_epoch"] == run["steps_per_epoch"] == 4
-    # the same seed, video and batches: the first two epochs (before this run's decay) repeat the record to the weight gradient's atomics
-    assert np.allclose(rx["epoch_loss"][:2], run["epoch_loss"][:2], atol=2e-3), (rx["epoch_loss"], run["epoch_loss"][:3])
+    # the same seed, video and batches: the first two epochs (before this run's decay) repeat the record to what the weight gradient's
+    # atomic summation order lets through (four recorded runs: epoch 0 2.6045 every time, epoch 1 2.5570 ... 2.5600)
+    assert abs(rx["epoch_loss"][0] - run["epoch_loss"][0]) < 1e-3 and abs(rx["epoch_loss"][1] - run["epoch_loss"][1]) < 1e-2, (
+        rx["epoch_loss"], run["epoch_loss"][:3])
     assert ry["stopped_at_epoch"] == 0 and ry["epochs_run"] == 1  # a threshold the first epoch meets stops the run there
