@@ -113,14 +113,16 @@ _SIDE_STREAMS = {}
 _SIDE_SKIP = 0  # (tools/experimental/probe_side_stream_index.py: leave the first k process-wide side streams to others)
 
 
-def _side_stream(device, cur):
-    """The side stream that belongs to stream `cur` of `device` (a training loop that runs its items on several streams gets
-    one per stream: the query encoders of two items in flight do not queue behind each other).  Taken from the process-wide list
-    of ops.side_streams — the SAME streams the synthesis engine's two-stream mode uses: which hardware queue a torch stream lands
-    on depends on how many streams the process has created before it, and a side stream created after bench.py's two-stream bf16
-    leg shared a queue with the step's own stream (the query encoder no longer overlapped the target encoder: the config-5 leg ran
-    3.5 % slower inside the default bench run than alone, profiles/r05/trainleg_order.log)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
+def _side_stream(device, cur, role=0):
+    """The side stream of `role` (0: the query encoder, 1: the target encoder's fast pathway) that belongs to stream `cur` of `device`
+    (a training loop that runs its items on several streams — or a step captured as a HIP graph on a stream of its own — gets its own
+    set per step stream: the side work of two steps in flight does not queue behind each other, and the roles of ONE step never share
+    a stream: round 6 found the query encoder and the fast pathway of a captured step on one stream, 65 ms per step instead of 52).
+    Taken from the process-wide list of ops.side_streams — the SAME streams the synthesis engine's two-stream mode uses: which hardware
+    queue a torch stream lands on depends on how many streams the process has created before it, and a side stream created after
+    bench.py's two-stream bf16 leg shared a queue with the step's own stream (the query encoder no longer overlapped the target
+    encoder: the config-5 leg ran 3.5 % slower inside the default bench run than alone, profiles/r05/trainleg_order.log)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream, int(role))
     s = _SIDE_STREAMS.get(key)
     if s is None:
         taken = {v.cuda_stream for v in _SIDE_STREAMS.values()} | {cur.cuda_stream}

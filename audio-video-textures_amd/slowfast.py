@@ -198,13 +198,13 @@ class SlowFast(nn.Module):
         """The training forward with the FAST pathway on a side stream (round 5 experiment, PATHWAY_STREAMS): the fast pathway depends
         on nothing of the slow one, so its stem and stages run ahead on their own stream; the slow pathway's stream waits for the
         fast features of a stage only where the lateral connection reads them.  autograd replays every backward node on its
-        forward's stream and orders the streams itself.  Only for a forward that runs on the device's default stream (the target
-        encoder of a training step: the query encoder already has a side stream of its own — three hardware queues in all)."""
-        from . import ops
+        forward's stream and orders the streams itself.  Only for a forward that runs on the STEP's own stream (the target encoder of a
+        training step; the query encoder already runs on a side stream of its own — three hardware queues in all): the default stream,
+        or the stream a captured step runs on (train_ops.GraphedStep)."""
+        from . import models
 
         dev = x[0].device
-        side = [s for s in ops.side_streams(dev, 3) if s.cuda_stream != cur.cuda_stream]
-        fs = side[1]  # (side[0] is the query encoder's: models._side_stream)
+        fs = models._side_stream(dev, cur, role=1)  # (role 0 of this step stream is the query encoder's)
         fs.wait_stream(cur)
         stages, fuses = (self.s2, self.s3, self.s4, self.s5), (self.s1_fuse, self.s2_fuse, self.s3_fuse, self.s4_fuse)
         with torch.cuda.stream(fs):

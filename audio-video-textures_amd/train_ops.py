@@ -359,15 +359,27 @@ class GraphedStep:
 
     def __init__(self, step_fn, device, warmup=3):
         self.graph, self.out = None, None
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
+        # warm-up and capture run on ONE stream of this object: the step's side streams are chosen per step stream
+        # (models._side_stream), and a capture stream that differs from the warm-up's was handed the fast pathway's side stream for
+        # its query encoder — two of the graph's three branches on one stream: 65 ms per one-item step instead of 52
+        # (profiles/r06/graph_stream_order.log)
+        # The first warm-up steps run eagerly on the CALLER's stream, the last one on the capture stream: the step's side streams of
+        # the caller's stream exist before the capture stream and its own side streams are created.  Measured, not understood
+        # (profiles/r06/graph_stream_order.log, ..._fixed.log): with the capture stream as the process's FIRST stream the replayed
+        # one-item step takes 76 ms, after an eager step on the default stream 53 ms — the graph's parallel branches land on other
+        # hardware queues
+        for _ in range(max(warmup - 1, 0)):
+            step_fn()
+        torch.cuda.synchronize(device)
+        self.stream = torch.cuda.Stream(device=device)
+        self.stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(self.stream):
+            if warmup > 0:
                 step_fn()
-        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.current_stream(device).wait_stream(self.stream)
         torch.cuda.synchronize(device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=self.stream):
             self.out = step_fn()
         self.graph = g
 
@@ -753,7 +765,9 @@ class _ConvX3(torch.autograd.Function):
 
 def _conv_backward(ctx, dy, dalias):
     """(dx, dw) of the convolution; dalias = a gradient that reached the input by another path (conv3d_fork), summed into dx
-    in the stride-1 kernel's epilogue instead of by a separate pass."""
+    in the stride-1 kernel's epilogue instead of by a separate pass.  (Weight gradients on a side stream of their own — nothing in the
+    backward waits for a dW — were measured three times and not kept: round 5 at 8 items per rank, -4 ... -11 %; round 6 at one item
+    per rank, eager 234 -> 227 clips/s, inside the replayed HIP graph 303 -> 280: profiles/r06/train_wgrad_side_stream_ab_not_kept.log)"""
     from . import ops
     x, weight = ctx.saved_tensors
     stride, padding, kernel, cin, cout = ctx.conf
