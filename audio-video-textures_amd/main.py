@@ -54,6 +54,10 @@ def build_parser():
            "what the reference's DataParallel gives every GPU's share of the batch (main.py:420), running statistics from "
            "the first group only as DataParallel keeps replica 0's buffers; 1 = over the rank's whole batch; -1 = one group "
            "per item (batch 8 on 8 GPUs in the reference)")
+    a("--train_graph", default=0, type=int, choices=[0, 1],
+      help="1: train() captures the device side of a step (forward, loss, backward, optimizer) once per batch shape as a HIP graph and "
+           "replays it (train_ops.GraphedStep) — for small batches whose launches the host issues slower than the device runs them; one "
+           "process only; the first batch of a shape also serves the two warm-up steps (not in the reference)")
     a("--train_conv", default="x3", choices=["x3", "fp32"],
       help="arithmetic of the training convolutions (with --train_layout ndhwc): x3 = split-plane MFMA kernels, fp32 "
            "accumulation, forward 2^-22 / gradients 2^-16 per product (default; train_ops.py); fp32 = MIOpen's fp32 "

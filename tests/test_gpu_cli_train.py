@@ -68,6 +68,22 @@ def test_train_one_epoch(avt, dev):
     assert losses[0] < np.log(11) * 1.5  # starts near log(1 + negs); n_negs >= 8 as in the reference (dataset.py:190 needs room for the hard negatives)
 
 
+def test_train_one_epoch_as_a_replayed_graph(avt, dev):
+    """`--train_graph 1`: train() captures the device side of a step once per batch shape (train_ops.GraphedStep) and replays it — the
+    same loop, the same meters; the loss falls like the eager loop's (the first batch of a shape also serves the two warm-up steps)."""
+    args = SimpleNamespace(vdata="/tmp", adata=None, n_negs=10, img_size=32, enc_arch="slowfast", window=0, stride=0,
+                           print_freq=100, log_freq=100, train_graph=1)
+    torch.manual_seed(1)
+    ds = avt.AudioVideoSegments(args, "x", split="train", video=(_video(90, 32), 10.0))
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=True, num_workers=0, drop_last=True)
+    model = avt.ContrastivePredictionTemporal(seeded(TinySlowFast, 1), seeded(TinySlowFast, 2), None, 1, 128, temp=0.1,
+                                              window=5, stride=2, enc_arch="slowfast", img_size=32).to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    np.random.seed(0)
+    losses = [avt.train(loader, model, opt, args, epoch) for epoch in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] and losses[0] < np.log(11) * 1.5
+
+
 def test_validate_m2_driving_audio_on_mfma_encoders(avt, dev, capsys):
     """Config 3 wiring with the production encoders: real SlowFast x2 AND VGGish run on the hand-written MFMA
     convolutions (validate.py swaps both in), source + driving audio tables are built once, aligned N x N mode."""
