@@ -98,6 +98,8 @@ SIGNATURES = {
     "avt_weight_planes_f32": [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp],
     "avt_weight_planes_t_f32": [_vp, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _vp, _vp, _vp],
     "avt_weight_planes_gather_f32": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp],
+    "avt_weight_planes_job_bytes": [],
+    "avt_weight_planes_multi": [_vp, _vp, C.c_int, _vp],
     "avt_maxpool_train_fwd": [_vp, _vp, _vp] + [C.c_int] * 4 + [C.c_int64, _vp],
     "avt_maxpool_train_bwd": [_vp, _vp, _vp] + [C.c_int] * 4 + [C.c_int64, _vp],
     "avt_stem_wgrad_x3_supported": [C.c_int] * 4,

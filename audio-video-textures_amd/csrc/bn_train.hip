@@ -223,20 +223,31 @@ __global__ __launch_bounds__(kT) void bn_pre_reduce_kernel(PreArgs a) {
   const double* src = a.src + ((size_t)g * a.rows * a.unit + u) * a.len;
   double* dst = a.dst + (((size_t)g * nchunk + chunk) * a.unit + u) * a.len;
   const int sl = threadIdx.x / cols, c = threadIdx.x % cols;
-  for (int col = c; col < a.len; col += cols) {
-    double acc = 0.0;
-    for (int r = r0 + sl; r < r1; r += slices) acc += src[(size_t)r * a.unit * a.len + col];
-    if (slices > 1) {
-      sh[threadIdx.x] = acc;
-      __syncthreads();
-      if (sl == 0) {
-        for (int k = 1; k < slices; ++k) acc += sh[k * cols + c];
-        dst[col] = acc;
-      }
-      __syncthreads();
-    } else {
+  const int col = blockIdx.z * cols + c;  // (grid.z = len / cols column blocks: a launch is one round of loads deep, not len / kT)
+  // kPreDepth rows' loads are issued before the first is added — in the same order as a one-by-one walk, so the sums keep their
+  // bits: the walk was a chain of 32-64 dependent L2 round trips (24 us per launch on a config-5 step of ONE item, 243 launches a
+  // step: profiles/r06/rocprof_train_one_item_kernel_stats.csv)
+  constexpr int kPreDepth = 16;
+  const size_t rstride = (size_t)a.unit * a.len;
+  double acc = 0.0;
+  int r = r0 + sl;
+  for (; r + (kPreDepth - 1) * slices < r1; r += kPreDepth * slices) {
+    double v[kPreDepth];
+#pragma unroll
+    for (int k = 0; k < kPreDepth; ++k) v[k] = src[(size_t)(r + k * slices) * rstride + col];
+#pragma unroll
+    for (int k = 0; k < kPreDepth; ++k) acc += v[k];
+  }
+  for (; r < r1; r += slices) acc += src[(size_t)r * rstride + col];
+  if (slices > 1) {
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0) {
+      for (int k = 1; k < slices; ++k) acc += sh[k * cols + c];
       dst[col] = acc;
     }
+  } else {
+    dst[col] = acc;
   }
 }
 
@@ -508,7 +519,7 @@ static int bn_train_fwd_impl(const float* x, const float* res, float* y, int64_t
       p.rows = pre_rows / a.unit;
       p.unit = a.unit;
       p.len = a.nq * 8;
-      hipLaunchKernelGGL(bn_pre_reduce_kernel, dim3(fin / a.unit, a.unit * groups), dim3(kT), 0, st, p);
+      hipLaunchKernelGGL(bn_pre_reduce_kernel, dim3(fin / a.unit, a.unit * groups, p.len > kT ? p.len / kT : 1), dim3(kT), 0, st, p);
       f.part = p.dst;
       f.blocks = fin;
     }
@@ -556,7 +567,7 @@ extern "C" int avt_bn_train_bwd_pre(const float* g, const float* x, int64_t m, i
     p.rows = pre_rows / a.unit;
     p.unit = a.unit;
     p.len = a.nq * 8;
-    hipLaunchKernelGGL(bn_pre_reduce_kernel, dim3(fin / a.unit, a.unit * groups), dim3(kT), 0, st, p);
+    hipLaunchKernelGGL(bn_pre_reduce_kernel, dim3(fin / a.unit, a.unit * groups, p.len > kT ? p.len / kT : 1), dim3(kT), 0, st, p);
     f.part = p.dst;
     f.blocks = fin;
   }

@@ -319,10 +319,9 @@ __global__ __launch_bounds__(256) void maxpool_train_bwd_kernel(MpArgs a) {
 // Two kernels instead: the forward's planes straight from the channels-last weight (its memory IS [cout][taps][cin]), and the
 // input gradient's transposed, tap-selected planes W'[ci][tap a][co] = W[co][taps[a]][ci] through a 32 x 32 LDS transpose.
 template <bool F16>
-__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ w, int K, uint16_t* __restrict__ hi,
-                                                            uint16_t* __restrict__ lo, float* __restrict__ wscale) {
-  __shared__ float red[256];
-  const float* row = w + (int64_t)blockIdx.x * K;
+__device__ __forceinline__ void weight_planes_row(const float* __restrict__ w, int K, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                  float* __restrict__ wscale, int r, float* red) {
+  const float* row = w + (int64_t)r * K;
   float sc = 1.0f;
   if (wscale) {  // fp16 planes: the row scaled by a power of two into [2^9, 2^10) (undone on the accumulator: wscale = 1 / scale)
     float mx = 0.0f;
@@ -337,14 +336,21 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restr
     int e;
     (void)frexpf(mx, &e);  // mx = m * 2^e, m in [0.5, 1): floor(log2(mx)) = e - 1
     sc = ldexpf(1.0f, 10 - e);
-    if (threadIdx.x == 0) wscale[blockIdx.x] = ldexpf(1.0f, e - 10);
+    if (threadIdx.x == 0) wscale[r] = ldexpf(1.0f, e - 10);
   }
   for (int k = 2 * threadIdx.x; k < K; k += 512) {
     uint32_t h, l;
     avt::split2<F16>(row[k] * sc, row[k + 1] * sc, h, l);
-    *reinterpret_cast<uint32_t*>(hi + (int64_t)blockIdx.x * K + k) = h;
-    *reinterpret_cast<uint32_t*>(lo + (int64_t)blockIdx.x * K + k) = l;
+    *reinterpret_cast<uint32_t*>(hi + (int64_t)r * K + k) = h;
+    *reinterpret_cast<uint32_t*>(lo + (int64_t)r * K + k) = l;
   }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ w, int K, uint16_t* __restrict__ hi,
+                                                            uint16_t* __restrict__ lo, float* __restrict__ wscale) {
+  __shared__ float red[256];
+  weight_planes_row<F16>(w, K, hi, lo, wscale, (int)blockIdx.x, red);
 }
 
 struct WtArgs {
@@ -355,15 +361,16 @@ struct WtArgs {
   int sel[32];     // source tap of output tap a
 };
 
-__global__ __launch_bounds__(256) void weight_planes_t_kernel(WtArgs a) {
-  __shared__ float tile[32][33];
-  const int tap = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+// (tile: 32 x 33 floats)
+__device__ __forceinline__ void weight_planes_t_block(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                      int cout, int taps, int cin, int nsel, int src, int bx, int by, int tap,
+                                                      float (*tile)[33]) {
+  const int co0 = by * 32, ci0 = bx * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int src = a.sel[tap];
 #pragma unroll
   for (int j = ty; j < 32; j += 8) {
     const int co = co0 + j, ci = ci0 + tx;
-    tile[j][tx] = (co < a.cout && ci < a.cin) ? a.w[((int64_t)co * a.taps + src) * a.cin + ci] : 0.0f;
+    tile[j][tx] = (co < cout && ci < cin) ? w[((int64_t)co * taps + src) * cin + ci] : 0.0f;
   }
   __syncthreads();
   // out row ci0 + i, columns co0 .. co0 + 31 as 16 pairs: thread (pair p = tx & 15, row i = ty + 8 * (tx >> 4) + 16 * h)
@@ -371,14 +378,20 @@ __global__ __launch_bounds__(256) void weight_planes_t_kernel(WtArgs a) {
   for (int h = 0; h < 2; ++h) {
     const int i = ty + 8 * (tx >> 4) + 16 * h, p = tx & 15;
     const int ci = ci0 + i, co = co0 + 2 * p;
-    if (ci < a.cin && co < a.cout) {
+    if (ci < cin && co < cout) {
       uint32_t hh, ll;
       avt::split2<false>(tile[2 * p][i], tile[2 * p + 1][i], hh, ll);
-      const int64_t o = ((int64_t)ci * a.nsel + tap) * a.cout + co;
-      *reinterpret_cast<uint32_t*>(a.hi + o) = hh;
-      *reinterpret_cast<uint32_t*>(a.lo + o) = ll;
+      const int64_t o = ((int64_t)ci * nsel + tap) * cout + co;
+      *reinterpret_cast<uint32_t*>(hi + o) = hh;
+      *reinterpret_cast<uint32_t*>(lo + o) = ll;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void weight_planes_t_kernel(WtArgs a) {
+  __shared__ float tile[32][33];
+  weight_planes_t_block(a.w, a.hi, a.lo, a.cout, a.taps, a.cin, a.nsel, a.sel[blockIdx.z], (int)blockIdx.x, (int)blockIdx.y,
+                        (int)blockIdx.z, tile);
 }
 
 template <int KT, int CO>
@@ -497,11 +510,10 @@ extern "C" int avt_maxpool_train_bwd(const float* dy, const void* tap, float* dx
 // pixel-grouped (block-Toeplitz) forms of the few-channel layers' weights (train_ops._grouped_planes), which torch assembled with a flip,
 // a cat, an index, a permute and a copy per weight and step (~700 launches of a config-5 step) in front of weight_planes_kernel
 template <bool F16>
-__global__ __launch_bounds__(256) void weight_planes_gather_kernel(const float* __restrict__ w, const int32_t* __restrict__ map, int K,
-                                                                   uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                                                   float* __restrict__ wscale) {
-  __shared__ float red[256];
-  const int32_t* mrow = map + (int64_t)blockIdx.x * K;
+__device__ __forceinline__ void weight_planes_gather_row(const float* __restrict__ w, const int32_t* __restrict__ map, int K,
+                                                         uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, float* __restrict__ wscale,
+                                                         int r, float* red) {
+  const int32_t* mrow = map + (int64_t)r * K;
   auto at = [&](int k) { const int32_t i = mrow[k]; return i >= 0 ? w[i] : 0.0f; };
   float sc = 1.0f;
   if (wscale) {
@@ -517,14 +529,71 @@ __global__ __launch_bounds__(256) void weight_planes_gather_kernel(const float* 
     int e;
     (void)frexpf(mx, &e);
     sc = ldexpf(1.0f, 10 - e);
-    if (threadIdx.x == 0) wscale[blockIdx.x] = ldexpf(1.0f, e - 10);
+    if (threadIdx.x == 0) wscale[r] = ldexpf(1.0f, e - 10);
   }
   for (int k = 2 * threadIdx.x; k < K; k += 512) {
     uint32_t h, l;
     avt::split2<F16>(at(k) * sc, at(k + 1) * sc, h, l);
-    *reinterpret_cast<uint32_t*>(hi + (int64_t)blockIdx.x * K + k) = h;
-    *reinterpret_cast<uint32_t*>(lo + (int64_t)blockIdx.x * K + k) = l;
+    *reinterpret_cast<uint32_t*>(hi + (int64_t)r * K + k) = h;
+    *reinterpret_cast<uint32_t*>(lo + (int64_t)r * K + k) = l;
   }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void weight_planes_gather_kernel(const float* __restrict__ w, const int32_t* __restrict__ map, int K,
+                                                                   uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                                   float* __restrict__ wscale) {
+  __shared__ float red[256];
+  weight_planes_gather_row<F16>(w, map, K, hi, lo, wscale, (int)blockIdx.x, red);
+}
+
+// Every weight's planes of a training step in ONE launch (round 6): the optimizer has changed all of them, and re-made one by one
+// they are ~450 launches of 5 us in front of the convolutions that read them — 2.3 ms of a 49 ms config-5 step at one item per rank
+// (profiles/r06/one_item_graph_timeline.txt).  A job is one launch of the kernels above (include/avt.h AvtPlaneJob); block b of the
+// grid is block b - blk0 of job blk2job[b]: the same device functions, the same bits.
+struct PlaneJob {
+  const float* w;
+  uint16_t* hi;
+  uint16_t* lo;
+  float* wscale;        // fp16 row planes / gathered rows: 1 / scale per row; NULL: bf16 planes
+  const int32_t* map;   // gathered rows
+  int kind;             // 0 rows, 1 transposed + tap-selected, 2 gathered rows
+  int f16;              // rows / gathered rows: fp16 planes (with wscale) or bf16 planes
+  int rows, K;          // rows / gathered rows
+  int cout, taps, cin, nsel;  // transposed: w [cout][taps][cin] -> [cin][nsel][cout]
+  int gx, gy;           // transposed: tiles along cin, cout (blocks = gx * gy * nsel)
+  int blk0;             // the job's first block
+  int pad_;
+  int sel[32];
+};
+static_assert(sizeof(PlaneJob) == 216, "AvtPlaneJob layout (include/avt.h)");
+
+__global__ __launch_bounds__(256) void weight_planes_multi_kernel(const PlaneJob* __restrict__ jobs, const int32_t* __restrict__ blk2job) {
+  __shared__ float sm[32 * 33];
+  const PlaneJob& j = jobs[blk2job[blockIdx.x]];
+  const int b = (int)blockIdx.x - j.blk0;
+  if (j.kind == 0) {
+    if (j.f16) weight_planes_row<true>(j.w, j.K, j.hi, j.lo, j.wscale, b, sm);
+    else weight_planes_row<false>(j.w, j.K, j.hi, j.lo, nullptr, b, sm);
+  } else if (j.kind == 1) {
+    const int bx = b % j.gx, t1 = b / j.gx, by = t1 % j.gy, tap = t1 / j.gy;
+    weight_planes_t_block(j.w, j.hi, j.lo, j.cout, j.taps, j.cin, j.nsel, j.sel[tap], bx, by, tap, reinterpret_cast<float(*)[33]>(sm));
+  } else {
+    if (j.f16) weight_planes_gather_row<true>(j.w, j.map, j.K, j.hi, j.lo, j.wscale, b, sm);
+    else weight_planes_gather_row<false>(j.w, j.map, j.K, j.hi, j.lo, nullptr, b, sm);
+  }
+}
+
+extern "C" int avt_weight_planes_job_bytes(void) { return (int)sizeof(PlaneJob); }
+
+// jobs: DEVICE array of AvtPlaneJob, blk2job: DEVICE int32 [nblocks]; the host has validated the jobs (train_ops builds them from the
+// arguments its one-by-one launches passed the checks of avt_weight_planes_*_f32 with)
+extern "C" int avt_weight_planes_multi(const void* jobs, const int32_t* blk2job, int nblocks, void* stream) {
+  AVT_REQUIRE(jobs && blk2job && nblocks > 0, "avt_weight_planes_multi: NULL pointer / no blocks");
+  AVT_REQUIRE(reinterpret_cast<uintptr_t>(jobs) % 8 == 0, "avt_weight_planes_multi: the job table must be 8-byte aligned");
+  hipLaunchKernelGGL(weight_planes_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const PlaneJob*>(jobs), blk2job);
+  return avt::check_launch("avt_weight_planes_multi");
 }
 
 extern "C" int avt_weight_planes_gather_f32(const float* w, const int32_t* map, int rows, int k, void* hi, void* lo, float* wscale,

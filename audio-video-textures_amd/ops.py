@@ -597,6 +597,17 @@ def weight_planes_gather_f32(w, idx_map, plane_dtype):
     return hi, lo, ws
 
 
+def weight_planes_job_bytes():
+    return int(_lib.lib().avt_weight_planes_job_bytes())
+
+
+def weight_planes_multi(jobs, blk2job, nblocks):
+    """Every job of a DEVICE table of AvtPlaneJob (include/avt.h) in one launch: the planes of all of a step's weights, in place
+    (train_ops._refresh_planes builds the table from the single launches' own arguments)."""
+    assert jobs.is_cuda and blk2job.is_cuda and blk2job.dtype == torch.int32 and blk2job.numel() == nblocks
+    _lib.check(_lib.lib().avt_weight_planes_multi(_p(jobs), _p(blk2job), int(nblocks), _stream()), "avt_weight_planes_multi")
+
+
 def weight_planes_t_f32(w3d, sel):
     """[cout, taps, cin] fp32 -> (hi, lo) bf16 planes [cin, len(sel) * cout] with out[ci][a][co] = w[co][sel[a]][ci]: the input
     gradient's filter (sel = all taps reversed) or one residue class of a strided layer's (csrc/stem_train.hip)."""

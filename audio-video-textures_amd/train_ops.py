@@ -22,6 +22,7 @@ import contextlib
 import ctypes as C
 import weakref
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -55,16 +56,21 @@ def conv_mode():
     return "x3" if _CONV_X3 else "fp32"
 
 
-def invalidate_weight_cache():
-    """Drop the cached weight planes (needed after in-place updates through `.data`, which `_version` does not see)."""
-    _PLANES.clear()
+def invalidate_weight_cache(drop=False):
+    """Mark every cached set of weight planes stale (needed after in-place updates through `.data`, which `_version` does not see): the
+    next lookup re-makes them — all of them in one launch (_refresh_planes).  drop=True forgets the entries themselves (tests that
+    compare two ways of MAKING the planes)."""
+    _PLANES_GEN[0] += 1
+    if drop:
+        _PLANES.clear()
+        _PLANE_TABLES.clear()
     _STEM_IMAGES.clear()
 
 
 # per-process launch counters of the hand-written training kernels (tests assert that the default path really runs them)
 CALLS = {"conv_fwd_x3": 0, "dgrad_x3": 0, "dgrad_strided_x3": 0, "wgrad_x3": 0, "wgrad_stem_x3": 0, "bn_fwd": 0, "bn_bwd": 0,
          "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0, "maxpool_hip": 0, "pw_f32": 0,
-         "bn_fwd_pre": 0, "bn_bwd_pre": 0, "dgrad_bwdstats": 0}
+         "bn_fwd_pre": 0, "bn_bwd_pre": 0, "dgrad_bwdstats": 0, "planes_multi": 0}
 
 
 def _p(t):
@@ -500,6 +506,105 @@ class MicroBatchGradients:
 # The weight gradient is csrc/wgrad_x3.hip (bf16 planes, transposing LDS stage, split over positions with fp32 atomics);
 # the strided layers' input gradients are `_dgrad_strided` below; the stems have kernels of their own (`_StemX3`).
 _TABS, _PLANES = {}, {}
+_PLANES_MULTI = 1      # stale planes are re-made by ONE launch over every cached weight (0: one by one, as rounds 3-5 did; tests)
+_PLANES_GEN = [0]      # invalidate_weight_cache() bumps it
+_PLANE_TABLES = {}     # device -> (key, job table, blk2job, blocks) of the last multi-job launch
+_PLANE_REFRESH = {}    # device -> {"id", "event", "stream", "waited": {stream handle: id}}
+
+
+class _PlaneEntry:
+    """A cached set of weight planes: `value` is what the lookup returns; `jobs` describes the launches that made its tensors
+    (None: not re-makeable in place — torch-assembled forms), as dicts {"off": byte offset of the source in the owner's storage,
+    "fields": the AvtPlaneJob fields after `w` up to `blk0`, "sel": taps, "blocks": grid size}."""
+    __slots__ = ("ref", "version", "gen", "value", "jobs")
+
+    def __init__(self, owner, value, jobs=None):
+        self.ref, self.version, self.gen, self.value, self.jobs = weakref.ref(owner), owner._version, _PLANES_GEN[0], value, jobs
+
+    def stale(self, owner):
+        return self.version != owner._version or self.gen != _PLANES_GEN[0]
+
+
+def _job_rows(w, owner, hi, lo, ws, f16, rows, k, idx_map=None):
+    kind = 0 if idx_map is None else 2
+    return {"off": w.data_ptr() - owner.data_ptr(), "blocks": int(rows),
+            "fields": (hi.data_ptr(), lo.data_ptr(), ws.data_ptr() if ws is not None else 0, idx_map.data_ptr() if idx_map is not None else 0,
+                       kind, int(bool(f16)), int(rows), int(k), 0, 0, 0, 0, 0, 0),
+            "sel": (), "keep": (hi, lo, ws, idx_map)}
+
+
+def _job_transposed(w, owner, hi, lo, cout, taps, cin, sel):
+    gx, gy = (cin + 31) // 32, (cout + 31) // 32
+    return {"off": w.data_ptr() - owner.data_ptr(), "blocks": gx * gy * len(sel),
+            "fields": (hi.data_ptr(), lo.data_ptr(), 0, 0, 1, 0, 0, 0, int(cout), int(taps), int(cin), len(sel), gx, gy),
+            "sel": tuple(int(v) for v in sel), "keep": (hi, lo)}
+
+
+def _refresh_planes(device):
+    """Re-make EVERY stale cached plane set of `device` whose recipe is known, in place, with one launch (ops.weight_planes_multi);
+    -> False when there was nothing to do.  Other streams order themselves behind the launch in _plane_lookup (one event)."""
+    import struct
+
+    from . import ops
+    todo = []
+    for ent in _PLANES.values():
+        owner = ent.ref()
+        if owner is not None and ent.jobs and owner.device == device and ent.stale(owner):
+            todo.append((ent, owner))
+    if not todo:
+        return False
+    recs = tuple((owner.data_ptr() + j["off"],) + j["fields"] + j["sel"] for ent, owner in todo for j in ent.jobs)
+    tab = _PLANE_TABLES.get(device)
+    if tab is None or tab[0] != recs:  # (the same weights at the same addresses every step: built once; a HIP graph captures its pointers)
+        raw, blk, b0 = [], [], 0
+        for n, (ent, owner) in enumerate(todo):
+            for j in ent.jobs:
+                sel = j["sel"] + (0,) * (32 - len(j["sel"]))
+                raw.append(struct.pack("<5Q12i32i", owner.data_ptr() + j["off"], *j["fields"][:4], *j["fields"][4:], b0, 0, *sel))
+                blk.append(np.full(j["blocks"], len(raw) - 1, dtype=np.int32))
+                b0 += j["blocks"]
+        raw = b"".join(raw)
+        assert len(raw) == len(blk) * ops.weight_planes_job_bytes(), "AvtPlaneJob layout"
+        tab = (recs, torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(device), torch.from_numpy(np.concatenate(blk)).to(device), b0)
+        _PLANE_TABLES[device] = tab
+    with torch.no_grad():
+        ops.weight_planes_multi(tab[1], tab[2], tab[3])
+    for ent, owner in todo:
+        ent.version, ent.gen = owner._version, _PLANES_GEN[0]
+    cur = torch.cuda.current_stream(device)
+    r = _PLANE_REFRESH.setdefault(device, {"id": 0, "waited": {}})
+    r["id"] += 1
+    r["event"] = torch.cuda.Event()
+    r["event"].record(cur)
+    r["stream"] = cur
+    r["waited"] = {}
+    CALLS["planes_multi"] += 1
+    return True
+
+
+def _plane_lookup(key, owner):
+    """The cached planes under `key` if they are `owner`'s and current — made current, together with every other stale entry, by one
+    launch when only the optimizer step lies between (same tensors, new values) — else None."""
+    ent = _PLANES.get(key)
+    if ent is None or ent.ref() is not owner:
+        return None
+    if ent.stale(owner):
+        if not (_PLANES_MULTI and ent.jobs and owner.is_cuda and _refresh_planes(owner.device)) or ent.stale(owner):
+            return None
+    r = _PLANE_REFRESH.get(owner.device) if owner.is_cuda else None
+    if r is not None and r.get("event") is not None and ent.jobs:  # the launch that wrote these planes ran on another stream: behind it, once
+        cur = torch.cuda.current_stream(owner.device)
+        if cur != r["stream"] and r["waited"].get(cur.cuda_stream) != r["id"]:
+            cur.wait_event(r["event"])
+            r["waited"][cur.cuda_stream] = r["id"]
+    return ent.value
+
+
+def _plane_store(key, owner, value, jobs=None):
+    if len(_PLANES) > 4096:  # entries of models that are gone
+        for k in [k for k, v in _PLANES.items() if v.ref() is None]:
+            del _PLANES[k]
+    _PLANES[key] = _PlaneEntry(owner, value, jobs)
 
 
 def _ktab(cin, kernel, h, w, ldi, device):
@@ -521,10 +626,11 @@ def _weight_planes(weight, transposed):
     # hit the cache and left an entry per call behind; a view shares its base's version counter
     owner = weight._base if weight._base is not None else weight
     key = (id(owner), bool(transposed), tuple(weight.shape))
-    hit = _PLANES.get(key)
     # (the entry remembers WHICH tensor it was made from: an id — like an address — can be reused after the first one died)
-    if hit is not None and hit[0]() is owner and hit[1] == owner._version:
-        return hit[2]
+    hit = _plane_lookup(key, owner)
+    if hit is not None:
+        return hit
+    jobs = None
     with torch.no_grad():
         w = weight.detach()
         fast = (_PLANES_HIP and w.dtype == torch.float32 and w.dim() == 5 and w.shape[1] % 8 == 0 and w.shape[0] % 2 == 0 and
@@ -535,9 +641,12 @@ def _weight_planes(weight, transposed):
             taps = w.shape[2] * w.shape[3] * w.shape[4]
             rows = w.permute(0, 2, 3, 4, 1).reshape(cout, taps * cin)  # a view
             if transposed:
-                planes = ops.weight_planes_t_f32(rows.view(cout, taps, cin), list(range(taps - 1, -1, -1))) + (None,)
+                sel = list(range(taps - 1, -1, -1))
+                planes = ops.weight_planes_t_f32(rows.view(cout, taps, cin), sel) + (None,)
+                jobs = [_job_transposed(rows, owner, planes[0], planes[1], cout, taps, cin, sel)]
             else:
                 planes = ops.weight_planes_f32(rows, ops.X3_F16)
+                jobs = [_job_rows(rows, owner, planes[0], planes[1], planes[2], True, cout, taps * cin)]
         else:
             w = w.float()
             if w.shape[1] % 8:  # the stems' 3 input channels, padded with zero taps
@@ -553,10 +662,7 @@ def _weight_planes(weight, transposed):
                 sc = torch.pow(2.0, 9.0 - torch.floor(torch.log2(mx)))
                 hi, lo = split_planes(wt * sc.view(-1, 1), ops.X3_F16)
                 planes = (hi, lo, (1.0 / sc).float().contiguous())
-    if len(_PLANES) > 4096:  # entries of models that are gone
-        for k in [k for k, v in _PLANES.items() if v[0]() is None]:
-            del _PLANES[k]
-    _PLANES[key] = (weakref.ref(owner), owner._version, planes)
+    _plane_store(key, owner, planes, jobs)
     return planes
 
 
@@ -621,9 +727,10 @@ def _grouped_planes(weight, g, transposed, plane_dtype):
     launch (ops.weight_planes_gather_f32) instead of a flip, a cat, an index, a permute and a copy in front of the split."""
     from . import ops
     key = (id(weight), "group", g, bool(transposed))
-    hit = _PLANES.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
-        return hit[2]
+    hit = _plane_lookup(key, weight)
+    if hit is not None:
+        return hit
+    jobs = None
     with torch.no_grad():
         w = weight.detach()
         dense = w.dtype == torch.float32 and (w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last_3d))
@@ -635,11 +742,13 @@ def _grouped_planes(weight, g, transposed, plane_dtype):
                 rows, kern, rg = _grouped_rows(offs, g, transposed)
                 ent = (rows.to(torch.int32).contiguous().to(w.device), kern, rg)
                 _GROUP_MAPS[mkey] = ent
-            planes = (ops.weight_planes_gather_f32(w, ent[0], plane_dtype), ent[1], ent[2])
+            pl = ops.weight_planes_gather_f32(w, ent[0], plane_dtype)
+            planes = (pl, ent[1], ent[2])
+            jobs = [_job_rows(w, weight, pl[0], pl[1], pl[2], plane_dtype == ops.X3_F16, ent[0].shape[0], ent[0].shape[1], idx_map=ent[0])]
         else:
             rows, kern, rg = _grouped_rows(w.float(), g, transposed)
             planes = (ops.weight_planes_f32(rows, plane_dtype), kern, rg)
-    _PLANES[key] = (weakref.ref(weight), weight._version, planes)
+    _plane_store(key, weight, planes, jobs)
     return planes
 
 
@@ -892,14 +1001,12 @@ def _dgrad_strided(dy, weight, stride, padding, kernel, xshape):
     if st > 1 and to * st != t:
         return None
     key = (id(weight), "strided", tuple(stride), tuple(padding))
-    hit = _PLANES.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
-        classes = hit[2]
-    else:
+    classes = _plane_lookup(key, weight)
+    if classes is None:
         per_dim = [_stride_classes(k, s_, p, x, y) for k, s_, p, x, y in zip(kernel, stride, padding, (t, h, w), (to, ho, wo))]
         if any(c is None for c in per_dim):
             return None
-        classes = []
+        classes, jobs = [], []
         with torch.no_grad():
             wd = weight.detach()
             fast = (_PLANES_HIP and wd.dtype == torch.float32 and wd.is_contiguous(memory_format=torch.channels_last_3d) and
@@ -915,12 +1022,13 @@ def _dgrad_strided(dy, weight, stride, padding, kernel, xshape):
                         if fast:  # one launch: the class's taps (row-major over its (dt, dh, dw) lists) gathered and transposed
                             sel = [(a * kernel[1] + b_) * kernel[2] + c_ for a in dt for b_ in dh for c_ in dw]
                             hi, lo = ops.weight_planes_t_f32(w3, sel)
+                            jobs.append(_job_transposed(w3, weight, hi, lo, cout, kernel[0] * kernel[1] * kernel[2], cin, sel))
                         else:
                             sub = wf[:, :, dt][:, :, :, dh][:, :, :, :, dw]                  # [cout, cin, |dt|, |dh|, |dw|]
                             wt = sub.transpose(0, 1).permute(0, 2, 3, 4, 1).reshape(cin, -1)   # rows ci, K = (taps, co)
                             hi, lo = split_planes(wt, ops.X3_BF16)
                         classes.append(((rt, rh, rw), (hi, lo, (len(dt), len(dh), len(dw)), (pbt, pbh, pbw), (nt, nh, nw))))
-        _PLANES[key] = (weakref.ref(weight), weight._version, classes)
+        _plane_store(key, weight, classes, jobs if fast else None)
     dx = torch.empty((b, cin, t, h, w), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last_3d)
     if any(c[1] is None for c in classes):  # classes no tap reaches (a 1x1x1 filter at stride 2: three of four) are zeros
         dx.zero_()

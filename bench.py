@@ -561,6 +561,9 @@ def train_bench(args, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def flush():  # (the graphed step reads its losses one step late: the last one here)
+        pass
+
     # --train-graph: the device side of a step (sample + pack, forward, loss, backward, optimizer) captured once as a HIP graph and
     # replayed — for steps whose launches the host cannot issue as fast as the device runs them (one item per rank).  One pass per
     # step, one rank; the item indices travel through a static device tensor
@@ -585,9 +588,25 @@ def train_bench(args, rank, world, dev):
             idx_buf.copy_(torch.from_numpy(rng.randint(0, len(ds), size=items)))
             gstep = train_ops.GraphedStep(device_step, dev, warmup=max(args.warmup, 3))
 
+            # the host reads every step's loss (train.py:118 reads loss.item() per batch) — ONE STEP LATE: the indices of step k + 1 go
+            # out through pinned memory behind replay k, replay k + 1 is enqueued, and only then is loss k read, so that the device
+            # never waits for the host between two replays (read at once, the gap between replays was ~1 ms of a 49 ms step:
+            # profiles/r06/one_item_graph_timeline.txt)
+            pin = [torch.empty(items, dtype=torch.int64).pin_memory() for _ in range(2)]
+            pend, count = [], [0]
+
             def step():  # noqa: F811 (the graphed form replaces the eager step)
-                idx_buf.copy_(torch.from_numpy(rng.randint(0, len(ds), size=items)), non_blocking=False)
-                losses.append(float(gstep()))
+                b = pin[count[0] % 2]  # (its last copy, two steps ago, is complete: loss k - 1 has been read since)
+                count[0] += 1
+                b.copy_(torch.from_numpy(rng.randint(0, len(ds), size=items)))
+                idx_buf.copy_(b, non_blocking=True)
+                pend.append(gstep().clone())
+                if len(pend) > 1:
+                    losses.append(float(pend.pop(0)))
+
+            def flush():  # noqa: F811
+                while pend:
+                    losses.append(float(pend.pop(0)))
 
             graph_note = "captured"
         except Exception as e:  # (a step that cannot be captured runs eagerly, and the line says so)
@@ -616,9 +635,12 @@ def train_bench(args, rank, world, dev):
             step()
             torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=90), file=sys.stderr)
+    flush()
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    flush()
     sync_all()
     total_s = adist.barrier_max_time(time.perf_counter() - t0, dev)
     if rank != 0:

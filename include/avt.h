@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 8  /* 8: avt_res2_x3 (round 6); 7: BatchNorm statistics on the producing convolution's epilogue: avt_conv3d_igemm_x3_f32_stats, avt_bn_train_fwd_pre (round 5); 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4); 6: avt_pw_x3_f32 (round 4) */
+#define AVT_ABI_VERSION 8  /* 8: avt_res2_x3, avt_weight_planes_gather_f32, avt_weight_planes_multi (round 6); 7: BatchNorm statistics on the producing convolution's epilogue: avt_conv3d_igemm_x3_f32_stats, avt_bn_train_fwd_pre (round 5); 2: avt_bn_train_fwd gained num_batches_tracked (round 2); 3: avt_bn_train_* take groups (+ beta, relu in bwd), avt_stem_conv_x3 takes frames_per_tile (round 3); 4: avt_stem_conv_pool_x3 removed, avt_stem_conv_x3 / avt_maxpool_hw3s2_ndhwc_x3 take a frame index, avt_stem_conv_x3_merged, avt_lateral_x3 (round 4); 5: avt_bn_train_fwd / _bwd and avt_maxpool_train_fwd / _bwd take the leading dimension of y / dy (round 4); 6: avt_pw_x3_f32 (round 4) */
 
 typedef enum {
   AVT_OK = 0,
@@ -671,6 +671,28 @@ int avt_weight_planes_gather_f32(const float* w, const int32_t* map, int rows, i
                                  int plane_dtype, void* stream);
 int avt_weight_planes_t_f32(const float* w, int cout, int taps, int cin, const int32_t* sel, int nsel, void* hi, void* lo,
                             void* stream);
+/* ... and ALL of a step's planes in one launch (round 6): `jobs` is a DEVICE array of AvtPlaneJob — one per launch of the three entry
+ * points above, with the arguments that launch would take — and `blk2job` a DEVICE int32 [nblocks] naming the job of every block
+ * (job j owns blocks blk0 .. blk0 + its own grid size: rows for kinds 0 / 2, gx * gy * nsel for kind 1).  The blocks run the same device
+ * code as the single launches: the planes are bit-identical.  The caller validates the jobs (it has made each of them once through the
+ * single entry points); avt_weight_planes_job_bytes() = sizeof(AvtPlaneJob), for bindings that build the table as raw bytes. */
+typedef struct AvtPlaneJob {
+  const float* w;        /* the weight (rows / transposed), or the tensor `map` indexes (gathered rows) */
+  void* hi;
+  void* lo;
+  float* wscale;         /* kinds 0 / 2 with fp16 planes: [rows] receives 1 / scale; else NULL */
+  const int32_t* map;    /* kind 2: [rows][k] element offsets into w, < 0 = zero */
+  int32_t kind;          /* 0: avt_weight_planes_f32, 1: avt_weight_planes_t_f32, 2: avt_weight_planes_gather_f32 */
+  int32_t f16;           /* kinds 0 / 2: 1 = fp16 planes (row-scaled), 0 = bf16 planes */
+  int32_t rows, k;       /* kinds 0 / 2 */
+  int32_t cout, taps, cin, nsel; /* kind 1 */
+  int32_t gx, gy;        /* kind 1: ceil(cin / 32), ceil(cout / 32) */
+  int32_t blk0;          /* first block of the job in the launch */
+  int32_t pad_;
+  int32_t sel[32];       /* kind 1: source tap of output tap a */
+} AvtPlaneJob;
+int avt_weight_planes_job_bytes(void);
+int avt_weight_planes_multi(const void* jobs, const int32_t* blk2job, int nblocks, void* stream);
 
 /* MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the stems in the training step on fp32 NDHWC rows [bt, h, w, c] (csrc/stem_train.hip;
  * the reference: the third-party SlowFast stem under autograd, train.py:114-141).  fwd: y [bt, ho, wo, c] and `tap`

@@ -824,7 +824,7 @@ def test_grouped_planes_by_one_gather_equal_the_torch_assembly(shape, g, transpo
         out = []
         for flag in (1, 0):
             keep, train_ops._GROUP_GATHER = train_ops._GROUP_GATHER, flag
-            train_ops.invalidate_weight_cache()
+            train_ops.invalidate_weight_cache(drop=True)
             try:
                 out.append(train_ops._grouped_planes(w, g, transposed, pd))
             finally:
@@ -833,4 +833,70 @@ def test_grouped_planes_by_one_gather_equal_the_torch_assembly(shape, g, transpo
         assert ka == kb and ra == rb
         for a, b in zip(pa, pb):
             assert (a is None and b is None) or torch.equal(a, b)
-    train_ops.invalidate_weight_cache()
+    train_ops.invalidate_weight_cache(drop=True)
+
+
+def _flat_tensors(v, out):
+    if torch.is_tensor(v):
+        out.append(v)
+    elif isinstance(v, (tuple, list)):
+        for e in v:
+            _flat_tensors(e, out)
+    return out
+
+
+@pytest.mark.gpu
+def test_stale_weight_planes_are_remade_by_one_launch_bit_for_bit():
+    """Round 6: after the optimizer step every cached set of weight planes is stale; the first lookup of the next step re-makes ALL of
+    them in place with ONE launch (avt_weight_planes_multi over a device table of the single launches' own arguments).  The planes must
+    be, bit for bit and scale for scale, what the one-by-one launches produce from the same weights: plain rows (fp16, row-scaled),
+    transposed + tap-selected (the input gradient's filters, stride 1 and the strided layers' residue classes) and the gathered rows of
+    the pixel-grouped few-channel layers."""
+    from avtex import train_ops
+    from avtex.slowfast import ResBlock
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(ResBlock(16, 64, 16, 3, 1), ResBlock(64, 128, 32, 1, 2), ResBlock(128, 128, 32, 3, 1))
+    net = net.to(dev).to(memory_format=torch.channels_last_3d).train()
+    x = torch.randn(2, 16, 4, 16, 16, device=dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+
+    def fwd_bwd():
+        net.zero_grad(set_to_none=True)
+        with train_ops.bn_replicas(1):
+            net(x).square().mean().backward()
+
+    train_ops.invalidate_weight_cache(drop=True)
+    keep, train_ops._PLANES_MULTI = train_ops._PLANES_MULTI, 1
+    try:
+        fwd_bwd()                                    # every entry made one by one
+        own = {id(p) for p in net.parameters()}
+        mine = {k: e for k, e in train_ops._PLANES.items() if e.ref() is not None and id(e.ref()) in own}
+        kinds = sorted({j["fields"][4] for e in mine.values() if e.jobs for j in e.jobs})
+        assert kinds == [0, 1, 2], kinds             # rows, transposed, gathered rows all occur in this net
+        assert any(k[1] == "strided" and e.jobs for k, e in mine.items() if isinstance(k[1], str))
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(1.03).add_(0.001)             # "the optimizer step": versions move, the tensors stay
+        n0 = train_ops.CALLS["planes_multi"]
+        fwd_bwd()
+        assert train_ops.CALLS["planes_multi"] == n0 + 1   # ONE launch for the whole step (forward and backward filters alike)
+        torch.cuda.synchronize()
+        multi = {k: [t.clone() for t in _flat_tensors(e.value, [])] for k, e in mine.items() if e.jobs}
+        assert all(not e.stale(e.ref()) for e in mine.values())
+        train_ops._PLANES_MULTI = 0
+        train_ops.invalidate_weight_cache(drop=True)
+        fwd_bwd()                                    # the same weights, one launch per plane set
+        torch.cuda.synchronize()
+        assert train_ops.CALLS["planes_multi"] == n0 + 1
+        checked = 0
+        for k, ts in multi.items():
+            ref = _flat_tensors(train_ops._PLANES[k].value, [])
+            assert len(ref) == len(ts)
+            for a, b in zip(ts, ref):
+                assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), k
+                checked += 1
+        assert checked >= 2 * len(multi)
+    finally:
+        train_ops._PLANES_MULTI = keep
+        train_ops.invalidate_weight_cache(drop=True)
