@@ -80,6 +80,7 @@ SIGNATURES = {
     "avt_conv3d_igemm_x3_f32_ex": [_vp] * 6 + [C.c_int] * 21 + [_vp],
     "avt_conv3d_wgrad_x3_f32": [_vp, _vp, _vp] + [C.c_int] * 17 + [_vp],
     "avt_wgrad_x3_set_xl": [C.c_int],
+    "avt_conv_x3_set_small_tile": [C.c_int],
     "avt_conv3d_wgrad_x3_sub_f32": [_vp, _vp, _vp] + [C.c_int] * 22 + [_vp],
     "avt_interp_pack_pair_u8": [_vp, _vp, C.c_int, C.c_int, _f32p, _vp, _vp, _vp, C.c_int, _vp],
     "avt_avgpool2_x3": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp],
@@ -157,6 +158,8 @@ def lib():
         if handle.avt_abi_version() != ABI_VERSION:
             raise AvtError("libavt_hip.so ABI version %d, expected %d: rebuild with `make -C %s`"
                            % (handle.avt_abi_version(), ABI_VERSION, os.path.join(_HERE, "csrc")))
+        if os.environ.get("AVT_SMALL_TILE", "") == "0":  # (A/Bs: the training convolutions' 64-row tile at small batches off)
+            handle.avt_conv_x3_set_small_tile(0)
         _lib = handle
     return _lib
 

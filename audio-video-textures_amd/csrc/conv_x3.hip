@@ -1088,8 +1088,22 @@ extern "C" int avt_gemm_nt_x3_f32out(const void* a_hi, const void* a_lo, int lda
 
 // fp32 rows in, fp32 rows out, split-plane arithmetic in between (the IO32 form of the kernel): see include/avt.h
 // the IO32 tile that avt_conv3d_igemm_x3_f32 launches for (cout, K, M): 256 = the XL tile, else 128 (rows per tile)
+// ... and 64 (round 6): a wide layer (128-column tiles) at a batch whose 128-row tiles would not give every CU its two workgroups —
+// config 5 at ONE item per rank: 15 target clips are 368 tiles at res4 and 184 at res5 on 256 CUs, 170-230 TFLOP/s where the same
+// layers reach 300 at 8 items (profiles/r06/train_layers_one_item.log).  Rows of 64 double the workgroups (the operand the kernel
+// pays VALU for — the fp32 activation rows it splits — is fetched as often as before; the weight planes twice as often, from L2).
+static int g_io32_small = 1;  // avt_conv_x3_set_small_tile
 static int io32_tile_rows(int cout, int k, int64_t m) {
-  return (k % 32 == 0 && m < (1ll << 31) && avt_conv3d_igemm_x3_xl_picked(cout, k, (int)m) && m >= 256 * 256) ? 256 : 128;
+  if (k % 32 == 0 && m < (1ll << 31) && avt_conv3d_igemm_x3_xl_picked(cout, k, (int)m) && m >= 256 * 256) return 256;
+  if (g_io32_small && cout > 64 && ((m + 127) / 128) * ((cout + 127) / 128) < 512) return 64;
+  return 128;
+}
+
+// 1 (default): the 64-row tile where io32_tile_rows picks it; 0: never (A/Bs, tests of the 128-row form at small sizes) -> the old value
+extern "C" int avt_conv_x3_set_small_tile(int on) {
+  const int was = g_io32_small;
+  g_io32_small = on ? 1 : 0;
+  return was;
 }
 
 static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, const float* add,
@@ -1142,22 +1156,26 @@ static int igemm_x3_f32_impl(const float* in, const void* wt_hi, const void* wt_
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (bst) {  // backward statistics: the 128-row tiles only (bf16 planes: gradients)
-    AVT_REQUIRE(plane_dtype == AVT_X3_BF16 && io32_tile_rows(cout, a.K, a.M) == 128,
-                "avt_conv3d_igemm_x3_f32_bwdstats: bf16 planes, layers of the 128-row tile (avt_conv3d_igemm_x3_f32_bwdstats_rows)");
+    AVT_REQUIRE(plane_dtype == AVT_X3_BF16 && io32_tile_rows(cout, a.K, a.M) != 256,
+                "avt_conv3d_igemm_x3_f32_bwdstats: bf16 planes, layers of the 128- / 64-row tiles (avt_conv3d_igemm_x3_f32_bwdstats_rows)");
     if (cout <= 32) return launch_x3<128, 32, 32, false, true, true>(a, s);
     if (cout <= 64) return launch_x3<128, 64, 64, false, true, true>(a, s);
+    if (io32_tile_rows(cout, a.K, a.M) == 64) return launch_x3<64, 128, 32, false, true, true>(a, s);
     return launch_x3<128, 128, 64, false, true, true>(a, s);
   }
+  const bool small = io32_tile_rows(cout, a.K, a.M) == 64;
   // long-K layers at a batch that fills 256 x 256 tiles (a rank's items as one batch): the XL tile's IO32 form
   if (a.oH == 0 && io32_tile_rows(cout, a.K, a.M) == 256)
     return plane_dtype == AVT_X3_F16 ? launch_x3_xl<true, true>(a, s) : launch_x3_xl<false, true>(a, s);
   if (plane_dtype == AVT_X3_F16) {
     if (cout <= 32) return launch_x3<128, 32, 32, true, true>(a, s);
     if (cout <= 64) return launch_x3<128, 64, 64, true, true>(a, s);
+    if (small) return launch_x3<64, 128, 32, true, true>(a, s);
     return launch_x3<128, 128, 64, true, true>(a, s);
   }
   if (cout <= 32) return launch_x3<128, 32, 32, false, true>(a, s);
   if (cout <= 64) return launch_x3<128, 64, 64, false, true>(a, s);
+  if (small) return launch_x3<64, 128, 32, false, true>(a, s);
   return launch_x3<128, 128, 64, false, true>(a, s);
 }
 
@@ -1188,8 +1206,10 @@ extern "C" int avt_conv3d_igemm_x3_f32_stats(const float* in, const void* wt_hi,
 
 // rows of partials per group avt_conv3d_igemm_x3_f32_bwdstats writes, or -1 where it does not apply (the 256 x 256 tile's layers)
 extern "C" int avt_conv3d_igemm_x3_f32_bwdstats_rows(int cout, int k, int64_t m, int groups) {
-  if (groups < 1 || m <= 0 || m % groups || io32_tile_rows(cout, k, m) != 128) return -1;
-  return (int)((m / groups + 127) / 128);
+  if (groups < 1 || m <= 0 || m % groups) return -1;
+  const int bm = io32_tile_rows(cout, k, m);
+  if (bm == 256) return -1;
+  return (int)((m / groups + bm - 1) / bm);
 }
 
 // The stride-1 INPUT GRADIENT whose result is the output gradient of a train-mode BatchNorm (+ ReLU): see include/avt.h

@@ -597,6 +597,11 @@ def weight_planes_gather_f32(w, idx_map, plane_dtype):
     return hi, lo, ws
 
 
+def conv_x3_set_small_tile(on):
+    """The IO32 convolutions' 64-row tile at small batches on / off (csrc/conv_x3.hip io32_tile_rows) -> the previous setting."""
+    return int(_lib.lib().avt_conv_x3_set_small_tile(int(bool(on))))
+
+
 def weight_planes_job_bytes():
     return int(_lib.lib().avt_weight_planes_job_bytes())
 

@@ -509,6 +509,7 @@ _TABS, _PLANES = {}, {}
 _PLANES_MULTI = 1      # stale planes are re-made by ONE launch over every cached weight (0: one by one, as rounds 3-5 did; tests)
 _PLANES_GEN = [0]      # invalidate_weight_cache() bumps it
 _PLANE_TABLES = {}     # device -> (key, job table, blk2job, blocks) of the last multi-job launch
+_PLANE_TABLES_CAPTURED = []  # tables a stream capture has launched with (kept alive for the graphs that replay them)
 _PLANE_REFRESH = {}    # device -> {"id", "event", "stream", "waited": {stream handle: id}}
 
 
@@ -516,10 +517,11 @@ class _PlaneEntry:
     """A cached set of weight planes: `value` is what the lookup returns; `jobs` describes the launches that made its tensors
     (None: not re-makeable in place — torch-assembled forms), as dicts {"off": byte offset of the source in the owner's storage,
     "fields": the AvtPlaneJob fields after `w` up to `blk0`, "sel": taps, "blocks": grid size}."""
-    __slots__ = ("ref", "version", "gen", "value", "jobs")
+    __slots__ = ("ref", "version", "gen", "value", "jobs", "sig")
 
     def __init__(self, owner, value, jobs=None):
         self.ref, self.version, self.gen, self.value, self.jobs = weakref.ref(owner), owner._version, _PLANES_GEN[0], value, jobs
+        self.sig = (tuple(owner.shape), tuple(owner.stride()), owner.dtype)  # what the jobs' sizes and offsets were derived from
 
     def stale(self, owner):
         return self.version != owner._version or self.gen != _PLANES_GEN[0]
@@ -550,6 +552,9 @@ def _refresh_planes(device):
     for ent in _PLANES.values():
         owner = ent.ref()
         if owner is not None and ent.jobs and owner.device == device and ent.stale(owner):
+            if ent.sig != (tuple(owner.shape), tuple(owner.stride()), owner.dtype):
+                ent.jobs = None  # (`param.data = other layout`: the recipe is void; the lookup misses and the planes are made anew)
+                continue
             todo.append((ent, owner))
     if not todo:
         return False
@@ -567,6 +572,8 @@ def _refresh_planes(device):
         assert len(raw) == len(blk) * ops.weight_planes_job_bytes(), "AvtPlaneJob layout"
         tab = (recs, torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(device), torch.from_numpy(np.concatenate(blk)).to(device), b0)
         _PLANE_TABLES[device] = tab
+    if torch.cuda.is_current_stream_capturing() and not any(t is tab for t in _PLANE_TABLES_CAPTURED):
+        _PLANE_TABLES_CAPTURED.append(tab)  # a HIP graph holds this table's address: it outlives every later rebuild
     with torch.no_grad():
         ops.weight_planes_multi(tab[1], tab[2], tab[3])
     for ent, owner in todo:

@@ -555,9 +555,13 @@ int avt_conv3d_igemm_x3_f32(const float* in, const void* wt_hi, const void* wt_l
  * straddles two groups), and tile t of group g writes row (g * rows + t) of `stat_part` — doubles, in the layout the BatchNorm's
  * finalize kernel sums in a fixed order (bitwise reproducible; per-thread fp32 sums over at most 16 rows, everything above in fp64).
  * stat_c = the BatchNorm's channel count: cout, or cout / g for a pixel-grouped layer (columns n and n + stat_c are one channel).
- * avt_conv3d_igemm_x3_f32_stat_rows -> rows of partials per group that call writes (tile height 128 or 256 by the layer's shape).
+ * avt_conv3d_igemm_x3_f32_stat_rows -> rows of partials per group that call writes (tile height 64, 128 or 256 by the layer's shape and batch).
  * avt_bn_train_fwd_pre = avt_bn_train_fwd without its statistics pass: `ws` holds pre_rows rows per group written by the producer
  * (pre_rows = stat_rows * max(1, c / 1024)), sized by avt_bn_train_ws_bytes_pre(c, groups, pre_rows). */
+/* The IO32 tiles are 256 rows (the XL tile's layers at >= 65 536 rows), 128 rows, or — round 6 — 64 rows where a wide layer's 128-row
+ * tiles would number fewer than two per CU (config 5 at one item per rank).  avt_conv_x3_set_small_tile(0) switches the 64-row form off
+ * (A/Bs, tests of the 128-row form at small sizes); returns the previous setting.  The *_stat_rows / *_bwdstats_rows queries follow it. */
+int avt_conv_x3_set_small_tile(int on);
 int avt_conv3d_igemm_x3_f32_stat_rows(int cout, int k, int64_t m, int groups);
 int avt_conv3d_igemm_x3_f32_stats(const float* in, const void* wt_hi, const void* wt_lo, const float* wscale, float* out,
                                   const int32_t* ktab, int batch, int t, int h, int w, int cin, int cout, int kt, int kh, int kw,

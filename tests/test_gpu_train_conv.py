@@ -900,3 +900,61 @@ def test_stale_weight_planes_are_remade_by_one_launch_bit_for_bit():
     finally:
         train_ops._PLANES_MULTI = keep
         train_ops.invalidate_weight_cache(drop=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,kernel,stride,pad,dims,groups", [
+    (32, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (6, 4, 10, 10), 3),       # 800 rows per group: 12.5 tiles of 64, 6.25 of 128
+    (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 14, 14), 2),      # res4 b at a small batch (K = 2304, two column tiles)
+    (1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 8, 14, 14), 1),     # res4 a on ONE clip: 1568 rows, K = 3072
+    (128, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 14, 14), 1),      # strided: the input gradient by residue classes (row remap)
+    (2048, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 8, 7, 7), 3),       # res5 a: 392 rows per group, K = 6144 (the table leaves the LDS)
+])
+def test_the_64_row_tile_equals_the_128_row_tile(cin, cout, kernel, stride, pad, dims, groups):
+    """Round 6: wide layers at small batches run 64-row tiles (twice the workgroups: config 5 at one item per rank).  Every output
+    element is the same sum in the same order as on the 128-row tile — the convolution and its input gradient are bit-identical — and
+    the BatchNorm statistics both epilogues leave behind (forward: of the output; backward: of the masked gradient) differ only in how
+    the rows are grouped into fp32 partial sums."""
+    import torch.nn as nn
+
+    from avtex import ops, train_ops
+
+    dev = "cuda:0"
+    torch.manual_seed(cin + cout)
+    b, t, h, w = dims
+    x0 = (torch.randn(b, cin, t, h, w, device=dev) * 1.5 + 0.4).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(small):
+        torch.manual_seed(7)
+        conv = nn.Conv3d(cin, cout, kernel, stride=stride, padding=pad, bias=False).to(dev).to(memory_format=torch.channels_last_3d).train()
+        bn_in, bn_out = nn.BatchNorm3d(cin).to(dev).train(), nn.BatchNorm3d(cout).to(dev).train()
+        with torch.no_grad():
+            for bn in (bn_in, bn_out):
+                bn.weight.copy_(torch.linspace(0.5, 1.5, bn.num_features))
+                bn.bias.copy_(torch.linspace(-0.3, 0.3, bn.num_features))
+        x = x0.clone().requires_grad_(True)
+        was = ops.conv_x3_set_small_tile(small)
+        for k in train_ops.CALLS:
+            train_ops.CALLS[k] = 0
+        try:
+            with train_ops.bn_replicas(groups):
+                y = train_ops.bn_act(x, bn_in, relu=True)
+                z0 = train_ops.conv3d(y, conv, stats=bn_out)
+                z = train_ops.bn_act(z0, bn_out, relu=True)
+            z.square().sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.conv_x3_set_small_tile(was)
+        return (z0.detach(), z.detach(), x.grad, conv.weight.grad, bn_in.weight.grad, bn_in.bias.grad, bn_out.weight.grad, bn_out.bias.grad,
+                bn_out.running_mean.clone(), bn_out.running_var.clone(), dict(train_ops.CALLS))
+
+    a, e = run(1), run(0)
+    m = z0_rows = a[0].numel() // cout
+    assert ops._lib.lib().avt_conv3d_igemm_x3_f32_stat_rows(cout, cin * kernel[0] * kernel[1] * kernel[2], m, groups) >= 1 and z0_rows
+    assert a[10]["conv_fwd_x3"] == e[10]["conv_fwd_x3"] == 1 and a[10]["bn_fwd_pre"] == e[10]["bn_fwd_pre"] == 1
+    assert a[10]["dgrad_bwdstats"] == e[10]["dgrad_bwdstats"] and a[10]["dgrad_strided_x3"] == e[10]["dgrad_strided_x3"]
+    assert torch.equal(a[0], e[0])  # the convolution: the same sums in the same order
+    for k, name in ((1, "z"), (2, "dx"), (3, "dw"), (4, "dgamma_in"), (5, "dbeta_in"), (6, "dgamma_out"), (7, "dbeta_out"),
+                    (8, "running_mean"), (9, "running_var")):
+        err = float((a[k] - e[k]).norm() / e[k].norm().clamp_min(1e-20))
+        assert err < (2e-4 if name == "dw" else 5e-6), (name, err)  # (dw: fp32 atomics, run-to-run order)
