@@ -549,7 +549,7 @@ def _refresh_planes(device):
 
     from . import ops
     todo = []
-    for ent in _PLANES.values():
+    for ent in list(_PLANES.values()):
         owner = ent.ref()
         if owner is not None and ent.jobs and owner.device == device and ent.stale(owner):
             if ent.sig != (tuple(owner.shape), tuple(owner.stride()), owner.dtype):
@@ -561,6 +561,8 @@ def _refresh_planes(device):
     recs = tuple((owner.data_ptr() + j["off"],) + j["fields"] + j["sel"] for ent, owner in todo for j in ent.jobs)
     tab = _PLANE_TABLES.get(device)
     if tab is None or tab[0] != recs:  # (the same weights at the same addresses every step: built once; a HIP graph captures its pointers)
+        if torch.cuda.is_current_stream_capturing():
+            return False  # (a capture whose warm-up did not see this set of weights: no host-to-device copy inside it — one by one, as before)
         raw, blk, b0 = [], [], 0
         for n, (ent, owner) in enumerate(todo):
             for j in ent.jobs:
