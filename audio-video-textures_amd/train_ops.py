@@ -67,6 +67,18 @@ def invalidate_weight_cache(drop=False):
     _STEM_IMAGES.clear()
 
 
+# Optimizers that update their parameters without moving Tensor._version — torch's FUSED kernels (SGD / Adam(W) with fused=True:
+# measured, _version 0 -> 0 over optimizer.step(), tools/experimental/debug_sgd_arena.py), updates through `.data` — would leave the
+# version-keyed plane cache serving the OLD weights to every convolution after them.  Every optimizer step of the process therefore
+# marks the cache stale (one global hook; the next lookup re-makes all planes in one launch, which a version bump would have asked for too).
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+
+    _STEP_HOOK = _register_step_hook(lambda *_a, **_k: invalidate_weight_cache())
+except ImportError:  # (torch < 2.0: callers invalidate by hand, as train() always has)
+    _STEP_HOOK = None
+
+
 # per-process launch counters of the hand-written training kernels (tests assert that the default path really runs them)
 CALLS = {"conv_fwd_x3": 0, "dgrad_x3": 0, "dgrad_strided_x3": 0, "wgrad_x3": 0, "wgrad_stem_x3": 0, "bn_fwd": 0, "bn_bwd": 0,
          "miopen_dgrad": 0, "miopen_wgrad": 0, "stem_fwd_patch": 0, "wgrad_stem_patch": 0, "maxpool_hip": 0, "pw_f32": 0,
@@ -441,14 +453,20 @@ class MicroBatchGradients:
 
     Same sum as autograd's own accumulation (fp32 adds in the same order per parameter)."""
 
-    def __init__(self, params):
+    def __init__(self, params, single_pass_arena=False):
         self.params = [p for p in params if p.requires_grad]
         self.acc = None
         self.seen = False
         self.arena = _GradArena()
+        # single_pass_arena (round 6): a step of ONE pass also takes its weight gradients as slices of the arena — one memset per step
+        # instead of one per convolution (110 of a one-item config-5 step's launches).  The gradients then ARE arena slices until the
+        # next begin() drops them: for loops that read .grad only between backward and the optimizer step, on one rank (DDP's buckets
+        # want gradients that own their storage)
+        self.single_pass_arena = bool(single_pass_arena)
+        self.passes = 1
 
     def begin(self, passes):
-        """passes: forward/backward passes of this optimizer step (1: nothing to accumulate, the arena stays off)."""
+        """passes: forward/backward passes of this optimizer step (1: nothing to accumulate; the arena stays off unless single_pass_arena)."""
         global _ARENA
         for p in self.params:
             p.grad = None
@@ -456,8 +474,10 @@ class MicroBatchGradients:
         if live:
             torch._foreach_zero_(live)
         self.seen = False
-        _ARENA = self.arena if passes > 1 else None
-        if passes > 1:
+        self.passes = passes
+        on = passes > 1 or self.single_pass_arena
+        _ARENA = self.arena if on else None
+        if on:
             self.arena.reset()
 
     def after_backward(self):
@@ -487,7 +507,7 @@ class MicroBatchGradients:
     def finish(self):
         global _ARENA
         arena_on, _ARENA = _ARENA is not None, None
-        if not arena_on:  # (a single pass: every gradient owns its storage)
+        if not arena_on or self.passes == 1:  # (a single pass: every gradient owns its storage — or, single_pass_arena, its slice until begin())
             return
         # the gradients the last pass produced as arena slices live on in .grad only where autograd accumulated into the
         # accumulator's own tensors; a parameter first seen in the last pass keeps an arena slice: give it its own storage
@@ -905,7 +925,10 @@ def _conv_wgrad(ctx, dy, x, weight, stride, padding, kernel, cin, cout):
         dims = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
         flat = _ARENA.take(weight.numel(), weight.device) if _ARENA is not None else None
         if flat is not None:  # a zeroed slice of the micro-batch's gradient arena: no memset launch per convolution
-            dw = flat.view(cout, kernel[0], kernel[1], kernel[2], cin).permute(0, 4, 1, 2, 3)
+            # (the weight's OWN strides, size-1 dimensions included: torch's multi-tensor optimizer kernels take their fast path only for
+            #  gradients whose strides equal the parameters' — a permuted view differs in the stride of a one-tap dimension, and a
+            #  foreach SGD then ran one launch per tensor: +4.8 ms on a 47 ms step, profiles/r06/train_one_item_arena_sgd_ab.log)
+            dw = torch.as_strided(flat, tuple(weight.shape), tuple(weight.stride()))
             ops.conv3d_wgrad_x3_sub_f32(dy.permute(0, 2, 3, 4, 1), x.permute(0, 2, 3, 4, 1), flat, dims, cin, cout, kernel, stride,
                                         padding, (0, 0, 0), cin, cout, taps * cin, False)
         else:

@@ -480,7 +480,18 @@ def train_bench(args, rank, world, dev):
     if channels_last:
         model = model.to(memory_format=torch.channels_last_3d)
     net = wrap_ddp(model, dev, dev.index) if world > 1 else model
-    opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, weight_decay=1e-4)  # README.md:38 / main.py:440-446
+    # README.md:38 / main.py:440-446: SGD + momentum + weight decay.  fused = torch's single-kernel form of the same update (a handful of
+    # launches per step instead of 21 multi-tensor ones: they sit behind the backward's last join, on nobody's shadow)
+    # (fused kernels do not move Tensor._version: train_ops marks its weight-plane cache stale from a global optimizer-step hook.
+    #  --train-fused-sgd 0 passes NO flag — torch's default, the multi-tensor form; fused=False would select the one-tensor-at-a-time loop)
+    opt = None
+    if getattr(args, "train_fused_sgd", 1):
+        try:
+            opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, weight_decay=1e-4, fused=True)
+        except (TypeError, RuntimeError):
+            opt = None
+    if opt is None:
+        opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, weight_decay=1e-4)
     crit = avtex.InfoNCECriterion()
     bat = DeviceSegmentBatcher(ds, dev)
     np.random.seed(1 + rank)
@@ -497,7 +508,8 @@ def train_bench(args, rank, world, dev):
         import avtex.slowfast as _sf
 
         _sf.PATHWAY_STREAMS = int(args.train_pathway_streams)
-    grads = train_ops.MicroBatchGradients(model.parameters()) if args.grad_accumulator else None
+    # (one rank: a single-pass step also takes its weight gradients as slices of ONE zeroed arena — a memset per step, not per convolution)
+    grads = train_ops.MicroBatchGradients(model.parameters(), single_pass_arena=world == 1) if args.grad_accumulator else None
 
     # --item-streams 2: consecutive items alternate between two streams; the forward of item k + 1 is ordered after the forward
     # of item k (BatchNorm running statistics, the batcher's generator, the weight-plane caches) and its backward after the
@@ -573,7 +585,10 @@ def train_bench(args, rank, world, dev):
         labels0 = torch.zeros(items, dtype=torch.long, device=dev)
 
         def device_step():
-            opt.zero_grad(set_to_none=True)
+            if grads is not None:
+                grads.begin(1)
+            else:
+                opt.zero_grad(set_to_none=True)
             q, t, _, _ = bat.batch(idx_buf)
             if channels_last:
                 q = [v.contiguous(memory_format=torch.channels_last_3d) for v in q]
@@ -581,6 +596,8 @@ def train_bench(args, rank, world, dev):
                 out = net(q, t)
             loss = crit(out.float(), labels0)
             loss.backward()
+            if grads is not None:
+                grads.finish()
             opt.step()
             return loss.detach()
 
@@ -747,6 +764,7 @@ def build_parser():
                     help="--mode train: capture the device side of a step as ONE HIP graph and replay it (train_ops.GraphedStep): for "
                          "steps the host cannot issue as fast as the device runs them (one item per rank); one pass per step, one rank")
     ap.add_argument("--no-train-one-item-leg", action="store_true", help="skip the one-item config-5 leg of the default run")
+    ap.add_argument("--train-fused-sgd", type=int, default=1, choices=[0, 1], help="--mode train: torch's fused SGD kernel (0: the multi-tensor form)")
     ap.add_argument("--train-pass-items", type=int, default=0,
                     help="--mode train: items per forward/backward pass (0 = all of the rank's items as one batch with per-item "
                          "BatchNorm groups; 1 = one pass per item, round 2's loop)")

@@ -67,6 +67,25 @@ def test_weight_planes_follow_the_optimizer():
     assert torch.allclose(y1, 2 * y0, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("kw", [dict(foreach=True), dict(fused=True)])
+def test_weight_planes_follow_every_optimizer_step(kw):
+    """torch's fused optimizer kernels update the parameters WITHOUT moving Tensor._version (round 6, measured: 0 -> 0 over
+    SGD(fused=True).step()): a plane cache keyed on versions alone would serve the old weights to every later convolution.  A global
+    optimizer-step hook marks the cache stale; the convolution after the step sees the new weights either way."""
+    from avtex import train_ops
+    torch.manual_seed(4)
+    conv = nn.Conv3d(16, 16, (1, 3, 3), padding=(0, 1, 1), bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
+    x = _cl(torch.randn(1, 16, 2, 8, 8, device=DEV))
+    opt = torch.optim.SGD(conv.parameters(), lr=0.5, **kw)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        train_ops.conv3d(x, conv).square().mean().backward()
+        opt.step()
+        want = torch.nn.functional.conv3d(x, conv.weight.detach(), padding=(0, 1, 1))
+        got = train_ops.conv3d(x, conv).detach()
+        assert float((got - want).abs().max()) <= 3e-6 * float(want.abs().max())
+
+
 def test_falls_back_outside_its_domain():
     from avtex import train_ops
     stem = nn.Conv3d(3, 64, (1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3), bias=False).to(DEV).to(memory_format=torch.channels_last_3d).train()
@@ -318,10 +337,12 @@ def test_training_convolution_at_full_size_scales():
     assert float((dw4 - 16 * dw1).norm()) <= 1e-5 * float((16 * dw1).norm())
 
 
-@pytest.mark.parametrize("passes", [1, 3])
-def test_micro_batch_gradients_equal_autograd_accumulation(passes):
+@pytest.mark.parametrize("passes,single_arena", [(1, False), (3, False), (1, True)])
+def test_micro_batch_gradients_equal_autograd_accumulation(passes, single_arena):
     """train_ops.MicroBatchGradients (one multi-tensor add per pass, weight gradients written into slices of one zeroed
-    arena) gives the sums autograd's own .grad accumulation gives, step after step (the arena is re-zeroed, not re-used dirty)."""
+    arena) gives the sums autograd's own .grad accumulation gives, step after step (the arena is re-zeroed, not re-used dirty).
+    single_arena (round 6): a ONE-pass step takes arena slices too — one memset per step — and an SGD step (torch's fused kernel, as
+    bench.py runs it) reads those slices as gradients."""
     from avtex import train_ops
 
     class Net(nn.Module):
@@ -341,7 +362,7 @@ def test_micro_batch_gradients_equal_autograd_accumulation(passes):
 
     def run(accumulate):
         out = []
-        acc = train_ops.MicroBatchGradients(net.parameters()) if accumulate else None
+        acc = train_ops.MicroBatchGradients(net.parameters(), single_pass_arena=single_arena) if accumulate else None
         for step in range(3):  # the second and third steps meet a used arena / used accumulators
             if acc is not None:
                 acc.begin(passes)
@@ -368,6 +389,26 @@ def test_micro_batch_gradients_equal_autograd_accumulation(passes):
         assert set(w) == set(g) and "unused.weight" not in g
         for k in w:
             assert float((w[k] - g[k]).abs().max()) <= 2e-5 * float(w[k].abs().max()) + 1e-12, k
+    if single_arena:  # the arena's slices as the optimizer's gradients: a fused SGD step equals the multi-tensor one on owned gradients
+        import copy
+
+        def sgd(fused, arena):
+            m = copy.deepcopy(net)
+            opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2, fused=fused)
+            acc = train_ops.MicroBatchGradients(m.parameters(), single_pass_arena=arena)
+            for step in range(3):
+                acc.begin(1)
+                (m(xs[0] * (1.0 + step)).square().mean()).backward()
+                acc.finish()
+                if arena and step:  # (from the second step on the weight gradients are slices of the arena)
+                    buf = acc.arena.buf[m.c1.weight.device]
+                    assert buf.data_ptr() <= m.c1.weight.grad.data_ptr() < buf.data_ptr() + 4 * buf.numel()
+                opt.step()
+            torch.cuda.synchronize()
+            return [p.detach().clone() for p in m.parameters()]
+
+        for a, b in zip(sgd(True, True), sgd(False, False)):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
 
 
 @pytest.mark.parametrize("dims,c", [((2, 3, 12, 12), 8), ((1, 2, 11, 9), 64), ((2, 1, 112, 112), 16)])
