@@ -781,7 +781,7 @@ def build_parser():
                     help="HIP streams for the q / t encoders (4 also splits each clip batch in halves); 0 = by encoder mode: one "
                          "for the contract-grade kernels (their XL / fused-block launches fill the chip; a second stream measured "
                          "-1.4 %%), two for the bf16 path (+13 %%)")
-    ap.add_argument("--cpu-clips", type=int, default=4, help="windows in the timed CPU-baseline sample")
+    ap.add_argument("--cpu-clips", type=int, default=8, help="windows in the timed CPU-baseline sample (8: ~10 s of wall time on 16 threads with the thread-count probe)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4],
                     help="BASELINE.json config: 2 = the headline (N = 4096 windows per GPU, threshold select); 4 = N = 16384 windows "
                          "sharded over 8 GPUs = 2048 windows per GPU (sets --windows 2048), the select leg followed by the top-k (k = 8) "

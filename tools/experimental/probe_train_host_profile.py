@@ -13,7 +13,8 @@ import bench  # noqa: E402
 
 
 def main():
-    args = bench.build_parser().parse_args(["--mode", "train", "--steps", "4", "--warmup", "2"])
+    # (extra command-line words are handed to bench.py's parser: `--train-items 1` profiles the one-item step)
+    args = bench.build_parser().parse_args(["--mode", "train", "--steps", "6", "--warmup", "3"] + sys.argv[1:])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     torch.backends.cudnn.benchmark = True
