@@ -25,6 +25,25 @@ def test_library_exports_every_declared_symbol(avt):
     assert avt._lib.lib().avt_abi_version() == avt._lib.ABI_VERSION == 8
 
 
+def test_plane_job_table_layout_matches_the_header(avt):
+    """AvtPlaneJob (include/avt.h) as the three parties see it: the header's fields mirrored in ctypes, the library's own sizeof, and the
+    struct format train_ops._refresh_planes packs its device table with."""
+    import struct
+
+    class AvtPlaneJob(ctypes.Structure):
+        _fields_ = ([(n, ctypes.c_void_p) for n in ("w", "hi", "lo", "wscale", "map")] +
+                    [(n, ctypes.c_int32) for n in ("kind", "f16", "rows", "k", "cout", "taps", "cin", "nsel", "gx", "gy", "blk0", "pad_")] +
+                    [("sel", ctypes.c_int32 * 32)])
+
+    src = open(avt._lib.HEADER_PATH).read()
+    body = src[src.index("typedef struct AvtPlaneJob {"):src.index("} AvtPlaneJob;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    declared = re.findall(r"\b([a-z_0-9]+)(?:\[32\])?\s*[;,]", body)
+    assert declared == [f[0] for f in AvtPlaneJob._fields_], declared
+    assert ctypes.sizeof(AvtPlaneJob) == avt._lib.lib().avt_weight_planes_job_bytes() == struct.calcsize("<5Q12i32i") == 216
+    assert AvtPlaneJob.sel.offset == 88 and AvtPlaneJob.blk0.offset == 80
+
+
 def test_no_torch_types_in_header(avt):
     src = open(avt._lib.HEADER_PATH).read()
     code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)  # comments cite the torch calls each entry replaces
