@@ -479,7 +479,13 @@ def train_bench(args, rank, world, dev):
     channels_last = args.train_layout == "ndhwc" or args.train_channels_last
     if channels_last:
         model = model.to(memory_format=torch.channels_last_3d)
-    net = wrap_ddp(model, dev, dev.index) if world > 1 else model
+    # world > 1: DistributedDataParallel through the product's main.wrap_ddp (eager steps) — or, --train-graph 1, the PLAIN module
+    # whose forward + backward is replayed as a HIP graph on every rank, with the gradient exchange outside the capture (below)
+    graph_ranks = bool(getattr(args, "train_graph", 0)) and world > 1 and args.item_streams <= 1
+    if graph_ranks:
+        for tns in list(model.parameters()) + list(model.buffers()):  # (what DDP's constructor does: rank 0's state everywhere)
+            torch.distributed.broadcast(tns.data, 0)
+    net = wrap_ddp(model, dev, dev.index) if (world > 1 and not graph_ranks) else model
     # README.md:38 / main.py:440-446: SGD + momentum + weight decay.  fused = torch's single-kernel form of the same update (a handful of
     # launches per step instead of 21 multi-tensor ones: they sit behind the backward's last join, on nobody's shadow)
     # (fused kernels do not move Tensor._version: train_ops marks its weight-plane cache stale from a global optimizer-step hook.
@@ -509,7 +515,8 @@ def train_bench(args, rank, world, dev):
 
         _sf.PATHWAY_STREAMS = int(args.train_pathway_streams)
     # (one rank: a single-pass step also takes its weight gradients as slices of ONE zeroed arena — a memset per step, not per convolution)
-    grads = train_ops.MicroBatchGradients(model.parameters(), single_pass_arena=world == 1) if args.grad_accumulator else None
+    grads = (train_ops.MicroBatchGradients(model.parameters(), single_pass_arena=(world == 1 or graph_ranks))
+             if (args.grad_accumulator or graph_ranks) else None)
 
     # --item-streams 2: consecutive items alternate between two streams; the forward of item k + 1 is ordered after the forward
     # of item k (BatchNorm running statistics, the batcher's generator, the weight-plane caches) and its backward after the
@@ -580,11 +587,22 @@ def train_bench(args, rank, world, dev):
     # replayed — for steps whose launches the host cannot issue as fast as the device runs them (one item per rank).  One pass per
     # step, one rank; the item indices travel through a static device tensor
     graph_note = None
-    if getattr(args, "train_graph", 0) and world == 1 and not istreams and plan["passes"] == 1:
+    if getattr(args, "train_graph", 0) and (world == 1 or graph_ranks) and not istreams and plan["passes"] == 1:
         idx_buf = torch.zeros(items, dtype=torch.int64, device=dev)
         labels0 = torch.zeros(items, dtype=torch.long, device=dev)
+        # world > 1 (one item per rank: BASELINE config 5 as the reference runs it): the captured part ends with the backward; the
+        # gradients are exchanged OUTSIDE the capture — the convolutions' weight gradients are slices of ONE arena
+        # (MicroBatchGradients(single_pass_arena)), everything else (BatchNorm scales and shifts, the heads) is copied into ONE flat
+        # buffer by the graph's last launch — two all-reduces of the mean (the loss is scaled by 1 / world inside the graph), then
+        # the optimizer.  No bucket waits for a stream, nothing overlaps the backward: at 270 MB over xGMI the exchange is a few
+        # per cent of a 46 ms step, and the host issues a dozen launches per step instead of ≈ 2900
+        exch = {"flat": None, "rest": None, "views": None}
 
         def device_step():
+            if graph_ranks:
+                # the optimizer runs OUTSIDE this function: whatever ran since the last call, the weight planes are re-made here — and
+                # that launch is part of the capture (a capture that found the cache current would replay convolutions on old planes)
+                train_ops.invalidate_weight_cache()
             if grads is not None:
                 grads.begin(1)
             else:
@@ -595,14 +613,53 @@ def train_bench(args, rank, world, dev):
             with amp(), train_ops.bn_replicas(items):
                 out = net(q, t)
             loss = crit(out.float(), labels0)
-            loss.backward()
+            (loss / world if graph_ranks else loss).backward()
             if grads is not None:
                 grads.finish()
-            opt.step()
+            if graph_ranks:
+                if exch["flat"] is not None:  # (set up after the first warm-up step, below: the same tensors in every later step)
+                    torch._foreach_copy_(exch["views"], [p.grad for p in exch["rest"]])
+            else:
+                opt.step()
             return loss.detach()
+
+        def exchange_and_step():  # eager, after the replay: what crosses the ranks, then the update
+            buf = grads.arena.buf.get(dev)
+            used = grads.arena.used.get(dev, 0)
+            if buf is not None and used:
+                torch.distributed.all_reduce(buf[:used])
+            torch.distributed.all_reduce(exch["flat"])
+            torch._foreach_copy_([p.grad for p in exch["rest"]], exch["views"])
+            opt.step()
+
+        def setup_exchange():
+            """After a warm-up step: which gradients live in the arena (exchanged in place), and the flat buffer for the rest."""
+            buf = grads.arena.buf.get(dev)
+            lo = buf.data_ptr() if buf is not None else 0
+            hi = lo + 4 * buf.numel() if buf is not None else 0
+            rest = [p for p in model.parameters() if p.grad is not None and not (lo <= p.grad.data_ptr() < hi)]
+            flat = torch.zeros(sum(p.numel() for p in rest), dtype=torch.float32, device=dev)
+            views, o = [], 0
+            for p in rest:
+                views.append(flat[o : o + p.numel()].view(p.grad.shape) if p.grad.is_contiguous() else
+                             torch.as_strided(flat, tuple(p.grad.shape), tuple(p.grad.stride()), o))
+                o += p.numel()
+            exch["flat"], exch["rest"], exch["views"] = flat, rest, views
 
         try:
             idx_buf.copy_(torch.from_numpy(rng.randint(0, len(ds), size=items)))
+            if graph_ranks:  # two eager steps first: the arena exists from the second one on, and with it the split of the gradients
+                for _ in range(2):
+                    device_step()
+                    torch.cuda.synchronize()
+                    if exch["flat"] is None and grads.arena.buf.get(dev) is not None:
+                        setup_exchange()
+                        torch._foreach_copy_(exch["views"], [p.grad for p in exch["rest"]])
+                    if exch["flat"] is not None:
+                        exchange_and_step()
+                    # (the first of the two only sizes the arena: its gradients own their storage and are dropped, no update — a
+                    #  rank-local step would leave every rank its own momentum buffers)
+                assert exch["flat"] is not None, "the gradient arena did not come up in the warm-up steps"
             gstep = train_ops.GraphedStep(device_step, dev, warmup=max(args.warmup, 3))
 
             # the host reads every step's loss (train.py:118 reads loss.item() per batch) — ONE STEP LATE: the indices of step k + 1 go
@@ -618,6 +675,8 @@ def train_bench(args, rank, world, dev):
                 b.copy_(torch.from_numpy(rng.randint(0, len(ds), size=items)))
                 idx_buf.copy_(b, non_blocking=True)
                 pend.append(gstep().clone())
+                if graph_ranks:
+                    exchange_and_step()
                 if len(pend) > 1:
                     losses.append(float(pend.pop(0)))
 
@@ -627,6 +686,8 @@ def train_bench(args, rank, world, dev):
 
             graph_note = "captured"
         except Exception as e:  # (a step that cannot be captured runs eagerly, and the line says so)
+            if graph_ranks:  # (no eager form to fall back to: the plain module without an exchange would train every rank on its own)
+                raise
             graph_note = "capture failed: %s" % (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
             print("[bench] --train-graph: %s" % graph_note, file=sys.stderr, flush=True)
             torch.cuda.synchronize()
@@ -660,6 +721,15 @@ def train_bench(args, rank, world, dev):
     flush()
     sync_all()
     total_s = adist.barrier_max_time(time.perf_counter() - t0, dev)
+    spread = None
+    if world > 1:  # every rank must hold the same parameters after the timed steps (DDP's buckets, or the graph form's two all-reduces)
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        lo_, hi_ = chk.clone(), chk.clone()
+        if args.dist_backend != "nccl":
+            lo_, hi_ = lo_.cpu(), hi_.cpu()
+        torch.distributed.all_reduce(lo_, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi_, op=torch.distributed.ReduceOp.MAX)
+        spread = float(hi_ - lo_)
     if rank != 0:
         return None
     clips = B * (1 + 1 + negs)  # query + positive + negatives per item
@@ -682,11 +752,15 @@ def train_bench(args, rank, world, dev):
                                        "stride-1 dgrad, wgrad_x3, patch-resident stems (forward + weight gradient), bn_train; query encoder on a side stream; "
                                        "strided input gradients as residue-class convolutions, HIP max-pool; the rank's items as one batch of per-item BatchNorm groups") if hand
                    else "MIOpen convolutions through autograd (%s%s)" % (args.train_dtype, ", channels_last_3d" if channels_last else ""),
-                   "parallelism": ("dp%d: DistributedDataParallel (avtex.main.wrap_ddp) — bucketed gradient all-reduce started under the "
-                                   "backward of the rank's last pass, earlier passes under no_sync" % world) if world > 1 else "single GPU"},
+                   "parallelism": (("dp%d: forward + backward replayed as a HIP graph per rank; the mean gradient by two all-reduces after the "
+                                    "replay (the convolutions' gradient arena in place, one flat buffer for the rest), then SGD" % world)
+                                   if (graph_ranks and graph_note == "captured") else
+                                   ("dp%d: DistributedDataParallel (avtex.main.wrap_ddp) — bucketed gradient all-reduce started under the "
+                                    "backward of the rank's last pass, earlier passes under no_sync" % world)) if world > 1 else "single GPU"},
         "training_steps_per_s": args.steps / total_s, "items_per_s": B * args.steps / total_s,
         "max_memory_allocated_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         "loss_first_last": [losses[0], losses[-1]],
+        "ranks_param_checksum_spread": spread,
         "roofline": {"kernel": ("conv_x3_kernel<IO32> fwd / stride-1 dgrad + wgrad_x3_kernel (split-plane MFMA, 1/3 of the bf16 peak); "
                                 "whole step incl. BatchNorm passes, the stems, optimizer") if hand
                                else "MIOpen conv3d fwd/dgrad/wgrad (library)", "bound": "mfma", "achieved": flops * args.steps / total_s / 1e12,
@@ -800,6 +874,10 @@ def build_parser():
 
 def main():
     args = build_parser().parse_args()
+    if os.environ.get("AVT_DUMP_STACKS_AFTER"):  # (diagnostic: every thread's Python stack on stderr after N seconds — a hung rank says where)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["AVT_DUMP_STACKS_AFTER"]), repeat=False, file=sys.stderr)
     if args.config == 4:
         args.windows = 2048
         args.topk = args.topk or 8

@@ -267,3 +267,24 @@ def test_bench_eight_ranks_sharing_one_gpu_headline_and_one_item_training(dev):
     assert line["config"]["items_per_rank"] == 1 and line["config"]["clips_per_step"] == 128
     assert "DistributedDataParallel" in line["config"]["parallelism"]
     assert all(np.isfinite(v) for v in line["loss_first_last"]) and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_train_as_replayed_graphs_with_the_exchange_outside(dev):
+    """Round 6: `bench.py --mode train --gpus 2 --train-graph 1` — every rank replays its forward + backward as ONE HIP graph (the plain
+    module, not DistributedDataParallel) and the mean gradient crosses the ranks in two all-reduces AFTER the replay (the convolutions'
+    gradient arena in place, one flat buffer for everything else), then SGD.  Two gloo ranks share cuda:0 here; what the test holds: the
+    capture works next to a process group, the ranks hold the SAME parameters after the steps (checksum spread 0), the loss is finite
+    and the line says which form ran."""
+    import json
+
+    r = _run([sys.executable, "bench.py", "--mode", "train", "--gpus", "2", "--dist-backend", "gloo", "--train-graph", "1", "--train-items", "2",
+              "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["items_per_rank"] == 1 and line["config"]["hip_graph"] == "captured"
+    assert "replayed as a HIP graph" in line["config"]["parallelism"]
+    assert all(np.isfinite(v) for v in line["loss_first_last"]) and line["value"] > 0
+    assert line["ranks_param_checksum_spread"] == 0.0
