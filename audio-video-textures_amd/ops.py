@@ -30,7 +30,14 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the current stream's handle without building a Stream object
+
+
 def _stream():
+    # (one call per launch, ~2900 a step at one item per rank — a host-bound step: the raw getter is ~1.5 us cheaper than
+    #  torch.cuda.current_stream().cuda_stream)
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -89,7 +89,14 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the current stream's handle without building a Stream object
+
+
 def _stream():
+    # (one call per launch, ~2900 a step at one item per rank — a host-bound step: the raw getter is ~1.5 us cheaper than
+    #  torch.cuda.current_stream().cuda_stream)
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -622,10 +629,10 @@ def _plane_lookup(key, owner):
             return None
     r = _PLANE_REFRESH.get(owner.device) if owner.is_cuda else None
     if r is not None and r.get("event") is not None and ent.jobs:  # the launch that wrote these planes ran on another stream: behind it, once
-        cur = torch.cuda.current_stream(owner.device)
-        if cur != r["stream"] and r["waited"].get(cur.cuda_stream) != r["id"]:
-            cur.wait_event(r["event"])
-            r["waited"][cur.cuda_stream] = r["id"]
+        raw = _RAW_STREAM(owner.device.index) if _RAW_STREAM is not None else torch.cuda.current_stream(owner.device).cuda_stream
+        if raw != r["stream"].cuda_stream and r["waited"].get(raw) != r["id"]:
+            torch.cuda.current_stream(owner.device).wait_event(r["event"])
+            r["waited"][raw] = r["id"]
     return ent.value
 
 
