@@ -160,6 +160,8 @@ def lib():
                            % (handle.avt_abi_version(), ABI_VERSION, os.path.join(_HERE, "csrc")))
         if os.environ.get("AVT_SMALL_TILE", "") == "0":  # (A/Bs: the training convolutions' 64-row tile at small batches off)
             handle.avt_conv_x3_set_small_tile(0)
+        if os.environ.get("AVT_WGRAD_ROUNDS", "") == "0":  # (A/Bs: the weight gradient's round-aware split over positions off)
+            handle.avt_wgrad_x3_set_xl(7)
         _lib = handle
     return _lib
 

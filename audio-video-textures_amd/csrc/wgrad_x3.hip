@@ -357,6 +357,37 @@ extern int g_wgrad_buf;
 template <int BN, bool SWAP, bool BUF>
 int launch_b(WgArgs& a, int s_count, hipStream_t st);
 
+// The split over positions.  Every workgroup of a launch walks the same number of slabs and `slots` of them run at a time (two per CU
+// for the phase-serial tile, one for the pipelined one), so the launch lasts ceil(grid / slots) rounds of slabs_per_chunk slabs.  Rounds
+// 3-5 took "enough chunks to fill the chip twice" = ceil(2 * slots / tiles) — which makes the grid tiles * chunks >= 2 * slots, and
+// usually a few workgroups MORE: 1025, 1026, 1044 workgroups on 512 slots, 528 and 576 on 256 (res2 b, res3 b, res4 b, res4 a, res5 a
+// at 8 items of config 5) are THREE rounds, the third all but empty — a third of those launches' time (round 6, found on paper:
+// profiles/r06/wgrad_grid_rounds_model.txt).  Here: the chunk count at or below that figure with the least rounds * slabs; ties keep
+// the MORE chunks (two rounds of half the length suffer half as much from a CU that another stream's kernel holds).
+int g_wgrad_rounds = 1;  // (avt_wgrad_x3_set_xl(7) / (8): the round-aware choice off / on — A/Bs)
+static int pick_chunks(int tiles, int nslab, int slots, int min_slabs, bool even) {
+  int chunks = (2 * slots + tiles - 1) / tiles;
+  const int most = nslab / min_slabs > 1 ? nslab / min_slabs : 1;
+  if (chunks > most) chunks = most;
+  if (chunks < 1) chunks = 1;
+  if (!g_wgrad_rounds) return chunks;
+  long best_cost = -1;
+  int best = chunks;
+  for (int c = chunks; c >= 1; --c) {
+    int spc = (nslab + c - 1) / c;
+    if (even) spc += spc & 1;
+    const int nc = (nslab + spc - 1) / spc;
+    const long grid = (long)tiles * nc;
+    const long cost = ((grid + slots - 1) / slots) * spc;
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = c;
+    }
+    if (grid <= slots) break;  // (one round already: fewer chunks only lengthen it)
+  }
+  return best;
+}
+
 template <int BN, bool SWAP>
 int launch(WgArgs& a, int s_count, hipStream_t st) {
   const bool fits32 = g_wgrad_buf && a.x_bytes != 0u && a.dy_bytes != 0u && a.ldx < (1 << 17) && a.ldy < (1 << 17);
@@ -370,10 +401,7 @@ int launch_b(WgArgs& a, int s_count, hipStream_t st) {
   // split over positions: enough workgroups to fill the chip (256 CUs x 2), but at least 16 slabs each — a workgroup's
   // epilogue is 128 x BN atomics, and with 3 slabs apiece the pointwise layers spent their time there
   // (profiles/r02/probe_wgrad_v2.log: 16 TFLOP/s on 256 -> 1024 channels)
-  int chunks = (1024 + tiles - 1) / tiles;
-  const int most = a.nslab / 16 > 1 ? a.nslab / 16 : 1;
-  if (chunks > most) chunks = most;
-  if (chunks < 1) chunks = 1;
+  const int chunks = pick_chunks(tiles, a.nslab, 512, 16, false);
   a.slabs_per_chunk = (a.nslab + chunks - 1) / chunks;
   a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
   constexpr int lds_small = 4 * kPlane + 2 * 64 * 4 + 2 * 64 * kMaxTaps * 4 + 64 * 4;  // (+ the tap table)
@@ -679,10 +707,8 @@ int launch_xl(WgArgs& a, int r_count, int s_count, hipStream_t st) {
   a.s_tiles = (s_count + SW - 1) / SW;
   const int tiles = a.r_tiles * a.s_tiles;
   a.nslab = (a.M + XP - 1) / XP;  // steps of 32 positions
-  int chunks = (512 + tiles - 1) / tiles;  // one workgroup per CU: two rounds' worth of work items
-  const int most = a.nslab / 32 > 1 ? a.nslab / 32 : 1;  // at least 32 steps each (the epilogue is 256 x 128 atomics)
-  if (chunks > most) chunks = most;
-  if (chunks < 1) chunks = 1;
+  // one workgroup per CU; at least 32 steps each (the epilogue is 256 x 128 atomics)
+  const int chunks = pick_chunks(tiles, a.nslab, 256, 32, true);
   a.slabs_per_chunk = (a.nslab + chunks - 1) / chunks;
   a.slabs_per_chunk += a.slabs_per_chunk & 1;  // (the kernel walks its steps in pairs)
   a.nchunk = (a.nslab + a.slabs_per_chunk - 1) / a.slabs_per_chunk;
@@ -792,6 +818,10 @@ extern "C" int avt_wgrad_x3_set_xl(int on) {
   }
   if (on == 5 || on == 6) {  // (tests: the phase-serial tile without / with buffer loads; the tile mode stays)
     g_wgrad_buf = on == 6 ? 1 : 0;
+    return was;
+  }
+  if (on == 7 || on == 8) {  // (A/Bs: the round-aware split over positions off / on; the tile mode stays)
+    g_wgrad_rounds = on == 8 ? 1 : 0;
     return was;
   }
   g_wgrad_xl = on < 0 ? 0 : (on > 2 ? 2 : on);
